@@ -1,0 +1,166 @@
+"""ctypes binding of ``libgt4py_amd.so`` (the C ABI declared in ``include/gt4py_amd.h``).
+
+This is the Python side of the host->native boundary that the reference crosses with a
+per-stencil pybind11 module (``pyext_module.run_computation(...)``,
+/root/reference/src/gt4py/cartesian/backend/gtc_common.py:144-168).  There is no CPU fallback:
+if the shared library is missing or does not load, every entry point raises ``RuntimeError``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import pathlib
+import threading
+from typing import Optional, Sequence
+
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libgt4py_amd.so"
+HEADER_PATH = _HERE.parent / "include" / "gt4py_amd.h"
+
+#: every symbol include/gt4py_amd.h declares (kept in sync by tests/test_c_abi.py)
+EXPORTED_SYMBOLS = (
+    "gt4mi_abi_version",
+    "gt4mi_last_error",
+    "gt4mi_device_info",
+    "gt4mi_stream_sync",
+    "gt4mi_lap5_f64",
+    "gt4mi_lap5_f32",
+    "gt4mi_hdiff_f64",
+    "gt4mi_hdiff_f32",
+    "gt4mi_tridiag_f64",
+    "gt4mi_tridiag_f32",
+    "gt4mi_halo_pack",
+    "gt4mi_halo_unpack",
+    "gt4mi_stream_copy",
+)
+
+GT4MI_ABI_VERSION = 1
+
+# gt4mi_status
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_OUT_OF_BOUNDS = -2
+ERR_UNSUPPORTED = -3
+ERR_HIP = -4
+
+# lap5 variants / flags
+LAP_NOTEBOOK, LAP_DOCS, LAP_SUITE, LAP_AVG = 0, 1, 2, 3
+LAP_LITERAL_F32 = 1
+# hdiff flags
+HDIFF_LIMITER, HDIFF_INTERNAL_F32, HDIFF_COEFF_F32 = 1, 2, 4
+
+_Int3 = ctypes.c_int64 * 3
+
+
+class Field(ctypes.Structure):
+    """``gt4mi_field``: device pointer + shape + byte strides + origin."""
+
+    _fields_ = [
+        ("data", ctypes.c_void_p),
+        ("shape", _Int3),
+        ("stride", _Int3),
+        ("origin", _Int3),
+    ]
+
+    @classmethod
+    def make(cls, ptr: int, shape: Sequence[int], strides: Sequence[int], origin: Sequence[int]) -> "Field":
+        if not (len(shape) == len(strides) == len(origin) == 3):
+            raise ValueError("gt4mi_field describes exactly three axes (I, J, K)")
+        return cls(ctypes.c_void_p(ptr), _Int3(*map(int, shape)), _Int3(*map(int, strides)),
+                   _Int3(*map(int, origin)))
+
+
+class ExecInfo(ctypes.Structure):
+    """``gt4mi_exec_info``: host timestamps of the native call (run_cpp_start/end_time)."""
+
+    _fields_ = [("run_cpp_start_time", ctypes.c_double), ("run_cpp_end_time", ctypes.c_double)]
+
+
+class NativeError(RuntimeError):
+    """A libgt4py_amd entry point returned a non-zero status."""
+
+    def __init__(self, func: str, status: int, message: str):
+        super().__init__(f"{func} failed with status {status}: {message}")
+        self.status = status
+
+
+_lock = threading.Lock()
+_lib: Optional[ctypes.CDLL] = None
+
+
+def _declare(lib: ctypes.CDLL) -> None:
+    P, I, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    FP = ctypes.POINTER(Field)
+    DOM = ctypes.POINTER(ctypes.c_int64)
+    EI = ctypes.POINTER(ExecInfo)
+    lib.gt4mi_abi_version.restype = I
+    lib.gt4mi_abi_version.argtypes = []
+    lib.gt4mi_last_error.restype = ctypes.c_char_p
+    lib.gt4mi_last_error.argtypes = []
+    lib.gt4mi_device_info.restype = I
+    lib.gt4mi_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.gt4mi_stream_sync.restype = I
+    lib.gt4mi_stream_sync.argtypes = [P]
+    for name in ("gt4mi_lap5_f64", "gt4mi_lap5_f32"):
+        f = getattr(lib, name)
+        f.restype = I
+        f.argtypes = [DOM, FP, FP, I, I, P, EI]
+    for name in ("gt4mi_hdiff_f64", "gt4mi_hdiff_f32"):
+        f = getattr(lib, name)
+        f.restype = I
+        f.argtypes = [DOM, FP, FP, FP, D, I, P, EI]
+    for name in ("gt4mi_tridiag_f64", "gt4mi_tridiag_f32"):
+        f = getattr(lib, name)
+        f.restype = I
+        f.argtypes = [DOM, FP, FP, FP, FP, FP, P, EI]
+    lib.gt4mi_halo_pack.restype = I
+    lib.gt4mi_halo_pack.argtypes = [FP, DOM, DOM, P, I, P]
+    lib.gt4mi_halo_unpack.restype = I
+    lib.gt4mi_halo_unpack.argtypes = [FP, DOM, DOM, P, I, P]
+    lib.gt4mi_stream_copy.restype = I
+    lib.gt4mi_stream_copy.argtypes = [P, P, ctypes.c_size_t, P]
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises ``RuntimeError`` when it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = pathlib.Path(os.environ.get("GT4PY_AMD_LIB", LIB_PATH))
+        if not path.exists():
+            raise RuntimeError(
+                f"libgt4py_amd.so not found at {path}. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gt4py_amd/csrc`. "
+                "The hip:mi300 backend has no CPU fallback."
+            )
+        try:
+            lib = ctypes.CDLL(str(path))
+        except OSError as exc:  # pragma: no cover - depends on the machine
+            raise RuntimeError(f"cannot load {path}: {exc}") from exc
+        _declare(lib)
+        if lib.gt4mi_abi_version() != GT4MI_ABI_VERSION:
+            raise RuntimeError(
+                f"{path} has ABI version {lib.gt4mi_abi_version()}, expected {GT4MI_ABI_VERSION}"
+            )
+        _lib = lib
+    return _lib
+
+
+def check(func: str, status: int) -> None:
+    if status != OK:
+        raise NativeError(func, status, load().gt4mi_last_error().decode("utf-8", "replace"))
+
+
+def domain3(domain: Sequence[int]):
+    return _Int3(*map(int, domain))
+
+
+def device_info() -> str:
+    buf = ctypes.create_string_buffer(256)
+    check("gt4mi_device_info", load().gt4mi_device_info(buf, 256))
+    return buf.value.decode()

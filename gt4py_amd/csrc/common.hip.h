@@ -1,0 +1,152 @@
+// Shared helpers for the gfx950 stencil kernels (device + host launch side).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "gt4py_amd.h"
+
+// Bit-exact parity with the numpy backend forbids fused multiply-add contraction
+// (SURVEY.md section 8a note N1).  The build also passes -ffp-contract=off; the pragma makes the
+// guarantee local to the kernels in case a user rebuilds with other flags.
+#pragma clang fp contract(off)
+
+namespace gt4mi {
+
+// ---- error reporting -----------------------------------------------------------------------
+inline char* error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define GT4MI_HIP_CHECK(expr)                                                               \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return ::gt4mi::fail(GT4MI_ERR_HIP, "%s failed: %s (%s:%d)", #expr,             \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);                \
+    } while (0)
+
+// ---- field views -----------------------------------------------------------------------------
+// Pointer to the field's origin element plus element strides; what a kernel needs.
+template <typename T>
+struct View {
+    T* p;            // element at the origin (first compute-domain point)
+    int64_t si, sj, sk;  // strides in ELEMENTS
+};
+
+// Validate a field against a domain and a halo requirement, and build its origin-shifted view.
+// halo_lo/hi: how far the stencil reaches below/above the compute domain along each axis.
+template <typename T>
+inline int make_view(const char* name, const gt4mi_field* f, const int64_t domain[3],
+                     const int halo_lo[3], const int halo_hi[3], View<T>* v) {
+    if (f == nullptr || f->data == nullptr)
+        return fail(GT4MI_ERR_INVALID_ARGUMENT, "field '%s' is null", name);
+    int64_t off = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (f->stride[a] % (int64_t)sizeof(T) != 0)
+            return fail(GT4MI_ERR_UNSUPPORTED,
+                        "field '%s': byte stride %lld along axis %d is not a multiple of the item size",
+                        name, (long long)f->stride[a], a);
+        if (f->origin[a] < halo_lo[a])
+            return fail(GT4MI_ERR_OUT_OF_BOUNDS,
+                        "field '%s': origin %lld along axis %d too small, must be at least %d", name,
+                        (long long)f->origin[a], a, halo_lo[a]);
+        if (f->origin[a] + domain[a] + halo_hi[a] > f->shape[a])
+            return fail(GT4MI_ERR_OUT_OF_BOUNDS,
+                        "field '%s': shape %lld along axis %d too small for origin %lld + domain %lld + halo %d",
+                        name, (long long)f->shape[a], a, (long long)f->origin[a],
+                        (long long)domain[a], halo_hi[a]);
+        off += f->origin[a] * f->stride[a];
+    }
+    v->p = reinterpret_cast<T*>(static_cast<char*>(f->data) + off);
+    v->si = f->stride[0] / (int64_t)sizeof(T);
+    v->sj = f->stride[1] / (int64_t)sizeof(T);
+    v->sk = f->stride[2] / (int64_t)sizeof(T);
+    return GT4MI_OK;
+}
+
+inline int check_domain(const int64_t domain[3]) {
+    if (domain == nullptr) return fail(GT4MI_ERR_INVALID_ARGUMENT, "domain is null");
+    for (int a = 0; a < 3; ++a) {
+        if (domain[a] < 0 || domain[a] > INT32_MAX)
+            return fail(GT4MI_ERR_INVALID_ARGUMENT, "invalid domain size %lld along axis %d",
+                        (long long)domain[a], a);
+    }
+    return GT4MI_OK;
+}
+
+// True when a view can be accessed with VEC-wide vectors along I for every (j,k) row.
+template <typename V>
+inline bool vec_ok(const V& v, int vec) {
+    if (v.si != 1) return false;
+    if ((reinterpret_cast<uintptr_t>(v.p) % (vec * sizeof(*v.p))) != 0) return false;
+    return (v.sj % vec == 0) && (v.sk % vec == 0);
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers ---------------------------------------------------------------------------
+template <typename T, int N>
+struct VecT;
+template <>
+struct VecT<double, 1> { using type = double; };
+template <>
+struct VecT<double, 2> { using type = double __attribute__((ext_vector_type(2))); };
+template <>
+struct VecT<float, 1> { using type = float; };
+template <>
+struct VecT<float, 2> { using type = float __attribute__((ext_vector_type(2))); };
+template <>
+struct VecT<float, 4> { using type = float __attribute__((ext_vector_type(4))); };
+
+// Vector load/store of N contiguous elements into/from a register array.
+template <typename T, int N>
+__device__ __forceinline__ void vload(const T* p, T (&r)[N]) {
+    if constexpr (N == 1) {
+        r[0] = *p;
+    } else {
+        using V = typename VecT<T, N>::type;
+        V v = *reinterpret_cast<const V*>(p);
+#pragma unroll
+        for (int e = 0; e < N; ++e) r[e] = v[e];
+    }
+}
+
+template <typename T, int N, bool NT>
+__device__ __forceinline__ void vstore(T* p, const T (&r)[N]) {
+    if constexpr (N == 1) {
+        if constexpr (NT) __builtin_nontemporal_store(r[0], p);
+        else *p = r[0];
+    } else {
+        using V = typename VecT<T, N>::type;
+        V v;
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = r[e];
+        if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+        else *reinterpret_cast<V*>(p) = v;
+    }
+}
+
+// Workgroup id remap: the dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md,
+// "Workgroup dispatch").  Give each XCD a contiguous range of logical tiles so that tiles that
+// share halo rows also share an L2.  Performance only; any mapping is correct.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
+    constexpr unsigned NX = 8;
+    const unsigned per = n / NX;  // tiles per XCD (full part)
+    if (b >= per * NX) return b;  // tail: identity
+    return (b % NX) * per + (b / NX);
+}
+
+}  // namespace gt4mi

@@ -1,0 +1,252 @@
+// Horizontal diffusion, wave-autonomous "J-march" kernel for I-contiguous fields (the fast path).
+//
+// One wave owns a strip of 64*VEC columns (VEC contiguous elements per lane = one 8/16-byte vector)
+// and walks down LJ rows of J at one K level.  Per step it loads ONE new row of `in` (row j+2),
+// and keeps in registers: in rows j, j+1, lap rows j, j+1 and fly row j-1.  Horizontal neighbours
+// come from the adjacent lane with DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- no
+// LDS, no barriers.  The first and last H lanes of a wave are halo lanes (they only feed their
+// neighbours), so consecutive waves overlap by 2*H lanes (H = 1 for VEC >= 2, 2 for VEC == 1):
+//
+//   lane:      0      1 ..................... 62      63
+//   columns: [halo][ ---- 62*VEC outputs ---- ][halo]      wave w starts at (w*62 - 1)*VEC
+//
+// lap, flx, fly are computed exactly once per point inside a strip (plus the halo lanes and the
+// 2-row prologue), in the same arithmetic as hdiff_generic_kernel.
+#pragma once
+
+#include "common.hip.h"
+
+#pragma clang fp contract(off)
+
+namespace gt4mi {
+
+// ---- cross-lane shifts -------------------------------------------------------------------------
+#ifndef GT4MI_NO_DPP
+__device__ __forceinline__ int lane_from_prev(int v) {  // lane l receives lane l-1
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int lane_from_next(int v) {  // lane l receives lane l+1
+    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+#else
+__device__ __forceinline__ int lane_from_prev(int v) { return __shfl_up(v, 1); }
+__device__ __forceinline__ int lane_from_next(int v) { return __shfl_down(v, 1); }
+#endif
+
+template <typename X, bool FROM_PREV>
+__device__ __forceinline__ X lane_shift(X v) {
+    if constexpr (sizeof(X) == 4) {
+        int r = FROM_PREV ? lane_from_prev(__builtin_bit_cast(int, v))
+                          : lane_from_next(__builtin_bit_cast(int, v));
+        return __builtin_bit_cast(X, r);
+    } else {
+        static_assert(sizeof(X) == 8, "lane_shift: 4- or 8-byte types only");
+        const long long b = __builtin_bit_cast(long long, v);
+        int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+        lo = FROM_PREV ? lane_from_prev(lo) : lane_from_next(lo);
+        hi = FROM_PREV ? lane_from_prev(hi) : lane_from_next(hi);
+        const long long r = ((long long)hi << 32) | (unsigned int)lo;
+        return __builtin_bit_cast(X, r);
+    }
+}
+
+inline bool hdiff_jmarch_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("GT4MI_HDIFF_GENERIC");
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ,
+          int PF>
+__global__ void __launch_bounds__(256)
+hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scalar, int dI,
+                    int dJ, unsigned waves_i, unsigned tiles_j, unsigned nwaves) {
+    constexpr int H = (VEC >= 2) ? 1 : 2;   // halo lanes per side
+    constexpr int OUT_LANES = 64 - 2 * H;
+    const unsigned lane = threadIdx.x & 63;
+    unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const unsigned wi = wid % waves_i;
+    const unsigned tj = (wid / waves_i) % tiles_j;
+    const unsigned k = wid / (waves_i * tiles_j);
+
+    const int col = ((int)(wi * OUT_LANES) - H + (int)lane) * VEC;  // first column of this lane
+    const int j0 = (int)tj * LJ;
+    const int nrows = (dJ - j0 < LJ) ? (dJ - j0) : LJ;
+
+    // `in` is readable on columns [-2, dI+2), out/coeff on [0, dI).
+    const bool in_full = (col >= -2) && (col + VEC <= dI + 2);
+    const bool in_any = (col + VEC > -2) && (col < dI + 2);
+    const bool is_out_lane = (lane >= (unsigned)H) && (lane < (unsigned)(64 - H));
+    const bool out_full = is_out_lane && (col >= 0) && (col + VEC <= dI);
+    const bool out_any = is_out_lane && (col + VEC > 0) && (col < dI);
+
+    const T* __restrict__ ip = in.p + (int64_t)k * in.sk + col;
+    T* __restrict__ op = out.p + (int64_t)k * out.sk + col;
+    const T* __restrict__ cp = COEFF_FIELD ? (cf.p + (int64_t)k * cf.sk + col) : nullptr;
+
+    auto load_in = [&](int j, T (&r)[VEC]) {
+        const T* p = ip + (int64_t)j * in.sj;
+        if (in_full) {
+            vload<T, VEC>(p, r);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                r[e] = (in_any && col + e >= -2 && col + e < dI + 2) ? p[e] : (T)0;
+        }
+    };
+    auto load_cf = [&](int j, T (&r)[VEC]) {
+        const T* p = cp + (int64_t)j * cf.sj;
+        if (out_full) {
+            vload<T, VEC>(p, r);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                r[e] = (out_any && col + e >= 0 && col + e < dI) ? p[e] : (T)0;
+        }
+    };
+    // lap of row `c` given the rows below (b) and above (d); fills right-shifted copy of c's
+    // first element (the +i neighbour of the lane's last column) for reuse by the flux.
+    auto lap_row = [&](const T (&b)[VEC], const T (&c)[VEC], const T (&d)[VEC], W (&lap)[VEC],
+                       T& c_next_first) {
+        const T c_prev_last = lane_shift<T, true>(c[VEC - 1]);
+        c_next_first = lane_shift<T, false>(c[0]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const T im = (e == 0) ? c_prev_last : c[e - 1];
+            const T ipv = (e == VEC - 1) ? c_next_first : c[e + 1];
+            lap[e] = hd_lap<T, W>(c[e], ipv, im, d[e], b[e]);
+        }
+    };
+    auto fly_row = [&](const W (&lap_hi)[VEC], const W (&lap_lo)[VEC], const T (&in_hi)[VEC],
+                       const T (&in_lo)[VEC], W (&fly)[VEC]) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            fly[e] = hd_flux<T, W, LIMITER>(lap_hi[e], lap_lo[e], in_hi[e], in_lo[e]);
+    };
+
+    // ---- prologue: rows j0-2 .. j0+1 -> lap(j0-1), lap(j0), fly(j0-1) ---------------------------
+    T a[VEC], bm[VEC], b[VEC], c[VEC];
+    load_in(j0 - 2, a);
+    load_in(j0 - 1, bm);
+    load_in(j0, b);
+    load_in(j0 + 1, c);
+    // prefetch queue: rows j0+2 .. j0+1+PF
+    T q[PF][VEC];
+    T qc[PF][VEC];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+        if (t < nrows) load_in(j0 + 2 + t, q[t]);
+        if constexpr (COEFF_FIELD)
+            if (t < nrows) load_cf(j0 + t, qc[t]);
+    }
+    W lap_m[VEC], lap_b[VEC], fly_prev[VEC];
+    T unused, b_next_first;
+    lap_row(a, bm, b, lap_m, unused);
+    lap_row(bm, b, c, lap_b, b_next_first);
+    fly_row(lap_b, lap_m, b, bm, fly_prev);
+
+    auto step = [&](int jj, int nr) {
+        // row j = j0 + jj is produced; q[0] holds in row j+2, qc[0] holds coeff row j
+        T d[VEC], cfr[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d[e] = q[0][e];
+        if constexpr (COEFF_FIELD) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) cfr[e] = qc[0][e];
+        }
+#pragma unroll
+        for (int t = 0; t + 1 < PF; ++t) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                q[t][e] = q[t + 1][e];
+                if constexpr (COEFF_FIELD) qc[t][e] = qc[t + 1][e];
+            }
+        }
+        if (jj + PF < nr) {
+            load_in(j0 + jj + PF + 2, q[PF - 1]);
+            if constexpr (COEFF_FIELD) load_cf(j0 + jj + PF, qc[PF - 1]);
+        }
+        W lap_c[VEC];
+        T c_next_first;
+        lap_row(b, c, d, lap_c, c_next_first);
+        // flx(row j) at column e needs lap_b and in row j at column e+1
+        W flx[VEC], fly[VEC];
+        const W lapb_next_first = lane_shift<W, false>(lap_b[0]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const W l1 = (e == VEC - 1) ? lapb_next_first : lap_b[e + 1];
+            const T i1 = (e == VEC - 1) ? b_next_first : b[e + 1];
+            flx[e] = hd_flux<T, W, LIMITER>(l1, lap_b[e], i1, b[e]);
+        }
+        const W flx_prev_last = lane_shift<W, true>(flx[VEC - 1]);
+        fly_row(lap_c, lap_b, c, b, fly);
+        T res[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const W fm = (e == 0) ? flx_prev_last : flx[e - 1];
+            PW cv;
+            if constexpr (COEFF_FIELD) cv = (PW)cfr[e];
+            else cv = coeff_scalar;
+            res[e] = hd_out<T, W, PW>(b[e], cv, flx[e], fm, fly[e], fly_prev[e]);
+        }
+        T* o = op + (int64_t)(j0 + jj) * out.sj;
+        if (out_full) {
+            vstore<T, VEC, true>(o, res);
+        } else if (out_any) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (col + e >= 0 && col + e < dI) o[e] = res[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            b[e] = c[e];
+            c[e] = d[e];
+            lap_b[e] = lap_c[e];
+            fly_prev[e] = fly[e];
+        }
+        b_next_first = c_next_first;
+    };
+
+    if (nrows == LJ) {
+#pragma unroll
+        for (int jj = 0; jj < LJ; ++jj) step(jj, LJ);
+    } else {
+        for (int jj = 0; jj < nrows; ++jj) step(jj, nrows);
+    }
+}
+
+struct HdiffTuning {
+    static constexpr int LJ = 32;
+    static constexpr int PF = 2;
+};
+
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC>
+inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
+                                   const View<const T>& cf, PW coeff_scalar, const int64_t d[3],
+                                   hipStream_t stream) {
+    constexpr int H = (VEC >= 2) ? 1 : 2;
+    constexpr int LJ = HdiffTuning::LJ;
+    const unsigned waves_i = (unsigned)cdiv(d[0], (int64_t)(64 - 2 * H) * VEC);
+    const unsigned tiles_j = (unsigned)cdiv(d[1], LJ);
+    const int64_t nwaves = (int64_t)waves_i * tiles_j * d[2];
+    if (nwaves > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: domain too large for one launch");
+    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, HdiffTuning::PF>),
+                       dim3((unsigned)cdiv(nwaves, 4)), dim3(256), 0, stream, in, out, cf,
+                       coeff_scalar, (int)d[0], (int)d[1], waves_i, tiles_j, (unsigned)nwaves);
+    return GT4MI_OK;
+}
+
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD>
+inline int hdiff_launch_jmarch(const View<const T>& in, const View<T>& out, const View<const T>& cf,
+                               PW coeff_scalar, const int64_t d[3], hipStream_t stream) {
+    constexpr int VMAX = 16 / sizeof(T);
+    const bool vec = vec_ok(in, VMAX) && vec_ok(out, VMAX) && (!COEFF_FIELD || vec_ok(cf, VMAX));
+    if (vec)
+        return hdiff_launch_jmarch_vec<T, W, PW, LIMITER, COEFF_FIELD, VMAX>(in, out, cf, coeff_scalar, d, stream);
+    return hdiff_launch_jmarch_vec<T, W, PW, LIMITER, COEFF_FIELD, 1>(in, out, cf, coeff_scalar, d, stream);
+}
+
+}  // namespace gt4mi

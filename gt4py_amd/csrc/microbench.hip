@@ -1,0 +1,405 @@
+// Stand-alone tuning harness for the gfx950 stencil kernels (not part of the product path).
+// Prints one line per (kernel, configuration): ms per apply, GLUPS, algorithmic GB/s, % of 8 TB/s.
+// Also self-checks: DPP wave shifts, J-march kernels against the any-stride kernels (bitwise).
+//
+//   microbench [section ...]     sections: dpp copy lap hdiff tridiag (default: all)
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hip.h"
+#include "halo.hip.h"
+#include "hdiff.hip.h"
+#include "lap5.hip.h"
+#include "tridiag.hip.h"
+
+using namespace gt4mi;
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+static constexpr double PEAK_GBS = 8000.0;
+
+template <typename F>
+static double time_ms(F&& launch, int iters, int warmup = 3) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < warmup; ++i) launch(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) launch(i);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a));
+    CK(hipEventDestroy(b));
+    return ms / iters;
+}
+
+static void report(const char* name, const char* cfg, double ms, double lups, double bytes_per_lup) {
+    const double glups = lups / (ms * 1e-3) / 1e9;
+    const double gbs = glups * bytes_per_lup;
+    printf("%-10s %-44s %9.4f ms %9.1f GLUPS %9.1f GB/s %6.1f%% of 8TB/s\n", name, cfg, ms, glups, gbs,
+           100.0 * gbs / PEAK_GBS);
+    fflush(stdout);
+}
+
+// ---- a gt4py-storage-like padded field: I contiguous, rows padded to `align` items, element
+// [halo] of every row aligned to align*sizeof(T) bytes -------------------------------------------
+template <typename T>
+struct DevField {
+    char* raw = nullptr;
+    T* data = nullptr;  // element [0,0,0]
+    int64_t shape[3], sj, sk;
+    int halo[3];
+    size_t bytes;
+    DevField(int64_t ni, int64_t nj, int64_t nk, int hi, int hj, int align_items = 32, int64_t extra_pitch = 0) {
+        shape[0] = ni + 2 * hi;
+        shape[1] = nj + 2 * hj;
+        shape[2] = nk;
+        halo[0] = hi;
+        halo[1] = hj;
+        halo[2] = 0;
+        sj = cdiv(shape[0], align_items) * align_items + extra_pitch;
+        sk = sj * shape[1];
+        const size_t align_b = align_items * sizeof(T);
+        bytes = (size_t)sk * nk * sizeof(T) + 2 * align_b;
+        CK(hipMalloc(&raw, bytes));
+        // offset so that element index `hi` is aligned
+        const size_t off = (align_b - ((size_t)hi * sizeof(T)) % align_b) % align_b;
+        data = reinterpret_cast<T*>(raw + off);
+    }
+    ~DevField() { hipFree(raw); }
+    View<T> view() const {  // origin-shifted
+        return View<T>{data + halo[0] + halo[1] * sj, 1, sj, sk};
+    }
+    View<const T> cview() const {
+        return View<const T>{data + halo[0] + halo[1] * sj, 1, sj, sk};
+    }
+    size_t elems() const { return (size_t)sk * shape[2]; }
+};
+
+template <typename T>
+__global__ void fill_kernel(T* p, size_t n, unsigned seed, T lo, T hi) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ULL + seed * 0xD1B54A32D192ED03ULL;
+        x ^= x >> 29;
+        x *= 0xBF58476D1CE4E5B9ULL;
+        x ^= x >> 32;
+        const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+        p[i] = (T)(lo + (hi - lo) * u);
+    }
+}
+
+template <typename T>
+static void fill(DevField<T>& f, unsigned seed, double lo, double hi) {
+    hipLaunchKernelGGL(fill_kernel<T>, dim3(4096), dim3(256), 0, 0, f.data, f.elems() - 64, seed, (T)lo, (T)hi);
+    CK(hipDeviceSynchronize());
+}
+
+template <typename T>
+__global__ void diff_kernel(View<const T> a, View<const T> b, int dI, int dJ, int dK, unsigned long long* nbad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y, k = blockIdx.z;
+    if (i >= dI) return;
+    const T x = a.p[i + j * a.sj + k * a.sk], y = b.p[i + j * b.sj + k * b.sk];
+    const bool same = (x == y) || (x != x && y != y);
+    if (!same) atomicAdd(nbad, 1ULL);
+}
+
+template <typename T>
+static unsigned long long count_diff(const DevField<T>& a, const DevField<T>& b, int dI, int dJ, int dK) {
+    unsigned long long* d;
+    CK(hipMalloc(&d, 8));
+    CK(hipMemset(d, 0, 8));
+    hipLaunchKernelGGL(diff_kernel<T>, dim3((unsigned)cdiv(dI, 256), dJ, dK), dim3(256), 0, 0, a.cview(), b.cview(), dI, dJ, dK, d);
+    unsigned long long h = 0;
+    CK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void dpp_test_kernel(int* out_prev, int* out_next, double* dprev) {
+    const int l = threadIdx.x;
+    out_prev[l] = lane_from_prev(l + 100);
+    out_next[l] = lane_from_next(l + 100);
+    dprev[l] = lane_shift<double, true>((double)l + 0.5);
+}
+
+static bool section_dpp() {
+    int *p, *n;
+    double* d;
+    CK(hipMalloc(&p, 64 * 4));
+    CK(hipMalloc(&n, 64 * 4));
+    CK(hipMalloc(&d, 64 * 8));
+    hipLaunchKernelGGL(dpp_test_kernel, dim3(1), dim3(64), 0, 0, p, n, d);
+    int hp[64], hn[64];
+    double hd[64];
+    CK(hipMemcpy(hp, p, 256, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hn, n, 256, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hd, d, 512, hipMemcpyDeviceToHost));
+    bool ok = true;
+    for (int l = 1; l < 64; ++l) ok &= (hp[l] == l - 1 + 100) && (hd[l] == (double)(l - 1) + 0.5);
+    for (int l = 0; l < 63; ++l) ok &= (hn[l] == l + 1 + 100);
+    printf("dpp        wave_shr/wave_shl self-test: %s (lane0 prev=%d, lane63 next=%d)\n", ok ? "OK" : "FAILED", hp[0], hn[63]);
+    hipFree(p);
+    hipFree(n);
+    hipFree(d);
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int UNROLL, bool NT>
+static void copy_variant(const u32x4* src, u32x4* dst, size_t nvec, unsigned blocks_per_cu) {
+    size_t blocks = (nvec + 256 * UNROLL - 1) / (256 * UNROLL);
+    char cfg[96];
+    if (blocks_per_cu) {
+        blocks = std::min<size_t>(blocks, 256ull * blocks_per_cu);
+    }
+    snprintf(cfg, sizeof cfg, "16B/lane unroll=%d nt=%d blocks=%zu", UNROLL, (int)NT, blocks);
+    const double ms = time_ms([&](int) { hipLaunchKernelGGL((stream_copy_kernel<UNROLL, NT>), dim3((unsigned)blocks), dim3(256), 0, 0, src, dst, nvec); }, 10);
+    report("copy", cfg, ms, (double)nvec, 32.0);
+}
+
+static void section_copy() {
+    const size_t nbytes = 1ull << 30;
+    char *a, *b;
+    CK(hipMalloc(&a, nbytes));
+    CK(hipMalloc(&b, nbytes));
+    CK(hipMemset(a, 1, nbytes));
+    CK(hipMemset(b, 2, nbytes));
+    const size_t nvec = nbytes / 16;
+    const u32x4* s = reinterpret_cast<const u32x4*>(a);
+    u32x4* d = reinterpret_cast<u32x4*>(b);
+    copy_variant<1, false>(s, d, nvec, 0);
+    copy_variant<1, true>(s, d, nvec, 0);
+    copy_variant<2, true>(s, d, nvec, 0);
+    copy_variant<4, false>(s, d, nvec, 0);
+    copy_variant<4, true>(s, d, nvec, 0);
+    copy_variant<8, true>(s, d, nvec, 0);
+    copy_variant<4, true>(s, d, nvec, 8);
+    copy_variant<4, true>(s, d, nvec, 16);
+    copy_variant<8, true>(s, d, nvec, 8);
+    copy_variant<4, false>(s, d, nvec, 8);
+    {
+        const double ms = time_ms([&](int) { CK(hipMemcpyAsync(b, a, nbytes, hipMemcpyDeviceToDevice, 0)); }, 10);
+        report("copy", "hipMemcpyAsync D2D", ms, (double)nvec, 32.0);
+    }
+    hipFree(a);
+    hipFree(b);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int LJ, int BLOCK, bool NT, bool XCD>
+static void lap_variant(const DevField<double>& in, DevField<double>& out, int dI, int dJ, int dK, const char* tag) {
+    constexpr int VEC = 2;
+    const unsigned tx = (unsigned)cdiv(dI, BLOCK * VEC), ty = (unsigned)cdiv(dJ, LJ);
+    const unsigned n = tx * ty * dK;
+    char cfg[96];
+    snprintf(cfg, sizeof cfg, "%s jmarch LJ=%d block=%d nt=%d xcd=%d", tag, LJ, BLOCK, (int)NT, (int)XCD);
+    const double ms = time_ms([&](int) {
+        hipLaunchKernelGGL((lap5_jmarch_kernel<double, double, 0, VEC, LJ, BLOCK, NT, XCD>), dim3(n), dim3(BLOCK), 0, 0,
+                           in.cview(), out.view(), dI, dJ, tx, ty, n);
+    }, 20);
+    report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+}
+
+static void lap_suite(int dI, int dJ, int dK, int64_t extra_pitch, const char* tag) {
+    DevField<double> in(dI, dJ, dK, 1, 1, 32, extra_pitch), out(dI, dJ, dK, 1, 1, 32, extra_pitch), ref(dI, dJ, dK, 1, 1, 32, extra_pitch);
+    fill(in, 1337, -1.0, 1.0);
+    CK(hipMemset(out.raw, 0, out.bytes));
+    CK(hipMemset(ref.raw, 0, ref.bytes));
+    // reference: any-stride kernel
+    {
+        dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+        const double ms = time_ms([&](int) {
+            hipLaunchKernelGGL((lap5_generic_kernel<double, double, 0>), grid, dim3(256), 0, 0, in.cview(), ref.view(), dI, dJ, dK);
+        }, 5, 1);
+        char cfg[64];
+        snprintf(cfg, sizeof cfg, "%s generic (one thread per point)", tag);
+        report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+    }
+    lap_variant<8, 256, true, true>(in, out, dI, dJ, dK, tag);
+    printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+    lap_variant<16, 256, true, true>(in, out, dI, dJ, dK, tag);
+    lap_variant<32, 256, true, true>(in, out, dI, dJ, dK, tag);
+    printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+    lap_variant<64, 256, true, true>(in, out, dI, dJ, dK, tag);
+    lap_variant<128, 256, true, true>(in, out, dI, dJ, dK, tag);
+    lap_variant<32, 256, false, true>(in, out, dI, dJ, dK, tag);
+    lap_variant<32, 256, true, false>(in, out, dI, dJ, dK, tag);
+    lap_variant<32, 256, false, false>(in, out, dI, dJ, dK, tag);
+    lap_variant<64, 256, true, false>(in, out, dI, dJ, dK, tag);
+    lap_variant<32, 128, true, true>(in, out, dI, dJ, dK, tag);
+    lap_variant<64, 128, true, true>(in, out, dI, dJ, dK, tag);
+    lap_variant<32, 64, true, true>(in, out, dI, dJ, dK, tag);
+    // through the library dispatch
+    {
+        const int64_t d[3] = {dI, dJ, dK};
+        const double ms = time_ms([&](int) { lap5_launch_variant<double, double, 0>(in.cview(), out.view(), d, 0); }, 20);
+        char cfg[64];
+        snprintf(cfg, sizeof cfg, "%s library default", tag);
+        report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+    }
+}
+
+static void section_lap() {
+    lap_suite(512, 512, 512, 0, "512^3");
+    lap_suite(512, 512, 512, 16, "512^3 pitch+16");
+    lap_suite(512, 512, 128, 0, "512x512x128");
+    lap_suite(128, 256, 512, 0, "128x256x512");
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename W, int VEC, int LJ, int PF>
+static void hdiff_variant(const DevField<T>& in, DevField<T>& out, const DevField<T>& cf, int dI, int dJ, int dK, const char* tag,
+                          double bpl) {
+    constexpr int H = (VEC >= 2) ? 1 : 2;
+    const unsigned waves_i = (unsigned)cdiv(dI, (64 - 2 * H) * VEC), tiles_j = (unsigned)cdiv(dJ, LJ);
+    const unsigned nw = waves_i * tiles_j * dK;
+    char cfg[96];
+    snprintf(cfg, sizeof cfg, "%s jmarch VEC=%d LJ=%d PF=%d waves=%u", tag, VEC, LJ, PF, nw);
+    const double ms = time_ms([&](int) {
+        hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, W, true, true, VEC, LJ, PF>), dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, 0,
+                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, nw);
+    }, 20);
+    report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, bpl);
+}
+
+template <typename T>
+static void hdiff_suite(int dI, int dJ, int dK, const char* tag) {
+    using W = double;
+    constexpr int VMAX = 16 / sizeof(T);
+    const double bpl = 3.0 * sizeof(T);
+    DevField<T> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), ref(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+    fill(in, 2024, 1.0, 9.0);
+    fill(cf, 7, 0.0, 0.05);
+    CK(hipMemset(out.raw, 0, out.bytes));
+    CK(hipMemset(ref.raw, 0, ref.bytes));
+    {
+        dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+        const double ms = time_ms([&](int) {
+            hipLaunchKernelGGL((hdiff_generic_kernel<T, W, W, true, true>), grid, dim3(256), 0, 0, in.cview(), ref.view(), cf.cview(), (W)0, dI, dJ, dK);
+        }, 5, 1);
+        char cfg[64];
+        snprintf(cfg, sizeof cfg, "%s generic (one thread per point)", tag);
+        report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, bpl);
+    }
+    hdiff_variant<T, W, VMAX, 32, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+    printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+    CK(hipMemset(out.raw, 0, out.bytes));
+    hdiff_variant<T, W, 1, 32, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+    printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+    CK(hipMemset(out.raw, 0, out.bytes));
+    hdiff_variant<T, W, 2, 32, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+    printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+    hdiff_variant<T, W, VMAX, 16, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 64, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 32, 1>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 32, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 16, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, 2, 16, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, 2, 16, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, 2, 64, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+}
+
+static void section_hdiff() {
+    hdiff_suite<float>(1024, 1024, 80, "1024x1024x80");
+    hdiff_suite<double>(512, 1024, 80, "512x1024x80");
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC, int UNROLL>
+static void tridiag_variant(DevField<T>& a, DevField<T>& d, DevField<T>& s, DevField<T>& r, DevField<T>& o, int dI, int dJ, int dK,
+                            const char* tag) {
+    const unsigned ti = (unsigned)cdiv(dI, 256 * VEC);
+    char cfg[96];
+    snprintf(cfg, sizeof cfg, "%s VEC=%d UNROLL=%d", tag, VEC, UNROLL);
+    const double ms = time_ms([&](int) {
+        hipLaunchKernelGGL((tridiag_kernel<T, VEC, UNROLL>), dim3(ti * dJ), dim3(256), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+    }, 5, 1);
+    report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
+}
+
+static void section_tridiag() {
+    const int dI = 1024, dJ = 1024, dK = 160;
+    DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
+    DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+    fill(a, 1, -1.0, 1.0);
+    fill(d, 2, 4.0, 5.0);
+    // correctness: vector kernel vs any-stride kernel from identical inputs
+    fill(s, 3, -1.0, 1.0);
+    fill(r, 4, -10.0, 10.0);
+    fill(s2, 3, -1.0, 1.0);
+    fill(r2, 4, -10.0, 10.0);
+    {
+        const unsigned ti = (unsigned)cdiv(dI, 512);
+        hipLaunchKernelGGL((tridiag_kernel<double, 2, 4>), dim3(ti * dJ), dim3(256), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+        dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4));
+        const double ms = time_ms([&](int) {
+            fill(s2, 3, -1.0, 1.0);
+            fill(r2, 4, -10.0, 10.0);
+            hipLaunchKernelGGL((tridiag_generic_kernel<double>), grid, dim3(256), 0, 0, a.cview(), d.cview(), s2.view(), r2.view(), o2.view(), dI, dJ, dK);
+        }, 1, 0);
+        (void)ms;
+        CK(hipDeviceSynchronize());
+        printf("           check vec2 vs generic: out %llu sup %llu rhs %llu mismatches\n", count_diff(o, o2, dI, dJ, dK),
+               count_diff(s, s2, dI, dJ, dK), count_diff(r, r2, dI, dJ, dK));
+    }
+    // timing (inputs drift because sup/rhs are rewritten in place; diag-dominant keeps them finite)
+    {
+        dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4));
+        const double ms = time_ms([&](int) {
+            hipLaunchKernelGGL((tridiag_generic_kernel<double>), grid, dim3(256), 0, 0, a.cview(), d.cview(), s2.view(), r2.view(), o2.view(), dI, dJ, dK);
+        }, 3, 1);
+        report("tridiag64", "1024x1024x160 generic", ms, (double)dI * dJ * dK, 56.0);
+    }
+    tridiag_variant<double, 2, 4>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    tridiag_variant<double, 2, 2>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    tridiag_variant<double, 2, 8>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    tridiag_variant<double, 1, 4>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    tridiag_variant<double, 1, 8>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    tridiag_variant<double, 2, 1>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+}
+
+int main(int argc, char** argv) {
+    std::vector<std::string> want;
+    for (int i = 1; i < argc; ++i) want.push_back(argv[i]);
+    auto on = [&](const char* s) {
+        if (want.empty()) return true;
+        for (auto& w : want)
+            if (w == s) return true;
+        return false;
+    };
+    char info[256];
+    if (gt4mi_device_info(info, sizeof info) == 0) printf("%s\n", info);
+    bool ok = true;
+    if (on("dpp")) ok &= section_dpp();
+    if (on("copy")) section_copy();
+    if (on("lap")) section_lap();
+    if (on("hdiff")) section_hdiff();
+    if (on("tridiag")) section_tridiag();
+    return ok ? 0 : 1;
+}
+
+// device_info lives in gt4mi.hip; the micro-benchmark links stand-alone, so provide it here too.
+extern "C" int gt4mi_device_info(char* buf, size_t buflen) {
+    int dev = 0;
+    CK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, buflen, "device=%d name=%s arch=%s cus=%d clock_mhz=%d", dev, prop.name, prop.gcnArchName,
+             prop.multiProcessorCount, prop.clockRate / 1000);
+    return 0;
+}

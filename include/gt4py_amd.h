@@ -1,0 +1,143 @@
+/*
+ * gt4py_amd.h -- C ABI of the MI355X-native stencil-execution library (libgt4py_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of gt4py.cartesian.  In the
+ * reference every compiled backend exposes ONE native entry per stencil, generated at JIT time:
+ *
+ *     run_computation(std::array<uint_t,3> domain,
+ *                     {py::buffer|py::object field, std::array<int_t,ndim> field_origin}...,
+ *                     scalars by value..., py::object exec_info)
+ *         -- /root/reference/src/gt4py/cartesian/backend/gtc_common.py:65-103  (bindings template)
+ *         -- /root/reference/src/gt4py/cartesian/backend/gtcpp_backend.py:77-106 (argument marshalling)
+ *         -- /root/reference/src/gt4py/cartesian/backend/gtc_common.py:30-62  (buffer -> SID, origin shift)
+ *
+ * The functions below are the same entry, one per hand-written kernel family, with the pybind11
+ * objects replaced by plain pointers and sizes so that they can be bound from ctypes / cffi / any
+ * FFI.  A field is described exactly by what `pybuffer_to_sid` extracts from the Python buffer
+ * (pointer, shape, byte strides) plus the per-field origin the generated wrapper passes next to it.
+ *
+ * All pointers are DEVICE pointers (HIP, gfx950).  No function allocates or frees caller memory.
+ * Every function returns 0 on success or a negative gt4mi_status; the message of the last failure
+ * on the calling thread is available from gt4mi_last_error().  Launches are asynchronous on
+ * `stream` (a hipStream_t passed as void*; NULL = the default stream); the caller synchronises
+ * (the reference synchronises the device after every gt:gpu call unless device_sync=False --
+ * backend/gtc_common.py:288-296; the Python host code does the same through gt4mi_stream_sync).
+ */
+#ifndef GT4PY_AMD_H
+#define GT4PY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GT4MI_ABI_VERSION 1
+
+typedef enum gt4mi_status {
+    GT4MI_OK = 0,
+    GT4MI_ERR_INVALID_ARGUMENT = -1, /* null pointer, bad enum, negative size ...              */
+    GT4MI_ERR_OUT_OF_BOUNDS = -2,    /* origin/domain/halo do not fit in the field's shape     */
+    GT4MI_ERR_UNSUPPORTED = -3,      /* combination not implemented by any kernel              */
+    GT4MI_ERR_HIP = -4               /* a HIP runtime call failed; see gt4mi_last_error()      */
+} gt4mi_status;
+
+/* One stencil field argument.
+ * Replaces the (py::buffer, origin) pair of run_computation (gtc_common.py:80-82, 30-62). */
+typedef struct gt4mi_field {
+    void* data;        /* device address of element [0,0,0]                                  */
+    int64_t shape[3];  /* extent along I, J, K                                               */
+    int64_t stride[3]; /* BYTE strides along I, J, K (any layout; I-contiguous is the fast one) */
+    int64_t origin[3]; /* index of the first compute-domain point (the `_origin_[name]` entry) */
+} gt4mi_field;
+
+/* Optional host-side timestamps, the counterpart of exec_info["run_cpp_start_time"/"..end_time"]
+ * (gtc_common.py:83-99).  Seconds from a monotonic clock. May be NULL. */
+typedef struct gt4mi_exec_info {
+    double run_cpp_start_time;
+    double run_cpp_end_time;
+} gt4mi_exec_info;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int gt4mi_abi_version(void);
+const char* gt4mi_last_error(void);
+/* Writes a NUL-terminated description of the current HIP device (name, arch, CUs) into buf. */
+int gt4mi_device_info(char* buf, size_t buflen);
+int gt4mi_stream_sync(void* stream);
+
+/* ---- 5-point star stencils (single statement, PARALLEL, interval(...)) ------------------------
+ * Replaces run_computation of the stencils generated from
+ *   variant 0: examples/lap_cartesian_vs_next.ipynb cell 7
+ *              out = -4.0*inp[0,0,0] + inp[-1,0,0] + inp[1,0,0] + inp[0,-1,0] + inp[0,1,0]
+ *   variant 1: docs/user/cartesian/index.rst:24-28
+ *              out = -4.*inp + (inp[I+1] + inp[I-1] + inp[J+1] + inp[J-1])
+ *   variant 2: tests/.../multi_feature_tests/test_suites.py:214 (Laplacian of horizontal diffusion)
+ *              out = 4.0*inp - (inp[1,0,0] + inp[-1,0,0] + inp[0,1,0] + inp[0,-1,0])
+ *   variant 3: tests/.../feature_tests/test_call_interface.py:159-164
+ *              out = 0.25*(inp[0,1,0] + inp[0,-1,0] + inp[1,0,0] + inp[-1,0,0])
+ * Expression trees are evaluated exactly as parsed (left-assoc, one rounding per op, no FMA).
+ * `inp` needs a halo of 1 in I and J around the compute domain (field_info boundary
+ * ((1,1),(1,1),(0,0)), module_generator.py:56-106); `inp` and `out` must not overlap
+ * (gtir_to_oir.py:19-46 rejects such stencils). */
+enum { GT4MI_LAP_NOTEBOOK = 0, GT4MI_LAP_DOCS = 1, GT4MI_LAP_SUITE = 2, GT4MI_LAP_AVG = 3 };
+/* flags (f32 entry only): GT4MI_LAP_LITERAL_F32 = float literals typed float32
+ * (literal_float_precision=32, frontend/gtscript_frontend.py:1250-1259): all arithmetic in float.
+ * Default: literals are float64, so float fields are widened, computed in double and rounded once
+ * on store (gtc/passes/gtir_upcaster.py:43-143). */
+enum { GT4MI_LAP_LITERAL_F32 = 1 };
+
+int gt4mi_lap5_f64(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out,
+                   int variant, int flags, void* stream, gt4mi_exec_info* info);
+int gt4mi_lap5_f32(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out,
+                   int variant, int flags, void* stream, gt4mi_exec_info* info);
+
+/* ---- horizontal diffusion ----------------------------------------------------------------------
+ * Replaces run_computation of `horizontal_diffusion` (flux limiter) and
+ * `simple_horizontal_diffusion` / TestHorizontalDiffusion (no limiter):
+ *   tests/.../multi_feature_tests/stencil_definitions.py:316-328, :206-216; test_suites.py:212-220.
+ * `in_field` needs a halo of 2 in I and J.  The diffusion coefficient is a field (coeff != NULL)
+ * or a scalar parameter (coeff == NULL, value in coeff_scalar; for the f32 entry the scalar is
+ * first rounded to float when GT4MI_HDIFF_COEFF_F32 is set, i.e. the parameter was declared
+ * float32).  flags:
+ *   GT4MI_HDIFF_LIMITER       apply the flux limiter (ternary -> select, npir_codegen.py:225)
+ *   GT4MI_HDIFF_INTERNAL_F32  (f32 entry only) literals typed float32 (literal_float_precision=32):
+ *                             all arithmetic in float.  Default follows the reference default
+ *                             (float64 literals => lap/flx/fly in double, gtir_upcaster.py:43-143). */
+enum { GT4MI_HDIFF_LIMITER = 1, GT4MI_HDIFF_INTERNAL_F32 = 2, GT4MI_HDIFF_COEFF_F32 = 4 };
+
+int gt4mi_hdiff_f64(const int64_t domain[3], const gt4mi_field* in_field,
+                    const gt4mi_field* out_field, const gt4mi_field* coeff, double coeff_scalar,
+                    int flags, void* stream, gt4mi_exec_info* info);
+int gt4mi_hdiff_f32(const int64_t domain[3], const gt4mi_field* in_field,
+                    const gt4mi_field* out_field, const gt4mi_field* coeff, double coeff_scalar,
+                    int flags, void* stream, gt4mi_exec_info* info);
+
+/* ---- vertical tridiagonal (Thomas) solve --------------------------------------------------------
+ * Replaces run_computation of `tridiagonal_solver` (stencil_definitions.py:219-232):
+ * FORWARD sweep rewrites sup and rhs IN PLACE (they are READ_WRITE API fields), BACKWARD sweep
+ * writes out.  domain[2] must be >= 2 (min_sequential_axis_size, gtir_k_boundary.py:78-109). */
+int gt4mi_tridiag_f64(const int64_t domain[3], const gt4mi_field* inf, const gt4mi_field* diag,
+                      const gt4mi_field* sup, const gt4mi_field* rhs, const gt4mi_field* out,
+                      void* stream, gt4mi_exec_info* info);
+int gt4mi_tridiag_f32(const int64_t domain[3], const gt4mi_field* inf, const gt4mi_field* diag,
+                      const gt4mi_field* sup, const gt4mi_field* rhs, const gt4mi_field* out,
+                      void* stream, gt4mi_exec_info* info);
+
+/* ---- halo pack / unpack (NEW: the reference has no multi-device path) -----
+ * Copies the box [lo, lo+extent) of `field` (indices relative to element [0,0,0], NOT to the
+ * origin) to / from a dense buffer laid out I-fastest, then J, then K.  elem_size is 4 or 8. */
+int gt4mi_halo_pack(const gt4mi_field* field, const int64_t lo[3], const int64_t extent[3],
+                    void* buffer, int elem_size, void* stream);
+int gt4mi_halo_unpack(const gt4mi_field* field, const int64_t lo[3], const int64_t extent[3],
+                      const void* buffer, int elem_size, void* stream);
+
+/* ---- measurement helper ---------------------------------------------------------------------
+ * Streaming device copy of nbytes (multiple of 16) with 16-byte lanes: the "achievable HBM"
+ * yardstick printed next to the stencil numbers. */
+int gt4mi_stream_copy(const void* src, void* dst, size_t nbytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GT4PY_AMD_H */

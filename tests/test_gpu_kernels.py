@@ -1,0 +1,314 @@
+"""GPU parity tests: hand-written HIP kernels (through the C ABI) vs the CPU oracle.
+
+Bar: bit-exact against the numpy restatement (oracle/ref_numpy.py), which follows the numpy
+backend's evaluation order and dtype rules.  The north-star tolerance (1e-12 in fp64) is therefore
+met with margin; the tests assert equality and report the max abs difference on failure.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_numpy as R  # noqa: E402  (oracle = checker only)
+
+DOMAINS = [(1, 1, 1), (3, 5, 2), (17, 33, 5), (64, 64, 8), (65, 63, 7), (130, 40, 3), (300, 37, 2)]
+LAYOUTS = ["ifirst", "ifirst_unaligned", "kfirst", "jfirst"]
+
+
+def _eq(got, want, what=""):
+    if not np.array_equal(got, want, equal_nan=True):
+        diff = np.nanmax(np.abs(got.astype(np.float64) - want.astype(np.float64)))
+        nbad = int((~((got == want) | (np.isnan(got) & np.isnan(want)))).sum())
+        raise AssertionError(f"{what}: {nbad} mismatching elements, max abs diff {diff:.3e}")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("domain", DOMAINS)
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_lap5_f64_parity(domain, layout, variant):
+    import gpu_util as G
+
+    rng = np.random.default_rng(1337)
+    shape = (domain[0] + 2, domain[1] + 2, domain[2])
+    inp = rng.uniform(-1, 1, shape)
+    out0 = rng.uniform(-1, 1, shape)  # halo of `out` must stay untouched
+    want = out0.copy()
+    R.laplacian(inp, want, origin_inp=(1, 1, 0), origin_out=(1, 1, 0), domain=domain,
+                variant=["notebook", "docs", "suite", "avg"][variant])
+    d_in = G.DevArray(inp, layout, align_index=(1, 1, 0))
+    d_out = G.DevArray(out0, layout, align_index=(1, 1, 0))
+    G.lap5(d_in, d_out, (1, 1, 0), (1, 1, 0), domain, variant)
+    _eq(d_out.get(), want, f"lap5 f64 {domain} {layout} v{variant}")
+
+
+@pytest.mark.parametrize("literal32", [False, True])
+@pytest.mark.parametrize("domain", [(17, 33, 5), (64, 64, 8), (300, 37, 2)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_lap5_f32_parity(domain, variant, literal32):
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    rng = np.random.default_rng(7)
+    shape = (domain[0] + 2, domain[1] + 2, domain[2])
+    inp = rng.uniform(-1, 1, shape).astype(np.float32)
+    # oracle: float64-literal semantics == compute in float64 from float32 inputs where the
+    # expression tree says so; emulate by following the same tree explicitly
+    c = inp[1:-1, 1:-1]
+    w, e, s, n = inp[:-2, 1:-1], inp[2:, 1:-1], inp[1:-1, :-2], inp[1:-1, 2:]
+    W = np.float32 if literal32 else np.float64
+    if variant == 0:
+        r = ((((W(-4.0) * c.astype(W)) + w.astype(W)) + e.astype(W)) + s.astype(W)) + n.astype(W)
+    elif variant == 1:
+        r = (W(-4.0) * c.astype(W)) + (((e + w) + n) + s).astype(W)
+    elif variant == 2:
+        r = (W(4.0) * c.astype(W)) - (((e + w) + n) + s).astype(W)
+    else:
+        r = W(0.25) * (((n + s) + e) + w).astype(W)
+    want = np.zeros(shape, np.float32)
+    want[1:-1, 1:-1] = r.astype(np.float32)
+    d_in = G.DevArray(inp, "ifirst", align_index=(1, 1, 0))
+    d_out = G.DevArray(np.zeros(shape, np.float32), "ifirst", align_index=(1, 1, 0))
+    G.lap5(d_in, d_out, (1, 1, 0), (1, 1, 0), domain, variant, _lib.LAP_LITERAL_F32 if literal32 else 0)
+    _eq(d_out.get(), want, f"lap5 f32 {domain} v{variant} lit32={literal32}")
+
+
+def test_lap5_known_answers():
+    """Reference KATs: x^2+y^2 -> 4 (examples/lap_cartesian_vs_next.ipynb cells 5-9);
+    avg of ones -> 1 (test_call_interface.py:221-285)."""
+    import gpu_util as G
+
+    nx = ny = 32
+    inp = np.fromfunction(lambda x, y, z: x**2 + y**2, (nx, ny, 1))
+    d_in = G.DevArray(inp, "ifirst", align_index=(1, 1, 0))
+    d_out = G.DevArray(np.zeros_like(inp), "ifirst", align_index=(1, 1, 0))
+    G.lap5(d_in, d_out, (1, 1, 0), (1, 1, 0), (nx - 2, ny - 2, 1), 0)
+    out = d_out.get()
+    assert (out[1:-1, 1:-1] == 4.0).all()
+    assert (out[0] == 0).all() and (out[-1] == 0).all() and (out[:, 0] == 0).all() and (out[:, -1] == 0).all()
+
+    ones = np.ones((22, 22, 10))
+    d_in = G.DevArray(ones, "ifirst", align_index=(1, 1, 0))
+    d_out = G.DevArray(np.zeros_like(ones), "ifirst", align_index=(1, 1, 0))
+    G.lap5(d_in, d_out, (2, 2, 0), (2, 2, 0), (10, 10, 10), 3)
+    out = d_out.get()
+    assert (out[2:12, 2:12, :] == 1).all() and out.sum() == 1000
+
+
+def test_lap5_bounds_are_checked():
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    a = G.DevArray(np.ones((22, 22, 10)), "ifirst")
+    b = G.DevArray(np.zeros((22, 22, 10)), "ifirst")
+    with pytest.raises(_lib.NativeError) as ei:
+        G.lap5(a, b, (2, 2, 0), (2, 2, 0), (20, 20, 10), 3)
+    assert ei.value.status == _lib.ERR_OUT_OF_BOUNDS
+    with pytest.raises(_lib.NativeError):
+        G.lap5(a, b, (0, 1, 0), (0, 1, 0), (5, 5, 5), 0)
+
+
+# ------------------------------------------------------------------------------------------------
+def _hdiff_inputs(domain, dtype, seed=2024):
+    rng = np.random.default_rng(seed)
+    ni, nj, nk = domain[0] + 4, domain[1] + 4, domain[2]
+    x = np.arange(ni)[:, None, None] / max(ni, 2)
+    y = np.arange(nj)[None, :, None] / max(nj, 2)
+    f = 5 + 8 * (2 + np.cos(np.pi * (x + 1.5 * y)) + np.sin(2 * np.pi * (x + 1.5 * y))) / 4
+    f = f + 0.1 * rng.uniform(-1, 1, (ni, nj, nk))
+    coeff = rng.uniform(0.0, 0.05, (ni, nj, nk))
+    return f.astype(dtype), coeff.astype(dtype)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("limiter", [True, False])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("domain", DOMAINS)
+def test_hdiff_parity_field_coeff(domain, dtype, limiter, layout):
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    inp, coeff = _hdiff_inputs(domain, dtype)
+    out0 = np.full(inp.shape, -7.0, dtype)
+    want = out0.copy()
+    R.hdiff(inp, want, coeff, origin_in=(2, 2, 0), origin_out=(2, 2, 0), origin_coeff=(2, 2, 0),
+            domain=domain, limiter=limiter)
+    d_in = G.DevArray(inp, layout, align_index=(2, 2, 0))
+    d_cf = G.DevArray(coeff, layout, align_index=(2, 2, 0))
+    d_out = G.DevArray(out0, layout, align_index=(2, 2, 0))
+    G.hdiff(d_in, d_out, d_cf, (2, 2, 0), (2, 2, 0), (2, 2, 0), domain, _lib.HDIFF_LIMITER if limiter else 0)
+    _eq(d_out.get(), want, f"hdiff {np.dtype(dtype).name} {domain} {layout} limiter={limiter}")
+
+
+@pytest.mark.parametrize("dtype,lit32,c32", [(np.float64, False, False), (np.float32, False, False),
+                                             (np.float32, True, True), (np.float32, True, False),
+                                             (np.float32, False, True)])
+@pytest.mark.parametrize("domain", [(17, 33, 5), (130, 40, 3)])
+def test_hdiff_parity_scalar_coeff_and_precisions(domain, dtype, lit32, c32):
+    """weight as a scalar parameter (test_suites.py:205-220) and literal_float_precision=32."""
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    inp, _ = _hdiff_inputs(domain, dtype, seed=11)
+    weight = np.float32(0.31) if c32 else np.float64(0.31)
+    want = np.zeros_like(inp)
+    R.hdiff(inp, want, weight, domain=domain, limiter=True, literal_float_precision=32 if lit32 else 64)
+    flags = _lib.HDIFF_LIMITER | (_lib.HDIFF_INTERNAL_F32 if lit32 else 0) | (_lib.HDIFF_COEFF_F32 if c32 else 0)
+    d_in = G.DevArray(inp, "ifirst", align_index=(2, 2, 0))
+    d_out = G.DevArray(np.zeros_like(inp), "ifirst", align_index=(2, 2, 0))
+    G.hdiff(d_in, d_out, float(weight), (2, 2, 0), (2, 2, 0), None, domain, flags)
+    _eq(d_out.get(), want, f"hdiff scalar {np.dtype(dtype).name} lit32={lit32} c32={c32}")
+
+
+def test_hdiff_reference_validation_function():
+    """No-limiter hdiff against the reference's own numpy validation (test_suites.py:222-230),
+    on the reference's input ranges (u in [-10,10], weight in [0,0.5], halo 2, fp64)."""
+    import gpu_util as G
+
+    rng = np.random.default_rng(3)
+    for domain in [(1, 1, 1), (5, 9, 3), (15, 15, 15)]:
+        u = rng.uniform(-10, 10, (domain[0] + 4, domain[1] + 4, domain[2]))
+        weight = float(rng.uniform(0, 0.5))
+        want = R.hdiff_validation(u, weight)
+        d_in = G.DevArray(u, "ifirst", align_index=(2, 2, 0))
+        d_out = G.DevArray(np.zeros(domain), "ifirst")
+        G.hdiff(d_in, d_out, weight, (2, 2, 0), (0, 0, 0), None, domain, 0)
+        _eq(d_out.get(), want, f"hdiff validation {domain}")
+
+
+def test_hdiff_plane_is_identity():
+    """lap of an affine plane is exactly 0 -> all fluxes 0 -> out == in bit-exactly."""
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    i, j, k = np.meshgrid(np.arange(36.0), np.arange(28.0), np.arange(3.0), indexing="ij")
+    plane = 3.0 * i - 2.0 * j + 0.5 * k + 7.0
+    d_in = G.DevArray(plane, "ifirst", align_index=(2, 2, 0))
+    d_out = G.DevArray(np.zeros_like(plane), "ifirst", align_index=(2, 2, 0))
+    G.hdiff(d_in, d_out, 0.4, (2, 2, 0), (2, 2, 0), None, (32, 24, 3), _lib.HDIFF_LIMITER)
+    assert np.array_equal(d_out.get()[2:-2, 2:-2], plane[2:-2, 2:-2])
+
+
+def test_hdiff_nan_and_inf_propagate_like_numpy():
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    inp, coeff = _hdiff_inputs((20, 12, 2), np.float64)
+    inp[7, 6, 0] = np.nan
+    inp[12, 5, 1] = np.inf
+    want = np.zeros_like(inp)
+    R.hdiff(inp, want, coeff, domain=(20, 12, 2), limiter=True)
+    d_in, d_cf = G.DevArray(inp, "ifirst", (2, 2, 0)), G.DevArray(coeff, "ifirst", (2, 2, 0))
+    d_out = G.DevArray(np.zeros_like(inp), "ifirst", (2, 2, 0))
+    G.hdiff(d_in, d_out, d_cf, (2, 2, 0), (2, 2, 0), (2, 2, 0), (20, 12, 2), _lib.HDIFF_LIMITER)
+    _eq(d_out.get(), want, "hdiff nan/inf")
+
+
+# ------------------------------------------------------------------------------------------------
+def _tridiag_inputs(shape, dtype, seed=7):
+    rng = np.random.default_rng(seed)
+    diag = rng.uniform(4, 5, shape).astype(dtype)
+    inf = rng.uniform(-1, 1, shape).astype(dtype)
+    sup = rng.uniform(-1, 1, shape).astype(dtype)
+    rhs = rng.uniform(-10, 10, shape).astype(dtype)
+    return inf, diag, sup, rhs
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(1, 1, 2), (3, 5, 2), (17, 33, 5), (64, 64, 8), (65, 63, 7), (40, 9, 160), (514, 3, 19)])
+def test_tridiag_parity(shape, dtype, layout):
+    import gpu_util as G
+
+    inf, diag, sup, rhs = _tridiag_inputs(shape, dtype)
+    s_w, r_w, o_w = sup.copy(), rhs.copy(), np.zeros(shape, dtype)
+    R.tridiag(inf, diag, s_w, r_w, o_w)
+    d = [G.DevArray(a, layout) for a in (inf, diag, sup, rhs, np.zeros(shape, dtype))]
+    origins = {n: (0, 0, 0) for n in ("inf", "diag", "sup", "rhs", "out")}
+    G.tridiag(*d, origins, shape)
+    _eq(d[4].get(), o_w, f"tridiag out {shape} {layout}")
+    _eq(d[2].get(), s_w, "tridiag sup (in-place)")
+    _eq(d[3].get(), r_w, "tridiag rhs (in-place)")
+
+
+def test_tridiag_against_scipy_and_residual():
+    import gpu_util as G
+    from scipy.linalg import solve_banded
+
+    shape = (6, 5, 40)
+    inf, diag, sup, rhs = _tridiag_inputs(shape, np.float64, seed=99)
+    d = [G.DevArray(a, "ifirst") for a in (inf, diag, sup, rhs, np.zeros(shape))]
+    G.tridiag(*d, {n: (0, 0, 0) for n in ("inf", "diag", "sup", "rhs", "out")}, shape)
+    x = d[4].get()
+    for i in range(shape[0]):
+        for j in range(shape[1]):
+            ab = np.zeros((3, shape[2]))
+            ab[0, 1:] = sup[i, j, :-1]
+            ab[1] = diag[i, j]
+            ab[2, :-1] = inf[i, j, 1:]
+            ref = solve_banded((1, 1), ab, rhs[i, j])
+            assert np.abs(ref - x[i, j]).max() <= 1e-12
+    res = diag * x - rhs
+    res[:, :, 1:] += inf[:, :, 1:] * x[:, :, :-1]
+    res[:, :, :-1] += sup[:, :, :-1] * x[:, :, 1:]
+    assert np.abs(res).max() <= 1e-13 * 10 * 5
+
+
+def test_tridiag_subdomain_with_origins_and_singular_pivot():
+    """origin/domain smaller than the arrays; untouched outside; 0/0 propagates as in numpy (N3)."""
+    import gpu_util as G
+
+    shape = (9, 8, 12)
+    inf, diag, sup, rhs = _tridiag_inputs(shape, np.float64, seed=5)
+    diag[3, 3, 0] = 0.0
+    rhs[3, 3, 0] = 0.0
+    origins = {"inf": (1, 2, 0), "diag": (1, 2, 0), "sup": (1, 2, 1), "rhs": (1, 2, 0), "out": (0, 0, 2)}
+    domain = (7, 5, 10)
+    out0 = np.full(shape, 3.0)
+    s_w, r_w, o_w = sup.copy(), rhs.copy(), out0.copy()
+    R.tridiag(inf, diag, s_w, r_w, o_w, origins=origins, domain=domain)
+    d = [G.DevArray(a, "ifirst") for a in (inf, diag, sup, rhs, out0)]
+    G.tridiag(*d, origins, domain)
+    _eq(d[4].get(), o_w, "tridiag out sub-domain")
+    _eq(d[2].get(), s_w, "tridiag sup sub-domain")
+    _eq(d[3].get(), r_w, "tridiag rhs sub-domain")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_halo_pack_unpack_roundtrip(dtype):
+    import ctypes
+
+    import gpu_util as G
+    import torch
+    from gt4py_amd import _lib
+
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-1, 1, (20, 14, 6)).astype(dtype)
+    d = G.DevArray(a, "ifirst", (2, 2, 0))
+    lo, ext = (3, 1, 0), (2, 11, 6)
+    buf = torch.empty(int(np.prod(ext)), dtype=G.TORCH_DT[np.dtype(dtype)], device="cuda")
+    G.call("gt4mi_halo_pack", ctypes.byref(d.field((0, 0, 0))), _lib.domain3(lo), _lib.domain3(ext),
+           buf.data_ptr(), a.dtype.itemsize, G.stream_ptr())
+    got = buf.cpu().numpy().reshape(ext[::-1]).transpose(2, 1, 0)
+    assert np.array_equal(got, a[3:5, 1:12, 0:6])
+    # unpack into another place of a second array
+    b = np.zeros_like(a)
+    db = G.DevArray(b, "kfirst")
+    G.call("gt4mi_halo_unpack", ctypes.byref(db.field((0, 0, 0))), _lib.domain3((10, 2, 0)), _lib.domain3(ext),
+           buf.data_ptr(), a.dtype.itemsize, G.stream_ptr())
+    want = b.copy()
+    want[10:12, 2:13, :] = a[3:5, 1:12, :]
+    assert np.array_equal(db.get(), want)
+
+
+def test_stream_copy():
+    import gpu_util as G
+    import torch
+
+    src = torch.arange(1 << 20, dtype=torch.float64, device="cuda")
+    dst = torch.zeros_like(src)
+    G.call("gt4mi_stream_copy", src.data_ptr(), dst.data_ptr(), src.numel() * 8, G.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)

@@ -15,40 +15,11 @@
 #pragma once
 
 #include "common.hip.h"
+#include "lane_shift.hip.h"
 
 #pragma clang fp contract(off)
 
 namespace gt4mi {
-
-// ---- cross-lane shifts -------------------------------------------------------------------------
-#ifndef GT4MI_NO_DPP
-__device__ __forceinline__ int lane_from_prev(int v) {  // lane l receives lane l-1
-    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-__device__ __forceinline__ int lane_from_next(int v) {  // lane l receives lane l+1
-    return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-}
-#else
-__device__ __forceinline__ int lane_from_prev(int v) { return __shfl_up(v, 1); }
-__device__ __forceinline__ int lane_from_next(int v) { return __shfl_down(v, 1); }
-#endif
-
-template <typename X, bool FROM_PREV>
-__device__ __forceinline__ X lane_shift(X v) {
-    if constexpr (sizeof(X) == 4) {
-        int r = FROM_PREV ? lane_from_prev(__builtin_bit_cast(int, v))
-                          : lane_from_next(__builtin_bit_cast(int, v));
-        return __builtin_bit_cast(X, r);
-    } else {
-        static_assert(sizeof(X) == 8, "lane_shift: 4- or 8-byte types only");
-        const long long b = __builtin_bit_cast(long long, v);
-        int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
-        lo = FROM_PREV ? lane_from_prev(lo) : lane_from_next(lo);
-        hi = FROM_PREV ? lane_from_prev(hi) : lane_from_next(hi);
-        const long long r = ((long long)hi << 32) | (unsigned int)lo;
-        return __builtin_bit_cast(X, r);
-    }
-}
 
 inline bool hdiff_jmarch_enabled() {
     static const bool on = [] {
@@ -218,9 +189,13 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
     }
 }
 
+// Rows per strip / rows prefetched ahead, from the sweep in profiles/r1_microbench_d_*.log
+// (MI355X, 1024x1024x80 f32 and 512x1024x80 f64): short strips with most of their rows in flight
+// win; the 4-row prologue is re-read from L2.
+template <typename T>
 struct HdiffTuning {
-    static constexpr int LJ = 32;
-    static constexpr int PF = 2;
+    static constexpr int LJ = sizeof(T) == 4 ? 12 : 8;
+    static constexpr int PF = sizeof(T) == 4 ? 6 : 8;
 };
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC>
@@ -228,12 +203,12 @@ inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
                                    const View<const T>& cf, PW coeff_scalar, const int64_t d[3],
                                    hipStream_t stream) {
     constexpr int H = (VEC >= 2) ? 1 : 2;
-    constexpr int LJ = HdiffTuning::LJ;
+    constexpr int LJ = HdiffTuning<T>::LJ;
     const unsigned waves_i = (unsigned)cdiv(d[0], (int64_t)(64 - 2 * H) * VEC);
     const unsigned tiles_j = (unsigned)cdiv(d[1], LJ);
     const int64_t nwaves = (int64_t)waves_i * tiles_j * d[2];
     if (nwaves > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: domain too large for one launch");
-    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, HdiffTuning::PF>),
+    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, HdiffTuning<T>::PF>),
                        dim3((unsigned)cdiv(nwaves, 4)), dim3(256), 0, stream, in, out, cf,
                        coeff_scalar, (int)d[0], (int)d[1], waves_i, tiles_j, (unsigned)nwaves);
     return GT4MI_OK;

@@ -5,15 +5,19 @@
 //
 // Roofline: HBM.  Algorithmic traffic 2*sizeof(T) bytes per lattice update (one read, one write).
 //
-// Fast path ("J-march"): a workgroup owns a strip BLOCK*VEC points wide in I (contiguous, one
-// 16-byte vector per lane) and LJ rows tall in J at one K level.  Every lane walks down J keeping a
-// three-row window (j-1, j, j+1) in registers, so each element of `in` is fetched from global
-// memory once per strip (plus the two halo rows of the strip, 2/LJ extra).  The I-neighbours
-// in[i-1], in[i+VEC] are one extra 4/8-byte load each that hits the line the neighbouring lane's
-// vector load just brought into L1 -- no LDS, no barriers, waves run fully decoupled.
+// Fast path ("strip" kernel): a workgroup owns a strip BLOCK*VEC points wide in I (contiguous, one
+// 16-byte vector per lane) and LJ rows tall in J at one K level.
+//   1. every lane issues the loads of all LJ+2 rows of its column vector up front (maximum bytes in
+//      flight per wave; measured +8 % over a rolling three-row window on MI355X),
+//   2. the I-neighbours in[i-1], in[i+VEC] come from the adjacent lanes with DPP wave shifts
+//      (v_mov_b32_dpp wave_shr:1 / wave_shl:1); only the two edge lanes of a wave load them,
+//   3. results leave with non-temporal 16-byte stores (`out` is never re-read).
+// No LDS and no barriers: the J reuse lives in registers, the strip's two halo rows are L2 hits.
+// Tuning data: profiles/r1_microbench_*.log (LJ, block size, nt loads/stores, XCD order).
 #pragma once
 
 #include "common.hip.h"
+#include "lane_shift.hip.h"
 
 #pragma clang fp contract(off)
 
@@ -47,62 +51,58 @@ __device__ __forceinline__ T lap5_expr(T c, T w, T e, T s, T n) {
     }
 }
 
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, bool NT, bool XCD>
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-lap5_jmarch_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x,
-                   unsigned tiles_y, unsigned ntiles) {
-    unsigned b = blockIdx.x;
-    if constexpr (XCD) b = xcd_remap(b, ntiles);
+lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x, unsigned tiles_y) {
+    const unsigned b = blockIdx.x;
     const unsigned bx = b % tiles_x;
     const unsigned by = (b / tiles_x) % tiles_y;
     const unsigned k = b / (tiles_x * tiles_y);
+    const unsigned lane = threadIdx.x & 63;
 
-    const int i0 = (int)(bx * BLOCK + threadIdx.x) * VEC;
-    if (i0 >= dI) return;
+    // Lanes past the end of the row stay active (DPP needs their neighbours' exec bits) but are
+    // clamped onto the last valid vector and never store.
+    int i0 = (int)(bx * BLOCK + threadIdx.x) * VEC;
+    const bool active = i0 < dI;
+    if (!active) i0 = dI - VEC;
     const int j0 = (int)by * LJ;
+    const bool edge_w = lane == 0;
+    const bool edge_e = (lane == 63) || (i0 + VEC >= dI);
 
-    const T* __restrict__ row = in.p + (int64_t)k * in.sk + (int64_t)(j0 - 1) * in.sj + i0;
-    T* __restrict__ orow = out.p + (int64_t)k * out.sk + (int64_t)j0 * out.sj + i0;
+    const T* __restrict__ col = in.p + (int64_t)k * in.sk + i0;
+    T* __restrict__ ocol = out.p + (int64_t)k * out.sk + i0;
 
-    T prev[VEC], cur[VEC], nxt[VEC];
-    T cw, ce, nw = 0, ne = 0;
-    vload<T, VEC>(row, prev);
-    row += in.sj;
-    vload<T, VEC>(row, cur);
-    cw = row[-1];
-    ce = row[VEC];
-
-    auto step = [&](bool more) {
-        row += in.sj;
-        vload<T, VEC>(row, nxt);
-        if (more) {
-            nw = row[-1];
-            ne = row[VEC];
-        }
+    // Row t of the register tile is `in` row min(j0 - 1 + t, dJ): rows past the strip's last valid
+    // halo row are clamped (their results are never stored).
+    T r[LJ + 2][VEC];
+    int64_t roff[LJ + 2];
+#pragma unroll
+    for (int t = 0; t < LJ + 2; ++t) {
+        int jr = j0 - 1 + t;
+        jr = jr > dJ ? dJ : jr;
+        roff[t] = (int64_t)jr * in.sj;
+        vload<T, VEC>(col + roff[t], r[t]);
+    }
+    T w[LJ + 2], e[LJ + 2];
+#pragma unroll
+    for (int t = 1; t <= LJ; ++t) {
+        T wl = lane_shift<T, true>(r[t][VEC - 1]);
+        T el = lane_shift<T, false>(r[t][0]);
+        if (edge_w) wl = col[roff[t] - 1];
+        if (edge_e) el = col[roff[t] + VEC];
+        w[t] = wl;
+        e[t] = el;
+    }
+#pragma unroll
+    for (int t = 1; t <= LJ; ++t) {
         T res[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const T w = (e == 0) ? cw : cur[e - 1];
-            const T ee = (e == VEC - 1) ? ce : cur[e + 1];
-            res[e] = lap5_expr<T, W, VARIANT>(cur[e], w, ee, prev[e], nxt[e]);
+        for (int v = 0; v < VEC; ++v) {
+            const T wv = (v == 0) ? w[t] : r[t][v - 1];
+            const T ev = (v == VEC - 1) ? e[t] : r[t][v + 1];
+            res[v] = lap5_expr<T, W, VARIANT>(r[t][v], wv, ev, r[t - 1][v], r[t + 1][v]);
         }
-        vstore<T, VEC, NT>(orow, res);
-        orow += out.sj;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            prev[e] = cur[e];
-            cur[e] = nxt[e];
-        }
-        cw = nw;
-        ce = ne;
-    };
-
-    if (j0 + LJ <= dJ) {
-#pragma unroll
-        for (int jj = 0; jj < LJ; ++jj) step(jj + 1 < LJ);
-    } else {
-        const int nrows = dJ - j0;
-        for (int jj = 0; jj < nrows; ++jj) step(jj + 1 < nrows);
+        if (active && (j0 + t - 1 < dJ)) vstore<T, VEC, true>(ocol + (int64_t)(j0 + t - 1) * out.sj, res);
     }
 }
 
@@ -123,22 +123,19 @@ lap5_generic_kernel(View<const T> in, View<T> out, int dI, int dJ, int dK) {
 
 // ---- launch configuration ------------------------------------------------------------------
 struct Lap5Tuning {
-    static constexpr int LJ = 32;       // rows per strip (halo overhead 2/LJ)
-    static constexpr bool NT = true;    // non-temporal stores: `out` is never re-read by this kernel
-    static constexpr bool XCD = true;   // XCD-contiguous tile order
+    static constexpr int LJ = 8;  // rows per strip; all LJ+2 row loads are in flight at once
 };
 
 template <typename T, typename W, int VARIANT, int VEC, int BLOCK>
-inline int lap5_launch_jmarch(const View<const T>& in, const View<T>& out, const int64_t d[3],
-                              hipStream_t stream) {
+inline int lap5_launch_strip(const View<const T>& in, const View<T>& out, const int64_t d[3],
+                             hipStream_t stream) {
     constexpr int LJ = Lap5Tuning::LJ;
     const unsigned tx = (unsigned)cdiv(d[0], (int64_t)BLOCK * VEC);
     const unsigned ty = (unsigned)cdiv(d[1], LJ);
     const int64_t n = (int64_t)tx * ty * d[2];
     if (n > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "lap5: domain too large for one launch");
-    hipLaunchKernelGGL((lap5_jmarch_kernel<T, W, VARIANT, VEC, LJ, BLOCK, Lap5Tuning::NT, Lap5Tuning::XCD>),
-                       dim3((unsigned)n), dim3(BLOCK), 0, stream, in, out, (int)d[0], (int)d[1], tx,
-                       ty, (unsigned)n);
+    hipLaunchKernelGGL((lap5_strip_kernel<T, W, VARIANT, VEC, LJ, BLOCK>), dim3((unsigned)n), dim3(BLOCK),
+                       0, stream, in, out, (int)d[0], (int)d[1], tx, ty);
     return GT4MI_OK;
 }
 
@@ -150,12 +147,12 @@ inline int lap5_launch_variant(const View<const T>& in, const View<T>& out, cons
         const bool vec = vec_ok(in, VMAX) && vec_ok(out, VMAX) && (d[0] % VMAX == 0);
         if (vec) {
             const int64_t lanes = d[0] / VMAX;
-            if (lanes <= 64) return lap5_launch_jmarch<T, W, VARIANT, VMAX, 64>(in, out, d, stream);
-            if (lanes <= 128) return lap5_launch_jmarch<T, W, VARIANT, VMAX, 128>(in, out, d, stream);
-            return lap5_launch_jmarch<T, W, VARIANT, VMAX, 256>(in, out, d, stream);
+            if (lanes <= 64) return lap5_launch_strip<T, W, VARIANT, VMAX, 64>(in, out, d, stream);
+            if (lanes <= 128) return lap5_launch_strip<T, W, VARIANT, VMAX, 128>(in, out, d, stream);
+            return lap5_launch_strip<T, W, VARIANT, VMAX, 256>(in, out, d, stream);
         }
-        if (d[0] <= 64) return lap5_launch_jmarch<T, W, VARIANT, 1, 64>(in, out, d, stream);
-        return lap5_launch_jmarch<T, W, VARIANT, 1, 256>(in, out, d, stream);
+        if (d[0] <= 64) return lap5_launch_strip<T, W, VARIANT, 1, 64>(in, out, d, stream);
+        return lap5_launch_strip<T, W, VARIANT, 1, 256>(in, out, d, stream);
     }
     dim3 grid((unsigned)cdiv(d[0], 64), (unsigned)cdiv(d[1], 4),
               (unsigned)(d[2] < 65535 ? d[2] : 65535));

@@ -201,16 +201,16 @@ static void section_copy() {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int LJ, int BLOCK, bool NT, bool XCD>
+template <int LJ, int BLOCK>
 static void lap_variant(const DevField<double>& in, DevField<double>& out, int dI, int dJ, int dK, const char* tag) {
     constexpr int VEC = 2;
     const unsigned tx = (unsigned)cdiv(dI, BLOCK * VEC), ty = (unsigned)cdiv(dJ, LJ);
     const unsigned n = tx * ty * dK;
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%s jmarch LJ=%d block=%d nt=%d xcd=%d", tag, LJ, BLOCK, (int)NT, (int)XCD);
+    snprintf(cfg, sizeof cfg, "%s strip LJ=%d block=%d", tag, LJ, BLOCK);
     const double ms = time_ms([&](int) {
-        hipLaunchKernelGGL((lap5_jmarch_kernel<double, double, 0, VEC, LJ, BLOCK, NT, XCD>), dim3(n), dim3(BLOCK), 0, 0,
-                           in.cview(), out.view(), dI, dJ, tx, ty, n);
+        hipLaunchKernelGGL((lap5_strip_kernel<double, double, 0, VEC, LJ, BLOCK>), dim3(n), dim3(BLOCK), 0, 0,
+                           in.cview(), out.view(), dI, dJ, tx, ty);
     }, 20);
     report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
 }
@@ -220,7 +220,6 @@ static void lap_suite(int dI, int dJ, int dK, int64_t extra_pitch, const char* t
     fill(in, 1337, -1.0, 1.0);
     CK(hipMemset(out.raw, 0, out.bytes));
     CK(hipMemset(ref.raw, 0, ref.bytes));
-    // reference: any-stride kernel
     {
         dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
         const double ms = time_ms([&](int) {
@@ -230,35 +229,29 @@ static void lap_suite(int dI, int dJ, int dK, int64_t extra_pitch, const char* t
         snprintf(cfg, sizeof cfg, "%s generic (one thread per point)", tag);
         report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
     }
-    lap_variant<8, 256, true, true>(in, out, dI, dJ, dK, tag);
-    printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
-    lap_variant<16, 256, true, true>(in, out, dI, dJ, dK, tag);
-    lap_variant<32, 256, true, true>(in, out, dI, dJ, dK, tag);
-    printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
-    lap_variant<64, 256, true, true>(in, out, dI, dJ, dK, tag);
-    lap_variant<128, 256, true, true>(in, out, dI, dJ, dK, tag);
-    lap_variant<32, 256, false, true>(in, out, dI, dJ, dK, tag);
-    lap_variant<32, 256, true, false>(in, out, dI, dJ, dK, tag);
-    lap_variant<32, 256, false, false>(in, out, dI, dJ, dK, tag);
-    lap_variant<64, 256, true, false>(in, out, dI, dJ, dK, tag);
-    lap_variant<32, 128, true, true>(in, out, dI, dJ, dK, tag);
-    lap_variant<64, 128, true, true>(in, out, dI, dJ, dK, tag);
-    lap_variant<32, 64, true, true>(in, out, dI, dJ, dK, tag);
-    // through the library dispatch
-    {
+    for (int rep = 0; rep < 2; ++rep) {
+        lap_variant<4, 256>(in, out, dI, dJ, dK, tag);
+        lap_variant<8, 256>(in, out, dI, dJ, dK, tag);
+        if (rep == 0) printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+        lap_variant<12, 256>(in, out, dI, dJ, dK, tag);
+        lap_variant<16, 256>(in, out, dI, dJ, dK, tag);
+        lap_variant<8, 128>(in, out, dI, dJ, dK, tag);
+        lap_variant<16, 128>(in, out, dI, dJ, dK, tag);
+        lap_variant<8, 64>(in, out, dI, dJ, dK, tag);
         const int64_t d[3] = {dI, dJ, dK};
         const double ms = time_ms([&](int) { lap5_launch_variant<double, double, 0>(in.cview(), out.view(), d, 0); }, 20);
         char cfg[64];
         snprintf(cfg, sizeof cfg, "%s library default", tag);
         report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+        if (rep == 0) printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
     }
 }
 
 static void section_lap() {
     lap_suite(512, 512, 512, 0, "512^3");
-    lap_suite(512, 512, 512, 16, "512^3 pitch+16");
     lap_suite(512, 512, 128, 0, "512x512x128");
     lap_suite(128, 256, 512, 0, "128x256x512");
+    lap_suite(256, 256, 512, 0, "256x256x512");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -312,6 +305,15 @@ static void hdiff_suite(int dI, int dJ, int dK, const char* tag) {
     hdiff_variant<T, W, 2, 16, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
     hdiff_variant<T, W, 2, 16, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
     hdiff_variant<T, W, 2, 64, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 8, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 8, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 12, 6>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 16, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 16, 16>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 24, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 32, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, 2, 8, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, 2, 16, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
 }
 
 static void section_hdiff() {
@@ -371,6 +373,8 @@ static void section_tridiag() {
     tridiag_variant<double, 1, 4>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
     tridiag_variant<double, 1, 8>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
     tridiag_variant<double, 2, 1>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    tridiag_variant<double, 1, 16>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    tridiag_variant<double, 1, 8>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
 }
 
 int main(int argc, char** argv) {

@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GLUPS of the fp64 5-point Laplacian on a 512^3 grid through the full user
+path (gt4py_amd.storage -> @gtscript.stencil(backend="hip:mi300") -> FrozenStencil -> C ABI -> HIP).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one apply of the stencil over the whole 512^3 grid on synthetic input that is already
+resident in HBM.  With N > 1 the SAME 512^3 grid is split over the ranks along J (strong scaling);
+a step is then halo exchange (RCCL send/recv on a side stream) overlapped with the interior kernel,
+followed by the boundary-strip kernels.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line (see DESIGN.md "Measurement"):
+  roofline      HBM roofline of the dominant kernel (lap5_strip_kernel): algorithmic bytes
+                (16 B per lattice update) / mean launch duration measured with HIP events on the
+                launch stream, against the 8.0 TB/s nominal peak; `traffic` = HBM bytes per launch
+                from rocprofv3 PMC counters when a committed measurement exists, else null.
+  cpu_baseline  the oracle's C/OpenMP restatement of gt:cpu_ifirst semantics (kind "port") timed on
+                this host's cores on a bounded sample (N == 1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BYTES_PER_LUP = 16.0  # fp64: one read + one write per lattice update
+PEAK_GBS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md)
+GRID = (512, 512, 512)
+
+
+def _lap_definition():
+    from gt4py_amd.cartesian.backend import hip_templates
+
+    return hip_templates.lap_notebook
+
+
+def _device_fields(shape, n_pairs, seed):
+    """`n_pairs` (inp, out) pairs in HBM with the hip:mi300 layout; inp ~ U[-1, 1), seeded on device."""
+    import gt4py_amd.storage as gt_storage
+
+    pairs = []
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    for _ in range(n_pairs):
+        inp = gt_storage.empty(shape, np.float64, backend="hip:mi300", aligned_index=(1, 1, 0))
+        out = gt_storage.zeros(shape, np.float64, backend="hip:mi300", aligned_index=(1, 1, 0))
+        inp.tensor.copy_(torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1)
+        pairs.append((inp, out))
+    return pairs
+
+
+def _time_launches(fn, steps):
+    """Mean duration (ms) of `steps` back-to-back launches, from HIP events on the launch stream."""
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for i in range(steps):
+        fn(i)
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / steps
+
+
+def cpu_baseline(seconds_budget: float = 12.0):
+    """Time the oracle's C/OpenMP port on a bounded sample of the same workload (512x512x64 slabs)."""
+    from oracle import cpu_ifirst
+
+    lib = None
+    try:  # rebuild for this host's ISA when a compiler is around; else use the prebuilt library
+        path = cpu_ifirst.build(march="native", out=pathlib.Path("/tmp") / f"libcpu_ifirst_{os.getpid()}.so")
+        lib = cpu_ifirst.load(path)
+    except Exception:
+        if cpu_ifirst.available():
+            lib = cpu_ifirst.load()
+    if lib is None:
+        return None
+    cores = os.cpu_count() or 1
+    lib.oracle_set_threads(cores)
+    dom = (512, 512, 64)
+    rng = np.random.default_rng(1337)
+    inp = np.asfortranarray(rng.uniform(-1, 1, (dom[0] + 2, dom[1] + 2, dom[2])))
+    out = np.asfortranarray(np.zeros_like(inp))
+    cpu_ifirst.lap5_f64(inp, out, (1, 1, 0), (1, 1, 0), dom, lib=lib)  # warm-up / page touch
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        cpu_ifirst.lap5_f64(inp, out, (1, 1, 0), (1, 1, 0), dom, lib=lib)
+        reps += 1
+        if time.perf_counter() - t0 > seconds_budget or reps >= 400:
+            break
+    dt = time.perf_counter() - t0
+    glups = dom[0] * dom[1] * dom[2] * reps / dt / 1e9
+    return {
+        "value": round(glups, 4),
+        "unit": "GLUPS",
+        "cores": lib.oracle_max_threads(),
+        "kind": "port",
+        "sample": f"fp64 5-pt Laplacian on a {dom[0]}x{dom[1]}x{dom[2]} slab of the 512^3 grid, {reps} applies in "
+                  f"{dt:.1f} s, C/OpenMP restatement of gt:cpu_ifirst semantics (oracle/cpu_ifirst.c), I-contiguous",
+        "gb_per_s": round(glups * BYTES_PER_LUP, 2),
+    }
+
+
+def _committed_traffic(workload: str):
+    f = ROOT / "profiles" / "hbm_traffic.json"
+    if f.exists():
+        try:
+            return json.loads(f.read_text()).get(workload)
+        except Exception:
+            return None
+    return None
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if distributed else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; running on {n_gpus} GPU(s)", file=sys.stderr)
+
+    from gt4py_amd import _lib
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.distributed import Decomposition, HaloExchanger, choose_process_grid, overlapped_apply
+
+    lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64},
+                           device_sync=False)
+    origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}
+
+    if not distributed:
+        shape = (GRID[0] + 2, GRID[1] + 2, GRID[2])
+        pairs = _device_fields(shape, n_pairs=2, seed=1337)  # rotate pairs: nothing survives in MALL/L2
+        frozen = lap.freeze(origin=origin, domain=GRID)
+
+        def step(i):
+            inp, out = pairs[i % len(pairs)]
+            frozen(inp=inp, out=out)
+
+        local_domain = GRID
+        kernel_step = step
+        config = {"workload": "fp64 5-point Laplacian 512x512x512 (examples/lap_cartesian_vs_next.ipynb cell 7), "
+                              "origin (1,1,0), hip:mi300 storage layout", "grid": list(GRID), "decomposition": "1x1",
+                  "call_path": "FrozenStencil"}
+    else:
+        grid = choose_process_grid(world, GRID)
+        dec = Decomposition(GRID, grid, rank, halo=1)
+        pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank)
+        exchangers = [HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank)) for _ in pairs]
+        local_domain = dec.local_domain
+        frozen = lap.freeze(origin=origin, domain=local_domain)
+
+        def step(i):
+            inp, out = pairs[i % len(pairs)]
+            overlapped_apply(lap, dec, origin, {"inp": inp, "out": out}, {"inp": exchangers[i % len(pairs)]})
+
+        def kernel_step(i):  # the local kernel alone, for the per-GPU roofline figure
+            inp, out = pairs[i % len(pairs)]
+            frozen(inp=inp, out=out)
+
+        config = {"workload": "fp64 5-point Laplacian 512x512x512 split over ranks (strong scaling), halo 1 exchanged "
+                              "every step with RCCL send/recv overlapped with the interior kernel",
+                  "grid": list(GRID), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(local_domain),
+                  "halo_bytes_per_rank_per_step": exchangers[0].bytes_per_exchange}
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: mean launch duration from HIP events on the launch stream
+    torch.cuda.synchronize()
+    kernel_ms = _time_launches(kernel_step, args.steps)
+    local_lups = float(np.prod(local_domain))
+    achieved = BYTES_PER_LUP * local_lups / (kernel_ms * 1e-3) / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+    glups = float(np.prod(GRID)) * args.steps / elapsed / 1e9
+
+    if rank == 0:
+        traffic = _committed_traffic("lap5_f64_512") if not distributed else None
+        line = {
+            "metric": "GLUPS (lattice updates/s) fp64 5-pt Laplacian 512^3",
+            "value": round(glups, 2),
+            "unit": "GLUPS",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": config,
+            "pct_hbm_roofline": round(100.0 * glups * BYTES_PER_LUP / (PEAK_GBS * n_gpus), 2),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "lap5_strip_kernel<double,double,0,2,8,*>",
+                "achieved": round(achieved, 1),
+                "peak": PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / PEAK_GBS, 4),
+                "traffic": traffic,
+                "kernel_ms": round(kernel_ms, 5),
+                "algorithmic_bytes_per_launch": BYTES_PER_LUP * local_lups,
+            },
+            "device": _lib.device_info(),
+        }
+        if not distributed and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as ex:  # the baseline must never take the GPU number down with it
+                line["cpu_baseline"] = None
+                print(f"cpu_baseline failed: {ex!r}", file=sys.stderr)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

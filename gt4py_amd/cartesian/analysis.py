@@ -1,0 +1,140 @@
+"""Static analysis of an ``ir.Stencil``: horizontal extents, access kinds, K boundaries, minimum K
+size -> the ``field_info`` / ``parameter_info`` / ``domain_info`` a StencilObject exposes.
+
+Restates, for the small IR, the rules of
+* ``StencilExtentComputer`` (/root/reference/src/gt4py/cartesian/gtc/passes/oir_optimizations/utils.py:250-313):
+  statements are visited last to first; the block extent of a statement is the union of the extents
+  already required of the fields it writes (zero for fields nobody reads later); every read then
+  requires ``block extent + offset`` of the field read;
+* ``AccessKindComputer`` (gtc/passes/oir_access_kinds.py:21-67): right-hand side before left;
+  WRITE after READ = READ_WRITE, READ after WRITE stays WRITE;
+* ``compute_k_boundary`` / ``compute_min_k_size`` (gtc/passes/gtir_k_boundary.py:24-109);
+* ``make_args_data_from_gtir`` (backend/module_generator.py:56-106).
+Pinned by SURVEY.md Appendix E.1 and the reference tests cited there.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import ir
+from .definitions import AccessKind, Boundary, DomainInfo, FieldInfo, ParameterInfo
+
+Extent2 = Tuple[Tuple[int, int], Tuple[int, int]]  # ((i_lo, i_hi), (j_lo, j_hi)), lo <= 0 <= hi
+ZERO_EXTENT: Extent2 = ((0, 0), (0, 0))
+
+
+def _union(a: Extent2, b: Extent2) -> Extent2:
+    return tuple((min(x[0], y[0]), max(x[1], y[1])) for x, y in zip(a, b))  # type: ignore[return-value]
+
+
+def _shift(block: Extent2, offset: Tuple[int, int, int]) -> Extent2:
+    return tuple((lo + o, hi + o) for (lo, hi), o in zip(block, offset[:2]))  # type: ignore[return-value]
+
+
+@dataclass
+class ExtentInfo:
+    fields: Dict[str, Extent2]
+    blocks: List[Extent2]  # one per statement, in program order
+
+
+def compute_extents(stencil: ir.Stencil) -> ExtentInfo:
+    stmts = [s for _, _, s in stencil.statements()]
+    fields: Dict[str, Extent2] = {}
+    blocks: List[Extent2] = [ZERO_EXTENT] * len(stmts)
+    for idx in range(len(stmts) - 1, -1, -1):
+        stmt = stmts[idx]
+        block = _union(ZERO_EXTENT, fields.setdefault(stmt.target.name, ZERO_EXTENT))
+        blocks[idx] = block
+        for e in ir.walk(stmt.value):
+            if isinstance(e, ir.FieldAccess):
+                need = _shift(block, e.offset)
+                fields[e.name] = _union(fields[e.name], need) if e.name in fields else need
+    for f in stencil.fields:
+        fields.setdefault(f.name, ZERO_EXTENT)
+    return ExtentInfo(fields, blocks)
+
+
+def compute_access_kinds(stencil: ir.Stencil) -> Dict[str, AccessKind]:
+    access: Dict[str, AccessKind] = {}
+
+    def touch(name: str, kind: AccessKind) -> None:
+        if kind == AccessKind.WRITE and access.get(name) == AccessKind.READ:
+            access[name] = AccessKind.READ_WRITE
+        elif name not in access:
+            access[name] = kind
+
+    for _, _, stmt in stencil.statements():
+        for e in ir.walk(stmt.value):
+            if isinstance(e, (ir.FieldAccess, ir.ScalarAccess)):
+                touch(e.name, AccessKind.READ)
+        touch(stmt.target.name, AccessKind.WRITE)
+    return access
+
+
+def compute_k_boundary(stencil: ir.Stencil) -> Dict[str, Tuple[int, int]]:
+    neg_inf = float("-inf")
+    bounds: Dict[str, Tuple[float, float]] = {d.name: (neg_inf, neg_inf) for d in (*stencil.fields, *stencil.temporaries)}
+    for _, block, stmt in stencil.statements():
+        accesses = [stmt.target] + [e for e in ir.walk(stmt.value) if isinstance(e, ir.FieldAccess)]
+        for acc in accesses:
+            lo, hi = bounds[acc.name]
+            if block.interval.start.level is ir.Level.START:
+                lo = max(-block.interval.start.offset - acc.offset[2], lo)
+            if block.interval.end.level is ir.Level.END:
+                hi = max(block.interval.end.offset + acc.offset[2], hi)
+            bounds[acc.name] = (lo, hi)
+    return {n: (int(lo) if lo != neg_inf else 0, int(hi) if hi != neg_inf else 0) for n, (lo, hi) in bounds.items()}
+
+
+def compute_min_k_size(stencil: ir.Stencil) -> int:
+    min_start = min_end = biggest = 0
+    for comp in stencil.computations:
+        for block in comp.blocks:
+            s, e = block.interval.start, block.interval.end
+            if s.level is ir.Level.START and e.level is ir.Level.END:
+                if not (s.offset == 0 and e.offset == 0):
+                    biggest = max(biggest, s.offset - e.offset + 1)
+            elif s.level is ir.Level.START and e.level is ir.Level.START:
+                min_start = max(min_start, e.offset)
+                biggest = max(biggest, e.offset)
+            else:
+                min_end = max(min_end, -s.offset)
+                biggest = max(biggest, -s.offset)
+    return max(min_start + min_end, biggest)
+
+
+@dataclass
+class ArgsData:
+    field_info: Dict[str, FieldInfo]
+    parameter_info: Dict[str, ParameterInfo]
+    domain_info: DomainInfo
+    extents: ExtentInfo
+
+
+def make_args_data(stencil: ir.Stencil) -> ArgsData:
+    extents = compute_extents(stencil)
+    access = compute_access_kinds(stencil)
+    k_bounds = compute_k_boundary(stencil)
+    field_info: Dict[str, FieldInfo] = {}
+    for decl in stencil.fields:
+        kind = access.get(decl.name, AccessKind.NONE)
+        if kind != AccessKind.NONE:
+            (ilo, ihi), (jlo, jhi) = extents.fields[decl.name]
+            klo, khi = k_bounds[decl.name]
+            # extent -> boundary: lower = max(0, -lo), upper = max(0, hi); K boundary is NOT clamped
+            boundary = Boundary(((max(0, -ilo), max(0, ihi)), (max(0, -jlo), max(0, jhi)), (klo, khi)))
+        else:
+            boundary = Boundary.zeros(3)
+        field_info[decl.name] = FieldInfo(access=kind, boundary=boundary, axes=tuple(decl.axes),
+                                          data_dims=tuple(decl.data_dims), dtype=np.dtype(decl.dtype))
+    parameter_info = {
+        p.name: ParameterInfo(access=access.get(p.name, AccessKind.NONE), dtype=np.dtype(p.dtype))
+        for p in stencil.params
+    }
+    domain_info = DomainInfo(parallel_axes=("I", "J"), sequential_axis="K",
+                             min_sequential_axis_size=compute_min_k_size(stencil), ndim=3)
+    return ArgsData(field_info, parameter_info, domain_info, extents)

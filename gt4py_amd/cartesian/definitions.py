@@ -87,7 +87,7 @@ class _IntTuple(tuple):
         for v in values:
             if not isinstance(v, numbers.Integral) or (cls._MIN is not None and v < cls._MIN):
                 raise TypeError(f"Invalid {cls.__name__} definition")
-        return super().__new__(cls, values)
+        return super().__new__(cls, tuple(int(v) for v in values))  # numpy integer scalars -> int
 
     # constructors -------------------------------------------------------------------------
     @classmethod

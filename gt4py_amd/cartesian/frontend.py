@@ -1,0 +1,550 @@
+"""Minimal GTScript recogniser: Python ``ast`` of a stencil definition -> typed ``ir.Stencil``.
+
+The reference's frontend (/root/reference/src/gt4py/cartesian/frontend/gtscript_frontend.py, 4.5 kLoC)
+is a general compiler front end and out of scope.  This module parses the
+sub-language the hot-path stencils and their known-answer tests are written in
+and applies the reference's VALUE-relevant rules exactly:
+
+* expression trees as Python parses them (left-assoc), ``-4.0`` = UnaryOp(neg, 4.0)
+  (gtscript_frontend.py:1477-1504);
+* literals typed by ``literal_int_precision`` / ``literal_float_precision`` (:1236-1266);
+* temporaries typed by their first right-hand side (gtc/passes/gtir_dtype_resolver.py:54-57);
+* operand promotion by the smallest matching numpy-ufunc signature, ternary branches to the max
+  dtype, assignment casts to the target dtype (gtc/passes/gtir_upcaster.py:43-143);
+* interval arithmetic and ordering checks (gtscript_frontend.py:133-160, 1037-1065, 1124-1167).
+
+Anything outside the subset raises ``GTScriptSyntaxError`` -- never a silent approximation.
+"""
+
+from __future__ import annotations
+
+import ast
+import inspect
+import numbers
+import textwrap
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import definitions as gt_definitions, gtscript, ir
+from .definitions import GTScriptDefinitionError, GTScriptSymbolError, GTScriptSyntaxError
+
+# DataType order of the reference (gtc/common.py:105-118): bool < int8 < ... < float64.
+_RANK = {
+    np.dtype("bool"): 10,
+    np.dtype("int8"): 11,
+    np.dtype("int16"): 12,
+    np.dtype("int32"): 14,
+    np.dtype("int64"): 18,
+    np.dtype("float32"): 104,
+    np.dtype("float64"): 108,
+}
+_CHAR_TO_DTYPE = {np.dtype(d).char: np.dtype(d) for d in _RANK}
+
+_BIN_OPS = {
+    ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/", ast.Mod: "%", ast.Pow: "**",
+}
+_CMP_OPS = {ast.Gt: ">", ast.Lt: "<", ast.GtE: ">=", ast.LtE: "<=", ast.Eq: "==", ast.NotEq: "!="}
+_OP_UFUNC = {
+    "+": np.add, "-": np.subtract, "*": np.multiply, "/": np.true_divide, "%": np.remainder,
+    "**": np.power, ">": np.greater, "<": np.less, ">=": np.greater_equal, "<=": np.less_equal,
+    "==": np.equal, "!=": np.not_equal, "and": np.logical_and, "or": np.logical_or,
+    "neg": np.negative, "pos": np.positive, "not": np.logical_not,
+}
+_NATIVE_UFUNC = {
+    "abs": np.abs, "min": np.minimum, "max": np.maximum, "mod": np.remainder, "sin": np.sin,
+    "cos": np.cos, "tan": np.tan, "asin": np.arcsin, "acos": np.arccos, "atan": np.arctan,
+    "sinh": np.sinh, "cosh": np.cosh, "tanh": np.tanh, "asinh": np.arcsinh, "acosh": np.arccosh,
+    "atanh": np.arctanh, "sqrt": np.sqrt, "exp": np.exp, "log": np.log, "log10": np.log10,
+    "cbrt": np.cbrt, "isfinite": np.isfinite, "isinf": np.isinf, "isnan": np.isnan,
+    "floor": np.floor, "ceil": np.ceil, "trunc": np.trunc,
+}
+_CAST_FUNCS = {"int32": np.dtype("int32"), "int64": np.dtype("int64"), "float32": np.dtype("float32"),
+               "float64": np.dtype("float64")}
+
+
+def ufunc_signature(ufunc: np.ufunc, dtypes: Sequence[np.dtype]) -> Tuple[np.dtype, ...]:
+    """Input dtypes of the smallest ufunc loop every operand fits in.
+
+    Restates ``_numpy_ufunc_upcasting_rule`` (gtc/passes/gtir_upcaster.py:43-68): among the loops in
+    ``ufunc.types`` whose every input is >= the operand (in the reference's DataType order) pick
+    the one with the smallest sum of DataType values.
+    """
+    best_key, best = None, None
+    for sig in ufunc.types:
+        ins, _ = sig.split("->")
+        if len(ins) != len(dtypes) or any(c not in _CHAR_TO_DTYPE for c in ins):
+            continue
+        cand = tuple(_CHAR_TO_DTYPE[c] for c in ins)
+        if all(_RANK[a] <= _RANK[c] for a, c in zip(dtypes, cand)):
+            key = sum(_RANK[c] for c in cand)
+            if best_key is None or key < best_key:
+                best_key, best = key, cand
+    if best is None:
+        raise GTScriptSyntaxError(f"No numpy loop of '{ufunc.__name__}' accepts operand dtypes {list(map(str, dtypes))}")
+    return best
+
+
+def _max_dtype(*dtypes: np.dtype) -> np.dtype:
+    return max(dtypes, key=lambda d: _RANK[d])
+
+
+class _Parser(ast.NodeVisitor):
+    def __init__(self, definition, annotations, externals, options: gt_definitions.BuildOptions):
+        self.definition = definition
+        self.externals = dict(externals)
+        self.int_dtype = np.dtype(gt_definitions.get_integer_type(options.literal_int_precision))
+        self.float_dtype = np.dtype(gt_definitions.get_float_type(options.literal_float_precision))
+        self.fields: Dict[str, ir.FieldDecl] = {}
+        self.params: Dict[str, ir.ScalarDecl] = {}
+        self.temporaries: Dict[str, ir.FieldDecl] = {}
+        self.imported: Dict[str, Any] = {}
+        self._order: Optional[ir.LoopOrder] = None
+        for pname, ann in annotations.items():
+            if isinstance(ann, gtscript._FieldDescriptor):
+                axes = tuple(a.name if isinstance(a, gtscript.Axis) else str(a) for a in ann.axes)
+                self.fields[pname] = ir.FieldDecl(pname, np.dtype(ann.dtype), axes, tuple(ann.data_dims), True)
+            else:
+                try:
+                    dt = np.dtype(ann)
+                except TypeError as ex:
+                    raise GTScriptDefinitionError(
+                        f"Invalid annotated dtype value for argument '{pname}': {ann}") from ex
+                if dt not in _RANK:
+                    raise GTScriptDefinitionError(f"Invalid annotated dtype value for argument '{pname}': {ann}")
+                self.params[pname] = ir.ScalarDecl(pname, dt)
+
+    # ---- helpers -------------------------------------------------------------------------
+    def _err(self, node, msg):
+        line = getattr(node, "lineno", "?")
+        return GTScriptSyntaxError(f"{msg} (in '{self.definition.__name__}', line {line})", loc=line)
+
+    def _const(self, node) -> Any:
+        """Compile-time value of a small expression (ints, externals, unary minus, None, Ellipsis)."""
+        if isinstance(node, ast.Constant):
+            return node.value
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            v = self._const(node.operand)
+            return -v if isinstance(node.op, ast.USub) else +v
+        if isinstance(node, ast.Name) and node.id in self.imported:
+            return self.imported[node.id]
+        if isinstance(node, ast.BinOp) and type(node.op) in _BIN_OPS:
+            a, b = self._const(node.left), self._const(node.right)
+            return eval(f"a {_BIN_OPS[type(node.op)]} b", {}, {"a": a, "b": b})  # noqa: S307 - ints/floats only
+        if isinstance(node, ast.Compare) and len(node.ops) == 1 and type(node.ops[0]) in _CMP_OPS:
+            a, b = self._const(node.left), self._const(node.comparators[0])
+            return eval(f"a {_CMP_OPS[type(node.ops[0])]} b", {}, {"a": a, "b": b})  # noqa: S307
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.Not):
+            return not self._const(node.operand)
+        raise self._err(node, "Expected a compile-time constant")
+
+    # ---- body structure ------------------------------------------------------------------
+    def parse(self) -> ir.Stencil:
+        src = textwrap.dedent(inspect.getsource(self.definition))
+        tree = ast.parse(src)
+        fdef = next(n for n in tree.body if isinstance(n, (ast.FunctionDef,)))
+        computations: List[ir.Computation] = []
+        for stmt in fdef.body:
+            if isinstance(stmt, ast.Expr) and isinstance(stmt.value, ast.Constant) and isinstance(stmt.value.value, str):
+                continue  # docstring
+            if isinstance(stmt, ast.ImportFrom):
+                self._visit_import(stmt)
+                continue
+            if isinstance(stmt, ast.With):
+                computations.extend(self._visit_with(stmt))
+                continue
+            if isinstance(stmt, ast.Pass):
+                continue
+            raise self._err(stmt, "Only 'with computation(...)' blocks are allowed at the top level of a stencil")
+        if not computations:
+            raise self._err(fdef, "Stencil definition contains no computation")
+        return ir.Stencil(
+            name=self.definition.__name__,
+            fields=tuple(self.fields.values()),
+            params=tuple(self.params.values()),
+            temporaries=tuple(self.temporaries.values()),
+            computations=tuple(computations),
+        )
+
+    def _visit_import(self, node: ast.ImportFrom) -> None:
+        if node.module not in ("__externals__", "gt4py.cartesian.__externals__", "gtscript.__externals__"):
+            if node.module and (node.module.endswith("gtscript") or node.module.startswith("gt4py")):
+                return  # importing gtscript names inside the body is harmless
+            raise self._err(node, f"Unsupported import from '{node.module}' inside a stencil")
+        for alias in node.names:
+            if alias.name not in self.externals:
+                raise GTScriptSymbolError(f"Missing value for external symbol '{alias.name}'")
+            self.imported[alias.asname or alias.name] = self.externals[alias.name]
+
+    @staticmethod
+    def _call_name(node) -> Optional[str]:
+        if isinstance(node, ast.Call):
+            f = node.func
+            if isinstance(f, ast.Name):
+                return f.id
+            if isinstance(f, ast.Attribute):
+                return f.attr
+        return None
+
+    def _visit_with(self, node: ast.With) -> List[ir.Computation]:
+        names = [self._call_name(item.context_expr) for item in node.items]
+        if names and names[0] == "computation":
+            order = self._parse_order(node.items[0].context_expr)
+            if len(names) == 2 and names[1] == "interval":
+                block = self._parse_interval_block(node.items[1].context_expr, node.body, order)
+                return [ir.Computation(order, (block,))]
+            if len(names) == 1:
+                blocks = []
+                for inner in node.body:
+                    if not (isinstance(inner, ast.With) and len(inner.items) == 1
+                            and self._call_name(inner.items[0].context_expr) == "interval"):
+                        raise self._err(inner, "Expected 'with interval(...)' inside 'with computation(...)'")
+                    blocks.append(self._parse_interval_block(inner.items[0].context_expr, inner.body, order))
+                self._check_interval_order(node, order, blocks)
+                return [ir.Computation(order, tuple(blocks))]
+        raise self._err(node, "Invalid 'with' statement: expected 'with computation(ORDER), interval(...)'")
+
+    def _parse_order(self, call: ast.Call) -> ir.LoopOrder:
+        if len(call.args) != 1:
+            raise self._err(call, "computation() takes exactly one iteration order")
+        arg = call.args[0]
+        name = arg.id if isinstance(arg, ast.Name) else (arg.attr if isinstance(arg, ast.Attribute) else None)
+        try:
+            return {"PARALLEL": ir.LoopOrder.PARALLEL, "FORWARD": ir.LoopOrder.FORWARD,
+                    "BACKWARD": ir.LoopOrder.BACKWARD}[name]
+        except KeyError:
+            raise self._err(call, "Invalid iteration order, expected PARALLEL, FORWARD or BACKWARD") from None
+
+    def _parse_interval(self, call: ast.Call) -> ir.Interval:
+        args = call.args
+        if len(args) == 1 and isinstance(args[0], ast.Constant) and args[0].value is Ellipsis:
+            return ir.Interval.full()
+        if len(args) != 2:
+            raise self._err(call, "Invalid interval specification: expected interval(...) or interval(start, end)")
+        lo, hi = self._const(args[0]), self._const(args[1])
+        if lo is None:
+            lo = 0
+        if not isinstance(lo, numbers.Integral) or not (hi is None or isinstance(hi, numbers.Integral)):
+            raise self._err(call, "Invalid interval range specification")
+        start = ir.AxisBound(ir.Level.START, int(lo)) if lo >= 0 else ir.AxisBound(ir.Level.END, int(lo))
+        if hi is None:
+            end = ir.AxisBound(ir.Level.END, 0)
+        elif hi < 0:
+            end = ir.AxisBound(ir.Level.END, int(hi))
+        else:
+            end = ir.AxisBound(ir.Level.START, int(hi))
+        # reject intervals that are empty for every domain size
+        if start.level == end.level and start.offset >= end.offset:
+            raise self._err(call, "Invalid interval range specification")
+        return ir.Interval(start, end)
+
+    def _check_interval_order(self, node, order, blocks: List[ir.IntervalBlock]) -> None:
+        """Blocks must be disjoint and listed in execution order (gtscript_frontend.py:1037-1065)."""
+        big = 10_000
+
+        def key(b: ir.AxisBound) -> int:
+            return b.offset if b.level is ir.Level.START else big + b.offset
+
+        ranges = [(key(b.interval.start), key(b.interval.end)) for b in blocks]
+        seq = ranges if order is not ir.LoopOrder.BACKWARD else list(reversed(ranges))
+        for (a0, a1), (b0, b1) in zip(seq, seq[1:]):
+            if a1 > b0:
+                raise self._err(node, "Overlapping or unordered intervals in computation "
+                                      "(intervals must be listed in order of execution)")
+
+    def _parse_interval_block(self, call, body, order) -> ir.IntervalBlock:
+        interval = self._parse_interval(call)
+        self._order = order
+        stmts: List[ir.Assign] = []
+        for stmt in body:
+            stmts.extend(self._visit_stmt(stmt))
+        return ir.IntervalBlock(interval, tuple(stmts))
+
+    # ---- statements ----------------------------------------------------------------------
+    def _visit_stmt(self, node) -> List[ir.Assign]:
+        if isinstance(node, ast.Assign):
+            if len(node.targets) != 1:
+                raise self._err(node, "Chained assignment is not supported")
+            return [self._make_assign(node.targets[0], self.visit(node.value), node)]
+        if isinstance(node, ast.AugAssign):
+            if type(node.op) not in _BIN_OPS:
+                raise self._err(node, "Unsupported augmented assignment")
+            target_read = self._target_access(node.target, node, reading=True)
+            value = ir.BinaryOp(_BIN_OPS[type(node.op)], target_read, self.visit(node.value))
+            return [self._make_assign(node.target, value, node)]
+        if isinstance(node, ast.If):
+            test = node.test
+            if self._call_name(test) == "__INLINED":
+                branch = node.body if self._const(test.args[0]) else node.orelse
+                out: List[ir.Assign] = []
+                for s in branch:
+                    out.extend(self._visit_stmt(s))
+                return out
+            raise self._err(node, "Run-time 'if' statements are outside the supported GTScript subset; "
+                                  "use a ternary expression")
+        if isinstance(node, ast.Pass):
+            return []
+        if isinstance(node, ast.Expr) and isinstance(node.value, ast.Constant):
+            return []
+        raise self._err(node, f"Unsupported statement '{type(node).__name__}' in stencil body")
+
+    def _target_access(self, target, node, reading=False) -> ir.FieldAccess:
+        if isinstance(target, ast.Name):
+            name, offset = target.id, (0, 0, 0)
+        elif isinstance(target, ast.Subscript) and isinstance(target.value, ast.Name):
+            name = target.value.id
+            offset = self._parse_offset(target, name)
+        else:
+            raise self._err(node, "Invalid assignment target")
+        if offset[0] != 0 or offset[1] != 0:
+            raise self._err(node, "Assignment to non-zero offsets is not supported in IJ")
+        if offset[2] != 0 and self._order is ir.LoopOrder.PARALLEL:
+            raise self._err(node, "Assignment to non-zero offsets in K is not available in PARALLEL. "
+                                  "Choose FORWARD or BACKWARD.")
+        if name in self.params or name in self.imported:
+            raise self._err(node, f"Cannot assign to scalar parameter or external '{name}'")
+        if reading and name not in self.fields and name not in self.temporaries:
+            raise GTScriptSymbolError(f"Unknown symbol '{name}'")
+        return ir.FieldAccess(name, offset)
+
+    def _make_assign(self, target, value: ir.Expr, node) -> ir.Assign:
+        access = self._target_access(target, node)
+        if access.name not in self.fields and access.name not in self.temporaries:
+            self.temporaries[access.name] = ir.FieldDecl(access.name, None, ("I", "J", "K"), (), False)
+        return ir.Assign(access, value)
+
+    # ---- expressions ---------------------------------------------------------------------
+    def generic_visit(self, node):
+        raise self._err(node, f"Unsupported expression '{type(node).__name__}'")
+
+    def visit_Constant(self, node: ast.Constant) -> ir.Expr:
+        v = node.value
+        if isinstance(v, bool):
+            return ir.Literal(v, np.dtype("bool"))
+        if isinstance(v, int):
+            return ir.Literal(v, self.int_dtype)
+        if isinstance(v, float):
+            return ir.Literal(v, self.float_dtype)
+        raise self._err(node, f"Unsupported literal {v!r}")
+
+    def _literal_from_python(self, value, node) -> ir.Expr:
+        if isinstance(value, (bool, np.bool_)):
+            return ir.Literal(bool(value), np.dtype("bool"))
+        if isinstance(value, np.generic) and np.dtype(type(value)) in _RANK:
+            return ir.Literal(value.item(), np.dtype(type(value)))
+        if isinstance(value, numbers.Integral):
+            return ir.Literal(int(value), self.int_dtype)
+        if isinstance(value, numbers.Real):
+            return ir.Literal(float(value), self.float_dtype)
+        raise self._err(node, f"External value {value!r} is not a supported constant")
+
+    def visit_Name(self, node: ast.Name) -> ir.Expr:
+        name = node.id
+        if name in self.fields or name in self.temporaries:
+            return ir.FieldAccess(name, (0, 0, 0))
+        if name in self.params:
+            return ir.ScalarAccess(name, self.params[name].dtype)
+        if name in self.imported:
+            return self._literal_from_python(self.imported[name], node)
+        if name in ("True", "False"):
+            return ir.Literal(name == "True", np.dtype("bool"))
+        raise GTScriptSymbolError(f"Unknown symbol '{name}' in stencil '{self.definition.__name__}'")
+
+    def _parse_offset(self, node: ast.Subscript, name: str) -> Tuple[int, int, int]:
+        decl = self.fields.get(name) or self.temporaries.get(name)
+        axes = decl.axes if decl is not None else ("I", "J", "K")
+        index = node.slice
+        elts = list(index.elts) if isinstance(index, ast.Tuple) else [index]
+        offset = {"I": 0, "J": 0, "K": 0}
+
+        def axis_shift(e) -> Optional[Tuple[str, int]]:
+            if isinstance(e, ast.Name) and e.id in ("I", "J", "K"):
+                return e.id, 0
+            if (isinstance(e, ast.BinOp) and isinstance(e.op, (ast.Add, ast.Sub))
+                    and isinstance(e.left, ast.Name) and e.left.id in ("I", "J", "K")):
+                shift = self._const(e.right)
+                if not isinstance(shift, numbers.Integral):
+                    raise self._err(node, "Axis offsets must be integer constants")
+                return e.left.id, int(shift) if isinstance(e.op, ast.Add) else -int(shift)
+            return None
+
+        shifted = [axis_shift(e) for e in elts]
+        if all(s is not None for s in shifted):  # new style: f[I + 1], f[J - 1, K + 1]
+            seen = []
+            for ax, sh in shifted:
+                if ax in seen or (seen and "IJK".index(ax) < "IJK".index(seen[-1])):
+                    raise self._err(node, "Axis offsets must be given once, in I, J, K order")
+                if ax not in axes:
+                    raise self._err(node, f"Field '{name}' has no axis {ax}")
+                seen.append(ax)
+                offset[ax] = sh
+        elif any(s is not None for s in shifted):
+            raise self._err(node, "Cannot mix axis offsets and integer offsets")
+        else:
+            values = [self._const(e) for e in elts]
+            if len(values) != len(axes):
+                raise self._err(node, f"Incorrect offset specification detected for field '{name}'. "
+                                      f"Found {values} but the field has dimensions ({', '.join(axes)})")
+            for ax, v in zip(axes, values):
+                if not isinstance(v, numbers.Integral):
+                    raise self._err(node, "Field offsets must be integer constants")
+                offset[ax] = int(v)
+        return offset["I"], offset["J"], offset["K"]
+
+    def visit_Subscript(self, node: ast.Subscript) -> ir.Expr:
+        if not isinstance(node.value, ast.Name):
+            raise self._err(node, "Only fields can be subscripted")
+        name = node.value.id
+        if name not in self.fields and name not in self.temporaries:
+            raise GTScriptSymbolError(f"Unknown field '{name}' in stencil '{self.definition.__name__}'")
+        return ir.FieldAccess(name, self._parse_offset(node, name))
+
+    def visit_UnaryOp(self, node: ast.UnaryOp) -> ir.Expr:
+        op = {ast.USub: "-", ast.UAdd: "+", ast.Not: "not"}.get(type(node.op))
+        if op is None:
+            raise self._err(node, "Unsupported unary operator")
+        return ir.UnaryOp(op, self.visit(node.operand))
+
+    def visit_BinOp(self, node: ast.BinOp) -> ir.Expr:
+        if type(node.op) not in _BIN_OPS:
+            raise self._err(node, f"Unsupported binary operator '{type(node.op).__name__}'")
+        return ir.BinaryOp(_BIN_OPS[type(node.op)], self.visit(node.left), self.visit(node.right))
+
+    def visit_Compare(self, node: ast.Compare) -> ir.Expr:
+        if len(node.ops) != 1 or type(node.ops[0]) not in _CMP_OPS:
+            raise self._err(node, "Only single binary comparisons are supported")
+        return ir.BinaryOp(_CMP_OPS[type(node.ops[0])], self.visit(node.left), self.visit(node.comparators[0]))
+
+    def visit_BoolOp(self, node: ast.BoolOp) -> ir.Expr:
+        op = "and" if isinstance(node.op, ast.And) else "or"
+        values = [self.visit(v) for v in node.values]
+        # right-nested like the reference (gtscript_frontend.py:1558-1571)
+        expr = values[-1]
+        for v in reversed(values[:-1]):
+            expr = ir.BinaryOp(op, v, expr)
+        return expr
+
+    def visit_IfExp(self, node: ast.IfExp) -> ir.Expr:
+        return ir.TernaryOp(self.visit(node.test), self.visit(node.body), self.visit(node.orelse))
+
+    def visit_Call(self, node: ast.Call) -> ir.Expr:
+        name = self._call_name(node)
+        if node.keywords:
+            raise self._err(node, "Keyword arguments are not supported in calls")
+        args = tuple(self.visit(a) for a in node.args)
+        if name in _CAST_FUNCS or name in ("int", "float"):
+            if len(args) != 1:
+                raise self._err(node, f"{name}() takes exactly one argument")
+            dt = _CAST_FUNCS.get(name) or (self.int_dtype if name == "int" else self.float_dtype)
+            return ir.NativeCall(f"cast:{dt.name}", args, dt)
+        if name in _NATIVE_UFUNC:
+            return ir.NativeCall(name, args)
+        raise self._err(node, f"Unsupported call to '{name}'")
+
+
+# ---------------------------------------------------------------------------------------------
+# typing passes
+# ---------------------------------------------------------------------------------------------
+def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
+    """Type every node, then make every dtype transition an explicit Cast."""
+    dtypes: Dict[str, Optional[np.dtype]] = {d.name: d.dtype for d in (*stencil.fields, *stencil.temporaries)}
+    for p in stencil.params:
+        dtypes[p.name] = p.dtype
+
+    def typed(expr: ir.Expr) -> ir.Expr:
+        def fn(e: ir.Expr) -> ir.Expr:
+            if isinstance(e, ir.FieldAccess):
+                dt = dtypes.get(e.name)
+                if dt is None:
+                    raise GTScriptSymbolError(f"Temporary '{e.name}' is read before it is assigned")
+                return ir.FieldAccess(e.name, e.offset, dt)
+            if isinstance(e, (ir.Literal, ir.ScalarAccess, ir.Cast)):
+                return e
+            if isinstance(e, ir.UnaryOp):
+                ufunc = _OP_UFUNC[{"-": "neg", "+": "pos", "not": "not"}[e.op]]
+                (target,) = ufunc_signature(ufunc, (e.expr.dtype,))
+                inner = e.expr if e.expr.dtype == target else ir.Cast(e.expr, target)
+                return ir.UnaryOp(e.op, inner, np.dtype("bool") if e.op == "not" else target)
+            if isinstance(e, ir.BinaryOp):
+                lt, rt = ufunc_signature(_OP_UFUNC[e.op], (e.left.dtype, e.right.dtype))
+                left = e.left if e.left.dtype == lt else ir.Cast(e.left, lt)
+                right = e.right if e.right.dtype == rt else ir.Cast(e.right, rt)
+                if e.op in ir.ARITHMETIC_OPS:
+                    out = _max_dtype(e.left.dtype, e.right.dtype)
+                    if e.op == "/" and _RANK[out] < _RANK[np.dtype("float32")]:
+                        out = lt  # true division of integers computes (and yields) floats
+                else:
+                    out = np.dtype("bool")
+                return ir.BinaryOp(e.op, left, right, out)
+            if isinstance(e, ir.TernaryOp):
+                out = _max_dtype(e.true_expr.dtype, e.false_expr.dtype)
+                t = e.true_expr if e.true_expr.dtype == out else ir.Cast(e.true_expr, out)
+                f = e.false_expr if e.false_expr.dtype == out else ir.Cast(e.false_expr, out)
+                return ir.TernaryOp(e.cond, t, f, out)
+            if isinstance(e, ir.NativeCall):
+                if e.func.startswith("cast:"):
+                    return e
+                arg_dt = tuple(a.dtype for a in e.args)
+                sig = ufunc_signature(_NATIVE_UFUNC[e.func], arg_dt)
+                args = tuple(a if a.dtype == s else ir.Cast(a, s) for a, s in zip(e.args, sig))
+                out = np.dtype("bool") if e.func in ("isfinite", "isinf", "isnan") else _max_dtype(*sig)
+                return ir.NativeCall(e.func, args, out)
+            raise TypeError(e)
+
+        return ir.map_expr(expr, fn)
+
+    new_comps = []
+    for comp in stencil.computations:
+        new_blocks = []
+        for block in comp.blocks:
+            new_body = []
+            for stmt in block.body:
+                value = typed(stmt.value)
+                name = stmt.target.name
+                if dtypes.get(name) is None:
+                    dtypes[name] = value.dtype  # AUTO temporaries: dtype of the first RHS
+                tdt = dtypes[name]
+                if value.dtype != tdt:
+                    value = ir.Cast(value, tdt)
+                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt), value))
+            new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
+        new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
+    temps = tuple(ir.FieldDecl(t.name, dtypes[t.name], t.axes, t.data_dims, False) for t in stencil.temporaries)
+    return ir.Stencil(stencil.name, stencil.fields, stencil.params, temps, tuple(new_comps))
+
+
+def _check_semantics(stencil: ir.Stencil) -> None:
+    api = {f.name for f in stencil.fields}
+    written = {s.target.name for _, _, s in stencil.statements()}
+    for comp, _, stmt in stencil.statements():
+        for e in ir.walk(stmt.value):
+            if not isinstance(e, ir.FieldAccess):
+                continue
+            if e.offset[2] != 0 and e.name not in api and comp.order is ir.LoopOrder.PARALLEL and e.name in written:
+                # temporaries with K offsets in PARALLEL computations are a race in the reference too
+                raise GTScriptSyntaxError(f"Invalid K offset access to temporary '{e.name}' in a PARALLEL computation")
+            # N5: a written API field may not be read with a horizontal offset (gtir_to_oir.py:19-46)
+            if e.name in api and e.name in written and (e.offset[0] != 0 or e.offset[1] != 0):
+                raise ValueError(f"Found non-zero read extent on written fields: {e.name}")
+    for comp, _, stmt in stencil.statements():
+        if comp.order is ir.LoopOrder.PARALLEL:
+            for e in ir.walk(stmt.value):
+                if isinstance(e, ir.FieldAccess) and e.name == stmt.target.name and e.offset[2] != 0:
+                    raise GTScriptSyntaxError(
+                        f"Self-assignment with a K offset to '{e.name}' is not allowed in PARALLEL computations")
+
+
+def parse_stencil(definition, *, externals: Dict[str, Any], dtypes: Dict[Any, Any],
+                  options: gt_definitions.BuildOptions) -> ir.Stencil:
+    """Definition function -> typed, upcast ``ir.Stencil`` (raises on anything outside the subset)."""
+    sig = inspect.signature(definition)
+    for p in sig.parameters.values():
+        if p.kind == inspect.Parameter.VAR_POSITIONAL:
+            raise GTScriptDefinitionError("'*args' tuple parameter is not supported in GTScript definitions")
+        if p.kind == inspect.Parameter.VAR_KEYWORD:
+            raise GTScriptDefinitionError("'**kwargs' dict parameter is not supported in GTScript definitions")
+    annotations = gtscript._resolve_annotations(definition, dtypes)
+    untyped = _Parser(definition, annotations, externals, options).parse()
+    typed = _resolve_and_upcast(untyped)
+    _check_semantics(typed)
+    return typed

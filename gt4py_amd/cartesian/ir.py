@@ -1,0 +1,227 @@
+"""A small typed stencil IR: what the minimal GTScript recogniser produces and what the ``hip:mi300``
+backend pattern-matches against its hand-written kernel families.
+
+This is deliberately NOT the reference's GTIR/OIR tower (SURVEY.md section 2 rows 9-11 are out of scope).
+It keeps exactly the information that decides *values* and *shapes* on the hot path:
+
+* computations in program order, each with an iteration order and K intervals
+  (gtscript_frontend.py:1099-1167 of the reference),
+* assignments of expression trees exactly as Python parses them (no re-association),
+* per-node dtypes after the reference's promotion rules (gtir_upcaster.py:43-143) with explicit
+  ``Cast`` nodes.
+"""
+
+from __future__ import annotations
+
+import enum
+from dataclasses import dataclass, field, replace
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+
+
+class LoopOrder(str, enum.Enum):
+    PARALLEL = "parallel"
+    FORWARD = "forward"
+    BACKWARD = "backward"
+
+
+class Level(str, enum.Enum):
+    START = "start"
+    END = "end"
+
+
+@dataclass(frozen=True)
+class AxisBound:
+    level: Level
+    offset: int = 0
+
+    def resolve(self, size: int) -> int:
+        return self.offset if self.level is Level.START else size + self.offset
+
+
+@dataclass(frozen=True)
+class Interval:
+    start: AxisBound
+    end: AxisBound
+
+    @classmethod
+    def full(cls) -> "Interval":
+        return cls(AxisBound(Level.START, 0), AxisBound(Level.END, 0))
+
+    def range(self, size: int) -> Tuple[int, int]:
+        return self.start.resolve(size), self.end.resolve(size)
+
+
+# ---- expressions -------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Expr:
+    pass
+
+
+@dataclass(frozen=True)
+class Literal(Expr):
+    value: Union[bool, int, float]
+    dtype: Optional[np.dtype]
+
+
+@dataclass(frozen=True)
+class FieldAccess(Expr):
+    name: str
+    offset: Tuple[int, int, int]
+    dtype: Optional[np.dtype] = None
+
+
+@dataclass(frozen=True)
+class ScalarAccess(Expr):
+    name: str
+    dtype: Optional[np.dtype] = None
+
+
+@dataclass(frozen=True)
+class UnaryOp(Expr):
+    op: str  # "-", "+", "not"
+    expr: Expr
+    dtype: Optional[np.dtype] = None
+
+
+@dataclass(frozen=True)
+class BinaryOp(Expr):
+    op: str  # + - * / % ** > < >= <= == != and or
+    left: Expr
+    right: Expr
+    dtype: Optional[np.dtype] = None
+
+
+@dataclass(frozen=True)
+class TernaryOp(Expr):
+    cond: Expr
+    true_expr: Expr
+    false_expr: Expr
+    dtype: Optional[np.dtype] = None
+
+
+@dataclass(frozen=True)
+class Cast(Expr):
+    expr: Expr
+    dtype: np.dtype
+
+
+@dataclass(frozen=True)
+class NativeCall(Expr):
+    func: str
+    args: Tuple[Expr, ...]
+    dtype: Optional[np.dtype] = None
+
+
+ARITHMETIC_OPS = ("+", "-", "*", "/", "%", "**")
+COMPARISON_OPS = (">", "<", ">=", "<=", "==", "!=")
+LOGICAL_OPS = ("and", "or")
+
+
+# ---- statements --------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Assign:
+    target: FieldAccess
+    value: Expr
+
+
+@dataclass(frozen=True)
+class IntervalBlock:
+    interval: Interval
+    body: Tuple[Assign, ...]
+
+
+@dataclass(frozen=True)
+class Computation:
+    order: LoopOrder
+    blocks: Tuple[IntervalBlock, ...]
+
+
+@dataclass(frozen=True)
+class FieldDecl:
+    name: str
+    dtype: Optional[np.dtype]  # None = AUTO (temporary not yet typed)
+    axes: Tuple[str, ...] = ("I", "J", "K")
+    data_dims: Tuple[int, ...] = ()
+    is_api: bool = True
+
+
+@dataclass(frozen=True)
+class ScalarDecl:
+    name: str
+    dtype: np.dtype
+
+
+@dataclass(frozen=True)
+class Stencil:
+    name: str
+    fields: Tuple[FieldDecl, ...]  # API fields in signature order
+    params: Tuple[ScalarDecl, ...]  # scalar parameters in signature order
+    temporaries: Tuple[FieldDecl, ...]
+    computations: Tuple[Computation, ...]
+
+    def decl(self, name: str) -> Union[FieldDecl, ScalarDecl]:
+        for d in (*self.fields, *self.temporaries, *self.params):
+            if d.name == name:
+                return d
+        raise KeyError(name)
+
+    def statements(self):
+        """(computation, block, assign) triples in program order."""
+        for comp in self.computations:
+            for block in comp.blocks:
+                for stmt in block.body:
+                    yield comp, block, stmt
+
+
+def walk(expr: Expr):
+    """Pre-order traversal of an expression tree."""
+    yield expr
+    if isinstance(expr, (UnaryOp, Cast)):
+        yield from walk(expr.expr)
+    elif isinstance(expr, BinaryOp):
+        yield from walk(expr.left)
+        yield from walk(expr.right)
+    elif isinstance(expr, TernaryOp):
+        yield from walk(expr.cond)
+        yield from walk(expr.true_expr)
+        yield from walk(expr.false_expr)
+    elif isinstance(expr, NativeCall):
+        for a in expr.args:
+            yield from walk(a)
+
+
+def map_expr(expr: Expr, fn):
+    """Rebuild ``expr`` bottom-up, applying ``fn`` to every rebuilt node."""
+    if isinstance(expr, (UnaryOp, Cast)):
+        expr = replace(expr, expr=map_expr(expr.expr, fn))
+    elif isinstance(expr, BinaryOp):
+        expr = replace(expr, left=map_expr(expr.left, fn), right=map_expr(expr.right, fn))
+    elif isinstance(expr, TernaryOp):
+        expr = replace(expr, cond=map_expr(expr.cond, fn), true_expr=map_expr(expr.true_expr, fn),
+                       false_expr=map_expr(expr.false_expr, fn))
+    elif isinstance(expr, NativeCall):
+        expr = replace(expr, args=tuple(map_expr(a, fn) for a in expr.args))
+    return fn(expr)
+
+
+def fmt(expr: Expr) -> str:
+    """Readable one-line rendering (used in error messages and ``StencilObject.source``)."""
+    if isinstance(expr, Literal):
+        return f"{expr.dtype}({expr.value!r})" if expr.dtype is not None else repr(expr.value)
+    if isinstance(expr, FieldAccess):
+        return f"{expr.name}[{expr.offset[0]},{expr.offset[1]},{expr.offset[2]}]"
+    if isinstance(expr, ScalarAccess):
+        return expr.name
+    if isinstance(expr, UnaryOp):
+        return f"({expr.op}{fmt(expr.expr)})"
+    if isinstance(expr, BinaryOp):
+        return f"({fmt(expr.left)} {expr.op} {fmt(expr.right)})"
+    if isinstance(expr, TernaryOp):
+        return f"({fmt(expr.true_expr)} if {fmt(expr.cond)} else {fmt(expr.false_expr)})"
+    if isinstance(expr, Cast):
+        return f"{expr.dtype}({fmt(expr.expr)})"
+    if isinstance(expr, NativeCall):
+        return f"{expr.func}({', '.join(fmt(a) for a in expr.args)})"
+    return repr(expr)

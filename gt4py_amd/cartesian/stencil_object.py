@@ -1,0 +1,415 @@
+"""The run-time stencil callable: argument normalisation, validation, domain/origin cache, dispatch.
+
+Behavioural counterpart of /root/reference/src/gt4py/cartesian/stencil_object.py (``StencilObject``
+:154, ``_call_run`` :531-612, ``_validate_args`` :342-494, ``_normalize_origins`` :497-529,
+``_get_max_domain`` :296-340, ``FrozenStencil`` :103-136) and of the per-stencil wrapper the
+reference renders from backend/templates/stencil_module.py.in (``__call__`` :91-158, ``run``
+:160-169).  Same names, keyword arguments, exception classes and exec_info keys, so the reference's
+call-interface tests read unchanged against it.
+"""
+
+from __future__ import annotations
+
+import abc
+import collections.abc
+import numbers
+import sys
+import time
+import warnings
+from dataclasses import dataclass
+from pickle import dumps
+from typing import Any, Callable, ClassVar, Dict, Optional, Tuple, Union
+
+import numpy as np
+
+from . import backend as gt_backend
+from .definitions import (
+    AccessKind,
+    DomainInfo,
+    FieldInfo,
+    Index,
+    ParameterInfo,
+    Shape,
+    filter_mask,
+    interpolate_mask,
+)
+from ..storage import device_array as _device
+
+OriginType = Union[Tuple[int, ...], Dict[str, Tuple[int, ...]]]
+
+
+@dataclass
+class ArgsInfo:
+    device: str
+    array: Any
+    original_object: Any = None
+    origin: Optional[Tuple[int, ...]] = None
+    dimensions: Optional[Tuple[str, ...]] = None
+
+
+def _as_backend_array(arg, device: str):
+    """``storage_utils.asarray(arg, device=...)`` of the reference (storage/cartesian/utils.py:176-215)
+    without cupy: host backends take anything numpy can view, GPU backends take device buffers."""
+    if hasattr(arg, "ndarray") and not isinstance(arg, (np.ndarray, _device.DeviceArray)):
+        arg = arg.ndarray  # gt4py.next Field
+    if device == "cpu":
+        if isinstance(arg, _device.DeviceArray):
+            raise TypeError("a device array was passed to a CPU backend")
+        return np.asarray(arg)
+    if device == "gpu":
+        return _device.as_device_array(arg)
+    raise ValueError(f"Invalid device: {device!s}")
+
+
+def _extract_array_infos(field_args: Dict[str, Any], device: str) -> Dict[str, Optional[ArgsInfo]]:
+    infos: Dict[str, Optional[ArgsInfo]] = {}
+    for name, arg in field_args.items():
+        if arg is None:
+            infos[name] = None
+            continue
+        array = _as_backend_array(arg, device)
+        dims = getattr(arg, "__gt_dims__", None)
+        if dims is not None:
+            dims = tuple(str(d) for d in dims)
+            # bring the axes into canonical I, J, K, data0, data1, ... order (stencil_object.py:79-85)
+            canonical = [d for d in "IJK" if d in dims]
+            canonical += [str(d) for d in sorted(int(d) for d in dims if d.isdigit())]
+            array = array.transpose([dims.index(d) for d in canonical])
+            dims = tuple(canonical)
+        origin = getattr(arg, "__gt_origin__", None)
+        infos[name] = ArgsInfo(device=device, array=array, original_object=arg, dimensions=dims,
+                               origin=None if origin is None else tuple(int(o) for o in origin))
+    return infos
+
+
+def _cache_key(infos, parameter_args, domain, origin) -> int:
+    field_data = tuple((n, a.array.shape, a.origin or (0, 0, 0)) for n, a in infos.items() if a is not None)
+    return hash((field_data, *parameter_args.keys(), dumps(domain), dumps(origin)))
+
+
+@dataclass(frozen=True)
+class FrozenStencil:
+    """Stencil with pre-computed domain and per-field origins: no checks at call time."""
+
+    stencil_object: "StencilObject"
+    origin: Dict[str, Tuple[int, ...]]
+    domain: Tuple[int, ...]
+
+    def __post_init__(self):
+        for name, info in self.stencil_object.field_info.items():
+            if name not in self.origin or len(self.origin[name]) != info.ndim:
+                raise ValueError(
+                    f"'{name}' origin {self.origin.get(name)} is not a {info.ndim}-dimensional integer tuple"
+                )
+
+    def __call__(self, **kwargs) -> None:
+        assert "origin" not in kwargs and "domain" not in kwargs
+        exec_info = kwargs.get("exec_info")
+        if exec_info is not None:
+            exec_info["call_run_start_time"] = time.perf_counter()
+        so = self.stencil_object
+        fields = {name: kwargs[name] for name in so.field_info}
+        params = {name: kwargs[name] for name in so.parameter_info}
+        so.run(_domain_=self.domain, _origin_=self.origin, exec_info=exec_info, **fields, **params)
+        if exec_info is not None:
+            exec_info["call_run_end_time"] = time.perf_counter()
+
+
+class StencilObject(abc.ABC):
+    """Singleton, immutable callable generated per (definition, externals, options, backend)."""
+
+    _gt_id_: str
+    definition_func: Callable[..., Any]
+    _domain_origin_cache: ClassVar[Dict[int, Tuple[Tuple[int, ...], Dict[str, Tuple[int, ...]]]]]
+
+    # class attributes filled by the backend's make_stencil_class()
+    _gt_backend_: ClassVar[str]
+    _gt_source_: ClassVar[str]
+    _gt_domain_info_: ClassVar[DomainInfo]
+    _gt_field_info_: ClassVar[Dict[str, FieldInfo]]
+    _gt_parameter_info_: ClassVar[Dict[str, ParameterInfo]]
+    _gt_constants_: ClassVar[Dict[str, Any]]
+    _gt_options_: ClassVar[Dict[str, Any]]
+    _gt_signature_: ClassVar[Any]  # inspect.Signature of the definition
+
+    def __new__(cls, *args, **kwargs):
+        if getattr(cls, "_instance", None) is None:
+            cls._instance = object.__new__(cls)
+            cls._domain_origin_cache = {}
+        return cls._instance
+
+    def __setattr__(self, key, value) -> None:
+        raise AttributeError("Attempting a modification of an attribute in a frozen class")
+
+    def __delattr__(self, item) -> None:
+        raise AttributeError("Attempting a deletion of an attribute in a frozen class")
+
+    def __eq__(self, other) -> bool:
+        return type(self) is type(other)
+
+    def __hash__(self) -> int:
+        return int.from_bytes(type(self)._gt_id_.encode(), byteorder="little")
+
+    def __deepcopy__(self, memodict=None):
+        return self
+
+    def __str__(self) -> str:
+        return (
+            f"\n<StencilObject: {self.options['module'] + '.' + self.options['name']}> "
+            f'[backend="{self.backend}"]\n'
+            f"    - I/O fields: {self.field_info}\n"
+            f"    - Parameters: {self.parameter_info}\n"
+            f"    - Constants: {self.constants}\n"
+            f"    - Version: {self._gt_id_}\n"
+            f"    - Definition ({self.definition_func}):\n{self.source}\n"
+        )
+
+    # ---- metadata (stencil_module.py.in:64-89) ---------------------------------------------
+    @property
+    def backend(self) -> str:
+        return type(self)._gt_backend_
+
+    @property
+    def source(self) -> str:
+        return type(self)._gt_source_
+
+    @property
+    def domain_info(self) -> DomainInfo:
+        return type(self)._gt_domain_info_
+
+    @property
+    def field_info(self) -> Dict[str, FieldInfo]:
+        return type(self)._gt_field_info_
+
+    @property
+    def parameter_info(self) -> Dict[str, ParameterInfo]:
+        return type(self)._gt_parameter_info_
+
+    @property
+    def constants(self) -> Dict[str, Any]:
+        return type(self)._gt_constants_
+
+    @property
+    def options(self) -> Dict[str, Any]:
+        return type(self)._gt_options_
+
+    # ---- the generated wrapper: __call__ ---------------------------------------------------
+    def __call__(self, *args, domain=None, origin=None, validate_args=True, exec_info=None, **kwargs) -> None:
+        if exec_info is not None:
+            exec_info["call_start_time"] = time.perf_counter()
+        sig = type(self)._gt_signature_
+        try:
+            bound = sig.bind(*args, **kwargs)
+        except TypeError as ex:
+            raise TypeError(f"{self.options['name']}: {ex}") from None
+        bound.apply_defaults()
+        field_args = {name: bound.arguments[name] for name in self.field_info}
+        parameter_args = {name: bound.arguments[name] for name in self.parameter_info}
+        self._call_run(field_args=field_args, parameter_args=parameter_args, domain=domain, origin=origin,
+                       validate_args=validate_args, exec_info=exec_info)
+        if exec_info is not None:
+            exec_info["call_end_time"] = time.perf_counter()
+            if exec_info.get("__aggregate_data", False):
+                self._aggregate(exec_info)
+
+    def _aggregate(self, exec_info: Dict[str, Any]) -> None:
+        """Per-class cumulative counters (stencil_module.py.in:125-158)."""
+        stats = exec_info.setdefault(type(self).__name__, {})
+        call_time = exec_info["call_end_time"] - exec_info["call_start_time"]
+        run_time = exec_info["run_end_time"] - exec_info["run_start_time"]
+        stats["ncalls"] = stats.get("ncalls", 0) + 1
+        stats["call_time"] = call_time
+        stats["total_call_time"] = stats.get("total_call_time", 0.0) + call_time
+        stats["run_time"] = run_time
+        stats["total_run_time"] = stats.get("total_run_time", 0.0) + run_time
+        if "run_cpp_end_time" in exec_info:
+            cpp = exec_info["run_cpp_end_time"] - exec_info["run_cpp_start_time"]
+            stats["run_cpp_time"] = cpp
+            stats["total_run_cpp_time"] = stats.get("total_run_cpp_time", 0.0) + cpp
+
+    # ---- the generated wrapper: run --------------------------------------------------------
+    def run(self, _domain_, _origin_, exec_info, **fields_and_params) -> None:
+        if exec_info is not None:
+            exec_info["domain"] = _domain_
+            exec_info["origin"] = _origin_
+            exec_info["run_start_time"] = time.perf_counter()
+        self._run_implementation(_domain_, _origin_, exec_info, fields_and_params)
+        if exec_info is not None:
+            exec_info["run_end_time"] = time.perf_counter()
+
+    @abc.abstractmethod
+    def _run_implementation(self, domain, origin, exec_info, arguments: Dict[str, Any]) -> None:
+        """Backend-specific execution (the ``{{ implementation }}`` slot of the reference template)."""
+
+    # ---- origin / domain handling ----------------------------------------------------------
+    @staticmethod
+    def _make_origin_dict(origin) -> Dict[str, Tuple[int, ...]]:
+        try:
+            if isinstance(origin, dict):
+                return {str(k): v for k, v in origin.items()}
+            if origin is None:
+                return {}
+            if isinstance(origin, collections.abc.Iterable):
+                return {"_all_": Index.from_value(origin)}
+            if isinstance(origin, numbers.Integral):
+                return {"_all_": Index.from_k(int(origin))}
+        except Exception:
+            pass
+        raise ValueError(f"Invalid 'origin' value ({origin})")
+
+    @staticmethod
+    def _get_max_domain(array_infos, domain_info: DomainInfo, field_infos: Dict[str, FieldInfo],
+                        origin: Dict[str, Tuple[int, ...]], *, squeeze: bool = True) -> Shape:
+        """Largest domain every accessed field can serve: min over fields of
+        ``shape - (origin + upper_boundary)`` (stencil_object.py:296-340)."""
+        big = sys.maxsize
+        max_domain = Shape([big] * domain_info.ndim)
+        for name, finfo in field_infos.items():
+            if finfo.access == AccessKind.NONE:
+                continue
+            info = array_infos.get(name, None)
+            assert info is not None, f"Invalid value for '{name}' field."
+            mask = finfo.domain_mask
+            upper = filter_mask(finfo.boundary.upper_indices, mask)
+            f_origin = Index.from_value(origin[name])
+            f_domain = tuple(info.array.shape[i] - (f_origin[i] + upper[i]) for i in range(finfo.domain_ndim))
+            max_domain &= Shape.from_mask(f_domain, mask, default=big)
+        if squeeze:
+            return Shape([d if d != big else 1 for d in max_domain])
+        return max_domain
+
+    @staticmethod
+    def _normalize_origins(array_infos, field_infos: Dict[str, FieldInfo], origin) -> Dict[str, Tuple[int, ...]]:
+        """Explicit per-field entry > '_all_' > the array's ``__gt_origin__`` > zeros
+        (stencil_object.py:497-529).  The caller's dict is extended, never rewritten."""
+        origin = StencilObject._make_origin_dict(origin)
+        all_origin = origin.get("_all_", None)
+        for name, finfo in field_infos.items():
+            assert name in array_infos, f"Missing value for '{name}' field."
+            f_origin = origin.get(name, None)
+            if f_origin is not None:
+                if len(f_origin) != finfo.ndim:
+                    assert len(f_origin) == finfo.domain_ndim, (
+                        f"Invalid origin specification ({f_origin}) for '{name}' field.")
+                    origin[name] = (*f_origin, *((0,) * len(finfo.data_dims)))
+            elif all_origin is not None:
+                origin[name] = (*filter_mask(all_origin, finfo.domain_mask), *((0,) * len(finfo.data_dims)))
+            elif getattr(array_infos.get(name), "origin", None) is not None:
+                origin[name] = array_infos[name].origin
+            else:
+                origin[name] = (0,) * finfo.ndim
+        return origin
+
+    def _validate_args(self, arg_infos, param_args, domain, origin) -> None:
+        """Raise ValueError / TypeError for inconsistent calls (stencil_object.py:342-494)."""
+        assert isinstance(arg_infos, dict) and isinstance(param_args, dict)
+        ndim = self.domain_info.ndim
+        if len(domain) != ndim:
+            raise ValueError(f"Invalid 'domain' value '{domain}'")
+        try:
+            domain = Shape(domain)
+        except Exception as ex:
+            raise ValueError(f"Invalid 'domain' value ({domain})") from ex
+        if not domain > Shape.zeros(ndim):
+            raise ValueError(f"Compute domain contains zero sizes '{domain}')")
+        if not domain <= self._get_max_domain(arg_infos, self.domain_info, self.field_info, origin, squeeze=False):
+            offending = []
+            for name, info in self.field_info.items():
+                used = self._get_max_domain(arg_infos, self.domain_info, {name: info}, origin, squeeze=False)
+                if used < domain:
+                    offending.append((name, used))
+            raise ValueError(
+                f"Compute domain too large for stencil {self.options['name']}: \n"
+                f"  Stencil domain is {domain} but field indexation leads to read outside of bounds.\n"
+                f"  Check region/horizontal offsets or interval/vertical offsets, or stencil domain.\n"
+                f"  Offending fields (name, size with offset removed): {offending}"
+            )
+        if domain[2] < self.domain_info.min_sequential_axis_size:
+            raise ValueError(
+                f"Compute domain too small. Sequential axis is {domain[2]}, but must be at least "
+                f"{self.domain_info.min_sequential_axis_size}."
+            )
+        backend_cls = gt_backend.from_name(self.backend)
+        for name, finfo in self.field_info.items():
+            if finfo.access == AccessKind.NONE:
+                continue
+            if name not in arg_infos:
+                raise ValueError(f"Missing value for '{name}' field.")
+            arg = arg_infos[name]
+            assert arg is not None
+            dims = tuple(list(finfo.axes) + [str(d) for d in range(len(finfo.data_dims))])
+            if not backend_cls.storage_info["is_optimal_layout"](arg.array, dims):
+                warnings.warn(
+                    f"The layout of the field '{name}' is not recommended for this backend."
+                    f"This may lead to performance degradation. Please consider using the"
+                    f"provided allocators in `gt4py.storage`.",
+                    stacklevel=2,
+                )
+            if not arg.array.dtype == finfo.dtype:
+                raise TypeError(f"The dtype of field '{name}' is '{arg.array.dtype}' instead of '{finfo.dtype}'")
+            mask = finfo.domain_mask
+            f_ndim = finfo.domain_ndim
+            f_origin = Index.from_mask(origin[name], mask[:ndim])
+            if arg.array.ndim != f_ndim + len(finfo.data_dims):
+                raise ValueError(
+                    f"Storage for '{name}' has {arg.array.ndim} dimensions but the API signature "
+                    f"expects {f_ndim + len(finfo.data_dims)} ('{finfo.axes}[{finfo.data_dims}]')"
+                )
+            if arg.dimensions is not None and dims != arg.dimensions:
+                raise ValueError(
+                    f"Storage for '{name}' has dimensions '{arg.dimensions}' but the API signature "
+                    f"expects '[{', '.join(finfo.axes)}]'"
+                    + (f" and {len(finfo.data_dims)}" if finfo.data_dims else "")
+                )
+            if tuple(arg.array.shape[f_ndim:]) != tuple(finfo.data_dims):
+                raise ValueError(
+                    f"Field '{name}' expects data dimensions {finfo.data_dims} but got {arg.array.shape[f_ndim:]}"
+                )
+            lower = filter_mask(finfo.boundary.lower_indices, mask)
+            upper = filter_mask(finfo.boundary.upper_indices, mask)
+            min_origin = Index(interpolate_mask(lower, mask, 0))
+            if f_origin < min_origin:
+                raise ValueError(
+                    f"Origin for field {name} too small. Must be at least {min_origin}, is {f_origin}")
+            spatial_domain = filter_mask(domain, mask)
+            min_shape = tuple(lb + d + ub for lb, d, ub in zip(lower, spatial_domain, upper))
+            if min_shape > tuple(arg.array.shape):  # plain tuple comparison, as in the reference (:481)
+                raise ValueError(
+                    f"Shape of field {name} is {arg.array.shape} but must be at least {min_shape} "
+                    f"for given domain and origin.")
+        for name, pinfo in self.parameter_info.items():
+            if pinfo.access == AccessKind.NONE:
+                continue
+            if name not in param_args:
+                raise ValueError(f"Missing value for '{name}' parameter.")
+            value = param_args[name]
+            if np.dtype(type(value)) != pinfo.dtype:
+                raise TypeError(f"The type of parameter '{name}' is '{type(value)}' instead of '{pinfo.dtype}'")
+
+    def _call_run(self, field_args, parameter_args, domain, origin, *, validate_args=True, exec_info=None) -> None:
+        if exec_info is not None:
+            exec_info["call_run_start_time"] = time.perf_counter()
+        device = gt_backend.from_name(self.backend).storage_info["device"]
+        array_infos = _extract_array_infos(field_args, device)
+        key = _cache_key(array_infos, parameter_args, domain, origin)
+        cache = type(self)._domain_origin_cache
+        if key not in cache:
+            origin = self._normalize_origins(array_infos, self.field_info, origin)
+            if domain is None:
+                domain = self._get_max_domain(array_infos, self.domain_info, self.field_info, origin)
+            if validate_args:
+                self._validate_args(array_infos, parameter_args, domain, origin)
+            cache[key] = (domain, origin)
+        else:
+            domain, origin = cache[key]
+        arrays = {name: (info.array if info is not None else None) for name, info in array_infos.items()}
+        self.run(_domain_=domain, _origin_=origin, exec_info=exec_info, **arrays, **parameter_args)
+        if exec_info is not None:
+            exec_info["call_run_end_time"] = time.perf_counter()
+
+    def freeze(self, *, origin: Dict[str, Tuple[int, ...]], domain: Tuple[int, ...]) -> FrozenStencil:
+        """Fixed-origin/domain wrapper that skips all per-call checks (stencil_object.py:614-643)."""
+        return FrozenStencil(self, origin, domain)
+
+    def clean_call_args_cache(self) -> None:
+        type(self)._domain_origin_cache.clear()

@@ -1,0 +1,191 @@
+"""ORACLE (test infrastructure, NOT product code): a ``numpy`` backend for gt4py_amd's stencil IR.
+
+Generic restatement of what the reference's numpy backend executes
+(/root/reference/src/gt4py/cartesian/gtc/numpy/npir_codegen.py:331-367 module skeleton, :281-318
+vertical passes and horizontal blocks, :205-225 assignments / np.where, :243-248 sequential K loops;
+/root/reference/src/gt4py/cartesian/utils/field.py:15-74 origin-shifting ``Field`` shim;
+/root/reference/src/gt4py/cartesian/gtc/numpy/oir_to_npir.py:42-56 temporaries).
+
+Importing this module REGISTERS backend ``"numpy"`` with ``gt4py_amd.cartesian.backend`` so that the
+CPU tests can run the reference's call-interface tests and BASELINE config[0] ("5-point Laplacian via
+@gtscript.stencil on backend=numpy") without a GPU.  It interprets the product's parsed IR, so it
+shares the product's frontend; the hand-written restatements in ``ref_numpy.py`` are the independent
+check (tests/test_oracle.py compares the two).  Nothing under ``gt4py_amd/`` imports this file.
+"""
+
+from __future__ import annotations
+
+import inspect
+from typing import Any, Dict, Tuple
+
+import numpy as np
+
+from gt4py_amd.cartesian import analysis, ir
+from gt4py_amd.cartesian.backend import base
+from gt4py_amd.cartesian.stencil_object import StencilObject
+from gt4py_amd.storage import layout as storage_layout
+
+_BIN = {
+    "+": np.add, "-": np.subtract, "*": np.multiply, "/": np.true_divide, "%": np.remainder, "**": np.power,
+    ">": np.greater, "<": np.less, ">=": np.greater_equal, "<=": np.less_equal, "==": np.equal,
+    "!=": np.not_equal, "and": np.logical_and, "or": np.logical_or,
+}
+_UN = {"-": np.negative, "+": np.positive, "not": np.logical_not}
+_NATIVE = {
+    "abs": np.abs, "min": np.minimum, "max": np.maximum, "mod": np.remainder, "sin": np.sin, "cos": np.cos,
+    "tan": np.tan, "asin": np.arcsin, "acos": np.arccos, "atan": np.arctan, "sinh": np.sinh, "cosh": np.cosh,
+    "tanh": np.tanh, "asinh": np.arcsinh, "acosh": np.arccosh, "atanh": np.arctanh, "sqrt": np.sqrt,
+    "exp": np.exp, "log": np.log, "log10": np.log10, "cbrt": np.cbrt, "isfinite": np.isfinite,
+    "isinf": np.isinf, "isnan": np.isnan, "floor": np.floor, "ceil": np.ceil, "trunc": np.trunc,
+}
+
+
+class _FieldShim:
+    """Array + per-axis origin; missing cartesian axes broadcast (utils/field.py:15-74)."""
+
+    def __init__(self, array: np.ndarray, origin: Tuple[int, ...], axes: Tuple[str, ...]):
+        mask = [a in axes for a in "IJK"]
+        full_origin, it = [], iter(origin)
+        index = []
+        for present in mask:
+            if present:
+                full_origin.append(int(next(it)))
+                index.append(slice(None))
+            else:
+                full_origin.append(0)
+                index.append(np.newaxis)
+        self.array = array[tuple(index)] if not all(mask) else array
+        self.origin = tuple(full_origin)
+        self.mask = mask
+
+    def window(self, lo, hi, offset, krange):
+        """View over [lo, hi) per horizontal axis (relative to the origin), shifted by offset."""
+        idx = []
+        for ax in range(2):
+            if self.mask[ax]:
+                a = self.origin[ax] + lo[ax] + offset[ax]
+                b = self.origin[ax] + hi[ax] + offset[ax]
+                assert a >= 0 and b <= self.array.shape[ax], "numpy oracle: access outside of the array"
+                idx.append(slice(a, b))
+            else:
+                idx.append(slice(None))
+        if self.mask[2]:
+            a = self.origin[2] + krange[0] + offset[2]
+            b = self.origin[2] + krange[1] + offset[2]
+            assert a >= 0 and b <= self.array.shape[2], "numpy oracle: K access outside of the array"
+            idx.append(slice(a, b))
+        else:
+            idx.append(slice(None))
+        return self.array[tuple(idx)]
+
+
+def _evaluate(expr: ir.Expr, env, lo, hi, krange):
+    def ev(e):
+        if isinstance(e, ir.Literal):
+            return np.dtype(e.dtype).type(e.value)
+        if isinstance(e, ir.FieldAccess):
+            return env[e.name].window(lo, hi, e.offset, krange)
+        if isinstance(e, ir.ScalarAccess):
+            return env[e.name]
+        if isinstance(e, ir.Cast):
+            v = ev(e.expr)
+            return v.astype(e.dtype) if isinstance(v, np.ndarray) else np.dtype(e.dtype).type(v)
+        if isinstance(e, ir.UnaryOp):
+            return _UN[e.op](ev(e.expr))
+        if isinstance(e, ir.BinaryOp):
+            return _BIN[e.op](ev(e.left), ev(e.right))
+        if isinstance(e, ir.TernaryOp):
+            return np.where(ev(e.cond), ev(e.true_expr), ev(e.false_expr))
+        if isinstance(e, ir.NativeCall):
+            if e.func.startswith("cast:"):
+                v = ev(e.args[0])
+                return v.astype(e.dtype) if isinstance(v, np.ndarray) else np.dtype(e.dtype).type(v)
+            return _NATIVE[e.func](*[ev(a) for a in e.args])
+        raise TypeError(e)
+
+    return ev(expr)
+
+
+def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origin, arrays: Dict[str, Any],
+                params: Dict[str, Any]) -> None:
+    dI, dJ, dK = (int(d) for d in domain)
+    env: Dict[str, Any] = {}
+    for decl in stencil.fields:
+        if arrays.get(decl.name) is not None:
+            env[decl.name] = _FieldShim(arrays[decl.name], tuple(origin[decl.name])[: len(decl.axes)], decl.axes)
+    for decl in stencil.temporaries:
+        (ilo, ihi), (jlo, jhi) = extents.fields.get(decl.name, analysis.ZERO_EXTENT)
+        shape = (dI + (ihi - ilo), dJ + (jhi - jlo), dK)
+        env[decl.name] = _FieldShim(np.empty(shape, dtype=decl.dtype), (-ilo, -jlo, 0), ("I", "J", "K"))
+    for p in stencil.params:
+        # a missing (None) parameter stays None: using it raises TypeError inside numpy, exactly what
+        # the reference's generated code does when validation was skipped by the call cache
+        env[p.name] = None if params.get(p.name) is None else np.dtype(p.dtype).type(params[p.name])
+
+    stmt_blocks = iter(extents.blocks)
+    with np.errstate(divide="ignore", over="ignore", under="ignore", invalid="ignore"):
+        for comp in stencil.computations:
+            for block in comp.blocks:
+                k0, k1 = block.interval.range(dK)
+                plan = [(stmt, next(stmt_blocks)) for stmt in block.body]
+
+                def execute(krange):
+                    for stmt, ((ilo, ihi), (jlo, jhi)) in plan:
+                        lo, hi = (ilo, jlo), (dI + ihi, dJ + jhi)
+                        value = _evaluate(stmt.value, env, lo, hi, krange)
+                        env[stmt.target.name].window(lo, hi, stmt.target.offset, krange)[...] = value
+
+                if comp.order is ir.LoopOrder.PARALLEL:
+                    if k1 > k0:
+                        execute((k0, k1))
+                elif comp.order is ir.LoopOrder.FORWARD:
+                    for k in range(k0, k1):
+                        execute((k, k + 1))
+                else:
+                    for k in range(k1 - 1, k0 - 1, -1):
+                        execute((k, k + 1))
+
+
+class NumpyOracleStencilObject(StencilObject):
+    def _run_implementation(self, domain, origin, exec_info, arguments):
+        cls = type(self)
+        arrays = {n: arguments.get(n) for n in cls._gt_field_info_}
+        params = {n: arguments.get(n) for n in cls._gt_parameter_info_}
+        run_stencil(cls._oracle_ir_, cls._oracle_extents_, domain, origin, arrays, params)
+
+
+class NumpyOracleBackend(base.BaseBackend):
+    name = "numpy"
+    options = {"ignore_np_errstate": {"versioning": True, "type": bool}}
+    storage_info = storage_layout.from_name("numpy")
+    languages = {"computation": "python", "bindings": ["python"]}
+
+    def make_stencil_class(self):
+        b = self.builder
+        sig = inspect.signature(b.definition)
+        sig = sig.replace(parameters=[p.replace(annotation=inspect.Parameter.empty) for p in sig.parameters.values()])
+        attrs = {
+            "_gt_id_": b.stencil_id,
+            "definition_func": staticmethod(b.definition),
+            "_gt_backend_": self.name,
+            "_gt_source_": b.source,
+            "_gt_domain_info_": b.args_data.domain_info,
+            "_gt_field_info_": b.args_data.field_info,
+            "_gt_parameter_info_": b.args_data.parameter_info,
+            "_gt_constants_": dict(b.externals),
+            "_gt_options_": b.options.as_dict(),
+            "_gt_signature_": sig,
+            "_oracle_ir_": b.stencil_ir,
+            "_oracle_extents_": b.args_data.extents,
+            "__module__": b.options.module,
+        }
+        return type(b.class_name, (NumpyOracleStencilObject,), attrs)
+
+
+def register() -> None:
+    """Register the oracle as backend "numpy" (idempotent)."""
+    if "numpy" not in base.REGISTRY:
+        base.register(NumpyOracleBackend)
+
+
+register()

@@ -1,0 +1,172 @@
+"""N > 1 path on the CPU: decomposition geometry, and a world_size-2 gloo run of
+halo exchange + interior/strip execution that must reproduce the single-domain oracle bit-exactly.
+
+On the GPU the same ``HaloExchanger`` runs with the HIP pack kernels and the RCCL backend; here the
+transport is gloo on CPU tensors, the packer is a torch-slicing stand-in defined in this file, and
+the compute is the oracle (tests may use it).
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gt4py_amd.distributed import Decomposition, HaloExchanger, choose_process_grid, scatter_global
+from oracle import ref_numpy as R
+
+
+class TorchSlicePacker:
+    """CPU stand-in for the HIP pack kernels: dense buffer is I-fastest, then J, then K."""
+
+    @staticmethod
+    def _box(t, lo, ext):
+        return t[lo[0]:lo[0] + ext[0], lo[1]:lo[1] + ext[1], lo[2]:lo[2] + ext[2]]
+
+    def pack(self, tensor, lo, ext, buffer):
+        buffer.copy_(self._box(tensor, lo, ext).permute(2, 1, 0).reshape(-1))
+
+    def unpack(self, tensor, lo, ext, buffer):
+        self._box(tensor, lo, ext).copy_(buffer.reshape(ext[2], ext[1], ext[0]).permute(2, 1, 0))
+
+
+def test_choose_process_grid_prefers_j_cuts():
+    assert choose_process_grid(1, (512, 512, 512)) == (1, 1)
+    assert choose_process_grid(2, (512, 512, 512)) == (1, 2)
+    assert choose_process_grid(8, (512, 512, 512)) == (1, 8)
+    assert choose_process_grid(8, (2048, 64, 80)) == (4, 2)  # J would get thinner than 32 rows
+
+
+@pytest.mark.parametrize("grid", [(1, 1), (2, 1), (1, 2), (4, 2), (3, 3)])
+def test_decomposition_tiles_the_domain(grid):
+    gd, h = (37, 29, 3), 2
+    seen = np.zeros(gd[:2], int)
+    for rank in range(grid[0] * grid[1]):
+        d = Decomposition(gd, grid, rank, h)
+        (oi, oj, _), (di, dj, dk) = d.offset, d.local_domain
+        seen[oi:oi + di, oj:oj + dj] += 1
+        assert dk == gd[2] and d.local_shape == (di + 2 * h, dj + 2 * h, dk)
+        nb = d.neighbours
+        ci, cj = d.coords
+        assert (nb["W"] is None) == (ci == 0) and (nb["E"] is None) == (ci == grid[0] - 1)
+        assert (nb["S"] is None) == (cj == 0) and (nb["N"] is None) == (cj == grid[1] - 1)
+        # interior + strips tile the local domain exactly once
+        cover = np.zeros((di, dj), int)
+        (si, sj, _), (ei, ej, _) = d.interior_and_strips()[0]
+        if ei > 0 and ej > 0:
+            cover[si:si + ei, sj:sj + ej] += 1
+        for (si, sj, _), (ei, ej, _) in d.interior_and_strips()[1]:
+            cover[si:si + ei, sj:sj + ej] += 1
+        assert (cover == 1).all()
+    assert (seen == 1).all()
+
+
+def test_in_process_4x2_exchange_and_hdiff():
+    """All 8 ranks simulated in one process (no transport): after the two-phase exchange every
+    rank's halo -- corners included -- equals the global field, and decomposed hdiff == global."""
+    rng = np.random.default_rng(4)
+    gd, h, grid = (20, 14, 3), 2, (4, 2)
+    glob = rng.uniform(-10, 10, (gd[0] + 2 * h, gd[1] + 2 * h, gd[2]))
+    coeff = rng.uniform(0, 0.5, glob.shape)
+    want = np.zeros_like(glob)
+    R.hdiff(glob, want, coeff, domain=gd)
+    decs = [Decomposition(gd, grid, r, h) for r in range(8)]
+    local = []
+    for d in decs:
+        blk = scatter_global(glob, d).copy()
+        # wipe the ghost cells that belong to neighbours: they must come from the exchange
+        nb = d.neighbours
+        if nb["W"] is not None:
+            blk[:h] = np.nan
+        if nb["E"] is not None:
+            blk[-h:] = np.nan
+        if nb["S"] is not None:
+            blk[:, :h] = np.nan
+        if nb["N"] is not None:
+            blk[:, -h:] = np.nan
+        local.append(torch.from_numpy(blk))
+    p = TorchSlicePacker()
+    exchangers = [HaloExchanger(d, torch.float64, "cpu", packer=p) for d in decs]
+    for phase in (0, 1):  # play the exchanger's own box tables, delivering the buffers by hand
+        mail = {}
+        for ex, t in zip(exchangers, local):
+            for peer, send_lo, _, ext in ex.phases[phase]:
+                buf = torch.empty(int(np.prod(ext)), dtype=t.dtype)
+                p.pack(t, send_lo, ext, buf)
+                mail[(ex.decomp.rank, peer)] = (buf, ext)
+        for ex, t in zip(exchangers, local):
+            for peer, _, recv_lo, ext in ex.phases[phase]:
+                buf, sent_ext = mail[(peer, ex.decomp.rank)]
+                assert tuple(sent_ext) == tuple(ext)
+                p.unpack(t, recv_lo, ext, buf)
+    got = np.zeros_like(glob)
+    for d, t in zip(decs, local):
+        blk = t.numpy()
+        assert np.array_equal(blk, scatter_global(glob, d))  # halos (with corners) restored exactly
+        out = np.zeros_like(blk)
+        cf = scatter_global(coeff, d)
+        (shift, sub), strips = d.interior_and_strips()
+        for sh, dom in [(shift, sub)] + strips:
+            if all(x > 0 for x in dom):
+                org = tuple(o + s for o, s in zip(d.origin, sh))
+                R.hdiff(blk, out, cf, origin_in=org, origin_out=org, origin_coeff=org, domain=dom)
+        got[d.global_slices(with_halo=False)] = out[h:-h, h:-h]
+    assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h])
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, grid, tmpdir: str):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(99)  # same stream on every rank -> same global field
+        gd, h = (24, 18, 4), 1
+        glob = rng.uniform(-1, 1, (gd[0] + 2, gd[1] + 2, gd[2]))
+        dec = Decomposition(gd, grid, rank, h)
+        blk = scatter_global(glob, dec).copy()
+        nb = dec.neighbours
+        if nb["W"] is not None:
+            blk[:h] = 0
+        if nb["E"] is not None:
+            blk[-h:] = 0
+        if nb["S"] is not None:
+            blk[:, :h] = 0
+        if nb["N"] is not None:
+            blk[:, -h:] = 0
+        t = torch.from_numpy(blk)
+        ex = HaloExchanger(dec, torch.float64, "cpu", packer=TorchSlicePacker())
+        ex.exchange(t)
+        out = np.zeros_like(blk)
+        (shift, sub), strips = dec.interior_and_strips()
+        for sh, dom in [(shift, sub)] + strips:
+            org = tuple(o + s for o, s in zip(dec.origin, sh))
+            R.laplacian(blk, out, origin_inp=org, origin_out=org, domain=dom)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (dec.global_slices(with_halo=False), out[h:-h, h:-h], ex.bytes_per_exchange))
+        if rank == 0:
+            got = np.zeros_like(glob)
+            for sl, o, _ in gathered:
+                got[sl] = o
+            want = np.zeros_like(glob)
+            R.laplacian(glob, want)
+            np.save(os.path.join(tmpdir, "ok.npy"), np.array([np.array_equal(got, want), gathered[0][2]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid", [(1, 2), (2, 1)])
+def test_gloo_world_size_2_laplacian(grid, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, grid, str(tmp_path)), nprocs=2, join=True)
+    ok, nbytes = np.load(tmp_path / "ok.npy")
+    assert ok == 1
+    assert nbytes > 0

@@ -1,0 +1,348 @@
+"""Minimal GTScript recogniser + static analysis, pinned by the reference's own expectations.
+
+* field_info / domain_info of the three hot-path stencils: SURVEY.md Appendix E.1, derived from
+  /root/reference/src/gt4py/cartesian/backend/module_generator.py:56-106.
+* K-boundary and minimum-K table: the 14 cases of
+  /root/reference/tests/cartesian_tests/unit_tests/test_gtc/test_passes/test_min_k_interval.py:44-180
+  (same definitions, same expected values).
+* access kinds: tests/cartesian_tests/unit_tests/backend_tests/test_backend.py:55-107.
+* dtype promotion: gtc/passes/gtir_upcaster.py:43-143.
+"""
+
+import numpy as np
+import pytest
+
+from gt4py_amd.cartesian import analysis, definitions as D, frontend, ir
+from gt4py_amd.cartesian.backend import hip_backend, hip_templates
+from gt4py_amd.cartesian.definitions import AccessKind, Boundary
+from gt4py_amd.cartesian.gtscript import BACKWARD, FORWARD, PARALLEL, Field, I, J, K, computation, interval  # noqa: F401
+
+F64 = np.dtype("float64")
+F32 = np.dtype("float32")
+
+
+def parse(defn, *, dtypes=None, externals=None, **opts):
+    options = D.BuildOptions(name=defn.__name__, module=__name__, backend_opts={}, **opts)
+    return frontend.parse_stencil(defn, externals=externals or {}, dtypes=dtypes or {}, options=options)
+
+
+# ---- the three stencils ---------------------------------------------------------------------------
+def test_field_info_laplacian():
+    st = parse(hip_templates.lap_notebook, dtypes={"T": F64})
+    info = analysis.make_args_data(st)
+    assert info.field_info["inp"].access == AccessKind.READ
+    assert info.field_info["inp"].boundary == Boundary(((1, 1), (1, 1), (0, 0)))
+    assert info.field_info["out"].access == AccessKind.WRITE
+    assert info.field_info["out"].boundary == Boundary.zeros(3)
+    assert info.domain_info == D.DomainInfo(("I", "J"), "K", 0, 3)
+    assert info.field_info["inp"].axes == ("I", "J", "K") and info.field_info["inp"].dtype == F64
+
+
+def test_field_info_horizontal_diffusion():
+    st = parse(hip_templates.hdiff_limiter_field, dtypes={"T": F64})
+    info = analysis.make_args_data(st)
+    assert info.field_info["in_field"].boundary == Boundary(((2, 2), (2, 2), (0, 0)))  # cf. test_suites.py:207
+    assert info.field_info["in_field"].access == AccessKind.READ
+    assert info.field_info["coeff"].boundary == Boundary.zeros(3)
+    assert info.field_info["out_field"].access == AccessKind.WRITE
+    # block extents per statement: lap (-1,1)^2, out (0,0)^2
+    assert info.extents.blocks[0] == ((-1, 1), (-1, 1)) and info.extents.blocks[-1] == ((0, 0), (0, 0))
+    assert info.extents.fields["flx_field"] == ((-1, 0), (0, 0))
+    assert info.extents.fields["fly_field"] == ((0, 0), (-1, 0))
+    assert {t.name: t.dtype for t in st.temporaries} == {n: F64 for n in ("lap_field", "res", "flx_field", "fly_field")}
+
+
+def test_field_info_tridiagonal():
+    st = parse(hip_templates.tridiagonal_solver, dtypes={"T": F64})
+    info = analysis.make_args_data(st)
+    kinds = {n: f.access for n, f in info.field_info.items()}
+    assert kinds == {"inf": AccessKind.READ, "diag": AccessKind.READ, "sup": AccessKind.READ_WRITE,
+                     "rhs": AccessKind.READ_WRITE, "out": AccessKind.WRITE}
+    assert info.domain_info.min_sequential_axis_size == 2
+    for name in ("diag", "sup", "rhs", "out"):
+        assert info.field_info[name].boundary == Boundary.zeros(3)
+    # `inf` is only touched in interval(1, None): the reference's rule gives it a K lower bound of -1
+    # (gtir_k_boundary.py:39-70: max(-start.offset - k_offset) = -1)
+    assert info.field_info["inf"].boundary == Boundary(((0, 0), (0, 0), (-1, 0)))
+    assert [c.order for c in st.computations] == [ir.LoopOrder.FORWARD, ir.LoopOrder.BACKWARD]
+    assert [b.interval.range(10) for b in st.computations[1].blocks] == [(9, 10), (0, 9)]
+
+
+# ---- dtype rules ------------------------------------------------------------------------------------
+def test_float32_fields_compute_in_float64_by_default():
+    st = parse(hip_templates.hdiff_limiter_field, dtypes={"T": F32})
+    stmts = [s for _, _, s in st.statements()]
+    lap = stmts[0].value
+    assert lap.dtype == F64 and isinstance(lap.left.right, ir.Cast) and lap.left.right.dtype == F64
+    # the bracket of four float32 reads is summed in float32 and widened once
+    assert isinstance(lap.right, ir.Cast) and lap.right.expr.dtype == F32
+    # (in[1,0,0] - in) is a float32 subtraction widened for the product
+    flx = stmts[2].value
+    prod = flx.cond.left
+    assert isinstance(prod.right, ir.Cast) and prod.right.expr.dtype == F32 and prod.dtype == F64
+    # literal 0 is int64 cast to float64 in both the comparison and the ternary branch
+    assert flx.cond.right == ir.Cast(ir.Literal(0, np.dtype("int64")), F64)
+    assert flx.true_expr == ir.Cast(ir.Literal(0, np.dtype("int64")), F64)
+    # final right-hand side is float64, rounded once to float32
+    out = stmts[-1].value
+    assert isinstance(out, ir.Cast) and out.dtype == F32 and out.expr.dtype == F64
+
+
+def test_literal_float_precision_32_keeps_float32():
+    st = parse(hip_templates.hdiff_limiter_field, dtypes={"T": F32}, literal_float_precision=32)
+    assert {t.dtype for t in st.temporaries} == {F32}
+    assert all(not isinstance(e, ir.Cast) or e.dtype != F64 for _, _, s in st.statements() for e in ir.walk(s.value))
+
+
+def test_unary_minus_literal_is_an_operator_node():
+    st = parse(hip_templates.lap_notebook, dtypes={"T": F64})
+    (stmt,) = [s for _, _, s in st.statements()]
+    e = stmt.value
+    while isinstance(e, ir.BinaryOp) and e.op == "+":
+        e = e.left
+    assert e.op == "*" and e.left == ir.UnaryOp("-", ir.Literal(4.0, F64), F64)
+
+
+def test_ufunc_signature_rule():
+    i64, b = np.dtype("int64"), np.dtype("bool")
+    assert frontend.ufunc_signature(np.multiply, (F32, F64)) == (F64, F64)
+    assert frontend.ufunc_signature(np.multiply, (i64, F32)) == (F32, F32)  # reference DataType order
+    assert frontend.ufunc_signature(np.greater, (F64, i64)) == (F64, F64)
+    assert frontend.ufunc_signature(np.add, (b, b)) == (b, b)
+
+
+# ---- K boundary / minimum K size (reference table) -------------------------------------------------
+def k_no_extent_0(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(...):
+        field_a = field_b[0, 0, 0]
+
+
+def k_no_extent_1(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(0, 2):
+        field_a = field_b[0, 0, 0]
+
+
+def k_no_extent_2(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(1, 2):
+        field_a = field_b[0, 0, 0]
+
+
+def k_no_extent_3(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(0, 2):
+        field_a = field_b[0, 0, 0]
+    with computation(PARALLEL), interval(2, 3):
+        field_a = field_b[0, 0, 0]
+    with computation(PARALLEL), interval(3, None):
+        field_a = field_b[0, 0, 0]
+
+
+def k_no_extent_4(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(-1, None):
+        field_a = field_b[0, 0, 0]
+
+
+def k_no_extent_5(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(0, 1):
+        field_a = field_b[0, 0, 0]
+    with computation(PARALLEL), interval(-2, None):
+        field_a = field_b[0, 0, 0]
+
+
+def k_no_extent_6(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(1, -2):
+        field_a[0, 0, 0] = field_b[0, 0, 0]
+
+
+def k_extent_0(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(...):
+        field_a = field_b[0, 0, -5]
+
+
+def k_extent_1(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(1, 2):
+        field_a = field_b[0, 0, -5]
+
+
+def k_extent_2(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(1, 2):
+        field_a = field_b[0, 0, 5]
+
+
+def k_extent_3(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(0, 2):
+        field_a = field_b[0, 0, -1]
+    with computation(PARALLEL), interval(2, 3):
+        field_a = field_b[0, 0, -5]
+    with computation(PARALLEL), interval(3, None):
+        field_a = field_b[0, 0, -3]
+
+
+def k_extent_4(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(0, -1):
+        field_a = field_b[0, 0, 5]
+    with computation(PARALLEL), interval(-1, None):
+        field_a = field_b[0, 0, 5]
+
+
+def k_extent_5(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(0, 1):
+        field_a = field_b[0, 0, -5]
+    with computation(PARALLEL), interval(-2, None):
+        field_a = field_b[0, 0, -5]
+
+
+def k_extent_6(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(0, 1):
+        field_a = field_b[0, 0, -5] + field_b[0, 0, 3]
+    with computation(PARALLEL), interval(-1, None):
+        field_a = field_b[0, 0, -5] + field_b[0, 0, 3]
+
+
+K_TABLE = [
+    (k_no_extent_0, (0, 0), 0), (k_no_extent_1, (0, 0), 2), (k_no_extent_2, (-1, 0), 2),
+    (k_no_extent_3, (0, 0), 4), (k_no_extent_4, (0, 0), 1), (k_no_extent_5, (0, 0), 3),
+    (k_no_extent_6, (-1, -2), 4), (k_extent_0, (5, -5), 0), (k_extent_1, (4, 0), 2),
+    (k_extent_2, (-6, 0), 2), (k_extent_3, (3, -3), 4), (k_extent_4, (-5, 5), 2),
+    (k_extent_5, (5, -5), 3), (k_extent_6, (5, 3), 2),
+]
+
+
+@pytest.mark.parametrize("defn,k_bounds,min_k", K_TABLE, ids=[t[0].__name__ for t in K_TABLE])
+def test_k_boundary_and_min_k_size(defn, k_bounds, min_k):
+    st = parse(defn)
+    assert analysis.compute_k_boundary(st)["field_b"] == k_bounds
+    assert analysis.compute_min_k_size(st) == min_k
+
+
+# ---- access kinds (test_backend.py:55-107 style) ---------------------------------------------------
+def access_kinds_stencil(in_field: Field[float], inout_field: Field[float], out_field: Field[float],
+                         unused: Field[float], *, par: float, unused_par: float):
+    with computation(PARALLEL), interval(...):
+        inout_field = inout_field + in_field * par
+        out_field = inout_field
+        tmp = out_field
+        out_field = tmp + 1.0
+
+
+def test_access_kinds_and_parameters():
+    info = analysis.make_args_data(parse(access_kinds_stencil))
+    assert {n: f.access for n, f in info.field_info.items()} == {
+        "in_field": AccessKind.READ, "inout_field": AccessKind.READ_WRITE, "out_field": AccessKind.WRITE,
+        "unused": AccessKind.NONE}
+    assert info.parameter_info["par"].access == AccessKind.READ
+    assert info.parameter_info["unused_par"].access == AccessKind.NONE
+    assert info.parameter_info["par"].dtype == F64
+    assert info.field_info["unused"].boundary == Boundary.zeros(3)
+
+
+# ---- syntax the subset accepts / rejects --------------------------------------------------------------
+def axis_offsets(a: Field[np.float64], b: Field[np.float64]):
+    with computation(PARALLEL), interval(...):
+        b = a[I + 1] + a[J - 2] + a[K + 1] + a[I - 1, K - 1]
+
+
+def test_axis_offset_syntax():
+    (stmt,) = [s for _, _, s in parse(axis_offsets).statements()]
+    offs = sorted(e.offset for e in ir.walk(stmt.value) if isinstance(e, ir.FieldAccess))
+    assert offs == sorted([(1, 0, 0), (0, -2, 0), (0, 0, 1), (-1, 0, -1)])
+
+
+def with_externals(a: Field[np.float64], b: Field[np.float64]):
+    from __externals__ import FACTOR, USE_A
+
+    with computation(PARALLEL), interval(...):
+        if __INLINED(USE_A):  # noqa: F821
+            b = a * FACTOR
+        else:
+            b = FACTOR
+
+
+def test_externals_and_inlined_if():
+    st = parse(with_externals, externals={"FACTOR": 3.0, "USE_A": True})
+    (stmt,) = [s for _, _, s in st.statements()]
+    assert stmt.value == ir.BinaryOp("*", ir.FieldAccess("a", (0, 0, 0), F64), ir.Literal(3.0, F64), F64)
+    st = parse(with_externals, externals={"FACTOR": 3.0, "USE_A": False})
+    assert [s.value for _, _, s in st.statements()] == [ir.Literal(3.0, F64)]
+    with pytest.raises(D.GTScriptSymbolError):
+        parse(with_externals, externals={"FACTOR": 3.0})
+
+
+def race_stencil(a: Field[np.float64]):
+    with computation(PARALLEL), interval(...):
+        a = a[1, 0, 0] + a[-1, 0, 0]
+
+
+def write_offset_stencil(a: Field[np.float64], b: Field[np.float64]):
+    with computation(PARALLEL), interval(...):
+        b[1, 0, 0] = a
+
+
+def runtime_if_stencil(a: Field[np.float64], b: Field[np.float64]):
+    with computation(PARALLEL), interval(...):
+        if a > 0.0:
+            b = a
+
+
+def unknown_symbol_stencil(a: Field[np.float64], b: Field[np.float64]):
+    with computation(PARALLEL), interval(...):
+        b = a + c  # noqa: F821
+
+
+def bad_interval_order(a: Field[np.float64], b: Field[np.float64]):
+    with computation(BACKWARD):
+        with interval(0, -1):
+            b = a
+        with interval(-1, None):
+            b = a
+
+
+def test_rejections():
+    # written API field read with a horizontal offset (gtir_to_oir.py:19-46; test_code_generation.py:1693)
+    with pytest.raises(ValueError, match="non-zero read extent on written fields"):
+        parse(race_stencil)
+    with pytest.raises(D.GTScriptSyntaxError, match="non-zero offsets"):
+        parse(write_offset_stencil)
+    with pytest.raises(D.GTScriptSyntaxError, match="Run-time 'if'"):
+        parse(runtime_if_stencil)
+    with pytest.raises(D.GTScriptSymbolError):
+        parse(unknown_symbol_stencil)
+    # BACKWARD intervals must be listed highest first (quickstart.rst:261-265 lists them the invalid way)
+    with pytest.raises(D.GTScriptSyntaxError, match="order of execution"):
+        parse(bad_interval_order)
+
+
+# ---- kernel recognition ----------------------------------------------------------------------------
+def user_laplacian(phi: Field[np.float64], lap_phi: Field[np.float64]):
+    with computation(PARALLEL), interval(...):
+        lap_phi = (-4.0 * phi) + phi[-1, 0, 0] + phi[I + 1] + phi[0, -1, 0] + phi[J + 1]
+
+
+def reassociated_laplacian(phi: Field[np.float64], lap_phi: Field[np.float64]):
+    with computation(PARALLEL), interval(...):
+        lap_phi = -4.0 * phi + (phi[-1, 0, 0] + phi[1, 0, 0]) + (phi[0, -1, 0] + phi[0, 1, 0])
+
+
+def suite_hdiff(u: Field[np.float64], diffusion: Field[np.float64], *, weight: np.float64):
+    with computation(PARALLEL), interval(...):
+        laplacian = 4.0 * u[0, 0, 0] - (u[1, 0, 0] + u[-1, 0, 0] + u[0, 1, 0] + u[0, -1, 0])
+        flux_i = laplacian[1, 0, 0] - laplacian[0, 0, 0]
+        flux_j = laplacian[0, 1, 0] - laplacian[0, 0, 0]
+        diffusion = u[0, 0, 0] - weight * (flux_i[0, 0, 0] - flux_i[-1, 0, 0] + flux_j[0, 0, 0] - flux_j[0, -1, 0])
+
+
+def test_recognise_is_alpha_equivalence_not_text():
+    opts = D.BuildOptions(name="x", module=__name__, backend_opts={})
+    b = hip_backend.recognise(parse(user_laplacian), opts)
+    assert b is not None and b.family == "lap5" and b.template == "lap_notebook"
+    assert b.roles == {"inp": "phi", "out": "lap_phi"} and b.dtype == F64
+    # a different association of the additions changes rounding -> must NOT be accepted
+    assert hip_backend.recognise(parse(reassociated_laplacian), opts) is None
+    # TestHorizontalDiffusion (test_suites.py:212-220): other names, other argument order, scalar weight
+    b = hip_backend.recognise(parse(suite_hdiff), opts)
+    assert b.family == "hdiff" and b.template == "hdiff_plain_scalar"
+    assert b.roles["in_field"] == "u" and b.roles["out_field"] == "diffusion" and b.roles["coeff"] == "weight"
+    for name in ("hdiff_limiter_field", "hdiff_plain_field", "tridiagonal_solver", "lap_docs", "lap_suite", "lap_avg"):
+        for T in (F64, F32):
+            st = parse(getattr(hip_templates, name), dtypes={"T": T})
+            assert hip_backend.recognise(st, opts).template == name
+    assert hip_backend.recognise(parse(access_kinds_stencil), opts) is None

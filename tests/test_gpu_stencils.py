@@ -1,0 +1,244 @@
+"""GPU: the full user path -- gt4py_amd.storage + @gtscript.stencil(backend="hip:mi300") -- vs the oracle.
+
+These read like the reference's own integration tests (test_call_interface.py, test_suites.py) with
+the backend name swapped.  Results are compared bit-exactly with oracle/ref_numpy.py; fp64 target of
+the north star is 1e-12, fp32 target 1 ulp: both are met with equality.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BACKEND = "hip:mi300"
+
+
+def _imports():
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+
+    return gt_storage, gtscript
+
+
+def lap_cartesian(inp: "Field[np.float64]", out: "Field[np.float64]"):  # noqa: F821
+    with computation(PARALLEL), interval(...):  # noqa: F821
+        out = -4.0 * inp[0, 0, 0] + inp[-1, 0, 0] + inp[1, 0, 0] + inp[0, -1, 0] + inp[0, 1, 0]  # noqa: F841
+
+
+def avg_stencil(in_field: "Field[np.float64]", out_field: "Field[np.float64]"):  # noqa: F821
+    with computation(PARALLEL), interval(...):  # noqa: F821
+        out_field = 0.25 * (+in_field[0, 1, 0] + in_field[0, -1, 0] + in_field[1, 0, 0] + in_field[-1, 0, 0])  # noqa: F841
+
+
+def test_storage_allocation_on_device():
+    """test_interface.py:184-240 (test_allocate_gpu): alignment of the aligned_index column, layout."""
+    gt_storage, _ = _imports()
+    from gt4py_amd.storage import layout as gt_layout
+
+    a = gt_storage.zeros((516, 516, 8), np.float64, backend=BACKEND, aligned_index=(2, 2, 0))
+    assert isinstance(a, gt_storage.DeviceArray) and a.shape == (516, 516, 8) and a.dtype == np.float64
+    assert a.strides == (8, 4352, 4352 * 516)
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        j, k = int(rng.integers(0, 516)), int(rng.integers(0, 8))
+        assert (a.ptr + 2 * 8 + j * 4352 + k * 4352 * 516) % 256 == 0
+    assert gt_layout.from_name(BACKEND)["is_optimal_layout"](a, ("I", "J", "K"))
+    assert a.__cuda_array_interface__["data"][0] == a.ptr and a.__hip_array_interface__["strides"] == a.strides
+    f32 = gt_storage.ones((7, 5, 3), np.float32, backend=BACKEND, aligned_index=(1, 1, 0))
+    assert (f32.ptr + 4) % 128 == 0 and (f32 == 1).all() and f32.sum() == 105
+    host = np.arange(60.0).reshape(3, 4, 5)
+    d = gt_storage.from_array(host, backend=BACKEND)
+    assert np.array_equal(d.get(), host) and np.array_equal(np.asarray(d[1:, 2]), host[1:, 2])
+    d[0, 0, :] = -1.0
+    assert (d[0, 0] == -1).all()
+
+
+def test_notebook_known_answer():
+    """examples/lap_cartesian_vs_next.ipynb cells 5-9 on hip:mi300."""
+    gt_storage, gtscript = _imports()
+    nx = ny = 32
+    lap = gtscript.stencil(backend=BACKEND, definition=lap_cartesian)
+    inp = gt_storage.from_array(np.fromfunction(lambda x, y, z: x**2 + y**2, (nx, ny, 1)), backend=BACKEND,
+                                aligned_index=(1, 1, 0))
+    out = gt_storage.zeros((nx, ny, 1), backend=BACKEND, aligned_index=(1, 1, 0))
+    lap(inp=inp, out=out, origin=(1, 1, 0), domain=(nx - 2, ny - 2, 1))
+    res = out.get()
+    assert (res[1:-1, 1:-1] == 4.0).all() and res.sum() == 4.0 * 30 * 30
+    assert lap.backend == BACKEND and lap.field_info["inp"].boundary == ((1, 1), (1, 1), (0, 0))
+
+
+def test_halo_checks_on_device():
+    """test_call_interface.py:221-285 with backend hip:mi300."""
+    from helpers import OriginWrapper
+
+    gt_storage, gtscript = _imports()
+    stencil = gtscript.stencil(definition=avg_stencil, backend=BACKEND)
+
+    def pair(n=22):
+        mk = lambda f: OriginWrapper(array=f(backend=BACKEND, shape=(n, n, 10), aligned_index=(1, 1, 0),  # noqa: E731
+                                             dtype=np.float64), origin=(1, 1, 0))
+        return mk(gt_storage.ones), mk(gt_storage.zeros)
+
+    i, o = pair()
+    stencil(in_field=i, out_field=o)
+    assert (o.array[1:-1, 1:-1, :] == 1).all()
+    i, o = pair()
+    stencil(in_field=i, out_field=o, origin=(2, 2, 0), domain=(10, 10, 10))
+    assert (o.array[2:12, 2:12, :] == 1).all() and o.array.sum() == 1000
+    i, o = pair()
+    with pytest.raises(ValueError):
+        stencil(in_field=i, out_field=o, origin=(2, 2, 0), domain=(20, 20, 10))
+    i, o = pair(23)
+    stencil(in_field=i, out_field=o, origin=(2, 2, 0), domain=(20, 20, 10))
+
+
+def test_host_arrays_are_rejected_and_unknown_stencils_raise():
+    gt_storage, gtscript = _imports()
+    stencil = gtscript.stencil(definition=avg_stencil, backend=BACKEND)
+    with pytest.raises(TypeError, match="device array"):
+        stencil(np.ones((8, 8, 2)), np.zeros((8, 8, 2)))
+
+    def other(a: gtscript.Field[np.float64], b: gtscript.Field[np.float64]):
+        with computation(PARALLEL), interval(...):  # noqa: F821
+            b = a + 1.0  # noqa: F841
+
+    with pytest.raises(NotImplementedError, match="hand-written gfx950 kernels"):
+        gtscript.stencil(definition=other, backend=BACKEND)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_horizontal_diffusion_demo(dtype):
+    """examples/cartesian/demo_horizontal_diffusion.ipynb cells 7-13 (N=30, origin (2,2,0), default domain)."""
+    from gt4py_amd.cartesian.backend import hip_templates
+    from oracle import ref_numpy as R
+
+    gt_storage, gtscript = _imports()
+    hd = gtscript.stencil(backend=BACKEND, definition=hip_templates.hdiff_limiter_field, dtypes={"T": dtype})
+    N = 30
+    idx = np.arange(N)
+    xx = (np.zeros((N, N, N)) + idx.reshape(N, 1, 1)) / N
+    yy = (np.zeros((N, N, N)) + idx.reshape(1, N, 1)) / N
+    in_data = (5.0 + 8.0 * (2.0 + np.cos(np.pi * (xx + 1.5 * yy)) + np.sin(2 * np.pi * (xx + 1.5 * yy))) / 4.0)
+    in_data = (in_data + 0.1 * np.random.default_rng(2024).uniform(-1, 1, in_data.shape)).astype(dtype)
+    coeff = (0.025 * np.ones((N, N, N))).astype(dtype)
+    origin = (2, 2, 0)
+    d_in = gt_storage.from_array(in_data, dtype, backend=BACKEND, aligned_index=origin)
+    d_out = gt_storage.from_array(np.zeros((N, N, N)), dtype, backend=BACKEND, aligned_index=origin)
+    d_cf = gt_storage.from_array(coeff, dtype, backend=BACKEND, aligned_index=origin)
+    exec_info = {}
+    hd(d_in, d_out, d_cf, origin=origin, exec_info=exec_info)
+    want = np.zeros((N, N, N), dtype)
+    R.hdiff(in_data, want, coeff, domain=(N - 4, N - 4, N))
+    assert np.array_equal(d_out.get(), want)
+    assert exec_info["run_cpp_end_time"] >= exec_info["run_cpp_start_time"]
+    assert exec_info["call_start_time"] < exec_info["run_start_time"] < exec_info["run_end_time"] < exec_info["call_end_time"]
+
+
+def test_suite_horizontal_diffusion_scalar_weight():
+    """TestHorizontalDiffusion (test_suites.py:200-230): definition + validation, domains 1..15, halo 2."""
+    from oracle import ref_numpy as R
+
+    gt_storage, gtscript = _imports()
+
+    def definition(u: gtscript.Field[np.float64], diffusion: gtscript.Field[np.float64], *, weight: np.float64):
+        with computation(PARALLEL), interval(...):  # noqa: F821
+            laplacian = 4.0 * u[0, 0, 0] - (u[1, 0, 0] + u[-1, 0, 0] + u[0, 1, 0] + u[0, -1, 0])
+            flux_i = laplacian[1, 0, 0] - laplacian[0, 0, 0]
+            flux_j = laplacian[0, 1, 0] - laplacian[0, 0, 0]
+            diffusion = u[0, 0, 0] - weight * (  # noqa: F841
+                flux_i[0, 0, 0] - flux_i[-1, 0, 0] + flux_j[0, 0, 0] - flux_j[0, -1, 0])
+
+    stencil = gtscript.stencil(backend=BACKEND, definition=definition)
+    rng = np.random.default_rng(77)
+    for domain in [(1, 1, 1), (2, 15, 3), (15, 1, 15), (15, 15, 15), (7, 9, 4)]:
+        u = rng.uniform(-10, 10, (domain[0] + 4, domain[1] + 4, domain[2]))
+        weight = float(rng.uniform(0, 0.5))
+        d_u = gt_storage.from_array(u, backend=BACKEND, aligned_index=(2, 2, 0))
+        d_out = gt_storage.zeros(domain, backend=BACKEND)
+        stencil(d_u, d_out, weight=weight, origin={"u": (2, 2, 0), "diffusion": (0, 0, 0)}, domain=domain)
+        got = d_out.get()
+        want = R.hdiff_validation(u, weight)
+        # the reference's own tolerance (suites.py:42-43) and, stronger, bit equality with the oracle
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-8)
+        assert np.array_equal(got, want)
+
+
+def test_tridiagonal_solver_through_the_decorator():
+    from gt4py_amd.cartesian.backend import hip_templates
+    from oracle import ref_numpy as R
+
+    gt_storage, gtscript = _imports()
+    tri = gtscript.stencil(backend=BACKEND, definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64})
+    assert tri.domain_info.min_sequential_axis_size == 2
+    rng = np.random.default_rng(7)
+    shape = (33, 17, 40)
+    inf, diag = rng.uniform(-1, 1, shape), rng.uniform(4, 5, shape)
+    sup, rhs = rng.uniform(-1, 1, shape), rng.uniform(-10, 10, shape)
+    dev = [gt_storage.from_array(a, backend=BACKEND) for a in (inf, diag, sup, rhs, np.zeros(shape))]
+    tri(*dev)
+    s, r, o = sup.copy(), rhs.copy(), np.zeros(shape)
+    R.tridiag(inf, diag, s, r, o)
+    assert np.array_equal(dev[4].get(), o) and np.array_equal(dev[2].get(), s) and np.array_equal(dev[3].get(), r)
+    with pytest.raises(ValueError, match="Compute domain too small"):
+        one = [gt_storage.from_array(a[:, :, :1], backend=BACKEND) for a in (inf, diag, sup, rhs, np.zeros(shape))]
+        tri(*one)
+
+
+def test_frozen_stencil_and_torch_tensors():
+    """FrozenStencil fast path (stencil_object.py:103-136) with plain torch ROCm tensors as arguments."""
+    import torch
+
+    from oracle import ref_numpy as R
+
+    _, gtscript = _imports()
+    lap = gtscript.stencil(backend=BACKEND, definition=lap_cartesian, device_sync=False)
+    rng = np.random.default_rng(1337)
+    host = rng.uniform(-1, 1, (66, 34, 5))
+    # I-contiguous torch tensors: allocate (K, J, I) and permute
+    t_in = torch.from_numpy(np.ascontiguousarray(host.transpose(2, 1, 0))).cuda().permute(2, 1, 0)
+    t_out = torch.zeros((5, 34, 66), dtype=torch.float64, device="cuda").permute(2, 1, 0)
+    frozen = lap.freeze(origin={"inp": (1, 1, 0), "out": (1, 1, 0)}, domain=(64, 32, 5))
+    from gt4py_amd.storage import as_device_array
+
+    frozen(inp=as_device_array(t_in), out=as_device_array(t_out))
+    torch.cuda.synchronize()
+    want = np.zeros_like(host)
+    R.laplacian(host, want)
+    assert np.array_equal(t_out.cpu().numpy(), want)
+
+
+def test_large_domain_properties_512cubed():
+    """BASELINE size (512^3 fp64): size-independent properties instead of a full CPU reference.
+
+    * linearity of the stencil in exact arithmetic cases: lap(x^2 + y^2) == 4 everywhere,
+    * lap(constant) == 0, halo of `out` untouched,
+    * a checksum of a random slab against the oracle on that slab only.
+    """
+    from oracle import ref_numpy as R
+
+    gt_storage, gtscript = _imports()
+    import torch
+
+    lap = gtscript.stencil(backend=BACKEND, definition=lap_cartesian)
+    n = 512
+    shape = (n + 2, n + 2, n)
+    inp = gt_storage.empty(shape, backend=BACKEND, aligned_index=(1, 1, 0))
+    out = gt_storage.full(shape, -3.0, backend=BACKEND, aligned_index=(1, 1, 0))
+    x = torch.arange(n + 2, dtype=torch.float64, device="cuda").reshape(-1, 1, 1)
+    y = torch.arange(n + 2, dtype=torch.float64, device="cuda").reshape(1, -1, 1)
+    inp.tensor.copy_((x * x + y * y).expand(shape))
+    lap(inp, out, origin=(1, 1, 0))
+    t = out.tensor
+    assert bool((t[1:-1, 1:-1, :] == 4.0).all())
+    assert bool((t[0] == -3.0).all()) and bool((t[-1] == -3.0).all())
+    assert bool((t[:, 0] == -3.0).all()) and bool((t[:, -1] == -3.0).all())
+    inp.tensor.fill_(2.5)
+    lap(inp, out, origin=(1, 1, 0))
+    assert bool((t[1:-1, 1:-1, :] == 0.0).all())
+    g = torch.Generator(device="cuda").manual_seed(1337)
+    inp.tensor.copy_(torch.rand(shape, dtype=torch.float64, device="cuda", generator=g) * 2 - 1)
+    lap(inp, out, origin=(1, 1, 0))
+    slab = inp[:, 200:215, 100:103].get()
+    want = np.zeros_like(slab)
+    R.laplacian(slab, want)
+    assert np.array_equal(out[1:-1, 201:214, 100:103].get(), want[1:-1, 1:-1])

@@ -142,6 +142,18 @@ __device__ __forceinline__ void vstore(T* p, const T (&r)[N]) {
 // Workgroup id remap: the dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md,
 // "Workgroup dispatch").  Give each XCD a contiguous range of logical tiles so that tiles that
 // share halo rows also share an L2.  Performance only; any mapping is correct.
+// Grouped variant: runs of G consecutive logical tiles go to one XCD, runs are dealt round-robin.
+// Small G keeps the chip-wide access stream nearly sequential in memory (which the HBM channels
+// like) while still letting G-1 of every G tile boundaries be shared inside one L2.
+template <unsigned G>
+__device__ __forceinline__ unsigned xcd_remap_grouped(unsigned b, unsigned n) {
+    constexpr unsigned NX = 8;
+    constexpr unsigned R = NX * G;  // tiles per round
+    if (b >= (n / R) * R) return b;  // tail: identity
+    const unsigned round = b / R, r = b % R;
+    return round * R + (r % NX) * G + (r / NX);
+}
+
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
     constexpr unsigned NX = 8;
     const unsigned per = n / NX;  // tiles per XCD (full part)

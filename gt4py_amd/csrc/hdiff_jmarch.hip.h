@@ -30,18 +30,22 @@ inline bool hdiff_jmarch_enabled() {
 }
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ,
-          int PF>
+          int PF, int XCDG = 0>
 __global__ void __launch_bounds__(256)
 hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scalar, int dI,
-                    int dJ, unsigned waves_i, unsigned tiles_j, unsigned nwaves) {
+                    int dJ, unsigned waves_i, unsigned tiles_j, unsigned groups_j) {
     constexpr int H = (VEC >= 2) ? 1 : 2;   // halo lanes per side
     constexpr int OUT_LANES = 64 - 2 * H;
     const unsigned lane = threadIdx.x & 63;
-    unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= nwaves) return;
-    const unsigned wi = wid % waves_i;
-    const unsigned tj = (wid / waves_i) % tiles_j;
-    const unsigned k = wid / (waves_i * tiles_j);
+    // A workgroup = 4 independent waves on 4 consecutive J strips of one I column, so 3 of the 4
+    // strip boundaries (4 shared rows each) are re-read inside one CU; workgroups are ordered along
+    // J, then I, then K, and runs of XCDG of them share an XCD (see lap5.hip.h).
+    unsigned wg = blockIdx.x;
+    if constexpr (XCDG > 0) wg = xcd_remap_grouped<(unsigned)XCDG>(wg, gridDim.x);
+    const unsigned tj = (wg % groups_j) * 4 + (threadIdx.x >> 6);
+    if (tj >= tiles_j) return;
+    const unsigned wi = (wg / groups_j) % waves_i;
+    const unsigned k = wg / (groups_j * waves_i);
 
     const int col = ((int)(wi * OUT_LANES) - H + (int)lane) * VEC;  // first column of this lane
     const int j0 = (int)tj * LJ;
@@ -194,8 +198,10 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
 // win; the 4-row prologue is re-read from L2.
 template <typename T>
 struct HdiffTuning {
-    static constexpr int LJ = sizeof(T) == 4 ? 12 : 8;
+    // profiles/r1_microbench_h_hdiff_groups.log: all rows of a strip in flight (PF == LJ)
+    static constexpr int LJ = sizeof(T) == 4 ? 6 : 8;
     static constexpr int PF = sizeof(T) == 4 ? 6 : 8;
+    static constexpr int XCDG = 4;  // workgroups per XCD run (see lap5.hip.h Lap5Tuning::XCDG)
 };
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC>
@@ -206,11 +212,13 @@ inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
     constexpr int LJ = HdiffTuning<T>::LJ;
     const unsigned waves_i = (unsigned)cdiv(d[0], (int64_t)(64 - 2 * H) * VEC);
     const unsigned tiles_j = (unsigned)cdiv(d[1], LJ);
-    const int64_t nwaves = (int64_t)waves_i * tiles_j * d[2];
-    if (nwaves > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: domain too large for one launch");
-    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, HdiffTuning<T>::PF>),
-                       dim3((unsigned)cdiv(nwaves, 4)), dim3(256), 0, stream, in, out, cf,
-                       coeff_scalar, (int)d[0], (int)d[1], waves_i, tiles_j, (unsigned)nwaves);
+    const unsigned groups_j = (unsigned)cdiv(tiles_j, 4);
+    const int64_t nblocks = (int64_t)waves_i * groups_j * d[2];
+    if (nblocks > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: domain too large for one launch");
+    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, HdiffTuning<T>::PF,
+                                            HdiffTuning<T>::XCDG>),
+                       dim3((unsigned)nblocks), dim3(256), 0, stream, in, out, cf, coeff_scalar, (int)d[0],
+                       (int)d[1], waves_i, tiles_j, groups_j);
     return GT4MI_OK;
 }
 

@@ -51,10 +51,14 @@ __device__ __forceinline__ T lap5_expr(T c, T w, T e, T s, T n) {
     }
 }
 
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK>
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG = 0>
 __global__ void __launch_bounds__(BLOCK)
 lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x, unsigned tiles_y) {
-    const unsigned b = blockIdx.x;
+    // XCDG > 0: runs of XCDG consecutive strips share an XCD (private L2), so the halo rows they
+    // share are L2 hits instead of a second fabric fetch.  XCDG = -1: one contiguous range per XCD.
+    unsigned b = blockIdx.x;
+    if constexpr (XCDG > 0) b = xcd_remap_grouped<(unsigned)XCDG>(b, gridDim.x);
+    if constexpr (XCDG < 0) b = xcd_remap(b, gridDim.x);
     const unsigned bx = b % tiles_x;
     const unsigned by = (b / tiles_x) % tiles_y;
     const unsigned k = b / (tiles_x * tiles_y);
@@ -124,6 +128,10 @@ lap5_generic_kernel(View<const T> in, View<T> out, int dI, int dJ, int dK) {
 // ---- launch configuration ------------------------------------------------------------------
 struct Lap5Tuning {
     static constexpr int LJ = 8;  // rows per strip; all LJ+2 row loads are in flight at once
+    // Runs of 4 consecutive strips per XCD: measured 382 vs 372 GLUPS (none) vs 370 (one contiguous
+    // range per XCD) at 512^3, and L2->fabric reads 1.13x instead of 1.33x the algorithmic bytes
+    // (profiles/r1_microbench_g_xcd_groups.log, r1_lap512_fetch_by_variant.txt).
+    static constexpr int XCDG = 4;
 };
 
 template <typename T, typename W, int VARIANT, int VEC, int BLOCK>
@@ -134,7 +142,7 @@ inline int lap5_launch_strip(const View<const T>& in, const View<T>& out, const 
     const unsigned ty = (unsigned)cdiv(d[1], LJ);
     const int64_t n = (int64_t)tx * ty * d[2];
     if (n > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "lap5: domain too large for one launch");
-    hipLaunchKernelGGL((lap5_strip_kernel<T, W, VARIANT, VEC, LJ, BLOCK>), dim3((unsigned)n), dim3(BLOCK),
+    hipLaunchKernelGGL((lap5_strip_kernel<T, W, VARIANT, VEC, LJ, BLOCK, Lap5Tuning::XCDG>), dim3((unsigned)n), dim3(BLOCK),
                        0, stream, in, out, (int)d[0], (int)d[1], tx, ty);
     return GT4MI_OK;
 }

@@ -201,15 +201,15 @@ static void section_copy() {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int LJ, int BLOCK>
+template <int LJ, int BLOCK, int XCD = 0>
 static void lap_variant(const DevField<double>& in, DevField<double>& out, int dI, int dJ, int dK, const char* tag) {
     constexpr int VEC = 2;
     const unsigned tx = (unsigned)cdiv(dI, BLOCK * VEC), ty = (unsigned)cdiv(dJ, LJ);
     const unsigned n = tx * ty * dK;
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%s strip LJ=%d block=%d", tag, LJ, BLOCK);
+    snprintf(cfg, sizeof cfg, "%s strip LJ=%d block=%d xcd=%d", tag, LJ, BLOCK, (int)XCD);
     const double ms = time_ms([&](int) {
-        hipLaunchKernelGGL((lap5_strip_kernel<double, double, 0, VEC, LJ, BLOCK>), dim3(n), dim3(BLOCK), 0, 0,
+        hipLaunchKernelGGL((lap5_strip_kernel<double, double, 0, VEC, LJ, BLOCK, XCD>), dim3(n), dim3(BLOCK), 0, 0,
                            in.cview(), out.view(), dI, dJ, tx, ty);
     }, 20);
     report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
@@ -233,8 +233,17 @@ static void lap_suite(int dI, int dJ, int dK, int64_t extra_pitch, const char* t
         lap_variant<4, 256>(in, out, dI, dJ, dK, tag);
         lap_variant<8, 256>(in, out, dI, dJ, dK, tag);
         if (rep == 0) printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+        lap_variant<8, 256, -1>(in, out, dI, dJ, dK, tag);
+        lap_variant<8, 256, 2>(in, out, dI, dJ, dK, tag);
+        lap_variant<8, 256, 4>(in, out, dI, dJ, dK, tag);
+        lap_variant<8, 256, 8>(in, out, dI, dJ, dK, tag);
+        lap_variant<8, 256, 16>(in, out, dI, dJ, dK, tag);
+        lap_variant<8, 256, 64>(in, out, dI, dJ, dK, tag);
+        lap_variant<4, 256, 4>(in, out, dI, dJ, dK, tag);
+        lap_variant<4, 256, 16>(in, out, dI, dJ, dK, tag);
         lap_variant<12, 256>(in, out, dI, dJ, dK, tag);
         lap_variant<16, 256>(in, out, dI, dJ, dK, tag);
+        lap_variant<16, 256, 4>(in, out, dI, dJ, dK, tag);
         lap_variant<8, 128>(in, out, dI, dJ, dK, tag);
         lap_variant<16, 128>(in, out, dI, dJ, dK, tag);
         lap_variant<8, 64>(in, out, dI, dJ, dK, tag);
@@ -255,17 +264,18 @@ static void section_lap() {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename W, int VEC, int LJ, int PF>
+template <typename T, typename W, int VEC, int LJ, int PF, int XCDG = 0>
 static void hdiff_variant(const DevField<T>& in, DevField<T>& out, const DevField<T>& cf, int dI, int dJ, int dK, const char* tag,
                           double bpl) {
     constexpr int H = (VEC >= 2) ? 1 : 2;
     const unsigned waves_i = (unsigned)cdiv(dI, (64 - 2 * H) * VEC), tiles_j = (unsigned)cdiv(dJ, LJ);
-    const unsigned nw = waves_i * tiles_j * dK;
+    const unsigned groups_j = (unsigned)cdiv(tiles_j, 4);
+    const unsigned nb = waves_i * groups_j * dK;
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%s jmarch VEC=%d LJ=%d PF=%d waves=%u", tag, VEC, LJ, PF, nw);
+    snprintf(cfg, sizeof cfg, "%s jmarch VEC=%d LJ=%d PF=%d xcd=%d", tag, VEC, LJ, PF, XCDG);
     const double ms = time_ms([&](int) {
-        hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, W, true, true, VEC, LJ, PF>), dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, 0,
-                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, nw);
+        hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, W, true, true, VEC, LJ, PF, XCDG>), dim3(nb), dim3(256), 0, 0,
+                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, groups_j);
     }, 20);
     report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, bpl);
 }
@@ -289,31 +299,34 @@ static void hdiff_suite(int dI, int dJ, int dK, const char* tag) {
         snprintf(cfg, sizeof cfg, "%s generic (one thread per point)", tag);
         report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, bpl);
     }
-    hdiff_variant<T, W, VMAX, 32, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, VMAX, 12, 6, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
     printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
     CK(hipMemset(out.raw, 0, out.bytes));
-    hdiff_variant<T, W, 1, 32, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+    hdiff_variant<T, W, 1, 8, 8, 0>(in, out, cf, dI, dJ, dK, tag, bpl);
     printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
-    CK(hipMemset(out.raw, 0, out.bytes));
-    hdiff_variant<T, W, 2, 32, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
-    printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
-    hdiff_variant<T, W, VMAX, 16, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 64, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 32, 1>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 32, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 16, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, 2, 16, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, 2, 16, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, 2, 64, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 8, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 8, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 12, 6>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 16, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 16, 16>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 24, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, VMAX, 32, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, 2, 8, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
-    hdiff_variant<T, W, 2, 16, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
+    for (int rep = 0; rep < 2; ++rep) {
+        hdiff_variant<T, W, VMAX, 8, 8, 0>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 8, 8, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 8, 8, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 8, 8, 8>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 12, 6, 0>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 12, 6, 2>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 12, 6, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 12, 12, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 16, 8, 0>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 16, 8, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 16, 16, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, VMAX, 6, 6, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+        hdiff_variant<T, W, 2, 8, 8, 4>(in, out, cf, dI, dJ, dK, tag, bpl);
+    }
+    {
+        const int64_t d[3] = {dI, dJ, dK};
+        const double ms = time_ms([&](int) { hdiff_launch<T, W, W, true, true>(in.cview(), out.view(), cf.cview(), (W)0, d, 0); }, 20);
+        char cfg[64];
+        snprintf(cfg, sizeof cfg, "%s library default", tag);
+        report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, bpl);
+        printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+    }
 }
 
 static void section_hdiff() {
@@ -392,6 +405,7 @@ int main(int argc, char** argv) {
     if (on("dpp")) ok &= section_dpp();
     if (on("copy")) section_copy();
     if (on("lap")) section_lap();
+    if (!want.empty() && on("lap512")) lap_suite(512, 512, 512, 0, "512^3");
     if (on("hdiff")) section_hdiff();
     if (on("tridiag")) section_tridiag();
     return ok ? 0 : 1;

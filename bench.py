@@ -139,7 +139,18 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-selfloop", action="store_true",
+                    help="1-GPU rehearsal of the N>1 step: periodic-in-J domain whose halo messages go to the "
+                         "rank itself through RCCL (not the headline metric)")
+    ap.add_argument("--selfloop-ranks", type=int, default=1,
+                    help="with --dist-selfloop: shrink J to 512/N, the per-rank share of an N-GPU run")
     args = ap.parse_args()
+
+    # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on
+    # stdout, so everything else is routed to stderr until the final print.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,13 +170,16 @@ def main() -> None:
 
     from gt4py_amd import _lib
     from gt4py_amd.cartesian import gtscript
-    from gt4py_amd.distributed import Decomposition, HaloExchanger, choose_process_grid, overlapped_apply
+    from gt4py_amd.distributed import (Decomposition, HaloExchanger, NativeComm, NativeHaloExchanger,
+                                       choose_process_grid, overlapped_apply)
+
+    decomposed = distributed or args.dist_selfloop
 
     lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64},
                            device_sync=False)
     origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}
 
-    if not distributed:
+    if not decomposed:
         shape = (GRID[0] + 2, GRID[1] + 2, GRID[2])
         pairs = _device_fields(shape, n_pairs=2, seed=1337)  # rotate pairs: nothing survives in MALL/L2
         frozen = lap.freeze(origin=origin, domain=GRID)
@@ -180,16 +194,29 @@ def main() -> None:
                               "origin (1,1,0), hip:mi300 storage layout", "grid": list(GRID), "decomposition": "1x1",
                   "call_path": "FrozenStencil"}
     else:
-        grid = choose_process_grid(world, GRID)
-        dec = Decomposition(GRID, grid, rank, halo=1)
+        selfloop = args.dist_selfloop and world == 1
+        grid = (1, 1) if selfloop else choose_process_grid(world, GRID)
+        total = (GRID[0], GRID[1] // max(args.selfloop_ranks, 1), GRID[2]) if selfloop else GRID
+        dec = Decomposition(total, grid, rank, halo=1, periodic=(False, True) if selfloop else (False, False))
         pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank)
-        exchangers = [HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank)) for _ in pairs]
         local_domain = dec.local_domain
         frozen = lap.freeze(origin=origin, domain=local_domain)
+        transport = os.environ.get("GT4MI_BENCH_COMM", "native")
+        if transport == "native":
+            # whole step (pack, RCCL send/recv, unpack, interior, strips, 2 streams) = one C call
+            comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
+            exchangers = [NativeHaloExchanger(dec, np.float64, comm) for _ in pairs]
+            steps_bound = [ex.make_dist_lap5(inp, out, origin["inp"], origin["out"]) for ex, (inp, out) in
+                           zip(exchangers, pairs)]
 
-        def step(i):
-            inp, out = pairs[i % len(pairs)]
-            overlapped_apply(lap, dec, origin, {"inp": inp, "out": out}, {"inp": exchangers[i % len(pairs)]})
+            def step(i):
+                steps_bound[i % len(pairs)]()
+        else:  # torch.distributed point-to-point ops driven from Python
+            exchangers = [HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank)) for _ in pairs]
+
+            def step(i):
+                inp, out = pairs[i % len(pairs)]
+                overlapped_apply(lap, dec, origin, {"inp": inp, "out": out}, {"inp": exchangers[i % len(pairs)]})
 
         def kernel_step(i):  # the local kernel alone, for the per-GPU roofline figure
             inp, out = pairs[i % len(pairs)]
@@ -198,7 +225,8 @@ def main() -> None:
         config = {"workload": "fp64 5-point Laplacian 512x512x512 split over ranks (strong scaling), halo 1 exchanged "
                               "every step with RCCL send/recv overlapped with the interior kernel",
                   "grid": list(GRID), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(local_domain),
-                  "halo_bytes_per_rank_per_step": exchangers[0].bytes_per_exchange}
+                  "halo_bytes_per_rank_per_step": exchangers[0].bytes_per_exchange, "transport": transport,
+                  "selfloop": bool(selfloop)}
 
     def barrier():
         if distributed:
@@ -224,10 +252,11 @@ def main() -> None:
     local_lups = float(np.prod(local_domain))
     achieved = BYTES_PER_LUP * local_lups / (kernel_ms * 1e-3) / 1e9
     ms_per_step = elapsed / args.steps * 1e3
-    glups = float(np.prod(GRID)) * args.steps / elapsed / 1e9
+    total_lups = float(np.prod(dec.global_domain)) if decomposed else float(np.prod(GRID))
+    glups = total_lups * args.steps / elapsed / 1e9
 
     if rank == 0:
-        traffic = _committed_traffic("lap5_f64_512") if not distributed else None
+        traffic = _committed_traffic("lap5_f64_512") if not decomposed else None
         line = {
             "metric": "GLUPS (lattice updates/s) fp64 5-pt Laplacian 512^3",
             "value": round(glups, 2),
@@ -256,13 +285,16 @@ def main() -> None:
             },
             "device": _lib.device_info(),
         }
-        if not distributed and not args.no_cpu_baseline:
+        if not decomposed and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = None
                 print(f"cpu_baseline failed: {ex!r}", file=sys.stderr)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)  # anything native code prints while tearing down goes to stderr again
     if distributed:
         dist.destroy_process_group()
 

@@ -33,6 +33,16 @@ EXPORTED_SYMBOLS = (
     "gt4mi_tridiag_f32",
     "gt4mi_halo_pack",
     "gt4mi_halo_unpack",
+    "gt4mi_comm_unique_id",
+    "gt4mi_comm_create",
+    "gt4mi_comm_destroy",
+    "gt4mi_halo_plan_create",
+    "gt4mi_halo_plan_destroy",
+    "gt4mi_halo_exchange",
+    "gt4mi_halo_exchange_begin",
+    "gt4mi_halo_exchange_fork",
+    "gt4mi_halo_exchange_end",
+    "gt4mi_dist_lap5_f64",
     "gt4mi_stream_copy",
 )
 
@@ -70,6 +80,16 @@ class Field(ctypes.Structure):
             raise ValueError("gt4mi_field describes exactly three axes (I, J, K)")
         return cls(ctypes.c_void_p(ptr), _Int3(*map(int, shape)), _Int3(*map(int, strides)),
                    _Int3(*map(int, origin)))
+
+
+class HaloMsg(ctypes.Structure):
+    """``gt4mi_halo_msg``: one box sent to / received from ``peer`` in ``phase`` 0 (I faces) or 1 (J faces)."""
+
+    _fields_ = [("peer", ctypes.c_int32), ("phase", ctypes.c_int32), ("lo", _Int3), ("extent", _Int3)]
+
+    @classmethod
+    def make(cls, peer: int, phase: int, lo: Sequence[int], extent: Sequence[int]) -> "HaloMsg":
+        return cls(int(peer), int(phase), _Int3(*map(int, lo)), _Int3(*map(int, extent)))
 
 
 class ExecInfo(ctypes.Structure):
@@ -121,6 +141,28 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_halo_unpack.argtypes = [FP, DOM, DOM, P, I, P]
     lib.gt4mi_stream_copy.restype = I
     lib.gt4mi_stream_copy.argtypes = [P, P, ctypes.c_size_t, P]
+    MP = ctypes.POINTER(HaloMsg)
+    PP = ctypes.POINTER(ctypes.c_void_p)
+    lib.gt4mi_comm_unique_id.restype = I
+    lib.gt4mi_comm_unique_id.argtypes = [P]
+    lib.gt4mi_comm_create.restype = I
+    lib.gt4mi_comm_create.argtypes = [P, I, I, PP]
+    lib.gt4mi_comm_destroy.restype = I
+    lib.gt4mi_comm_destroy.argtypes = [P]
+    lib.gt4mi_halo_plan_create.restype = I
+    lib.gt4mi_halo_plan_create.argtypes = [P, I, MP, I, MP, I, PP]
+    lib.gt4mi_halo_plan_destroy.restype = I
+    lib.gt4mi_halo_plan_destroy.argtypes = [P]
+    lib.gt4mi_halo_exchange.restype = I
+    lib.gt4mi_halo_exchange.argtypes = [P, FP, P]
+    lib.gt4mi_halo_exchange_begin.restype = I
+    lib.gt4mi_halo_exchange_begin.argtypes = [P, FP, P]
+    lib.gt4mi_halo_exchange_end.restype = I
+    lib.gt4mi_halo_exchange_end.argtypes = [P, P]
+    lib.gt4mi_halo_exchange_fork.restype = I
+    lib.gt4mi_halo_exchange_fork.argtypes = [P, P]
+    lib.gt4mi_dist_lap5_f64.restype = I
+    lib.gt4mi_dist_lap5_f64.argtypes = [P, DOM, FP, FP, I, I, P]
 
 
 def load() -> ctypes.CDLL:

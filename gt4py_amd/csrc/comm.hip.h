@@ -1,0 +1,211 @@
+// RCCL halo exchange driven from native code -- NEW: gt4py.cartesian has no communication layer
+// (SURVEY.md section 8e).  One process per GPU; the communicator is created from a 128-byte unique id
+// that the host side distributes (torch.distributed / any launcher).
+//
+// Why native: at 8 GPUs a 512^3 fp64 Laplacian step is ~45 us of kernel time per GPU; issuing pack,
+// 4 point-to-point operations, unpack and 3-5 kernel launches from Python costs several times that.
+// Here one C call enqueues the whole step on two HIP streams:
+//
+//   comm stream : wait(main) -> pack faces -> ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd (I faces)
+//                 -> unpack -> same for J faces (including fresh I-halo columns => corners) -> record
+//   main stream : interior kernel ......................................... wait(comm) -> strips
+//
+// xGMI is point-to-point, messages are <= 2 MB: the exchange is latency-bound, every neighbour uses
+// its own link, and there is no collective on the path.
+//
+// librccl is resolved with dlopen at first use (the copy PyTorch already loaded is reused when
+// present), so the stencil library itself loads on machines without RCCL.
+#pragma once
+
+#include <dlfcn.h>
+
+#include <vector>
+
+#include "common.hip.h"
+#include "halo.hip.h"
+
+namespace gt4mi {
+
+// ---- minimal RCCL surface (names and ABI of <rccl/rccl.h>) ---------------------------------------
+struct RcclUniqueId { char internal[128]; };
+typedef void* RcclComm;
+enum { RCCL_UINT8 = 1 };  // ncclUint8 / ncclChar = 1 in nccl.h's ncclDataType_t (ncclInt8 = 0)
+
+struct RcclApi {
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+inline RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // already in the process (PyTorch)?
+            if (h) break;
+        }
+        if (!h)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
+        if (!h) return a;
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+        a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
+        return a;
+    }();
+    return api;
+}
+
+#define GT4MI_RCCL_CHECK(expr)                                                                      \
+    do {                                                                                            \
+        int _r = (expr);                                                                            \
+        if (_r != 0)                                                                                \
+            return ::gt4mi::fail(GT4MI_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                     \
+                                 ::gt4mi::rccl().GetErrorString ? ::gt4mi::rccl().GetErrorString(_r) \
+                                                                : "rccl error",                    \
+                                 __FILE__, __LINE__);                                               \
+    } while (0)
+
+}  // namespace gt4mi
+
+// ---- opaque objects of the C ABI -----------------------------------------------------------------
+struct gt4mi_comm {
+    gt4mi::RcclComm comm = nullptr;
+    int nranks = 0, rank = 0;
+};
+
+struct gt4mi_halo_plan {
+    gt4mi_comm* comm = nullptr;
+    int elem_size = 8;
+    struct Msg {
+        int peer;
+        int64_t lo[3], ext[3];
+        size_t bytes;
+        void* buffer;
+    };
+    std::vector<Msg> sends[2], recvs[2];  // [phase]
+    hipStream_t stream = nullptr;         // side stream the exchange runs on in the overlapped form
+    hipEvent_t ready = nullptr, done = nullptr;
+    bool forked = false;                  // `ready` already recorded by gt4mi_halo_exchange_fork
+};
+
+namespace gt4mi {
+
+// All boxes of one phase are packed (or unpacked) by ONE launch: blockIdx.y selects the box.  The
+// exchange is latency-bound, so launches on its critical path are what matters.
+struct BoxBatch {
+    static constexpr int MAX = 4;
+    int n;
+    int64_t offset[MAX];  // element offset of the box start inside the field
+    int ext[MAX][3];
+    void* buffer[MAX];
+};
+
+template <typename U, bool PACK>
+__global__ void __launch_bounds__(256)
+halo_batch_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b) {
+    const int m = blockIdx.y;
+    const int ei = b.ext[m][0], ej = b.ext[m][1], ek = b.ext[m][2];
+    const int64_t n = (int64_t)ei * ej * ek;
+    U* base = field + b.offset[m];
+    U* buf = static_cast<U*>(b.buffer[m]);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const int i = (int)(t % ei);
+        const int64_t r = t / ei;
+        const int j = (int)(r % ej);
+        const int k = (int)(r / ej);
+        U* f = base + i * si + j * sj + k * sk;
+        if constexpr (PACK) buf[t] = *f;
+        else *f = buf[t];
+    }
+}
+
+template <typename U, bool PACK>
+inline int plan_copy_batch(const gt4mi_field* f, const std::vector<gt4mi_halo_plan::Msg>& msgs, hipStream_t s) {
+    if (msgs.empty()) return GT4MI_OK;
+    if ((int)msgs.size() > BoxBatch::MAX) return fail(GT4MI_ERR_UNSUPPORTED, "halo: more than %d boxes per phase", BoxBatch::MAX);
+    BoxBatch b;
+    b.n = (int)msgs.size();
+    int64_t nmax = 0;
+    for (int m = 0; m < b.n; ++m) {
+        int64_t off = 0, n = 1;
+        for (int a = 0; a < 3; ++a) {
+            if (msgs[m].lo[a] + msgs[m].ext[a] > f->shape[a])
+                return fail(GT4MI_ERR_OUT_OF_BOUNDS, "halo: box [%lld, %lld) outside of axis %d (size %lld)",
+                            (long long)msgs[m].lo[a], (long long)(msgs[m].lo[a] + msgs[m].ext[a]), a, (long long)f->shape[a]);
+            if (f->stride[a] % (int64_t)sizeof(U) != 0) return fail(GT4MI_ERR_UNSUPPORTED, "halo: stride not a multiple of the item size");
+            off += msgs[m].lo[a] * (f->stride[a] / (int64_t)sizeof(U));
+            b.ext[m][a] = (int)msgs[m].ext[a];
+            n *= msgs[m].ext[a];
+        }
+        b.offset[m] = off;
+        b.buffer[m] = msgs[m].buffer;
+        nmax = n > nmax ? n : nmax;
+    }
+    if (nmax == 0) return GT4MI_OK;
+    int64_t blocks = cdiv(nmax, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((halo_batch_kernel<U, PACK>), dim3((unsigned)blocks, (unsigned)b.n), dim3(256), 0, s,
+                       static_cast<U*>(f->data), f->stride[0] / (int64_t)sizeof(U), f->stride[1] / (int64_t)sizeof(U),
+                       f->stride[2] / (int64_t)sizeof(U), b);
+    GT4MI_HIP_CHECK(hipGetLastError());
+    return GT4MI_OK;
+}
+
+template <bool PACK>
+inline int plan_copy(const gt4mi_halo_plan* plan, const gt4mi_field* f, const std::vector<gt4mi_halo_plan::Msg>& msgs,
+                     hipStream_t s) {
+    if (plan->elem_size == 8) return plan_copy_batch<uint64_t, PACK>(f, msgs, s);
+    return plan_copy_batch<uint32_t, PACK>(f, msgs, s);
+}
+
+inline int first_phase(const gt4mi_halo_plan* plan) {
+    for (int phase = 0; phase < 2; ++phase)
+        if (!plan->sends[phase].empty() || !plan->recvs[phase].empty()) return phase;
+    return 2;
+}
+
+// Pack the faces of the first non-empty phase only (they depend on nothing but the field itself,
+// so a caller can enqueue this ahead of its interior kernel).
+inline int halo_pack_first(gt4mi_halo_plan* plan, const gt4mi_field* field, hipStream_t s) {
+    const int p = first_phase(plan);
+    if (p > 1) return GT4MI_OK;
+    return plan_copy<true>(plan, field, plan->sends[p], s);
+}
+
+// Enqueue the two-phase exchange of `field`'s ghost cells on stream `s`.
+inline int halo_exchange_on(gt4mi_halo_plan* plan, const gt4mi_field* field, hipStream_t s,
+                            bool first_pack_done = false) {
+    RcclApi& api = rccl();
+    const int p0 = first_phase(plan);
+    for (int phase = 0; phase < 2; ++phase) {
+        auto& sends = plan->sends[phase];
+        auto& recvs = plan->recvs[phase];
+        if (sends.empty() && recvs.empty()) continue;
+        if (!(first_pack_done && phase == p0))
+            if (int rc = plan_copy<true>(plan, field, sends, s)) return rc;
+        GT4MI_RCCL_CHECK(api.GroupStart());
+        for (auto& m : sends) GT4MI_RCCL_CHECK(api.Send(m.buffer, m.bytes, RCCL_UINT8, m.peer, plan->comm->comm, s));
+        for (auto& m : recvs) GT4MI_RCCL_CHECK(api.Recv(m.buffer, m.bytes, RCCL_UINT8, m.peer, plan->comm->comm, s));
+        GT4MI_RCCL_CHECK(api.GroupEnd());
+        if (int rc = plan_copy<false>(plan, field, recvs, s)) return rc;
+    }
+    return GT4MI_OK;
+}
+
+}  // namespace gt4mi

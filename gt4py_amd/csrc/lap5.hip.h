@@ -51,17 +51,10 @@ __device__ __forceinline__ T lap5_expr(T c, T w, T e, T s, T n) {
     }
 }
 
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG = 0>
-__global__ void __launch_bounds__(BLOCK)
-lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x, unsigned tiles_y) {
-    // XCDG > 0: runs of XCDG consecutive strips share an XCD (private L2), so the halo rows they
-    // share are L2 hits instead of a second fabric fetch.  XCDG = -1: one contiguous range per XCD.
-    unsigned b = blockIdx.x;
-    if constexpr (XCDG > 0) b = xcd_remap_grouped<(unsigned)XCDG>(b, gridDim.x);
-    if constexpr (XCDG < 0) b = xcd_remap(b, gridDim.x);
-    const unsigned bx = b % tiles_x;
-    const unsigned by = (b / tiles_x) % tiles_y;
-    const unsigned k = b / (tiles_x * tiles_y);
+// One strip: columns [bx*BLOCK*VEC, ...) x rows [j0, min(j0+LJ, dJ)) of level k.
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK>
+__device__ __forceinline__ void lap5_strip_tile(const View<const T>& in, const View<T>& out, int dI, int dJ,
+                                                unsigned bx, int j0, unsigned k) {
     const unsigned lane = threadIdx.x & 63;
 
     // Lanes past the end of the row stay active (DPP needs their neighbours' exec bits) but are
@@ -69,7 +62,6 @@ lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_
     int i0 = (int)(bx * BLOCK + threadIdx.x) * VEC;
     const bool active = i0 < dI;
     if (!active) i0 = dI - VEC;
-    const int j0 = (int)by * LJ;
     const bool edge_w = lane == 0;
     const bool edge_e = (lane == 63) || (i0 + VEC >= dI);
 
@@ -108,6 +100,33 @@ lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_
         }
         if (active && (j0 + t - 1 < dJ)) vstore<T, VEC, true>(ocol + (int64_t)(j0 + t - 1) * out.sj, res);
     }
+}
+
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG = 0>
+__global__ void __launch_bounds__(BLOCK)
+lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x, unsigned tiles_y) {
+    // XCDG > 0: runs of XCDG consecutive strips share an XCD (private L2), so the halo rows they
+    // share are L2 hits instead of a second fabric fetch.  XCDG = -1: one contiguous range per XCD.
+    unsigned b = blockIdx.x;
+    if constexpr (XCDG > 0) b = xcd_remap_grouped<(unsigned)XCDG>(b, gridDim.x);
+    if constexpr (XCDG < 0) b = xcd_remap(b, gridDim.x);
+    const unsigned bx = b % tiles_x;
+    const unsigned by = (b / tiles_x) % tiles_y;
+    const unsigned k = b / (tiles_x * tiles_y);
+    lap5_strip_tile<T, W, VARIANT, VEC, LJ, BLOCK>(in, out, dI, dJ, bx, (int)by * LJ, k);
+}
+
+// Up to two single J rows (row_a, row_b) of every level in ONE launch: the boundary strips of a
+// J-decomposed domain, which wait for the halo exchange (gt4mi_dist_lap5_f64).
+template <typename T, typename W, int VARIANT, int VEC, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+lap5_rows_kernel(View<const T> in, View<T> out, int dI, int row_a, int row_b, unsigned tiles_x, unsigned nrows) {
+    const unsigned b = blockIdx.x;
+    const unsigned bx = b % tiles_x;
+    const unsigned r = (b / tiles_x) % nrows;
+    const unsigned k = b / (tiles_x * nrows);
+    const int j = r == 0 ? row_a : row_b;
+    lap5_strip_tile<T, W, VARIANT, VEC, 1, BLOCK>(in, out, dI, j + 1, bx, j, k);
 }
 
 // Any-stride fallback: one thread per point, I fastest across lanes.  Correct for every layout the
@@ -189,6 +208,54 @@ inline int lap5_run(const int64_t domain[3], const gt4mi_field* inp, const gt4mi
     }
     if (rc) return rc;
     GT4MI_HIP_CHECK(hipGetLastError());
+    return GT4MI_OK;
+}
+
+// Rows row_a (and row_b when nrows == 2) of the compute domain, all K levels, in one launch.
+// Falls back to per-row lap5_run calls when the fields do not qualify for the vector path.
+template <typename T, typename W, int VARIANT>
+inline int lap5_rows_variant(const View<const T>& in, const View<T>& out, const int64_t d[3], int row_a, int row_b,
+                             int nrows, hipStream_t stream, bool* done) {
+    constexpr int VMAX = 16 / sizeof(T);
+    *done = false;
+    if (!(in.si == 1 && out.si == 1 && vec_ok(in, VMAX) && vec_ok(out, VMAX) && d[0] % VMAX == 0)) return GT4MI_OK;
+    const unsigned tx = (unsigned)cdiv(d[0], (int64_t)256 * VMAX);
+    hipLaunchKernelGGL((lap5_rows_kernel<T, W, VARIANT, VMAX, 256>), dim3(tx * (unsigned)nrows * (unsigned)d[2]), dim3(256), 0,
+                       stream, in, out, (int)d[0], row_a, row_b, tx, (unsigned)nrows);
+    *done = true;
+    return GT4MI_OK;
+}
+
+template <typename T, typename W>
+inline int lap5_run_rows(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* outf, int variant,
+                         int row_a, int row_b, int nrows, hipStream_t stream) {
+    if (nrows <= 0 || domain[0] <= 0 || domain[2] <= 0) return GT4MI_OK;
+    if (int rc = check_domain(domain)) return rc;
+    const int h1[3] = {1, 1, 0}, h0[3] = {0, 0, 0};
+    View<T> in_v, out_v;
+    if (int rc = make_view<T>("inp", inp, domain, h1, h1, &in_v)) return rc;
+    if (int rc = make_view<T>("out", outf, domain, h0, h0, &out_v)) return rc;
+    View<const T> in_c{in_v.p, in_v.si, in_v.sj, in_v.sk};
+    bool done = false;
+    switch (variant) {
+        case GT4MI_LAP_NOTEBOOK: lap5_rows_variant<T, W, GT4MI_LAP_NOTEBOOK>(in_c, out_v, domain, row_a, row_b, nrows, stream, &done); break;
+        case GT4MI_LAP_DOCS: lap5_rows_variant<T, W, GT4MI_LAP_DOCS>(in_c, out_v, domain, row_a, row_b, nrows, stream, &done); break;
+        case GT4MI_LAP_SUITE: lap5_rows_variant<T, W, GT4MI_LAP_SUITE>(in_c, out_v, domain, row_a, row_b, nrows, stream, &done); break;
+        case GT4MI_LAP_AVG: lap5_rows_variant<T, W, GT4MI_LAP_AVG>(in_c, out_v, domain, row_a, row_b, nrows, stream, &done); break;
+        default: return fail(GT4MI_ERR_INVALID_ARGUMENT, "lap5: unknown variant %d", variant);
+    }
+    if (done) {
+        GT4MI_HIP_CHECK(hipGetLastError());
+        return GT4MI_OK;
+    }
+    for (int r = 0; r < nrows; ++r) {  // generic layouts: one ordinary launch per row
+        gt4mi_field a = *inp, b = *outf;
+        const int j = r == 0 ? row_a : row_b;
+        a.origin[1] += j;
+        b.origin[1] += j;
+        const int64_t d1[3] = {domain[0], 1, domain[2]};
+        if (int rc = lap5_run<T, W>(d1, &a, &b, variant, stream)) return rc;
+    }
     return GT4MI_OK;
 }
 

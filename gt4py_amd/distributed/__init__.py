@@ -7,9 +7,11 @@ from __future__ import annotations
 
 from typing import Any, Dict, Mapping, Sequence
 
-from .halo import Decomposition, HaloExchanger, HipPacker, choose_process_grid, scatter_global
+from .halo import Decomposition, HaloExchanger, HipPacker, choose_process_grid, halo_boxes, scatter_global
+from .native import NativeComm, NativeHaloExchanger
 
-__all__ = ["Decomposition", "HaloExchanger", "HipPacker", "choose_process_grid", "overlapped_apply", "scatter_global"]
+__all__ = ["Decomposition", "HaloExchanger", "HipPacker", "NativeComm", "NativeHaloExchanger", "choose_process_grid",
+           "halo_boxes", "overlapped_apply", "scatter_global"]
 
 
 def _shifted(origin: Mapping[str, Sequence[int]], shift: Sequence[int]) -> Dict[str, tuple]:
@@ -30,11 +32,23 @@ def overlapped_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequen
     ``arguments`` holds the device arrays / scalars by parameter name; ``origin`` the per-field origin
     of the LOCAL compute domain.
     """
-    events = [(ex, ex.start(arguments[name].tensor)) for name, ex in exchange.items()]
+    events = []
+    native = [(name, ex) for name, ex in exchange.items() if isinstance(ex, NativeHaloExchanger)]
+    for name, ex in exchange.items():
+        if not isinstance(ex, NativeHaloExchanger):
+            events.append((ex, ex.start(arguments[name].tensor)))
+    for _, ex in native:  # fork first, enqueue the exchange after the interior kernel (GPU busy meanwhile)
+        ex.fork()
     (shift, sub), strips = decomp.interior_and_strips()
     if all(d > 0 for d in sub):
         stencil.run(_domain_=tuple(sub), _origin_=_shifted(origin, shift), exec_info=None, **arguments)
+    for name, ex in native:  # pack + RCCL + unpack on the side stream inside one C call
+        ex.begin(arguments[name])
+        events.append((ex, None))
     for ex, done in events:
-        ex.finish(done)
+        if done is None:
+            ex.end()
+        else:
+            ex.finish(done)
     for shift, sub in strips:
         stencil.run(_domain_=tuple(sub), _origin_=_shifted(origin, shift), exec_info=None, **arguments)

@@ -69,12 +69,19 @@ class Decomposition:
     grid: Tuple[int, int]
     rank: int
     halo: int
+    #: periodic wrap-around in (I, J); default False = physical boundary (ghost cells untouched,
+    #: as the reference leaves halos untouched -- SURVEY.md section 8a N4)
+    periodic: Tuple[bool, bool] = (False, False)
 
     @property
     def coords(self) -> Tuple[int, int]:
         return self.rank % self.grid[0], self.rank // self.grid[0]  # I fastest
 
     def rank_of(self, ci: int, cj: int) -> Optional[int]:
+        if self.periodic[0]:
+            ci %= self.grid[0]
+        if self.periodic[1]:
+            cj %= self.grid[1]
         if 0 <= ci < self.grid[0] and 0 <= cj < self.grid[1]:
             return cj * self.grid[0] + ci
         return None
@@ -164,8 +171,39 @@ class HipPacker:
         self._lib_mod.check("gt4mi_halo_unpack", rc)
 
 
+Box = Tuple[int, Tuple[int, int, int], Tuple[int, int, int], Tuple[int, int, int]]
+
+
+def halo_boxes(decomp: Decomposition) -> List[List[Box]]:
+    """Per phase, the (peer, send_lo, recv_lo, extent) boxes of this rank in LOCAL array indices,
+    low side first.
+
+    Phase 0, I faces: they span the owned rows plus the halo rows on sides WITHOUT a J neighbour --
+    those rows hold physical-boundary data the neighbour's corner reads need; halo rows on sides with
+    a J neighbour are not valid yet and arrive (I-halo columns included) in phase 1.
+    Phase 1, J faces over the full I extent including the halo columns -> corners travel with them.
+    """
+    h = decomp.halo
+    di, dj, dk = decomp.local_domain
+    si = decomp.local_shape[0]
+    nb = decomp.neighbours
+    phases: List[List[Box]] = [[], []]
+    j_lo = 0 if nb["S"] is None else h
+    j_hi = dj + 2 * h if nb["N"] is None else dj + h
+    if nb["W"] is not None:
+        phases[0].append((nb["W"], (h, j_lo, 0), (0, j_lo, 0), (h, j_hi - j_lo, dk)))
+    if nb["E"] is not None:
+        phases[0].append((nb["E"], (di, j_lo, 0), (di + h, j_lo, 0), (h, j_hi - j_lo, dk)))
+    if nb["S"] is not None:
+        phases[1].append((nb["S"], (0, h, 0), (0, 0, 0), (si, h, dk)))
+    if nb["N"] is not None:
+        phases[1].append((nb["N"], (0, dj, 0), (0, dj + h, 0), (si, h, dk)))
+    return phases
+
+
 class HaloExchanger:
-    """Persistent-buffer halo exchange of one field shape/dtype for one rank."""
+    """Halo exchange of one field shape/dtype for one rank through ``torch.distributed`` point-to-point
+    operations (RCCL on GPUs, gloo in the CPU tests), with persistent staging buffers."""
 
     def __init__(self, decomp: Decomposition, dtype, device, packer=None, group=None):
         self.decomp = decomp
@@ -173,54 +211,37 @@ class HaloExchanger:
         self.device = torch.device(device)
         self.packer = packer if packer is not None else HipPacker()
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        h = decomp.halo
-        di, dj, dk = decomp.local_domain
-        si, sj, _ = decomp.local_shape
-        nb = decomp.neighbours
-        # boxes in local array coordinates: (send_lo, recv_lo, extent)
-        self.phases: List[List[Tuple[int, Tuple[int, int, int], Tuple[int, int, int], Tuple[int, int, int]]]] = [[], []]
-        # I faces span the owned rows plus the halo rows on sides WITHOUT a J neighbour: those rows
-        # hold physical-boundary data the neighbour's corner reads need; halo rows on sides with a
-        # J neighbour are not valid yet and arrive (I-halo columns included) in phase 2.
-        j_lo = 0 if nb["S"] is None else h
-        j_hi = dj + 2 * h if nb["N"] is None else dj + h
-        if nb["W"] is not None:
-            self.phases[0].append((nb["W"], (h, j_lo, 0), (0, j_lo, 0), (h, j_hi - j_lo, dk)))
-        if nb["E"] is not None:
-            self.phases[0].append((nb["E"], (di, j_lo, 0), (di + h, j_lo, 0), (h, j_hi - j_lo, dk)))
-        if nb["S"] is not None:  # full I extent incl. halo columns -> corners travel in phase 2
-            self.phases[1].append((nb["S"], (0, h, 0), (0, 0, 0), (si, h, dk)))
-        if nb["N"] is not None:
-            self.phases[1].append((nb["N"], (0, dj, 0), (0, dj + h, 0), (si, h, dk)))
+        self.phases = halo_boxes(decomp)
         self.buffers = {}
-        for phase in self.phases:
-            for peer, _, _, ext in phase:
+        for p, phase in enumerate(self.phases):
+            for m, (_, _, _, ext) in enumerate(phase):
                 n = int(np.prod(ext))
-                self.buffers[(peer, "send")] = torch.empty(n, dtype=dtype, device=self.device)
-                self.buffers[(peer, "recv")] = torch.empty(n, dtype=dtype, device=self.device)
+                self.buffers[(p, m, "send")] = torch.empty(n, dtype=dtype, device=self.device)
+                self.buffers[(p, m, "recv")] = torch.empty(n, dtype=dtype, device=self.device)
 
     @property
     def bytes_per_exchange(self) -> int:
-        return sum(b.numel() * b.element_size() for (_, kind), b in self.buffers.items() if kind == "send")
+        return sum(b.numel() * b.element_size() for key, b in self.buffers.items() if key[2] == "send")
 
-    def _run_phase(self, tensor, phase) -> None:
+    def _run_phase(self, tensor, p: int) -> None:
+        phase = self.phases[p]
         if not phase:
             return
         ops = []
-        for peer, send_lo, _, ext in phase:
-            self.packer.pack(tensor, send_lo, ext, self.buffers[(peer, "send")])
-        for peer, _, _, _ in phase:
-            ops.append(dist.P2POp(dist.isend, self.buffers[(peer, "send")], peer, self.group))
-            ops.append(dist.P2POp(dist.irecv, self.buffers[(peer, "recv")], peer, self.group))
+        for m, (_, send_lo, _, ext) in enumerate(phase):
+            self.packer.pack(tensor, send_lo, ext, self.buffers[(p, m, "send")])
+        for m, (peer, _, _, _) in enumerate(phase):
+            ops.append(dist.P2POp(dist.isend, self.buffers[(p, m, "send")], peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, self.buffers[(p, m, "recv")], peer, self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        for peer, _, recv_lo, ext in phase:
-            self.packer.unpack(tensor, recv_lo, ext, self.buffers[(peer, "recv")])
+        for m, (_, _, recv_lo, ext) in enumerate(phase):
+            self.packer.unpack(tensor, recv_lo, ext, self.buffers[(p, m, "recv")])
 
     def exchange(self, tensor) -> None:
         """Blocking (stream-ordered on GPU) exchange of ``tensor``'s halo on the CURRENT stream."""
-        for phase in self.phases:
-            self._run_phase(tensor, phase)
+        for p in range(len(self.phases)):
+            self._run_phase(tensor, p)
 
     def start(self, tensor):
         """Launch the exchange on the side stream; returns an event to wait on (GPU only)."""

@@ -1,0 +1,155 @@
+"""Halo exchange driven from native code: RCCL send/recv + pack/unpack + stream choreography inside
+``libgt4py_amd.so`` (``gt4mi_comm_*``, ``gt4mi_halo_plan_*``, ``gt4mi_halo_exchange*``,
+``gt4mi_dist_lap5_f64`` in include/gt4py_amd.h).
+
+The Python classes below only build the box tables once and then make ONE ctypes call per exchange
+(or per distributed stencil apply), which matters when a step is tens of microseconds of GPU time.
+NEW relative to the reference: gt4py.cartesian has no multi-device path.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .. import _lib
+from .halo import Decomposition, halo_boxes
+
+
+def _stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+class NativeComm:
+    """An RCCL communicator owned by libgt4py_amd (one rank per process/GPU).
+
+    The 128-byte unique id is created on rank 0 and broadcast through ``torch.distributed`` when a
+    process group is initialised (any launcher would do); a single-process run needs no group.
+    """
+
+    def __init__(self, rank: Optional[int] = None, world_size: Optional[int] = None, group=None):
+        lib = _lib.load()
+        if rank is None or world_size is None:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                rank, world_size = dist.get_rank(group), dist.get_world_size(group)
+            else:
+                rank, world_size = 0, 1
+        self.rank, self.world_size = int(rank), int(world_size)
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check("gt4mi_comm_unique_id", lib.gt4mi_comm_unique_id(uid))
+        if self.world_size > 1:
+            import torch.distributed as dist
+
+            box = [uid.raw if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        handle = ctypes.c_void_p()
+        _lib.check("gt4mi_comm_create", lib.gt4mi_comm_create(uid, self.world_size, self.rank, ctypes.byref(handle)))
+        self._handle = handle
+        self._lib = lib
+
+    @property
+    def handle(self) -> ctypes.c_void_p:
+        return self._handle
+
+    def close(self) -> None:
+        if self._handle is not None and self._handle.value:
+            self._lib.gt4mi_comm_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover - interpreter shutdown order
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _field_struct(array, origin=(0, 0, 0)) -> _lib.Field:
+    """gt4mi_field of a DeviceArray or torch tensor."""
+    if hasattr(array, "ptr"):
+        return _lib.Field.make(array.ptr, array.shape, array.strides, origin)
+    isz = array.element_size()
+    return _lib.Field.make(array.data_ptr(), tuple(array.shape), tuple(s * isz for s in array.stride()), origin)
+
+
+class NativeHaloExchanger:
+    """Two-phase ghost-cell exchange of one field shape through a native plan (see halo.halo_boxes)."""
+
+    def __init__(self, decomp: Decomposition, dtype, comm: NativeComm):
+        self.decomp = decomp
+        self.comm = comm
+        self.itemsize = np.dtype(dtype).itemsize
+        phases = halo_boxes(decomp)
+        sends, recvs = [], []
+        for p, phase in enumerate(phases):
+            for peer, send_lo, _, ext in phase:  # sends: low side first
+                sends.append(_lib.HaloMsg.make(peer, p, send_lo, ext))
+            # receives in the opposite side order: with a periodic 2-rank (or 1-rank) axis both
+            # messages go to the same peer, and the k-th send pairs with the k-th receive there --
+            # my low-side face must land in the peer's HIGH-side halo.
+            for peer, _, recv_lo, ext in reversed(phase):
+                recvs.append(_lib.HaloMsg.make(peer, p, recv_lo, ext))
+        self.bytes_per_exchange = sum(int(np.prod(tuple(m.extent))) for m in sends) * self.itemsize
+        SendArr, RecvArr = _lib.HaloMsg * max(len(sends), 1), _lib.HaloMsg * max(len(recvs), 1)
+        plan = ctypes.c_void_p()
+        lib = _lib.load()
+        _lib.check("gt4mi_halo_plan_create",
+                   lib.gt4mi_halo_plan_create(comm.handle, self.itemsize, SendArr(*sends), len(sends),
+                                              RecvArr(*recvs), len(recvs), ctypes.byref(plan)))
+        self._plan = plan
+        self._lib = lib
+        nb = decomp.neighbours
+        self.sides = ((1 if nb["W"] is not None else 0) | (2 if nb["E"] is not None else 0)
+                      | (4 if nb["S"] is not None else 0) | (8 if nb["N"] is not None else 0))
+
+    def exchange(self, array) -> None:
+        """Enqueue the exchange of ``array``'s ghost cells on the current stream."""
+        f = _field_struct(array)
+        _lib.check("gt4mi_halo_exchange", self._lib.gt4mi_halo_exchange(self._plan, ctypes.byref(f), _stream_ptr()))
+
+    def fork(self) -> None:
+        """Mark the fork point on the current stream; the next ``begin`` waits only for earlier work."""
+        _lib.check("gt4mi_halo_exchange_fork", self._lib.gt4mi_halo_exchange_fork(self._plan, _stream_ptr()))
+
+    def begin(self, array) -> None:
+        f = _field_struct(array)
+        _lib.check("gt4mi_halo_exchange_begin",
+                   self._lib.gt4mi_halo_exchange_begin(self._plan, ctypes.byref(f), _stream_ptr()))
+
+    def end(self) -> None:
+        _lib.check("gt4mi_halo_exchange_end", self._lib.gt4mi_halo_exchange_end(self._plan, _stream_ptr()))
+
+    def make_dist_lap5(self, inp, out, origin_inp: Sequence[int], origin_out: Sequence[int], variant: int = 0):
+        """Pre-bind one distributed Laplacian apply (halo 1) -> a zero-argument callable."""
+        if self.decomp.halo != 1 or self.itemsize != 8:
+            raise ValueError("gt4mi_dist_lap5_f64 needs fp64 fields and a halo of 1")
+        fi, fo = _field_struct(inp, origin_inp), _field_struct(out, origin_out)
+        dom = _lib.domain3(self.decomp.local_domain)
+        fn, plan, sides = self._lib.gt4mi_dist_lap5_f64, self._plan, self.sides
+        ri, ro = ctypes.byref(fi), ctypes.byref(fo)
+
+        def apply():
+            rc = fn(plan, dom, ri, ro, variant, sides, _stream_ptr())
+            if rc:
+                _lib.check("gt4mi_dist_lap5_f64", rc)
+
+        apply._keepalive = (fi, fo, dom, inp, out)  # type: ignore[attr-defined]
+        return apply
+
+    def close(self) -> None:
+        if self._plan is not None and self._plan.value:
+            self._lib.gt4mi_halo_plan_destroy(self._plan)
+            self._plan = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -132,6 +132,47 @@ int gt4mi_halo_pack(const gt4mi_field* field, const int64_t lo[3], const int64_t
 int gt4mi_halo_unpack(const gt4mi_field* field, const int64_t lo[3], const int64_t extent[3],
                       const void* buffer, int elem_size, void* stream);
 
+/* ---- multi-GPU: RCCL halo exchange driven from native code (NEW, no reference counterpart) --------
+ * One process per GPU.  gt4mi_comm wraps an RCCL communicator created from a 128-byte unique id
+ * (gt4mi_comm_unique_id on one rank, distributed by the host program, e.g. torch.distributed).
+ * A gt4mi_halo_plan holds, for one field shape, the boxes to send/receive in the two phases of the
+ * exchange (phase 0: I faces, phase 1: J faces including the I-halo columns) and owns the dense
+ * device staging buffers.  Within a phase the k-th send to a peer pairs with the k-th receive that
+ * peer posts from this rank (RCCL point-to-point ordering). */
+typedef struct gt4mi_comm gt4mi_comm;
+typedef struct gt4mi_halo_plan gt4mi_halo_plan;
+
+typedef struct gt4mi_halo_msg {
+    int32_t peer;      /* rank of the neighbour                                                  */
+    int32_t phase;     /* 0 or 1                                                                  */
+    int64_t lo[3];     /* box start, in indices of the field array (NOT relative to the origin)  */
+    int64_t extent[3]; /* box size                                                                */
+} gt4mi_halo_msg;
+
+int gt4mi_comm_unique_id(void* id128);
+int gt4mi_comm_create(const void* id128, int nranks, int rank, gt4mi_comm** comm);
+int gt4mi_comm_destroy(gt4mi_comm* comm);
+int gt4mi_halo_plan_create(gt4mi_comm* comm, int elem_size, const gt4mi_halo_msg* sends, int nsends,
+                           const gt4mi_halo_msg* recvs, int nrecvs, gt4mi_halo_plan** plan);
+int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
+/* Enqueue the whole exchange of `field` on `stream` (stream-ordered, returns immediately). */
+int gt4mi_halo_exchange(gt4mi_halo_plan* plan, const gt4mi_field* field, void* stream);
+/* Overlapped form: _begin makes the plan's side stream wait for `main_stream`, enqueues the exchange
+ * there and records completion; _end makes `main_stream` wait for that completion.  Work enqueued on
+ * `main_stream` between the two calls (the interior kernel) runs concurrently with the exchange. */
+int gt4mi_halo_exchange_begin(gt4mi_halo_plan* plan, const gt4mi_field* field, void* main_stream);
+/* Optional: mark the fork point on `main_stream` NOW and enqueue the exchange later.  Lets the
+ * caller enqueue the interior kernel before _begin, so the GPU is already busy while the host is
+ * still issuing the pack / RCCL / unpack sequence; the next _begin then waits only for work that
+ * was on `main_stream` before the fork. */
+int gt4mi_halo_exchange_fork(gt4mi_halo_plan* plan, void* main_stream);
+int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream);
+/* One distributed apply of a 5-point stencil in a single call: exchange of `inp`'s halo (width 1)
+ * overlapped with the interior kernel, then the boundary strips.  `sides` = bit mask of the sides
+ * that have a neighbour: 1 = low I (W), 2 = high I (E), 4 = low J (S), 8 = high J (N). */
+int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
+                        const gt4mi_field* out, int variant, int sides, void* main_stream);
+
 /* ---- measurement helper ---------------------------------------------------------------------
  * Streaming device copy of nbytes (multiple of 16) with 16-byte lanes: the "achievable HBM"
  * yardstick printed next to the stencil numbers. */

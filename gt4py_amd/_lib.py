@@ -38,11 +38,13 @@ EXPORTED_SYMBOLS = (
     "gt4mi_comm_destroy",
     "gt4mi_halo_plan_create",
     "gt4mi_halo_plan_destroy",
+    "gt4mi_halo_plan_concurrent",
     "gt4mi_halo_exchange",
     "gt4mi_halo_exchange_begin",
     "gt4mi_halo_exchange_fork",
     "gt4mi_halo_exchange_end",
     "gt4mi_dist_lap5_f64",
+    "gt4mi_dist_lap5_f64_pipelined",
     "gt4mi_stream_copy",
 )
 
@@ -153,6 +155,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_halo_plan_create.argtypes = [P, I, MP, I, MP, I, PP]
     lib.gt4mi_halo_plan_destroy.restype = I
     lib.gt4mi_halo_plan_destroy.argtypes = [P]
+    lib.gt4mi_halo_plan_concurrent.restype = I
+    lib.gt4mi_halo_plan_concurrent.argtypes = [P]
     lib.gt4mi_halo_exchange.restype = I
     lib.gt4mi_halo_exchange.argtypes = [P, FP, P]
     lib.gt4mi_halo_exchange_begin.restype = I
@@ -163,6 +167,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_halo_exchange_fork.argtypes = [P, P]
     lib.gt4mi_dist_lap5_f64.restype = I
     lib.gt4mi_dist_lap5_f64.argtypes = [P, DOM, FP, FP, I, I, P]
+    lib.gt4mi_dist_lap5_f64_pipelined.restype = I
+    lib.gt4mi_dist_lap5_f64_pipelined.argtypes = [P, DOM, FP, FP, I, I, P]
 
 
 def load() -> ctypes.CDLL:

@@ -102,9 +102,63 @@ struct gt4mi_halo_plan {
     hipStream_t stream = nullptr;         // side stream the exchange runs on in the overlapped form
     hipEvent_t ready = nullptr, done = nullptr;
     bool forked = false;                  // `ready` already recorded by gt4mi_halo_exchange_fork
+    bool primed = false;                  // `done` has been recorded at least once (pipelined stepping)
+    // concurrency probe (ensure_concurrent_stream)
+    unsigned* probe = nullptr;            // two device words: flag, result
+    hipStream_t probed_main = nullptr;
+    bool probed = false, concurrent = false;
 };
 
 namespace gt4mi {
+
+// HIP multiplexes streams onto a handful of hardware queues (4 by default) and two streams that
+// land on the same queue run strictly in submission order -- measured on MI355X: with the side
+// stream on the main stream's queue the "overlapped" exchange simply ran after the interior kernel
+// (97 us per 512x64x512 step instead of ~60).  There is no API to ask for a distinct queue, so the
+// plan PROBES: a one-thread kernel on the main stream waits (bounded) for a flag that a one-thread
+// kernel submitted AFTERWARDS on the side stream raises.  The flag only arrives if the two streams
+// really execute concurrently; otherwise the side stream is replaced (colliding ones are kept alive
+// until a good one is found, so that their queue is not handed out again).
+__global__ void probe_wait_kernel(unsigned* words, long long timeout_ticks) {
+    const long long t0 = wall_clock64();  // 100 MHz
+    while (__hip_atomic_load(&words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        if (wall_clock64() - t0 > timeout_ticks) {
+            words[1] = 0u;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    words[1] = 1u;
+}
+__global__ void probe_set_kernel(unsigned* words) {
+    __hip_atomic_store(&words[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+inline int ensure_concurrent_stream(gt4mi_halo_plan* plan, hipStream_t main_stream) {
+    if (plan->probed && plan->probed_main == main_stream) return GT4MI_OK;
+    std::vector<hipStream_t> colliding;
+    bool ok = false;
+    for (int attempt = 0; attempt < 12 && !ok; ++attempt) {
+        GT4MI_HIP_CHECK(hipMemsetAsync(plan->probe, 0, 8, main_stream));
+        GT4MI_HIP_CHECK(hipStreamSynchronize(main_stream));
+        hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, main_stream, plan->probe, 30000LL /* 0.3 ms */);
+        hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, plan->stream, plan->probe);
+        GT4MI_HIP_CHECK(hipStreamSynchronize(main_stream));
+        GT4MI_HIP_CHECK(hipStreamSynchronize(plan->stream));
+        unsigned words[2] = {0, 0};
+        GT4MI_HIP_CHECK(hipMemcpy(words, plan->probe, 8, hipMemcpyDeviceToHost));
+        ok = words[1] == 1u;
+        if (!ok) {
+            colliding.push_back(plan->stream);
+            GT4MI_HIP_CHECK(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking));
+        }
+    }
+    for (hipStream_t s : colliding) (void)hipStreamDestroy(s);
+    plan->probed = true;
+    plan->probed_main = main_stream;
+    plan->concurrent = ok;
+    return GT4MI_OK;
+}
 
 // All boxes of one phase are packed (or unpacked) by ONE launch: blockIdx.y selects the box.  The
 // exchange is latency-bound, so launches on its critical path are what matters.

@@ -192,6 +192,12 @@ int gt4mi_halo_plan_create(gt4mi_comm* comm, int elem_size, const gt4mi_halo_msg
     if (rc == GT4MI_OK && (hipEventCreateWithFlags(&p->ready, hipEventDisableTiming) != hipSuccess ||
                            hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess))
         rc = gt4mi::fail(GT4MI_ERR_HIP, "halo_plan_create: hipEventCreate failed");
+    if (rc == GT4MI_OK) {
+        void* words = nullptr;
+        if (hipMalloc(&words, 256) != hipSuccess)
+            rc = gt4mi::fail(GT4MI_ERR_HIP, "halo_plan_create: hipMalloc failed");
+        p->probe = static_cast<unsigned*>(words);
+    }
     if (rc != GT4MI_OK) {
         gt4mi_halo_plan_destroy(p);
         return rc;
@@ -200,12 +206,18 @@ int gt4mi_halo_plan_create(gt4mi_comm* comm, int elem_size, const gt4mi_halo_msg
     return GT4MI_OK;
 }
 
+int gt4mi_halo_plan_concurrent(gt4mi_halo_plan* plan) {
+    if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_concurrent: null plan");
+    return plan->probed ? (plan->concurrent ? 1 : 0) : 2;
+}
+
 int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan) {
     if (plan == nullptr) return GT4MI_OK;
     for (int ph = 0; ph < 2; ++ph) {
         for (auto& m : plan->sends[ph]) if (m.buffer) (void)hipFree(m.buffer);
         for (auto& m : plan->recvs[ph]) if (m.buffer) (void)hipFree(m.buffer);
     }
+    if (plan->probe) (void)hipFree(plan->probe);
     if (plan->ready) (void)hipEventDestroy(plan->ready);
     if (plan->done) (void)hipEventDestroy(plan->done);
     if (plan->stream) (void)hipStreamDestroy(plan->stream);
@@ -227,11 +239,14 @@ int gt4mi_halo_exchange_fork(gt4mi_halo_plan* plan, void* main_stream) {
 
 int gt4mi_halo_exchange_begin(gt4mi_halo_plan* plan, const gt4mi_field* field, void* main_stream) {
     if (plan == nullptr || field == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_exchange_begin: null argument");
+    if (!plan->forked)
+        if (int rc = gt4mi::ensure_concurrent_stream(plan, static_cast<hipStream_t>(main_stream))) return rc;
     if (!plan->forked) GT4MI_HIP_CHECK(hipEventRecord(plan->ready, static_cast<hipStream_t>(main_stream)));
     plan->forked = false;
     GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
     if (int rc = gt4mi::halo_exchange_on(plan, field, plan->stream)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+    plan->primed = true;
     return GT4MI_OK;
 }
 
@@ -246,10 +261,7 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
     if (plan == nullptr || inp == nullptr || out == nullptr || domain == nullptr)
         return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5: null argument");
     hipStream_t ms = static_cast<hipStream_t>(main_stream);
-    // The side stream must only wait for what is ALREADY on the main stream (the previous step), so
-    // the fork point is recorded before the interior kernel is enqueued; the interior kernel is
-    // enqueued first so that the GPU is busy while the host issues the pack/RCCL/unpack sequence.
-    GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+    if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
     const int64_t di = domain[0], dj = domain[1], dk = domain[2];
     const int64_t lo_i = (sides & 1) ? 1 : 0, hi_i = (sides & 2) ? 1 : 0;
     const int64_t lo_j = (sides & 4) ? 1 : 0, hi_j = (sides & 8) ? 1 : 0;
@@ -261,16 +273,17 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
         const int64_t d[3] = {ei, ej, dk};
         return gt4mi::lap5_run<double, double>(d, &a, &b, variant, ms);
     };
-    // 1. side stream (high priority): pack the first faces NOW -- a few microseconds while the GPU
-    //    is otherwise idle, instead of queueing behind the interior kernel's workgroups
+    // 1. pack the first faces ON THE MAIN STREAM, ahead of the interior kernel: alone it takes ~5 us;
+    //    launched next to the interior kernel's thousands of workgroups it took 22 us and delayed the
+    //    whole exchange past the end of the interior kernel (profiles/r1_dist_step_timeline.txt).
+    //    The side stream then only waits for this pack (and whatever preceded it).
+    if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
+    GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
     GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-    static const bool early_pack = !(getenv("GT4MI_EARLY_PACK") && getenv("GT4MI_EARLY_PACK")[0] == '0');
-    if (early_pack)
-        if (int rc = gt4mi::halo_pack_first(plan, inp, plan->stream)) return rc;
     // 2. main stream: interior, independent of the ghost cells in flight
     if (int rc = run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j)) return rc;
     // 3. side stream: RCCL send/recv + unpack (+ second phase), concurrent with the interior kernel
-    if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/early_pack)) return rc;
+    if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/true)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
     // 4. main stream: join, then the boundary strips (both J rows in one launch)
     if (int rc = gt4mi_halo_exchange_end(plan, main_stream)) return rc;
@@ -284,6 +297,59 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
     }
     if (lo_i) if (int rc = run(0, lo_j, 1, dj - lo_j - hi_j)) return rc;
     if (hi_i && di - 1 >= lo_i) if (int rc = run(di - 1, lo_j, 1, dj - lo_j - hi_j)) return rc;
+    return GT4MI_OK;
+}
+
+int gt4mi_dist_lap5_f64_pipelined(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
+                                  const gt4mi_field* out, int variant, int sides, void* main_stream) {
+    if (plan == nullptr || inp == nullptr || out == nullptr || domain == nullptr)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5_pipelined: null argument");
+    if (!plan->primed)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT,
+                           "dist_lap5_pipelined: the ghost cells of the first input were never exchanged "
+                           "(call gt4mi_halo_exchange_begin on it once before the first step)");
+    hipStream_t ms = static_cast<hipStream_t>(main_stream);
+    const int64_t di = domain[0], dj = domain[1], dk = domain[2];
+    const int64_t lo_i = (sides & 1) ? 1 : 0, hi_i = (sides & 2) ? 1 : 0;
+    const int64_t lo_j = (sides & 4) ? 1 : 0, hi_j = (sides & 8) ? 1 : 0;
+    auto run = [&](int64_t si, int64_t sj, int64_t ei, int64_t ej) -> int {
+        if (ei <= 0 || ej <= 0 || dk <= 0) return GT4MI_OK;
+        gt4mi_field a = *inp, b = *out;
+        a.origin[0] += si; a.origin[1] += sj;
+        b.origin[0] += si; b.origin[1] += sj;
+        const int64_t d[3] = {ei, ej, dk};
+        return gt4mi::lap5_run<double, double>(d, &a, &b, variant, ms);
+    };
+    if (!(plan->probed && plan->probed_main == ms)) {
+        // the probe synchronises: keep the priming exchange ordered before it
+        GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+        if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
+        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+    }
+    // 1. join the exchange that filled `inp`'s ghost cells (started one step ago, long finished)
+    GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+    // 2. boundary strips of `out` first: they are what the neighbours need next
+    {
+        int rows[2], n = 0;
+        if (lo_j) rows[n++] = 0;
+        if (hi_j && dj - 1 >= lo_j) rows[n++] = (int)(dj - 1);
+        if (n)
+            if (int rc = gt4mi::lap5_run_rows<double, double>(domain, inp, out, variant, rows[0], n > 1 ? rows[1] : rows[0], n, ms))
+                return rc;
+    }
+    if (lo_i) if (int rc = run(0, lo_j, 1, dj - lo_j - hi_j)) return rc;
+    if (hi_i && di - 1 >= lo_i) if (int rc = run(di - 1, lo_j, 1, dj - lo_j - hi_j)) return rc;
+    // 3. pack `out`'s fresh faces on the main stream (before the interior kernel floods the CUs),
+    //    then fork: the side stream waits for exactly this point
+    if (int rc = gt4mi::halo_pack_first(plan, out, ms)) return rc;
+    GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+    GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+    // 4. ... the interior kernel goes out on the main stream ...
+    if (int rc = run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j)) return rc;
+    // 5. ... and RCCL send/recv + unpack of `out`'s ghost cells run next to it; nobody waits for
+    //    them until step 1 of the NEXT call (where `out` is the input)
+    if (int rc = gt4mi::halo_exchange_on(plan, out, plan->stream, /*first_pack_done=*/true)) return rc;
+    GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
     return GT4MI_OK;
 }
 

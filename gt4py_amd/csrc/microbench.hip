@@ -390,6 +390,57 @@ static void section_tridiag() {
     tridiag_variant<double, 1, 8>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
 }
 
+// ---------------------------------------------------------------------------------------------
+// What does cross-stream synchronisation cost on the main stream?  Per "step": a 512x64x512 strip
+// kernel (~46 us) and a 2-row kernel (~5 us), with (a) nothing, (b) hipEventRecord +
+// hipStreamWaitEvent on an already-completed event of another stream, (c) a side stream doing a
+// small kernel per step joined with events (the shape of the distributed step).
+__global__ void tiny_kernel(unsigned* p) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(p, 1u); }
+
+static void section_events() {
+    const int dI = 512, dJ = 64, dK = 512;
+    DevField<double> in(dI, dJ, dK, 1, 1), out(dI, dJ, dK, 1, 1);
+    fill(in, 1, -1.0, 1.0);
+    unsigned* ctr;
+    CK(hipMalloc(&ctr, 4));
+    CK(hipMemset(ctr, 0, 4));
+    hipStream_t side;
+    CK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipEvent_t ready, done;
+    CK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    CK(hipEventRecord(done, side));
+    const unsigned tx = 1, ty = dJ / 8, n = tx * ty * dK;
+    auto big = [&]() { hipLaunchKernelGGL((lap5_strip_kernel<double, double, 0, 2, 8, 256, 4>), dim3(n), dim3(256), 0, 0, in.cview(), out.view(), dI, dJ, tx, ty); };
+    auto rows = [&]() { hipLaunchKernelGGL((lap5_rows_kernel<double, double, 0, 2, 256>), dim3(2 * dK), dim3(256), 0, 0, in.cview(), out.view(), dI, 0, dJ - 1, 1u, 2u); };
+    const int iters = 300;
+    double ms;
+    ms = time_ms([&](int) { big(); }, iters);
+    printf("events     big kernel only                                  %8.1f us/step\n", ms * 1e3);
+    ms = time_ms([&](int) { rows(); big(); }, iters);
+    printf("events     rows + big (same stream, no events)              %8.1f us/step\n", ms * 1e3);
+    ms = time_ms([&](int) { rows(); CK(hipEventRecord(ready, 0)); big(); }, iters);
+    printf("events     rows + record + big                              %8.1f us/step\n", ms * 1e3);
+    ms = time_ms([&](int) { CK(hipStreamWaitEvent(0, done, 0)); rows(); big(); }, iters);
+    printf("events     wait(completed event) + rows + big               %8.1f us/step\n", ms * 1e3);
+    ms = time_ms([&](int) { CK(hipStreamWaitEvent(0, done, 0)); rows(); CK(hipEventRecord(ready, 0)); big(); }, iters);
+    printf("events     wait + rows + record + big                       %8.1f us/step\n", ms * 1e3);
+    ms = time_ms([&](int) {
+        CK(hipStreamWaitEvent(0, done, 0));
+        rows();
+        CK(hipEventRecord(ready, 0));
+        CK(hipStreamWaitEvent(side, ready, 0));
+        hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, side, ctr);
+        big();
+        hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, side, ctr);
+        hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, side, ctr);
+        CK(hipEventRecord(done, side));
+    }, iters);
+    printf("events     full choreography with 3 tiny side-stream kernels %7.1f us/step\n", ms * 1e3);
+    CK(hipDeviceSynchronize());
+    hipFree(ctr);
+}
+
 int main(int argc, char** argv) {
     std::vector<std::string> want;
     for (int i = 1; i < argc; ++i) want.push_back(argv[i]);
@@ -408,6 +459,7 @@ int main(int argc, char** argv) {
     if (!want.empty() && on("lap512")) lap_suite(512, 512, 512, 0, "512^3");
     if (on("hdiff")) section_hdiff();
     if (on("tridiag")) section_tridiag();
+    if (!want.empty() && on("events")) section_events();
     return ok ? 0 : 1;
 }
 

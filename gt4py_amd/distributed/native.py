@@ -143,6 +143,37 @@ class NativeHaloExchanger:
         apply._keepalive = (fi, fo, dom, inp, out)  # type: ignore[attr-defined]
         return apply
 
+    @property
+    def concurrent(self):
+        """True / False once the side stream has been probed against the caller's stream, else None."""
+        v = self._lib.gt4mi_halo_plan_concurrent(self._plan)
+        return None if v == 2 else bool(v)
+
+    def make_time_stepper_lap5(self, field_a, field_b, origin: Sequence[int], variant: int = 0):
+        """Pre-bind the pipelined time-stepping Laplacian: call n computes b = lap(a) for even n and
+        a = lap(b) for odd n, exchanging the freshly written field's ghost cells next to the interior
+        kernel (gt4mi_dist_lap5_f64_pipelined).  Primes the pipeline with one exchange of ``field_a``.
+        Returns a zero-argument callable; ``callable.result()`` is the field written last."""
+        if self.decomp.halo != 1 or self.itemsize != 8:
+            raise ValueError("gt4mi_dist_lap5_f64_pipelined needs fp64 fields and a halo of 1")
+        fa, fb = _field_struct(field_a, origin), _field_struct(field_b, origin)
+        dom = _lib.domain3(self.decomp.local_domain)
+        fn, plan, sides = self._lib.gt4mi_dist_lap5_f64_pipelined, self._plan, self.sides
+        ra, rb = ctypes.byref(fa), ctypes.byref(fb)
+        self.begin(field_a)  # ghost cells of the first input
+        state = {"n": 0}
+
+        def step():
+            src, dst = (ra, rb) if state["n"] % 2 == 0 else (rb, ra)
+            rc = fn(plan, dom, src, dst, variant, sides, _stream_ptr())
+            if rc:
+                _lib.check("gt4mi_dist_lap5_f64_pipelined", rc)
+            state["n"] += 1
+
+        step.result = lambda: field_b if state["n"] % 2 == 1 else field_a  # type: ignore[attr-defined]
+        step._keepalive = (fa, fb, dom, field_a, field_b)  # type: ignore[attr-defined]
+        return step
+
     def close(self) -> None:
         if self._plan is not None and self._plan.value:
             self._lib.gt4mi_halo_plan_destroy(self._plan)

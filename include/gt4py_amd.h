@@ -155,6 +155,11 @@ int gt4mi_comm_destroy(gt4mi_comm* comm);
 int gt4mi_halo_plan_create(gt4mi_comm* comm, int elem_size, const gt4mi_halo_msg* sends, int nsends,
                            const gt4mi_halo_msg* recvs, int nrecvs, gt4mi_halo_plan** plan);
 int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
+/* 1 = the plan's side stream was verified to run concurrently with the caller's stream, 0 = no
+ * concurrent stream could be found (the exchange still works, serialised), 2 = not probed yet.
+ * HIP multiplexes streams onto a few hardware queues; the overlapped entry points probe on first use
+ * and replace a side stream that shares the caller's queue. */
+int gt4mi_halo_plan_concurrent(gt4mi_halo_plan* plan);
 /* Enqueue the whole exchange of `field` on `stream` (stream-ordered, returns immediately). */
 int gt4mi_halo_exchange(gt4mi_halo_plan* plan, const gt4mi_field* field, void* stream);
 /* Overlapped form: _begin makes the plan's side stream wait for `main_stream`, enqueues the exchange
@@ -172,6 +177,18 @@ int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream);
  * that have a neighbour: 1 = low I (W), 2 = high I (E), 4 = low J (S), 8 = high J (N). */
 int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int sides, void* main_stream);
+
+/* Time-stepping form (out of step n is inp of step n+1): each call
+ *   1. joins the exchange that delivered `inp`'s ghost cells (started by the previous call, or once by
+ *      gt4mi_halo_exchange_begin(plan, first_input, ...) before the first step),
+ *   2. computes the boundary strips of `out`,
+ *   3. starts the exchange of `out`'s ghost cells on the plan's side stream,
+ *   4. computes the interior of `out` concurrently with that exchange.
+ * Nothing on the main stream ever waits for an exchange that has not had a whole interior kernel to
+ * complete.  After the last step `out`'s ghost cells are (being) refreshed; gt4mi_halo_exchange_end
+ * joins. */
+int gt4mi_dist_lap5_f64_pipelined(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
+                                  const gt4mi_field* out, int variant, int sides, void* main_stream);
 
 /* ---- measurement helper ---------------------------------------------------------------------
  * Streaming device copy of nbytes (multiple of 16) with 16-byte lanes: the "achievable HBM"

@@ -118,3 +118,48 @@ def test_overlapped_apply_with_native_exchanger(comm):
     R.hdiff(_wrap(host, 2), want, coeff, domain=gd)
     assert np.array_equal(d_out.get(), want)
     ex.close()
+
+
+@pytest.mark.parametrize("periodic", [(False, True), (True, True), (True, False)])
+def test_pipelined_time_stepping(comm, periodic):
+    """gt4mi_dist_lap5_f64_pipelined: n steps of u <- lap(u) on a periodic domain (ghost cells of the
+    freshly written field exchanged next to the interior kernel) == n oracle steps with numpy wrap."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from oracle import ref_numpy as R
+
+    gd = (64, 40, 5)
+    dec = Decomposition(gd, (1, 1), 0, 1, periodic=periodic)
+    rng = np.random.default_rng(21)
+    host = rng.uniform(-1, 1, dec.local_shape) * 1e-3
+    a = gt_storage.from_array(host, backend="hip:mi300", aligned_index=(1, 1, 0))
+    b = gt_storage.from_array(host * 0 + 7.0, backend="hip:mi300", aligned_index=(1, 1, 0))
+    ex = NativeHaloExchanger(dec, np.float64, comm)
+    step = ex.make_time_stepper_lap5(a, b, (1, 1, 0))
+    nsteps = 7
+    for _ in range(nsteps):
+        step()
+    ex.end()
+    torch.cuda.synchronize()
+    # oracle: non-periodic ghost cells of the OUTPUT buffers keep whatever they held (host / 7.0)
+    u, v = host.copy(), host * 0 + 7.0
+    for _ in range(nsteps):
+        u = _wrap(u, 1, *periodic)
+        R.laplacian(u, v)
+        u, v = v, u
+    u = _wrap(u, 1, *periodic)
+    got = step.result().get()
+    assert np.array_equal(got, u)
+    ex.close()
+    with pytest.raises(Exception, match="never exchanged"):
+        ex2 = NativeHaloExchanger(dec, np.float64, comm)
+        f = __import__("gt4py_amd.distributed.native", fromlist=["_field_struct"])._field_struct
+        import ctypes
+
+        from gt4py_amd import _lib
+
+        fa, fb = f(a, (1, 1, 0)), f(b, (1, 1, 0))
+        _lib.check("x", ex2._lib.gt4mi_dist_lap5_f64_pipelined(ex2._plan, _lib.domain3(gd), ctypes.byref(fa), ctypes.byref(fb),
+                                                               0, ex2.sides, None))

@@ -47,15 +47,15 @@ def _lap_definition():
     return hip_templates.lap_notebook
 
 
-def _device_fields(shape, n_pairs, seed):
+def _device_fields(shape, n_pairs, seed, origin=(1, 1, 0)):
     """`n_pairs` (inp, out) pairs in HBM with the hip:mi300 layout; inp ~ U[-1, 1), seeded on device."""
     import gt4py_amd.storage as gt_storage
 
     pairs = []
     gen = torch.Generator(device="cuda").manual_seed(seed)
     for _ in range(n_pairs):
-        inp = gt_storage.empty(shape, np.float64, backend="hip:mi300", aligned_index=(1, 1, 0))
-        out = gt_storage.zeros(shape, np.float64, backend="hip:mi300", aligned_index=(1, 1, 0))
+        inp = gt_storage.empty(shape, np.float64, backend="hip:mi300", aligned_index=origin)
+        out = gt_storage.zeros(shape, np.float64, backend="hip:mi300", aligned_index=origin)
         inp.tensor.copy_(torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1)
         pairs.append((inp, out))
     return pairs
@@ -197,18 +197,29 @@ def main() -> None:
         selfloop = args.dist_selfloop and world == 1
         grid = (1, 1) if selfloop else choose_process_grid(world, GRID)
         total = (GRID[0], GRID[1] // max(args.selfloop_ranks, 1), GRID[2]) if selfloop else GRID
-        dec = Decomposition(total, grid, rank, halo=1, periodic=(False, True) if selfloop else (False, False))
-        pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank)
+        transport = os.environ.get("GT4MI_BENCH_COMM", "native")
+        mode = os.environ.get("GT4MI_BENCH_MODE", "timestep")
+        # ghost depth = steps served by one exchange (communication-avoiding time stepping); the
+        # independent-apply and torch-transport modes exchange every step with depth 1
+        # Depth 2 by default: in the 1-GPU rehearsal depth 4 is fastest (65.8 vs 72.5 vs 83.8 us per
+        # 512x64x512 step for depth 4 / 2 / 1), but message size grows with depth while only ONE
+        # interior kernel covers the transfer, and real xGMI links are slower than the rehearsal's
+        # self-copy; depth 2 is the robust middle (profiles/r1_dist_step_timeline.txt).
+        halo = max(1, int(os.environ.get("GT4MI_BENCH_HALO", "2"))) if (transport == "native" and mode == "timestep") else 1
+        dec = Decomposition(total, grid, rank, halo=halo, periodic=(False, True) if selfloop else (False, False))
+        origin = {"inp": dec.origin, "out": dec.origin}
+        pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank, origin=dec.origin)
         local_domain = dec.local_domain
         frozen = lap.freeze(origin=origin, domain=local_domain)
-        transport = os.environ.get("GT4MI_BENCH_COMM", "native")
         if transport == "native":
             # whole step (pack, RCCL send/recv, unpack, interior, strips, 2 streams) = one C call
             comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
             exchangers = [NativeHaloExchanger(dec, np.float64, comm) for _ in pairs]
-            if os.environ.get("GT4MI_BENCH_MODE", "timestep") == "timestep":
-                # time stepping u <- lap(u) between two buffers: the ghost cells of the field written
-                # in step n travel while step n's interior kernel runs and are joined in step n+1.
+            if mode == "timestep":
+                # time stepping u <- lap(u) between two buffers.  Ghost regions are `halo` deep and one
+                # exchange serves `halo` steps (the steps in between grow their domain into the ghost
+                # region instead of communicating); the exchange of the freshly written field travels
+                # next to that step's interior kernel and is joined `halo` steps later.
                 # The amplitude starts at 1e-150 so that ~8x growth per step stays finite for 600 steps.
                 a, b = pairs[0][0], pairs[1][0]
                 a.tensor.mul_(1e-150)
@@ -233,11 +244,13 @@ def main() -> None:
             inp, out = pairs[i % len(pairs)]
             frozen(inp=inp, out=out)
 
-        config = {"workload": "fp64 5-point Laplacian 512x512x512 split over ranks (strong scaling), halo 1 exchanged "
-                              "every step with RCCL send/recv overlapped with the interior kernel",
+        config = {"workload": "fp64 5-point Laplacian 512x512x512 split over ranks along J (strong scaling); "
+                              + ("time stepping u <- lap(u), ghost regions %d deep: one RCCL send/recv exchange per %d "
+                                 "steps, overlapped with the interior kernel" % (halo, halo) if mode == "timestep"
+                                 and transport == "native" else "independent applies, ghost cells exchanged every step"),
                   "grid": list(GRID), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(local_domain),
-                  "halo_bytes_per_rank_per_step": exchangers[0].bytes_per_exchange, "transport": transport,
-                  "selfloop": bool(selfloop)}
+                  "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange,
+                  "transport": transport, "mode": mode, "selfloop": bool(selfloop)}
 
     def barrier():
         if distributed:

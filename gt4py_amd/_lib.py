@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_halo_exchange_end",
     "gt4mi_dist_lap5_f64",
     "gt4mi_dist_lap5_f64_pipelined",
+    "gt4mi_dist_lap5_f64_wide",
     "gt4mi_stream_copy",
 )
 
@@ -169,6 +170,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_dist_lap5_f64.argtypes = [P, DOM, FP, FP, I, I, P]
     lib.gt4mi_dist_lap5_f64_pipelined.restype = I
     lib.gt4mi_dist_lap5_f64_pipelined.argtypes = [P, DOM, FP, FP, I, I, P]
+    lib.gt4mi_dist_lap5_f64_wide.restype = I
+    lib.gt4mi_dist_lap5_f64_wide.argtypes = [P, DOM, FP, FP, I, I, I, I, P]
 
 
 def load() -> ctypes.CDLL:

@@ -300,58 +300,78 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
     return GT4MI_OK;
 }
 
-int gt4mi_dist_lap5_f64_pipelined(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
-                                  const gt4mi_field* out, int variant, int sides, void* main_stream) {
+int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
+                             const gt4mi_field* out, int variant, int sides, int halo, int phase, void* main_stream) {
     if (plan == nullptr || inp == nullptr || out == nullptr || domain == nullptr)
-        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5_pipelined: null argument");
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5_wide: null argument");
+    if (halo < 1 || phase < 0 || phase >= halo)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5_wide: need halo >= 1 and 0 <= phase < halo");
     if (!plan->primed)
         return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT,
-                           "dist_lap5_pipelined: the ghost cells of the first input were never exchanged "
+                           "dist_lap5_wide: the ghost cells of the first input were never exchanged "
                            "(call gt4mi_halo_exchange_begin on it once before the first step)");
     hipStream_t ms = static_cast<hipStream_t>(main_stream);
-    const int64_t di = domain[0], dj = domain[1], dk = domain[2];
-    const int64_t lo_i = (sides & 1) ? 1 : 0, hi_i = (sides & 2) ? 1 : 0;
-    const int64_t lo_j = (sides & 4) ? 1 : 0, hi_j = (sides & 8) ? 1 : 0;
-    auto run = [&](int64_t si, int64_t sj, int64_t ei, int64_t ej) -> int {
-        if (ei <= 0 || ej <= 0 || dk <= 0) return GT4MI_OK;
+    const int64_t di = domain[0], dj = domain[1], dk = domain[2], H = halo;
+    const bool w = sides & 1, e = sides & 2, s = sides & 4, n = sides & 8;
+    if ((w || e) && di < 2 * H) return gt4mi::fail(GT4MI_ERR_UNSUPPORTED, "dist_lap5_wide: local I extent smaller than 2*halo");
+    if ((s || n) && dj < 2 * H) return gt4mi::fail(GT4MI_ERR_UNSUPPORTED, "dist_lap5_wide: local J extent smaller than 2*halo");
+    // region [i0, i1) x [j0, j1) relative to the local compute-domain origin
+    auto run = [&](int64_t i0, int64_t i1, int64_t j0, int64_t j1) -> int {
+        if (i1 <= i0 || j1 <= j0 || dk <= 0) return GT4MI_OK;
         gt4mi_field a = *inp, b = *out;
-        a.origin[0] += si; a.origin[1] += sj;
-        b.origin[0] += si; b.origin[1] += sj;
-        const int64_t d[3] = {ei, ej, dk};
+        a.origin[0] += i0; a.origin[1] += j0;
+        b.origin[0] += i0; b.origin[1] += j0;
+        const int64_t d[3] = {i1 - i0, j1 - j0, dk};
         return gt4mi::lap5_run<double, double>(d, &a, &b, variant, ms);
     };
-    if (!(plan->probed && plan->probed_main == ms)) {
-        // the probe synchronises: keep the priming exchange ordered before it
+    if (phase == 0) {
+        if (!(plan->probed && plan->probed_main == ms)) {
+            // the probe synchronises: keep the exchange in flight ordered before it
+            GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+            if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        }
+        // join the exchange that delivered `inp`'s ghost cells (started `halo` steps ago)
         GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
-        if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
-        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
     }
-    // 1. join the exchange that filled `inp`'s ghost cells (started one step ago, long finished)
-    GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
-    // 2. boundary strips of `out` first: they are what the neighbours need next
-    {
-        int rows[2], n = 0;
-        if (lo_j) rows[n++] = 0;
-        if (hi_j && dj - 1 >= lo_j) rows[n++] = (int)(dj - 1);
-        if (n)
-            if (int rc = gt4mi::lap5_run_rows<double, double>(domain, inp, out, variant, rows[0], n > 1 ? rows[1] : rows[0], n, ms))
+    const int64_t ext = H - 1 - phase;  // how far this step still reaches into the ghost region
+    if (ext > 0) {
+        // redundant-compute step: one launch over the domain grown by `ext` towards every neighbour;
+        // its ghost results are valid inputs for the next step, no communication
+        return run(w ? -ext : 0, di + (e ? ext : 0), s ? -ext : 0, dj + (n ? ext : 0));
+    }
+    // last step of the cycle: `out`'s faces (H deep) are what the neighbours need next
+    const int64_t lo_i = w ? H : 0, hi_i = e ? H : 0, lo_j = s ? H : 0, hi_j = n ? H : 0;
+    if (H == 1 && !w && !e) {  // both single rows in one launch
+        int rows[2], nr = 0;
+        if (s) rows[nr++] = 0;
+        if (n) rows[nr++] = (int)(dj - 1);
+        if (nr)
+            if (int rc = gt4mi::lap5_run_rows<double, double>(domain, inp, out, variant, rows[0], nr > 1 ? rows[1] : rows[0], nr, ms))
                 return rc;
+    } else {
+        if (int rc = run(0, di, 0, lo_j)) return rc;
+        if (int rc = run(0, di, dj - hi_j, dj)) return rc;
+        if (int rc = run(0, lo_i, lo_j, dj - hi_j)) return rc;
+        if (int rc = run(di - hi_i, di, lo_j, dj - hi_j)) return rc;
     }
-    if (lo_i) if (int rc = run(0, lo_j, 1, dj - lo_j - hi_j)) return rc;
-    if (hi_i && di - 1 >= lo_i) if (int rc = run(di - 1, lo_j, 1, dj - lo_j - hi_j)) return rc;
-    // 3. pack `out`'s fresh faces on the main stream (before the interior kernel floods the CUs),
-    //    then fork: the side stream waits for exactly this point
+    // pack on the main stream (before the interior kernel floods the CUs), then fork
     if (int rc = gt4mi::halo_pack_first(plan, out, ms)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
     GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-    // 4. ... the interior kernel goes out on the main stream ...
-    if (int rc = run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j)) return rc;
-    // 5. ... and RCCL send/recv + unpack of `out`'s ghost cells run next to it; nobody waits for
-    //    them until step 1 of the NEXT call (where `out` is the input)
+    // interior on the main stream, RCCL send/recv + unpack of `out`'s ghost cells next to it; nobody
+    // waits for them until phase 0 of the next cycle (where `out` is the input)
+    if (int rc = run(lo_i, di - hi_i, lo_j, dj - hi_j)) return rc;
     if (int rc = gt4mi::halo_exchange_on(plan, out, plan->stream, /*first_pack_done=*/true)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
     return GT4MI_OK;
 }
+
+int gt4mi_dist_lap5_f64_pipelined(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
+                                  const gt4mi_field* out, int variant, int sides, void* main_stream) {
+    return gt4mi_dist_lap5_f64_wide(plan, domain, inp, out, variant, sides, 1, 0, main_stream);
+}
+
 
 int gt4mi_stream_copy(const void* src, void* dst, size_t nbytes, void* stream) {
     if (src == nullptr || dst == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "stream_copy: null pointer");

@@ -151,24 +151,31 @@ class NativeHaloExchanger:
 
     def make_time_stepper_lap5(self, field_a, field_b, origin: Sequence[int], variant: int = 0):
         """Pre-bind the pipelined time-stepping Laplacian: call n computes b = lap(a) for even n and
-        a = lap(b) for odd n, exchanging the freshly written field's ghost cells next to the interior
-        kernel (gt4mi_dist_lap5_f64_pipelined).  Primes the pipeline with one exchange of ``field_a``.
+        a = lap(b) for odd n (gt4mi_dist_lap5_f64_wide).  With a ghost depth H = ``decomp.halo`` one
+        exchange serves H steps: step n of a cycle (phase n % H) computes the local domain grown by
+        H-1-phase rows towards every neighbour -- redundantly recomputing what the neighbour also
+        computes -- and only the last phase exchanges the freshly written field's H-deep faces, next
+        to its interior kernel.  H == 1 is the plain pipelined exchange-every-step scheme.  Results
+        are bit-identical to the undecomposed run for every H (the redundant rows evaluate the same
+        expression on the same values).  Primes the pipeline with one exchange of ``field_a``.
         Returns a zero-argument callable; ``callable.result()`` is the field written last."""
-        if self.decomp.halo != 1 or self.itemsize != 8:
-            raise ValueError("gt4mi_dist_lap5_f64_pipelined needs fp64 fields and a halo of 1")
+        if self.itemsize != 8:
+            raise ValueError("the native Laplacian time stepper needs fp64 fields")
+        halo = int(self.decomp.halo)  # ghost depth == number of steps one exchange serves
         fa, fb = _field_struct(field_a, origin), _field_struct(field_b, origin)
         dom = _lib.domain3(self.decomp.local_domain)
-        fn, plan, sides = self._lib.gt4mi_dist_lap5_f64_pipelined, self._plan, self.sides
+        fn, plan, sides = self._lib.gt4mi_dist_lap5_f64_wide, self._plan, self.sides
         ra, rb = ctypes.byref(fa), ctypes.byref(fb)
         self.begin(field_a)  # ghost cells of the first input
         state = {"n": 0}
 
         def step():
-            src, dst = (ra, rb) if state["n"] % 2 == 0 else (rb, ra)
-            rc = fn(plan, dom, src, dst, variant, sides, _stream_ptr())
+            n = state["n"]
+            src, dst = (ra, rb) if n % 2 == 0 else (rb, ra)
+            rc = fn(plan, dom, src, dst, variant, sides, halo, n % halo, _stream_ptr())
             if rc:
-                _lib.check("gt4mi_dist_lap5_f64_pipelined", rc)
-            state["n"] += 1
+                _lib.check("gt4mi_dist_lap5_f64_wide", rc)
+            state["n"] = n + 1
 
         step.result = lambda: field_b if state["n"] % 2 == 1 else field_a  # type: ignore[attr-defined]
         step._keepalive = (fa, fb, dom, field_a, field_b)  # type: ignore[attr-defined]

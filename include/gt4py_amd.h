@@ -189,6 +189,20 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
  * joins. */
 int gt4mi_dist_lap5_f64_pipelined(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                                   const gt4mi_field* out, int variant, int sides, void* main_stream);
+/* Communication-avoiding generalisation: the fields carry ghost regions `halo` >= 1 cells deep (the
+ * plan exchanges faces that deep) and ONE exchange serves `halo` consecutive steps.  Call with
+ * phase = 0, 1, ..., halo-1, 0, 1, ... :
+ *   phase 0            joins the exchange that delivered `inp`'s ghost cells;
+ *   phase < halo-1     one launch over the compute domain grown by (halo-1-phase) cells towards every
+ *                      neighbour -- the ghost results it writes are valid inputs of the next step, no
+ *                      communication at all;
+ *   phase == halo-1    the pipelined step above: boundary strips (halo deep) of `out`, pack, then the
+ *                      exchange of `out`'s ghost cells next to the interior kernel.
+ * Per-step overhead of the exchange choreography is divided by `halo` for (halo-1)/2 redundant rows
+ * per side on average.  halo = 1 is gt4mi_dist_lap5_f64_pipelined. */
+int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
+                             const gt4mi_field* out, int variant, int sides, int halo, int phase,
+                             void* main_stream);
 
 /* ---- measurement helper ---------------------------------------------------------------------
  * Streaming device copy of nbytes (multiple of 16) with 16-byte lanes: the "achievable HBM"

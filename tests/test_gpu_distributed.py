@@ -163,3 +163,41 @@ def test_pipelined_time_stepping(comm, periodic):
         fa, fb = f(a, (1, 1, 0)), f(b, (1, 1, 0))
         _lib.check("x", ex2._lib.gt4mi_dist_lap5_f64_pipelined(ex2._plan, _lib.domain3(gd), ctypes.byref(fa), ctypes.byref(fb),
                                                                0, ex2.sides, None))
+
+
+@pytest.mark.parametrize("nsteps", [1, 4, 7])
+@pytest.mark.parametrize("halo", [2, 3, 4])
+@pytest.mark.parametrize("periodic", [(False, True), (True, True)])
+def test_wide_halo_time_stepping(comm, periodic, halo, nsteps):
+    """gt4mi_dist_lap5_f64_wide: ghost regions `halo` deep, one exchange per `halo` steps, redundant
+    rows computed in between; the compute domain after n steps equals n oracle steps with a fresh
+    periodic wrap every step."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from oracle import ref_numpy as R
+
+    gd = (48, 40, 4)
+    dec = Decomposition(gd, (1, 1), 0, halo, periodic=periodic)
+    o = dec.origin
+    rng = np.random.default_rng(100 + halo)
+    host = rng.uniform(-1, 1, dec.local_shape) * 1e-3
+    a = gt_storage.from_array(host, backend="hip:mi300", aligned_index=o)
+    b = gt_storage.from_array(host * 0 + 7.0, backend="hip:mi300", aligned_index=o)
+    ex = NativeHaloExchanger(dec, np.float64, comm)
+    step = ex.make_time_stepper_lap5(a, b, o)
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    # oracle on a depth-1 halo view: only the compute domain is compared
+    h = halo
+    core = (slice(h - 1, -(h - 1)) if h > 1 else slice(None),) * 2 + (slice(None),)
+    u, v = host[core].copy(), (host * 0 + 7.0)[core].copy()
+    for _ in range(nsteps):
+        u = _wrap(u, 1, *periodic)
+        R.laplacian(u, v)
+        u, v = v, u
+    got = step.result().get()[core]
+    assert np.array_equal(got[1:-1, 1:-1], u[1:-1, 1:-1])
+    ex.close()

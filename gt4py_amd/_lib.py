@@ -46,6 +46,12 @@ EXPORTED_SYMBOLS = (
     "gt4mi_dist_lap5_f64",
     "gt4mi_dist_lap5_f64_pipelined",
     "gt4mi_dist_lap5_f64_wide",
+    "gt4mi_rtc_compile",
+    "gt4mi_rtc_free",
+    "gt4mi_module_load",
+    "gt4mi_module_unload",
+    "gt4mi_module_function",
+    "gt4mi_launch",
     "gt4mi_stream_copy",
 )
 
@@ -172,6 +178,21 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_dist_lap5_f64_pipelined.argtypes = [P, DOM, FP, FP, I, I, P]
     lib.gt4mi_dist_lap5_f64_wide.restype = I
     lib.gt4mi_dist_lap5_f64_wide.argtypes = [P, DOM, FP, FP, I, I, I, I, P]
+    SZ = ctypes.c_size_t
+    lib.gt4mi_rtc_compile.restype = I
+    lib.gt4mi_rtc_compile.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), I, PP,
+                                      ctypes.POINTER(SZ), ctypes.c_char_p, SZ]
+    lib.gt4mi_rtc_free.restype = I
+    lib.gt4mi_rtc_free.argtypes = [P]
+    lib.gt4mi_module_load.restype = I
+    lib.gt4mi_module_load.argtypes = [P, PP]
+    lib.gt4mi_module_unload.restype = I
+    lib.gt4mi_module_unload.argtypes = [P]
+    lib.gt4mi_module_function.restype = I
+    lib.gt4mi_module_function.argtypes = [P, ctypes.c_char_p, PP]
+    U3 = ctypes.POINTER(ctypes.c_uint32)
+    lib.gt4mi_launch.restype = I
+    lib.gt4mi_launch.argtypes = [P, U3, U3, P, SZ, P, EI]
 
 
 def load() -> ctypes.CDLL:
@@ -209,6 +230,23 @@ def check(func: str, status: int) -> None:
 
 def domain3(domain: Sequence[int]):
     return _Int3(*map(int, domain))
+
+
+def rtc_compile(source: str, name: str = "gt4mi_stencil.hip", options: Sequence[str] = ()) -> bytes:
+    """HIP source -> gfx950 code object (bytes) through hiprtc inside the library.  Needs no GPU."""
+    lib = load()
+    code, size = ctypes.c_void_p(), ctypes.c_size_t()
+    log = ctypes.create_string_buffer(1 << 16)
+    opts = (ctypes.c_char_p * max(len(options), 1))(*[o.encode() for o in options])
+    rc = lib.gt4mi_rtc_compile(source.encode(), name.encode(), opts, len(options), ctypes.byref(code),
+                               ctypes.byref(size), log, len(log))
+    if rc != OK:
+        raise NativeError("gt4mi_rtc_compile", rc,
+                          lib.gt4mi_last_error().decode("utf-8", "replace") + "\n" + log.value.decode("utf-8", "replace"))
+    try:
+        return ctypes.string_at(code, size.value)
+    finally:
+        lib.gt4mi_rtc_free(code)
 
 
 def device_info() -> str:

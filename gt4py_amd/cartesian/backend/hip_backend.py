@@ -4,11 +4,13 @@ Registered through the reference's own plug-in mechanism (``@register`` on a ``B
 with ``name / options / storage_info / languages`` --
 /root/reference/src/gt4py/cartesian/backend/base.py:35-152; GPU precedent ``GTGpuBackend``,
 backend/gtcpp_backend.py:169-183).  Where ``gt:gpu`` generates GridTools C++ and JIT-compiles a
-pybind11 module, this backend recognises the stencil (hip_templates.py) and binds it to a
-hand-written gfx950 kernel in ``libgt4py_amd.so`` through the C ABI (include/gt4py_amd.h).
+pybind11 module, this backend first tries to recognise the stencil (hip_templates.py) and bind it to a
+hand-written gfx950 kernel in ``libgt4py_amd.so`` through the C ABI (include/gt4py_amd.h); any other
+stencil of the accepted sub-language goes to the generic executor (hip_codegen.py -> HIP source ->
+hiprtc inside the library -> one launch per stage, hip_generic.py).
 
-No generic code generation and no fallback: a stencil that is not one of the kernel families raises
-``NotImplementedError`` at decoration time; a missing shared library raises ``RuntimeError``.
+There is no CPU fallback: what neither path can run exactly raises ``NotImplementedError`` at
+decoration time; a missing shared library raises ``RuntimeError``.
 """
 
 from __future__ import annotations
@@ -20,7 +22,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple, Type
 
 import numpy as np
 
-from . import base, hip_templates
+from . import base, hip_codegen, hip_generic, hip_templates
 from .. import definitions as gt_definitions, frontend, ir
 from ..stencil_object import StencilObject
 from ... import _lib
@@ -218,20 +220,28 @@ class HipMI300Backend(base.BaseBackend):
     options = {
         # same meaning as gt:gpu's option (backend/gtcpp_backend.py:178): synchronise after each call
         "device_sync": {"versioning": True, "type": bool},
+        # False: skip the hand-written kernel library and always generate code (testing, comparisons)
+        "use_kernel_library": {"versioning": True, "type": bool},
     }
     storage_info = HIP_MI300_LAYOUT
     languages = {"computation": "hip", "bindings": ["c-abi/ctypes"]}
 
     def make_stencil_class(self) -> Type[StencilObject]:
         builder = self.builder
-        binding = recognise(builder.stencil_ir, builder.options)
+        binding = None
+        if builder.options.backend_opts.get("use_kernel_library", True):
+            binding = recognise(builder.stencil_ir, builder.options)
+        program = None
         if binding is None:
-            supported = ", ".join(list(_LAP_VARIANTS) + list(_HDIFF_TEMPLATES) + ["tridiagonal_solver"])
-            raise NotImplementedError(
-                f"Stencil '{builder.options.name}' is not one of the shapes backend 'hip:mi300' implements "
-                f"with hand-written gfx950 kernels ({supported}; see gt4py_amd/cartesian/backend/hip_templates.py). "
-                "There is no generic code generator and no CPU fallback in this backend."
-            )
+            try:
+                program = hip_codegen.generate(builder.stencil_ir)
+            except hip_codegen.UnsupportedStencil as ex:
+                supported = ", ".join(list(_LAP_VARIANTS) + list(_HDIFF_TEMPLATES) + ["tridiagonal_solver"])
+                raise NotImplementedError(
+                    f"Stencil '{builder.options.name}' is neither one of the hand-written gfx950 kernel families "
+                    f"of backend 'hip:mi300' ({supported}; gt4py_amd/cartesian/backend/hip_templates.py) nor "
+                    f"within reach of its generic executor: {ex}. There is no CPU fallback in this backend."
+                ) from ex
         sig = inspect.signature(builder.definition)
         sig = sig.replace(parameters=[p.replace(annotation=inspect.Parameter.empty) for p in sig.parameters.values()])
         attrs = {
@@ -245,9 +255,12 @@ class HipMI300Backend(base.BaseBackend):
             "_gt_constants_": dict(builder.externals),
             "_gt_options_": builder.options.as_dict(),
             "_gt_signature_": sig,
-            "_gt_binding_": binding,
             "_gt_device_sync_": bool(builder.options.backend_opts.get("device_sync", True)),
             "__module__": builder.options.module,
             "__doc__": builder.definition.__doc__,
         }
-        return type(builder.class_name, (HipStencilObject,), attrs)
+        if binding is not None:
+            attrs["_gt_binding_"] = binding
+            return type(builder.class_name, (HipStencilObject,), attrs)
+        attrs.update({"_gt_program_": program, "_gt_variants_": {}, "_gt_scratch_": {}})
+        return type(builder.class_name, (hip_generic.HipGenericStencilObject,), attrs)

@@ -1,0 +1,800 @@
+"""Generic executor, host half: typed stencil IR -> stages -> HIP source for gfx950.
+
+What the reference does for stencils on ``gt:gpu`` is a compiler tower (GTIR -> OIR -> optimisation
+passes -> GridTools C++ -> nvcc; /root/reference/src/gt4py/cartesian/gtc/gtcpp/gtcpp_codegen.py,
+backend/gtcpp_backend.py:109-166).  This module is a much smaller thing with the same contract --
+*the values the numpy backend produces* (gtc/numpy/npir_codegen.py:205-318) -- for the sub-language the
+frontend accepts (assignments of expression trees under ``computation``/``interval``):
+
+1. ``inline_horizontal_temporaries``: inside one PARALLEL interval block, temporaries that are read at
+   horizontal offsets and depend only on never-written inputs are substituted into their readers
+   (SSA over re-assigned names), i.e. recomputed at the shifted point.  The reference's counterpart is
+   on-the-fly recomputation in ``OnTheFlyMerging``
+   (gtc/passes/oir_optimizations/horizontal_execution_merging.py:135-330).  Values are unchanged: the
+   same expression is evaluated on the same inputs, in the same dtype, without contraction.
+2. ``plan_stages``: program order is cut into *stages* (one kernel launch each) wherever a value
+   written by one column is read by another (read-after-write or write-after-read at a horizontal
+   offset); inside a stage every (i, j) column is independent.  A stage is mapped ``ijk`` (one
+   thread per point) when it only holds PARALLEL work without vertical dependencies on its own
+   writes, else ``column`` (one thread per column, K loops inside -- the numpy backend's
+   ``for k_ in range(k, K)``, npir_codegen.py:243-248, turned inside out, which is exact because the
+   columns are independent).
+3. temporaries become thread-local values when a value never leaves the iteration that defined it,
+   global scratch (I-contiguous, extent-padded) otherwise; in ``column`` stages a value only read one
+   level behind the sweep is additionally forwarded in a register (cf. the reference's K caches,
+   gtc/passes/oir_optimizations/caches.py:92-143).
+4. ``emit``: one ``extern "C" __global__`` kernel per stage taking ONE struct by value.
+
+Every IR node carries its dtype and every conversion is an explicit ``Cast`` (frontend.py), so the C
+expression tree is a transliteration; hiprtc gets ``-ffp-contract=off`` and no fast-math flags.
+``**`` and transcendental functions go to the device math library and are NOT bit-identical to numpy.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import hashlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+
+from .. import analysis, ir
+
+Extent2 = analysis.Extent2
+
+
+class UnsupportedStencil(NotImplementedError):
+    """The stencil is outside what the generic executor can run exactly."""
+
+
+# ---------------------------------------------------------------------------------------------------
+# 1. inlining of horizontally offset temporaries
+# ---------------------------------------------------------------------------------------------------
+def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
+    return ir.FieldAccess(e.name, (e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]), e.dtype)
+
+
+def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[str]]:
+    """Returns (rewritten stencil, names of SSA values that are thread-local by construction)."""
+    written = {s.target.name for _, _, s in stencil.statements()}
+    pure_inputs = {f.name for f in stencil.fields if f.name not in written}
+    temps = {t.name: t for t in stencil.temporaries}
+
+    touched: Dict[str, Set[Tuple[int, int]]] = {}
+    k_offset_read: Set[str] = set()
+    ij_offset_read: Set[str] = set()
+    for ci, comp in enumerate(stencil.computations):
+        for bi, block in enumerate(comp.blocks):
+            for stmt in block.body:
+                touched.setdefault(stmt.target.name, set()).add((ci, bi))
+                for e in ir.walk(stmt.value):
+                    if isinstance(e, ir.FieldAccess):
+                        touched.setdefault(e.name, set()).add((ci, bi))
+                        if e.offset[2] != 0:
+                            k_offset_read.add(e.name)
+                        if e.offset[0] != 0 or e.offset[1] != 0:
+                            ij_offset_read.add(e.name)
+
+    cand = {
+        n for n in temps
+        if len(touched.get(n, ())) == 1 and n not in k_offset_read
+        and stencil.computations[next(iter(touched[n]))[0]].order is ir.LoopOrder.PARALLEL
+    }
+    changed = True
+    while changed:
+        changed = False
+        for _, _, stmt in stencil.statements():
+            if stmt.target.name in cand:
+                for e in ir.walk(stmt.value):
+                    if isinstance(e, ir.FieldAccess) and e.name not in pure_inputs and e.name not in cand:
+                        cand.discard(stmt.target.name)
+                        changed = True
+                        break
+    # inline what is read at a horizontal offset, plus everything such a definition refers to
+    inline = {n for n in cand if n in ij_offset_read}
+    changed = True
+    while changed:
+        changed = False
+        for _, _, stmt in stencil.statements():
+            if stmt.target.name in inline:
+                for e in ir.walk(stmt.value):
+                    if isinstance(e, ir.FieldAccess) and e.name in cand and e.name not in inline:
+                        inline.add(e.name)
+                        changed = True
+    if not inline:
+        return stencil, set()
+
+    ssa_locals: Dict[str, np.dtype] = {}
+    new_comps = []
+    for comp in stencil.computations:
+        new_blocks = []
+        for block in comp.blocks:
+            version: Dict[str, str] = {}
+            defs: Dict[str, ir.Expr] = {}
+            order: List[Tuple[str, object]] = []  # ("def", version) | ("stmt", Assign)
+
+            def to_versions(expr: ir.Expr) -> ir.Expr:
+                def fn(e):
+                    if isinstance(e, ir.FieldAccess) and e.name in inline:
+                        if e.name not in version:  # the frontend rejects this already
+                            raise UnsupportedStencil(f"temporary '{e.name}' is read before it is assigned")
+                        return ir.FieldAccess(version[e.name], e.offset, e.dtype)
+                    return e
+
+                return ir.map_expr(expr, fn)
+
+            for stmt in block.body:
+                value = to_versions(stmt.value)
+                name = stmt.target.name
+                if name in inline:
+                    v = f"{name}__v{sum(1 for k in defs if k.rsplit('__v', 1)[0] == name)}"
+                    defs[v] = value
+                    version[name] = v
+                    order.append(("def", v))
+                else:
+                    order.append(("stmt", ir.Assign(stmt.target, value)))
+
+            memo: Dict[Tuple[str, Tuple[int, int]], ir.Expr] = {}
+            needed: Set[str] = set()
+
+            def expand(expr: ir.Expr, shift: Tuple[int, int]) -> ir.Expr:
+                def fn(e):
+                    if isinstance(e, ir.FieldAccess):
+                        if e.name in defs:
+                            s = (shift[0] + e.offset[0], shift[1] + e.offset[1])
+                            if s == (0, 0):
+                                needed.add(e.name)
+                                return ir.FieldAccess(e.name, (0, 0, 0), e.dtype)
+                            key = (e.name, s)
+                            if key not in memo:
+                                memo[key] = expand(defs[e.name], s)
+                            return memo[key]
+                        return _shift_access(e, shift) if shift != (0, 0) else e
+                    return e
+
+                return ir.map_expr(expr, fn)
+
+            body_stmts = [(kind, expand(obj.value, (0, 0)) if kind == "stmt" else None, obj) for kind, obj in order]
+            local_defs: Dict[str, ir.Expr] = {}
+            pending = list(needed)
+            while pending:  # thread-local values referenced at the thread's own point
+                v = pending.pop()
+                if v in local_defs:
+                    continue
+                before = set(needed)
+                local_defs[v] = expand(defs[v], (0, 0))
+                pending.extend(needed - before)
+            new_body = []
+            for kind, value, obj in body_stmts:
+                if kind == "def":
+                    if obj in local_defs:
+                        dt = local_defs[obj].dtype
+                        ssa_locals[obj] = np.dtype(temps[obj.rsplit("__v", 1)[0]].dtype)
+                        new_body.append(ir.Assign(ir.FieldAccess(obj, (0, 0, 0), ssa_locals[obj]), local_defs[obj]))
+                else:
+                    new_body.append(ir.Assign(obj.target, value))
+            new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
+        new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
+    new_temps = tuple(t for t in stencil.temporaries if t.name not in inline) + tuple(
+        ir.FieldDecl(n, dt, ("I", "J", "K"), (), False) for n, dt in ssa_locals.items())
+    return ir.Stencil(stencil.name, stencil.fields, stencil.params, new_temps, tuple(new_comps)), set(ssa_locals)
+
+
+# ---------------------------------------------------------------------------------------------------
+# 2./3. stages and storage classes
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class Stmt:
+    target: ir.FieldAccess
+    value: ir.Expr
+    extent: Extent2
+
+
+@dataclass
+class Nest:
+    order: ir.LoopOrder
+    interval: ir.Interval
+    stmts: List[Stmt]
+    block_id: Tuple[int, int]
+    split_statements: bool = False  # PARALLEL block that has to run statement by statement over K
+
+
+@dataclass
+class Stage:
+    nests: List[Nest] = field(default_factory=list)
+    written: Set[str] = field(default_factory=set)
+    offset_reads: Set[str] = field(default_factory=set)
+    mapping: str = "ijk"
+    extent: Extent2 = analysis.ZERO_EXTENT
+
+
+@dataclass
+class Plan:
+    stencil: ir.Stencil  # after inlining
+    stages: List[Stage]
+    field_extents: Dict[str, Extent2]
+    locals: Set[str]  # thread-local temporaries
+    scratch: Dict[str, Tuple[np.dtype, Extent2]]  # temporaries in global memory
+    forwarded: Dict[Tuple[int, str], int]  # (stage index, name) -> +-1: value of the previous level kept in a register
+    prime: Dict[Tuple[int, int, str], Tuple[str, Optional[int]]]  # (stage, nest, name) -> (mode, previous nest)
+    register_only: Set[str]  # forwarded temporaries that never need memory
+    api_fields: List[ir.FieldDecl]  # API fields a kernel touches
+    params: List[ir.ScalarDecl]  # scalar parameters a kernel reads
+
+
+def _field_reads(expr: ir.Expr):
+    return [e for e in ir.walk(expr) if isinstance(e, ir.FieldAccess)]
+
+
+def plan_stages(stencil_in: ir.Stencil) -> Plan:
+    for d in (*stencil_in.fields, *stencil_in.temporaries):
+        if d.data_dims:
+            raise UnsupportedStencil(f"field '{d.name}' has data dimensions")
+    stencil, ssa_locals = inline_horizontal_temporaries(stencil_in)
+    extents = analysis.compute_extents(stencil)
+    written_anywhere = {s.target.name for _, _, s in stencil.statements()}
+
+    stages: List[Stage] = []
+    cur: Optional[Stage] = None
+    ext_iter = iter(extents.blocks)
+    for ci, comp in enumerate(stencil.computations):
+        for bi, block in enumerate(comp.blocks):
+            stmts = [Stmt(s.target, s.value, next(ext_iter)) for s in block.body]
+            units = [[s] for s in stmts] if comp.order is ir.LoopOrder.PARALLEL else [stmts]
+            for unit in units:
+                if not unit:
+                    continue
+                writes = {s.target.name for s in unit}
+                offreads = {
+                    e.name for s in unit for e in _field_reads(s.value)
+                    if (e.offset[0] != 0 or e.offset[1] != 0) and e.name in written_anywhere
+                }
+                if writes & offreads:
+                    raise UnsupportedStencil(
+                        f"{sorted(writes & offreads)} written and read at a horizontal offset inside one "
+                        f"{comp.order.value} interval block: columns are not independent")
+                if cur is not None and ((offreads & cur.written) or (writes & cur.offset_reads)):
+                    cur = None
+                if cur is None:
+                    cur = Stage()
+                    stages.append(cur)
+                if cur.nests and cur.nests[-1].block_id == (ci, bi):
+                    cur.nests[-1].stmts.extend(unit)
+                else:
+                    cur.nests.append(Nest(comp.order, block.interval, list(unit), (ci, bi)))
+                cur.written |= writes
+                cur.offset_reads |= offreads
+
+    # mapping, statement splitting, extents
+    for stage in stages:
+        column = False
+        for nest in stage.nests:
+            nest_writes = {s.target.name for s in nest.stmts}
+            if nest.order is not ir.LoopOrder.PARALLEL:
+                column = True
+            for s in nest.stmts:
+                for e in _field_reads(s.value):
+                    if e.offset[2] != 0 and e.name in stage.written:
+                        column = True
+                        if nest.order is ir.LoopOrder.PARALLEL and e.name in nest_writes:
+                            nest.split_statements = True
+        stage.mapping = "column" if column else "ijk"
+        ext = None
+        for nest in stage.nests:
+            for s in nest.stmts:
+                ext = s.extent if ext is None else analysis._union(ext, s.extent)
+        stage.extent = ext or analysis.ZERO_EXTENT
+
+    # storage class of the remaining temporaries
+    temp_names = {t.name for t in stencil.temporaries}
+    where: Dict[str, Set[int]] = {}  # name -> ids of nests touching it
+    nest_list = [(si, n) for si, st in enumerate(stages) for n in st.nests]
+    bad_local: Set[str] = set()
+    for nid, (si, nest) in enumerate(nest_list):
+        defined: Set[str] = set()
+        for s in nest.stmts:
+            for e in _field_reads(s.value):
+                if e.name in temp_names:
+                    where.setdefault(e.name, set()).add(nid)
+                    if e.offset != (0, 0, 0) or e.name not in defined or nest.split_statements:
+                        bad_local.add(e.name)
+            if s.target.name in temp_names:
+                where.setdefault(s.target.name, set()).add(nid)
+                defined.add(s.target.name)
+    local_names = {n for n in temp_names if n in where and n not in bad_local}
+    # a local that is written in one nest and never read anywhere is dead but harmless
+    scratch: Dict[str, Tuple[np.dtype, Extent2]] = {}
+    for t in stencil.temporaries:
+        if t.name in where and t.name not in local_names:
+            scratch[t.name] = (np.dtype(t.dtype), extents.fields.get(t.name, analysis.ZERO_EXTENT))
+    assert ssa_locals <= local_names | (temp_names - set(where)), "SSA values must stay thread-local"
+
+    # register forwarding in column stages: a value read exactly one level behind the sweep stays in a
+    # register instead of being re-read from memory.  Exact only when (a) every vertical-offset read
+    # of the name in the stage is that one pattern and (b) its writers and those readers cover the same
+    # columns (otherwise a skipped write would leave a stale register).
+    forwarded: Dict[Tuple[int, str], int] = {}
+    for si, stage in enumerate(stages):
+        if stage.mapping != "column":
+            continue
+        patterns: Dict[str, Set[Tuple[ir.LoopOrder, Tuple[int, int, int]]]] = {}
+        extents_of: Dict[str, Set[Extent2]] = {}
+        for nest in stage.nests:
+            for s in nest.stmts:
+                if s.target.name in stage.written:
+                    extents_of.setdefault(s.target.name, set()).add(s.extent)
+                for e in _field_reads(s.value):
+                    if e.offset[2] != 0 and e.name in stage.written:
+                        patterns.setdefault(e.name, set()).add((nest.order, e.offset))
+                        extents_of.setdefault(e.name, set()).add(s.extent)
+        for name, pats in patterns.items():
+            if name in local_names or len(extents_of.get(name, ())) != 1:
+                continue
+            if pats == {(ir.LoopOrder.FORWARD, (0, 0, -1))}:
+                forwarded[(si, name)] = -1
+            elif pats == {(ir.LoopOrder.BACKWARD, (0, 0, 1))}:
+                forwarded[(si, name)] = 1
+
+    # How each back-reading nest gets the register's first value, and which temporaries can live in
+    # registers alone.  "carried": the previous nest of the chain left it there (statically adjacent
+    # intervals, statically non-empty); "prime_if_prev_empty": adjacent, but the previous interval may be
+    # empty at run time; "prime": load the level behind the first one from memory.
+    def _static_length(iv: ir.Interval) -> Optional[int]:
+        return iv.end.offset - iv.start.offset if iv.start.level is iv.end.level else None
+
+    touched_in: Dict[str, Set[int]] = {}
+    for si, stage in enumerate(stages):
+        for nest in stage.nests:
+            for st in nest.stmts:
+                touched_in.setdefault(st.target.name, set()).add(si)
+                for e in _field_reads(st.value):
+                    touched_in.setdefault(e.name, set()).add(si)
+    prime: Dict[Tuple[int, int, str], Tuple[str, Optional[int]]] = {}
+    register_only: Set[str] = set()
+    for (si, name), back in forwarded.items():
+        stage = stages[si]
+        want = ir.LoopOrder.FORWARD if back == -1 else ir.LoopOrder.BACKWARD
+        needs_memory = name not in scratch or touched_in.get(name, set()) != {si}
+        prev: Optional[int] = None
+        for ni, nest in enumerate(stage.nests):
+            writes = [idx for idx, st in enumerate(nest.stmts) if st.target.name == name]
+            reads = [(idx, e) for idx, st in enumerate(nest.stmts) for e in _field_reads(st.value) if e.name == name]
+            if not writes and not reads:
+                continue
+            if nest.order is not want:
+                needs_memory = True
+                if writes:
+                    prev = None
+                continue
+            if any(e.offset == (0, 0, 0) and (not writes or idx <= writes[0]) for idx, e in reads):
+                needs_memory = True  # reads the current level before this iteration wrote it
+            if any(e.offset == (0, 0, back) for _, e in reads):
+                mode = "prime"
+                if prev is not None:
+                    piv = stage.nests[prev].interval
+                    adjacent = piv.end == nest.interval.start if back == -1 else piv.start == nest.interval.end
+                    if adjacent:
+                        n = _static_length(piv)
+                        mode = "carried" if (n is not None and n > 0) else "prime_if_prev_empty"
+                if mode != "carried":
+                    needs_memory = True
+                prime[(si, ni, name)] = (mode, prev)
+                if not writes:
+                    needs_memory = True  # the register is refilled from memory level by level
+            prev = ni
+        if not needs_memory:
+            register_only.add(name)
+    for name in register_only:
+        del scratch[name]
+
+    used: Set[str] = set()
+    for _, nest in nest_list:
+        for s in nest.stmts:
+            used.add(s.target.name)
+            for e in ir.walk(s.value):
+                if isinstance(e, (ir.FieldAccess, ir.ScalarAccess)):
+                    used.add(e.name)
+    api_fields = [f for f in stencil.fields if f.name in used]
+    params = [p for p in stencil.params if p.name in used]
+    return Plan(stencil, stages, dict(extents.fields), local_names, scratch, forwarded, prime, register_only,
+                api_fields, params)
+
+
+# ---------------------------------------------------------------------------------------------------
+# 4. emission
+# ---------------------------------------------------------------------------------------------------
+_CTYPE = {
+    "bool": "bool", "int8": "signed char", "int16": "short", "int32": "int", "int64": "long long",
+    "uint8": "unsigned char", "uint16": "unsigned short", "uint32": "unsigned int", "uint64": "unsigned long long",
+    "float32": "float", "float64": "double",
+}
+_CTYPES_TYPE = {
+    "bool": ctypes.c_bool, "int8": ctypes.c_int8, "int16": ctypes.c_int16, "int32": ctypes.c_int32,
+    "int64": ctypes.c_int64, "uint8": ctypes.c_uint8, "uint16": ctypes.c_uint16, "uint32": ctypes.c_uint32,
+    "uint64": ctypes.c_uint64, "float32": ctypes.c_float, "float64": ctypes.c_double,
+}
+
+PRELUDE = r"""
+// generated by gt4py_amd.cartesian.backend.hip_codegen -- do not edit
+#pragma clang fp contract(off)
+typedef long long gt_i64;
+#define GT_DEV static __device__ __forceinline__
+GT_DEV double gt_min(double a, double b) { return (a != a || b != b) ? a + b : (a < b ? a : b); }
+GT_DEV float gt_min(float a, float b) { return (a != a || b != b) ? a + b : (a < b ? a : b); }
+GT_DEV double gt_max(double a, double b) { return (a != a || b != b) ? a + b : (a > b ? a : b); }
+GT_DEV float gt_max(float a, float b) { return (a != a || b != b) ? a + b : (a > b ? a : b); }
+template <class T> GT_DEV T gt_min(T a, T b) { return a < b ? a : b; }
+template <class T> GT_DEV T gt_max(T a, T b) { return a > b ? a : b; }
+// numpy.remainder: result takes the sign of the divisor (npy_divmod)
+GT_DEV double gt_mod(double a, double b) {
+    double m = __builtin_fmod(a, b);
+    if (b == 0.0) return m;
+    if (m != 0.0) { if ((b < 0.0) != (m < 0.0)) m += b; } else { m = __builtin_copysign(0.0, b); }
+    return m;
+}
+GT_DEV float gt_mod(float a, float b) {
+    float m = __builtin_fmodf(a, b);
+    if (b == 0.0f) return m;
+    if (m != 0.0f) { if ((b < 0.0f) != (m < 0.0f)) m += b; } else { m = __builtin_copysignf(0.0f, b); }
+    return m;
+}
+template <class T> GT_DEV T gt_mod(T a, T b) {
+    if (b == 0) return 0;
+    T m = a % b;
+    return (m != 0 && ((m < 0) != (b < 0))) ? m + b : m;
+}
+GT_DEV double gt_pow(double a, double b) { return __builtin_pow(a, b); }
+GT_DEV float gt_pow(float a, float b) { return __builtin_powf(a, b); }
+template <class T> GT_DEV T gt_pow(T a, T b) {
+    T r = 1;
+    for (T n = 0; n < b; ++n) r *= a;
+    return r;
+}
+GT_DEV double gt_abs(double a) { return __builtin_fabs(a); }
+GT_DEV float gt_abs(float a) { return __builtin_fabsf(a); }
+template <class T> GT_DEV T gt_abs(T a) { return a < 0 ? -a : a; }
+#define GT_MATH1(name, fd, ff) \
+    GT_DEV double gt_##name(double a) { return fd(a); } \
+    GT_DEV float gt_##name(float a) { return ff(a); }
+GT_MATH1(sqrt, __builtin_sqrt, __builtin_sqrtf)
+GT_MATH1(floor, __builtin_floor, __builtin_floorf)
+GT_MATH1(ceil, __builtin_ceil, __builtin_ceilf)
+GT_MATH1(trunc, __builtin_trunc, __builtin_truncf)
+GT_MATH1(sin, __builtin_sin, __builtin_sinf)
+GT_MATH1(cos, __builtin_cos, __builtin_cosf)
+GT_MATH1(tan, __builtin_tan, __builtin_tanf)
+GT_MATH1(asin, __builtin_asin, __builtin_asinf)
+GT_MATH1(acos, __builtin_acos, __builtin_acosf)
+GT_MATH1(atan, __builtin_atan, __builtin_atanf)
+GT_MATH1(sinh, __builtin_sinh, __builtin_sinhf)
+GT_MATH1(cosh, __builtin_cosh, __builtin_coshf)
+GT_MATH1(tanh, __builtin_tanh, __builtin_tanhf)
+GT_MATH1(asinh, __builtin_asinh, __builtin_asinhf)
+GT_MATH1(acosh, __builtin_acosh, __builtin_acoshf)
+GT_MATH1(atanh, __builtin_atanh, __builtin_atanhf)
+GT_MATH1(exp, __builtin_exp, __builtin_expf)
+GT_MATH1(log, __builtin_log, __builtin_logf)
+GT_MATH1(log10, __builtin_log10, __builtin_log10f)
+GT_MATH1(cbrt, __builtin_cbrt, __builtin_cbrtf)
+template <class T> GT_DEV bool gt_isnan(T a) { return a != a; }
+template <class T> GT_DEV bool gt_isinf(T a) { return a == a && (a - a) != (a - a); }
+template <class T> GT_DEV bool gt_isfinite(T a) { return (a - a) == (a - a); }
+"""
+
+_EXACT_CALLS = {"abs", "min", "max", "mod", "sqrt", "floor", "ceil", "trunc", "isfinite", "isinf", "isnan"}
+
+
+def _c_ident(name: str) -> str:
+    return "".join(ch if ch.isalnum() else "_" for ch in name)
+
+
+def _literal(value, dtype: np.dtype) -> str:
+    dt = np.dtype(dtype)
+    if dt == np.dtype("bool"):
+        return "true" if value else "false"
+    if dt.kind == "f":
+        v = dt.type(value)
+        if np.isnan(v):
+            return f"(({_CTYPE[dt.name]})__builtin_nan(\"\"))"
+        if np.isinf(v):
+            return f"(({_CTYPE[dt.name]})({'-' if v < 0 else ''}__builtin_inf()))"
+        text = float(v).hex()  # exact for float32 too: every float32 is a double
+        return f"{text}f" if dt == np.dtype("float32") else text
+    suffix = {"int64": "LL", "uint64": "ULL", "uint32": "U"}.get(dt.name, "")
+    return f"(({_CTYPE[dt.name]}){int(value)}{suffix})"
+
+
+@dataclass
+class KernelSource:
+    name: str
+    mapping: str
+    extent: Extent2
+    block: Tuple[int, int, int]
+
+
+@dataclass
+class GeneratedProgram:
+    source: str
+    kernels: List[KernelSource]
+    args_struct: type  # ctypes.Structure subclass mirroring `struct gt_args`
+    plan: Plan
+    inexact_calls: Set[str]
+
+    @property
+    def digest(self) -> str:
+        return hashlib.sha256(self.source.encode()).hexdigest()[:16]
+
+
+class _Emitter:
+    def __init__(self, plan: Plan):
+        self.plan = plan
+        self.lines: List[str] = []
+        self.inexact: Set[str] = set()
+        self.decl_dtype: Dict[str, np.dtype] = {}
+        for d in (*plan.stencil.fields, *plan.stencil.temporaries):
+            self.decl_dtype[d.name] = np.dtype(d.dtype)
+        self.axes: Dict[str, Tuple[str, ...]] = {f.name: tuple(f.axes) for f in plan.stencil.fields}
+        self.global_names = [f.name for f in plan.api_fields] + list(plan.scratch)
+        self.written = {s.target.name for _, _, s in plan.stencil.statements()}
+
+    # -- expressions --------------------------------------------------------------------------
+    def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str]) -> str:
+        """C expression of a field read.  ``reg`` maps (name, k offset) -> register holding that level."""
+        name = e.name
+        if name in self.plan.locals:
+            return f"l_{_c_ident(name)}"
+        if (name, e.offset[2]) in reg and e.offset[:2] == (0, 0):
+            return reg[(name, e.offset[2])]
+        if name in self.plan.register_only:
+            raise AssertionError(f"register-only temporary '{name}' needs memory at offset {e.offset}")
+        c = _c_ident(name)
+        di, dj, dk = e.offset
+        axes = self.axes.get(name, ("I", "J", "K"))
+        terms = []
+        if "K" in axes:
+            terms.append(f"({k}{dk:+d}) * a.{c}_sk" if dk else f"{k} * a.{c}_sk")
+        if di and "I" in axes:
+            terms.append(f"{di} * GT_SI(a.{c}_si)")
+        if dj and "J" in axes:
+            terms.append(f"{dj} * a.{c}_sj")
+        return f"b_{c}[{' + '.join(terms) if terms else '0'}]"
+
+    def expr(self, e: ir.Expr, k: str, si: int, reg: Dict[str, str]) -> str:
+        rec = lambda x: self.expr(x, k, si, reg)  # noqa: E731
+        if isinstance(e, ir.Literal):
+            return _literal(e.value, e.dtype)
+        if isinstance(e, ir.FieldAccess):
+            return self.access(e, k, si, reg)
+        if isinstance(e, ir.ScalarAccess):
+            return f"a.p_{_c_ident(e.name)}"
+        if isinstance(e, ir.Cast):
+            dt = np.dtype(e.dtype)
+            inner = rec(e.expr)
+            return f"(({inner}) != 0)" if dt == np.dtype("bool") else f"(({_CTYPE[dt.name]})({inner}))"
+        ct = _CTYPE[np.dtype(e.dtype).name] if getattr(e, "dtype", None) is not None else None
+        if isinstance(e, ir.UnaryOp):
+            if e.op == "not":
+                return f"(!({rec(e.expr)}))"
+            return f"(({ct})({e.op}({rec(e.expr)})))"
+        if isinstance(e, ir.BinaryOp):
+            left, right = rec(e.left), rec(e.right)
+            if e.op in ("+", "-", "*", "/"):
+                return f"(({ct})(({left}) {e.op} ({right})))"
+            if e.op == "%":
+                return f"gt_mod({left}, {right})"
+            if e.op == "**":
+                self.inexact.add("**")
+                return f"gt_pow({left}, {right})"
+            if e.op in ir.COMPARISON_OPS:
+                return f"(({left}) {e.op} ({right}))"
+            if e.op == "and":
+                return f"((bool)({left}) & (bool)({right}))"
+            if e.op == "or":
+                return f"((bool)({left}) | (bool)({right}))"
+            raise UnsupportedStencil(f"binary operator {e.op}")
+        if isinstance(e, ir.TernaryOp):
+            return f"(({rec(e.cond)}) ? ({rec(e.true_expr)}) : ({rec(e.false_expr)}))"
+        if isinstance(e, ir.NativeCall):
+            if e.func.startswith("cast:"):
+                dt = np.dtype(e.dtype)
+                inner = rec(e.args[0])
+                return f"(({inner}) != 0)" if dt == np.dtype("bool") else f"(({_CTYPE[dt.name]})({inner}))"
+            if e.func not in _EXACT_CALLS:
+                self.inexact.add(e.func)
+            return f"gt_{e.func}({', '.join(rec(a) for a in e.args)})"
+        raise UnsupportedStencil(f"expression node {type(e).__name__}")
+
+    # -- statements ---------------------------------------------------------------------------
+    def guard(self, s: Stmt, stage: Stage) -> Optional[str]:
+        (ilo, ihi), (jlo, jhi) = s.extent
+        (silo, sihi), (sjlo, sjhi) = stage.extent
+        conds = []
+        if ilo != silo:
+            conds.append(f"i >= {ilo}")
+        if ihi != sihi:
+            conds.append(f"i < a.dI + ({ihi})")
+        if jlo != sjlo:
+            conds.append(f"j >= {jlo}")
+        if jhi != sjhi:
+            conds.append(f"j < a.dJ + ({jhi})")
+        return " && ".join(conds) if conds else None
+
+    def statement(self, s: Stmt, stage: Stage, si: int, k: str, reg: Dict, indent: str, carry: Sequence[str] = ()) -> None:
+        value = self.expr(s.value, k, si, reg)
+        name = s.target.name
+        g = self.guard(s, stage)
+        pad = indent
+        if g:
+            self.lines.append(f"{indent}if ({g}) {{")
+            pad = indent + "    "
+        if name in self.plan.locals:
+            self.lines.append(f"{pad}l_{_c_ident(name)} = {value};")
+        elif name in carry:  # keep the freshly written level for this iteration's later reads and the next one
+            self.lines.append(f"{pad}n_{_c_ident(name)} = {value};")
+            if name not in self.plan.register_only:
+                self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset), k, -1, {})} = n_{_c_ident(name)};")
+            reg[(name, 0)] = f"n_{_c_ident(name)}"
+        else:
+            self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset), k, -1, {})} = {value};")
+        if g:
+            self.lines.append(f"{indent}}}")
+
+    def column_in_extent(self, name: str, stage: Stage) -> Optional[str]:
+        """Condition for the thread's column to lie inside the extent ``name`` is accessed on."""
+        (ilo, ihi), (jlo, jhi) = self.plan.field_extents.get(name, analysis.ZERO_EXTENT)
+        (silo, sihi), (sjlo, sjhi) = stage.extent
+        conds = []
+        if ilo > silo:
+            conds.append(f"i >= {ilo}")
+        if ihi < sihi:
+            conds.append(f"i < a.dI + ({ihi})")
+        if jlo > sjlo:
+            conds.append(f"j >= {jlo}")
+        if jhi < sjhi:
+            conds.append(f"j < a.dJ + ({jhi})")
+        return " && ".join(conds) if conds else None
+
+    def local_decls(self, nest: Nest, indent: str) -> None:
+        seen = []
+        for s in nest.stmts:
+            n = s.target.name
+            if n in self.plan.locals and n not in seen:
+                seen.append(n)
+                self.lines.append(f"{indent}{_CTYPE[self.decl_dtype[n].name]} l_{_c_ident(n)};")
+
+    @staticmethod
+    def bound(b: ir.AxisBound) -> str:
+        return f"{b.offset}" if b.level is ir.Level.START else f"(a.dK + ({b.offset}))"
+
+    # -- kernels ------------------------------------------------------------------------------
+    def stage_globals(self, stage: Stage) -> List[str]:
+        names = []
+        for nest in stage.nests:
+            for s in nest.stmts:
+                for n in [s.target.name] + [e.name for e in _field_reads(s.value)]:
+                    if n not in self.plan.locals and n not in names:
+                        names.append(n)
+        return names
+
+    def kernel(self, si: int, stage: Stage, kname: str) -> KernelSource:
+        L = self.lines
+        (ilo, ihi), (jlo, jhi) = stage.extent
+        block = (64, 4, 1)
+        L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}(const gt_args a) {{')
+        L.append(f"    const gt_i64 i = (gt_i64)blockIdx.x * {block[0]} + threadIdx.x + ({ilo});")
+        L.append(f"    const gt_i64 j = (gt_i64)blockIdx.y * {block[1]} + threadIdx.y + ({jlo});")
+        L.append(f"    if (i >= a.dI + ({ihi}) || j >= a.dJ + ({jhi})) return;")
+        for n in self.stage_globals(stage):
+            if n in self.plan.register_only:
+                continue
+            c = _c_ident(n)
+            ct = _CTYPE[self.decl_dtype[n].name]
+            axes = self.axes.get(n, ("I", "J", "K"))
+            const = "" if n in stage.written else "const "
+            # scratch never aliases anything; API arrays only when the host checked that they are disjoint
+            qual = " __restrict__" if n in self.plan.scratch else " GT_RESTRICT"
+            off = " + ".join(t for t in (f"i * GT_SI(a.{c}_si)" if "I" in axes else "", f"j * a.{c}_sj" if "J" in axes else "") if t) or "0"
+            L.append(f"    {const}{ct}* const{qual} b_{c} = a.{c} + {off};")
+        if stage.mapping == "ijk":
+            L.append("    const gt_i64 k = blockIdx.z;")
+            for nest in stage.nests:
+                L.append(f"    if (k >= {self.bound(nest.interval.start)} && k < {self.bound(nest.interval.end)}) {{")
+                self.local_decls(nest, "        ")
+                for s in nest.stmts:
+                    self.statement(s, stage, si, "k", {}, "        ")
+                L.append("    }")
+        else:
+            stage_fwd = {n: d for (s_i, n), d in self.plan.forwarded.items() if s_i == si}
+            for n in stage_fwd:  # r_<n>: the level behind the sweep, alive across the stage's nests
+                L.append(f"    {_CTYPE[self.decl_dtype[n].name]} r_{_c_ident(n)} = {_CTYPE[self.decl_dtype[n].name]}();")
+            for ni, nest in enumerate(stage.nests):
+                L.append("    {")
+                L.append(f"        const gt_i64 k0 = {self.bound(nest.interval.start)}, k1 = {self.bound(nest.interval.end)};")
+                back = -1 if nest.order is ir.LoopOrder.FORWARD else 1
+                active = [n for n, d in stage_fwd.items() if nest.order is not ir.LoopOrder.PARALLEL and d == back
+                          and any(s.target.name == n or any(e.name == n for e in _field_reads(s.value)) for s in nest.stmts)]
+                loop = ("for (gt_i64 k = k1 - 1; k >= k0; --k)" if nest.order is ir.LoopOrder.BACKWARD
+                        else "for (gt_i64 k = k0; k < k1; ++k)")
+                groups = [[s] for s in nest.stmts] if nest.split_statements else [nest.stmts]
+                first = "k0" if nest.order is ir.LoopOrder.FORWARD else "(k1 - 1)"
+                for n in active:
+                    mode, prev = self.plan.prime.get((si, ni, n), (None, None))
+                    if mode in (None, "carried"):
+                        continue
+                    # Priming from memory: the first iteration's read of the level behind is an access the
+                    # stencil makes anyway, so it is inside the array whenever the loop runs at all and the
+                    # column lies in the extent the field is accessed on.
+                    conds = ["k1 > k0"]
+                    if mode == "prime_if_prev_empty":
+                        piv = stage.nests[prev].interval
+                        conds.append(f"!({self.bound(piv.end)} > {self.bound(piv.start)})")
+                    cond = self.column_in_extent(n, stage)
+                    if cond:
+                        conds.append(cond)
+                    L.append(f"        if ({' && '.join(conds)}) r_{_c_ident(n)} = "
+                             f"{self.access(ir.FieldAccess(n, (0, 0, back)), first, -1, {})};")
+                for group in groups:
+                    L.append(f"        {loop} {{")
+                    self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), "            ")
+                    carry = [n for n in active if any(s.target.name == n for s in group)]
+                    reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
+                    for n in carry:
+                        L.append(f"            {_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
+                    for s in group:
+                        self.statement(s, stage, si, "k", reg, "            ", carry)
+                    for n in active:
+                        c = _c_ident(n)
+                        if n in carry:
+                            L.append(f"            r_{c} = n_{c};")
+                        else:  # only read in this nest: rotate in the level just passed
+                            cond = self.column_in_extent(n, stage)
+                            load = self.access(ir.FieldAccess(n, (0, 0, 0)), "k", -1, {})
+                            L.append(f"            {'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
+                    L.append("        }")
+                L.append("    }")
+        L.append("}")
+        L.append("")
+        return KernelSource(kname, stage.mapping, stage.extent, block)
+
+
+def generate(stencil: ir.Stencil) -> GeneratedProgram:
+    """Typed IR -> HIP source + the ctypes mirror of its argument struct."""
+    plan = plan_stages(stencil)
+    em = _Emitter(plan)
+    fields_c: List[Tuple[str, object]] = []
+    struct_lines = ["struct gt_args {"]
+    for n in em.global_names:
+        c = _c_ident(n)
+        ct = _CTYPE[em.decl_dtype[n].name]
+        struct_lines.append(f"    {ct}* {c}; gt_i64 {c}_si, {c}_sj, {c}_sk;")
+        fields_c += [(c, ctypes.c_void_p), (f"{c}_si", ctypes.c_int64), (f"{c}_sj", ctypes.c_int64),
+                     (f"{c}_sk", ctypes.c_int64)]
+    for p in plan.params:
+        dt = np.dtype(p.dtype)
+        struct_lines.append(f"    {_CTYPE[dt.name]} p_{_c_ident(p.name)};")
+        fields_c.append((f"p_{_c_ident(p.name)}", _CTYPES_TYPE[dt.name]))
+    struct_lines.append("    gt_i64 dI, dJ, dK;")
+    struct_lines.append("};")
+    fields_c += [("dI", ctypes.c_int64), ("dJ", ctypes.c_int64), ("dK", ctypes.c_int64)]
+    args_struct = type("gt_args", (ctypes.Structure,), {"_fields_": fields_c})
+
+    kernels = []
+    for si, stage in enumerate(plan.stages):
+        kernels.append(em.kernel(si, stage, f"gt4mi_{_c_ident(stencil.name)}_stage{si}"))
+    header = [
+        PRELUDE,
+        "#ifdef GT4MI_UNIT_I_STRIDE",
+        "#define GT_SI(x) 1",
+        "#else",
+        "#define GT_SI(x) (x)",
+        "#endif",
+        "#ifdef GT4MI_NO_ALIAS",
+        "#define GT_RESTRICT __restrict__",
+        "#else",
+        "#define GT_RESTRICT",
+        "#endif",
+        "",
+    ]
+    source = "\n".join(header + struct_lines + [""] + em.lines)
+    return GeneratedProgram(source, kernels, args_struct, plan, set(em.inexact))

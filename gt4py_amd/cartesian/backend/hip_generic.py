@@ -1,0 +1,140 @@
+"""Generic executor, run-time half: compile the generated program once per layout variant, keep the
+scratch buffers of the temporaries, fill the kernel-argument block and launch stage by stage through
+the C ABI (``gt4mi_rtc_compile`` / ``gt4mi_module_*`` / ``gt4mi_launch`` in include/gt4py_amd.h).
+
+Counterpart in the reference: the generated module's ``run()`` calling the JIT-built extension
+(/root/reference/src/gt4py/cartesian/backend/gtc_common.py:144-168, :226-296).  Temporaries are owned by
+the stencil object and cached per domain, where GridTools allocates them inside ``run_computation``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Any, Dict, List, Tuple
+
+import numpy as np
+
+from . import hip_codegen
+from ..stencil_object import StencilObject
+from ... import _lib
+
+_U3 = ctypes.c_uint32 * 3
+
+
+class _Variant:
+    """One compiled flavour of a generated program: loaded module + kernel handles."""
+
+    def __init__(self, program: hip_codegen.GeneratedProgram, unit_i: bool, no_alias: bool):
+        options = []
+        if unit_i:
+            options.append("-DGT4MI_UNIT_I_STRIDE=1")
+        if no_alias:
+            options.append("-DGT4MI_NO_ALIAS=1")
+        lib = _lib.load()
+        self.code = _lib.rtc_compile(program.source, f"{program.plan.stencil.name}.hip", options)
+        self._code_buf = ctypes.create_string_buffer(self.code, len(self.code))
+        module = ctypes.c_void_p()
+        _lib.check("gt4mi_module_load", lib.gt4mi_module_load(self._code_buf, ctypes.byref(module)))
+        self.module = module
+        self.functions: List[ctypes.c_void_p] = []
+        for kern in program.kernels:
+            fn = ctypes.c_void_p()
+            _lib.check("gt4mi_module_function",
+                       lib.gt4mi_module_function(module, kern.name.encode(), ctypes.byref(fn)))
+            self.functions.append(fn)
+
+
+def _ranges_disjoint(ranges: List[Tuple[int, int]]) -> bool:
+    ranges = sorted(ranges)
+    return all(ranges[n][1] <= ranges[n + 1][0] for n in range(len(ranges) - 1))
+
+
+class HipGenericStencilObject(StencilObject):
+    """StencilObject whose ``run`` launches run-time compiled gfx950 kernels, one per stage."""
+
+    _gt_program_: hip_codegen.GeneratedProgram
+    _gt_device_sync_: bool
+    _gt_variants_: Dict[Tuple[bool, bool], _Variant]
+    _gt_scratch_: Dict[Tuple[int, int, int], Any]
+
+    def _run_implementation(self, domain, origin, exec_info, arguments: Dict[str, Any]) -> None:
+        cls = type(self)
+        program = cls._gt_program_
+        plan = program.plan
+        lib = _lib.load()
+        try:
+            import torch
+
+            stream = torch.cuda.current_stream().cuda_stream
+        except Exception as ex:  # pragma: no cover - no GPU
+            raise RuntimeError("hip:mi300 needs PyTorch-ROCm with a visible MI355X") from ex
+        dI, dJ, dK = (int(d) for d in domain)
+        args = program.args_struct()
+        unit_i = True
+        spans: List[Tuple[int, int]] = []
+        for decl in plan.api_fields:
+            arr = arguments[decl.name]
+            c = hip_codegen._c_ident(decl.name)
+            isz = arr.itemsize
+            byte_strides = dict(zip(decl.axes, arr.strides))
+            org = dict(zip(decl.axes, origin[decl.name]))
+            if any(s % isz for s in arr.strides):
+                raise ValueError(f"field '{decl.name}': strides {arr.strides} are not multiples of the item size")
+            ptr = arr.ptr + sum(org[a] * byte_strides[a] for a in decl.axes)
+            setattr(args, c, ptr)
+            for axis, suffix in (("I", "si"), ("J", "sj"), ("K", "sk")):
+                setattr(args, f"{c}_{suffix}", byte_strides.get(axis, 0) // isz)
+            if "I" in decl.axes and byte_strides["I"] != isz:
+                unit_i = False
+            hi = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s > 0) + isz
+            lo = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s < 0)
+            spans.append((arr.ptr + lo, arr.ptr + hi))
+        if plan.scratch:
+            key = (dI, dJ, dK)
+            entry = cls._gt_scratch_.get(key)
+            if entry is None:
+                layout, total = {}, 0
+                for name, (dt, ((ilo, ihi), (jlo, jhi))) in plan.scratch.items():
+                    ni = -(-(dI + ihi - ilo) // 32) * 32  # rows padded like the storage preset
+                    nj = dJ + jhi - jlo
+                    layout[name] = (total, ni, nj, dt.itemsize, -ilo, -jlo)
+                    total += -(-(ni * nj * max(dK, 1) * dt.itemsize) // 256) * 256
+                buf = torch.empty(total, dtype=torch.uint8, device="cuda")
+                cls._gt_scratch_.clear()  # one domain at a time: scratch can be gigabytes
+                entry = cls._gt_scratch_[key] = (buf, layout)
+            buf, layout = entry
+            base = buf.data_ptr()
+            for name, (off, ni, nj, isz, oi, oj) in layout.items():
+                c = hip_codegen._c_ident(name)
+                setattr(args, c, base + off + (oi + oj * ni) * isz)
+                setattr(args, f"{c}_si", 1)
+                setattr(args, f"{c}_sj", ni)
+                setattr(args, f"{c}_sk", ni * nj)
+        for p in plan.params:
+            setattr(args, f"p_{hip_codegen._c_ident(p.name)}", np.dtype(p.dtype).type(arguments[p.name]).item())
+        args.dI, args.dJ, args.dK = dI, dJ, dK
+
+        vkey = (unit_i, _ranges_disjoint(spans))
+        variant = cls._gt_variants_.get(vkey)
+        if variant is None:
+            variant = cls._gt_variants_[vkey] = _Variant(program, *vkey)
+
+        info = _lib.ExecInfo() if exec_info is not None else None
+        t0 = t1 = None
+        for kern, fn in zip(program.kernels, variant.functions):
+            (ilo, ihi), (jlo, jhi) = kern.extent
+            ni, nj = dI + ihi - ilo, dJ + jhi - jlo
+            if ni <= 0 or nj <= 0 or dK <= 0:
+                continue
+            grid = _U3(-(-ni // kern.block[0]), -(-nj // kern.block[1]), dK if kern.mapping == "ijk" else 1)
+            rc = lib.gt4mi_launch(fn, grid, _U3(*kern.block), ctypes.byref(args), ctypes.sizeof(args), stream,
+                                  ctypes.byref(info) if info is not None else None)
+            _lib.check("gt4mi_launch", rc)
+            if info is not None:
+                t0 = info.run_cpp_start_time if t0 is None else t0
+                t1 = info.run_cpp_end_time
+        if cls._gt_device_sync_:
+            _lib.check("gt4mi_stream_sync", lib.gt4mi_stream_sync(stream))
+        if exec_info is not None and t0 is not None:
+            exec_info["run_cpp_start_time"] = t0
+            exec_info["run_cpp_end_time"] = t1

@@ -12,6 +12,7 @@
 #include "halo.hip.h"
 #include "hdiff.hip.h"
 #include "lap5.hip.h"
+#include "rtc.hip.h"
 #include "tridiag.hip.h"
 
 namespace {
@@ -386,6 +387,68 @@ int gt4mi_stream_copy(const void* src, void* dst, size_t nbytes, void* stream) {
                        static_cast<hipStream_t>(stream), static_cast<const gt4mi::u32x4*>(src),
                        static_cast<gt4mi::u32x4*>(dst), nvec);
     GT4MI_HIP_CHECK(hipGetLastError());
+    return GT4MI_OK;
+}
+
+// ---- run-time compiled stencils (generic executor) -------------------------------------------------
+
+int gt4mi_rtc_compile(const char* source, const char* name, const char* const* options, int n_options,
+                      void** code, size_t* code_size, char* log, size_t log_size) {
+    return gt4mi::rtc_compile(source, name, options, n_options, code, code_size, log, log_size);
+}
+
+int gt4mi_rtc_free(void* code) {
+    free(code);
+    return GT4MI_OK;
+}
+
+int gt4mi_module_load(const void* code, gt4mi_module** module) {
+    if (code == nullptr || module == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "module_load: null argument");
+    auto* m = new gt4mi_module();
+    hipError_t e = hipModuleLoadData(&m->module, code);
+    if (e != hipSuccess) {
+        delete m;
+        return gt4mi::fail(GT4MI_ERR_HIP, "hipModuleLoadData failed: %s", hipGetErrorString(e));
+    }
+    *module = m;
+    return GT4MI_OK;
+}
+
+int gt4mi_module_unload(gt4mi_module* module) {
+    if (module == nullptr) return GT4MI_OK;
+    hipError_t e = module->module ? hipModuleUnload(module->module) : hipSuccess;
+    delete module;
+    if (e != hipSuccess) return gt4mi::fail(GT4MI_ERR_HIP, "hipModuleUnload failed: %s", hipGetErrorString(e));
+    return GT4MI_OK;
+}
+
+int gt4mi_module_function(gt4mi_module* module, const char* name, void** function) {
+    if (module == nullptr || name == nullptr || function == nullptr)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "module_function: null argument");
+    hipFunction_t fn = nullptr;
+    hipError_t e = hipModuleGetFunction(&fn, module->module, name);
+    if (e != hipSuccess)
+        return gt4mi::fail(GT4MI_ERR_HIP, "hipModuleGetFunction(%s) failed: %s", name, hipGetErrorString(e));
+    *function = fn;
+    return GT4MI_OK;
+}
+
+int gt4mi_launch(void* function, const uint32_t grid[3], const uint32_t block[3], const void* args,
+                 size_t args_size, void* stream, gt4mi_exec_info* info) {
+    Timer timer(info);
+    if (function == nullptr || grid == nullptr || block == nullptr || (args == nullptr && args_size != 0))
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "launch: null argument");
+    if (grid[0] == 0 || grid[1] == 0 || grid[2] == 0) return GT4MI_OK;  // empty iteration space
+    if ((size_t)block[0] * block[1] * block[2] > 1024 || block[0] * block[1] * block[2] == 0)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "launch: workgroup of %u x %u x %u threads", block[0],
+                           block[1], block[2]);
+    if (grid[1] > 65535u || grid[2] > 65535u)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "launch: grid %u x %u x %u exceeds 65535 in y or z", grid[0],
+                           grid[1], grid[2]);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args), HIP_LAUNCH_PARAM_BUFFER_SIZE,
+                     &args_size, HIP_LAUNCH_PARAM_END};
+    GT4MI_HIP_CHECK(hipModuleLaunchKernel(static_cast<hipFunction_t>(function), grid[0], grid[1], grid[2], block[0],
+                                          block[1], block[2], 0, static_cast<hipStream_t>(stream), nullptr, extra));
     return GT4MI_OK;
 }
 

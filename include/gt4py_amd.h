@@ -204,6 +204,29 @@ int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], con
                              const gt4mi_field* out, int variant, int sides, int halo, int phase,
                              void* main_stream);
 
+/* ---- run-time compiled stencils (generic executor) --------------------------------------------
+ * Replaces the reference's per-stencil JIT build: setuptools + nvcc building a pybind11 extension
+ * (/root/reference/src/gt4py/cartesian/backend/pyext_builder.py:176-303, driven by
+ * backend/gtc_common.py:226-275) and that extension's `run_computation`
+ * (backend/gtc_common.py:65-103).  The host generates HIP source for stencils outside the hand-written
+ * families (gt4py_amd/cartesian/backend/hip_codegen.py); these entries compile it in-process with
+ * hiprtc for gfx950 (always with -O3 -std=c++17 -ffp-contract=off; `options` are appended), load the
+ * code object and launch kernels from it.  Compilation needs no GPU; load/launch do.
+ *
+ * gt4mi_rtc_compile: *code is malloc'ed by the library, release it with gt4mi_rtc_free.  `log`
+ * (optional) receives the compiler log, truncated to log_size.
+ * gt4mi_launch: `args` is the kernel-argument block (the generated kernel takes ONE struct by value;
+ * the host lays it out with C rules), copied at launch.  grid is in workgroups. */
+typedef struct gt4mi_module gt4mi_module;
+int gt4mi_rtc_compile(const char* source, const char* name, const char* const* options, int n_options,
+                      void** code, size_t* code_size, char* log, size_t log_size);
+int gt4mi_rtc_free(void* code);
+int gt4mi_module_load(const void* code, gt4mi_module** module);
+int gt4mi_module_unload(gt4mi_module* module);
+int gt4mi_module_function(gt4mi_module* module, const char* name, void** function);
+int gt4mi_launch(void* function, const uint32_t grid[3], const uint32_t block[3], const void* args,
+                 size_t args_size, void* stream, gt4mi_exec_info* info);
+
 /* ---- measurement helper ---------------------------------------------------------------------
  * Streaming device copy of nbytes (multiple of 16) with 16-byte lanes: the "achievable HBM"
  * yardstick printed next to the stencil numbers. */

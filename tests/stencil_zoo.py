@@ -1,0 +1,263 @@
+"""Stencil definitions shared by the code-generation tests (CPU: planning + compilation; GPU: values).
+
+Most are restatements of definitions in the reference's test-suite
+(/root/reference/tests/cartesian_tests/integration_tests/multi_feature_tests/stencil_definitions.py and
+test_suites.py); the rest are small shapes that pin one decision of the stage planner each.
+Annotation strings are evaluated by ``gtscript.stencil`` (Field, IJ, K, np are in scope there).
+"""
+# flake8: noqa: F821, F841
+import numpy as np
+
+F64 = "Field[np.float64]"
+F32 = "Field[np.float32]"
+
+
+def copy_stencil(a: F64, b: F64):
+    """stencil_definitions.py:66-69"""
+    with computation(PARALLEL), interval(...):
+        b = a
+
+
+def native_functions(a: F64, b: F64):
+    """stencil_definitions.py:145-153 (the exactly-rounded subset)"""
+    with computation(PARALLEL), interval(...):
+        abs_res = abs(a)
+        max_res = max(abs_res, b)
+        min_res = min(max_res, 42)
+        b = sqrt(abs(min_res)) + floor(a) - ceil(b) + trunc(a * 3.5) + (a % 0.3)
+
+
+def ternary_mix(a: F64, b: F64, c: F64):
+    with computation(PARALLEL), interval(...):
+        c = max(a, b) if (a > 0.0 and b < 0.5) or not (a < -0.5) else sqrt(abs(a)) / (b + 2.0)
+
+
+def mixed_precision(a: F32, b: F64, c: F32, *, w: np.float32):
+    """f32 fields with f64 literals: everything computed in f64, rounded once on store."""
+    with computation(PARALLEL), interval(...):
+        t = a * 0.3 + b
+        c = t * w - a / 3.0
+
+
+def int_fields(a: "Field[np.int32]", b: "Field[np.int64]", c: "Field[np.int64]"):
+    with computation(PARALLEL), interval(...):
+        c = a * 3 + b - (a if a > b else b) + (a % 7)
+
+
+def k_intervals(a: F64, b: F64, out: F64):
+    """different expressions per K interval, reads of inputs at K offsets (large_k_interval-like)"""
+    with computation(PARALLEL):
+        with interval(0, 2):
+            out = a
+        with interval(2, -1):
+            out = a + b[0, 0, -2] * b[0, 0, 1]
+        with interval(-1, None):
+            out = a - b[0, 0, -1]
+
+
+def horizontal_diffusion(in_field: F64, out_field: F64, coeff: F64):
+    """stencil_definitions.py:316-328"""
+    with computation(PARALLEL), interval(...):
+        lap_field = 4.0 * in_field[0, 0, 0] - (
+            in_field[1, 0, 0] + in_field[-1, 0, 0] + in_field[0, 1, 0] + in_field[0, -1, 0]
+        )
+        res = lap_field[1, 0, 0] - lap_field[0, 0, 0]
+        flx_field = 0 if (res * (in_field[1, 0, 0] - in_field[0, 0, 0])) > 0 else res
+        res = lap_field[0, 1, 0] - lap_field[0, 0, 0]
+        fly_field = 0 if (res * (in_field[0, 1, 0] - in_field[0, 0, 0])) > 0 else res
+        out_field = in_field[0, 0, 0] - coeff[0, 0, 0] * (
+            flx_field[0, 0, 0] - flx_field[-1, 0, 0] + fly_field[0, 0, 0] - fly_field[0, -1, 0]
+        )
+
+
+def horizontal_diffusion_f32(in_field: F32, out_field: F32, coeff: F32):
+    with computation(PARALLEL), interval(...):
+        lap_field = 4.0 * in_field[0, 0, 0] - (
+            in_field[1, 0, 0] + in_field[-1, 0, 0] + in_field[0, 1, 0] + in_field[0, -1, 0]
+        )
+        res = lap_field[1, 0, 0] - lap_field[0, 0, 0]
+        flx_field = 0 if (res * (in_field[1, 0, 0] - in_field[0, 0, 0])) > 0 else res
+        res = lap_field[0, 1, 0] - lap_field[0, 0, 0]
+        fly_field = 0 if (res * (in_field[0, 1, 0] - in_field[0, 0, 0])) > 0 else res
+        out_field = in_field[0, 0, 0] - coeff[0, 0, 0] * (
+            flx_field[0, 0, 0] - flx_field[-1, 0, 0] + fly_field[0, 0, 0] - fly_field[0, -1, 0]
+        )
+
+
+def laplacian(inp: F64, out: F64):
+    with computation(PARALLEL), interval(...):
+        out = -4.0 * inp[0, 0, 0] + inp[-1, 0, 0] + inp[1, 0, 0] + inp[0, -1, 0] + inp[0, 1, 0]
+
+
+def tridiagonal_solver(inf: F64, diag: F64, sup: F64, rhs: F64, out: F64):
+    """stencil_definitions.py:219-232"""
+    with computation(FORWARD):
+        with interval(0, 1):
+            sup = sup / diag
+            rhs = rhs / diag
+        with interval(1, None):
+            sup = sup / (diag - sup[0, 0, -1] * inf)
+            rhs = (rhs - inf * rhs[0, 0, -1]) / (diag - sup[0, 0, -1] * inf)
+    with computation(BACKWARD):
+        with interval(-1, None):
+            out = rhs
+        with interval(0, -1):
+            out = rhs - sup * out[0, 0, 1]
+
+
+def vertical_advection_dycore(utens_stage: F64, u_stage: F64, wcon: F64, u_pos: F64, utens: F64, *, dtr_stage: float):
+    """stencil_definitions.py:235-313"""
+    from __externals__ import BET_M, BET_P
+
+    with computation(FORWARD):
+        with interval(0, 1):
+            gcv = 0.25 * (wcon[1, 0, 1] + wcon[0, 0, 1])
+            cs = gcv * BET_M
+
+            ccol = gcv * BET_P
+            bcol = dtr_stage - ccol[0, 0, 0]
+
+            # update the d column
+            correction_term = -cs * (u_stage[0, 0, 1] - u_stage[0, 0, 0])
+            dcol = dtr_stage * u_pos[0, 0, 0] + utens[0, 0, 0] + utens_stage[0, 0, 0] + correction_term
+
+            # Thomas forward
+            divided = 1.0 / bcol[0, 0, 0]
+            ccol = ccol[0, 0, 0] * divided
+            dcol = dcol[0, 0, 0] * divided
+
+        with interval(1, -1):
+            gav = -0.25 * (wcon[1, 0, 0] + wcon[0, 0, 0])
+            gcv = 0.25 * (wcon[1, 0, 1] + wcon[0, 0, 1])
+
+            as_ = gav * BET_M
+            cs = gcv * BET_M
+
+            acol = gav * BET_P
+            ccol = gcv * BET_P
+            bcol = dtr_stage - acol[0, 0, 0] - ccol[0, 0, 0]
+
+            # update the d column
+            correction_term = -as_ * (u_stage[0, 0, -1] - u_stage[0, 0, 0]) - cs * (
+                u_stage[0, 0, 1] - u_stage[0, 0, 0]
+            )
+            dcol = dtr_stage * u_pos[0, 0, 0] + utens[0, 0, 0] + utens_stage[0, 0, 0] + correction_term
+
+            # Thomas forward
+            divided = 1.0 / (bcol[0, 0, 0] - ccol[0, 0, -1] * acol[0, 0, 0])
+            ccol = ccol[0, 0, 0] * divided
+            dcol = (dcol[0, 0, 0] - (dcol[0, 0, -1]) * acol[0, 0, 0]) * divided
+
+        with interval(-1, None):
+            gav = -0.25 * (wcon[1, 0, 0] + wcon[0, 0, 0])
+            as_ = gav * BET_M
+            acol = gav * BET_P
+            bcol = dtr_stage - acol[0, 0, 0]
+
+            # update the d column
+            correction_term = -as_ * (u_stage[0, 0, -1] - u_stage[0, 0, 0])
+            dcol = dtr_stage * u_pos[0, 0, 0] + utens[0, 0, 0] + utens_stage[0, 0, 0] + correction_term
+
+            # Thomas forward
+            divided = 1.0 / (bcol[0, 0, 0] - ccol[0, 0, -1] * acol[0, 0, 0])
+            dcol = (dcol[0, 0, 0] - (dcol[0, 0, -1]) * acol[0, 0, 0]) * divided
+
+    with computation(BACKWARD):
+        with interval(-1, None):
+            datacol = dcol[0, 0, 0]
+            utens_stage = dtr_stage * (datacol - u_pos[0, 0, 0])
+
+        with interval(0, -1):
+            datacol = dcol[0, 0, 0] - ccol[0, 0, 0] * datacol[0, 0, 1]
+            utens_stage = dtr_stage * (datacol - u_pos[0, 0, 0])
+
+
+def column_sum_then_gradient(a: F64, out: F64):
+    """a FORWARD-accumulated temporary read at horizontal offsets afterwards: two stages, scratch"""
+    with computation(FORWARD):
+        with interval(0, 1):
+            acc = a
+        with interval(1, None):
+            acc = acc[0, 0, -1] + a
+    with computation(PARALLEL), interval(...):
+        out = acc[1, 0, 0] - acc[-1, 0, 0] + acc[0, 1, 0]
+
+
+def backward_scan(a: F64, out: F64):
+    """test_code_generation.py:622-649 shape: BACKWARD recurrence over an API field"""
+    with computation(BACKWARD):
+        with interval(-1, None):
+            out = a + 1.0
+        with interval(0, -1):
+            out = out[0, 0, 1] * 0.5 + a[0, 0, 1]
+
+
+def parallel_k_dependency(a: F64, b: F64):
+    """PARALLEL block that reads a field at a K offset and then overwrites it: statement by statement"""
+    with computation(PARALLEL), interval(0, -1):
+        tmp = a[0, 0, 1] * 2.0
+        a = tmp + b
+        b = a[0, 0, 1] - tmp
+
+
+def lower_dimensional(a: F64, surf: "Field[IJ, np.float64]", prof: "Field[K, np.float64]", out: F64):
+    """test_code_generation.py:178-314 shape: IJ and K fields broadcast against a 3-d field"""
+    with computation(PARALLEL), interval(...):
+        out = a * surf + prof[1] * surf[1, 0] - prof
+
+
+def two_stage_written_input(a: F64, b: F64, out: F64):
+    """a temporary that depends on a *written* API field cannot be recomputed: scratch + second stage"""
+    with computation(PARALLEL), interval(...):
+        b = a * 2.0
+        t = b + a
+        out = t[1, 0, 0] + t[0, -1, 0]
+
+
+ZOO = {
+    # name: (definition, externals, scalars, backend options)
+    "copy_stencil": (copy_stencil, {}, {}, {}),
+    "native_functions": (native_functions, {}, {}, {}),
+    "ternary_mix": (ternary_mix, {}, {}, {}),
+    "mixed_precision": (mixed_precision, {}, {"w": np.float32(0.7)}, {}),
+    "int_fields": (int_fields, {}, {}, {}),
+    "k_intervals": (k_intervals, {}, {}, {}),
+    "horizontal_diffusion": (horizontal_diffusion, {}, {}, {"use_kernel_library": False}),
+    "horizontal_diffusion_f32": (horizontal_diffusion_f32, {}, {}, {"use_kernel_library": False}),
+    "laplacian": (laplacian, {}, {}, {"use_kernel_library": False}),
+    "tridiagonal_solver": (tridiagonal_solver, {}, {}, {"use_kernel_library": False}),
+    "vertical_advection_dycore": (vertical_advection_dycore, {"BET_M": 0.5, "BET_P": 0.5}, {"dtr_stage": 3.0 / 20.0}, {}),
+    "column_sum_then_gradient": (column_sum_then_gradient, {}, {}, {}),
+    "backward_scan": (backward_scan, {}, {}, {}),
+    "parallel_k_dependency": (parallel_k_dependency, {}, {}, {}),
+    "lower_dimensional": (lower_dimensional, {}, {}, {}),
+    "two_stage_written_input": (two_stage_written_input, {}, {}, {}),
+}
+
+
+def make_inputs(stencil_object, domain, seed=1337):
+    """Random arrays sized domain + boundary for every field of a built stencil -> (arrays, origins)."""
+    rng = np.random.default_rng(seed)
+    arrays, origins = {}, {}
+    for name, info in stencil_object.field_info.items():
+        if info is None:
+            continue
+        shape, origin = [], []
+        for axis, d in zip("IJK", domain):
+            if axis not in info.axes:
+                continue
+            lo, hi = (max(0, int(b)) for b in info.boundary["IJK".index(axis)])
+            shape.append(int(d) + lo + hi)
+            origin.append(lo)
+        dt = np.dtype(info.dtype)
+        if dt.kind == "f":
+            data = rng.uniform(-1.0, 1.0, shape).astype(dt)
+            if name == "diag":
+                data = (data + 4.5).astype(dt)
+        elif dt.kind in "iu":
+            data = rng.integers(-50, 50, shape).astype(dt)
+        else:
+            data = rng.integers(0, 2, shape).astype(dt)
+        arrays[name] = data
+        origins[name] = tuple(origin)
+    return arrays, origins

@@ -1,0 +1,123 @@
+"""CPU: the generic executor's planner and code generator (gt4py_amd/cartesian/backend/hip_codegen.py).
+
+No kernel runs here.  Checked without a GPU: (1) the stage plan of each zoo stencil; (2) the rewritten
+(inlined) IR evaluates to exactly the same values as the original under the numpy oracle; (3) every
+generated program compiles for gfx950 through the library's hiprtc entry point, in both layout
+variants.  Values on the device are checked in tests/test_gpu_generic.py.
+"""
+
+import numpy as np
+import pytest
+
+import oracle.numpy_backend as oracle_backend  # registers backend "numpy"
+import stencil_zoo as zoo
+from gt4py_amd import _lib
+from gt4py_amd.cartesian import analysis, gtscript, ir
+from gt4py_amd.cartesian.backend import hip_codegen
+
+
+def _build(name, backend):
+    defn, externals, _, opts = zoo.ZOO[name]
+    return gtscript.stencil(backend=backend, definition=defn, externals=externals,
+                            **(opts if backend != "numpy" else {}))
+
+
+@pytest.fixture(scope="module")
+def programs():
+    return {name: type(_build(name, "hip:mi300"))._gt_program_ for name in zoo.ZOO}
+
+
+def test_every_zoo_stencil_goes_to_the_generic_executor(programs):
+    assert all(isinstance(p, hip_codegen.GeneratedProgram) for p in programs.values())
+    # and without the option the kernel library still wins for its own shapes
+    for name in ("horizontal_diffusion", "laplacian", "tridiagonal_solver"):
+        defn, externals, _, _ = zoo.ZOO[name]
+        obj = gtscript.stencil(backend="hip:mi300", definition=defn, externals=externals)
+        assert hasattr(type(obj), "_gt_binding_") and not hasattr(type(obj), "_gt_program_")
+
+
+EXPECTED_PLANS = {
+    # name: ([(mapping, extent)], scratch, register_only, forwarded names)
+    "copy_stencil": ([("ijk", ((0, 0), (0, 0)))], [], [], []),
+    "native_functions": ([("ijk", ((0, 0), (0, 0)))], [], [], []),
+    "k_intervals": ([("ijk", ((0, 0), (0, 0)))], [], [], []),
+    "horizontal_diffusion": ([("ijk", ((0, 0), (0, 0)))], [], [], []),
+    "tridiagonal_solver": ([("column", ((0, 0), (0, 0)))], [], [], ["out", "rhs", "sup"]),
+    "vertical_advection_dycore": ([("column", ((0, 0), (0, 0)))], ["ccol", "dcol"], ["datacol"],
+                                  ["ccol", "datacol", "dcol"]),
+    "column_sum_then_gradient": ([("column", ((-1, 1), (0, 1))), ("ijk", ((0, 0), (0, 0)))], ["acc"], [], ["acc"]),
+    "backward_scan": ([("column", ((0, 0), (0, 0)))], [], [], ["out"]),
+    "parallel_k_dependency": ([("column", ((0, 0), (0, 0)))], ["tmp"], [], []),
+    "two_stage_written_input": ([("ijk", ((0, 1), (-1, 0))), ("ijk", ((0, 0), (0, 0)))], ["t"], [], []),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED_PLANS))
+def test_stage_plan(programs, name):
+    plan = programs[name].plan
+    stages, scratch, register_only, forwarded = EXPECTED_PLANS[name]
+    assert [(s.mapping, s.extent) for s in plan.stages] == stages
+    assert sorted(plan.scratch) == scratch
+    assert sorted(plan.register_only) == register_only
+    assert sorted({n for _, n in plan.forwarded}) == forwarded
+    assert not programs[name].inexact_calls
+
+
+def test_hdiff_is_recomputed_not_staged(programs):
+    """lap/flx/fly disappear as fields: one kernel, no scratch, and the input is read up to 2 cells away."""
+    plan = programs["horizontal_diffusion"].plan
+    offsets = {e.offset[:2] for _, _, s in plan.stencil.statements() for e in ir.walk(s.value)
+               if isinstance(e, ir.FieldAccess) and e.name == "in_field"}
+    assert {(2, 0), (0, 2), (-2, 0), (0, -2), (1, 1), (-1, 1), (1, -1), (-1, -1), (0, 0)} <= offsets
+    assert max(abs(i) + abs(j) for i, j in offsets) == 2
+    assert plan.field_extents["in_field"] == ((-2, 2), (-2, 2))  # unchanged by the rewrite
+    assert all(n.startswith(("lap_field__v", "res__v", "flx_field__v", "fly_field__v")) for n in plan.locals)
+
+
+def test_parallel_block_with_vertical_dependency_is_split(programs):
+    (stage,) = programs["parallel_k_dependency"].plan.stages
+    assert stage.mapping == "column" and [n.split_statements for n in stage.nests] == [True]
+
+
+def test_unsupported_shapes_are_rejected_loudly():
+    def cross_column_recurrence(a: "Field[np.float64]", b: "Field[np.float64]"):  # noqa: F821
+        with computation(FORWARD), interval(1, None):  # noqa: F821
+            t = a[0, 0, -1] + b  # noqa: F841
+            a = t[1, 0, 0] + t[-1, 0, 0]  # noqa: F841
+
+    with pytest.raises(NotImplementedError, match="columns are not independent"):
+        gtscript.stencil(backend="hip:mi300", definition=cross_column_recurrence)
+
+
+@pytest.mark.parametrize("name", sorted(zoo.ZOO))
+def test_rewritten_ir_is_value_equivalent(programs, name):
+    """Run the ORIGINAL and the REWRITTEN (inlined, SSA) IR through the numpy oracle: same bits."""
+    _, _, scalars, _ = zoo.ZOO[name]
+    ref = _build(name, "numpy")
+    domain = (6, 5, 7)
+    arrays, origins = zoo.make_inputs(ref, domain)
+    expect = {k: v.copy() for k, v in arrays.items()}
+    ref(**expect, **scalars, origin=origins, domain=domain)
+    got = {k: v.copy() for k, v in arrays.items()}
+    rewritten = programs[name].plan.stencil
+    oracle_backend.run_stencil(rewritten, analysis.compute_extents(rewritten), domain, origins, got, scalars)
+    for k in arrays:
+        np.testing.assert_array_equal(got[k], expect[k], err_msg=f"{name}: field {k}")
+
+
+@pytest.mark.parametrize("name", sorted(zoo.ZOO))
+def test_generated_source_compiles_for_gfx950(programs, name):
+    prog = programs[name]
+    for options in ([], ["-DGT4MI_UNIT_I_STRIDE=1", "-DGT4MI_NO_ALIAS=1"]):
+        code = _lib.rtc_compile(prog.source, f"{name}.hip", options)
+        assert code[:4] == b"\x7fELF"
+        for kern in prog.kernels:
+            assert kern.name.encode() in code
+    # the argument block mirrors `struct gt_args`: pointers + 3 strides per array, scalars, 3 extents
+    n_arrays = len(prog.plan.api_fields) + len(prog.plan.scratch)
+    assert len(prog.args_struct._fields_) == 4 * n_arrays + len(prog.plan.params) + 3
+
+
+def test_compiler_errors_surface_with_the_log():
+    with pytest.raises(_lib.NativeError, match="expected ';'"):
+        _lib.rtc_compile('extern "C" __global__ void k(double* a) { a[0] = 1.0 }')

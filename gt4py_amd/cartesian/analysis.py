@@ -45,14 +45,25 @@ def compute_extents(stencil: ir.Stencil) -> ExtentInfo:
     stmts = [s for _, _, s in stencil.statements()]
     fields: Dict[str, Extent2] = {}
     blocks: List[Extent2] = [ZERO_EXTENT] * len(stmts)
-    for idx in range(len(stmts) - 1, -1, -1):
-        stmt = stmts[idx]
-        block = _union(ZERO_EXTENT, fields.setdefault(stmt.target.name, ZERO_EXTENT))
-        blocks[idx] = block
-        for e in ir.walk(stmt.value):
-            if isinstance(e, ir.FieldAccess):
-                need = _shift(block, e.offset)
-                fields[e.name] = _union(fields[e.name], need) if e.name in fields else need
+    idx = len(stmts) - 1
+    while idx >= 0:
+        # one horizontal execution = one plain statement, or all statements flattened from one `if`
+        first = idx
+        if stmts[idx].group >= 0:
+            while first > 0 and stmts[first - 1].group == stmts[idx].group:
+                first -= 1
+        members = range(first, idx + 1)
+        block = ZERO_EXTENT
+        for m in members:
+            block = _union(block, fields.setdefault(stmts[m].target.name, ZERO_EXTENT))
+        for m in members:
+            blocks[m] = block
+        for m in members:
+            for e in ir.stmt_reads(stmts[m]):
+                if isinstance(e, ir.FieldAccess):
+                    need = _shift(block, e.offset)
+                    fields[e.name] = _union(fields[e.name], need) if e.name in fields else need
+        idx = first - 1
     for f in stencil.fields:
         fields.setdefault(f.name, ZERO_EXTENT)
     return ExtentInfo(fields, blocks)
@@ -68,7 +79,7 @@ def compute_access_kinds(stencil: ir.Stencil) -> Dict[str, AccessKind]:
             access[name] = kind
 
     for _, _, stmt in stencil.statements():
-        for e in ir.walk(stmt.value):
+        for e in ir.stmt_reads(stmt):
             if isinstance(e, (ir.FieldAccess, ir.ScalarAccess)):
                 touch(e.name, AccessKind.READ)
         touch(stmt.target.name, AccessKind.WRITE)
@@ -79,7 +90,7 @@ def compute_k_boundary(stencil: ir.Stencil) -> Dict[str, Tuple[int, int]]:
     neg_inf = float("-inf")
     bounds: Dict[str, Tuple[float, float]] = {d.name: (neg_inf, neg_inf) for d in (*stencil.fields, *stencil.temporaries)}
     for _, block, stmt in stencil.statements():
-        accesses = [stmt.target] + [e for e in ir.walk(stmt.value) if isinstance(e, ir.FieldAccess)]
+        accesses = [stmt.target] + [e for e in ir.stmt_reads(stmt) if isinstance(e, ir.FieldAccess)]
         for acc in accesses:
             lo, hi = bounds[acc.name]
             if block.interval.start.level is ir.Level.START:

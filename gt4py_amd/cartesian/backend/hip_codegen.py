@@ -44,6 +44,22 @@ from .. import analysis, ir
 Extent2 = analysis.Extent2
 
 
+def _env_tuple(name: str, default: Tuple[int, ...]) -> Tuple[int, ...]:
+    import os
+
+    text = os.environ.get(name)
+    return tuple(int(x) for x in text.split(",")) if text else default
+
+
+#: launch geometry / unrolling of the generated kernels, from the sweep in
+#: profiles/r1_codegen_sweep.log (env overrides are for tuning experiments)
+TUNING = {
+    "block_ijk": _env_tuple("GT4MI_CODEGEN_BLOCK_IJK", (64, 2, 4)),  # threads along I, J; K levels per thread
+    "block_column": _env_tuple("GT4MI_CODEGEN_BLOCK_COLUMN", (64, 4)),
+    "unroll": _env_tuple("GT4MI_CODEGEN_UNROLL", (8,))[0],  # sequential K loops
+}
+
+
 class UnsupportedStencil(NotImplementedError):
     """The stencil is outside what the generic executor can run exactly."""
 
@@ -64,11 +80,14 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
     touched: Dict[str, Set[Tuple[int, int]]] = {}
     k_offset_read: Set[str] = set()
     ij_offset_read: Set[str] = set()
+    masked_write: Set[str] = set()  # conditionally assigned: the old value shows through, no substitution
     for ci, comp in enumerate(stencil.computations):
         for bi, block in enumerate(comp.blocks):
             for stmt in block.body:
                 touched.setdefault(stmt.target.name, set()).add((ci, bi))
-                for e in ir.walk(stmt.value):
+                if stmt.mask is not None:
+                    masked_write.add(stmt.target.name)
+                for e in ir.stmt_reads(stmt):
                     if isinstance(e, ir.FieldAccess):
                         touched.setdefault(e.name, set()).add((ci, bi))
                         if e.offset[2] != 0:
@@ -78,7 +97,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
 
     cand = {
         n for n in temps
-        if len(touched.get(n, ())) == 1 and n not in k_offset_read
+        if len(touched.get(n, ())) == 1 and n not in k_offset_read and n not in masked_write
         and stencil.computations[next(iter(touched[n]))[0]].order is ir.LoopOrder.PARALLEL
     }
     changed = True
@@ -86,7 +105,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
         changed = False
         for _, _, stmt in stencil.statements():
             if stmt.target.name in cand:
-                for e in ir.walk(stmt.value):
+                for e in ir.stmt_reads(stmt):
                     if isinstance(e, ir.FieldAccess) and e.name not in pure_inputs and e.name not in cand:
                         cand.discard(stmt.target.name)
                         changed = True
@@ -98,7 +117,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
         changed = False
         for _, _, stmt in stencil.statements():
             if stmt.target.name in inline:
-                for e in ir.walk(stmt.value):
+                for e in ir.stmt_reads(stmt):
                     if isinstance(e, ir.FieldAccess) and e.name in cand and e.name not in inline:
                         inline.add(e.name)
                         changed = True
@@ -126,6 +145,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
 
             for stmt in block.body:
                 value = to_versions(stmt.value)
+                mask = to_versions(stmt.mask) if stmt.mask is not None else None
                 name = stmt.target.name
                 if name in inline:
                     v = f"{name}__v{sum(1 for k in defs if k.rsplit('__v', 1)[0] == name)}"
@@ -133,7 +153,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                     version[name] = v
                     order.append(("def", v))
                 else:
-                    order.append(("stmt", ir.Assign(stmt.target, value)))
+                    order.append(("stmt", ir.Assign(stmt.target, value, mask, stmt.group)))
 
             memo: Dict[Tuple[str, Tuple[int, int]], ir.Expr] = {}
             needed: Set[str] = set()
@@ -155,7 +175,8 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
 
                 return ir.map_expr(expr, fn)
 
-            body_stmts = [(kind, expand(obj.value, (0, 0)) if kind == "stmt" else None, obj) for kind, obj in order]
+            body_stmts = [(kind, (expand(obj.value, (0, 0)), expand(obj.mask, (0, 0)) if obj.mask is not None else None)
+                           if kind == "stmt" else None, obj) for kind, obj in order]
             local_defs: Dict[str, ir.Expr] = {}
             pending = list(needed)
             while pending:  # thread-local values referenced at the thread's own point
@@ -173,7 +194,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                         ssa_locals[obj] = np.dtype(temps[obj.rsplit("__v", 1)[0]].dtype)
                         new_body.append(ir.Assign(ir.FieldAccess(obj, (0, 0, 0), ssa_locals[obj]), local_defs[obj]))
                 else:
-                    new_body.append(ir.Assign(obj.target, value))
+                    new_body.append(ir.Assign(obj.target, value[0], value[1], obj.group))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     new_temps = tuple(t for t in stencil.temporaries if t.name not in inline) + tuple(
@@ -189,6 +210,7 @@ class Stmt:
     target: ir.FieldAccess
     value: ir.Expr
     extent: Extent2
+    mask: Optional[ir.Expr] = None
 
 
 @dataclass
@@ -227,6 +249,12 @@ def _field_reads(expr: ir.Expr):
     return [e for e in ir.walk(expr) if isinstance(e, ir.FieldAccess)]
 
 
+def _stmt_field_reads(s) -> List[ir.FieldAccess]:
+    """Field reads of a planned statement or an ``ir.Assign``: mask and value."""
+    reads = _field_reads(s.value)
+    return (_field_reads(s.mask) + reads) if s.mask is not None else reads
+
+
 def plan_stages(stencil_in: ir.Stencil) -> Plan:
     for d in (*stencil_in.fields, *stencil_in.temporaries):
         if d.data_dims:
@@ -240,14 +268,14 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     ext_iter = iter(extents.blocks)
     for ci, comp in enumerate(stencil.computations):
         for bi, block in enumerate(comp.blocks):
-            stmts = [Stmt(s.target, s.value, next(ext_iter)) for s in block.body]
+            stmts = [Stmt(s.target, s.value, next(ext_iter), s.mask) for s in block.body]
             units = [[s] for s in stmts] if comp.order is ir.LoopOrder.PARALLEL else [stmts]
             for unit in units:
                 if not unit:
                     continue
                 writes = {s.target.name for s in unit}
                 offreads = {
-                    e.name for s in unit for e in _field_reads(s.value)
+                    e.name for s in unit for e in _stmt_field_reads(s)
                     if (e.offset[0] != 0 or e.offset[1] != 0) and e.name in written_anywhere
                 }
                 if writes & offreads:
@@ -274,7 +302,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
             if nest.order is not ir.LoopOrder.PARALLEL:
                 column = True
             for s in nest.stmts:
-                for e in _field_reads(s.value):
+                for e in _stmt_field_reads(s):
                     if e.offset[2] != 0 and e.name in stage.written:
                         column = True
                         if nest.order is ir.LoopOrder.PARALLEL and e.name in nest_writes:
@@ -294,7 +322,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     for nid, (si, nest) in enumerate(nest_list):
         defined: Set[str] = set()
         for s in nest.stmts:
-            for e in _field_reads(s.value):
+            for e in _stmt_field_reads(s):
                 if e.name in temp_names:
                     where.setdefault(e.name, set()).add(nid)
                     if e.offset != (0, 0, 0) or e.name not in defined or nest.split_statements:
@@ -324,12 +352,14 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
             for s in nest.stmts:
                 if s.target.name in stage.written:
                     extents_of.setdefault(s.target.name, set()).add(s.extent)
-                for e in _field_reads(s.value):
+                for e in _stmt_field_reads(s):
                     if e.offset[2] != 0 and e.name in stage.written:
                         patterns.setdefault(e.name, set()).add((nest.order, e.offset))
                         extents_of.setdefault(e.name, set()).add(s.extent)
+        unsafe = {s.target.name for nest in stage.nests for s in nest.stmts
+                  if s.mask is not None or s.target.offset != (0, 0, 0)}  # conditional / displaced writes
         for name, pats in patterns.items():
-            if name in local_names or len(extents_of.get(name, ())) != 1:
+            if name in local_names or name in unsafe or len(extents_of.get(name, ())) != 1:
                 continue
             if pats == {(ir.LoopOrder.FORWARD, (0, 0, -1))}:
                 forwarded[(si, name)] = -1
@@ -348,7 +378,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
         for nest in stage.nests:
             for st in nest.stmts:
                 touched_in.setdefault(st.target.name, set()).add(si)
-                for e in _field_reads(st.value):
+                for e in _stmt_field_reads(st):
                     touched_in.setdefault(e.name, set()).add(si)
     prime: Dict[Tuple[int, int, str], Tuple[str, Optional[int]]] = {}
     register_only: Set[str] = set()
@@ -359,7 +389,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
         prev: Optional[int] = None
         for ni, nest in enumerate(stage.nests):
             writes = [idx for idx, st in enumerate(nest.stmts) if st.target.name == name]
-            reads = [(idx, e) for idx, st in enumerate(nest.stmts) for e in _field_reads(st.value) if e.name == name]
+            reads = [(idx, e) for idx, st in enumerate(nest.stmts) for e in _stmt_field_reads(st) if e.name == name]
             if not writes and not reads:
                 continue
             if nest.order is not want:
@@ -392,9 +422,10 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     for _, nest in nest_list:
         for s in nest.stmts:
             used.add(s.target.name)
-            for e in ir.walk(s.value):
-                if isinstance(e, (ir.FieldAccess, ir.ScalarAccess)):
-                    used.add(e.name)
+            for ex in ([s.value] if s.mask is None else [s.mask, s.value]):
+                for e in ir.walk(ex):
+                    if isinstance(e, (ir.FieldAccess, ir.ScalarAccess)):
+                        used.add(e.name)
     api_fields = [f for f in stencil.fields if f.name in used]
     params = [p for p in stencil.params if p.name in used]
     return Plan(stencil, stages, dict(extents.fields), local_names, scratch, forwarded, prime, register_only,
@@ -511,6 +542,7 @@ class KernelSource:
     mapping: str
     extent: Extent2
     block: Tuple[int, int, int]
+    k_per_thread: int = 1
 
 
 @dataclass
@@ -624,6 +656,9 @@ class _Emitter:
         value = self.expr(s.value, k, si, reg)
         name = s.target.name
         g = self.guard(s, stage)
+        if s.mask is not None:  # np.where(mask, value, target): untouched where the mask is false
+            m = self.expr(s.mask, k, si, reg)
+            g = f"({g}) && ({m})" if g else m
         pad = indent
         if g:
             self.lines.append(f"{indent}if ({g}) {{")
@@ -672,7 +707,7 @@ class _Emitter:
         names = []
         for nest in stage.nests:
             for s in nest.stmts:
-                for n in [s.target.name] + [e.name for e in _field_reads(s.value)]:
+                for n in [s.target.name] + [e.name for e in _stmt_field_reads(s)]:
                     if n not in self.plan.locals and n not in names:
                         names.append(n)
         return names
@@ -680,7 +715,11 @@ class _Emitter:
     def kernel(self, si: int, stage: Stage, kname: str) -> KernelSource:
         L = self.lines
         (ilo, ihi), (jlo, jhi) = stage.extent
-        block = (64, 4, 1)
+        if stage.mapping == "ijk":
+            bi, bj, k_per_thread = TUNING["block_ijk"]
+        else:
+            (bi, bj), k_per_thread = TUNING["block_column"], 1
+        block = (bi, bj, 1)
         L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}(const gt_args a) {{')
         L.append(f"    const gt_i64 i = (gt_i64)blockIdx.x * {block[0]} + threadIdx.x + ({ilo});")
         L.append(f"    const gt_i64 j = (gt_i64)blockIdx.y * {block[1]} + threadIdx.y + ({jlo});")
@@ -697,12 +736,19 @@ class _Emitter:
             off = " + ".join(t for t in (f"i * GT_SI(a.{c}_si)" if "I" in axes else "", f"j * a.{c}_sj" if "J" in axes else "") if t) or "0"
             L.append(f"    {const}{ct}* const{qual} b_{c} = a.{c} + {off};")
         if stage.mapping == "ijk":
-            L.append("    const gt_i64 k = blockIdx.z;")
+            if k_per_thread > 1:
+                L.append(f"    #pragma unroll")
+                L.append(f"    for (int kk = 0; kk < {k_per_thread}; ++kk) {{")
+                L.append(f"    const gt_i64 k = (gt_i64)blockIdx.z * {k_per_thread} + kk;")
+            else:
+                L.append("    const gt_i64 k = blockIdx.z;")
             for nest in stage.nests:
                 L.append(f"    if (k >= {self.bound(nest.interval.start)} && k < {self.bound(nest.interval.end)}) {{")
                 self.local_decls(nest, "        ")
                 for s in nest.stmts:
                     self.statement(s, stage, si, "k", {}, "        ")
+                L.append("    }")
+            if k_per_thread > 1:
                 L.append("    }")
         else:
             stage_fwd = {n: d for (s_i, n), d in self.plan.forwarded.items() if s_i == si}
@@ -713,7 +759,7 @@ class _Emitter:
                 L.append(f"        const gt_i64 k0 = {self.bound(nest.interval.start)}, k1 = {self.bound(nest.interval.end)};")
                 back = -1 if nest.order is ir.LoopOrder.FORWARD else 1
                 active = [n for n, d in stage_fwd.items() if nest.order is not ir.LoopOrder.PARALLEL and d == back
-                          and any(s.target.name == n or any(e.name == n for e in _field_reads(s.value)) for s in nest.stmts)]
+                          and any(s.target.name == n or any(e.name == n for e in _stmt_field_reads(s)) for s in nest.stmts)]
                 loop = ("for (gt_i64 k = k1 - 1; k >= k0; --k)" if nest.order is ir.LoopOrder.BACKWARD
                         else "for (gt_i64 k = k0; k < k1; ++k)")
                 groups = [[s] for s in nest.stmts] if nest.split_statements else [nest.stmts]
@@ -735,6 +781,8 @@ class _Emitter:
                     L.append(f"        if ({' && '.join(conds)}) r_{_c_ident(n)} = "
                              f"{self.access(ir.FieldAccess(n, (0, 0, back)), first, -1, {})};")
                 for group in groups:
+                    if TUNING["unroll"] > 1:
+                        L.append(f"        #pragma unroll {TUNING['unroll']}")
                     L.append(f"        {loop} {{")
                     self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), "            ")
                     carry = [n for n in active if any(s.target.name == n for s in group)]
@@ -755,7 +803,7 @@ class _Emitter:
                 L.append("    }")
         L.append("}")
         L.append("")
-        return KernelSource(kname, stage.mapping, stage.extent, block)
+        return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread)
 
 
 def generate(stencil: ir.Stencil) -> GeneratedProgram:

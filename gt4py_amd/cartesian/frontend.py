@@ -100,6 +100,8 @@ class _Parser(ast.NodeVisitor):
         self.temporaries: Dict[str, ir.FieldDecl] = {}
         self.imported: Dict[str, Any] = {}
         self._order: Optional[ir.LoopOrder] = None
+        self._groups = 0  # top-level `if` statements seen (one horizontal execution each)
+        self._masks = 0
         for pname, ann in annotations.items():
             if isinstance(ann, gtscript._FieldDescriptor):
                 axes = tuple(a.name if isinstance(a, gtscript.Axis) else str(a) for a in ann.axes)
@@ -261,27 +263,48 @@ class _Parser(ast.NodeVisitor):
         return ir.IntervalBlock(interval, tuple(stmts))
 
     # ---- statements ----------------------------------------------------------------------
-    def _visit_stmt(self, node) -> List[ir.Assign]:
+    def _visit_stmt(self, node, mask: Optional[ir.Expr] = None, group: int = -1) -> List[ir.Assign]:
         if isinstance(node, ast.Assign):
             if len(node.targets) != 1:
                 raise self._err(node, "Chained assignment is not supported")
-            return [self._make_assign(node.targets[0], self.visit(node.value), node)]
+            return [self._make_assign(node.targets[0], self.visit(node.value), node, mask, group)]
         if isinstance(node, ast.AugAssign):
             if type(node.op) not in _BIN_OPS:
                 raise self._err(node, "Unsupported augmented assignment")
             target_read = self._target_access(node.target, node, reading=True)
             value = ir.BinaryOp(_BIN_OPS[type(node.op)], target_read, self.visit(node.value))
-            return [self._make_assign(node.target, value, node)]
+            return [self._make_assign(node.target, value, node, mask, group)]
         if isinstance(node, ast.If):
             test = node.test
+            out: List[ir.Assign] = []
             if self._call_name(test) == "__INLINED":
                 branch = node.body if self._const(test.args[0]) else node.orelse
-                out: List[ir.Assign] = []
                 for s in branch:
-                    out.extend(self._visit_stmt(s))
+                    out.extend(self._visit_stmt(s, mask, group))
                 return out
-            raise self._err(node, "Run-time 'if' statements are outside the supported GTScript subset; "
-                                  "use a ternary expression")
+            # Run-time if: flattened into masked assignments (gtir_to_oir.py:146-218).  A condition that
+            # reads fields is evaluated ONCE into a boolean temporary before either branch runs; a
+            # scalar condition is used as it is.  Nested masks are AND-ed (oir_to_npir.py visit_MaskStmt).
+            if group < 0:
+                group = self._groups
+                self._groups += 1
+            cond = self.visit(test)
+            if any(isinstance(e, ir.FieldAccess) for e in ir.walk(cond)):
+                name = f"mask_{self._masks}"
+                while name in self.fields or name in self.params or name in self.temporaries:
+                    self._masks += 1
+                    name = f"mask_{self._masks}"
+                self._masks += 1
+                self.temporaries[name] = ir.FieldDecl(name, np.dtype("bool"), ("I", "J", "K"), (), False)
+                out.append(ir.Assign(ir.FieldAccess(name, (0, 0, 0)), cond, mask, group))
+                cond = ir.FieldAccess(name, (0, 0, 0))
+            for branch, this in ((node.body, cond), (node.orelse, ir.UnaryOp("not", cond))):
+                if not branch:
+                    continue
+                combined = this if mask is None else ir.BinaryOp("and", mask, this)
+                for s in branch:
+                    out.extend(self._visit_stmt(s, combined, group))
+            return out
         if isinstance(node, ast.Pass):
             return []
         if isinstance(node, ast.Expr) and isinstance(node.value, ast.Constant):
@@ -307,11 +330,11 @@ class _Parser(ast.NodeVisitor):
             raise GTScriptSymbolError(f"Unknown symbol '{name}'")
         return ir.FieldAccess(name, offset)
 
-    def _make_assign(self, target, value: ir.Expr, node) -> ir.Assign:
+    def _make_assign(self, target, value: ir.Expr, node, mask: Optional[ir.Expr] = None, group: int = -1) -> ir.Assign:
         access = self._target_access(target, node)
         if access.name not in self.fields and access.name not in self.temporaries:
             self.temporaries[access.name] = ir.FieldDecl(access.name, None, ("I", "J", "K"), (), False)
-        return ir.Assign(access, value)
+        return ir.Assign(access, value, mask, group)
 
     # ---- expressions ---------------------------------------------------------------------
     def generic_visit(self, node):
@@ -499,6 +522,11 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
         for block in comp.blocks:
             new_body = []
             for stmt in block.body:
+                mask = None
+                if stmt.mask is not None:
+                    mask = typed(stmt.mask)
+                    if mask.dtype != np.dtype("bool"):
+                        mask = ir.Cast(mask, np.dtype("bool"))
                 value = typed(stmt.value)
                 name = stmt.target.name
                 if dtypes.get(name) is None:
@@ -506,7 +534,7 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
                 tdt = dtypes[name]
                 if value.dtype != tdt:
                     value = ir.Cast(value, tdt)
-                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt), value))
+                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt), value, mask, stmt.group))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     temps = tuple(ir.FieldDecl(t.name, dtypes[t.name], t.axes, t.data_dims, False) for t in stencil.temporaries)
@@ -517,7 +545,7 @@ def _check_semantics(stencil: ir.Stencil) -> None:
     api = {f.name for f in stencil.fields}
     written = {s.target.name for _, _, s in stencil.statements()}
     for comp, _, stmt in stencil.statements():
-        for e in ir.walk(stmt.value):
+        for e in ir.stmt_reads(stmt):
             if not isinstance(e, ir.FieldAccess):
                 continue
             if e.offset[2] != 0 and e.name not in api and comp.order is ir.LoopOrder.PARALLEL and e.name in written:
@@ -528,7 +556,7 @@ def _check_semantics(stencil: ir.Stencil) -> None:
                 raise ValueError(f"Found non-zero read extent on written fields: {e.name}")
     for comp, _, stmt in stencil.statements():
         if comp.order is ir.LoopOrder.PARALLEL:
-            for e in ir.walk(stmt.value):
+            for e in ir.stmt_reads(stmt):
                 if isinstance(e, ir.FieldAccess) and e.name == stmt.target.name and e.offset[2] != 0:
                     raise GTScriptSyntaxError(
                         f"Self-assignment with a K offset to '{e.name}' is not allowed in PARALLEL computations")

@@ -122,8 +122,32 @@ LOGICAL_OPS = ("and", "or")
 # ---- statements --------------------------------------------------------------------------------
 @dataclass(frozen=True)
 class Assign:
+    """``target = value``, or ``target = where(mask, value, target)`` when ``mask`` is set.
+
+    Run-time ``if`` statements are flattened into masked assignments the way the reference lowers them
+    (gtc/gtir_to_oir.py:146-218: a boolean mask temporary assigned once, then ``MaskStmt`` bodies;
+    gtc/numpy/npir_codegen.py:205-210: ``np.where(mask, right, left)``).  ``group`` ties together the
+    statements that came from ONE top-level statement of the interval block: the reference puts them
+    in one HorizontalExecution (gtir_to_oir.py:225-232), so they share one compute extent.
+    """
+
     target: FieldAccess
     value: Expr
+    mask: Optional[Expr] = None
+    group: int = -1
+
+
+def stmt_exprs(stmt: "Assign"):
+    """The expressions a statement reads: mask first (it is evaluated first), then the value."""
+    if stmt.mask is not None:
+        yield stmt.mask
+    yield stmt.value
+
+
+def stmt_reads(stmt: "Assign"):
+    """Every expression node read by ``stmt`` (pre-order over mask and value)."""
+    for e in stmt_exprs(stmt):
+        yield from walk(e)
 
 
 @dataclass(frozen=True)

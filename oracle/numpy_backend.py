@@ -132,8 +132,13 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
                 def execute(krange):
                     for stmt, ((ilo, ihi), (jlo, jhi)) in plan:
                         lo, hi = (ilo, jlo), (dI + ihi, dJ + jhi)
-                        value = _evaluate(stmt.value, env, lo, hi, krange)
-                        env[stmt.target.name].window(lo, hi, stmt.target.offset, krange)[...] = value
+                        target = env[stmt.target.name].window(lo, hi, stmt.target.offset, krange)
+                        if stmt.mask is not None:  # npir_codegen.py:205-210: np.where(mask, right, left)
+                            mask = _evaluate(stmt.mask, env, lo, hi, krange)
+                            value = np.where(mask, _evaluate(stmt.value, env, lo, hi, krange), target)
+                        else:
+                            value = _evaluate(stmt.value, env, lo, hi, krange)
+                        target[...] = value
 
                 if comp.order is ir.LoopOrder.PARALLEL:
                     if k1 > k0:

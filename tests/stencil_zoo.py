@@ -214,6 +214,44 @@ def two_stage_written_input(a: F64, b: F64, out: F64):
         out = t[1, 0, 0] + t[0, -1, 0]
 
 
+def runtime_if(field_a: F64, field_b: F64):
+    """stencil_definitions.py:195-203"""
+    with computation(BACKWARD), interval(...):
+        if field_a > 0.0:
+            field_b = -1
+            field_a = -field_a
+        else:
+            field_b = 1
+            field_a = field_a
+
+
+def nested_if(a: F64, b: F64, out: F64, *, thresh: float):
+    """field and scalar conditions, nesting, a temporary assigned in both branches, a recurrence"""
+    with computation(FORWARD):
+        with interval(0, 1):
+            out = a
+        with interval(1, None):
+            if a > b:
+                t = a - b
+                if thresh > 0.0:
+                    t = t * thresh
+                    if b < 0.0:
+                        t = -t
+            else:
+                t = out[0, 0, -1]
+            out = t + out[0, 0, -1] * 0.5
+
+
+def if_with_offsets(a: F64, out: F64):
+    """condition and body read at horizontal offsets; the whole `if` is one horizontal execution"""
+    with computation(PARALLEL), interval(...):
+        lap = a[1, 0, 0] + a[-1, 0, 0] - 2.0 * a
+        if lap[0, 1, 0] > lap[0, -1, 0]:
+            out = lap[1, 0, 0]
+        else:
+            out = a[0, 1, 0] if lap > 0.0 else a[0, -1, 0]
+
+
 ZOO = {
     # name: (definition, externals, scalars, backend options)
     "copy_stencil": (copy_stencil, {}, {}, {}),
@@ -232,6 +270,9 @@ ZOO = {
     "parallel_k_dependency": (parallel_k_dependency, {}, {}, {}),
     "lower_dimensional": (lower_dimensional, {}, {}, {}),
     "two_stage_written_input": (two_stage_written_input, {}, {}, {}),
+    "runtime_if": (runtime_if, {}, {}, {}),
+    "nested_if": (nested_if, {}, {"thresh": 0.75}, {}),
+    "if_with_offsets": (if_with_offsets, {}, {}, {}),
 }
 
 

@@ -296,14 +296,52 @@ def bad_interval_order(a: Field[np.float64], b: Field[np.float64]):
             b = a
 
 
+def nested_if_stencil(a: Field[np.float64], b: Field[np.float64], *, s: float):
+    with computation(PARALLEL), interval(...):
+        if a > 0.0:
+            b = a
+            if s > 1.0:
+                b = b * s
+        else:
+            t = a[1, 0, 0]
+            b = t
+
+
+def test_runtime_if_is_flattened_into_masked_assignments():
+    """gtir_to_oir.py:146-218: a field condition is evaluated once into a bool temporary; bodies become
+    masked assignments; a scalar condition is used directly; nested masks are AND-ed; the whole `if` is
+    one horizontal execution (one compute extent, gtir_to_oir.py:225-232)."""
+    st = parse(runtime_if_stencil)
+    m, body = [s for _, _, s in st.statements()]
+    B = np.dtype("bool")
+    assert m.target == ir.FieldAccess("mask_0", (0, 0, 0), B) and m.mask is None and m.value.dtype == B
+    assert body.mask == ir.FieldAccess("mask_0", (0, 0, 0), B) and body.target.name == "b"
+    assert m.group == body.group >= 0
+    assert [t.name for t in st.temporaries] == ["mask_0"] and st.temporaries[0].dtype == B
+    info = analysis.make_args_data(st)
+    assert info.field_info["b"].access == D.AccessKind.WRITE and info.field_info["a"].access == D.AccessKind.READ
+
+    st = parse(nested_if_stencil)
+    stmts = [s for _, _, s in st.statements()]
+    assert [s.target.name for s in stmts] == ["mask_0", "b", "b", "t", "b"]
+    mask0 = ir.FieldAccess("mask_0", (0, 0, 0), B)
+    assert stmts[1].mask == mask0
+    inner = stmts[2].mask
+    assert isinstance(inner, ir.BinaryOp) and inner.op == "and" and inner.left == mask0
+    assert not any(isinstance(e, ir.FieldAccess) for e in ir.walk(inner.right))  # scalar condition, no temporary
+    assert stmts[3].mask == ir.UnaryOp("not", mask0, B) == stmts[4].mask
+    assert len({s.group for s in stmts}) == 1
+    # one horizontal execution: the condition is evaluated on the extent the else-branch's temporary needs
+    ext = analysis.compute_extents(st)
+    assert len(set(ext.blocks)) == 1 and ext.fields["a"] == ((0, 1), (0, 0))
+
+
 def test_rejections():
     # written API field read with a horizontal offset (gtir_to_oir.py:19-46; test_code_generation.py:1693)
     with pytest.raises(ValueError, match="non-zero read extent on written fields"):
         parse(race_stencil)
     with pytest.raises(D.GTScriptSyntaxError, match="non-zero offsets"):
         parse(write_offset_stencil)
-    with pytest.raises(D.GTScriptSyntaxError, match="Run-time 'if'"):
-        parse(runtime_if_stencil)
     with pytest.raises(D.GTScriptSymbolError):
         parse(unknown_symbol_stencil)
     # BACKWARD intervals must be listed highest first (quickstart.rst:261-265 lists them the invalid way)

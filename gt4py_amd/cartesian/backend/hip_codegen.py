@@ -54,7 +54,8 @@ def _env_tuple(name: str, default: Tuple[int, ...]) -> Tuple[int, ...]:
 #: launch geometry / unrolling of the generated kernels, from the sweep in
 #: profiles/r1_codegen_sweep.log (env overrides are for tuning experiments)
 TUNING = {
-    "block_ijk": _env_tuple("GT4MI_CODEGEN_BLOCK_IJK", (64, 2, 4)),  # threads along I, J; K levels per thread
+    # threads along I, J; K levels per thread; consecutive I points per thread
+    "block_ijk": _env_tuple("GT4MI_CODEGEN_BLOCK_IJK", (64, 2, 4, 1)),
     "block_column": _env_tuple("GT4MI_CODEGEN_BLOCK_COLUMN", (64, 4)),
     "unroll": _env_tuple("GT4MI_CODEGEN_UNROLL", (8,))[0],  # sequential K loops
 }
@@ -543,6 +544,7 @@ class KernelSource:
     extent: Extent2
     block: Tuple[int, int, int]
     k_per_thread: int = 1
+    i_per_thread: int = 1
 
 
 @dataclass
@@ -716,14 +718,21 @@ class _Emitter:
         L = self.lines
         (ilo, ihi), (jlo, jhi) = stage.extent
         if stage.mapping == "ijk":
-            bi, bj, k_per_thread = TUNING["block_ijk"]
+            bi, bj, k_per_thread, i_per_thread = (tuple(TUNING["block_ijk"]) + (1,))[:4]
         else:
-            (bi, bj), k_per_thread = TUNING["block_column"], 1
+            (bi, bj), k_per_thread, i_per_thread = TUNING["block_column"], 1, 1
         block = (bi, bj, 1)
         L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}(const gt_args a) {{')
-        L.append(f"    const gt_i64 i = (gt_i64)blockIdx.x * {block[0]} + threadIdx.x + ({ilo});")
         L.append(f"    const gt_i64 j = (gt_i64)blockIdx.y * {block[1]} + threadIdx.y + ({jlo});")
-        L.append(f"    if (i >= a.dI + ({ihi}) || j >= a.dJ + ({jhi})) return;")
+        L.append(f"    if (j >= a.dJ + ({jhi})) return;")
+        if i_per_thread > 1:  # adjacent points per lane: the compiler merges their loads/stores into vectors
+            L.append("    #pragma unroll")
+            L.append(f"    for (int iv = 0; iv < {i_per_thread}; ++iv) {{")
+            L.append(f"    const gt_i64 i = ((gt_i64)blockIdx.x * {block[0]} + threadIdx.x) * {i_per_thread} + iv + ({ilo});")
+            L.append(f"    if (i >= a.dI + ({ihi})) break;")
+        else:
+            L.append(f"    const gt_i64 i = (gt_i64)blockIdx.x * {block[0]} + threadIdx.x + ({ilo});")
+            L.append(f"    if (i >= a.dI + ({ihi})) return;")
         for n in self.stage_globals(stage):
             if n in self.plan.register_only:
                 continue
@@ -801,9 +810,11 @@ class _Emitter:
                             L.append(f"            {'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
                     L.append("        }")
                 L.append("    }")
+        if i_per_thread > 1:
+            L.append("    }")
         L.append("}")
         L.append("")
-        return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread)
+        return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, i_per_thread)
 
 
 def generate(stencil: ir.Stencil) -> GeneratedProgram:

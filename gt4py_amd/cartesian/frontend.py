@@ -26,7 +26,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import definitions as gt_definitions, gtscript, ir
+from . import call_inliner, definitions as gt_definitions, gtscript, ir
 from .definitions import GTScriptDefinitionError, GTScriptSymbolError, GTScriptSyntaxError
 
 # DataType order of the reference (gtc/common.py:105-118): bool < int8 < ... < float64.
@@ -145,6 +145,8 @@ class _Parser(ast.NodeVisitor):
         src = textwrap.dedent(inspect.getsource(self.definition))
         tree = ast.parse(src)
         fdef = next(n for n in tree.body if isinstance(n, (ast.FunctionDef,)))
+        for imp in call_inliner.inline_calls(fdef, self.definition, self.externals):  # @gtscript.function calls -> statements
+            self._visit_import(imp)
         computations: List[ir.Computation] = []
         for stmt in fdef.body:
             if isinstance(stmt, ast.Expr) and isinstance(stmt.value, ast.Constant) and isinstance(stmt.value.value, str):
@@ -170,7 +172,7 @@ class _Parser(ast.NodeVisitor):
 
     def _visit_import(self, node: ast.ImportFrom) -> None:
         if node.module not in ("__externals__", "gt4py.cartesian.__externals__", "gtscript.__externals__"):
-            if node.module and (node.module.endswith("gtscript") or node.module.startswith("gt4py")):
+            if node.module and (node.module.strip("_").endswith("gtscript") or node.module.startswith("gt4py")):
                 return  # importing gtscript names inside the body is harmless
             raise self._err(node, f"Unsupported import from '{node.module}' inside a stencil")
         for alias in node.names:

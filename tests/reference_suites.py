@@ -1,0 +1,430 @@
+"""The reference's integration suites as data: GTScript definition + independent numpy validation.
+
+Source of every entry: /root/reference/tests/cartesian_tests/integration_tests/multi_feature_tests/
+test_suites.py (line ranges in each docstring).  There a hypothesis-driven harness
+(`gt4py.cartesian.testing.StencilTestSuite`) draws domains/values, runs the stencil on every backend and
+compares with the suite's ``validation`` -- a plain-numpy function that does NOT go through gt4py.
+Those validations are the reference's own known answers for these stencils, so they pin parity
+independently of this repository's oracle.  Here each suite is one ``Suite`` record: the definition is
+re-typed with explicit annotations (the reference injects dtypes through its harness), ``expected``
+restates the validation on arrays laid out as ``domain + boundary``, and the table is consumed by
+tests/test_reference_suites.py on the CPU (numpy oracle backend) and on the GPU (hip:mi300).
+"""
+# flake8: noqa: F821, F841
+from dataclasses import dataclass, field
+from typing import Any, Callable, Dict, Sequence, Tuple
+
+import numpy as np
+
+from gt4py_amd.cartesian import gtscript
+
+F64 = "Field[np.float64]"
+F32 = "Field[np.float32]"
+Z = ((0, 0), (0, 0), (0, 0))
+
+
+@dataclass
+class Suite:
+    definition: Callable
+    fields: Dict[str, Tuple[Any, Tuple[Tuple[int, int], ...], Tuple[float, float]]]  # dtype, boundary, value range
+    expected: Callable  # (arrays incl. boundary, params, externals, domain) -> {name: array over the domain}
+    params: Dict[str, Tuple[float, float]] = field(default_factory=dict)
+    externals: Sequence[Dict[str, Any]] = ({},)
+    domains: Sequence[Tuple[int, int, int]] = ((1, 1, 1), (3, 4, 5), (15, 14, 13))
+    optional: Dict[str, str] = field(default_factory=dict)  # field -> external that switches it on
+
+
+def _inner(a, b):
+    """View of ``a`` without its boundary ``b``."""
+    return a[tuple(slice(lo, a.shape[ax] - hi) for ax, (lo, hi) in enumerate(b))]
+
+
+# ---- test_suites.py:27-41 ----------------------------------------------------------------------
+def identity(field_a: F64):
+    with computation(PARALLEL), interval(...):
+        tmp = field_a
+        field_a = tmp
+
+
+# ---- :44-60 ------------------------------------------------------------------------------------
+def copy(field_a: F64, field_b: F64):
+    with computation(PARALLEL), interval(...):
+        field_b = field_a
+
+
+# ---- :63-83 ------------------------------------------------------------------------------------
+def aug_assign(field_a: F64, field_b: F64):
+    with computation(PARALLEL), interval(...):
+        field_a += 1.0
+        field_a *= 2.0
+        field_b -= 1.0
+        field_b /= 2.0
+
+
+# ---- :86-104 -----------------------------------------------------------------------------------
+def global_scale(field_a: F64):
+    from __externals__ import SCALE_FACTOR
+
+    with computation(PARALLEL), interval(...):
+        field_a = SCALE_FACTOR * field_a[0, 0, 0]
+
+
+# ---- :107-123 ----------------------------------------------------------------------------------
+def parametric_scale(field_a: F64, *, scale: float):
+    with computation(PARALLEL), interval(...):
+        field_a = scale * field_a
+
+
+# ---- :126-170 ----------------------------------------------------------------------------------
+def parametric_mix(field_a: F64, field_b: F64, field_c: F64, field_out: F32, *, weight: float, alpha_factor: float):
+    from __externals__ import USE_ALPHA
+    from __gtscript__ import __INLINED
+
+    with computation(PARALLEL), interval(...):
+        if __INLINED(USE_ALPHA):
+            factor = alpha_factor
+        else:
+            factor = 1.0
+        field_out = factor * field_a[0, 0, 0] - (1 - factor) * (field_b[0, 0, 0] - weight * field_c[0, 0, 0])
+
+
+def _parametric_mix_expected(a, p, ext, domain):
+    factor = p["alpha_factor"] if ext["USE_ALPHA"] else 1.0
+    return {"field_out": (factor * a["field_a"]) - (1 - factor) * (a["field_b"] - (p["weight"] * a["field_c"]))}
+
+
+# ---- :173-197 ----------------------------------------------------------------------------------
+def heat_equation_ftcs(u: F64, v: F64, u_new: F64, v_new: F64, *, ru: float, rv: float):
+    with computation(PARALLEL), interval(...):
+        u_new = u[0, 0, 0] + ru * (u[1, 0, 0] - 2 * u[0, 0, 0] + u[-1, 0, 0])
+        v_new = v[0, 0, 0] + rv * (v[0, 1, 0] - 2 * v[0, 0, 0] + v[0, -1, 0])
+
+
+def _heat_expected(a, p, ext, domain):
+    u, v = a["u"], a["v"]
+    return {
+        "u_new": u[1:-1] + p["ru"] * (u[2:] - 2 * u[1:-1] + u[:-2]),
+        "v_new": v[:, 1:-1] + p["rv"] * (v[:, 2:] - 2 * v[:, 1:-1] + v[:, :-2]),
+    }
+
+
+# ---- :200-230 ----------------------------------------------------------------------------------
+def horizontal_diffusion(u: F64, diffusion: F64, *, weight: float):
+    with computation(PARALLEL), interval(...):
+        laplacian = 4.0 * u[0, 0, 0] - (u[1, 0, 0] + u[-1, 0, 0] + u[0, 1, 0] + u[0, -1, 0])
+        flux_i = laplacian[1, 0, 0] - laplacian[0, 0, 0]
+        flux_j = laplacian[0, 1, 0] - laplacian[0, 0, 0]
+        diffusion = u[0, 0, 0] - weight * (flux_i[0, 0, 0] - flux_i[-1, 0, 0] + flux_j[0, 0, 0] - flux_j[0, -1, 0])
+
+
+def _hdiff_expected(a, p, ext, domain):
+    u = a["u"]
+    lap = 4.0 * u[1:-1, 1:-1] - (u[2:, 1:-1] + u[:-2, 1:-1] + u[1:-1, 2:] + u[1:-1, :-2])
+    flux_i = lap[1:, 1:-1] - lap[:-1, 1:-1]
+    flux_j = lap[1:-1, 1:] - lap[1:-1, :-1]
+    return {"diffusion": u[2:-2, 2:-2] - p["weight"] * (flux_i[1:] - flux_i[:-1] + flux_j[:, 1:] - flux_j[:, :-1])}
+
+
+# ---- :233-296 (subroutines; the function arrives as an external) -----------------------------------
+@gtscript.function
+def lap_op(u):
+    """Laplacian operator."""
+    return 4.0 * u[0, 0, 0] - (u[1, 0, 0] + u[-1, 0, 0] + u[0, 1, 0] + u[0, -1, 0])
+
+
+@gtscript.function
+def fwd_diff_op_xy(field):
+    dx = field[1, 0, 0] - field[0, 0, 0]
+    dy = field[0, 1, 0] - field[0, 0, 0]
+    return dx, dy
+
+
+@gtscript.function
+def wrap1arg2return(field):
+    dx, dy = fwd_diff_op_xy(field=field)
+    return dx, dy
+
+
+@gtscript.function
+def fwd_diff_op_x(field):
+    dx = field[1, 0, 0] - field[0, 0, 0]
+    return dx
+
+
+@gtscript.function
+def fwd_diff_op_y(field):
+    dy = field[0, 1, 0] - field[0, 0, 0]
+    return dy
+
+
+def horizontal_diffusion_subroutines(u: F64, diffusion: F64, *, weight: float):
+    from __externals__ import fwd_diff
+
+    with computation(PARALLEL), interval(...):
+        laplacian = lap_op(u=u)
+        flux_i, flux_j = fwd_diff(field=laplacian)
+        diffusion = u[0, 0, 0] - weight * (flux_i[0, 0, 0] - flux_i[-1, 0, 0] + flux_j[0, 0, 0] - flux_j[0, -1, 0])
+
+
+# ---- :299-337 ----------------------------------------------------------------------------------
+def horizontal_diffusion_subroutines2(u: F64, diffusion: F64, *, weight: float):
+    from __externals__ import BRANCH
+    from __gtscript__ import __INLINED
+
+    with computation(PARALLEL), interval(...):
+        laplacian = lap_op(u=u)
+        if __INLINED(BRANCH):
+            flux_i = fwd_diff_op_x(field=laplacian)
+            flux_j = fwd_diff_op_y(field=laplacian)
+        else:
+            flux_i, flux_j = fwd_diff_op_xy(field=laplacian)
+        diffusion = u[0, 0, 0] - weight * (flux_i[0, 0, 0] - flux_i[-1, 0, 0] + flux_j[0, 0, 0] - flux_j[0, -1, 0])
+
+
+# ---- :340-356 ----------------------------------------------------------------------------------
+def runtime_if_flat(outfield: F64):
+    with computation(PARALLEL), interval(...):
+        if True:
+            outfield = 1
+        else:
+            outfield = 2
+
+
+# ---- :359-378 ----------------------------------------------------------------------------------
+def runtime_if_nested(outfield: F64):
+    with computation(PARALLEL), interval(...):
+        if (outfield > 0 and outfield > 0) or (not outfield > 0 and not outfield > 0):
+            if False:
+                outfield = 1
+            else:
+                outfield = 2
+        else:
+            outfield = 3
+
+
+# ---- :381-404 ----------------------------------------------------------------------------------
+@gtscript.function
+def add_one(field_in):
+    """Add 1 to each element of `field_in`."""
+    return field_in + 1
+
+
+def three_fold_nested_if(field_a: F64):
+    with computation(PARALLEL), interval(...):
+        if field_a >= 0.0:
+            field_a = 0.0
+            if field_a > 1:
+                field_a = 1
+                if field_a > 2:
+                    field_a = 2
+
+
+def _three_fold_expected(a, p, ext, domain):
+    out = a["field_a"].copy()
+    for v in range(3):
+        out[np.where(out > v)] = v
+    return {"field_a": out}
+
+
+# ---- :407-438 ----------------------------------------------------------------------------------
+def runtime_if_nested_data_dependent(field_a: F64, field_b: F64, field_c: F64, *, factor: float):
+    with computation(PARALLEL), interval(...):
+        if factor > 0:
+            if field_a < 0:
+                field_b = -field_a
+            else:
+                field_b = field_a
+        else:
+            if field_a < 0:
+                field_c = -field_a
+            else:
+                field_c = field_a
+
+        field_a = add_one(field_a)
+
+
+def _data_dependent_expected(a, p, ext, domain):
+    out = {"field_a": a["field_a"] + 1}
+    out["field_b" if p["factor"] > 0 else "field_c"] = np.abs(a["field_a"])
+    return out
+
+
+# ---- :471-489 ----------------------------------------------------------------------------------
+def ternary_op(infield: F64, outfield: F64):
+    with computation(PARALLEL), interval(...):
+        outfield = infield if infield > 0.0 else -infield[0, 1, 0]
+
+
+def _ternary_expected(a, p, ext, domain):
+    x = a["infield"]
+    return {"outfield": (x[:, :-1] > 0.0) * x[:, :-1] + (x[:, :-1] <= 0.0) * (-x[:, 1:])}
+
+
+# ---- :492-533 ----------------------------------------------------------------------------------
+def three_way_and(outfield: F64, *, a: float, b: float, c: float):
+    with computation(PARALLEL), interval(...):
+        if a > 0 and b > 0 and c > 0:
+            outfield = 1
+        else:
+            outfield = 0
+
+
+def three_way_or(outfield: F64, *, a: float, b: float, c: float):
+    with computation(PARALLEL), interval(...):
+        if a > 0 or b > 0 or c > 0:
+            outfield = 1
+        else:
+            outfield = 0
+
+
+# ---- :536-561 with stencil_definitions.py:406-421 ------------------------------------------------
+def optional_field(in_field: F64, out_field: F64, dyn_tend: F64, phys_tend: F64 = None, *, dt: float):
+    from __externals__ import PHYS_TEND
+
+    with computation(PARALLEL), interval(...):
+        out_field = in_field + dt * dyn_tend
+        if __INLINED(PHYS_TEND):
+            out_field = out_field + dt * phys_tend
+
+
+def _optional_expected(a, p, ext, domain):
+    out = a["in_field"] + p["dt"] * a["dyn_tend"]
+    if ext["PHYS_TEND"]:
+        out = out + p["dt"] * a["phys_tend"]
+    return {"out_field": out}
+
+
+# ---- :700-762 ----------------------------------------------------------------------------------
+def read_outside_k_interval_1(field_in: F64, field_out: F64):
+    with computation(PARALLEL), interval(...):
+        field_out = field_in[0, 0, -1] + field_in[0, 0, 1]
+
+
+def read_outside_k_interval_2(field_in: F64, field_out: F64):
+    with computation(PARALLEL), interval(-1, None):
+        field_out = field_in[0, 0, 1]
+
+
+def read_outside_k_interval_3(field_in: F64, field_out: F64):
+    with computation(PARALLEL), interval(0, 1):
+        field_out = field_in[0, 0, -1]
+
+
+def _rok2_expected(a, p, ext, domain):
+    out = a["field_out"].copy()
+    out[:, :, -1] = a["field_in"][:, :, domain[2]]
+    return {"field_out": out}
+
+
+def _rok3_expected(a, p, ext, domain):
+    out = a["field_out"].copy()
+    out[:, :, 0] = a["field_in"][:, :, 0]
+    return {"field_out": out}
+
+
+# ---- :811-832 ----------------------------------------------------------------------------------
+def diagonal_k_offset(field_in: F64, field_out: F64):
+    with computation(PARALLEL), interval(...):
+        field_out = field_in[0, 0, 1]
+    with computation(PARALLEL), interval(0, -1):
+        field_out += field_in[0, -1, 1]
+
+
+def _diagonal_expected(a, p, ext, domain):
+    x = a["field_in"]
+    out = x[:, 1:, 1:].copy()
+    out[:, :, :-1] += x[:, :-1, 1:-1]
+    return {"field_out": out}
+
+
+R10 = (-10.0, 10.0)
+R1 = (-1.0, 1.0)
+SUITES: Dict[str, Suite] = {
+    "identity": Suite(identity, {"field_a": (np.float64, Z, R10)}, lambda a, p, e, d: {"field_a": a["field_a"]}),
+    "copy": Suite(copy, {"field_a": (np.float64, Z, R10), "field_b": (np.float64, Z, R10)},
+                  lambda a, p, e, d: {"field_b": a["field_a"]}),
+    "aug_assign": Suite(aug_assign, {"field_a": (np.float64, Z, R10), "field_b": (np.float64, Z, R10)},
+                        lambda a, p, e, d: {"field_a": (a["field_a"] + 1.0) * 2.0, "field_b": (a["field_b"] - 1.0) / 2.0}),
+    "global_scale": Suite(global_scale, {"field_a": (np.float64, Z, R1)},
+                          lambda a, p, e, d: {"field_a": e["SCALE_FACTOR"] * a["field_a"]},
+                          externals=({"SCALE_FACTOR": 1.0}, {"SCALE_FACTOR": 1e3}, {"SCALE_FACTOR": 1e6})),
+    "parametric_scale": Suite(parametric_scale, {"field_a": (np.float64, Z, R10)},
+                              lambda a, p, e, d: {"field_a": p["scale"] * a["field_a"]}, params={"scale": (-100, 100)}),
+    "parametric_mix": Suite(parametric_mix,
+                            {"field_a": (np.float64, Z, R10), "field_b": (np.float64, Z, R10),
+                             "field_c": (np.float64, Z, R10), "field_out": (np.float32, Z, R10)},
+                            _parametric_mix_expected, params={"weight": (-10, 10), "alpha_factor": (-1, 1)},
+                            externals=({"USE_ALPHA": True}, {"USE_ALPHA": False})),
+    "heat_equation_ftcs": Suite(heat_equation_ftcs,
+                                {"u": (np.float64, ((1, 1), (0, 0), (0, 0)), R10), "v": (np.float64, ((0, 0), (1, 1), (0, 0)), R10),
+                                 "u_new": (np.float64, Z, R10), "v_new": (np.float64, Z, R10)},
+                                _heat_expected, params={"ru": (0, 0.5), "rv": (0, 0.5)}),
+    "horizontal_diffusion": Suite(horizontal_diffusion,
+                                  {"u": (np.float64, ((2, 2), (2, 2), (0, 0)), R10), "diffusion": (np.float64, Z, R10)},
+                                  _hdiff_expected, params={"weight": (0, 0.5)}),
+    "horizontal_diffusion_subroutines": Suite(horizontal_diffusion_subroutines,
+                                              {"u": (np.float64, ((2, 2), (2, 2), (0, 0)), R10), "diffusion": (np.float64, Z, R10)},
+                                              _hdiff_expected, params={"weight": (0, 0.5)},
+                                              externals=({"fwd_diff": wrap1arg2return},)),
+    "horizontal_diffusion_subroutines2": Suite(horizontal_diffusion_subroutines2,
+                                               {"u": (np.float64, ((2, 2), (2, 2), (0, 0)), R10), "diffusion": (np.float64, Z, R10)},
+                                               _hdiff_expected, params={"weight": (0, 0.5)},
+                                               externals=({"BRANCH": True}, {"BRANCH": False})),
+    "runtime_if_flat": Suite(runtime_if_flat, {"outfield": (np.float64, Z, R10)},
+                             lambda a, p, e, d: {"outfield": np.full_like(a["outfield"], 1)}),
+    "runtime_if_nested": Suite(runtime_if_nested, {"outfield": (np.float64, Z, R10)},
+                               lambda a, p, e, d: {"outfield": np.full_like(a["outfield"], 2)}),
+    "three_fold_nested_if": Suite(three_fold_nested_if, {"field_a": (np.float64, Z, R1)}, _three_fold_expected,
+                                  domains=((3, 3, 3),)),
+    "runtime_if_nested_data_dependent": Suite(runtime_if_nested_data_dependent,
+                                              {"field_a": (np.float64, Z, R1), "field_b": (np.float64, Z, R1), "field_c": (np.float64, Z, R1)},
+                                              _data_dependent_expected, params={"factor": (-100, 100)}, domains=((3, 3, 3), (5, 4, 3))),
+    "ternary_op": Suite(ternary_op, {"infield": (np.float64, ((0, 0), (0, 1), (0, 0)), R10), "outfield": (np.float64, Z, R10)},
+                        _ternary_expected, domains=((1, 2, 1), (3, 4, 5), (15, 14, 13))),
+    "three_way_and": Suite(three_way_and, {"outfield": (np.float64, Z, R10)},
+                           lambda a, p, e, d: {"outfield": np.full_like(a["outfield"], 1 if p["a"] > 0 and p["b"] > 0 and p["c"] > 0 else 0)},
+                           params={"a": (-100, 100), "b": (-100, 100), "c": (-100, 100)}),
+    "three_way_or": Suite(three_way_or, {"outfield": (np.float64, Z, R10)},
+                          lambda a, p, e, d: {"outfield": np.full_like(a["outfield"], 1 if p["a"] > 0 or p["b"] > 0 or p["c"] > 0 else 0)},
+                          params={"a": (-100, 100), "b": (-100, 100), "c": (-100, 100)}),
+    "optional_field": Suite(optional_field,
+                            {"in_field": (np.float64, Z, R10), "out_field": (np.float64, Z, R10),
+                             "dyn_tend": (np.float64, Z, R10), "phys_tend": (np.float64, Z, R10)},
+                            _optional_expected, params={"dt": (0, 100)},
+                            externals=({"PHYS_TEND": False}, {"PHYS_TEND": True}), optional={"phys_tend": "PHYS_TEND"}),
+    "read_outside_k_interval_1": Suite(read_outside_k_interval_1,
+                                       {"field_in": (np.float64, ((0, 0), (0, 0), (1, 1)), R10), "field_out": (np.float64, Z, R10)},
+                                       lambda a, p, e, d: {"field_out": a["field_in"][:, :, 0:-2] + a["field_in"][:, :, 2:]},
+                                       domains=((4, 4, 4), (3, 2, 1))),
+    "read_outside_k_interval_2": Suite(read_outside_k_interval_2,
+                                       {"field_in": (np.float64, ((0, 0), (0, 0), (0, 1)), R10), "field_out": (np.float64, Z, R10)},
+                                       _rok2_expected, domains=((4, 4, 4),)),
+    "read_outside_k_interval_3": Suite(read_outside_k_interval_3,
+                                       {"field_in": (np.float64, ((0, 0), (0, 0), (1, 0)), R10), "field_out": (np.float64, Z, R10)},
+                                       _rok3_expected, domains=((4, 4, 4),)),
+    "diagonal_k_offset": Suite(diagonal_k_offset,
+                               {"field_in": (np.float64, ((0, 0), (1, 0), (0, 1)), (0.1, 10.0)), "field_out": (np.float64, Z, (0.1, 10.0))},
+                               _diagonal_expected, domains=((2, 2, 2), (2, 2, 8), (5, 6, 7))),
+}
+
+
+def cases():
+    """(suite name, externals, domain) triples."""
+    for name, suite in SUITES.items():
+        for ext in suite.externals:
+            for domain in suite.domains:
+                yield name, ext, domain
+
+
+def make_case(name: str, ext: Dict[str, Any], domain, seed: int = 1337):
+    """Seeded inputs for one case -> (arrays incl. boundary, origins, params, expected outputs over the domain)."""
+    suite = SUITES[name]
+    rng = np.random.default_rng(seed)
+    arrays, origins = {}, {}
+    for fname, (dt, boundary, (lo, hi)) in suite.fields.items():
+        shape = tuple(d + b[0] + b[1] for d, b in zip(domain, boundary))
+        arrays[fname] = rng.uniform(lo, hi, shape).astype(dt)
+        origins[fname] = tuple(b[0] for b in boundary)
+    params = {p: float(rng.uniform(lo, hi)) for p, (lo, hi) in suite.params.items()}
+    expected = suite.expected({k: v.copy() for k, v in arrays.items()}, params, ext, domain)
+    return arrays, origins, params, expected

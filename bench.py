@@ -72,6 +72,60 @@ def _time_launches(fn, steps):
     return start.elapsed_time(stop) / steps
 
 
+def other_kernels(steps: int = 10):
+    """The other kernels of the north star at their BASELINE.json sizes, through the same call path
+    (storage -> stencil -> FrozenStencil), HIP-event timed.  Informational: `value` stays the Laplacian."""
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+
+    gen = torch.Generator(device="cuda").manual_seed(2024)
+
+    def field(shape, dtype, origin, lo=-1.0, hi=1.0):
+        f = gt_storage.empty(shape, dtype, backend="hip:mi300", aligned_index=origin)
+        f.tensor.copy_(torch.rand(shape, dtype=f.tensor.dtype, device="cuda", generator=gen) * (hi - lo) + lo)
+        return f
+
+    out = {}
+
+    def run(name, obj, fields, origin, domain, bytes_per_lup, scalars=None, note=None):
+        frozen = obj.freeze(origin=origin, domain=domain)
+        call = lambda i: frozen(**fields, **(scalars or {}))  # noqa: E731
+        for i in range(2):
+            call(i)
+        torch.cuda.synchronize()
+        ms = _time_launches(call, steps)
+        lups = float(np.prod(domain))
+        gbs = bytes_per_lup * lups / (ms * 1e-3) / 1e9
+        out[name] = {"domain": list(domain), "ms": round(ms, 4), "glups": round(lups / ms / 1e6, 1),
+                     "algorithmic_bytes_per_lup": bytes_per_lup, "achieved_gbs": round(gbs, 1),
+                     "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4)}
+        if note:
+            out[name]["note"] = note
+
+    for tag, dt, dom in (("hdiff_limiter_f32_1024x1024x80", np.float32, (1024, 1024, 80)),
+                         ("hdiff_limiter_f64_512x1024x80", np.float64, (512, 1024, 80))):
+        obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": dt},
+                               device_sync=False)
+        shape = (dom[0] + 4, dom[1] + 4, dom[2])
+        fields = {"in_field": field(shape, dt, (2, 2, 0), 0.0, 10.0), "coeff": field(shape, dt, (2, 2, 0), 0.0, 0.05),
+                  "out_field": field(shape, dt, (2, 2, 0))}
+        run(tag, obj, fields, {k: (2, 2, 0) for k in fields}, dom, 3.0 * np.dtype(dt).itemsize)
+        del fields
+    dom = (1024, 1024, 160)
+    obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64},
+                           device_sync=False)
+    fields = {"inf": field(dom, np.float64, (0, 0, 0)), "diag": field(dom, np.float64, (0, 0, 0), 4.0, 5.0),
+              "sup": field(dom, np.float64, (0, 0, 0)), "rhs": field(dom, np.float64, (0, 0, 0), -10.0, 10.0),
+              "out": field(dom, np.float64, (0, 0, 0))}
+    run("tridiagonal_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 56.0,
+        note="two sweeps move 72 B/LUP: ceiling 0.78 of this roofline; inputs are whatever the previous launch "
+             "left in sup/rhs (timing only, values are checked in tests/)")
+    del fields
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(seconds_budget: float = 12.0):
     """Time the oracle's C/OpenMP port on the same 512^3 workload for a bounded number of applies.
 
@@ -139,6 +193,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-kernels", action="store_true",
+                    help="skip the informational hdiff / tridiagonal lines (N=1 only)")
     ap.add_argument("--dist-selfloop", action="store_true",
                     help="1-GPU rehearsal of the N>1 step: periodic-in-J domain whose halo messages go to the "
                          "rank itself through RCCL (not the headline metric)")
@@ -311,6 +367,12 @@ def main() -> None:
             },
             "device": _lib.device_info(),
         }
+        if not decomposed and not args.no_other_kernels:
+            try:
+                line["other_kernels"] = other_kernels()
+            except Exception as ex:
+                line["other_kernels"] = None
+                print(f"other_kernels failed: {ex!r}", file=sys.stderr)
         if not decomposed and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

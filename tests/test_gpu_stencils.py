@@ -99,10 +99,13 @@ def test_host_arrays_are_rejected_and_unknown_stencils_raise():
         stencil(np.ones((8, 8, 2)), np.zeros((8, 8, 2)))
 
     def other(a: gtscript.Field[np.float64], b: gtscript.Field[np.float64]):
-        with computation(PARALLEL), interval(...):  # noqa: F821
-            b = a + 1.0  # noqa: F841
+        with computation(FORWARD), interval(1, None):  # noqa: F821
+            t = a[0, 0, -1] + b  # noqa: F841
+            a = t[1, 0, 0] + t[-1, 0, 0]  # noqa: F841
 
-    with pytest.raises(NotImplementedError, match="hand-written gfx950 kernels"):
+    # columns depend on each other inside one sequential block: neither the kernel library nor the
+    # generic executor can run it exactly -> loud failure at decoration time, never a CPU fallback
+    with pytest.raises(NotImplementedError, match="no CPU fallback"):
         gtscript.stencil(definition=other, backend=BACKEND)
 
 
@@ -242,3 +245,63 @@ def test_large_domain_properties_512cubed():
     want = np.zeros_like(slab)
     R.laplacian(slab, want)
     assert np.array_equal(out[1:-1, 201:214, 100:103].get(), want[1:-1, 1:-1])
+
+
+def test_large_domain_properties_hdiff_and_tridiagonal():
+    """BASELINE sizes C3 (1024x1024x80 fp32 hdiff) and C4 (1024x1024x160 fp64 tridiagonal): properties
+    that need no full-size CPU run.
+
+    * hdiff of an affine plane is the identity (the Laplacian of a plane is exactly 0 in these units);
+    * hdiff of a random field equals the oracle on a slab cut out with its halo;
+    * the tridiagonal solution satisfies the ORIGINAL system: residual computed on the device with torch,
+      and two columns are compared bit for bit with the oracle.
+    """
+    from oracle import ref_numpy as R
+
+    gt_storage, gtscript = _imports()
+    import torch
+    from gt4py_amd.cartesian.backend import hip_templates
+
+    hd = gtscript.stencil(backend=BACKEND, definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float32})
+    ni, nj, nk = 1024, 1024, 80
+    shape = (ni + 4, nj + 4, nk)
+    mk = lambda: gt_storage.empty(shape, np.float32, backend=BACKEND, aligned_index=(2, 2, 0))  # noqa: E731
+    inp, coeff, out = mk(), mk(), mk()
+    x = torch.arange(shape[0], dtype=torch.float32, device="cuda").reshape(-1, 1, 1)
+    y = torch.arange(shape[1], dtype=torch.float32, device="cuda").reshape(1, -1, 1)
+    inp.tensor.copy_((3.0 * x - 2.0 * y + 7.0).expand(shape))  # small integers: exact in fp32
+    coeff.tensor.fill_(0.025)
+    out.tensor.fill_(-1.0)
+    hd(inp, out, coeff, origin=(2, 2, 0))
+    assert bool((out.tensor[2:-2, 2:-2] == inp.tensor[2:-2, 2:-2]).all())
+    assert bool((out.tensor[:2] == -1.0).all()) and bool((out.tensor[:, -2:] == -1.0).all())
+    g = torch.Generator(device="cuda").manual_seed(2024)
+    inp.tensor.copy_(torch.rand(shape, dtype=torch.float32, device="cuda", generator=g) * 10)
+    hd(inp, out, coeff, origin=(2, 2, 0))
+    sl = (slice(500, 540), slice(1000, 1028), slice(30, 33))
+    h_in, h_co = inp[sl].get(), coeff[sl].get()
+    want = np.zeros_like(h_in)
+    R.hdiff(h_in, want, h_co, origin_in=(2, 2, 0), origin_out=(2, 2, 0), origin_coeff=(2, 2, 0),
+            domain=(h_in.shape[0] - 4, h_in.shape[1] - 4, 3))
+    assert np.array_equal(out[sl].get()[2:-2, 2:-2], want[2:-2, 2:-2])
+    del inp, coeff, out
+
+    tri = gtscript.stencil(backend=BACKEND, definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64})
+    dom = (1024, 1024, 160)
+    f = {}
+    for name, (lo, hi) in {"inf": (-1, 1), "diag": (4, 5), "sup": (-1, 1), "rhs": (-10, 10), "out": (0, 0)}.items():
+        f[name] = gt_storage.empty(dom, np.float64, backend=BACKEND)
+        f[name].tensor.copy_(torch.rand(dom, dtype=torch.float64, device="cuda", generator=g) * (hi - lo) + lo)
+    sup0, rhs0 = f["sup"].tensor.clone(), f["rhs"].tensor.clone()
+    cols = [(0, 0), (1023, 517)]
+    host = {n: np.stack([f[n][i, j, :].get() for i, j in cols])[:, None, :].copy() for n in f}
+    tri(**f)
+    xs = f["out"].tensor
+    res = f["diag"].tensor * xs - rhs0
+    res[:, :, 1:] += f["inf"].tensor[:, :, 1:] * xs[:, :, :-1]
+    res[:, :, :-1] += sup0[:, :, :-1] * xs[:, :, 1:]
+    assert float(res.abs().max()) < 1e-13 * 10 * 8
+    R.tridiag(host["inf"], host["diag"], host["sup"], host["rhs"], host["out"])
+    for n, (i, j) in enumerate(cols):
+        for name in ("sup", "rhs", "out"):
+            assert np.array_equal(f[name][i, j, :].get(), host[name][n, 0]), (name, i, j)

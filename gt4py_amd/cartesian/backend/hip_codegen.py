@@ -54,10 +54,16 @@ def _env_tuple(name: str, default: Tuple[int, ...]) -> Tuple[int, ...]:
 #: launch geometry / unrolling of the generated kernels, from the sweep in
 #: profiles/r1_codegen_sweep.log (env overrides are for tuning experiments)
 TUNING = {
-    # threads along I, J; K levels per thread; consecutive I points per thread
+    # threads along I, J; K levels per thread; consecutive J rows per thread (unrolled: the compiler
+    # then shares the row loads and the recomputed temporaries between neighbouring rows)
     "block_ijk": _env_tuple("GT4MI_CODEGEN_BLOCK_IJK", (64, 2, 4, 1)),
     "block_column": _env_tuple("GT4MI_CODEGEN_BLOCK_COLUMN", (64, 4)),
     "unroll": _env_tuple("GT4MI_CODEGEN_UNROLL", (8,))[0],  # sequential K loops
+    # XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (private L2s); with R > 0 each
+    # XCD gets runs of R consecutive tile rows, so rows shared by neighbouring tiles hit in one L2
+    # (measured neutral-to-negative for thread-per-point kernels, profiles/r1_codegen_sweep.log: off)
+    "xcd_rows": _env_tuple("GT4MI_CODEGEN_XCD_ROWS", (0,))[0],
+    "nontemporal": _env_tuple("GT4MI_CODEGEN_NONTEMPORAL", (1,))[0],  # streaming stores for write-only outputs
 }
 
 
@@ -509,6 +515,20 @@ GT_MATH1(exp, __builtin_exp, __builtin_expf)
 GT_MATH1(log, __builtin_log, __builtin_logf)
 GT_MATH1(log10, __builtin_log10, __builtin_log10f)
 GT_MATH1(cbrt, __builtin_cbrt, __builtin_cbrtf)
+// Workgroup -> tile.  The dispatcher deals workgroups round-robin to the 8 XCDs in linear order (x
+// fastest); give each XCD runs of `rows` consecutive tile rows instead of every 8th tile.
+GT_DEV void gt_tile(unsigned rows, unsigned& bx, unsigned& by, unsigned& bz) {
+    const unsigned long long gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    unsigned long long l = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned long long g = gx * rows, span = 8ull * g;
+    if (rows != 0u && l < (n / span) * span) {
+        const unsigned long long xcd = l % 8ull, slot = l / 8ull;
+        l = ((slot / g) * 8ull + xcd) * g + slot % g;
+    }
+    bx = (unsigned)(l % gx);
+    by = (unsigned)((l / gx) % gy);
+    bz = (unsigned)(l / (gx * gy));
+}
 template <class T> GT_DEV bool gt_isnan(T a) { return a != a; }
 template <class T> GT_DEV bool gt_isinf(T a) { return a == a && (a - a) != (a - a); }
 template <class T> GT_DEV bool gt_isfinite(T a) { return (a - a) == (a - a); }
@@ -544,7 +564,7 @@ class KernelSource:
     extent: Extent2
     block: Tuple[int, int, int]
     k_per_thread: int = 1
-    i_per_thread: int = 1
+    j_per_thread: int = 1
 
 
 @dataclass
@@ -571,6 +591,10 @@ class _Emitter:
         self.axes: Dict[str, Tuple[str, ...]] = {f.name: tuple(f.axes) for f in plan.stencil.fields}
         self.global_names = [f.name for f in plan.api_fields] + list(plan.scratch)
         self.written = {s.target.name for _, _, s in plan.stencil.statements()}
+        read = {e.name for _, _, s in plan.stencil.statements() for e in ir.stmt_reads(s) if isinstance(e, ir.FieldAccess)}
+        api = {f.name for f in plan.api_fields}
+        # outputs nobody reads back: keep them out of the caches
+        self.streaming = (self.written & api) - read if TUNING["nontemporal"] else set()
 
     # -- expressions --------------------------------------------------------------------------
     def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str]) -> str:
@@ -672,6 +696,8 @@ class _Emitter:
             if name not in self.plan.register_only:
                 self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset), k, -1, {})} = n_{_c_ident(name)};")
             reg[(name, 0)] = f"n_{_c_ident(name)}"
+        elif name in self.streaming:
+            self.lines.append(f"{pad}__builtin_nontemporal_store({value}, &{self.access(ir.FieldAccess(name, s.target.offset), k, -1, {})});")
         else:
             self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset), k, -1, {})} = {value};")
         if g:
@@ -718,21 +744,23 @@ class _Emitter:
         L = self.lines
         (ilo, ihi), (jlo, jhi) = stage.extent
         if stage.mapping == "ijk":
-            bi, bj, k_per_thread, i_per_thread = (tuple(TUNING["block_ijk"]) + (1,))[:4]
+            bi, bj, k_per_thread, j_per_thread = (tuple(TUNING["block_ijk"]) + (1,))[:4]
         else:
-            (bi, bj), k_per_thread, i_per_thread = TUNING["block_column"], 1, 1
+            (bi, bj), k_per_thread, j_per_thread = TUNING["block_column"], 1, 1
         block = (bi, bj, 1)
         L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}(const gt_args a) {{')
-        L.append(f"    const gt_i64 j = (gt_i64)blockIdx.y * {block[1]} + threadIdx.y + ({jlo});")
-        L.append(f"    if (j >= a.dJ + ({jhi})) return;")
-        if i_per_thread > 1:  # adjacent points per lane: the compiler merges their loads/stores into vectors
+        L.append("    unsigned gt_bx, gt_by, gt_bz;")
+        L.append(f"    gt_tile({TUNING['xcd_rows']}u, gt_bx, gt_by, gt_bz);")
+        L.append(f"    const gt_i64 i = (gt_i64)gt_bx * {block[0]} + threadIdx.x + ({ilo});")
+        L.append(f"    if (i >= a.dI + ({ihi})) return;")
+        if j_per_thread > 1:
             L.append("    #pragma unroll")
-            L.append(f"    for (int iv = 0; iv < {i_per_thread}; ++iv) {{")
-            L.append(f"    const gt_i64 i = ((gt_i64)blockIdx.x * {block[0]} + threadIdx.x) * {i_per_thread} + iv + ({ilo});")
-            L.append(f"    if (i >= a.dI + ({ihi})) break;")
+            L.append(f"    for (int jv = 0; jv < {j_per_thread}; ++jv) {{")
+            L.append(f"    const gt_i64 j = ((gt_i64)gt_by * {block[1]} + threadIdx.y) * {j_per_thread} + jv + ({jlo});")
+            L.append(f"    if (j >= a.dJ + ({jhi})) break;")
         else:
-            L.append(f"    const gt_i64 i = (gt_i64)blockIdx.x * {block[0]} + threadIdx.x + ({ilo});")
-            L.append(f"    if (i >= a.dI + ({ihi})) return;")
+            L.append(f"    const gt_i64 j = (gt_i64)gt_by * {block[1]} + threadIdx.y + ({jlo});")
+            L.append(f"    if (j >= a.dJ + ({jhi})) return;")
         for n in self.stage_globals(stage):
             if n in self.plan.register_only:
                 continue
@@ -748,9 +776,9 @@ class _Emitter:
             if k_per_thread > 1:
                 L.append(f"    #pragma unroll")
                 L.append(f"    for (int kk = 0; kk < {k_per_thread}; ++kk) {{")
-                L.append(f"    const gt_i64 k = (gt_i64)blockIdx.z * {k_per_thread} + kk;")
+                L.append(f"    const gt_i64 k = (gt_i64)gt_bz * {k_per_thread} + kk;")
             else:
-                L.append("    const gt_i64 k = blockIdx.z;")
+                L.append("    const gt_i64 k = gt_bz;")
             for nest in stage.nests:
                 L.append(f"    if (k >= {self.bound(nest.interval.start)} && k < {self.bound(nest.interval.end)}) {{")
                 self.local_decls(nest, "        ")
@@ -810,11 +838,11 @@ class _Emitter:
                             L.append(f"            {'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
                     L.append("        }")
                 L.append("    }")
-        if i_per_thread > 1:
+        if j_per_thread > 1:
             L.append("    }")
         L.append("}")
         L.append("")
-        return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, i_per_thread)
+        return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread)
 
 
 def generate(stencil: ir.Stencil) -> GeneratedProgram:

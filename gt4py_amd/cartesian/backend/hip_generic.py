@@ -127,7 +127,7 @@ class HipGenericStencilObject(StencilObject):
             if ni <= 0 or nj <= 0 or dK <= 0:
                 continue
             nk = -(-dK // kern.k_per_thread) if kern.mapping == "ijk" else 1
-            grid = _U3(-(-ni // (kern.block[0] * kern.i_per_thread)), -(-nj // kern.block[1]), nk)
+            grid = _U3(-(-ni // kern.block[0]), -(-nj // (kern.block[1] * kern.j_per_thread)), nk)
             rc = lib.gt4mi_launch(fn, grid, _U3(*kern.block), ctypes.byref(args), ctypes.sizeof(args), stream,
                                   ctypes.byref(info) if info is not None else None)
             _lib.check("gt4mi_launch", rc)

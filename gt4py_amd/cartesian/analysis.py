@@ -41,6 +41,19 @@ class ExtentInfo:
     blocks: List[Extent2]  # one per statement, in program order
 
 
+def access_extent(block: Extent2, offset: Tuple[int, int, int], region: "ir.Region | None" = None):
+    """Extent a read at ``offset`` requires of its field when the statement runs on ``block``; None when
+    a horizontal mask does not overlap the block (GenericAccess.to_extent,
+    gtc/passes/oir_optimizations/utils.py:52-76)."""
+    if region is None:
+        return _shift(block, offset)
+    di, dj = region.i.overlap(block[0]), region.j.overlap(block[1])
+    if di is None or dj is None:
+        return None
+    reach = ((block[0][0] - di[0], block[0][1] - di[1]), (block[1][0] - dj[0], block[1][1] - dj[1]))
+    return _union(_shift(reach, offset), ZERO_EXTENT)
+
+
 def compute_extents(stencil: ir.Stencil) -> ExtentInfo:
     stmts = [s for _, _, s in stencil.statements()]
     fields: Dict[str, Extent2] = {}
@@ -61,8 +74,9 @@ def compute_extents(stencil: ir.Stencil) -> ExtentInfo:
         for m in members:
             for e in ir.stmt_reads(stmts[m]):
                 if isinstance(e, ir.FieldAccess):
-                    need = _shift(block, e.offset)
-                    fields[e.name] = _union(fields[e.name], need) if e.name in fields else need
+                    need = access_extent(block, e.offset, stmts[m].region)
+                    if need is not None:
+                        fields[e.name] = _union(fields[e.name], need) if e.name in fields else need
         idx = first - 1
     for f in stencil.fields:
         fields.setdefault(f.name, ZERO_EXTENT)

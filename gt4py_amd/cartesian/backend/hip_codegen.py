@@ -92,7 +92,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
         for bi, block in enumerate(comp.blocks):
             for stmt in block.body:
                 touched.setdefault(stmt.target.name, set()).add((ci, bi))
-                if stmt.mask is not None:
+                if stmt.mask is not None or stmt.region is not None:
                     masked_write.add(stmt.target.name)
                 for e in ir.stmt_reads(stmt):
                     if isinstance(e, ir.FieldAccess):
@@ -160,7 +160,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                     version[name] = v
                     order.append(("def", v))
                 else:
-                    order.append(("stmt", ir.Assign(stmt.target, value, mask, stmt.group)))
+                    order.append(("stmt", ir.Assign(stmt.target, value, mask, stmt.group, stmt.region)))
 
             memo: Dict[Tuple[str, Tuple[int, int]], ir.Expr] = {}
             needed: Set[str] = set()
@@ -201,7 +201,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                         ssa_locals[obj] = np.dtype(temps[obj.rsplit("__v", 1)[0]].dtype)
                         new_body.append(ir.Assign(ir.FieldAccess(obj, (0, 0, 0), ssa_locals[obj]), local_defs[obj]))
                 else:
-                    new_body.append(ir.Assign(obj.target, value[0], value[1], obj.group))
+                    new_body.append(ir.Assign(obj.target, value[0], value[1], obj.group, obj.region))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     new_temps = tuple(t for t in stencil.temporaries if t.name not in inline) + tuple(
@@ -218,6 +218,7 @@ class Stmt:
     value: ir.Expr
     extent: Extent2
     mask: Optional[ir.Expr] = None
+    region: Optional[ir.Region] = None
 
 
 @dataclass
@@ -275,7 +276,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     ext_iter = iter(extents.blocks)
     for ci, comp in enumerate(stencil.computations):
         for bi, block in enumerate(comp.blocks):
-            stmts = [Stmt(s.target, s.value, next(ext_iter), s.mask) for s in block.body]
+            stmts = [Stmt(s.target, s.value, next(ext_iter), s.mask, s.region) for s in block.body]
             units = [[s] for s in stmts] if comp.order is ir.LoopOrder.PARALLEL else [stmts]
             for unit in units:
                 if not unit:
@@ -364,7 +365,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                         patterns.setdefault(e.name, set()).add((nest.order, e.offset))
                         extents_of.setdefault(e.name, set()).add(s.extent)
         unsafe = {s.target.name for nest in stage.nests for s in nest.stmts
-                  if s.mask is not None or s.target.offset != (0, 0, 0)}  # conditional / displaced writes
+                  if s.mask is not None or s.region is not None or s.target.offset != (0, 0, 0)}  # conditional / displaced writes
         for name, pats in patterns.items():
             if name in local_names or name in unsafe or len(extents_of.get(name, ())) != 1:
                 continue
@@ -682,6 +683,15 @@ class _Emitter:
         value = self.expr(s.value, k, si, reg)
         name = s.target.name
         g = self.guard(s, stage)
+        if s.region is not None:  # horizontal mask: bounds relative to the compute domain
+            conds = []
+            for var, size, iv in (("i", "a.dI", s.region.i), ("j", "a.dJ", s.region.j)):
+                for b, op in ((iv.start, ">="), (iv.end, "<")):
+                    if b is not None:
+                        conds.append(f"{var} {op} {b.offset}" if b.level is ir.Level.START else f"{var} {op} {size} + ({b.offset})")
+            if conds:
+                r = " && ".join(conds)
+                g = f"({g}) && {r}" if g else r
         if s.mask is not None:  # np.where(mask, value, target): untouched where the mask is false
             m = self.expr(s.mask, k, si, reg)
             g = f"({g}) && ({m})" if g else m

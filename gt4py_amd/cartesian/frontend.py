@@ -100,6 +100,7 @@ class _Parser(ast.NodeVisitor):
         self.temporaries: Dict[str, ir.FieldDecl] = {}
         self.imported: Dict[str, Any] = {}
         self._order: Optional[ir.LoopOrder] = None
+        self._region: Optional[ir.Region] = None  # set while the body of `with horizontal(...)` is parsed
         self._groups = 0  # top-level `if` statements seen (one horizontal execution each)
         self._masks = 0
         for pname, ann in annotations.items():
@@ -298,7 +299,7 @@ class _Parser(ast.NodeVisitor):
                     name = f"mask_{self._masks}"
                 self._masks += 1
                 self.temporaries[name] = ir.FieldDecl(name, np.dtype("bool"), ("I", "J", "K"), (), False)
-                out.append(ir.Assign(ir.FieldAccess(name, (0, 0, 0)), cond, mask, group))
+                out.append(ir.Assign(ir.FieldAccess(name, (0, 0, 0)), cond, mask, group, self._region))
                 cond = ir.FieldAccess(name, (0, 0, 0))
             for branch, this in ((node.body, cond), (node.orelse, ir.UnaryOp("not", cond))):
                 if not branch:
@@ -307,11 +308,73 @@ class _Parser(ast.NodeVisitor):
                 for s in branch:
                     out.extend(self._visit_stmt(s, combined, group))
             return out
+        if isinstance(node, ast.With):
+            # `with horizontal(region[...], region[...]):` -- the body is repeated once per region, each
+            # copy its own horizontal execution restricted to that region
+            # (gtscript_frontend.py:1950-1980; one HorizontalIf per region)
+            if len(node.items) != 1 or self._call_name(node.items[0].context_expr) != "horizontal":
+                raise self._err(node, "Only 'with horizontal(region[...])' may appear inside an interval block")
+            if self._region is not None or any(isinstance(c, ast.With) for c in node.body):
+                raise self._err(node, "Cannot nest `with` node inside a horizontal region.")
+            call = node.items[0].context_expr
+            if not call.args or call.keywords:
+                raise self._err(node, "horizontal() takes one or more region[...] arguments")
+            out = []
+            for arg in call.args:
+                self._region = self._parse_region(arg)
+                this_group = group
+                if this_group < 0:
+                    this_group = self._groups
+                    self._groups += 1
+                try:
+                    for s in node.body:
+                        out.extend(self._visit_stmt(s, mask, this_group))
+                finally:
+                    self._region = None
+            return out
         if isinstance(node, ast.Pass):
             return []
         if isinstance(node, ast.Expr) and isinstance(node.value, ast.Constant):
             return []
         raise self._err(node, f"Unsupported statement '{type(node).__name__}' in stencil body")
+
+    # ---- horizontal regions --------------------------------------------------------------
+    def _parse_region(self, node) -> ir.Region:
+        """``region[<I spec>, <J spec>]`` with specs ``I[0]``, ``I[-1]``, ``I[0] + n``, ``a:b`` or ``:``
+        (HorizontalIntervalParser, gtscript_frontend.py:226-300; bounds :133-160)."""
+        if not (isinstance(node, ast.Subscript) and isinstance(node.value, ast.Name) and node.value.id == "region"):
+            raise self._err(node, "Invalid horizontal range specification: expected region[...]")
+        spec = node.slice
+        if not isinstance(spec, ast.Tuple) or len(spec.elts) != 2:
+            raise self._err(node, "Invalid horizontal range specification: region takes an I and a J range")
+        return ir.Region(self._parse_axis_interval(spec.elts[0], "I"), self._parse_axis_interval(spec.elts[1], "J"))
+
+    def _parse_axis_interval(self, node, axis: str) -> ir.HorizontalInterval:
+        def bound(e) -> Optional[ir.AxisBound]:
+            """AxisIndex arithmetic: I[0] -> START+0, I[-1] -> END-1, +- integer constants."""
+            if e is None:
+                return None
+            if isinstance(e, ast.Subscript) and isinstance(e.value, ast.Name):
+                if e.value.id != axis:
+                    raise self._err(e, f"Invalid horizontal range specification: Expected axis {axis}, got {e.value.id}")
+                index = self._const(e.slice)
+                if index not in (0, -1):
+                    raise self._err(e, f"Invalid horizontal range specification: Expected specification {axis}[0] or {axis}[-1]")
+                return ir.AxisBound(ir.Level.START, 0) if index == 0 else ir.AxisBound(ir.Level.END, -1)
+            if isinstance(e, ast.BinOp) and isinstance(e.op, (ast.Add, ast.Sub)):
+                left = bound(e.left)
+                shift = self._const(e.right)
+                if left is None or not isinstance(shift, int) or isinstance(shift, bool):
+                    raise self._err(e, "Invalid horizontal range specification")
+                return ir.AxisBound(left.level, left.offset + (shift if isinstance(e.op, ast.Add) else -shift))
+            raise self._err(e, "Invalid horizontal range specification")
+
+        if isinstance(node, ast.Slice):
+            if node.step is not None:
+                raise self._err(node, "Invalid horizontal range specification: no step allowed")
+            return ir.HorizontalInterval(bound(node.lower), bound(node.upper))
+        single = bound(node)
+        return ir.HorizontalInterval(single, ir.AxisBound(single.level, single.offset + 1))
 
     def _target_access(self, target, node, reading=False) -> ir.FieldAccess:
         if isinstance(target, ast.Name):
@@ -336,7 +399,7 @@ class _Parser(ast.NodeVisitor):
         access = self._target_access(target, node)
         if access.name not in self.fields and access.name not in self.temporaries:
             self.temporaries[access.name] = ir.FieldDecl(access.name, None, ("I", "J", "K"), (), False)
-        return ir.Assign(access, value, mask, group)
+        return ir.Assign(access, value, mask, group, self._region)
 
     # ---- expressions ---------------------------------------------------------------------
     def generic_visit(self, node):
@@ -536,7 +599,7 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
                 tdt = dtypes[name]
                 if value.dtype != tdt:
                     value = ir.Cast(value, tdt)
-                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt), value, mask, stmt.group))
+                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt), value, mask, stmt.group, stmt.region))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     temps = tuple(ir.FieldDecl(t.name, dtypes[t.name], t.axes, t.data_dims, False) for t in stencil.temporaries)

@@ -121,6 +121,57 @@ LOGICAL_OPS = ("and", "or")
 
 # ---- statements --------------------------------------------------------------------------------
 @dataclass(frozen=True)
+class HorizontalInterval:
+    """Half-open index range on one horizontal axis relative to the compute domain; None = unbounded
+    (gtc/common.py ``HorizontalInterval``).  ``I[0]`` is START+0, ``I[-1]`` is END-1."""
+
+    start: Optional[AxisBound] = None
+    end: Optional[AxisBound] = None
+
+    def overlap(self, extent: Tuple[int, int]) -> Optional[Tuple[int, int]]:
+        """Distances from the block extent to the domain edges where the interval overlaps it, else None.
+        Restates ``_overlap_along_axis`` (gtc/passes/horizontal_masks.py:15-47)."""
+        start_diff: Optional[int]
+        end_diff: Optional[int]
+        if self.start is None:
+            start_diff = 1000
+        elif self.start.level is Level.START:
+            start_diff = extent[0] - self.start.offset
+        else:
+            start_diff = None
+        if self.end is None:
+            end_diff = -1000
+        elif self.end.level is Level.END:
+            end_diff = extent[1] - self.end.offset
+        else:
+            end_diff = None
+        if start_diff is not None and start_diff > 0 and end_diff is None and self.end is not None:
+            if self.end.offset <= extent[0]:
+                return None
+        elif end_diff is not None and end_diff < 0 and start_diff is None and self.start is not None:
+            if self.start.offset > extent[1]:
+                return None
+        return (min(start_diff, 0) if start_diff is not None else -10000,
+                max(end_diff, 0) if end_diff is not None else 10000)
+
+    def clip(self, lo: int, hi: int, size: int) -> Tuple[int, int]:
+        """[lo, hi) (domain-relative, hi already includes ``size``) intersected with the interval."""
+        if self.start is not None:
+            lo = max(lo, self.start.resolve(size))
+        if self.end is not None:
+            hi = min(hi, self.end.resolve(size))
+        return lo, hi
+
+
+@dataclass(frozen=True)
+class Region:
+    """``with horizontal(region[i, j])``: the statement only runs where the mask holds."""
+
+    i: HorizontalInterval
+    j: HorizontalInterval
+
+
+@dataclass(frozen=True)
 class Assign:
     """``target = value``, or ``target = where(mask, value, target)`` when ``mask`` is set.
 
@@ -135,6 +186,7 @@ class Assign:
     value: Expr
     mask: Optional[Expr] = None
     group: int = -1
+    region: Optional[Region] = None
 
 
 def stmt_exprs(stmt: "Assign"):

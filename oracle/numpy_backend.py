@@ -132,6 +132,14 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
                 def execute(krange):
                     for stmt, ((ilo, ihi), (jlo, jhi)) in plan:
                         lo, hi = (ilo, jlo), (dI + ihi, dJ + jhi)
+                        if stmt.region is not None:
+                            # horizontal mask: the block clipped to the region, bounds relative to the
+                            # compute domain (horizontal_masks.py:61-112 compute_relative_mask)
+                            i0, i1 = stmt.region.i.clip(lo[0], hi[0], dI)
+                            j0, j1 = stmt.region.j.clip(lo[1], hi[1], dJ)
+                            if i1 <= i0 or j1 <= j0:
+                                continue
+                            lo, hi = (i0, j0), (i1, j1)
                         target = env[stmt.target.name].window(lo, hi, stmt.target.offset, krange)
                         if stmt.mask is not None:  # npir_codegen.py:205-210: np.where(mask, right, left)
                             mask = _evaluate(stmt.mask, env, lo, hi, krange)

@@ -337,6 +337,52 @@ def _diagonal_expected(a, p, ext, domain):
     return {"field_out": out}
 
 
+# ---- :835-943 (horizontal regions) ---------------------------------------------------------------
+def horizontal_regions(field_in: F32, field_out: F32):
+    with computation(PARALLEL), interval(...):
+        field_out = field_in
+        with horizontal(region[I[0], :], region[I[-1], :]):
+            field_out = field_in + 1.0
+        with horizontal(region[:, J[0]], region[:, J[-1]]):
+            field_out = field_in - 1.0
+
+
+def _regions_expected(a, p, ext, domain, start=None):
+    x = a["field_in"]
+    out = x.copy() if start is None else np.full_like(x, start)
+    out[0] = x[0] + 1.0
+    out[-1] = x[-1] + 1.0
+    out[:, 0] = x[:, 0] - 1.0
+    out[:, -1] = x[:, -1] - 1.0
+    return {"field_out": out}
+
+
+def horizontal_regions_partial_writes(field_in: F32, field_out: F32):
+    with computation(PARALLEL), interval(...):
+        with horizontal(region[I[0], :], region[I[-1], :]):
+            field_out = field_in + 1.0
+        with horizontal(region[:, J[0]], region[:, J[-1]]):
+            field_out = field_in - 1.0
+
+
+def horizontal_regions_corners(field_in: F32, field_out: F32):
+    with computation(PARALLEL), interval(...):
+        with horizontal(region[I[0] : I[0] + 2, J[0] : J[0] + 2], region[I[-1] - 2 : I[-1], J[-1] - 2 : J[-1]]):
+            field_out = field_in + 1.0
+        with horizontal(region[I[0] : I[0] + 2, J[-1] - 2 : J[-1]], region[I[-1] - 2 : I[-1], J[0] : J[0] + 2]):
+            field_out = field_in - 1.0
+
+
+def _corners_expected(a, p, ext, domain):
+    x = a["field_in"]
+    out = np.full_like(x, 42)
+    out[0:2, 0:2] = x[0:2, 0:2] + 1.0
+    out[-3:-1, -3:-1] = x[-3:-1, -3:-1] + 1.0
+    out[0:2, -3:-1] = x[0:2, -3:-1] - 1.0
+    out[-3:-1, 0:2] = x[-3:-1, 0:2] - 1.0
+    return {"field_out": out}
+
+
 R10 = (-10.0, 10.0)
 R1 = (-1.0, 1.0)
 SUITES: Dict[str, Suite] = {
@@ -405,6 +451,15 @@ SUITES: Dict[str, Suite] = {
     "diagonal_k_offset": Suite(diagonal_k_offset,
                                {"field_in": (np.float64, ((0, 0), (1, 0), (0, 1)), (0.1, 10.0)), "field_out": (np.float64, Z, (0.1, 10.0))},
                                _diagonal_expected, domains=((2, 2, 2), (2, 2, 8), (5, 6, 7))),
+    "horizontal_regions": Suite(horizontal_regions, {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
+                                _regions_expected, domains=((4, 4, 2), (9, 7, 3))),
+    "horizontal_regions_partial_writes": Suite(horizontal_regions_partial_writes,
+                                               {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, (42.0, 42.0))},
+                                               lambda a, p, e, d: _regions_expected(a, p, e, d, start=42),
+                                               domains=((4, 4, 2), (9, 7, 3))),
+    "horizontal_regions_corners": Suite(horizontal_regions_corners,
+                                        {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, (42.0, 42.0))},
+                                        _corners_expected, domains=((4, 4, 2), (8, 9, 3))),
 }
 
 

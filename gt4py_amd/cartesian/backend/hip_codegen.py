@@ -56,7 +56,7 @@ def _env_tuple(name: str, default: Tuple[int, ...]) -> Tuple[int, ...]:
 TUNING = {
     # threads along I, J; K levels per thread; consecutive J rows per thread (unrolled: the compiler
     # then shares the row loads and the recomputed temporaries between neighbouring rows)
-    "block_ijk": _env_tuple("GT4MI_CODEGEN_BLOCK_IJK", (64, 2, 4, 1)),
+    "block_ijk": _env_tuple("GT4MI_CODEGEN_BLOCK_IJK", (64, 4, 1, 1)),
     "block_column": _env_tuple("GT4MI_CODEGEN_BLOCK_COLUMN", (64, 4)),
     "unroll": _env_tuple("GT4MI_CODEGEN_UNROLL", (8,))[0],  # sequential K loops
     # XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (private L2s); with R > 0 each
@@ -64,6 +64,10 @@ TUNING = {
     # (measured neutral-to-negative for thread-per-point kernels, profiles/r1_codegen_sweep.log: off)
     "xcd_rows": _env_tuple("GT4MI_CODEGEN_XCD_ROWS", (0,))[0],
     "nontemporal": _env_tuple("GT4MI_CODEGEN_NONTEMPORAL", (1,))[0],  # streaming stores for write-only outputs
+    "vector": _env_tuple("GT4MI_CODEGEN_VECTOR", (1,))[0],  # 16-byte lanes for horizontal stages
+    # ... and consecutive J rows per lane in those kernels: rows (and recomputed temporaries) shared by
+    # neighbouring output rows are loaded (computed) once per strip
+    "vector_rows": _env_tuple("GT4MI_CODEGEN_VECTOR_ROWS", (4,))[0],
 }
 
 
@@ -530,6 +534,27 @@ GT_DEV void gt_tile(unsigned rows, unsigned& bx, unsigned& by, unsigned& bz) {
     by = (unsigned)((l / gx) % gy);
     bz = (unsigned)(l / (gx * gy));
 }
+// 16-byte lanes: a lane owns N consecutive I points; the points next to them sit in the neighbouring
+// lanes' registers and are fetched with whole-wave DPP shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1,
+// no LDS).  Lanes shifted in from outside the wave read 0 -- callers overwrite those lanes.
+template <class T, int N> using gt_vec = T __attribute__((ext_vector_type(N)));
+template <class T, bool FROM_BELOW> GT_DEV T gt_shift(T v) {
+    if constexpr (sizeof(T) == 4) {
+        const int b = __builtin_bit_cast(int, v);
+        const int r = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, b, 0x138, 0xF, 0xF, false)
+                                 : __builtin_amdgcn_update_dpp(0, b, 0x130, 0xF, 0xF, false);
+        return __builtin_bit_cast(T, r);
+    } else {
+        static_assert(sizeof(T) == 8, "gt_shift: 4- or 8-byte types");
+        const long long b = __builtin_bit_cast(long long, v);
+        int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+        lo = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, false)
+                        : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, false);
+        hi = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, false)
+                        : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, false);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned int)lo);
+    }
+}
 template <class T> GT_DEV bool gt_isnan(T a) { return a != a; }
 template <class T> GT_DEV bool gt_isinf(T a) { return a == a && (a - a) != (a - a); }
 template <class T> GT_DEV bool gt_isfinite(T a) { return (a - a) == (a - a); }
@@ -566,6 +591,9 @@ class KernelSource:
     block: Tuple[int, int, int]
     k_per_thread: int = 1
     j_per_thread: int = 1
+    vec: int = 0  # > 0: a `<name>_vec` kernel exists in which every lane owns `vec` consecutive I points
+    vec_fields: Tuple[str, ...] = ()  # arrays whose alignment / strides decide whether it may be launched
+    vec_rows: int = 1  # consecutive J rows per lane in the `_vec` kernel
 
 
 @dataclass
@@ -596,13 +624,21 @@ class _Emitter:
         api = {f.name for f in plan.api_fields}
         # outputs nobody reads back: keep them out of the caches
         self.streaming = (self.written & api) - read if TUNING["nontemporal"] else set()
+        # state of the 16-byte-lane emission (vector_kernel)
+        self.vec_rows: Optional[Dict[Tuple[str, int, int], Dict[int, str]]] = None
+        self.vec_component = 0
+        self.vec_row = 0
+        self.local_suffix = ""
+        self.base_prefix = "b_"
 
     # -- expressions --------------------------------------------------------------------------
     def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str]) -> str:
         """C expression of a field read.  ``reg`` maps (name, k offset) -> register holding that level."""
         name = e.name
         if name in self.plan.locals:
-            return f"l_{_c_ident(name)}"
+            return f"l_{_c_ident(name)}{self.local_suffix}"
+        if self.vec_rows is not None and "I" in self.axes.get(name, ("I", "J", "K")):
+            return self.vec_rows[(name, e.offset[1] + self.vec_row, e.offset[2])][self.vec_component + e.offset[0]]
         if (name, e.offset[2]) in reg and e.offset[:2] == (0, 0):
             return reg[(name, e.offset[2])]
         if name in self.plan.register_only:
@@ -617,7 +653,7 @@ class _Emitter:
             terms.append(f"{di} * GT_SI(a.{c}_si)")
         if dj and "J" in axes:
             terms.append(f"{dj} * a.{c}_sj")
-        return f"b_{c}[{' + '.join(terms) if terms else '0'}]"
+        return f"{self.base_prefix}{c}[{' + '.join(terms) if terms else '0'}]"
 
     def expr(self, e: ir.Expr, k: str, si: int, reg: Dict[str, str]) -> str:
         rec = lambda x: self.expr(x, k, si, reg)  # noqa: E731
@@ -665,27 +701,26 @@ class _Emitter:
         raise UnsupportedStencil(f"expression node {type(e).__name__}")
 
     # -- statements ---------------------------------------------------------------------------
-    def guard(self, s: Stmt, stage: Stage) -> Optional[str]:
+    def guard(self, s: Stmt, stage: Stage, ivar: str = "i", jvar: str = "j") -> Optional[str]:
         (ilo, ihi), (jlo, jhi) = s.extent
         (silo, sihi), (sjlo, sjhi) = stage.extent
         conds = []
         if ilo != silo:
-            conds.append(f"i >= {ilo}")
+            conds.append(f"{ivar} >= {ilo}")
         if ihi != sihi:
-            conds.append(f"i < a.dI + ({ihi})")
+            conds.append(f"{ivar} < a.dI + ({ihi})")
         if jlo != sjlo:
-            conds.append(f"j >= {jlo}")
+            conds.append(f"{jvar} >= {jlo}")
         if jhi != sjhi:
-            conds.append(f"j < a.dJ + ({jhi})")
+            conds.append(f"{jvar} < a.dJ + ({jhi})")
         return " && ".join(conds) if conds else None
 
-    def statement(self, s: Stmt, stage: Stage, si: int, k: str, reg: Dict, indent: str, carry: Sequence[str] = ()) -> None:
-        value = self.expr(s.value, k, si, reg)
-        name = s.target.name
-        g = self.guard(s, stage)
+    def full_guard(self, s: Stmt, stage: Stage, si: int, k: str, reg: Dict, ivar: str = "i", jvar: str = "j") -> Optional[str]:
+        """Extent guard, horizontal-region mask and run-time mask of a statement as one condition."""
+        g = self.guard(s, stage, ivar, jvar)
         if s.region is not None:  # horizontal mask: bounds relative to the compute domain
             conds = []
-            for var, size, iv in (("i", "a.dI", s.region.i), ("j", "a.dJ", s.region.j)):
+            for var, size, iv in ((ivar, "a.dI", s.region.i), (jvar, "a.dJ", s.region.j)):
                 for b, op in ((iv.start, ">="), (iv.end, "<")):
                     if b is not None:
                         conds.append(f"{var} {op} {b.offset}" if b.level is ir.Level.START else f"{var} {op} {size} + ({b.offset})")
@@ -695,12 +730,18 @@ class _Emitter:
         if s.mask is not None:  # np.where(mask, value, target): untouched where the mask is false
             m = self.expr(s.mask, k, si, reg)
             g = f"({g}) && ({m})" if g else m
+        return g
+
+    def statement(self, s: Stmt, stage: Stage, si: int, k: str, reg: Dict, indent: str, carry: Sequence[str] = ()) -> None:
+        value = self.expr(s.value, k, si, reg)
+        name = s.target.name
+        g = self.full_guard(s, stage, si, k, reg)
         pad = indent
         if g:
             self.lines.append(f"{indent}if ({g}) {{")
             pad = indent + "    "
         if name in self.plan.locals:
-            self.lines.append(f"{pad}l_{_c_ident(name)} = {value};")
+            self.lines.append(f"{pad}l_{_c_ident(name)}{self.local_suffix} = {value};")
         elif name in carry:  # keep the freshly written level for this iteration's later reads and the next one
             self.lines.append(f"{pad}n_{_c_ident(name)} = {value};")
             if name not in self.plan.register_only:
@@ -734,7 +775,7 @@ class _Emitter:
             n = s.target.name
             if n in self.plan.locals and n not in seen:
                 seen.append(n)
-                self.lines.append(f"{indent}{_CTYPE[self.decl_dtype[n].name]} l_{_c_ident(n)};")
+                self.lines.append(f"{indent}{_CTYPE[self.decl_dtype[n].name]} l_{_c_ident(n)}{self.local_suffix};")
 
     @staticmethod
     def bound(b: ir.AxisBound) -> str:
@@ -852,7 +893,188 @@ class _Emitter:
             L.append("    }")
         L.append("}")
         L.append("")
-        return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread)
+        vec = _vector_width(self, stage) if j_per_thread == 1 and block[0] == 64 else 0
+        vec_fields: Tuple[str, ...] = ()
+        vec_rows = max(1, TUNING["vector_rows"])
+        if vec:
+            vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread)
+        return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
+                            vec_rows if vec else 1)
+
+
+def _vector_width(em: "_Emitter", stage: Stage) -> int:
+    """How many consecutive I points a lane may own in this stage (0 = keep one point per thread).
+
+    Needs: thread-per-point mapping, the stage starting at the domain's first column, reads only of arrays
+    the stage does not write (so rows can be loaded once, up front), I offsets within one lane's reach,
+    4- or 8-byte elements."""
+    if stage.mapping != "ijk" or stage.extent[0][0] != 0 or not TUNING["vector"]:
+        return 0
+    sizes = set()
+    for nest in stage.nests:
+        for s in nest.stmts:
+            if s.target.offset != (0, 0, 0):
+                return 0
+            if s.target.name not in em.plan.locals:
+                if "I" not in em.axes.get(s.target.name, ("I", "J", "K")):
+                    return 0
+                sizes.add(em.decl_dtype[s.target.name].itemsize)
+            for e in _stmt_field_reads(s):
+                if e.name in em.plan.locals:
+                    continue
+                if e.name in stage.written:
+                    return 0
+                if "I" in em.axes.get(e.name, ("I", "J", "K")):
+                    sizes.add(em.decl_dtype[e.name].itemsize)
+    if not sizes or not sizes <= {4, 8}:
+        return 0
+    vec = 16 // max(sizes)
+    for nest in stage.nests:
+        for s in nest.stmts:
+            if any(abs(e.offset[0]) > vec for e in _stmt_field_reads(s) if e.name not in em.plan.locals):
+                return 0
+    return vec
+
+
+def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block,
+                        k_per_thread: int) -> Tuple[str, ...]:
+    """``<kname>_vec``: a lane owns ``vec`` consecutive I points times ``rows_per_lane`` consecutive J rows.
+    Returns the arrays it touches."""
+    L = em.lines
+    plan = em.plan
+    JT = rows_per_lane
+    (_, ihi), (jlo, jhi) = stage.extent
+    globals_ = [n for n in em.stage_globals(stage) if n not in plan.register_only]
+
+    def has(n: str, axis: str) -> bool:
+        return axis in em.axes.get(n, ("I", "J", "K"))
+
+    L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}_vec(const gt_args a) {{')
+    L.append("    unsigned gt_bx, gt_by, gt_bz;")
+    L.append(f"    gt_tile({TUNING['xcd_rows']}u, gt_bx, gt_by, gt_bz);")
+    L.append("    const int lane = threadIdx.x;  // blockDim.x == 64: one wave per row segment")
+    L.append(f"    const gt_i64 i0 = ((gt_i64)gt_bx * {block[0]} + lane) * {vec};")
+    L.append(f"    const gt_i64 iend = a.dI + ({ihi}), jend = a.dJ + ({jhi});")
+    L.append(f"    const gt_i64 j0 = ((gt_i64)gt_by * {block[1]} + threadIdx.y) * {JT} + ({jlo});")
+    L.append("    if (i0 >= iend || j0 >= jend) return;")
+    for n in globals_:
+        c = _c_ident(n)
+        ct = _CTYPE[em.decl_dtype[n].name]
+        const = "" if n in stage.written else "const "
+        qual = " __restrict__" if n in plan.scratch else " GT_RESTRICT"
+        off = " + ".join(t for t in ("i0" if has(n, "I") else "", f"j0 * a.{c}_sj" if has(n, "J") else "") if t) or "0"
+        L.append(f"    {const}{ct}* const{qual} b_{c} = a.{c} + {off};")
+    L.append(f"    const bool whole = i0 + {vec} <= iend && j0 + {JT} <= jend;  // else: a partial vector / strip")
+    L.append(f"    const bool edge_lo = lane == 0, edge_hi = lane == 63 || i0 + {2 * vec} > iend;")
+    if k_per_thread > 1:
+        L.append("    #pragma unroll")
+        L.append(f"    for (int kk = 0; kk < {k_per_thread}; ++kk) {{")
+        L.append(f"    const gt_i64 k = (gt_i64)gt_bz * {k_per_thread} + kk;")
+    else:
+        L.append("    const gt_i64 k = gt_bz;")
+    for nest in stage.nests:
+        L.append(f"    if (k >= {em.bound(nest.interval.start)} && k < {em.bound(nest.interval.end)}) {{")
+        L.append("      if (whole) {")
+        # rows: every (array, row offset, dk) read for the strip, with the element offsets needed around the lane
+        rows: Dict[Tuple[str, int, int], Set[int]] = {}
+        for s in nest.stmts:
+            for e in _stmt_field_reads(s):
+                if e.name in plan.locals or not has(e.name, "I"):
+                    continue
+                for jv in range(JT if has(e.name, "J") else 1):
+                    need = rows.setdefault((e.name, e.offset[1] + jv, e.offset[2]), set())
+                    for v in range(vec):
+                        need.add(v + e.offset[0])
+        names: Dict[Tuple[str, int, int], Dict[int, str]] = {}
+        for rn, ((name, dj, dk), need) in enumerate(sorted(rows.items(), key=lambda kv: (kv[0][0], kv[0][2], kv[0][1]))):
+            c = _c_ident(name)
+            ct = _CTYPE[em.decl_dtype[name].name]
+            base = em.access(ir.FieldAccess(name, (0, dj, dk)), "k", -1, {})  # b_x[...] of element 0
+            addr = base[base.index("[") + 1:-1]
+            L.append(f"        const {ct}* const p{rn} = b_{c} + ({addr});")
+            L.append(f"        const gt_vec<{ct}, {vec}> r{rn} = *reinterpret_cast<const gt_vec<{ct}, {vec}>*>(p{rn});")
+            elems = {v: f"r{rn}[{v}]" for v in range(vec)}
+            for e in sorted(x for x in need if x < 0):  # from the lane below: its component vec + e
+                var = f"r{rn}_m{-e}"
+                L.append(f"        {ct} {var} = gt_shift<{ct}, true>(r{rn}[{vec + e}]);")
+                L.append(f"        if (edge_lo) {var} = p{rn}[{e}];")
+                elems[e] = var
+            for e in sorted(x for x in need if x >= vec):  # from the lane above: its component e - vec
+                var = f"r{rn}_p{e}"
+                L.append(f"        {ct} {var} = gt_shift<{ct}, false>(r{rn}[{e - vec}]);")
+                L.append(f"        if (edge_hi) {var} = p{rn}[{e}];")
+                elems[e] = var
+            names[(name, dj, dk)] = elems
+        em.vec_rows = names
+        for jv in range(JT):
+            for v in range(vec):
+                em.local_suffix = f"_{jv}_{v}"
+                em.local_decls(nest, "        ")
+
+        def target_of(tname: str, jv: int) -> str:
+            saved, em.vec_rows = em.vec_rows, None  # the target is addressed in memory
+            t = em.access(ir.FieldAccess(tname, (0, jv if has(tname, "J") else 0, 0)), "k", -1, {})
+            em.vec_rows = saved
+            return t
+
+        for sn, s in enumerate(nest.stmts):
+            tname = s.target.name
+            uniform = s.mask is None and s.region is None and em.guard(s, stage) is None
+            for jv in range(JT):
+                values = []
+                for v in range(vec):
+                    em.vec_component, em.vec_row, em.local_suffix = v, jv, f"_{jv}_{v}"
+                    ivar, jvar = f"(i0 + {v})", f"(j0 + {jv})"
+                    if tname in plan.locals:
+                        g = em.full_guard(s, stage, si, "k", {}, ivar, jvar)
+                        val = em.expr(s.value, "k", si, {})
+                        L.append(f"        {'if (' + g + ') ' if g else ''}l_{_c_ident(tname)}_{jv}_{v} = {val};")
+                        continue
+                    ct = _CTYPE[em.decl_dtype[tname].name]
+                    val = em.expr(s.value, "k", si, {})
+                    if uniform:
+                        L.append(f"        const {ct} w{sn}_{jv}_{v} = {val};")
+                        values.append(f"w{sn}_{jv}_{v}")
+                    else:
+                        g = em.full_guard(s, stage, si, "k", {}, ivar, jvar)
+                        target = target_of(tname, jv)[:-1] + f" + {v}]"
+                        L.append(f"        {'if (' + g + ') ' if g else ''}{target} = {val};")
+                if values:
+                    ct = _CTYPE[em.decl_dtype[tname].name]
+                    packed = f"gt_vec<{ct}, {vec}>{{{', '.join(values)}}}"
+                    ptr = f"reinterpret_cast<gt_vec<{ct}, {vec}>*>(&{target_of(tname, jv)})"
+                    if tname in em.streaming:
+                        L.append(f"        __builtin_nontemporal_store({packed}, {ptr});")
+                    else:
+                        L.append(f"        *{ptr} = {packed};")
+        em.vec_rows, em.local_suffix, em.vec_component, em.vec_row = None, "", 0, 0
+        L.append("      } else {")
+        L.append(f"        for (int jv = 0; jv < {JT}; ++jv) {{")
+        L.append("          const gt_i64 j = j0 + jv;")
+        L.append("          if (j >= jend) break;")
+        L.append(f"          for (int v = 0; v < {vec}; ++v) {{")
+        L.append("            const gt_i64 i = i0 + v;")
+        L.append("            if (i >= iend) break;")
+        for n in globals_:
+            c = _c_ident(n)
+            ct = _CTYPE[em.decl_dtype[n].name]
+            const = "" if n in stage.written else "const "
+            step = " + ".join(t for t in ("v" if has(n, "I") else "", f"jv * a.{c}_sj" if has(n, "J") else "") if t) or "0"
+            L.append(f"            {const}{ct}* const t_{c} = b_{c} + {step};")
+        em.base_prefix = "t_"
+        em.local_decls(nest, "            ")
+        for s in nest.stmts:
+            em.statement(s, stage, si, "k", {}, "            ")
+        em.base_prefix = "b_"
+        L.append("          }")
+        L.append("        }")
+        L.append("      }")
+        L.append("    }")
+    if k_per_thread > 1:
+        L.append("    }")
+    L.append("}")
+    L.append("")
+    return tuple(globals_)
 
 
 def generate(stencil: ir.Stencil) -> GeneratedProgram:

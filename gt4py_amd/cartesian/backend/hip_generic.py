@@ -37,11 +37,18 @@ class _Variant:
         _lib.check("gt4mi_module_load", lib.gt4mi_module_load(self._code_buf, ctypes.byref(module)))
         self.module = module
         self.functions: List[ctypes.c_void_p] = []
+        self.vec_functions: List[Any] = []  # the 16-byte-lane twin of a stage kernel, or None
         for kern in program.kernels:
             fn = ctypes.c_void_p()
             _lib.check("gt4mi_module_function",
                        lib.gt4mi_module_function(module, kern.name.encode(), ctypes.byref(fn)))
             self.functions.append(fn)
+            vfn = None
+            if kern.vec and unit_i:
+                vfn = ctypes.c_void_p()
+                _lib.check("gt4mi_module_function",
+                           lib.gt4mi_module_function(module, (kern.name + "_vec").encode(), ctypes.byref(vfn)))
+            self.vec_functions.append(vfn)
 
 
 def _ranges_disjoint(ranges: List[Tuple[int, int]]) -> bool:
@@ -72,6 +79,7 @@ class HipGenericStencilObject(StencilObject):
         args = program.args_struct()
         unit_i = True
         spans: List[Tuple[int, int]] = []
+        geometry: Dict[str, Tuple[int, int, int, int]] = {}  # name -> (origin pointer, sj, sk, itemsize)
         for decl in plan.api_fields:
             arr = arguments[decl.name]
             c = hip_codegen._c_ident(decl.name)
@@ -86,6 +94,7 @@ class HipGenericStencilObject(StencilObject):
                 setattr(args, f"{c}_{suffix}", byte_strides.get(axis, 0) // isz)
             if "I" in decl.axes and byte_strides["I"] != isz:
                 unit_i = False
+            geometry[decl.name] = (ptr, byte_strides.get("J", 0) // isz, byte_strides.get("K", 0) // isz, isz)
             hi = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s > 0) + isz
             lo = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s < 0)
             spans.append((arr.ptr + lo, arr.ptr + hi))
@@ -95,9 +104,10 @@ class HipGenericStencilObject(StencilObject):
             if entry is None:
                 layout, total = {}, 0
                 for name, (dt, ((ilo, ihi), (jlo, jhi))) in plan.scratch.items():
-                    ni = -(-(dI + ihi - ilo) // 32) * 32  # rows padded like the storage preset
+                    oi = -(-(-ilo) // 4) * 4  # the domain's first column on a 16-byte boundary
+                    ni = -(-(dI + ihi + oi) // 32) * 32  # rows padded like the storage preset
                     nj = dJ + jhi - jlo
-                    layout[name] = (total, ni, nj, dt.itemsize, -ilo, -jlo)
+                    layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
                     total += -(-(ni * nj * max(dK, 1) * dt.itemsize) // 256) * 256
                 buf = torch.empty(total, dtype=torch.uint8, device="cuda")
                 cls._gt_scratch_.clear()  # one domain at a time: scratch can be gigabytes
@@ -110,6 +120,7 @@ class HipGenericStencilObject(StencilObject):
                 setattr(args, f"{c}_si", 1)
                 setattr(args, f"{c}_sj", ni)
                 setattr(args, f"{c}_sk", ni * nj)
+                geometry[name] = (base + off + (oi + oj * ni) * isz, ni, ni * nj, isz)
         for p in plan.params:
             setattr(args, f"p_{hip_codegen._c_ident(p.name)}", np.dtype(p.dtype).type(arguments[p.name]).item())
         args.dI, args.dJ, args.dK = dI, dJ, dK
@@ -121,13 +132,18 @@ class HipGenericStencilObject(StencilObject):
 
         info = _lib.ExecInfo() if exec_info is not None else None
         t0 = t1 = None
-        for kern, fn in zip(program.kernels, variant.functions):
+        for kern, fn, vfn in zip(program.kernels, variant.functions, variant.vec_functions):
             (ilo, ihi), (jlo, jhi) = kern.extent
             ni, nj = dI + ihi - ilo, dJ + jhi - jlo
             if ni <= 0 or nj <= 0 or dK <= 0:
                 continue
             nk = -(-dK // kern.k_per_thread) if kern.mapping == "ijk" else 1
-            grid = _U3(-(-ni // kern.block[0]), -(-nj // (kern.block[1] * kern.j_per_thread)), nk)
+            lanes = rows = 1
+            if vfn is not None and all(
+                    geometry[n][0] % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0
+                    and geometry[n][2] % kern.vec == 0 for n in kern.vec_fields):
+                fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned
+            grid = _U3(-(-ni // (kern.block[0] * lanes)), -(-nj // (kern.block[1] * kern.j_per_thread * rows)), nk)
             rc = lib.gt4mi_launch(fn, grid, _U3(*kern.block), ctypes.byref(args), ctypes.sizeof(args), stream,
                                   ctypes.byref(info) if info is not None else None)
             _lib.check("gt4mi_launch", rc)

@@ -118,6 +118,20 @@ def test_generated_source_compiles_for_gfx950(programs, name):
     assert len(prog.args_struct._fields_) == 4 * n_arrays + len(prog.plan.params) + 3
 
 
+def test_horizontal_stages_get_a_16_byte_lane_twin(programs):
+    """Thread-per-point stages that only read arrays they do not write also exist as `<name>_vec`: a lane
+    owns 2 fp64 (4 fp32) consecutive I points and several J rows; neighbours come from DPP lane shifts."""
+    lap = programs["laplacian"]
+    assert [(k.vec, k.vec_rows, k.vec_fields) for k in lap.kernels] == [(2, 4, ("out", "inp"))]
+    assert "gt4mi_laplacian_stage0_vec" in lap.source and "gt_shift<double, true>" in lap.source
+    assert [k.vec for k in programs["horizontal_diffusion_f32"].kernels] == [4]
+    assert [k.vec for k in programs["mixed_precision"].kernels] == [2]  # widest element decides
+    # not vectorised: sequential stages, stages that read what they write, arrays without an I axis as target
+    assert [k.vec for k in programs["tridiagonal_solver"].kernels] == [0]
+    assert [k.vec for k in programs["two_stage_written_input"].kernels] == [0, 2]
+    assert [k.vec for k in programs["column_sum_then_gradient"].kernels] == [0, 2]
+
+
 def test_compiler_errors_surface_with_the_log():
     with pytest.raises(_lib.NativeError, match="expected ';'"):
         _lib.rtc_compile('extern "C" __global__ void k(double* a) { a[0] = 1.0 }')

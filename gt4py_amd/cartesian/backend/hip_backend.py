@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import inspect
+import weakref
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Tuple, Type
 
@@ -168,6 +169,7 @@ class HipStencilObject(StencilObject):
 
     _gt_binding_: KernelBinding
     _gt_device_sync_: bool
+    _gt_launch_cache_: Dict[Any, Any]
 
     def _run_implementation(self, domain, origin, exec_info, arguments: Dict[str, Any]) -> None:
         cls = type(self)
@@ -180,12 +182,28 @@ class HipStencilObject(StencilObject):
         except Exception as ex:  # pragma: no cover - no GPU
             raise RuntimeError("hip:mi300 needs PyTorch-ROCm with a visible MI355X") from ex
 
-        def fld(role: str):
-            name = binding.roles[role]
-            arr = arguments[name]
-            return ctypes.byref(_lib.Field.make(arr.ptr, arr.shape, arr.strides, origin[name]))
-
-        dom = _lib.domain3(domain)
+        # ctypes structs of a call are cached per (arrays, origins, domain): building them costs more Python
+        # time than the launch.  Arrays are remembered by identity through weak references.
+        names = [binding.roles[r] for r in binding.roles if binding.roles[r] in cls._gt_field_info_]
+        ckey = (tuple(int(d) for d in domain), tuple(id(arguments[n]) for n in names), tuple(tuple(origin[n]) for n in names))
+        entry = cls._gt_launch_cache_.get(ckey)
+        if entry is not None and all(r() is arguments[n] for n, r in entry[0]):
+            _, dom, refs = entry
+        else:
+            refs = {}
+            for role, name in binding.roles.items():
+                if name in cls._gt_field_info_:
+                    arr = arguments[name]
+                    refs[role] = ctypes.byref(_lib.Field.make(arr.ptr, arr.shape, arr.strides, origin[name]))
+            dom = _lib.domain3(domain)
+            try:
+                weak = [(n, weakref.ref(arguments[n])) for n in names]
+                if len(cls._gt_launch_cache_) >= 8:
+                    cls._gt_launch_cache_.pop(next(iter(cls._gt_launch_cache_)))
+                cls._gt_launch_cache_[ckey] = (weak, dom, refs)
+            except TypeError:  # no weak-reference support: do not cache
+                pass
+        fld = refs.__getitem__
         info = _lib.ExecInfo() if exec_info is not None else None
         info_ref = ctypes.byref(info) if info is not None else None
         suffix = "f64" if binding.dtype == np.dtype("float64") else "f32"
@@ -262,6 +280,7 @@ class HipMI300Backend(base.BaseBackend):
         }
         if binding is not None:
             attrs["_gt_binding_"] = binding
+            attrs["_gt_launch_cache_"] = {}
             return type(builder.class_name, (HipStencilObject,), attrs)
-        attrs.update({"_gt_program_": program, "_gt_variants_": {}, "_gt_scratch_": {}})
+        attrs.update({"_gt_program_": program, "_gt_variants_": {}, "_gt_scratch_": {}, "_gt_launch_cache_": {}})
         return type(builder.class_name, (hip_generic.HipGenericStencilObject,), attrs)

@@ -10,6 +10,7 @@ the stencil object and cached per domain, where GridTools allocates them inside 
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Any, Dict, List, Tuple
 
 import numpy as np
@@ -63,6 +64,7 @@ class HipGenericStencilObject(StencilObject):
     _gt_device_sync_: bool
     _gt_variants_: Dict[Tuple[bool, bool], _Variant]
     _gt_scratch_: Dict[Tuple[int, int, int], Any]
+    _gt_launch_cache_: Dict[Any, Any]
 
     def _run_implementation(self, domain, origin, exec_info, arguments: Dict[str, Any]) -> None:
         cls = type(self)
@@ -76,6 +78,52 @@ class HipGenericStencilObject(StencilObject):
         except Exception as ex:  # pragma: no cover - no GPU
             raise RuntimeError("hip:mi300 needs PyTorch-ROCm with a visible MI355X") from ex
         dI, dJ, dK = (int(d) for d in domain)
+        # Launch plans are cached per (arrays, origins, domain, scalars): filling the argument block costs
+        # 20-50 us of Python, a cached call ~10 us.  Arrays are remembered by identity through weak
+        # references, so a recycled id() can never alias a dead array.
+        try:
+            ckey = (dI, dJ, dK, tuple(id(arguments[d.name]) for d in plan.api_fields),
+                    tuple(tuple(origin[d.name]) for d in plan.api_fields), tuple(arguments[p.name] for p in plan.params))
+            entry = cls._gt_launch_cache_.get(ckey)
+        except TypeError:  # an unhashable scalar
+            ckey = entry = None
+        if entry is not None and all(r() is arguments[n] for n, r in entry[0]):
+            _, args, launches, _keep = entry
+        else:
+            args, launches, keep = self._prepare(arguments, origin, (dI, dJ, dK))
+            if ckey is not None:
+                try:
+                    refs = [(d.name, weakref.ref(arguments[d.name])) for d in plan.api_fields]
+                    if len(cls._gt_launch_cache_) >= 8:
+                        cls._gt_launch_cache_.pop(next(iter(cls._gt_launch_cache_)))
+                    cls._gt_launch_cache_[ckey] = (refs, args, launches, keep)
+                except TypeError:  # an array type without weak-reference support: do not cache
+                    pass
+        info = _lib.ExecInfo() if exec_info is not None else None
+        info_ref = ctypes.byref(info) if info is not None else None
+        t0 = t1 = None
+        args_ref, args_size = ctypes.byref(args), ctypes.sizeof(args)
+        for fn, grid, block in launches:
+            rc = lib.gt4mi_launch(fn, grid, block, args_ref, args_size, stream, info_ref)
+            if rc:
+                _lib.check("gt4mi_launch", rc)
+            if info is not None:
+                t0 = info.run_cpp_start_time if t0 is None else t0
+                t1 = info.run_cpp_end_time
+        if cls._gt_device_sync_:
+            _lib.check("gt4mi_stream_sync", lib.gt4mi_stream_sync(stream))
+        if exec_info is not None and t0 is not None:
+            exec_info["run_cpp_start_time"] = t0
+            exec_info["run_cpp_end_time"] = t1
+
+    def _prepare(self, arguments: Dict[str, Any], origin, domain):
+        """Argument block + launch list [(function, grid, block)] for one (arrays, origins, domain, scalars)."""
+        cls = type(self)
+        program = cls._gt_program_
+        plan = program.plan
+        import torch
+
+        dI, dJ, dK = domain
         args = program.args_struct()
         unit_i = True
         spans: List[Tuple[int, int]] = []
@@ -110,7 +158,8 @@ class HipGenericStencilObject(StencilObject):
                     layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
                     total += -(-(ni * nj * max(dK, 1) * dt.itemsize) // 256) * 256
                 buf = torch.empty(total, dtype=torch.uint8, device="cuda")
-                cls._gt_scratch_.clear()  # one domain at a time: scratch can be gigabytes
+                cls._gt_scratch_.clear()  # one domain at a time: scratch can be gigabytes ...
+                cls._gt_launch_cache_.clear()  # ... and cached launch plans keep theirs alive
                 entry = cls._gt_scratch_[key] = (buf, layout)
             buf, layout = entry
             base = buf.data_ptr()
@@ -130,8 +179,7 @@ class HipGenericStencilObject(StencilObject):
         if variant is None:
             variant = cls._gt_variants_[vkey] = _Variant(program, *vkey)
 
-        info = _lib.ExecInfo() if exec_info is not None else None
-        t0 = t1 = None
+        launches = []
         for kern, fn, vfn in zip(program.kernels, variant.functions, variant.vec_functions):
             (ilo, ihi), (jlo, jhi) = kern.extent
             ni, nj = dI + ihi - ilo, dJ + jhi - jlo
@@ -144,14 +192,6 @@ class HipGenericStencilObject(StencilObject):
                     and geometry[n][2] % kern.vec == 0 for n in kern.vec_fields):
                 fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned
             grid = _U3(-(-ni // (kern.block[0] * lanes)), -(-nj // (kern.block[1] * kern.j_per_thread * rows)), nk)
-            rc = lib.gt4mi_launch(fn, grid, _U3(*kern.block), ctypes.byref(args), ctypes.sizeof(args), stream,
-                                  ctypes.byref(info) if info is not None else None)
-            _lib.check("gt4mi_launch", rc)
-            if info is not None:
-                t0 = info.run_cpp_start_time if t0 is None else t0
-                t1 = info.run_cpp_end_time
-        if cls._gt_device_sync_:
-            _lib.check("gt4mi_stream_sync", lib.gt4mi_stream_sync(stream))
-        if exec_info is not None and t0 is not None:
-            exec_info["run_cpp_start_time"] = t0
-            exec_info["run_cpp_end_time"] = t1
+            launches.append((fn, grid, _U3(*kern.block)))
+        # the scratch buffer must outlive every cached plan that points into it
+        return args, launches, cls._gt_scratch_.get((dI, dJ, dK))

@@ -58,7 +58,7 @@ class DeviceArray:
     ``strides`` are in BYTES (numpy convention), ``dtype`` is a ``numpy.dtype``.
     """
 
-    __slots__ = ("_t", "_owner")
+    __slots__ = ("_t", "_owner", "__weakref__")
     __array_priority__ = 100
 
     def __init__(self, tensor, owner: Any = None):

@@ -255,6 +255,23 @@ def main() -> None:
         total = (GRID[0], GRID[1] // max(args.selfloop_ranks, 1), GRID[2]) if selfloop else GRID
         transport = os.environ.get("GT4MI_BENCH_COMM", "native")
         mode = os.environ.get("GT4MI_BENCH_MODE", "timestep")
+        comm = None
+        if transport == "native":
+            # RCCL communicator owned by libgt4py_amd.  Creating it is collective; should it fail on any
+            # rank, every rank falls back to the torch.distributed transport together.
+            ok = 1
+            try:
+                comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
+            except Exception as ex:
+                ok = 0
+                print(f"rank {rank}: native RCCL communicator failed ({ex!r})", file=sys.stderr)
+            if distributed:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                transport, comm = "torch", None
+                print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
         # ghost depth = steps served by one exchange (communication-avoiding time stepping); the
         # independent-apply and torch-transport modes exchange every step with depth 1
         # Depth 2 by default: in the 1-GPU rehearsal depth 4 is fastest (65.8 vs 72.5 vs 83.8 us per
@@ -269,7 +286,6 @@ def main() -> None:
         frozen = lap.freeze(origin=origin, domain=local_domain)
         if transport == "native":
             # whole step (pack, RCCL send/recv, unpack, interior, strips, 2 streams) = one C call
-            comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
             exchangers = [NativeHaloExchanger(dec, np.float64, comm) for _ in pairs]
             if mode == "timestep":
                 # time stepping u <- lap(u) between two buffers.  Ghost regions are `halo` deep and one

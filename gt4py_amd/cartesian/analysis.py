@@ -83,6 +83,19 @@ def compute_extents(stencil: ir.Stencil) -> ExtentInfo:
     return ExtentInfo(fields, blocks)
 
 
+def storage_extents(stencil: ir.Stencil, extents: ExtentInfo) -> Dict[str, Extent2]:
+    """Extent a temporary's storage must cover: everything read of it AND every block it is written on.
+
+    The two differ when a temporary is only ever read at non-zero offsets (read extent ((-1, -1), ...),
+    written on ((-1, 0), ...)): sizing the array by the read extent alone, as the reference's numpy
+    backend does (gtc/numpy/oir_to_npir.py:42-56), leaves the write one element short."""
+    out: Dict[str, Extent2] = {t.name: extents.fields.get(t.name, ZERO_EXTENT) for t in stencil.temporaries}
+    for (_, _, stmt), block in zip(stencil.statements(), extents.blocks):
+        if stmt.target.name in out:
+            out[stmt.target.name] = _union(out[stmt.target.name], block)
+    return out
+
+
 def compute_access_kinds(stencil: ir.Stencil) -> Dict[str, AccessKind]:
     access: Dict[str, AccessKind] = {}
 

@@ -345,10 +345,12 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     local_names = {n for n in temp_names if n in where and n not in bad_local}
     # a local that is written in one nest and never read anywhere is dead but harmless
     scratch: Dict[str, Tuple[np.dtype, Extent2]] = {}
+    temp_extents = analysis.storage_extents(stencil, extents)
     for t in stencil.temporaries:
         if t.name in where and t.name not in local_names:
-            scratch[t.name] = (np.dtype(t.dtype), extents.fields.get(t.name, analysis.ZERO_EXTENT))
-    assert ssa_locals <= local_names | (temp_names - set(where)), "SSA values must stay thread-local"
+            scratch[t.name] = (np.dtype(t.dtype), temp_extents[t.name])
+    # (SSA values from the inliner are usually thread-local; one that is still needed after a stage cut --
+    # e.g. by a run-time `if` further down -- is simply kept in scratch like any other temporary)
 
     # register forwarding in column stages: a value read exactly one level behind the sweep stays in a
     # register instead of being re-read from memory.  Exact only when (a) every vertical-offset read
@@ -440,7 +442,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                         used.add(e.name)
     api_fields = [f for f in stencil.fields if f.name in used]
     params = [p for p in stencil.params if p.name in used]
-    return Plan(stencil, stages, dict(extents.fields), local_names, scratch, forwarded, prime, register_only,
+    return Plan(stencil, stages, {**extents.fields, **temp_extents}, local_names, scratch, forwarded, prime, register_only,
                 api_fields, params)
 
 

@@ -113,8 +113,9 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
     for decl in stencil.fields:
         if arrays.get(decl.name) is not None:
             env[decl.name] = _FieldShim(arrays[decl.name], tuple(origin[decl.name])[: len(decl.axes)], decl.axes)
+    temp_extents = analysis.storage_extents(stencil, extents)
     for decl in stencil.temporaries:
-        (ilo, ihi), (jlo, jhi) = extents.fields.get(decl.name, analysis.ZERO_EXTENT)
+        (ilo, ihi), (jlo, jhi) = temp_extents[decl.name]
         shape = (dI + (ihi - ilo), dJ + (jhi - jlo), dK)
         env[decl.name] = _FieldShim(np.empty(shape, dtype=decl.dtype), (-ilo, -jlo, 0), ("I", "J", "K"))
     for p in stencil.params:

@@ -908,13 +908,18 @@ def _vector_width(em: "_Emitter", stage: Stage) -> int:
     """How many consecutive I points a lane may own in this stage (0 = keep one point per thread).
 
     Needs: thread-per-point mapping, the stage starting at the domain's first column, reads only of arrays
-    the stage does not write (so rows can be loaded once, up front), I offsets within one lane's reach,
-    4- or 8-byte elements."""
+    the stage does not write (so rows can be loaded once, up front), every statement on the full stage
+    extent and outside horizontal regions, I offsets within one lane's reach, 4- or 8-byte elements."""
     if stage.mapping != "ijk" or stage.extent[0][0] != 0 or not TUNING["vector"]:
         return 0
     sizes = set()
     for nest in stage.nests:
         for s in nest.stmts:
+            # the strip form loads every row a nest reads before any statement runs, unconditionally: that is
+            # only inside the arrays when each statement covers the whole stage extent and none is restricted
+            # to a horizontal region (whose reads need less halo than an unrestricted statement's would)
+            if s.extent != stage.extent or s.region is not None:
+                return 0
             if s.target.offset != (0, 0, 0):
                 return 0
             if s.target.name not in em.plan.locals:

@@ -54,7 +54,7 @@ def canonical_form(stencil: ir.Stencil) -> Tuple[Tuple, Dict[str, str]]:
         if isinstance(e, ir.Literal):
             return ("lit", repr(e.value), str(e.dtype))
         if isinstance(e, ir.FieldAccess):
-            return ("field", canon(e.name), e.offset, str(e.dtype))
+            return ("field", canon(e.name), e.offset, str(e.dtype), expr(e.koffset) if e.koffset is not None else None)
         if isinstance(e, ir.ScalarAccess):
             return ("scalar", canon(e.name), str(e.dtype))
         if isinstance(e, ir.UnaryOp):

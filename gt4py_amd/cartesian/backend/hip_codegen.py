@@ -79,7 +79,7 @@ class UnsupportedStencil(NotImplementedError):
 # 1. inlining of horizontally offset temporaries
 # ---------------------------------------------------------------------------------------------------
 def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
-    return ir.FieldAccess(e.name, (e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]), e.dtype)
+    return ir.FieldAccess(e.name, (e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]), e.dtype, e.koffset)
 
 
 def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[str]]:
@@ -101,7 +101,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                 for e in ir.stmt_reads(stmt):
                     if isinstance(e, ir.FieldAccess):
                         touched.setdefault(e.name, set()).add((ci, bi))
-                        if e.offset[2] != 0:
+                        if e.offset[2] != 0 or e.koffset is not None:
                             k_offset_read.add(e.name)
                         if e.offset[0] != 0 or e.offset[1] != 0:
                             ij_offset_read.add(e.name)
@@ -149,7 +149,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                     if isinstance(e, ir.FieldAccess) and e.name in inline:
                         if e.name not in version:  # the frontend rejects this already
                             raise UnsupportedStencil(f"temporary '{e.name}' is read before it is assigned")
-                        return ir.FieldAccess(version[e.name], e.offset, e.dtype)
+                        return ir.FieldAccess(version[e.name], e.offset, e.dtype, e.koffset)
                     return e
 
                 return ir.map_expr(expr, fn)
@@ -315,7 +315,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                 column = True
             for s in nest.stmts:
                 for e in _stmt_field_reads(s):
-                    if e.offset[2] != 0 and e.name in stage.written:
+                    if (e.offset[2] != 0 or e.koffset is not None) and e.name in stage.written:
                         column = True
                         if nest.order is ir.LoopOrder.PARALLEL and e.name in nest_writes:
                             nest.split_statements = True
@@ -337,7 +337,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
             for e in _stmt_field_reads(s):
                 if e.name in temp_names:
                     where.setdefault(e.name, set()).add(nid)
-                    if e.offset != (0, 0, 0) or e.name not in defined or nest.split_statements:
+                    if e.offset != (0, 0, 0) or e.koffset is not None or e.name not in defined or nest.split_statements:
                         bad_local.add(e.name)
             if s.target.name in temp_names:
                 where.setdefault(s.target.name, set()).add(nid)
@@ -367,6 +367,8 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                 if s.target.name in stage.written:
                     extents_of.setdefault(s.target.name, set()).add(s.extent)
                 for e in _stmt_field_reads(s):
+                    if e.koffset is not None and e.name in stage.written:
+                        patterns.setdefault(e.name, set()).add((nest.order, ("variable",)))
                     if e.offset[2] != 0 and e.name in stage.written:
                         patterns.setdefault(e.name, set()).add((nest.order, e.offset))
                         extents_of.setdefault(e.name, set()).add(s.extent)
@@ -641,7 +643,7 @@ class _Emitter:
             return f"l_{_c_ident(name)}{self.local_suffix}"
         if self.vec_rows is not None and "I" in self.axes.get(name, ("I", "J", "K")):
             return self.vec_rows[(name, e.offset[1] + self.vec_row, e.offset[2])][self.vec_component + e.offset[0]]
-        if (name, e.offset[2]) in reg and e.offset[:2] == (0, 0):
+        if (name, e.offset[2]) in reg and e.offset[:2] == (0, 0) and e.koffset is None:
             return reg[(name, e.offset[2])]
         if name in self.plan.register_only:
             raise AssertionError(f"register-only temporary '{name}' needs memory at offset {e.offset}")
@@ -650,7 +652,12 @@ class _Emitter:
         axes = self.axes.get(name, ("I", "J", "K"))
         terms = []
         if "K" in axes:
-            terms.append(f"({k}{dk:+d}) * a.{c}_sk" if dk else f"{k} * a.{c}_sk")
+            if e.koffset is not None:
+                saved_rows, self.vec_rows = self.vec_rows, None  # the index itself is read from memory
+                terms.append(f"({k}{dk:+d} + (gt_i64)({self.expr(e.koffset, k, stage_index, reg)})) * a.{c}_sk")
+                self.vec_rows = saved_rows
+            else:
+                terms.append(f"({k}{dk:+d}) * a.{c}_sk" if dk else f"{k} * a.{c}_sk")
         if di and "I" in axes:
             terms.append(f"{di} * GT_SI(a.{c}_si)")
         if dj and "J" in axes:
@@ -927,6 +934,8 @@ def _vector_width(em: "_Emitter", stage: Stage) -> int:
                     return 0
                 sizes.add(em.decl_dtype[s.target.name].itemsize)
             for e in _stmt_field_reads(s):
+                if e.koffset is not None:
+                    return 0
                 if e.name in em.plan.locals:
                     continue
                 if e.name in stage.written:

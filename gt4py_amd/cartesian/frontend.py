@@ -438,7 +438,7 @@ class _Parser(ast.NodeVisitor):
             return ir.Literal(name == "True", np.dtype("bool"))
         raise GTScriptSymbolError(f"Unknown symbol '{name}' in stencil '{self.definition.__name__}'")
 
-    def _parse_offset(self, node: ast.Subscript, name: str) -> Tuple[int, int, int]:
+    def _parse_offset(self, node: ast.Subscript, name: str, variable: Optional[list] = None) -> Tuple[int, int, int]:
         decl = self.fields.get(name) or self.temporaries.get(name)
         axes = decl.axes if decl is not None else ("I", "J", "K")
         index = node.slice
@@ -469,7 +469,16 @@ class _Parser(ast.NodeVisitor):
         elif any(s is not None for s in shifted):
             raise self._err(node, "Cannot mix axis offsets and integer offsets")
         else:
-            values = [self._const(e) for e in elts]
+            values = []
+            for pos, e in enumerate(elts):
+                try:
+                    values.append(self._const(e))
+                except (GTScriptSyntaxError, GTScriptSymbolError):
+                    # a run-time K index: field[0, 0, <int expression>] (VariableKOffset)
+                    if variable is None or len(elts) != len(axes) or axes[pos] != "K":
+                        raise
+                    variable.append(self.visit(e))
+                    values.append(0)
             if len(values) != len(axes):
                 raise self._err(node, f"Incorrect offset specification detected for field '{name}'. "
                                       f"Found {values} but the field has dimensions ({', '.join(axes)})")
@@ -485,7 +494,9 @@ class _Parser(ast.NodeVisitor):
         name = node.value.id
         if name not in self.fields and name not in self.temporaries:
             raise GTScriptSymbolError(f"Unknown field '{name}' in stencil '{self.definition.__name__}'")
-        return ir.FieldAccess(name, self._parse_offset(node, name))
+        variable: list = []
+        offset = self._parse_offset(node, name, variable)
+        return ir.FieldAccess(name, offset, None, variable[0] if variable else None)
 
     def visit_UnaryOp(self, node: ast.UnaryOp) -> ir.Expr:
         op = {ast.USub: "-", ast.UAdd: "+", ast.Not: "not"}.get(type(node.op))
@@ -545,7 +556,11 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
                 dt = dtypes.get(e.name)
                 if dt is None:
                     raise GTScriptSymbolError(f"Temporary '{e.name}' is read before it is assigned")
-                return ir.FieldAccess(e.name, e.offset, dt)
+                koff = e.koffset
+                if koff is not None:  # already typed (map_expr is bottom-up); must be an integer
+                    if np.dtype(koff.dtype).kind not in "iu":
+                        raise GTScriptSyntaxError(f"Variable K offset of '{e.name}' must be an integer expression")
+                return ir.FieldAccess(e.name, e.offset, dt, koff)
             if isinstance(e, (ir.Literal, ir.ScalarAccess, ir.Cast)):
                 return e
             if isinstance(e, ir.UnaryOp):

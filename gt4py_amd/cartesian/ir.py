@@ -67,9 +67,14 @@ class Literal(Expr):
 
 @dataclass(frozen=True)
 class FieldAccess(Expr):
+    """``name[i, j, k]``.  ``koffset`` is a run-time integer expression ADDED to the K index
+    (``field[0, 0, index]``, the reference's VariableKOffset: gtc/common.py; numpy: ``lk + k``,
+    gtc/numpy/npir_codegen.py:110, 271-278); ``offset[2]`` is 0 then."""
+
     name: str
     offset: Tuple[int, int, int]
     dtype: Optional[np.dtype] = None
+    koffset: Optional[Expr] = None
 
 
 @dataclass(frozen=True)
@@ -254,6 +259,8 @@ class Stencil:
 def walk(expr: Expr):
     """Pre-order traversal of an expression tree."""
     yield expr
+    if isinstance(expr, FieldAccess) and expr.koffset is not None:
+        yield from walk(expr.koffset)
     if isinstance(expr, (UnaryOp, Cast)):
         yield from walk(expr.expr)
     elif isinstance(expr, BinaryOp):
@@ -270,7 +277,9 @@ def walk(expr: Expr):
 
 def map_expr(expr: Expr, fn):
     """Rebuild ``expr`` bottom-up, applying ``fn`` to every rebuilt node."""
-    if isinstance(expr, (UnaryOp, Cast)):
+    if isinstance(expr, FieldAccess) and expr.koffset is not None:
+        expr = replace(expr, koffset=map_expr(expr.koffset, fn))
+    elif isinstance(expr, (UnaryOp, Cast)):
         expr = replace(expr, expr=map_expr(expr.expr, fn))
     elif isinstance(expr, BinaryOp):
         expr = replace(expr, left=map_expr(expr.left, fn), right=map_expr(expr.right, fn))
@@ -287,7 +296,8 @@ def fmt(expr: Expr) -> str:
     if isinstance(expr, Literal):
         return f"{expr.dtype}({expr.value!r})" if expr.dtype is not None else repr(expr.value)
     if isinstance(expr, FieldAccess):
-        return f"{expr.name}[{expr.offset[0]},{expr.offset[1]},{expr.offset[2]}]"
+        k = f"{expr.offset[2]}" if expr.koffset is None else fmt(expr.koffset)
+        return f"{expr.name}[{expr.offset[0]},{expr.offset[1]},{k}]"
     if isinstance(expr, ScalarAccess):
         return expr.name
     if isinstance(expr, UnaryOp):

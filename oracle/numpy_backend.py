@@ -79,11 +79,37 @@ class _FieldShim:
         return self.array[tuple(idx)]
 
 
+def _gather(self, lo, hi, offset, krange, kshift):
+    """Values at (i, j, k + kshift[i, j, k]) over the window: numpy advanced indexing with index arrays."""
+    ni, nj, nk = hi[0] - lo[0], hi[1] - lo[1], krange[1] - krange[0]
+    kshift = np.broadcast_to(np.asarray(kshift), (ni, nj, nk)).astype(np.int64)
+    idx = []
+    for ax, n in ((0, ni), (1, nj)):
+        if self.mask[ax]:
+            base = self.origin[ax] + lo[ax] + offset[ax]
+            shape = [1, 1, 1]
+            shape[ax] = n
+            idx.append((base + np.arange(n)).reshape(shape))
+        else:
+            idx.append(np.zeros((1, 1, 1), dtype=np.int64))
+    if self.mask[2]:
+        kk = self.origin[2] + krange[0] + offset[2] + np.arange(nk).reshape(1, 1, nk) + kshift
+        assert kk.min() >= 0 and kk.max() < self.array.shape[2], "numpy oracle: variable K access outside of the array"
+    else:
+        kk = np.zeros((1, 1, 1), dtype=np.int64)
+    return self.array[idx[0], idx[1], kk]
+
+
+_FieldShim.gather = _gather
+
+
 def _evaluate(expr: ir.Expr, env, lo, hi, krange):
     def ev(e):
         if isinstance(e, ir.Literal):
             return np.dtype(e.dtype).type(e.value)
         if isinstance(e, ir.FieldAccess):
+            if e.koffset is not None:  # `lk + k` index arrays (npir_codegen.py:110, 271-278)
+                return env[e.name].gather(lo, hi, e.offset, krange, ev(e.koffset))
             return env[e.name].window(lo, hi, e.offset, krange)
         if isinstance(e, ir.ScalarAccess):
             return env[e.name]

@@ -32,6 +32,7 @@ class Suite:
     externals: Sequence[Dict[str, Any]] = ({},)
     domains: Sequence[Tuple[int, int, int]] = ((1, 1, 1), (3, 4, 5), (15, 14, 13))
     optional: Dict[str, str] = field(default_factory=dict)  # field -> external that switches it on
+    axes: Dict[str, str] = field(default_factory=dict)  # field -> "K", "IJ", ... (default "IJK")
 
 
 def _inner(a, b):
@@ -383,6 +384,33 @@ def _corners_expected(a, p, ext, domain):
     return {"field_out": out}
 
 
+# ---- :765-808 (run-time K index) -------------------------------------------------------------------
+def variable_k_read(field_in: F32, field_out: F32, index: "Field[K, np.int32]"):
+    with computation(PARALLEL), interval(1, None):
+        field_out = field_in[0, 0, index]
+
+
+def _variable_k_expected(a, p, ext, domain):
+    x, index = a["field_in"], a["index"]
+    out = a["field_out"].copy()
+    out[:, :, 1:] = x[:, :, (np.arange(x.shape[-1]) + index)[1:]]
+    return {"field_out": out}
+
+
+def variable_k_and_read_outside(field_in: F64, field_out: F64, index: "Field[K, np.int32]"):
+    with computation(PARALLEL), interval(1, None):
+        field_out[0, 0, 0] = field_in[0, 0, index] + field_in[0, 0, -2]
+
+
+def _variable_k_outside_expected(a, p, ext, domain):
+    x, index = a["field_in"], a["index"]  # field_in carries one extra level below the domain
+    out = a["field_out"].copy()
+    idx = 1 + (np.arange(domain[-1]) + index)[1:]
+    out[:, :, 1:] = x[:, :, idx]
+    out[:, :, 1:] += x[:, :, :-2]
+    return {"field_out": out}
+
+
 R10 = (-10.0, 10.0)
 R1 = (-1.0, 1.0)
 SUITES: Dict[str, Suite] = {
@@ -451,6 +479,14 @@ SUITES: Dict[str, Suite] = {
     "diagonal_k_offset": Suite(diagonal_k_offset,
                                {"field_in": (np.float64, ((0, 0), (1, 0), (0, 1)), (0.1, 10.0)), "field_out": (np.float64, Z, (0.1, 10.0))},
                                _diagonal_expected, domains=((2, 2, 2), (2, 2, 8), (5, 6, 7))),
+    "variable_k_read": Suite(variable_k_read,
+                             {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10), "index": (np.int32, Z, (-1, 0))},
+                             _variable_k_expected, domains=((2, 2, 2), (2, 2, 8), (5, 4, 9)), axes={"index": "K"}),
+    "variable_k_and_read_outside": Suite(variable_k_and_read_outside,
+                                         {"field_in": (np.float64, ((0, 0), (0, 0), (1, 0)), (0.1, 10.0)),
+                                          "field_out": (np.float64, Z, (0.1, 10.0)), "index": (np.int32, Z, (-1, 0))},
+                                         _variable_k_outside_expected, domains=((2, 2, 2), (2, 2, 8), (5, 4, 9)),
+                                         axes={"index": "K"}),
     "horizontal_regions": Suite(horizontal_regions, {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
                                 _regions_expected, domains=((4, 4, 2), (9, 7, 3))),
     "horizontal_regions_partial_writes": Suite(horizontal_regions_partial_writes,
@@ -477,9 +513,13 @@ def make_case(name: str, ext: Dict[str, Any], domain, seed: int = 1337):
     rng = np.random.default_rng(seed)
     arrays, origins = {}, {}
     for fname, (dt, boundary, (lo, hi)) in suite.fields.items():
-        shape = tuple(d + b[0] + b[1] for d, b in zip(domain, boundary))
-        arrays[fname] = rng.uniform(lo, hi, shape).astype(dt)
-        origins[fname] = tuple(b[0] for b in boundary)
+        present = [ax for ax, name in enumerate("IJK") if name in suite.axes.get(fname, "IJK")]
+        shape = tuple(domain[ax] + boundary[ax][0] + boundary[ax][1] for ax in present)
+        if np.dtype(dt).kind in "iu":
+            arrays[fname] = rng.integers(int(lo), int(hi) + 1, shape).astype(dt)
+        else:
+            arrays[fname] = rng.uniform(lo, hi, shape).astype(dt)
+        origins[fname] = tuple(boundary[ax][0] for ax in present)
     params = {p: float(rng.uniform(lo, hi)) for p, (lo, hi) in suite.params.items()}
     expected = suite.expected({k: v.copy() for k, v in arrays.items()}, params, ext, domain)
     return arrays, origins, params, expected

@@ -252,6 +252,21 @@ def if_with_offsets(a: F64, out: F64):
             out = a[0, 1, 0] if lap > 0.0 else a[0, -1, 0]
 
 
+def variable_k_offsets(a: F64, idx: "Field[np.int32]", out: F64):
+    """run-time K index from a 3-d integer field, also read at a horizontal offset (VariableKOffset)"""
+    with computation(PARALLEL), interval(1, -1):
+        t = a[1, 0, idx[1, 0, 0]] - a[0, 0, idx]
+        out = t[-1, 0, 0] + a[0, 0, idx + 0]
+
+
+def variable_k_of_written_field(a: F64, idx: "Field[np.int32]", out: F64):
+    """a field written in the stencil read back at a run-time K index: column stage, statement by statement"""
+    with computation(PARALLEL), interval(...):
+        out = a * 2.0
+    with computation(PARALLEL), interval(1, -1):
+        a = out[0, 0, idx] + 1.0
+
+
 ZOO = {
     # name: (definition, externals, scalars, backend options)
     "copy_stencil": (copy_stencil, {}, {}, {}),
@@ -270,6 +285,8 @@ ZOO = {
     "parallel_k_dependency": (parallel_k_dependency, {}, {}, {}),
     "lower_dimensional": (lower_dimensional, {}, {}, {}),
     "two_stage_written_input": (two_stage_written_input, {}, {}, {}),
+    "variable_k_offsets": (variable_k_offsets, {}, {}, {}),
+    "variable_k_of_written_field": (variable_k_of_written_field, {}, {}, {}),
     "runtime_if": (runtime_if, {}, {}, {}),
     "nested_if": (nested_if, {}, {"thresh": 0.75}, {}),
     "if_with_offsets": (if_with_offsets, {}, {}, {}),
@@ -296,7 +313,7 @@ def make_inputs(stencil_object, domain, seed=1337):
             if name == "diag":
                 data = (data + 4.5).astype(dt)
         elif dt.kind in "iu":
-            data = rng.integers(-50, 50, shape).astype(dt)
+            data = rng.integers(-1, 2, shape).astype(dt) if name == "idx" else rng.integers(-50, 50, shape).astype(dt)
         else:
             data = rng.integers(0, 2, shape).astype(dt)
         arrays[name] = data

@@ -22,3 +22,34 @@ for name in ("laplacian","vertical_advection_dycore","horizontal_diffusion"):
         for _ in range(n): obj(**dev, **scal, origin=origins, domain=domain)
         t1=time.perf_counter(); torch.cuda.synchronize()
         print(f"{name:28s} {'library' if use_lib else 'generated':9s} full   call host cost {(t1-t)/n*1e6:6.1f} us")
+
+# launch-bound loop: 20 dependent small applies, eager vs one hipGraph replay
+defn, ext, scal, opts = zoo.ZOO["laplacian"]
+obj = gtscript.stencil(backend="hip:mi300", definition=defn, device_sync=False)
+domain = (128, 128, 64)
+shape = (130, 130, 64)
+a = gt_storage.ones(shape, backend="hip:mi300", aligned_index=(1, 1, 0))
+b = gt_storage.ones(shape, backend="hip:mi300", aligned_index=(1, 1, 0))
+fr = obj.freeze(origin={"inp": (1, 1, 0), "out": (1, 1, 0)}, domain=domain)
+
+
+def loop():
+    for _ in range(10):
+        fr(inp=a, out=b)
+        fr(inp=b, out=a)
+
+
+loop(); torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(50): loop()
+torch.cuda.synchronize()
+eager = (time.perf_counter() - t) / 50
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    loop()
+g.replay(); torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(50): g.replay()
+torch.cuda.synchronize()
+graph = (time.perf_counter() - t) / 50
+print(f"20 dependent 128x128x64 Laplacian applies: eager {eager*1e6:7.1f} us, hipGraph replay {graph*1e6:7.1f} us")

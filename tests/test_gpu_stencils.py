@@ -305,3 +305,51 @@ def test_large_domain_properties_hdiff_and_tridiagonal():
     for n, (i, j) in enumerate(cols):
         for name in ("sup", "rhs", "out"):
             assert np.array_equal(f[name][i, j, :].get(), host[name][n, 0]), (name, i, j)
+
+
+def test_stencil_calls_can_be_captured_in_a_hip_graph():
+    """Launch-bound loops belong in hipGraphs: both execution paths launch on the caller's current stream, so
+    `torch.cuda.graph` (hipGraph on ROCm) captures them; replays reproduce the eager result bit for bit."""
+    import torch
+    from oracle import ref_numpy as R
+
+    gt_storage, gtscript = _imports()
+
+    def smooth(a: gtscript.Field[np.float64], b: gtscript.Field[np.float64], *, w: float):
+        with computation(PARALLEL), interval(...):  # noqa: F821
+            t = a[1, 0, 0] + a[-1, 0, 0] + a[0, 1, 0] + a[0, -1, 0]
+            b = a + w * (t - 4.0 * a)  # noqa: F841
+
+    lap = gtscript.stencil(backend=BACKEND, definition=lap_cartesian, device_sync=False)  # kernel library
+    gen = gtscript.stencil(backend=BACKEND, definition=smooth, device_sync=False)  # generated kernel
+    rng = np.random.default_rng(3)
+    host = rng.uniform(-1, 1, (66, 34, 6))
+    a = gt_storage.from_array(host, backend=BACKEND, aligned_index=(1, 1, 0))
+    b = gt_storage.zeros(host.shape, backend=BACKEND, aligned_index=(1, 1, 0))
+    c = gt_storage.zeros(host.shape, backend=BACKEND, aligned_index=(1, 1, 0))
+    dom = (64, 32, 6)
+    lap_f = lap.freeze(origin={"inp": (1, 1, 0), "out": (1, 1, 0)}, domain=dom)
+    gen_f = gen.freeze(origin={"a": (1, 1, 0), "b": (1, 1, 0)}, domain=dom)
+
+    def sequence():
+        lap_f(inp=a, out=b)
+        gen_f(a=b, b=c, w=0.125)
+
+    sequence()  # eager: compiles, fills caches, gives the expected values
+    torch.cuda.synchronize()
+    want_b, want_c = b.get().copy(), c.get().copy()
+    chk = np.zeros_like(host)
+    R.laplacian(host, chk)
+    assert np.array_equal(want_b, chk)
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sequence()
+    for fill in (7.0, -3.0):
+        b.tensor.fill_(fill)
+        c.tensor.fill_(fill)
+        graph.replay()
+        torch.cuda.synchronize()
+        got_b, got_c = b.get(), c.get()
+        assert np.array_equal(got_b[1:-1, 1:-1], want_b[1:-1, 1:-1])
+        assert np.array_equal(got_c[2:-2, 2:-2], want_c[2:-2, 2:-2])

@@ -72,6 +72,27 @@ def _time_launches(fn, steps):
     return start.elapsed_time(stop) / steps
 
 
+def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30) -> float:
+    """Streaming device copy (gt4mi_stream_copy, 16-byte lanes) of 1 GiB, read + write bytes per second:
+    the achievable-HBM yardstick SURVEY.md section 8d asks to report from the same run."""
+    from gt4py_amd import _lib
+
+    lib = _lib.load()
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    src.fill_(1)
+
+    def call(i):
+        _lib.check("gt4mi_stream_copy", lib.gt4mi_stream_copy(src.data_ptr(), dst.data_ptr(), nbytes,
+                                                              torch.cuda.current_stream().cuda_stream))
+
+    for i in range(2):
+        call(i)
+    torch.cuda.synchronize()
+    ms = _time_launches(call, steps)
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
 def other_kernels(steps: int = 10):
     """The other kernels of the north star at their BASELINE.json sizes, through the same call path
     (storage -> stencil -> FrozenStencil), HIP-event timed.  Informational: `value` stays the Laplacian."""
@@ -380,6 +401,8 @@ def main() -> None:
                 "traffic": traffic,
                 "kernel_ms": round(kernel_ms, 5),
                 "algorithmic_bytes_per_launch": BYTES_PER_LUP * local_lups,
+                # what a plain streaming copy reaches on this device in this run (not the bar, the context)
+                "measured_copy_gbs": round(copy_ceiling_gbs(), 1) if not decomposed else None,
             },
             "device": _lib.device_info(),
         }

@@ -380,9 +380,11 @@ int gt4mi_stream_copy(const void* src, void* dst, size_t nbytes, void* stream) {
         return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "stream_copy: pointers and size must be multiples of 16 bytes");
     const size_t nvec = nbytes / 16;
     if (nvec == 0) return GT4MI_OK;
-    constexpr int UNROLL = 4;
-    size_t blocks = (nvec + 256 * UNROLL - 1) / (256 * UNROLL);
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    // best of the variants in `microbench copy` (profiles/r1_microbench_*.log): one 16-byte vector per
+    // thread, no grid-stride loop, non-temporal stores -- 6.23 TB/s on MI355X
+    constexpr int UNROLL = 1;
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     hipLaunchKernelGGL((gt4mi::stream_copy_kernel<UNROLL, true>), dim3((unsigned)blocks), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const gt4mi::u32x4*>(src),
                        static_cast<gt4mi::u32x4*>(dst), nvec);

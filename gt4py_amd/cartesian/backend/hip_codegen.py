@@ -902,7 +902,7 @@ class _Emitter:
             L.append("    }")
         L.append("}")
         L.append("")
-        vec = _vector_width(self, stage) if j_per_thread == 1 and block[0] == 64 else 0
+        vec = _vector_width(self, stage) if j_per_thread == 1 and block[0] % 64 == 0 else 0
         vec_fields: Tuple[str, ...] = ()
         vec_rows = max(1, TUNING["vector_rows"])
         if vec:
@@ -968,8 +968,8 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
     L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}_vec(const gt_args a) {{')
     L.append("    unsigned gt_bx, gt_by, gt_bz;")
     L.append(f"    gt_tile({TUNING['xcd_rows']}u, gt_bx, gt_by, gt_bz);")
-    L.append("    const int lane = threadIdx.x;  // blockDim.x == 64: one wave per row segment")
-    L.append(f"    const gt_i64 i0 = ((gt_i64)gt_bx * {block[0]} + lane) * {vec};")
+    L.append("    const int lane = threadIdx.x & 63;  // waves lie along I: blockDim.x is a multiple of 64")
+    L.append(f"    const gt_i64 i0 = ((gt_i64)gt_bx * {block[0]} + threadIdx.x) * {vec};")
     L.append(f"    const gt_i64 iend = a.dI + ({ihi}), jend = a.dJ + ({jhi});")
     L.append(f"    const gt_i64 j0 = ((gt_i64)gt_by * {block[1]} + threadIdx.y) * {JT} + ({jlo});")
     L.append("    if (i0 >= iend || j0 >= jend) return;")

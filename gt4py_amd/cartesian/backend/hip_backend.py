@@ -77,7 +77,8 @@ def canonical_form(stencil: ir.Stencil) -> Tuple[Tuple, Dict[str, str]]:
             for stmt in block.body:
                 mask = expr(stmt.mask) if stmt.mask is not None else None
                 value = expr(stmt.value)  # right-hand side first, then the target
-                body.append((expr(stmt.target), value, mask, stmt.group, stmt.region))
+                loops = tuple((lid, expr(c)) for lid, c in stmt.loops)
+                body.append((expr(stmt.target), value, mask, stmt.group, stmt.region, loops))
             iv = block.interval
             blocks.append(((iv.start.level.value, iv.start.offset, iv.end.level.value, iv.end.offset), tuple(body)))
         comps.append((comp.order.value, tuple(blocks)))

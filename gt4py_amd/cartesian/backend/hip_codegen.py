@@ -96,7 +96,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
         for bi, block in enumerate(comp.blocks):
             for stmt in block.body:
                 touched.setdefault(stmt.target.name, set()).add((ci, bi))
-                if stmt.mask is not None or stmt.region is not None:
+                if stmt.mask is not None or stmt.region is not None or stmt.loops:
                     masked_write.add(stmt.target.name)
                 for e in ir.stmt_reads(stmt):
                     if isinstance(e, ir.FieldAccess):
@@ -157,6 +157,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
             for stmt in block.body:
                 value = to_versions(stmt.value)
                 mask = to_versions(stmt.mask) if stmt.mask is not None else None
+                loops = tuple((lid, to_versions(c)) for lid, c in stmt.loops)
                 name = stmt.target.name
                 if name in inline:
                     v = f"{name}__v{sum(1 for k in defs if k.rsplit('__v', 1)[0] == name)}"
@@ -164,7 +165,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                     version[name] = v
                     order.append(("def", v))
                 else:
-                    order.append(("stmt", ir.Assign(stmt.target, value, mask, stmt.group, stmt.region)))
+                    order.append(("stmt", ir.Assign(stmt.target, value, mask, stmt.group, stmt.region, loops)))
 
             memo: Dict[Tuple[str, Tuple[int, int]], ir.Expr] = {}
             needed: Set[str] = set()
@@ -186,7 +187,8 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
 
                 return ir.map_expr(expr, fn)
 
-            body_stmts = [(kind, (expand(obj.value, (0, 0)), expand(obj.mask, (0, 0)) if obj.mask is not None else None)
+            body_stmts = [(kind, (expand(obj.value, (0, 0)), expand(obj.mask, (0, 0)) if obj.mask is not None else None,
+                                  tuple((lid, expand(c, (0, 0))) for lid, c in obj.loops))
                            if kind == "stmt" else None, obj) for kind, obj in order]
             local_defs: Dict[str, ir.Expr] = {}
             pending = list(needed)
@@ -205,7 +207,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                         ssa_locals[obj] = np.dtype(temps[obj.rsplit("__v", 1)[0]].dtype)
                         new_body.append(ir.Assign(ir.FieldAccess(obj, (0, 0, 0), ssa_locals[obj]), local_defs[obj]))
                 else:
-                    new_body.append(ir.Assign(obj.target, value[0], value[1], obj.group, obj.region))
+                    new_body.append(ir.Assign(obj.target, value[0], value[1], obj.group, obj.region, value[2]))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     new_temps = tuple(t for t in stencil.temporaries if t.name not in inline) + tuple(
@@ -223,6 +225,7 @@ class Stmt:
     extent: Extent2
     mask: Optional[ir.Expr] = None
     region: Optional[ir.Region] = None
+    loops: Tuple[Tuple[int, ir.Expr], ...] = ()
 
 
 @dataclass
@@ -264,7 +267,11 @@ def _field_reads(expr: ir.Expr):
 def _stmt_field_reads(s) -> List[ir.FieldAccess]:
     """Field reads of a planned statement or an ``ir.Assign``: mask and value."""
     reads = _field_reads(s.value)
-    return (_field_reads(s.mask) + reads) if s.mask is not None else reads
+    if s.mask is not None:
+        reads = _field_reads(s.mask) + reads
+    for _, cond in getattr(s, "loops", ()):
+        reads = _field_reads(cond) + reads
+    return reads
 
 
 def plan_stages(stencil_in: ir.Stencil) -> Plan:
@@ -280,8 +287,16 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     ext_iter = iter(extents.blocks)
     for ci, comp in enumerate(stencil.computations):
         for bi, block in enumerate(comp.blocks):
-            stmts = [Stmt(s.target, s.value, next(ext_iter), s.mask, s.region) for s in block.body]
-            units = [[s] for s in stmts] if comp.order is ir.LoopOrder.PARALLEL else [stmts]
+            stmts = [Stmt(s.target, s.value, next(ext_iter), s.mask, s.region, s.loops) for s in block.body]
+            if comp.order is ir.LoopOrder.PARALLEL:
+                units = []  # one statement each, except that the body of a `while` stays together
+                for st in stmts:
+                    if st.loops and units and units[-1][-1].loops and units[-1][-1].loops[0][0] == st.loops[0][0]:
+                        units[-1].append(st)
+                    else:
+                        units.append([st])
+            else:
+                units = [stmts]
             for unit in units:
                 if not unit:
                     continue
@@ -319,6 +334,9 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                         column = True
                         if nest.order is ir.LoopOrder.PARALLEL and e.name in nest_writes:
                             nest.split_statements = True
+                            if any(x.loops for x in nest.stmts):
+                                raise UnsupportedStencil("a PARALLEL block with a `while` loop and a vertical dependency "
+                                                         "on its own writes")
         stage.mapping = "column" if column else "ijk"
         ext = None
         for nest in stage.nests:
@@ -373,7 +391,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                         patterns.setdefault(e.name, set()).add((nest.order, e.offset))
                         extents_of.setdefault(e.name, set()).add(s.extent)
         unsafe = {s.target.name for nest in stage.nests for s in nest.stmts
-                  if s.mask is not None or s.region is not None or s.target.offset != (0, 0, 0)}  # conditional / displaced writes
+                  if s.mask is not None or s.region is not None or s.loops or s.target.offset != (0, 0, 0)}  # conditional / displaced writes
         for name, pats in patterns.items():
             if name in local_names or name in unsafe or len(extents_of.get(name, ())) != 1:
                 continue
@@ -438,7 +456,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     for _, nest in nest_list:
         for s in nest.stmts:
             used.add(s.target.name)
-            for ex in ([s.value] if s.mask is None else [s.mask, s.value]):
+            for ex in ([c for _, c in s.loops] + ([s.value] if s.mask is None else [s.mask, s.value])):
                 for e in ir.walk(ex):
                     if isinstance(e, (ir.FieldAccess, ir.ScalarAccess)):
                         used.add(e.name)
@@ -763,6 +781,34 @@ class _Emitter:
         if g:
             self.lines.append(f"{indent}}}")
 
+    def statements(self, stmts: Sequence[Stmt], stage: Stage, si: int, k: str, reg: Dict, indent: str,
+                   carry: Sequence[str] = ()) -> None:
+        """Emit a statement list, opening and closing the `while` loops they sit in.  Per point a loop is
+        `while (cond) { body }`: cond already carries the enclosing masks (ir.Assign.loops), and it is only
+        evaluated where the loop's statements may run at all (their extent / region guard)."""
+        open_loops: List[int] = []
+        for s in stmts:
+            ids = [lid for lid, _ in s.loops]
+            common = 0
+            while common < len(open_loops) and common < len(ids) and open_loops[common] == ids[common]:
+                common += 1
+            while len(open_loops) > common:
+                open_loops.pop()
+                self.lines.append(f"{indent}{'    ' * len(open_loops)}}}")
+            for lid, cond in s.loops[common:]:
+                pad = indent + "    " * len(open_loops)
+                g = self.guard(s, stage)
+                if s.region is not None:
+                    only_region = Stmt(s.target, s.value, s.extent, None, s.region)
+                    g = self.full_guard(only_region, stage, si, k, reg)
+                c = self.expr(cond, k, si, reg)
+                self.lines.append(f"{pad}while ({'(' + g + ') && ' if g else ''}({c})) {{")
+                open_loops.append(lid)
+            self.statement(s, stage, si, k, reg, indent + "    " * len(open_loops), carry)
+        while open_loops:
+            open_loops.pop()
+            self.lines.append(f"{indent}{'    ' * len(open_loops)}}}")
+
     def column_in_extent(self, name: str, stage: Stage) -> Optional[str]:
         """Condition for the thread's column to lie inside the extent ``name`` is accessed on."""
         (ilo, ihi), (jlo, jhi) = self.plan.field_extents.get(name, analysis.ZERO_EXTENT)
@@ -842,8 +888,7 @@ class _Emitter:
             for nest in stage.nests:
                 L.append(f"    if (k >= {self.bound(nest.interval.start)} && k < {self.bound(nest.interval.end)}) {{")
                 self.local_decls(nest, "        ")
-                for s in nest.stmts:
-                    self.statement(s, stage, si, "k", {}, "        ")
+                self.statements(nest.stmts, stage, si, "k", {}, "        ")
                 L.append("    }")
             if k_per_thread > 1:
                 L.append("    }")
@@ -886,8 +931,7 @@ class _Emitter:
                     reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
                     for n in carry:
                         L.append(f"            {_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
-                    for s in group:
-                        self.statement(s, stage, si, "k", reg, "            ", carry)
+                    self.statements(group, stage, si, "k", reg, "            ", carry)
                     for n in active:
                         c = _c_ident(n)
                         if n in carry:
@@ -925,7 +969,7 @@ def _vector_width(em: "_Emitter", stage: Stage) -> int:
             # the strip form loads every row a nest reads before any statement runs, unconditionally: that is
             # only inside the arrays when each statement covers the whole stage extent and none is restricted
             # to a horizontal region (whose reads need less halo than an unrestricted statement's would)
-            if s.extent != stage.extent or s.region is not None:
+            if s.extent != stage.extent or s.region is not None or s.loops:
                 return 0
             if s.target.offset != (0, 0, 0):
                 return 0
@@ -1079,8 +1123,7 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
             L.append(f"            {const}{ct}* const t_{c} = b_{c} + {step};")
         em.base_prefix = "t_"
         em.local_decls(nest, "            ")
-        for s in nest.stmts:
-            em.statement(s, stage, si, "k", {}, "            ")
+        em.statements(nest.stmts, stage, si, "k", {}, "            ")
         em.base_prefix = "b_"
         L.append("          }")
         L.append("        }")

@@ -101,6 +101,8 @@ class _Parser(ast.NodeVisitor):
         self.imported: Dict[str, Any] = {}
         self._order: Optional[ir.LoopOrder] = None
         self._region: Optional[ir.Region] = None  # set while the body of `with horizontal(...)` is parsed
+        self._loops: Tuple[Tuple[int, ir.Expr], ...] = ()  # enclosing `while` loops of the statement being parsed
+        self._loop_count = 0
         self._groups = 0  # top-level `if` statements seen (one horizontal execution each)
         self._masks = 0
         for pname, ann in annotations.items():
@@ -299,7 +301,7 @@ class _Parser(ast.NodeVisitor):
                     name = f"mask_{self._masks}"
                 self._masks += 1
                 self.temporaries[name] = ir.FieldDecl(name, np.dtype("bool"), ("I", "J", "K"), (), False)
-                out.append(ir.Assign(ir.FieldAccess(name, (0, 0, 0)), cond, mask, group, self._region))
+                out.append(ir.Assign(ir.FieldAccess(name, (0, 0, 0)), cond, mask, group, self._region, self._loops))
                 cond = ir.FieldAccess(name, (0, 0, 0))
             for branch, this in ((node.body, cond), (node.orelse, ir.UnaryOp("not", cond))):
                 if not branch:
@@ -307,6 +309,29 @@ class _Parser(ast.NodeVisitor):
                 combined = this if mask is None else ir.BinaryOp("and", mask, this)
                 for s in branch:
                     out.extend(self._visit_stmt(s, combined, group))
+            return out
+        if isinstance(node, ast.While):
+            # `while cond: body` -- per point: repeat the body while the condition holds.  The condition is an
+            # expression re-evaluated every iteration (no temporary), AND-ed with the enclosing masks; the
+            # body statements are masked by it (oir_to_npir.py:176-185, npir_codegen.py:252-267).
+            if node.orelse:
+                raise self._err(node, "'while ... else' is not supported")
+            if group < 0:
+                group = self._groups
+                self._groups += 1
+            cond = self.visit(node.test)
+            full = cond if mask is None else ir.BinaryOp("and", mask, cond)
+            saved = self._loops
+            self._loops = saved + ((self._loop_count, full),)
+            self._loop_count += 1
+            out = []
+            try:
+                for s in node.body:
+                    out.extend(self._visit_stmt(s, full, group))
+            finally:
+                self._loops = saved
+            if not out:
+                raise self._err(node, "Empty 'while' body")
             return out
         if isinstance(node, ast.With):
             # `with horizontal(region[...], region[...]):` -- the body is repeated once per region, each
@@ -399,7 +424,7 @@ class _Parser(ast.NodeVisitor):
         access = self._target_access(target, node)
         if access.name not in self.fields and access.name not in self.temporaries:
             self.temporaries[access.name] = ir.FieldDecl(access.name, None, ("I", "J", "K"), (), False)
-        return ir.Assign(access, value, mask, group, self._region)
+        return ir.Assign(access, value, mask, group, self._region, self._loops)
 
     # ---- expressions ---------------------------------------------------------------------
     def generic_visit(self, node):
@@ -614,7 +639,12 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
                 tdt = dtypes[name]
                 if value.dtype != tdt:
                     value = ir.Cast(value, tdt)
-                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt), value, mask, stmt.group, stmt.region))
+                loops = []
+                for lid, cond in stmt.loops:
+                    cond = typed(cond)
+                    loops.append((lid, cond if cond.dtype == np.dtype("bool") else ir.Cast(cond, np.dtype("bool"))))
+                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt), value, mask, stmt.group, stmt.region,
+                                          tuple(loops)))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     temps = tuple(ir.FieldDecl(t.name, dtypes[t.name], t.axes, t.data_dims, False) for t in stencil.temporaries)

@@ -192,10 +192,17 @@ class Assign:
     mask: Optional[Expr] = None
     group: int = -1
     region: Optional[Region] = None
+    #: enclosing ``while`` loops, outermost first: (loop id, condition).  The condition already carries the
+    #: enclosing masks, as the reference builds it (gtc/numpy/oir_to_npir.py:176-185: cond = mask AND cond;
+    #: npir_codegen.py:252-267: ``while np.any(cond): body`` with every body statement masked by cond), and so
+    #: does ``mask``.  Consecutive statements sharing a loop id are that loop's body.
+    loops: Tuple[Tuple[int, Expr], ...] = ()
 
 
 def stmt_exprs(stmt: "Assign"):
-    """The expressions a statement reads: mask first (it is evaluated first), then the value."""
+    """The expressions a statement reads: loop conditions and mask first (evaluated first), then the value."""
+    for _, cond in stmt.loops:
+        yield cond
     if stmt.mask is not None:
         yield stmt.mask
     yield stmt.value

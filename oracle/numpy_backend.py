@@ -156,17 +156,41 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
                 k0, k1 = block.interval.range(dK)
                 plan = [(stmt, next(stmt_blocks)) for stmt in block.body]
 
-                def execute(krange):
-                    for stmt, ((ilo, ihi), (jlo, jhi)) in plan:
-                        lo, hi = (ilo, jlo), (dI + ihi, dJ + jhi)
-                        if stmt.region is not None:
-                            # horizontal mask: the block clipped to the region, bounds relative to the
-                            # compute domain (horizontal_masks.py:61-112 compute_relative_mask)
-                            i0, i1 = stmt.region.i.clip(lo[0], hi[0], dI)
-                            j0, j1 = stmt.region.j.clip(lo[1], hi[1], dJ)
-                            if i1 <= i0 or j1 <= j0:
-                                continue
-                            lo, hi = (i0, j0), (i1, j1)
+                def box(stmt, block):
+                    (ilo, ihi), (jlo, jhi) = block
+                    lo, hi = (ilo, jlo), (dI + ihi, dJ + jhi)
+                    if stmt.region is not None:
+                        # horizontal mask: the block clipped to the region, bounds relative to the
+                        # compute domain (horizontal_masks.py:61-112 compute_relative_mask)
+                        i0, i1 = stmt.region.i.clip(lo[0], hi[0], dI)
+                        j0, j1 = stmt.region.j.clip(lo[1], hi[1], dJ)
+                        if i1 <= i0 or j1 <= j0:
+                            return None
+                        lo, hi = (i0, j0), (i1, j1)
+                    return lo, hi
+
+                def run(items, depth, krange):
+                    n = 0
+                    while n < len(items):
+                        stmt, block = items[n]
+                        if len(stmt.loops) > depth:
+                            # `while np.any(cond): body` (npir_codegen.py:252-267); consecutive statements
+                            # with this loop id are the body
+                            lid, cond = stmt.loops[depth]
+                            m = n
+                            while m < len(items) and len(items[m][0].loops) > depth and items[m][0].loops[depth][0] == lid:
+                                m += 1
+                            span = box(stmt, block)
+                            if span is not None:
+                                while np.any(_evaluate(cond, env, span[0], span[1], krange)):
+                                    run(items[n:m], depth + 1, krange)
+                            n = m
+                            continue
+                        n += 1
+                        span = box(stmt, block)
+                        if span is None:
+                            continue
+                        lo, hi = span
                         target = env[stmt.target.name].window(lo, hi, stmt.target.offset, krange)
                         if stmt.mask is not None:  # npir_codegen.py:205-210: np.where(mask, right, left)
                             mask = _evaluate(stmt.mask, env, lo, hi, krange)
@@ -174,6 +198,9 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
                         else:
                             value = _evaluate(stmt.value, env, lo, hi, krange)
                         target[...] = value
+
+                def execute(krange):
+                    run(plan, 0, krange)
 
                 if comp.order is ir.LoopOrder.PARALLEL:
                     if k1 > k0:

@@ -250,6 +250,23 @@ def _data_dependent_expected(a, p, ext, domain):
     return out
 
 
+# ---- :441-468 ----------------------------------------------------------------------------------
+def runtime_if_nested_while(infield: F64, outfield: F64):
+    with computation(PARALLEL), interval(...):
+        if infield < 10:
+            outfield = 1
+            done = False
+            while not done:
+                outfield = 2
+                done = True
+        else:
+            condition = True
+            while condition:
+                outfield = 4
+                condition = False
+            outfield = 3
+
+
 # ---- :471-489 ----------------------------------------------------------------------------------
 def ternary_op(infield: F64, outfield: F64):
     with computation(PARALLEL), interval(...):
@@ -453,6 +470,9 @@ SUITES: Dict[str, Suite] = {
     "runtime_if_nested_data_dependent": Suite(runtime_if_nested_data_dependent,
                                               {"field_a": (np.float64, Z, R1), "field_b": (np.float64, Z, R1), "field_c": (np.float64, Z, R1)},
                                               _data_dependent_expected, params={"factor": (-100, 100)}, domains=((3, 3, 3), (5, 4, 3))),
+    "runtime_if_nested_while": Suite(runtime_if_nested_while,
+                                     {"infield": (np.float64, Z, R1), "outfield": (np.float64, Z, R10)},
+                                     lambda a, p, e, d: {"outfield": np.full_like(a["outfield"], 2)}),
     "ternary_op": Suite(ternary_op, {"infield": (np.float64, ((0, 0), (0, 1), (0, 0)), R10), "outfield": (np.float64, Z, R10)},
                         _ternary_expected, domains=((1, 2, 1), (3, 4, 5), (15, 14, 13))),
     "three_way_and": Suite(three_way_and, {"outfield": (np.float64, Z, R10)},

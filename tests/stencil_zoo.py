@@ -267,6 +267,34 @@ def variable_k_of_written_field(a: F64, idx: "Field[np.int32]", out: F64):
         a = out[0, 0, idx] + 1.0
 
 
+def newton_sqrt(a: F64, out: F64, *, tol: float):
+    """data-dependent iteration count per point: Newton's method inside a run-time `while`"""
+    with computation(PARALLEL), interval(...):
+        x = 1.0
+        target = abs(a) + 0.5
+        while abs(x * x - target) > tol:
+            x = 0.5 * (x + target / x)
+        out = x
+
+
+def while_in_if_and_scan(a: F64, out: F64):
+    """`while` nested in `if`/`else` inside a FORWARD recurrence, with a counter that bounds the loop"""
+    with computation(FORWARD):
+        with interval(0, 1):
+            out = a
+        with interval(1, None):
+            v = a + out[0, 0, -1] * 0.5
+            n = 0
+            if v > 0.0:
+                while v > 0.25 and n < 6:
+                    v = v * 0.5
+                    n = n + 1
+            else:
+                while v < -0.25:
+                    v = v * 0.5 + 0.01
+            out = v + n
+
+
 ZOO = {
     # name: (definition, externals, scalars, backend options)
     "copy_stencil": (copy_stencil, {}, {}, {}),
@@ -287,6 +315,8 @@ ZOO = {
     "two_stage_written_input": (two_stage_written_input, {}, {}, {}),
     "variable_k_offsets": (variable_k_offsets, {}, {}, {}),
     "variable_k_of_written_field": (variable_k_of_written_field, {}, {}, {}),
+    "newton_sqrt": (newton_sqrt, {}, {"tol": 1e-12}, {}),
+    "while_in_if_and_scan": (while_in_if_and_scan, {}, {}, {}),
     "runtime_if": (runtime_if, {}, {}, {}),
     "nested_if": (nested_if, {}, {"thresh": 0.75}, {}),
     "if_with_offsets": (if_with_offsets, {}, {}, {}),

@@ -22,6 +22,53 @@ from ... import _lib
 _U3 = ctypes.c_uint32 * 3
 
 
+def _cache_dir():
+    """Directory of compiled code objects, or None when caching is off.
+
+    Counterpart of the reference's on-disk build cache (`.gt_cache`, cache_settings in
+    /root/reference/src/gt4py/cartesian/config.py:45-63): there it holds generated sources and compiled
+    extensions keyed by a stencil fingerprint; here one gfx950 code object per (generated source, options).
+    ``GT4PY_AMD_CACHE_DIR`` moves it, ``GT4PY_AMD_CACHE_DIR=""`` (empty) switches it off."""
+    import os
+    import pathlib
+
+    root = os.environ.get("GT4PY_AMD_CACHE_DIR")
+    if root == "":
+        return None
+    path = pathlib.Path(root) if root else pathlib.Path.home() / ".cache" / "gt4py_amd" / "rtc"
+    try:
+        path.mkdir(parents=True, exist_ok=True)
+    except OSError:
+        return None
+    return path
+
+
+def _compile_cached(source: str, name: str, options) -> bytes:
+    import hashlib
+    import os
+
+    cache = _cache_dir()
+    entry = None
+    if cache is not None:
+        key = hashlib.sha256("\0".join([source, *options, "gfx950", str(_lib.GT4MI_ABI_VERSION)]).encode()).hexdigest()
+        entry = cache / f"{key}.hsaco"
+        try:
+            code = entry.read_bytes()
+            if code[:4] == b"\x7fELF":
+                return code
+        except OSError:
+            pass
+    code = _lib.rtc_compile(source, name, options)
+    if entry is not None:
+        try:
+            tmp = entry.with_suffix(f".{os.getpid()}.tmp")
+            tmp.write_bytes(code)
+            os.replace(tmp, entry)  # atomic: concurrent processes never see a partial file
+        except OSError:
+            pass
+    return code
+
+
 class _Variant:
     """One compiled flavour of a generated program: loaded module + kernel handles."""
 
@@ -32,7 +79,7 @@ class _Variant:
         if no_alias:
             options.append("-DGT4MI_NO_ALIAS=1")
         lib = _lib.load()
-        self.code = _lib.rtc_compile(program.source, f"{program.plan.stencil.name}.hip", options)
+        self.code = _compile_cached(program.source, f"{program.plan.stencil.name}.hip", options)
         self._code_buf = ctypes.create_string_buffer(self.code, len(self.code))
         module = ctypes.c_void_p()
         _lib.check("gt4mi_module_load", lib.gt4mi_module_load(self._code_buf, ctypes.byref(module)))

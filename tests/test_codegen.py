@@ -135,3 +135,22 @@ def test_horizontal_stages_get_a_16_byte_lane_twin(programs):
 def test_compiler_errors_surface_with_the_log():
     with pytest.raises(_lib.NativeError, match="expected ';'"):
         _lib.rtc_compile('extern "C" __global__ void k(double* a) { a[0] = 1.0 }')
+
+
+def test_code_objects_are_cached_on_disk(programs, tmp_path, monkeypatch):
+    """Counterpart of the reference's `.gt_cache`: one gfx950 code object per (source, options)."""
+    from gt4py_amd.cartesian.backend import hip_generic
+
+    monkeypatch.setenv("GT4PY_AMD_CACHE_DIR", str(tmp_path))
+    prog = programs["copy_stencil"]
+    calls = []
+    real = _lib.rtc_compile
+    monkeypatch.setattr(_lib, "rtc_compile", lambda *a, **k: (calls.append(a[1]), real(*a, **k))[1])
+    first = hip_generic._compile_cached(prog.source, "copy.hip", ["-DGT4MI_UNIT_I_STRIDE=1"])
+    again = hip_generic._compile_cached(prog.source, "copy.hip", ["-DGT4MI_UNIT_I_STRIDE=1"])
+    other = hip_generic._compile_cached(prog.source, "copy.hip", [])
+    assert first == again and first[:4] == b"\x7fELF" and len(calls) == 2  # the second call came from disk
+    assert len(list(tmp_path.glob("*.hsaco"))) == 2 and other[:4] == b"\x7fELF"
+    monkeypatch.setenv("GT4PY_AMD_CACHE_DIR", "")
+    hip_generic._compile_cached(prog.source, "copy.hip", [])
+    assert len(calls) == 3  # caching switched off: compiled again

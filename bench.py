@@ -140,8 +140,9 @@ def other_kernels(steps: int = 10):
               "sup": field(dom, np.float64, (0, 0, 0)), "rhs": field(dom, np.float64, (0, 0, 0), -10.0, 10.0),
               "out": field(dom, np.float64, (0, 0, 0))}
     run("tridiagonal_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 56.0,
-        note="two sweeps move 72 B/LUP: ceiling 0.78 of this roofline; inputs are whatever the previous launch "
-             "left in sup/rhs (timing only, values are checked in tests/)")
+        note="the backward sweep re-reads the part of sup', rhs' that does not fit on chip (72 of 160 levels stay in "
+             "registers + LDS): 64.8 B/LUP moved; inputs are whatever the previous launch left in sup/rhs "
+             "(timing only, values are checked in tests/)")
     del fields
     torch.cuda.empty_cache()
     return out

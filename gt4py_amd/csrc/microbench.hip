@@ -347,6 +347,33 @@ static void tridiag_variant(DevField<T>& a, DevField<T>& d, DevField<T>& s, DevF
     report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
 }
 
+template <int RL, int LL, int U>
+static void tridiag_stack_variant(DevField<double>& a, DevField<double>& d, DevField<double>& s, DevField<double>& r,
+                                  DevField<double>& o, DevField<double>& s2, DevField<double>& r2, DevField<double>& o2,
+                                  int dI, int dJ, int dK) {
+    const unsigned ti = (unsigned)cdiv(dI, 64);
+    char cfg[96];
+    snprintf(cfg, sizeof cfg, "stack RL=%d LL=%d U=%d (mem levels %d)", RL, LL, U, dK - RL - LL);
+    if (dK - RL - LL < 1) return;
+    // correctness against the two-sweep kernel from identical inputs
+    fill(s, 3, -1.0, 1.0);
+    fill(r, 4, -10.0, 10.0);
+    fill(s2, 3, -1.0, 1.0);
+    fill(r2, 4, -10.0, 10.0);
+    hipLaunchKernelGGL((tridiag_stack_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+    {
+        const unsigned t2 = (unsigned)cdiv(dI, 256);
+        hipLaunchKernelGGL((tridiag_kernel<double, 1, 8>), dim3(t2 * dJ), dim3(256), 0, 0, a.cview(), d.cview(), s2.view(), r2.view(), o2.view(), dI, dJ, dK, t2);
+    }
+    CK(hipDeviceSynchronize());
+    printf("           check %s: out %llu sup %llu rhs %llu mismatches\n", cfg, count_diff(o, o2, dI, dJ, dK),
+           count_diff(s, s2, dI, dJ, dK), count_diff(r, r2, dI, dJ, dK));
+    const double ms = time_ms([&](int) {
+        hipLaunchKernelGGL((tridiag_stack_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+    }, 5, 1);
+    report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
+}
+
 static void section_tridiag() {
     const int dI = 1024, dJ = 1024, dK = 160;
     DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
@@ -388,6 +415,17 @@ static void section_tridiag() {
     tridiag_variant<double, 2, 1>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
     tridiag_variant<double, 1, 16>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
     tridiag_variant<double, 1, 8>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    tridiag_stack_variant<32, 40, 8>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<32, 32, 16>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<32, 48, 16>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<16, 48, 16>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<32, 48, 8>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<40, 40, 8>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<24, 40, 8>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<32, 36, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<28, 40, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<36, 40, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    tridiag_stack_variant<32, 40, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -164,10 +164,20 @@ tridiag_generic_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<
     }
 }
 
+}  // namespace gt4mi
+
+#include "tridiag_stack.hip.h"
+
+namespace gt4mi {
+
 struct TridiagTuning {
     // profiles/r1_microbench_d_*.log: 8 bytes per lane with 8 levels of loads in flight beats
     // 16-byte lanes (84 vs 78 GLUPS on 1024x1024x160 f64).
     static constexpr int UNROLL = 8;
+    // on-chip stack of the forward sweep's results (tridiag_stack.hip.h): the last 32 levels in registers,
+    // the 40 before them in LDS; 16/24/48 register levels and 0..64 LDS levels measured within 2 % of each
+    // other, more than 48 register levels slower (profiles/r1_microbench_i_tridiag_stack.log)
+    static constexpr int STACK_REG = 32, STACK_LDS = 40, STACK_U = 8;
 };
 
 template <typename T>
@@ -188,7 +198,19 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
     if (domain[0] == 0 || domain[1] == 0) return GT4MI_OK;
     const View<const T> ac{a.p, a.si, a.sj, a.sk}, dc{d.p, d.si, d.sj, d.sk};
     const bool contiguous = a.si == 1 && d.si == 1 && s.si == 1 && r.si == 1 && o.si == 1;
-    if (contiguous) {
+    if (contiguous && domain[2] > TridiagTuning::STACK_REG) {
+        // keep the top of the column on chip between the sweeps
+        const unsigned ti = (unsigned)cdiv(domain[0], 64);
+        if (domain[2] > TridiagTuning::STACK_REG + TridiagTuning::STACK_LDS) {
+            hipLaunchKernelGGL((tridiag_stack_kernel<T, TridiagTuning::STACK_REG, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
+                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+                               (int)domain[1], (int)domain[2], ti);
+        } else {
+            hipLaunchKernelGGL((tridiag_stack_kernel<T, TridiagTuning::STACK_REG, 0, TridiagTuning::STACK_U>),
+                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+                               (int)domain[1], (int)domain[2], ti);
+        }
+    } else if (contiguous) {
         constexpr int VMAX = 8 / sizeof(T);
         const bool vec = VMAX > 1 &&vec_ok(a, VMAX) && vec_ok(d, VMAX) && vec_ok(s, VMAX) && vec_ok(r, VMAX) &&
                          vec_ok(o, VMAX) && (domain[0] % VMAX == 0);

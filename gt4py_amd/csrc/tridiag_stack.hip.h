@@ -1,0 +1,176 @@
+// Tridiagonal solve that keeps the forward sweep's results ON CHIP for the backward sweep.
+//
+// tridiag.hip.h moves 9 arrays' worth of bytes per solve: the backward sweep re-reads the sup', rhs'
+// the forward sweep has just written (PMC: 1.49x the algorithmic reads,
+// profiles/r1_kernel_hbm_traffic_pmc.txt) and it already runs at the streaming-copy rate, so the only way
+// up is to not re-read.  A CDNA4 CU has 512 KB of vector registers and 160 KB of LDS; a 160-level fp64
+// column pair is 2.5 KB.  Here a wave keeps the LAST `RL` levels of (sup', rhs') in registers (the level
+// loops over them are fully unrolled, so the arrays stay in VGPRs), the `LL` levels before those in LDS,
+// and only the first dK - RL - LL levels are read back from memory:
+//
+//     forward   k in [0, A)            compute, store                      (A = dK - LL - RL)
+//               k in [A, A + LL)       compute, store, keep in LDS
+//               k in [A + LL, dK)      compute, store, keep in registers   (unrolled)
+//     backward  the same three ranges in reverse; memory is only touched for [0, A) and for `out`.
+//
+// Traffic per lattice update: 7 values + 2 * A / dK values.  One wave per workgroup (LL * 1 KB of LDS each for
+// fp64), so with LL = 40 four waves share a CU and memory latency is hidden by issuing the loads of `U` levels
+// ahead of the dependent divides rather than by other waves.  Measured on MI355X, fp64 1024x1024x160
+// (profiles/r1_microbench_i_tridiag_stack.log): RL = 32, LL = 40 (72 of 160 levels on chip, 64.8 B instead of
+// 72 B per update) is 10-12 % faster than tridiag.hip.h on the same device; RL >= 48 is SLOWER again (the
+// compiler does keep 96 levels in 256 VGPRs + 180 AGPRs without scratch, but the unrolled code and the
+// single wave per SIMD cost more than the saved traffic brings).
+//
+// Values are those of tridiag.hip.h (same expressions, same order, IEEE divides, no contraction): the
+// on-chip copies are the very numbers that were stored.
+#pragma once
+
+#include "common.hip.h"
+
+#pragma clang fp contract(off)
+
+namespace gt4mi {
+
+template <typename T, int RL, int LL, int U>
+__global__ void __launch_bounds__(64)
+tridiag_stack_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<T> rhs, View<T> out, int dI, int dJ,
+                     int dK, unsigned tiles_i) {
+    static_assert(RL % U == 0 && LL % U == 0, "level ranges are processed in batches of U");
+    __shared__ T lds[LL > 0 ? LL * 2 * 64 : 1];
+    const unsigned bi = blockIdx.x % tiles_i;
+    const unsigned j = blockIdx.x / tiles_i;
+    const int lane = threadIdx.x;
+    const int i0 = (int)(bi * 64) + lane;
+    if (i0 >= dI) return;
+
+    const T* __restrict__ p_inf = inf.p + (int64_t)j * inf.sj + i0;
+    const T* __restrict__ p_diag = diag.p + (int64_t)j * diag.sj + i0;
+    T* __restrict__ p_sup = sup.p + (int64_t)j * sup.sj + i0;
+    T* __restrict__ p_rhs = rhs.p + (int64_t)j * rhs.sj + i0;
+    T* __restrict__ p_out = out.p + (int64_t)j * out.sj + i0;
+
+    const int A = dK - LL - RL;  // >= 1 (checked by the host): level 0 is always in the memory range
+    T sp, rp;                    // updated sup[k-1], rhs[k-1]
+    T S[RL], R[RL];              // the last RL levels; only ever indexed by compile-time constants
+
+    auto level = [&](T a, T d, T s, T r) {
+        const T den1 = d - (sp * a);
+        const T ns = s / den1;
+        const T num = r - (a * rp);
+        const T den2 = d - (sp * a);
+        const T nr = num / den2;
+        sp = ns;
+        rp = nr;
+    };
+
+    // ---- FORWARD, memory range [0, A) -----------------------------------------------------------
+    {
+        const T d = p_diag[0], s = p_sup[0], r = p_rhs[0];
+        sp = s / d;
+        rp = r / d;
+        __builtin_nontemporal_store(sp, p_sup);
+        __builtin_nontemporal_store(rp, p_rhs);
+    }
+    int k = 1;
+    for (; k + U <= A; k += U) {
+        T a[U], d[U], s[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = p_inf[(int64_t)(k + u) * inf.sk];
+            d[u] = p_diag[(int64_t)(k + u) * diag.sk];
+            s[u] = p_sup[(int64_t)(k + u) * sup.sk];
+            r[u] = p_rhs[(int64_t)(k + u) * rhs.sk];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            level(a[u], d[u], s[u], r[u]);
+            p_sup[(int64_t)(k + u) * sup.sk] = sp;  // read again by the backward sweep: keep cacheable
+            p_rhs[(int64_t)(k + u) * rhs.sk] = rp;
+        }
+    }
+    for (; k < A; ++k) {
+        level(p_inf[(int64_t)k * inf.sk], p_diag[(int64_t)k * diag.sk], p_sup[(int64_t)k * sup.sk],
+              p_rhs[(int64_t)k * rhs.sk]);
+        p_sup[(int64_t)k * sup.sk] = sp;
+        p_rhs[(int64_t)k * rhs.sk] = rp;
+    }
+    // ---- FORWARD, LDS range [A, A + LL) ---------------------------------------------------------
+#pragma unroll 1
+    for (int l = 0; l < LL; l += U) {
+        T a[U], d[U], s[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t kk = A + l + u;
+            a[u] = p_inf[kk * inf.sk];
+            d[u] = p_diag[kk * diag.sk];
+            s[u] = p_sup[kk * sup.sk];
+            r[u] = p_rhs[kk * rhs.sk];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t kk = A + l + u;
+            level(a[u], d[u], s[u], r[u]);
+            __builtin_nontemporal_store(sp, p_sup + kk * sup.sk);
+            __builtin_nontemporal_store(rp, p_rhs + kk * rhs.sk);
+            lds[((l + u) * 2 + 0) * 64 + lane] = sp;
+            lds[((l + u) * 2 + 1) * 64 + lane] = rp;
+        }
+    }
+    // ---- FORWARD, register range [A + LL, dK): fully unrolled -------------------------------------
+#pragma unroll
+    for (int l = 0; l < RL; l += U) {
+        T a[U], d[U], s[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t kk = A + LL + l + u;
+            a[u] = p_inf[kk * inf.sk];
+            d[u] = p_diag[kk * diag.sk];
+            s[u] = p_sup[kk * sup.sk];
+            r[u] = p_rhs[kk * rhs.sk];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t kk = A + LL + l + u;
+            level(a[u], d[u], s[u], r[u]);
+            __builtin_nontemporal_store(sp, p_sup + kk * sup.sk);
+            __builtin_nontemporal_store(rp, p_rhs + kk * rhs.sk);
+            S[l + u] = sp;
+            R[l + u] = rp;
+        }
+    }
+
+    // ---- BACKWARD ---------------------------------------------------------------------------------
+    T o = R[RL - 1];  // out[K-1] = rhs'[K-1]
+    __builtin_nontemporal_store(o, p_out + (int64_t)(dK - 1) * out.sk);
+#pragma unroll
+    for (int l = RL - 2; l >= 0; --l) {
+        o = R[l] - (S[l] * o);
+        __builtin_nontemporal_store(o, p_out + (int64_t)(A + LL + l) * out.sk);
+    }
+#pragma unroll 4
+    for (int l = LL - 1; l >= 0; --l) {
+        const T s = lds[(l * 2 + 0) * 64 + lane], r = lds[(l * 2 + 1) * 64 + lane];
+        o = r - (s * o);
+        __builtin_nontemporal_store(o, p_out + (int64_t)(A + l) * out.sk);
+    }
+    int kb = A - 1;
+    for (; kb - U + 1 >= 0; kb -= U) {
+        T s[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s[u] = p_sup[(int64_t)(kb - u) * sup.sk];
+            r[u] = p_rhs[(int64_t)(kb - u) * rhs.sk];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            o = r[u] - (s[u] * o);
+            __builtin_nontemporal_store(o, p_out + (int64_t)(kb - u) * out.sk);
+        }
+    }
+    for (; kb >= 0; --kb) {
+        o = p_rhs[(int64_t)kb * rhs.sk] - (p_sup[(int64_t)kb * sup.sk] * o);
+        __builtin_nontemporal_store(o, p_out + (int64_t)kb * out.sk);
+    }
+}
+
+}  // namespace gt4mi

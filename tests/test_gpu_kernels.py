@@ -217,7 +217,8 @@ def _tridiag_inputs(shape, dtype, seed=7):
 
 @pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(1, 1, 2), (3, 5, 2), (17, 33, 5), (64, 64, 8), (65, 63, 7), (40, 9, 160), (514, 3, 19)])
+@pytest.mark.parametrize("shape", [(1, 1, 2), (3, 5, 2), (17, 33, 5), (64, 64, 8), (65, 63, 7), (40, 9, 160), (514, 3, 19),
+                                   (34, 5, 50), (130, 3, 73), (70, 2, 33), (66, 4, 72)])  # K around the on-chip stack sizes
 def test_tridiag_parity(shape, dtype, layout):
     import gpu_util as G
 

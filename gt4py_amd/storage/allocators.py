@@ -90,6 +90,30 @@ def allocate_cpu(shape, layout_map, dtype, alignment_bytes, aligned_index) -> Tu
     return raw, view
 
 
+_SKEW_COUNTER = [0]
+
+
+def _channel_skew(alignment_bytes: int) -> int:
+    """Bytes by which the next big device allocation is shifted.
+
+    Equally shaped fields that a stencil streams side by side (five 1.34 GB arrays in the tridiagonal
+    solve) otherwise sit at addresses that differ by a multiple of a large power of two, so the same (i, j, k)
+    of every field lands in the same HBM channel.  Rotating the start over a few steps spreads them.  The
+    layout contract is untouched: strides, padding and the alignment of `aligned_index` are the reference's
+    (storage/allocators.py:187-273); only where the buffer begins inside its (over-)allocation changes.
+    ``GT4PY_AMD_ALLOC_SKEW_BYTES`` sets the step (0 = off).  Default 1.5 MiB: on MI355X the tridiagonal
+    solve on five 1024x1024x160 fp64 fields runs at 79-85 GLUPS without a skew, 88-92 with 128 KiB-1 MiB
+    steps, 96-97 with 1.25-1.5 MiB, 92 with 3 MiB; the two-field kernels do not care."""
+    import os
+
+    step = int(os.environ.get("GT4PY_AMD_ALLOC_SKEW_BYTES", str(3 << 19)))
+    if step <= 0:
+        return 0
+    step = -(-step // alignment_bytes) * alignment_bytes
+    _SKEW_COUNTER[0] = (_SKEW_COUNTER[0] + 1) % 8
+    return _SKEW_COUNTER[0] * step
+
+
 def allocate_gpu(shape, layout_map, dtype, alignment_bytes, aligned_index) -> Tuple["torch.Tensor", DeviceArray]:
     if torch is None or not torch.cuda.is_available():
         raise RuntimeError(
@@ -99,8 +123,9 @@ def allocate_gpu(shape, layout_map, dtype, alignment_bytes, aligned_index) -> Tu
     dtype = np.dtype(dtype)
     tdt = torch_dtype(dtype)
     plan = plan_buffer(shape, dtype, layout_map, alignment_bytes, aligned_index)
-    raw = torch.empty((plan.total_bytes,), dtype=torch.uint8, device="cuda")
-    offset = plan.byte_offset(raw.data_ptr())
+    skew = _channel_skew(alignment_bytes) if plan.total_bytes >= (1 << 24) else 0
+    raw = torch.empty((plan.total_bytes + skew,), dtype=torch.uint8, device="cuda")
+    offset = skew + plan.byte_offset(raw.data_ptr() + skew)
     assert offset % plan.itemsize == 0, "device allocation is not item-aligned"
     n_items = math.prod(plan.padded_shape)
     flat = raw[offset: offset + n_items * plan.itemsize].view(tdt)

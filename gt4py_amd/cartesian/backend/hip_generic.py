@@ -202,6 +202,9 @@ class HipGenericStencilObject(StencilObject):
                     oi = -(-(-ilo) // 4) * 4  # the domain's first column on a 16-byte boundary
                     ni = -(-(dI + ihi + oi) // 32) * 32  # rows padded like the storage preset
                     nj = dJ + jhi - jlo
+                    # equally shaped temporaries must not sit a multiple of 2 MiB apart (HBM channel aliasing,
+                    # see storage/allocators.py:_channel_skew): stagger them by 1.5 MiB steps
+                    total += (len(layout) % 8) * (3 << 19)
                     layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
                     total += -(-(ni * nj * max(dK, 1) * dt.itemsize) // 256) * 256
                 buf = torch.empty(total, dtype=torch.uint8, device="cuda")

@@ -6,6 +6,8 @@ backend/gtcpp_backend.py:109-166).  This module is a much smaller thing with the
 *the values the numpy backend produces* (gtc/numpy/npir_codegen.py:205-318) -- for the sub-language the
 frontend accepts (assignments of expression trees under ``computation``/``interval``):
 
+(passes 1-3 live in ``stage_planner.py``, pass 4 -- emission -- here)
+
 1. ``inline_horizontal_temporaries``: inside one PARALLEL interval block, temporaries that are read at
    horizontal offsets and depend only on never-written inputs are substituted into their readers
    (SSA over re-assigned names), i.e. recomputed at the shifted point.  The reference's counterpart is
@@ -70,400 +72,8 @@ TUNING = {
     "vector_rows": _env_tuple("GT4MI_CODEGEN_VECTOR_ROWS", (4,))[0],
 }
 
-
-class UnsupportedStencil(NotImplementedError):
-    """The stencil is outside what the generic executor can run exactly."""
-
-
-# ---------------------------------------------------------------------------------------------------
-# 1. inlining of horizontally offset temporaries
-# ---------------------------------------------------------------------------------------------------
-def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
-    return ir.FieldAccess(e.name, (e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]), e.dtype, e.koffset)
-
-
-def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[str]]:
-    """Returns (rewritten stencil, names of SSA values that are thread-local by construction)."""
-    written = {s.target.name for _, _, s in stencil.statements()}
-    pure_inputs = {f.name for f in stencil.fields if f.name not in written}
-    temps = {t.name: t for t in stencil.temporaries}
-
-    touched: Dict[str, Set[Tuple[int, int]]] = {}
-    k_offset_read: Set[str] = set()
-    ij_offset_read: Set[str] = set()
-    masked_write: Set[str] = set()  # conditionally assigned: the old value shows through, no substitution
-    for ci, comp in enumerate(stencil.computations):
-        for bi, block in enumerate(comp.blocks):
-            for stmt in block.body:
-                touched.setdefault(stmt.target.name, set()).add((ci, bi))
-                if stmt.mask is not None or stmt.region is not None or stmt.loops:
-                    masked_write.add(stmt.target.name)
-                for e in ir.stmt_reads(stmt):
-                    if isinstance(e, ir.FieldAccess):
-                        touched.setdefault(e.name, set()).add((ci, bi))
-                        if e.offset[2] != 0 or e.koffset is not None:
-                            k_offset_read.add(e.name)
-                        if e.offset[0] != 0 or e.offset[1] != 0:
-                            ij_offset_read.add(e.name)
-
-    cand = {
-        n for n in temps
-        if len(touched.get(n, ())) == 1 and n not in k_offset_read and n not in masked_write
-        and stencil.computations[next(iter(touched[n]))[0]].order is ir.LoopOrder.PARALLEL
-    }
-    changed = True
-    while changed:
-        changed = False
-        for _, _, stmt in stencil.statements():
-            if stmt.target.name in cand:
-                for e in ir.stmt_reads(stmt):
-                    if isinstance(e, ir.FieldAccess) and e.name not in pure_inputs and e.name not in cand:
-                        cand.discard(stmt.target.name)
-                        changed = True
-                        break
-    # inline what is read at a horizontal offset, plus everything such a definition refers to
-    inline = {n for n in cand if n in ij_offset_read}
-    changed = True
-    while changed:
-        changed = False
-        for _, _, stmt in stencil.statements():
-            if stmt.target.name in inline:
-                for e in ir.stmt_reads(stmt):
-                    if isinstance(e, ir.FieldAccess) and e.name in cand and e.name not in inline:
-                        inline.add(e.name)
-                        changed = True
-    if not inline:
-        return stencil, set()
-
-    ssa_locals: Dict[str, np.dtype] = {}
-    new_comps = []
-    for comp in stencil.computations:
-        new_blocks = []
-        for block in comp.blocks:
-            version: Dict[str, str] = {}
-            defs: Dict[str, ir.Expr] = {}
-            order: List[Tuple[str, object]] = []  # ("def", version) | ("stmt", Assign)
-
-            def to_versions(expr: ir.Expr) -> ir.Expr:
-                def fn(e):
-                    if isinstance(e, ir.FieldAccess) and e.name in inline:
-                        if e.name not in version:  # the frontend rejects this already
-                            raise UnsupportedStencil(f"temporary '{e.name}' is read before it is assigned")
-                        return ir.FieldAccess(version[e.name], e.offset, e.dtype, e.koffset)
-                    return e
-
-                return ir.map_expr(expr, fn)
-
-            for stmt in block.body:
-                value = to_versions(stmt.value)
-                mask = to_versions(stmt.mask) if stmt.mask is not None else None
-                loops = tuple((lid, to_versions(c)) for lid, c in stmt.loops)
-                name = stmt.target.name
-                if name in inline:
-                    v = f"{name}__v{sum(1 for k in defs if k.rsplit('__v', 1)[0] == name)}"
-                    defs[v] = value
-                    version[name] = v
-                    order.append(("def", v))
-                else:
-                    order.append(("stmt", ir.Assign(stmt.target, value, mask, stmt.group, stmt.region, loops)))
-
-            memo: Dict[Tuple[str, Tuple[int, int]], ir.Expr] = {}
-            needed: Set[str] = set()
-
-            def expand(expr: ir.Expr, shift: Tuple[int, int]) -> ir.Expr:
-                def fn(e):
-                    if isinstance(e, ir.FieldAccess):
-                        if e.name in defs:
-                            s = (shift[0] + e.offset[0], shift[1] + e.offset[1])
-                            if s == (0, 0):
-                                needed.add(e.name)
-                                return ir.FieldAccess(e.name, (0, 0, 0), e.dtype)
-                            key = (e.name, s)
-                            if key not in memo:
-                                memo[key] = expand(defs[e.name], s)
-                            return memo[key]
-                        return _shift_access(e, shift) if shift != (0, 0) else e
-                    return e
-
-                return ir.map_expr(expr, fn)
-
-            body_stmts = [(kind, (expand(obj.value, (0, 0)), expand(obj.mask, (0, 0)) if obj.mask is not None else None,
-                                  tuple((lid, expand(c, (0, 0))) for lid, c in obj.loops))
-                           if kind == "stmt" else None, obj) for kind, obj in order]
-            local_defs: Dict[str, ir.Expr] = {}
-            pending = list(needed)
-            while pending:  # thread-local values referenced at the thread's own point
-                v = pending.pop()
-                if v in local_defs:
-                    continue
-                before = set(needed)
-                local_defs[v] = expand(defs[v], (0, 0))
-                pending.extend(needed - before)
-            new_body = []
-            for kind, value, obj in body_stmts:
-                if kind == "def":
-                    if obj in local_defs:
-                        dt = local_defs[obj].dtype
-                        ssa_locals[obj] = np.dtype(temps[obj.rsplit("__v", 1)[0]].dtype)
-                        new_body.append(ir.Assign(ir.FieldAccess(obj, (0, 0, 0), ssa_locals[obj]), local_defs[obj]))
-                else:
-                    new_body.append(ir.Assign(obj.target, value[0], value[1], obj.group, obj.region, value[2]))
-            new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
-        new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
-    new_temps = tuple(t for t in stencil.temporaries if t.name not in inline) + tuple(
-        ir.FieldDecl(n, dt, ("I", "J", "K"), (), False) for n, dt in ssa_locals.items())
-    return ir.Stencil(stencil.name, stencil.fields, stencil.params, new_temps, tuple(new_comps)), set(ssa_locals)
-
-
-# ---------------------------------------------------------------------------------------------------
-# 2./3. stages and storage classes
-# ---------------------------------------------------------------------------------------------------
-@dataclass
-class Stmt:
-    target: ir.FieldAccess
-    value: ir.Expr
-    extent: Extent2
-    mask: Optional[ir.Expr] = None
-    region: Optional[ir.Region] = None
-    loops: Tuple[Tuple[int, ir.Expr], ...] = ()
-
-
-@dataclass
-class Nest:
-    order: ir.LoopOrder
-    interval: ir.Interval
-    stmts: List[Stmt]
-    block_id: Tuple[int, int]
-    split_statements: bool = False  # PARALLEL block that has to run statement by statement over K
-
-
-@dataclass
-class Stage:
-    nests: List[Nest] = field(default_factory=list)
-    written: Set[str] = field(default_factory=set)
-    offset_reads: Set[str] = field(default_factory=set)
-    mapping: str = "ijk"
-    extent: Extent2 = analysis.ZERO_EXTENT
-
-
-@dataclass
-class Plan:
-    stencil: ir.Stencil  # after inlining
-    stages: List[Stage]
-    field_extents: Dict[str, Extent2]
-    locals: Set[str]  # thread-local temporaries
-    scratch: Dict[str, Tuple[np.dtype, Extent2]]  # temporaries in global memory
-    forwarded: Dict[Tuple[int, str], int]  # (stage index, name) -> +-1: value of the previous level kept in a register
-    prime: Dict[Tuple[int, int, str], Tuple[str, Optional[int]]]  # (stage, nest, name) -> (mode, previous nest)
-    register_only: Set[str]  # forwarded temporaries that never need memory
-    api_fields: List[ir.FieldDecl]  # API fields a kernel touches
-    params: List[ir.ScalarDecl]  # scalar parameters a kernel reads
-
-
-def _field_reads(expr: ir.Expr):
-    return [e for e in ir.walk(expr) if isinstance(e, ir.FieldAccess)]
-
-
-def _stmt_field_reads(s) -> List[ir.FieldAccess]:
-    """Field reads of a planned statement or an ``ir.Assign``: mask and value."""
-    reads = _field_reads(s.value)
-    if s.mask is not None:
-        reads = _field_reads(s.mask) + reads
-    for _, cond in getattr(s, "loops", ()):
-        reads = _field_reads(cond) + reads
-    return reads
-
-
-def plan_stages(stencil_in: ir.Stencil) -> Plan:
-    for d in (*stencil_in.fields, *stencil_in.temporaries):
-        if d.data_dims:
-            raise UnsupportedStencil(f"field '{d.name}' has data dimensions")
-    stencil, ssa_locals = inline_horizontal_temporaries(stencil_in)
-    extents = analysis.compute_extents(stencil)
-    written_anywhere = {s.target.name for _, _, s in stencil.statements()}
-
-    stages: List[Stage] = []
-    cur: Optional[Stage] = None
-    ext_iter = iter(extents.blocks)
-    for ci, comp in enumerate(stencil.computations):
-        for bi, block in enumerate(comp.blocks):
-            stmts = [Stmt(s.target, s.value, next(ext_iter), s.mask, s.region, s.loops) for s in block.body]
-            if comp.order is ir.LoopOrder.PARALLEL:
-                units = []  # one statement each, except that the body of a `while` stays together
-                for st in stmts:
-                    if st.loops and units and units[-1][-1].loops and units[-1][-1].loops[0][0] == st.loops[0][0]:
-                        units[-1].append(st)
-                    else:
-                        units.append([st])
-            else:
-                units = [stmts]
-            for unit in units:
-                if not unit:
-                    continue
-                writes = {s.target.name for s in unit}
-                offreads = {
-                    e.name for s in unit for e in _stmt_field_reads(s)
-                    if (e.offset[0] != 0 or e.offset[1] != 0) and e.name in written_anywhere
-                }
-                if writes & offreads:
-                    raise UnsupportedStencil(
-                        f"{sorted(writes & offreads)} written and read at a horizontal offset inside one "
-                        f"{comp.order.value} interval block: columns are not independent")
-                if cur is not None and ((offreads & cur.written) or (writes & cur.offset_reads)):
-                    cur = None
-                if cur is None:
-                    cur = Stage()
-                    stages.append(cur)
-                if cur.nests and cur.nests[-1].block_id == (ci, bi):
-                    cur.nests[-1].stmts.extend(unit)
-                else:
-                    cur.nests.append(Nest(comp.order, block.interval, list(unit), (ci, bi)))
-                cur.written |= writes
-                cur.offset_reads |= offreads
-
-    # mapping, statement splitting, extents
-    for stage in stages:
-        column = False
-        for nest in stage.nests:
-            nest_writes = {s.target.name for s in nest.stmts}
-            if nest.order is not ir.LoopOrder.PARALLEL:
-                column = True
-            for s in nest.stmts:
-                for e in _stmt_field_reads(s):
-                    if (e.offset[2] != 0 or e.koffset is not None) and e.name in stage.written:
-                        column = True
-                        if nest.order is ir.LoopOrder.PARALLEL and e.name in nest_writes:
-                            nest.split_statements = True
-                            if any(x.loops for x in nest.stmts):
-                                raise UnsupportedStencil("a PARALLEL block with a `while` loop and a vertical dependency "
-                                                         "on its own writes")
-        stage.mapping = "column" if column else "ijk"
-        ext = None
-        for nest in stage.nests:
-            for s in nest.stmts:
-                ext = s.extent if ext is None else analysis._union(ext, s.extent)
-        stage.extent = ext or analysis.ZERO_EXTENT
-
-    # storage class of the remaining temporaries
-    temp_names = {t.name for t in stencil.temporaries}
-    where: Dict[str, Set[int]] = {}  # name -> ids of nests touching it
-    nest_list = [(si, n) for si, st in enumerate(stages) for n in st.nests]
-    bad_local: Set[str] = set()
-    for nid, (si, nest) in enumerate(nest_list):
-        defined: Set[str] = set()
-        for s in nest.stmts:
-            for e in _stmt_field_reads(s):
-                if e.name in temp_names:
-                    where.setdefault(e.name, set()).add(nid)
-                    if e.offset != (0, 0, 0) or e.koffset is not None or e.name not in defined or nest.split_statements:
-                        bad_local.add(e.name)
-            if s.target.name in temp_names:
-                where.setdefault(s.target.name, set()).add(nid)
-                defined.add(s.target.name)
-    local_names = {n for n in temp_names if n in where and n not in bad_local}
-    # a local that is written in one nest and never read anywhere is dead but harmless
-    scratch: Dict[str, Tuple[np.dtype, Extent2]] = {}
-    temp_extents = analysis.storage_extents(stencil, extents)
-    for t in stencil.temporaries:
-        if t.name in where and t.name not in local_names:
-            scratch[t.name] = (np.dtype(t.dtype), temp_extents[t.name])
-    # (SSA values from the inliner are usually thread-local; one that is still needed after a stage cut --
-    # e.g. by a run-time `if` further down -- is simply kept in scratch like any other temporary)
-
-    # register forwarding in column stages: a value read exactly one level behind the sweep stays in a
-    # register instead of being re-read from memory.  Exact only when (a) every vertical-offset read
-    # of the name in the stage is that one pattern and (b) its writers and those readers cover the same
-    # columns (otherwise a skipped write would leave a stale register).
-    forwarded: Dict[Tuple[int, str], int] = {}
-    for si, stage in enumerate(stages):
-        if stage.mapping != "column":
-            continue
-        patterns: Dict[str, Set[Tuple[ir.LoopOrder, Tuple[int, int, int]]]] = {}
-        extents_of: Dict[str, Set[Extent2]] = {}
-        for nest in stage.nests:
-            for s in nest.stmts:
-                if s.target.name in stage.written:
-                    extents_of.setdefault(s.target.name, set()).add(s.extent)
-                for e in _stmt_field_reads(s):
-                    if e.koffset is not None and e.name in stage.written:
-                        patterns.setdefault(e.name, set()).add((nest.order, ("variable",)))
-                    if e.offset[2] != 0 and e.name in stage.written:
-                        patterns.setdefault(e.name, set()).add((nest.order, e.offset))
-                        extents_of.setdefault(e.name, set()).add(s.extent)
-        unsafe = {s.target.name for nest in stage.nests for s in nest.stmts
-                  if s.mask is not None or s.region is not None or s.loops or s.target.offset != (0, 0, 0)}  # conditional / displaced writes
-        for name, pats in patterns.items():
-            if name in local_names or name in unsafe or len(extents_of.get(name, ())) != 1:
-                continue
-            if pats == {(ir.LoopOrder.FORWARD, (0, 0, -1))}:
-                forwarded[(si, name)] = -1
-            elif pats == {(ir.LoopOrder.BACKWARD, (0, 0, 1))}:
-                forwarded[(si, name)] = 1
-
-    # How each back-reading nest gets the register's first value, and which temporaries can live in
-    # registers alone.  "carried": the previous nest of the chain left it there (statically adjacent
-    # intervals, statically non-empty); "prime_if_prev_empty": adjacent, but the previous interval may be
-    # empty at run time; "prime": load the level behind the first one from memory.
-    def _static_length(iv: ir.Interval) -> Optional[int]:
-        return iv.end.offset - iv.start.offset if iv.start.level is iv.end.level else None
-
-    touched_in: Dict[str, Set[int]] = {}
-    for si, stage in enumerate(stages):
-        for nest in stage.nests:
-            for st in nest.stmts:
-                touched_in.setdefault(st.target.name, set()).add(si)
-                for e in _stmt_field_reads(st):
-                    touched_in.setdefault(e.name, set()).add(si)
-    prime: Dict[Tuple[int, int, str], Tuple[str, Optional[int]]] = {}
-    register_only: Set[str] = set()
-    for (si, name), back in forwarded.items():
-        stage = stages[si]
-        want = ir.LoopOrder.FORWARD if back == -1 else ir.LoopOrder.BACKWARD
-        needs_memory = name not in scratch or touched_in.get(name, set()) != {si}
-        prev: Optional[int] = None
-        for ni, nest in enumerate(stage.nests):
-            writes = [idx for idx, st in enumerate(nest.stmts) if st.target.name == name]
-            reads = [(idx, e) for idx, st in enumerate(nest.stmts) for e in _stmt_field_reads(st) if e.name == name]
-            if not writes and not reads:
-                continue
-            if nest.order is not want:
-                needs_memory = True
-                if writes:
-                    prev = None
-                continue
-            if any(e.offset == (0, 0, 0) and (not writes or idx <= writes[0]) for idx, e in reads):
-                needs_memory = True  # reads the current level before this iteration wrote it
-            if any(e.offset == (0, 0, back) for _, e in reads):
-                mode = "prime"
-                if prev is not None:
-                    piv = stage.nests[prev].interval
-                    adjacent = piv.end == nest.interval.start if back == -1 else piv.start == nest.interval.end
-                    if adjacent:
-                        n = _static_length(piv)
-                        mode = "carried" if (n is not None and n > 0) else "prime_if_prev_empty"
-                if mode != "carried":
-                    needs_memory = True
-                prime[(si, ni, name)] = (mode, prev)
-                if not writes:
-                    needs_memory = True  # the register is refilled from memory level by level
-            prev = ni
-        if not needs_memory:
-            register_only.add(name)
-    for name in register_only:
-        del scratch[name]
-
-    used: Set[str] = set()
-    for _, nest in nest_list:
-        for s in nest.stmts:
-            used.add(s.target.name)
-            for ex in ([c for _, c in s.loops] + ([s.value] if s.mask is None else [s.mask, s.value])):
-                for e in ir.walk(ex):
-                    if isinstance(e, (ir.FieldAccess, ir.ScalarAccess)):
-                        used.add(e.name)
-    api_fields = [f for f in stencil.fields if f.name in used]
-    params = [p for p in stencil.params if p.name in used]
-    return Plan(stencil, stages, {**extents.fields, **temp_extents}, local_names, scratch, forwarded, prime, register_only,
-                api_fields, params)
+from .stage_planner import (Nest, Plan, Stage, Stmt, UnsupportedStencil, _field_reads, _stmt_field_reads,  # noqa: F401
+                            inline_horizontal_temporaries, plan_stages)
 
 
 # ---------------------------------------------------------------------------------------------------

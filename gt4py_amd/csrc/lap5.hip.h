@@ -52,7 +52,7 @@ __device__ __forceinline__ T lap5_expr(T c, T w, T e, T s, T n) {
 }
 
 // One strip: columns [bx*BLOCK*VEC, ...) x rows [j0, min(j0+LJ, dJ)) of level k.
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK>
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int NTL = 0>
 __device__ __forceinline__ void lap5_strip_tile(const View<const T>& in, const View<T>& out, int dI, int dJ,
                                                 unsigned bx, int j0, unsigned k) {
     const unsigned lane = threadIdx.x & 63;
@@ -77,7 +77,20 @@ __device__ __forceinline__ void lap5_strip_tile(const View<const T>& in, const V
         int jr = j0 - 1 + t;
         jr = jr > dJ ? dJ : jr;
         roff[t] = (int64_t)jr * in.sj;
-        vload<T, VEC>(col + roff[t], r[t]);
+        // NTL: rows no other strip needs (t = 2 .. LJ-1) may be loaded non-temporally so that they do not
+        // displace the rows neighbouring strips share in L2 (1 = those rows only, 2 = every row)
+        if constexpr (NTL == 2 || (NTL == 1 && VEC == 2 && sizeof(T) == 8)) {
+            if (NTL == 2 || (t >= 2 && t <= LJ - 1)) {
+                using V = typename VecT<T, VEC>::type;
+                const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(col + roff[t]));
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) r[t][q] = v[q];
+            } else {
+                vload<T, VEC>(col + roff[t], r[t]);
+            }
+        } else {
+            vload<T, VEC>(col + roff[t], r[t]);
+        }
     }
     T w[LJ + 2], e[LJ + 2];
 #pragma unroll
@@ -102,7 +115,7 @@ __device__ __forceinline__ void lap5_strip_tile(const View<const T>& in, const V
     }
 }
 
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG = 0>
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG = 0, int NTL = 0>
 __global__ void __launch_bounds__(BLOCK)
 lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x, unsigned tiles_y) {
     // XCDG > 0: runs of XCDG consecutive strips share an XCD (private L2), so the halo rows they
@@ -113,7 +126,7 @@ lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_
     const unsigned bx = b % tiles_x;
     const unsigned by = (b / tiles_x) % tiles_y;
     const unsigned k = b / (tiles_x * tiles_y);
-    lap5_strip_tile<T, W, VARIANT, VEC, LJ, BLOCK>(in, out, dI, dJ, bx, (int)by * LJ, k);
+    lap5_strip_tile<T, W, VARIANT, VEC, LJ, BLOCK, NTL>(in, out, dI, dJ, bx, (int)by * LJ, k);
 }
 
 // Up to two single J rows (row_a, row_b) of every level in ONE launch: the boundary strips of a

@@ -201,6 +201,20 @@ static void section_copy() {
 }
 
 // ---------------------------------------------------------------------------------------------
+template <int LJ, int BLOCK, int XCD, int NTL>
+static void lap_ntl_variant(const DevField<double>& in, DevField<double>& out, int dI, int dJ, int dK, const char* tag) {
+    constexpr int VEC = 2;
+    const unsigned tx = (unsigned)cdiv(dI, BLOCK * VEC), ty = (unsigned)cdiv(dJ, LJ);
+    const unsigned n = tx * ty * dK;
+    char cfg[96];
+    snprintf(cfg, sizeof cfg, "%s strip LJ=%d block=%d xcd=%d nt-loads=%d", tag, LJ, BLOCK, (int)XCD, NTL);
+    const double ms = time_ms([&](int) {
+        hipLaunchKernelGGL((lap5_strip_kernel<double, double, 0, VEC, LJ, BLOCK, XCD, NTL>), dim3(n), dim3(BLOCK), 0, 0,
+                           in.cview(), out.view(), dI, dJ, tx, ty);
+    }, 20);
+    report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+}
+
 template <int LJ, int BLOCK, int XCD = 0>
 static void lap_variant(const DevField<double>& in, DevField<double>& out, int dI, int dJ, int dK, const char* tag) {
     constexpr int VEC = 2;
@@ -241,6 +255,12 @@ static void lap_suite(int dI, int dJ, int dK, int64_t extra_pitch, const char* t
         lap_variant<8, 256, 64>(in, out, dI, dJ, dK, tag);
         lap_variant<4, 256, 4>(in, out, dI, dJ, dK, tag);
         lap_variant<4, 256, 16>(in, out, dI, dJ, dK, tag);
+        lap_ntl_variant<8, 256, 4, 0>(in, out, dI, dJ, dK, tag);
+        lap_ntl_variant<8, 256, 4, 1>(in, out, dI, dJ, dK, tag);
+        lap_ntl_variant<8, 256, 4, 2>(in, out, dI, dJ, dK, tag);
+        if (rep == 0) printf("           check nt-loads vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
+        lap_ntl_variant<8, 256, 8, 1>(in, out, dI, dJ, dK, tag);
+        lap_ntl_variant<8, 256, 0, 1>(in, out, dI, dJ, dK, tag);
         lap_variant<12, 256>(in, out, dI, dJ, dK, tag);
         lap_variant<16, 256>(in, out, dI, dJ, dK, tag);
         lap_variant<16, 256, 4>(in, out, dI, dJ, dK, tag);

@@ -515,6 +515,23 @@ int main(int argc, char** argv) {
     if (on("copy")) section_copy();
     if (on("lap")) section_lap();
     if (!want.empty() && on("lap512")) lap_suite(512, 512, 512, 0, "512^3");
+    if (!want.empty() && on("lapalign")) {
+        // row alignment of the storage preset: 32 items (256 B, the gt:gpu value) vs 16 items (128 B = one L2
+        // line: the east halo of a row and the west halo of the next then share a line)
+        for (int align : {32, 16, 8}) {
+            const int dI = 512, dJ = 512, dK = 512;
+            DevField<double> in(dI, dJ, dK, 1, 1, align, 0), out(dI, dJ, dK, 1, 1, align, 0);
+            fill(in, 1337, -1.0, 1.0);
+            CK(hipMemset(out.raw, 0, out.bytes));
+            const int64_t d[3] = {dI, dJ, dK};
+            char cfg[64];
+            for (int rep = 0; rep < 3; ++rep) {
+                const double ms = time_ms([&](int) { lap5_launch_variant<double, double, 0>(in.cview(), out.view(), d, 0); }, 20);
+                snprintf(cfg, sizeof cfg, "512^3 library default, rows aligned to %d items (pitch %lld)", align, (long long)in.sj);
+                report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+            }
+        }
+    }
     if (on("hdiff")) section_hdiff();
     if (on("tridiag")) section_tridiag();
     if (!want.empty() && on("events")) section_events();

@@ -233,6 +233,9 @@ int gt4mi_halo_exchange(gt4mi_halo_plan* plan, const gt4mi_field* field, void* s
 
 int gt4mi_halo_exchange_fork(gt4mi_halo_plan* plan, void* main_stream) {
     if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_exchange_fork: null plan");
+    // first use with this stream: make sure the side stream does not share its hardware queue (one-off,
+    // synchronising probe) -- otherwise the "overlapped" exchange simply queues behind the interior kernel
+    if (int rc = gt4mi::ensure_concurrent_stream(plan, static_cast<hipStream_t>(main_stream))) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->ready, static_cast<hipStream_t>(main_stream)));
     plan->forked = true;
     return GT4MI_OK;

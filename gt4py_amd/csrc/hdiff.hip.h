@@ -54,12 +54,17 @@ __device__ __forceinline__ T hd_out(T in0, PW coeff, W flx, W flxm, W fly, W fly
 // served by L1/L2 for the overlapping neighbourhoods.  Used for non-I-contiguous layouts and as
 // the in-library cross-check of the J-march kernel.
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD>
+// TRANSPOSED = true: lanes run along J and the 4 sub-rows of a workgroup along I -- for domains only a few
+// columns wide (the west / east boundary strips of an IJ-decomposed apply), where lanes along I would
+// leave 62 of 64 lanes idle.  Same arithmetic per point.
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, bool TRANSPOSED = false>
 __global__ void __launch_bounds__(256)
 hdiff_generic_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scalar, int dI,
                      int dJ, int dK) {
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int a = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int i = TRANSPOSED ? b : a;
+    const int j = TRANSPOSED ? a : b;
     if (i >= dI || j >= dJ) return;
     const int64_t si = in.si, sj = in.sj;
     for (int k = blockIdx.z; k < dK; k += gridDim.z) {
@@ -101,8 +106,17 @@ template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD>
 inline int hdiff_launch(const View<const T>& in, const View<T>& out, const View<const T>& cf,
                         PW coeff_scalar, const int64_t d[3], hipStream_t stream) {
     const bool contiguous = in.si == 1 && out.si == 1 && (!COEFF_FIELD || cf.si == 1);
-    if (contiguous && hdiff_jmarch_enabled()) {
+    // Domains only a few columns wide (the west / east boundary strips of an IJ-decomposed apply) would use
+    // 2 of the 128-256 columns of a wave-wide tile: one thread per point is 5-10x faster there.
+    const bool skinny = d[0] < 32;
+    if (contiguous && !skinny && hdiff_jmarch_enabled()) {
         return hdiff_launch_jmarch<T, W, PW, LIMITER, COEFF_FIELD>(in, out, cf, coeff_scalar, d, stream);
+    }
+    if (skinny) {
+        dim3 grid((unsigned)cdiv(d[1], 64), (unsigned)cdiv(d[0], 4), (unsigned)(d[2] < 65535 ? d[2] : 65535));
+        hipLaunchKernelGGL((hdiff_generic_kernel<T, W, PW, LIMITER, COEFF_FIELD, true>), grid, dim3(256), 0, stream, in,
+                           out, cf, coeff_scalar, (int)d[0], (int)d[1], (int)d[2]);
+        return GT4MI_OK;
     }
     dim3 grid((unsigned)cdiv(d[0], 64), (unsigned)cdiv(d[1], 4),
               (unsigned)(d[2] < 65535 ? d[2] : 65535));

@@ -183,7 +183,8 @@ template <typename T, typename W, int VARIANT>
 inline int lap5_launch_variant(const View<const T>& in, const View<T>& out, const int64_t d[3],
                                hipStream_t stream) {
     constexpr int VMAX = 16 / sizeof(T);
-    if (in.si == 1 && out.si == 1) {
+    // (domains only a few columns wide -- west / east boundary strips -- go to the thread-per-point kernel)
+    if (in.si == 1 && out.si == 1 && d[0] >= 16) {
         const bool vec = vec_ok(in, VMAX) && vec_ok(out, VMAX) && (d[0] % VMAX == 0);
         if (vec) {
             const int64_t lanes = d[0] / VMAX;

@@ -37,14 +37,17 @@ def overlapped_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequen
     for name, ex in exchange.items():
         if not isinstance(ex, NativeHaloExchanger):
             events.append((ex, ex.start(arguments[name].tensor)))
-    for _, ex in native:  # fork first, enqueue the exchange after the interior kernel (GPU busy meanwhile)
+    # The exchange is enqueued BEFORE the interior kernel: its pack and send/recv kernels get onto the device
+    # while it is idle.  Once the interior kernel saturates HBM, the few workgroups of a send/recv kernel see
+    # loaded-memory latency and crawl (measured: 13 us alone, 170 us next to a 185 us hdiff interior), so
+    # whatever finishes before that is a gain (profiles/r1_dist_hdiff_rehearsal.log).
+    for name, ex in native:  # pack + RCCL + unpack on the side stream inside one C call
         ex.fork()
+        ex.begin(arguments[name])
+        events.append((ex, None))
     (shift, sub), strips = decomp.interior_and_strips()
     if all(d > 0 for d in sub):
         stencil.run(_domain_=tuple(sub), _origin_=_shifted(origin, shift), exec_info=None, **arguments)
-    for name, ex in native:  # pack + RCCL + unpack on the side stream inside one C call
-        ex.begin(arguments[name])
-        events.append((ex, None))
     for ex, done in events:
         if done is None:
             ex.end()

@@ -294,13 +294,50 @@ def main() -> None:
             if not ok:
                 transport, comm = "torch", None
                 print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
-        # ghost depth = steps served by one exchange (communication-avoiding time stepping); the
-        # independent-apply and torch-transport modes exchange every step with depth 1
-        # Depth 2 by default: in the 1-GPU rehearsal depth 4 is fastest (65.8 vs 72.5 vs 83.8 us per
-        # 512x64x512 step for depth 4 / 2 / 1), but message size grows with depth while only ONE
-        # interior kernel covers the transfer, and real xGMI links are slower than the rehearsal's
-        # self-copy; depth 2 is the robust middle (profiles/r1_dist_step_timeline.txt).
-        halo = max(1, int(os.environ.get("GT4MI_BENCH_HALO", "2"))) if (transport == "native" and mode == "timestep") else 1
+        # ghost depth = steps served by one exchange (communication-avoiding time stepping) and whether that
+        # exchange runs next to the last step's interior kernel or after a full-domain kernel.  Which
+        # combination wins depends on how long the links take: in the 1-GPU rehearsal (on-device self-copy)
+        # "depth 4, not overlapped" is fastest (58.9 us per 512x64x512 step vs 70.4 for depth 2 overlapped,
+        # profiles/r1_dist_selfloop_seq_vs_overlap.log), on slow links overlap and a smaller depth should win.
+        # So unless pinned through the environment, a short calibration BEFORE the warm-up picks it, with all
+        # ranks agreeing on the slowest rank's timings.
+        calibration = None
+        overlap = os.environ.get("GT4MI_BENCH_OVERLAP", "1") != "0"
+        halo = 1
+        if transport == "native" and mode == "timestep":
+            pinned = "GT4MI_BENCH_HALO" in os.environ or "GT4MI_BENCH_OVERLAP" in os.environ
+            halo = max(1, int(os.environ.get("GT4MI_BENCH_HALO", "2")))
+            if not pinned:
+                calibration = {}
+                for cand_halo in (1, 2, 4):
+                    if (grid[1] > 1 and total[1] // grid[1] < 2 * cand_halo) or (grid[0] > 1 and total[0] // grid[0] < 2 * cand_halo):
+                        continue
+                    cdec = Decomposition(total, grid, rank, halo=cand_halo,
+                                         periodic=(False, True) if selfloop else (False, False))
+                    cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
+                    for cand_overlap in (True, False):
+                        ca, cb = cpairs[0][0], cpairs[1][0]
+                        ca.tensor.mul_(1e-150)
+                        cex = NativeHaloExchanger(cdec, np.float64, comm)
+                        cstep = cex.make_time_stepper_lap5(ca, cb, cdec.origin, overlap=cand_overlap)
+                        for _ in range(2 * cand_halo):
+                            cstep()
+                        torch.cuda.synchronize()
+                        if distributed:
+                            dist.barrier()
+                        t0 = time.perf_counter()
+                        for _ in range(24):
+                            cstep()
+                        torch.cuda.synchronize()
+                        dt = torch.tensor([(time.perf_counter() - t0) / 24], dtype=torch.float64, device="cuda")
+                        if distributed:
+                            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                        calibration[f"halo{cand_halo}_{'overlap' if cand_overlap else 'sequential'}"] = round(float(dt.item()) * 1e3, 5)
+                        cex.close()
+                    del cpairs
+                torch.cuda.empty_cache()
+                best = min(calibration, key=calibration.get)
+                halo, overlap = int(best.split("_")[0][4:]), best.endswith("overlap")
         dec = Decomposition(total, grid, rank, halo=halo, periodic=(False, True) if selfloop else (False, False))
         origin = {"inp": dec.origin, "out": dec.origin}
         pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank, origin=dec.origin)
@@ -317,7 +354,7 @@ def main() -> None:
                 # The amplitude starts at 1e-150 so that ~8x growth per step stays finite for 600 steps.
                 a, b = pairs[0][0], pairs[1][0]
                 a.tensor.mul_(1e-150)
-                stepper = exchangers[0].make_time_stepper_lap5(a, b, origin["inp"])
+                stepper = exchangers[0].make_time_stepper_lap5(a, b, origin["inp"], overlap=overlap)
 
                 def step(i):
                     stepper()
@@ -344,7 +381,9 @@ def main() -> None:
                                  and transport == "native" else "independent applies, ghost cells exchanged every step"),
                   "grid": list(GRID), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(local_domain),
                   "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange,
-                  "transport": transport, "mode": mode, "selfloop": bool(selfloop)}
+                  "transport": transport, "mode": mode, "selfloop": bool(selfloop),
+                  "exchange_overlapped_with_interior": bool(overlap) if mode == "timestep" and transport == "native" else None,
+                  "calibration_ms_per_step": calibration}
 
     def barrier():
         if distributed:

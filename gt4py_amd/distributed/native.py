@@ -149,7 +149,7 @@ class NativeHaloExchanger:
         v = self._lib.gt4mi_halo_plan_concurrent(self._plan)
         return None if v == 2 else bool(v)
 
-    def make_time_stepper_lap5(self, field_a, field_b, origin: Sequence[int], variant: int = 0):
+    def make_time_stepper_lap5(self, field_a, field_b, origin: Sequence[int], variant: int = 0, overlap: bool = True):
         """Pre-bind the pipelined time-stepping Laplacian: call n computes b = lap(a) for even n and
         a = lap(b) for odd n (gt4mi_dist_lap5_f64_wide).  With a ghost depth H = ``decomp.halo`` one
         exchange serves H steps: step n of a cycle (phase n % H) computes the local domain grown by
@@ -158,6 +158,9 @@ class NativeHaloExchanger:
         to its interior kernel.  H == 1 is the plain pipelined exchange-every-step scheme.  Results
         are bit-identical to the undecomposed run for every H (the redundant rows evaluate the same
         expression on the same values).  Primes the pipeline with one exchange of ``field_a``.
+        ``overlap=False`` keeps everything on the caller's stream: the last phase is one full-domain kernel
+        followed by the exchange (pack, send/recv, unpack) -- no boundary strips, no side stream, nothing for a
+        send/recv kernel to compete with; which form wins depends on how long the links take.
         Returns a zero-argument callable; ``callable.result()`` is the field written last."""
         if self.itemsize != 8:
             raise ValueError("the native Laplacian time stepper needs fp64 fields")
@@ -169,12 +172,22 @@ class NativeHaloExchanger:
         self.begin(field_a)  # ghost cells of the first input
         state = {"n": 0}
 
+        lap, exchange = self._lib.gt4mi_lap5_f64, self._lib.gt4mi_halo_exchange
+        if not overlap:
+            self.end()  # the priming exchange is joined here; later ones run on the caller's stream
+
         def step():
             n = state["n"]
             src, dst = (ra, rb) if n % 2 == 0 else (rb, ra)
-            rc = fn(plan, dom, src, dst, variant, sides, halo, n % halo, _stream_ptr())
-            if rc:
-                _lib.check("gt4mi_dist_lap5_f64_wide", rc)
+            stream = _stream_ptr()
+            if overlap or n % halo < halo - 1:
+                rc = fn(plan, dom, src, dst, variant, sides, halo, n % halo, stream)
+                if rc:
+                    _lib.check("gt4mi_dist_lap5_f64_wide", rc)
+            else:
+                rc = lap(dom, src, dst, variant, 0, stream, None) or exchange(plan, dst, stream)
+                if rc:
+                    _lib.check("gt4mi_lap5_f64 / gt4mi_halo_exchange", rc)
             state["n"] = n + 1
 
         step.result = lambda: field_b if state["n"] % 2 == 1 else field_a  # type: ignore[attr-defined]

@@ -165,10 +165,11 @@ def test_pipelined_time_stepping(comm, periodic):
                                                                0, ex2.sides, None))
 
 
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("nsteps", [1, 4, 7])
-@pytest.mark.parametrize("halo", [2, 3, 4])
+@pytest.mark.parametrize("halo", [1, 2, 3, 4])
 @pytest.mark.parametrize("periodic", [(False, True), (True, True)])
-def test_wide_halo_time_stepping(comm, periodic, halo, nsteps):
+def test_wide_halo_time_stepping(comm, periodic, halo, nsteps, overlap):
     """gt4mi_dist_lap5_f64_wide: ghost regions `halo` deep, one exchange per `halo` steps, redundant
     rows computed in between; the compute domain after n steps equals n oracle steps with a fresh
     periodic wrap every step."""
@@ -186,7 +187,7 @@ def test_wide_halo_time_stepping(comm, periodic, halo, nsteps):
     a = gt_storage.from_array(host, backend="hip:mi300", aligned_index=o)
     b = gt_storage.from_array(host * 0 + 7.0, backend="hip:mi300", aligned_index=o)
     ex = NativeHaloExchanger(dec, np.float64, comm)
-    step = ex.make_time_stepper_lap5(a, b, o)
+    step = ex.make_time_stepper_lap5(a, b, o, overlap=overlap)
     for _ in range(nsteps):
         step()
     torch.cuda.synchronize()

@@ -10,8 +10,8 @@ from typing import Any, Dict, Mapping, Sequence
 from .halo import Decomposition, HaloExchanger, HipPacker, choose_process_grid, halo_boxes, scatter_global
 from .native import NativeComm, NativeHaloExchanger
 
-__all__ = ["Decomposition", "HaloExchanger", "HipPacker", "NativeComm", "NativeHaloExchanger", "choose_process_grid",
-           "halo_boxes", "overlapped_apply", "scatter_global"]
+__all__ = ["Decomposition", "HaloExchanger", "HipPacker", "NativeComm", "NativeHaloExchanger", "TunedApply",
+           "choose_process_grid", "halo_boxes", "overlapped_apply", "scatter_global", "sequential_apply"]
 
 
 def _shifted(origin: Mapping[str, Sequence[int]], shift: Sequence[int]) -> Dict[str, tuple]:
@@ -55,3 +55,63 @@ def overlapped_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequen
             ex.finish(done)
     for shift, sub in strips:
         stencil.run(_domain_=tuple(sub), _origin_=_shifted(origin, shift), exec_info=None, **arguments)
+
+
+def sequential_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequence[int]], arguments: Dict[str, Any],
+                     exchange: Mapping[str, Any]) -> None:
+    """The same distributed apply without overlap: refresh the ghost cells, then ONE launch over the whole local
+    domain, all on the caller's stream.  No boundary strips and nothing for the send/recv kernels to compete
+    with -- faster than ``overlapped_apply`` whenever the exchange is short next to the strips it saves
+    (profiles/r1_dist_hdiff_rehearsal.log)."""
+    for name, ex in exchange.items():
+        if isinstance(ex, NativeHaloExchanger):
+            ex.exchange(arguments[name])
+        else:
+            ex.finish(ex.start(arguments[name].tensor))
+    stencil.run(_domain_=tuple(decomp.local_domain), _origin_={n: tuple(o) for n, o in origin.items()}, exec_info=None,
+                **arguments)
+
+
+class TunedApply:
+    """Distributed apply that measures both forms once and keeps the faster one.
+
+    Which of ``overlapped_apply`` / ``sequential_apply`` wins depends on the stencil (how expensive its strips
+    are), the local domain and the links, none of which is known up front.  ``calibrate()`` times a few
+    applies of each on the current stream; with an initialised ``torch.distributed`` group every rank adopts
+    the choice that is best for the slowest rank.  Calibration applies are real applies (they overwrite the
+    outputs with the same values an ordinary apply would)."""
+
+    def __init__(self, stencil, decomp: Decomposition, origin: Mapping[str, Sequence[int]], exchange: Mapping[str, Any]):
+        self.stencil, self.decomp, self.origin, self.exchange = stencil, decomp, origin, exchange
+        self.choice = None
+        self.timings_ms: Dict[str, float] = {}
+
+    def calibrate(self, arguments: Dict[str, Any], iters: int = 8) -> str:
+        import time
+
+        import torch
+
+        group = torch.distributed.is_available() and torch.distributed.is_initialized()
+        forms = {"overlapped": overlapped_apply, "sequential": sequential_apply}
+        for name, fn in forms.items():
+            for _ in range(2):
+                fn(self.stencil, self.decomp, self.origin, arguments, self.exchange)
+            torch.cuda.synchronize()
+            if group:
+                torch.distributed.barrier()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn(self.stencil, self.decomp, self.origin, arguments, self.exchange)
+            torch.cuda.synchronize()
+            dt = torch.tensor([(time.perf_counter() - t0) / iters * 1e3], dtype=torch.float64, device="cuda")
+            if group:
+                torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+            self.timings_ms[name] = float(dt.item())
+        self.choice = min(self.timings_ms, key=self.timings_ms.get)
+        return self.choice
+
+    def __call__(self, arguments: Dict[str, Any]) -> None:
+        if self.choice is None:
+            self.calibrate(arguments)
+        fn = overlapped_apply if self.choice == "overlapped" else sequential_apply
+        fn(self.stencil, self.decomp, self.origin, arguments, self.exchange)

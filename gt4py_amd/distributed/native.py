@@ -82,20 +82,30 @@ def _field_struct(array, origin=(0, 0, 0)) -> _lib.Field:
 class NativeHaloExchanger:
     """Two-phase ghost-cell exchange of one field shape through a native plan (see halo.halo_boxes)."""
 
+    @staticmethod
+    def message_tables(decomp: Decomposition):
+        """(sends, recvs) of one rank as plain tuples (peer, phase, lo, extent), in the order RCCL sees them.
+
+        RCCL matches the k-th send to a peer with the k-th receive posted for that peer inside one group, so
+        the ORDER is part of the protocol: sends go low side first, receives high side first -- with a
+        periodic axis of 1 or 2 ranks both messages of a phase go to the same peer, and my low-side face must
+        land in the peer's HIGH-side ghost zone.  Pure Python (checked for whole process grids on the CPU in
+        tests/test_distributed.py: every send has a receive of the same size waiting for it)."""
+        sends, recvs = [], []
+        for p, phase in enumerate(halo_boxes(decomp)):
+            for peer, send_lo, _, ext in phase:
+                sends.append((int(peer), p, tuple(int(v) for v in send_lo), tuple(int(v) for v in ext)))
+            for peer, _, recv_lo, ext in reversed(phase):
+                recvs.append((int(peer), p, tuple(int(v) for v in recv_lo), tuple(int(v) for v in ext)))
+        return sends, recvs
+
     def __init__(self, decomp: Decomposition, dtype, comm: NativeComm):
         self.decomp = decomp
         self.comm = comm
         self.itemsize = np.dtype(dtype).itemsize
-        phases = halo_boxes(decomp)
-        sends, recvs = [], []
-        for p, phase in enumerate(phases):
-            for peer, send_lo, _, ext in phase:  # sends: low side first
-                sends.append(_lib.HaloMsg.make(peer, p, send_lo, ext))
-            # receives in the opposite side order: with a periodic 2-rank (or 1-rank) axis both
-            # messages go to the same peer, and the k-th send pairs with the k-th receive there --
-            # my low-side face must land in the peer's HIGH-side halo.
-            for peer, _, recv_lo, ext in reversed(phase):
-                recvs.append(_lib.HaloMsg.make(peer, p, recv_lo, ext))
+        send_table, recv_table = self.message_tables(decomp)
+        sends = [_lib.HaloMsg.make(*m) for m in send_table]
+        recvs = [_lib.HaloMsg.make(*m) for m in recv_table]
         self.bytes_per_exchange = sum(int(np.prod(tuple(m.extent))) for m in sends) * self.itemsize
         SendArr, RecvArr = _lib.HaloMsg * max(len(sends), 1), _lib.HaloMsg * max(len(recvs), 1)
         plan = ctypes.c_void_p()

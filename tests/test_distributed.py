@@ -170,3 +170,66 @@ def test_gloo_world_size_2_laplacian(grid, tmp_path):
     ok, nbytes = np.load(tmp_path / "ok.npy")
     assert ok == 1
     assert nbytes > 0
+
+
+@pytest.mark.parametrize("grid,periodic", [((1, 8), (False, False)), ((4, 2), (False, False)), ((2, 2), (True, True)),
+                                           ((1, 2), (False, True)), ((1, 1), (True, True)), ((2, 4), (True, False)),
+                                           ((1, 4), (False, True))])
+@pytest.mark.parametrize("halo", [1, 2])
+def test_native_message_tables_pair_up_across_ranks(grid, periodic, halo):
+    """The native (RCCL) exchanger cannot run on more than one rank here, but its protocol can be checked:
+    simulate every rank's message table and deliver the k-th send of rank r to peer p into p's k-th receive
+    from r (RCCL's matching rule inside one group).  Every message must find a receive of the same extent,
+    nothing may be left over, and after both phases every rank's ghost cells must hold the values of the
+    periodic / bounded global array -- exactly what the torch transport is tested for above."""
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+
+    global_domain = (16 * grid[0], 12 * grid[1], 3)
+    n = grid[0] * grid[1]
+    decs = [Decomposition(global_domain, grid, r, halo, periodic=periodic) for r in range(n)]
+    rng = np.random.default_rng(0)
+    gi, gj, gk = global_domain
+    full = rng.uniform(-1, 1, (gi + 2 * halo, gj + 2 * halo, gk))
+    # periodic axes: ghost cells of the global array wrap around; bounded axes keep their own values
+    if periodic[0]:
+        full[:halo], full[-halo:] = full[-2 * halo:-halo].copy(), full[halo:2 * halo].copy()
+    if periodic[1]:
+        full[:, :halo], full[:, -halo:] = full[:, -2 * halo:-halo].copy(), full[:, halo:2 * halo].copy()
+    locals_ = []
+    for d in decs:
+        i0, j0 = d.offset[0], d.offset[1]
+        li, lj, _ = d.local_domain
+        want = full[i0:i0 + li + 2 * halo, j0:j0 + lj + 2 * halo].copy()
+        have = want.copy()
+        nb = d.neighbours
+        # wipe the ghost cells that a neighbour is going to deliver
+        if nb["W"] is not None:
+            have[:halo] = np.nan
+        if nb["E"] is not None:
+            have[-halo:] = np.nan
+        if nb["S"] is not None:
+            have[:, :halo] = np.nan
+        if nb["N"] is not None:
+            have[:, -halo:] = np.nan
+        locals_.append((have, want))
+    tables = [NativeHaloExchanger.message_tables(d) for d in decs]
+    for phase in (0, 1):
+        mailbox = {}
+        for r, (sends, _) in enumerate(tables):
+            for peer, ph, lo, ext in sends:
+                if ph != phase:
+                    continue
+                box = locals_[r][0][lo[0]:lo[0] + ext[0], lo[1]:lo[1] + ext[1], lo[2]:lo[2] + ext[2]].copy()
+                mailbox.setdefault((r, peer), []).append(box)
+        for r, (_, recvs) in enumerate(tables):
+            for peer, ph, lo, ext in recvs:
+                if ph != phase:
+                    continue
+                queue = mailbox.get((peer, r))
+                assert queue, f"rank {r} waits for a message from {peer} that is never sent (phase {phase})"
+                box = queue.pop(0)
+                assert box.shape == tuple(ext), (r, peer, phase, box.shape, ext)
+                locals_[r][0][lo[0]:lo[0] + ext[0], lo[1]:lo[1] + ext[1], lo[2]:lo[2] + ext[2]] = box
+        assert all(not q for q in mailbox.values()), f"unmatched sends in phase {phase}"
+    for r, (have, want) in enumerate(locals_):
+        np.testing.assert_array_equal(have, want, err_msg=f"rank {r}")

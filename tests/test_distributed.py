@@ -233,3 +233,73 @@ def test_native_message_tables_pair_up_across_ranks(grid, periodic, halo):
         assert all(not q for q in mailbox.values()), f"unmatched sends in phase {phase}"
     for r, (have, want) in enumerate(locals_):
         np.testing.assert_array_equal(have, want, err_msg=f"rank {r}")
+
+
+@pytest.mark.parametrize("grid", [(1, 4), (2, 2), (1, 8)])
+@pytest.mark.parametrize("halo,nsteps", [(1, 3), (2, 5), (3, 7), (4, 8)])
+def test_wide_halo_scheme_model_on_bounded_grids(grid, halo, nsteps):
+    """Numpy model of gt4mi_dist_lap5_f64_wide over a whole NON-periodic process grid (ranks at the physical
+    boundary have neighbours on one side only -- a case the 1-GPU self-loop tests cannot reach): phase p of a
+    cycle computes the local domain grown by halo-1-p cells towards every side that HAS a neighbour, the last
+    phase exchanges `halo`-deep faces through the native message tables.  After n steps the assembled field
+    must equal n steps on the undecomposed array (whose own ghost ring is a fixed boundary condition)."""
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from oracle import ref_numpy as R
+
+    H = halo
+    gd = (12 * grid[0] + 0, 10 * grid[1], 2)
+    n = grid[0] * grid[1]
+    decs = [Decomposition(gd, grid, r, H) for r in range(n)]
+    rng = np.random.default_rng(3)
+    full = rng.uniform(-1, 1, (gd[0] + 2 * H, gd[1] + 2 * H, gd[2])) * 1e-3
+
+    # reference: n steps on the global array; only its compute domain changes
+    u, v = full.copy(), full.copy()
+    core = (slice(H - 1, -(H - 1)) if H > 1 else slice(None),) * 2 + (slice(None),)
+    for _ in range(nsteps):
+        R.laplacian(u[core], v[core])  # origin (1,1,0) of the depth-1 view = compute domain of the global array
+        u, v = v, u
+    want = u
+
+    def exchange(fields):
+        tables = [NativeHaloExchanger.message_tables(d) for d in decs]
+        for phase in (0, 1):
+            mailbox = {}
+            for r, (sends, _) in enumerate(tables):
+                for peer, ph, lo, ext in sends:
+                    if ph == phase:
+                        mailbox.setdefault((r, peer), []).append(
+                            fields[r][lo[0]:lo[0] + ext[0], lo[1]:lo[1] + ext[1], lo[2]:lo[2] + ext[2]].copy())
+            for r, (_, recvs) in enumerate(tables):
+                for peer, ph, lo, ext in recvs:
+                    if ph == phase:
+                        fields[r][lo[0]:lo[0] + ext[0], lo[1]:lo[1] + ext[1], lo[2]:lo[2] + ext[2]] = mailbox[(peer, r)].pop(0)
+
+    a, b = [], []
+    for d in decs:
+        i0, j0 = d.offset[0], d.offset[1]
+        li, lj, _ = d.local_domain
+        a.append(full[i0:i0 + li + 2 * H, j0:j0 + lj + 2 * H].copy())
+        b.append(full[i0:i0 + li + 2 * H, j0:j0 + lj + 2 * H].copy())
+    # (the initial ghost cells are already right: they were cut from the global array)
+    src, dst = a, b
+    for step in range(nsteps):
+        p = step % H
+        ext = H - 1 - p
+        for r, d in enumerate(decs):
+            nb = d.neighbours
+            li, lj, _ = d.local_domain
+            lo_i = H - (ext if nb["W"] is not None else 0)
+            hi_i = H + li + (ext if nb["E"] is not None else 0)
+            lo_j = H - (ext if nb["S"] is not None else 0)
+            hi_j = H + lj + (ext if nb["N"] is not None else 0)
+            view = (slice(lo_i - 1, hi_i + 1), slice(lo_j - 1, hi_j + 1), slice(None))
+            R.laplacian(src[r][view], dst[r][view])
+        if ext == 0:
+            exchange(dst)
+        src, dst = dst, src
+    for r, d in enumerate(decs):
+        i0, j0 = d.offset[0], d.offset[1]
+        li, lj, _ = d.local_domain
+        np.testing.assert_array_equal(src[r][H:H + li, H:H + lj], want[H + i0:H + i0 + li, H + j0:H + j0 + lj],
+                                      err_msg=f"rank {r}")

@@ -241,3 +241,77 @@ def test_sequential_and_tuned_apply_match_the_overlapped_form(comm):
         torch.cuda.synchronize()
         assert np.array_equal(d_out.get(), want), form
         ex.close()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("side", ["N", "S"])
+@pytest.mark.parametrize("halo", [1, 2, 3])
+def test_one_sided_rank(comm, halo, side, overlap):
+    """A rank with a neighbour on ONE J side only (what ranks 0 and N-1 of a bounded 1xN grid are): the plan
+    delivers that side's ghost rows (here from the rank's own opposite rows, the only peer a 1-GPU box has),
+    the other side is a physical boundary whose ghost rows never change.  Checked against the same scheme
+    written in numpy with the oracle's Laplacian."""
+    import ctypes
+
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from oracle import ref_numpy as R
+
+    H = halo
+    gd = (40, 24, 3)
+    dec = Decomposition(gd, (1, 1), 0, H, periodic=(False, True))
+    ex = NativeHaloExchanger(dec, np.float64, comm)
+    # replace the two-sided periodic plan by a one-sided one
+    ex.close()
+    li, lj, lk = gd
+    # a rank sends the face that lies on its neighbour's side (the overlapped step computes exactly those rows
+    # before packing); with itself as the only available peer, that face comes back as its own ghost rows
+    if side == "N":  # my last H rows -> my N ghost rows
+        send = _lib.HaloMsg.make(0, 1, (0, lj, 0), (li + 2 * H, H, lk))
+        recv = _lib.HaloMsg.make(0, 1, (0, H + lj, 0), (li + 2 * H, H, lk))
+        sides = 8
+    else:  # my first H rows -> my S ghost rows
+        send = _lib.HaloMsg.make(0, 1, (0, H, 0), (li + 2 * H, H, lk))
+        recv = _lib.HaloMsg.make(0, 1, (0, 0, 0), (li + 2 * H, H, lk))
+        sides = 4
+    plan = ctypes.c_void_p()
+    lib = _lib.load()
+    _lib.check("gt4mi_halo_plan_create", lib.gt4mi_halo_plan_create(comm.handle, 8, (_lib.HaloMsg * 1)(send), 1,
+                                                                   (_lib.HaloMsg * 1)(recv), 1, ctypes.byref(plan)))
+    ex._plan, ex.sides = plan, sides
+
+    rng = np.random.default_rng(17 + H)
+    host = rng.uniform(-1, 1, dec.local_shape) * 1e-3
+    o = dec.origin
+
+    def deliver(f):  # what the plan does to a host array
+        if side == "N":
+            f[:, H + lj:H + lj + H] = f[:, lj:lj + H]
+        else:
+            f[:, 0:H] = f[:, H:2 * H]
+
+    deliver(host)
+    a = gt_storage.from_array(host, backend="hip:mi300", aligned_index=o)
+    b = gt_storage.from_array(host.copy(), backend="hip:mi300", aligned_index=o)
+    step = ex.make_time_stepper_lap5(a, b, o, overlap=overlap)
+    nsteps = 2 * H + 1
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+
+    u, v = host.copy(), host.copy()
+    for n in range(nsteps):
+        ext = H - 1 - n % H
+        lo_j = H - (ext if side == "S" else 0)
+        hi_j = H + lj + (ext if side == "N" else 0)
+        view = (slice(H - 1, H + li + 1), slice(lo_j - 1, hi_j + 1), slice(None))
+        R.laplacian(u[view], v[view])
+        if ext == 0:
+            deliver(v)
+        u, v = v, u
+    got = step.result().get()
+    assert np.array_equal(got[H:H + li, H:H + lj], u[H:H + li, H:H + lj])
+    ex.close()

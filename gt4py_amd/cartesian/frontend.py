@@ -157,6 +157,14 @@ class _Parser(ast.NodeVisitor):
             if isinstance(stmt, ast.ImportFrom):
                 self._visit_import(stmt)
                 continue
+            if isinstance(stmt, ast.AnnAssign):
+                # typed temporary, optionally initialised: `tmp: Field[np.float32] = 0` at the top of the
+                # definition (gtscript_frontend.py:2245-2263); the initial value becomes a PARALLEL
+                # full-interval assignment ahead of everything else (:809-850)
+                init = self._declare_typed_temporary(stmt)
+                if init is not None:
+                    computations.append(init)
+                continue
             if isinstance(stmt, ast.With):
                 computations.extend(self._visit_with(stmt))
                 continue
@@ -172,6 +180,36 @@ class _Parser(ast.NodeVisitor):
             temporaries=tuple(self.temporaries.values()),
             computations=tuple(computations),
         )
+
+    def _declare_typed_temporary(self, node: ast.AnnAssign) -> Optional[ir.Computation]:
+        if not isinstance(node.target, ast.Name):
+            raise self._err(node, "Only plain names can be annotated as temporaries")
+        name = node.target.id
+        if name in self.fields or name in self.params or name in self.temporaries:
+            raise self._err(node, f"'{name}' is already defined")
+        scope = {"Field": gtscript.Field, "np": np, "I": gtscript.I, "J": gtscript.J, "K": gtscript.K,
+                 "IJ": gtscript.IJ, "IK": gtscript.IK, "JK": gtscript.JK, "IJK": gtscript.IJK}
+        scope.update(getattr(self.definition, "__globals__", {}))
+        try:
+            descriptor = eval(ast.unparse(node.annotation), scope)  # noqa: S307 - the user's own annotation
+        except Exception as ex:
+            raise self._err(node, f"Cannot evaluate the annotation of temporary '{name}'") from ex
+        if not isinstance(descriptor, gtscript._FieldDescriptor):
+            raise self._err(node, f"Temporary '{name}' must be annotated with Field[...]")
+        axes = tuple(a.name if isinstance(a, gtscript.Axis) else str(a) for a in descriptor.axes)
+        if axes != ("I", "J", "K"):
+            raise self._err(node, f"Found {''.join(axes)}, but only IJK is currently supported for temporaries")
+        if descriptor.data_dims:
+            raise self._err(node, "Temporaries with data dimensions are outside the supported GTScript subset")
+        dtype = np.dtype(descriptor.dtype)
+        self.temporaries[name] = ir.FieldDecl(name, dtype, ("I", "J", "K"), (), False)
+        if node.value is None:
+            return None
+        value = self._const(node.value)
+        if not isinstance(value, (bool, numbers.Number)):
+            raise self._err(node, "A temporary can only be initialised with a constant")
+        init = ir.Assign(ir.FieldAccess(name, (0, 0, 0)), self._literal_from_python(value, node))
+        return ir.Computation(ir.LoopOrder.PARALLEL, (ir.IntervalBlock(ir.Interval.full(), (init,)),))
 
     def _visit_import(self, node: ast.ImportFrom) -> None:
         if node.module not in ("__externals__", "gt4py.cartesian.__externals__", "gtscript.__externals__"):

@@ -8,6 +8,8 @@ Annotation strings are evaluated by ``gtscript.stencil`` (Field, IJ, K, np are i
 # flake8: noqa: F821, F841
 import numpy as np
 
+from gt4py_amd.cartesian.gtscript import Field  # noqa: F401 - used by annotations inside definitions
+
 F64 = "Field[np.float64]"
 F32 = "Field[np.float32]"
 
@@ -295,6 +297,14 @@ def while_in_if_and_scan(a: F64, out: F64):
             out = v + n
 
 
+def typed_temporary(a: F64, b: F64):
+    """typed, initialised temporary (gtscript_frontend.py:2245-2263): float32 accumulator between float64 fields"""
+    acc: Field[np.float32] = 1
+    with computation(PARALLEL), interval(...):
+        acc = acc + a
+        b = acc[1, 0, 0] * 2.0 - acc
+
+
 ZOO = {
     # name: (definition, externals, scalars, backend options)
     "copy_stencil": (copy_stencil, {}, {}, {}),
@@ -317,6 +327,7 @@ ZOO = {
     "variable_k_of_written_field": (variable_k_of_written_field, {}, {}, {}),
     "newton_sqrt": (newton_sqrt, {}, {"tol": 1e-12}, {}),
     "while_in_if_and_scan": (while_in_if_and_scan, {}, {}, {}),
+    "typed_temporary": (typed_temporary, {}, {}, {}),
     "runtime_if": (runtime_if, {}, {}, {}),
     "nested_if": (nested_if, {}, {"thresh": 0.75}, {}),
     "if_with_offsets": (if_with_offsets, {}, {}, {}),

@@ -384,3 +384,21 @@ def test_recognise_is_alpha_equivalence_not_text():
             st = parse(getattr(hip_templates, name), dtypes={"T": T})
             assert hip_backend.recognise(st, opts).template == name
     assert hip_backend.recognise(parse(access_kinds_stencil), opts) is None
+
+
+def typed_temporary(a: Field[np.float64], b: Field[np.float64]):
+    acc: Field[np.float32] = 1
+    with computation(PARALLEL), interval(...):
+        acc = acc + a
+        b = acc * 2.0
+
+
+def test_typed_temporary_with_initial_value():
+    """gtscript_frontend.py:2245-2263, 809-850: `tmp: Field[dtype] = c` declares the temporary's dtype and
+    prepends a PARALLEL full-interval `tmp = c`; later assignments are cast to the declared dtype."""
+    st = parse(typed_temporary)
+    assert [(t.name, t.dtype) for t in st.temporaries] == [("acc", np.dtype("float32"))]
+    first, second, third = [s for _, _, s in st.statements()]
+    assert first.target.name == "acc" and isinstance(first.value, (ir.Literal, ir.Cast)) and len(st.computations) == 2
+    assert second.target.name == "acc" and isinstance(second.value, ir.Cast) and second.value.dtype == np.dtype("float32")
+    assert third.value.dtype == np.dtype("float64")

@@ -54,7 +54,8 @@ def canonical_form(stencil: ir.Stencil) -> Tuple[Tuple, Dict[str, str]]:
         if isinstance(e, ir.Literal):
             return ("lit", repr(e.value), str(e.dtype))
         if isinstance(e, ir.FieldAccess):
-            return ("field", canon(e.name), e.offset, str(e.dtype), expr(e.koffset) if e.koffset is not None else None)
+            return ("field", canon(e.name), e.offset, str(e.dtype), expr(e.koffset) if e.koffset is not None else None,
+                    tuple(e.data_index or ()))
         if isinstance(e, ir.ScalarAccess):
             return ("scalar", canon(e.name), str(e.dtype))
         if isinstance(e, ir.UnaryOp):

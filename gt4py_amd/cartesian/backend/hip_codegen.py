@@ -250,6 +250,8 @@ class _Emitter:
         for d in (*plan.stencil.fields, *plan.stencil.temporaries):
             self.decl_dtype[d.name] = np.dtype(d.dtype)
         self.axes: Dict[str, Tuple[str, ...]] = {f.name: tuple(f.axes) for f in plan.stencil.fields}
+        self.data_dims: Dict[str, Tuple[int, ...]] = {d.name: tuple(d.data_dims) for d in
+                                                      (*plan.stencil.fields, *plan.stencil.temporaries)}
         self.global_names = [f.name for f in plan.api_fields] + list(plan.scratch)
         self.written = {s.target.name for _, _, s in plan.stencil.statements()}
         read = {e.name for _, _, s in plan.stencil.statements() for e in ir.stmt_reads(s) if isinstance(e, ir.FieldAccess)}
@@ -290,6 +292,9 @@ class _Emitter:
             terms.append(f"{di} * GT_SI(a.{c}_si)")
         if dj and "J" in axes:
             terms.append(f"{dj} * a.{c}_sj")
+        for n, d in enumerate(e.data_index or ()):
+            if d:
+                terms.append(f"{d} * a.{c}_d{n}")
         return f"{self.base_prefix}{c}[{' + '.join(terms) if terms else '0'}]"
 
     def expr(self, e: ir.Expr, k: str, si: int, reg: Dict[str, str]) -> str:
@@ -382,12 +387,12 @@ class _Emitter:
         elif name in carry:  # keep the freshly written level for this iteration's later reads and the next one
             self.lines.append(f"{pad}n_{_c_ident(name)} = {value};")
             if name not in self.plan.register_only:
-                self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset), k, -1, {})} = n_{_c_ident(name)};")
+                self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset, None, None, s.target.data_index), k, -1, {})} = n_{_c_ident(name)};")
             reg[(name, 0)] = f"n_{_c_ident(name)}"
         elif name in self.streaming:
-            self.lines.append(f"{pad}__builtin_nontemporal_store({value}, &{self.access(ir.FieldAccess(name, s.target.offset), k, -1, {})});")
+            self.lines.append(f"{pad}__builtin_nontemporal_store({value}, &{self.access(ir.FieldAccess(name, s.target.offset, None, None, s.target.data_index), k, -1, {})});")
         else:
-            self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset), k, -1, {})} = {value};")
+            self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset, None, None, s.target.data_index), k, -1, {})} = {value};")
         if g:
             self.lines.append(f"{indent}}}")
 
@@ -581,14 +586,14 @@ def _vector_width(em: "_Emitter", stage: Stage) -> int:
             # to a horizontal region (whose reads need less halo than an unrestricted statement's would)
             if s.extent != stage.extent or s.region is not None or s.loops:
                 return 0
-            if s.target.offset != (0, 0, 0):
+            if s.target.offset != (0, 0, 0) or s.target.data_index:
                 return 0
             if s.target.name not in em.plan.locals:
                 if "I" not in em.axes.get(s.target.name, ("I", "J", "K")):
                     return 0
                 sizes.add(em.decl_dtype[s.target.name].itemsize)
             for e in _stmt_field_reads(s):
-                if e.koffset is not None:
+                if e.koffset is not None or e.data_index:
                     return 0
                 if e.name in em.plan.locals:
                     continue
@@ -758,6 +763,9 @@ def generate(stencil: ir.Stencil) -> GeneratedProgram:
         struct_lines.append(f"    {ct}* {c}; gt_i64 {c}_si, {c}_sj, {c}_sk;")
         fields_c += [(c, ctypes.c_void_p), (f"{c}_si", ctypes.c_int64), (f"{c}_sj", ctypes.c_int64),
                      (f"{c}_sk", ctypes.c_int64)]
+        for dn in range(len(em.data_dims.get(n, ()))):  # element strides of the data dimensions
+            struct_lines.append(f"    gt_i64 {c}_d{dn};")
+            fields_c.append((f"{c}_d{dn}", ctypes.c_int64))
     for p in plan.params:
         dt = np.dtype(p.dtype)
         struct_lines.append(f"    {_CTYPE[dt.name]} p_{_c_ident(p.name)};")

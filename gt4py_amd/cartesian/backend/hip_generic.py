@@ -190,6 +190,8 @@ class HipGenericStencilObject(StencilObject):
             if "I" in decl.axes and byte_strides["I"] != isz:
                 unit_i = False
             geometry[decl.name] = (ptr, byte_strides.get("J", 0) // isz, byte_strides.get("K", 0) // isz, isz)
+            for dn, stride in enumerate(arr.strides[len(decl.axes):]):  # data dimensions
+                setattr(args, f"{c}_d{dn}", stride // isz)
             hi = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s > 0) + isz
             lo = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s < 0)
             spans.append((arr.ptr + lo, arr.ptr + hi))
@@ -198,6 +200,7 @@ class HipGenericStencilObject(StencilObject):
             entry = cls._gt_scratch_.get(key)
             if entry is None:
                 layout, total = {}, 0
+                temp_dims = {t.name: tuple(t.data_dims) for t in plan.stencil.temporaries}
                 for name, (dt, ((ilo, ihi), (jlo, jhi))) in plan.scratch.items():
                     oi = -(-(-ilo) // 4) * 4  # the domain's first column on a 16-byte boundary
                     ni = -(-(dI + ihi + oi) // 32) * 32  # rows padded like the storage preset
@@ -206,7 +209,8 @@ class HipGenericStencilObject(StencilObject):
                     # see storage/allocators.py:_channel_skew): stagger them by 1.5 MiB steps
                     total += (len(layout) % 8) * (3 << 19)
                     layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
-                    total += -(-(ni * nj * max(dK, 1) * dt.itemsize) // 256) * 256
+                    n_elem = int(np.prod(temp_dims.get(name, ()) or (1,)))  # data dimensions: outermost
+                    total += -(-(ni * nj * max(dK, 1) * n_elem * dt.itemsize) // 256) * 256
                 buf = torch.empty(total, dtype=torch.uint8, device="cuda")
                 cls._gt_scratch_.clear()  # one domain at a time: scratch can be gigabytes ...
                 cls._gt_launch_cache_.clear()  # ... and cached launch plans keep theirs alive
@@ -219,6 +223,11 @@ class HipGenericStencilObject(StencilObject):
                 setattr(args, f"{c}_si", 1)
                 setattr(args, f"{c}_sj", ni)
                 setattr(args, f"{c}_sk", ni * nj)
+                dims = tuple(next(t.data_dims for t in plan.stencil.temporaries if t.name == name))
+                stride = ni * nj * max(dK, 1)
+                for dn in range(len(dims) - 1, -1, -1):  # last data dimension varies fastest among them
+                    setattr(args, f"{c}_d{dn}", stride)
+                    stride *= dims[dn]
                 geometry[name] = (base + off + (oi + oj * ni) * isz, ni, ni * nj, isz)
         for p in plan.params:
             setattr(args, f"p_{hip_codegen._c_ident(p.name)}", np.dtype(p.dtype).type(arguments[p.name]).item())

@@ -30,7 +30,8 @@ class UnsupportedStencil(NotImplementedError):
 # 1. inlining of horizontally offset temporaries
 # ---------------------------------------------------------------------------------------------------
 def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
-    return ir.FieldAccess(e.name, (e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]), e.dtype, e.koffset)
+    return ir.FieldAccess(e.name, (e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]), e.dtype, e.koffset,
+                          e.data_index)
 
 
 def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[str]]:
@@ -59,7 +60,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
 
     cand = {
         n for n in temps
-        if len(touched.get(n, ())) == 1 and n not in k_offset_read and n not in masked_write
+        if len(touched.get(n, ())) == 1 and n not in k_offset_read and n not in masked_write and not temps[n].data_dims
         and stencil.computations[next(iter(touched[n]))[0]].order is ir.LoopOrder.PARALLEL
     }
     changed = True
@@ -100,7 +101,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                     if isinstance(e, ir.FieldAccess) and e.name in inline:
                         if e.name not in version:  # the frontend rejects this already
                             raise UnsupportedStencil(f"temporary '{e.name}' is read before it is assigned")
-                        return ir.FieldAccess(version[e.name], e.offset, e.dtype, e.koffset)
+                        return ir.FieldAccess(version[e.name], e.offset, e.dtype, e.koffset, e.data_index)
                     return e
 
                 return ir.map_expr(expr, fn)
@@ -226,9 +227,6 @@ def _stmt_field_reads(s) -> List[ir.FieldAccess]:
 
 
 def plan_stages(stencil_in: ir.Stencil) -> Plan:
-    for d in (*stencil_in.fields, *stencil_in.temporaries):
-        if d.data_dims:
-            raise UnsupportedStencil(f"field '{d.name}' has data dimensions")
     stencil, ssa_locals = inline_horizontal_temporaries(stencil_in)
     extents = analysis.compute_extents(stencil)
     written_anywhere = {s.target.name for _, _, s in stencil.statements()}
@@ -311,6 +309,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
             if s.target.name in temp_names:
                 where.setdefault(s.target.name, set()).add(nid)
                 defined.add(s.target.name)
+    bad_local |= {t.name for t in stencil.temporaries if t.data_dims}  # several values per point: not a scalar
     local_names = {n for n in temp_names if n in where and n not in bad_local}
     # a local that is written in one nest and never read anywhere is dead but harmless
     scratch: Dict[str, Tuple[np.dtype, Extent2]] = {}
@@ -341,7 +340,8 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                     if e.offset[2] != 0 and e.name in stage.written:
                         patterns.setdefault(e.name, set()).add((nest.order, e.offset))
                         extents_of.setdefault(e.name, set()).add(s.extent)
-        unsafe = {s.target.name for nest in stage.nests for s in nest.stmts
+        with_data_dims = {d.name for d in (*stencil.fields, *stencil.temporaries) if d.data_dims}
+        unsafe = with_data_dims | {s.target.name for nest in stage.nests for s in nest.stmts
                   if s.mask is not None or s.region is not None or s.loops or s.target.offset != (0, 0, 0)}  # conditional / displaced writes
         for name, pats in patterns.items():
             if name in local_names or name in unsafe or len(extents_of.get(name, ())) != 1:

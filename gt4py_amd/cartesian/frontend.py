@@ -199,17 +199,22 @@ class _Parser(ast.NodeVisitor):
         axes = tuple(a.name if isinstance(a, gtscript.Axis) else str(a) for a in descriptor.axes)
         if axes != ("I", "J", "K"):
             raise self._err(node, f"Found {''.join(axes)}, but only IJK is currently supported for temporaries")
-        if descriptor.data_dims:
-            raise self._err(node, "Temporaries with data dimensions are outside the supported GTScript subset")
         dtype = np.dtype(descriptor.dtype)
-        self.temporaries[name] = ir.FieldDecl(name, dtype, ("I", "J", "K"), (), False)
+        dims = tuple(int(n) for n in descriptor.data_dims)
+        self.temporaries[name] = ir.FieldDecl(name, dtype, ("I", "J", "K"), dims, False)
         if node.value is None:
             return None
         value = self._const(node.value)
         if not isinstance(value, (bool, numbers.Number)):
             raise self._err(node, "A temporary can only be initialised with a constant")
-        init = ir.Assign(ir.FieldAccess(name, (0, 0, 0)), self._literal_from_python(value, node))
-        return ir.Computation(ir.LoopOrder.PARALLEL, (ir.IntervalBlock(ir.Interval.full(), (init,)),))
+        import itertools
+
+        group = self._groups
+        self._groups += 1
+        inits = tuple(ir.Assign(ir.FieldAccess(name, (0, 0, 0), None, None, tuple(index)),
+                                self._literal_from_python(value, node), None, group if dims else -1)
+                      for index in itertools.product(*(range(n) for n in dims)))
+        return ir.Computation(ir.LoopOrder.PARALLEL, (ir.IntervalBlock(ir.Interval.full(), inits),))
 
     def _visit_import(self, node: ast.ImportFrom) -> None:
         if node.module not in ("__externals__", "gt4py.cartesian.__externals__", "gtscript.__externals__"):
@@ -310,13 +315,13 @@ class _Parser(ast.NodeVisitor):
         if isinstance(node, ast.Assign):
             if len(node.targets) != 1:
                 raise self._err(node, "Chained assignment is not supported")
-            return [self._make_assign(node.targets[0], self.visit(node.value), node, mask, group)]
+            return self._make_assign(node.targets[0], self.visit(node.value), node, mask, group)
         if isinstance(node, ast.AugAssign):
             if type(node.op) not in _BIN_OPS:
                 raise self._err(node, "Unsupported augmented assignment")
             target_read = self._target_access(node.target, node, reading=True)
             value = ir.BinaryOp(_BIN_OPS[type(node.op)], target_read, self.visit(node.value))
-            return [self._make_assign(node.target, value, node, mask, group)]
+            return self._make_assign(node.target, value, node, mask, group)
         if isinstance(node, ast.If):
             test = node.test
             out: List[ir.Assign] = []
@@ -332,6 +337,8 @@ class _Parser(ast.NodeVisitor):
                 group = self._groups
                 self._groups += 1
             cond = self.visit(test)
+            if any(isinstance(e, ir.FieldAccess) and e.data_index is None for e in ir.walk(cond)):
+                raise self._err(node, "Conditions must index the data dimensions of the fields they read")
             if any(isinstance(e, ir.FieldAccess) for e in ir.walk(cond)):
                 name = f"mask_{self._masks}"
                 while name in self.fields or name in self.params or name in self.temporaries:
@@ -358,6 +365,8 @@ class _Parser(ast.NodeVisitor):
                 group = self._groups
                 self._groups += 1
             cond = self.visit(node.test)
+            if any(isinstance(e, ir.FieldAccess) and e.data_index is None for e in ir.walk(cond)):
+                raise self._err(node, "Conditions must index the data dimensions of the fields they read")
             full = cond if mask is None else ir.BinaryOp("and", mask, cond)
             saved = self._loops
             self._loops = saved + ((self._loop_count, full),)
@@ -439,7 +448,26 @@ class _Parser(ast.NodeVisitor):
         single = bound(node)
         return ir.HorizontalInterval(single, ir.AxisBound(single.level, single.offset + 1))
 
+    def _data_dims(self, name: str) -> Tuple[int, ...]:
+        decl = self.fields.get(name) or self.temporaries.get(name)
+        return tuple(decl.data_dims) if decl is not None else ()
+
+    def _split_data_index(self, node: ast.Subscript):
+        """``f[i, j, k][d0, d1]`` -> (the ``f[i, j, k]`` node, (d0, d1)); plain subscripts -> (node, None)."""
+        inner = node.value
+        if isinstance(inner, ast.Subscript) and isinstance(inner.value, ast.Name) and self._data_dims(inner.value.id):
+            dims = self._data_dims(inner.value.id)
+            elts = list(node.slice.elts) if isinstance(node.slice, ast.Tuple) else [node.slice]
+            index = tuple(self._const(e) for e in elts)
+            if len(index) != len(dims) or not all(isinstance(v, numbers.Integral) and 0 <= v < n for v, n in zip(index, dims)):
+                raise self._err(node, f"Invalid data index {list(index)} for field '{inner.value.id}' with data dimensions {dims}")
+            return inner, tuple(int(v) for v in index)
+        return node, None
+
     def _target_access(self, target, node, reading=False) -> ir.FieldAccess:
+        data_index: Optional[Tuple[int, ...]] = None
+        if isinstance(target, ast.Subscript):
+            target, data_index = self._split_data_index(target)
         if isinstance(target, ast.Name):
             name, offset = target.id, (0, 0, 0)
         elif isinstance(target, ast.Subscript) and isinstance(target.value, ast.Name):
@@ -447,6 +475,8 @@ class _Parser(ast.NodeVisitor):
             offset = self._parse_offset(target, name)
         else:
             raise self._err(node, "Invalid assignment target")
+        if data_index is None and not self._data_dims(name):
+            data_index = ()
         if offset[0] != 0 or offset[1] != 0:
             raise self._err(node, "Assignment to non-zero offsets is not supported in IJ")
         if offset[2] != 0 and self._order is ir.LoopOrder.PARALLEL:
@@ -456,13 +486,41 @@ class _Parser(ast.NodeVisitor):
             raise self._err(node, f"Cannot assign to scalar parameter or external '{name}'")
         if reading and name not in self.fields and name not in self.temporaries:
             raise GTScriptSymbolError(f"Unknown symbol '{name}'")
-        return ir.FieldAccess(name, offset)
+        return ir.FieldAccess(name, offset, None, None, data_index)
 
-    def _make_assign(self, target, value: ir.Expr, node, mask: Optional[ir.Expr] = None, group: int = -1) -> ir.Assign:
+    def _make_assign(self, target, value: ir.Expr, node, mask: Optional[ir.Expr] = None, group: int = -1) -> List[ir.Assign]:
         access = self._target_access(target, node)
         if access.name not in self.fields and access.name not in self.temporaries:
             self.temporaries[access.name] = ir.FieldDecl(access.name, None, ("I", "J", "K"), (), False)
-        return ir.Assign(access, value, mask, group, self._region, self._loops)
+            access = ir.FieldAccess(access.name, access.offset, None, None, ())
+        # vector-valued statement: accesses to fields with data dimensions that carry no data index are
+        # replaced by every index in turn (all such fields must have the same data dimensions)
+        open_dims = {self._data_dims(e.name) for e in [access, *ir.walk(value)]
+                     if isinstance(e, ir.FieldAccess) and e.data_index is None}
+        if not open_dims:
+            return [ir.Assign(access, value, mask, group, self._region, self._loops)]
+        if len(open_dims) != 1:
+            raise self._err(node, f"Fields with different data dimensions {sorted(open_dims)} in one vector assignment")
+        if access.data_index is not None:
+            raise self._err(node, "A vector-valued expression cannot be assigned to a single element")
+        for extra in ([mask] if mask is not None else []) + [c for _, c in self._loops]:
+            if any(isinstance(e, ir.FieldAccess) and e.data_index is None for e in ir.walk(extra)):
+                raise self._err(node, "Conditions must index the data dimensions of the fields they read")
+        (dims,) = open_dims
+        if group < 0:
+            group = self._groups
+            self._groups += 1
+        out = []
+        import itertools
+
+        for index in itertools.product(*(range(n) for n in dims)):
+            def pick(e, index=index):
+                if isinstance(e, ir.FieldAccess) and e.data_index is None:
+                    return ir.FieldAccess(e.name, e.offset, e.dtype, e.koffset, tuple(index))
+                return e
+
+            out.append(ir.Assign(pick(access), ir.map_expr(value, pick), mask, group, self._region, self._loops))
+        return out
 
     # ---- expressions ---------------------------------------------------------------------
     def generic_visit(self, node):
@@ -492,7 +550,7 @@ class _Parser(ast.NodeVisitor):
     def visit_Name(self, node: ast.Name) -> ir.Expr:
         name = node.id
         if name in self.fields or name in self.temporaries:
-            return ir.FieldAccess(name, (0, 0, 0))
+            return ir.FieldAccess(name, (0, 0, 0), None, None, None if self._data_dims(name) else ())
         if name in self.params:
             return ir.ScalarAccess(name, self.params[name].dtype)
         if name in self.imported:
@@ -552,6 +610,7 @@ class _Parser(ast.NodeVisitor):
         return offset["I"], offset["J"], offset["K"]
 
     def visit_Subscript(self, node: ast.Subscript) -> ir.Expr:
+        node, data_index = self._split_data_index(node)
         if not isinstance(node.value, ast.Name):
             raise self._err(node, "Only fields can be subscripted")
         name = node.value.id
@@ -559,7 +618,9 @@ class _Parser(ast.NodeVisitor):
             raise GTScriptSymbolError(f"Unknown field '{name}' in stencil '{self.definition.__name__}'")
         variable: list = []
         offset = self._parse_offset(node, name, variable)
-        return ir.FieldAccess(name, offset, None, variable[0] if variable else None)
+        if data_index is None and not self._data_dims(name):
+            data_index = ()
+        return ir.FieldAccess(name, offset, None, variable[0] if variable else None, data_index)
 
     def visit_UnaryOp(self, node: ast.UnaryOp) -> ir.Expr:
         op = {ast.USub: "-", ast.UAdd: "+", ast.Not: "not"}.get(type(node.op))
@@ -623,7 +684,7 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
                 if koff is not None:  # already typed (map_expr is bottom-up); must be an integer
                     if np.dtype(koff.dtype).kind not in "iu":
                         raise GTScriptSyntaxError(f"Variable K offset of '{e.name}' must be an integer expression")
-                return ir.FieldAccess(e.name, e.offset, dt, koff)
+                return ir.FieldAccess(e.name, e.offset, dt, koff, e.data_index)
             if isinstance(e, (ir.Literal, ir.ScalarAccess, ir.Cast)):
                 return e
             if isinstance(e, ir.UnaryOp):
@@ -681,8 +742,8 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
                 for lid, cond in stmt.loops:
                     cond = typed(cond)
                     loops.append((lid, cond if cond.dtype == np.dtype("bool") else ir.Cast(cond, np.dtype("bool"))))
-                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt), value, mask, stmt.group, stmt.region,
-                                          tuple(loops)))
+                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt, None, stmt.target.data_index), value,
+                                          mask, stmt.group, stmt.region, tuple(loops)))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     temps = tuple(ir.FieldDecl(t.name, dtypes[t.name], t.axes, t.data_dims, False) for t in stencil.temporaries)

@@ -75,6 +75,10 @@ class FieldAccess(Expr):
     offset: Tuple[int, int, int]
     dtype: Optional[np.dtype] = None
     koffset: Optional[Expr] = None
+    #: constant index into the field's data dimensions (``field[0, 0, 0][1, 0]``); () for plain fields.  Only
+    #: inside the parser None stands for "not written": such statements are unrolled over every index
+    #: (vector-valued assignments, /root/reference/tests/.../test_suites.py:980-1060).
+    data_index: Optional[Tuple[int, ...]] = ()
 
 
 @dataclass(frozen=True)
@@ -304,7 +308,8 @@ def fmt(expr: Expr) -> str:
         return f"{expr.dtype}({expr.value!r})" if expr.dtype is not None else repr(expr.value)
     if isinstance(expr, FieldAccess):
         k = f"{expr.offset[2]}" if expr.koffset is None else fmt(expr.koffset)
-        return f"{expr.name}[{expr.offset[0]},{expr.offset[1]},{k}]"
+        data = "".join(f"[{d}]" for d in (expr.data_index or ()))
+        return f"{expr.name}[{expr.offset[0]},{expr.offset[1]},{k}]{data}"
     if isinstance(expr, ScalarAccess):
         return expr.name
     if isinstance(expr, UnaryOp):

@@ -58,8 +58,9 @@ class _FieldShim:
         self.origin = tuple(full_origin)
         self.mask = mask
 
-    def window(self, lo, hi, offset, krange):
-        """View over [lo, hi) per horizontal axis (relative to the origin), shifted by offset."""
+    def window(self, lo, hi, offset, krange, data_index=()):
+        """View over [lo, hi) per horizontal axis (relative to the origin), shifted by offset; ``data_index``
+        selects one element of the trailing data dimensions."""
         idx = []
         for ax in range(2):
             if self.mask[ax]:
@@ -76,7 +77,7 @@ class _FieldShim:
             idx.append(slice(a, b))
         else:
             idx.append(slice(None))
-        return self.array[tuple(idx)]
+        return self.array[tuple(idx) + tuple(data_index or ())]
 
 
 def _gather(self, lo, hi, offset, krange, kshift):
@@ -109,8 +110,9 @@ def _evaluate(expr: ir.Expr, env, lo, hi, krange):
             return np.dtype(e.dtype).type(e.value)
         if isinstance(e, ir.FieldAccess):
             if e.koffset is not None:  # `lk + k` index arrays (npir_codegen.py:110, 271-278)
+                assert not e.data_index, "numpy oracle: run-time K index on a field with data dimensions"
                 return env[e.name].gather(lo, hi, e.offset, krange, ev(e.koffset))
-            return env[e.name].window(lo, hi, e.offset, krange)
+            return env[e.name].window(lo, hi, e.offset, krange, e.data_index)
         if isinstance(e, ir.ScalarAccess):
             return env[e.name]
         if isinstance(e, ir.Cast):
@@ -142,7 +144,7 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
     temp_extents = analysis.storage_extents(stencil, extents)
     for decl in stencil.temporaries:
         (ilo, ihi), (jlo, jhi) = temp_extents[decl.name]
-        shape = (dI + (ihi - ilo), dJ + (jhi - jlo), dK)
+        shape = (dI + (ihi - ilo), dJ + (jhi - jlo), dK, *decl.data_dims)
         env[decl.name] = _FieldShim(np.empty(shape, dtype=decl.dtype), (-ilo, -jlo, 0), ("I", "J", "K"))
     for p in stencil.params:
         # a missing (None) parameter stays None: using it raises TypeError inside numpy, exactly what
@@ -191,7 +193,7 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
                         if span is None:
                             continue
                         lo, hi = span
-                        target = env[stmt.target.name].window(lo, hi, stmt.target.offset, krange)
+                        target = env[stmt.target.name].window(lo, hi, stmt.target.offset, krange, stmt.target.data_index)
                         if stmt.mask is not None:  # npir_codegen.py:205-210: np.where(mask, right, left)
                             mask = _evaluate(stmt.mask, env, lo, hi, krange)
                             value = np.where(mask, _evaluate(stmt.value, env, lo, hi, krange), target)

@@ -33,6 +33,7 @@ class Suite:
     domains: Sequence[Tuple[int, int, int]] = ((1, 1, 1), (3, 4, 5), (15, 14, 13))
     optional: Dict[str, str] = field(default_factory=dict)  # field -> external that switches it on
     axes: Dict[str, str] = field(default_factory=dict)  # field -> "K", "IJ", ... (default "IJK")
+    data_dims: Dict[str, Tuple[int, ...]] = field(default_factory=dict)  # field -> trailing data dimensions
 
 
 def _inner(a, b):
@@ -428,6 +429,89 @@ def _variable_k_outside_expected(a, p, ext, domain):
     return {"field_out": out}
 
 
+# ---- :614-697 (lower-dimensional fields with data dimensions) ----------------------------------------
+def non_3d_fields(field_in: "Field[K, np.float64]", another_field: "Field[IJ, (np.float64, (3, 2, 2))]",
+                  field_out: "Field[(np.float64, (3, 2))]"):
+    with computation(PARALLEL), interval(...):
+        field_out[0, 0, 0][0, 0] = field_in[0] + another_field[-1, -1][0, 0, 0] + another_field[-1, -1][0, 0, 1]
+        field_out[0, 0, 0][0, 1] = 2 * (
+            another_field[-1, -1][1, 0, 0]
+            + another_field[-1, -1][1, 0, 1]
+            + another_field[-1, -1][1, 1, 0]
+            + another_field[-1, -1][1, 1, 1]
+        )
+
+        field_out[0, 0, 0][1, 0] = field_in[0] + another_field[1, 1][0, 0, 0] + another_field[1, 1][0, 0, 1]
+        field_out[0, 0, 0][1, 1] = 3 * (
+            another_field[1, 1][1, 0, 0]
+            + another_field[1, 1][1, 0, 1]
+            + another_field[1, 1][1, 1, 0]
+            + another_field[1, 1][1, 1, 1]
+        )
+
+        field_out[0, 0, 0][2, 0] = field_in[0] + another_field[0, 0][0, 0, 0] + another_field[-1, 1][0, 0, 1]
+        field_out[0, 0, 0][2, 1] = 4 * (
+            another_field[-1, 1][1, 0, 0]
+            + another_field[-1, 1][1, 0, 1]
+            + another_field[-1, 1][1, 1, 0]
+            + another_field[-1, 1][1, 1, 1]
+        )
+
+
+def _non_3d_expected(a, p, ext, domain):
+    fi, af = a["field_in"], a["another_field"]
+    out = a["field_out"].copy()
+    out[:, :, :, 0, 0] = fi[:] + af[:-2, :-2, None, 0, 0, 0] + af[:-2, :-2, None, 0, 0, 1]
+    out[:, :, :, 0, 1] = 2 * (af[:-2, :-2, None, 1, 0, 0] + af[:-2, :-2, None, 1, 0, 1] + af[:-2, :-2, None, 1, 1, 0]
+                              + af[:-2, :-2, None, 1, 1, 1])
+    out[:, :, :, 1, 0] = fi[:] + af[2:, 2:, None, 0, 0, 0] + af[2:, 2:, None, 0, 0, 1]
+    out[:, :, :, 1, 1] = 3 * (af[2:, 2:, None, 1, 0, 0] + af[2:, 2:, None, 1, 0, 1] + af[2:, 2:, None, 1, 1, 0]
+                              + af[2:, 2:, None, 1, 1, 1])
+    out[:, :, :, 2, 0] = fi[:] + af[1:-1, 1:-1, None, 0, 0, 0] + af[:-2, 2:, None, 0, 0, 1]
+    out[:, :, :, 2, 1] = 4 * (af[:-2, 2:, None, 1, 0, 0] + af[:-2, 2:, None, 1, 0, 1] + af[:-2, 2:, None, 1, 1, 0]
+                              + af[:-2, 2:, None, 1, 1, 1])
+    return {"field_out": out}
+
+
+# ---- :946-977 ----------------------------------------------------------------------------------
+def typed_temporary(field_in: F32, field_out: F32):
+    tmp: Field[(np.float32, (2, 2))] = 0
+    with computation(PARALLEL):
+        with interval(0, -1):
+            tmp[0, 0, 0][0, 0] = field_in[0, 0, 0]
+            tmp[0, 0, 0][1, 0] = field_in[0, 0, 1]
+            tmp[0, 0, 0][0, 1] = -1.0
+            tmp[0, 0, 0][1, 1] = -1.0
+            field_out = tmp[0, 0, 0][0, 0] + tmp[0, 0, 0][1, 0]
+        with interval(-1, None):
+            field_out = 0
+
+
+def _typed_temporary_expected(a, p, ext, domain):
+    x = a["field_in"]
+    out = a["field_out"].copy()
+    out[:, :, :-1] = x[:, :, :-1] + x[:, :, 1:]
+    out[:, :, -1] = 0
+    return {"field_out": out}
+
+
+# ---- :980-1060 (vector-valued statements over data dimensions) ----------------------------------------
+def vector_gen_assignment(field_in: "Field[(np.float64, (2,))]", field_out: "Field[(np.float64, (2,))]"):
+    with computation(PARALLEL), interval(...):
+        field_out = 2 * field_in
+
+
+def matrix_assignment(field_in: "Field[(np.float32, (2, 3))]", field_out: "Field[(np.float32, (2, 3))]"):
+    with computation(PARALLEL), interval(...):
+        field_out = field_in
+
+
+def vector_vector_op(field_1: "Field[(np.float32, (2,))]", field_2: "Field[(np.float32, (2,))]",
+                     field_out: "Field[(np.float32, (2,))]"):
+    with computation(PARALLEL), interval(...):
+        field_out = field_1 + field_2
+
+
 R10 = (-10.0, 10.0)
 R1 = (-1.0, 1.0)
 SUITES: Dict[str, Suite] = {
@@ -507,6 +591,23 @@ SUITES: Dict[str, Suite] = {
                                           "field_out": (np.float64, Z, (0.1, 10.0)), "index": (np.int32, Z, (-1, 0))},
                                          _variable_k_outside_expected, domains=((2, 2, 2), (2, 2, 8), (5, 4, 9)),
                                          axes={"index": "K"}),
+    "non_3d_fields": Suite(non_3d_fields,
+                           {"field_in": (np.float64, Z, R10), "another_field": (np.float64, ((1, 1), (1, 1), (0, 0)), R10),
+                            "field_out": (np.float64, Z, R10)},
+                           _non_3d_expected, domains=((4, 4, 4), (10, 7, 5)), axes={"field_in": "K", "another_field": "IJ"},
+                           data_dims={"another_field": (3, 2, 2), "field_out": (3, 2)}),
+    "typed_temporary": Suite(typed_temporary, {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
+                             _typed_temporary_expected, domains=((2, 2, 2), (2, 2, 8), (5, 3, 6))),
+    "vector_gen_assignment": Suite(vector_gen_assignment, {"field_in": (np.float64, Z, R10), "field_out": (np.float64, Z, R10)},
+                                   lambda a, p, e, d: {"field_out": 2 * a["field_in"]}, domains=((2, 2, 2), (5, 4, 3)),
+                                   data_dims={"field_in": (2,), "field_out": (2,)}),
+    "matrix_assignment": Suite(matrix_assignment, {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
+                               lambda a, p, e, d: {"field_out": a["field_in"]}, domains=((2, 2, 2), (5, 4, 3)),
+                               data_dims={"field_in": (2, 3), "field_out": (2, 3)}),
+    "vector_vector_op": Suite(vector_vector_op,
+                              {"field_1": (np.float32, Z, R10), "field_2": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
+                              lambda a, p, e, d: {"field_out": a["field_1"] + a["field_2"]}, domains=((2, 2, 2), (5, 4, 3)),
+                              data_dims={"field_1": (2,), "field_2": (2,), "field_out": (2,)}),
     "horizontal_regions": Suite(horizontal_regions, {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
                                 _regions_expected, domains=((4, 4, 2), (9, 7, 3))),
     "horizontal_regions_partial_writes": Suite(horizontal_regions_partial_writes,
@@ -534,12 +635,12 @@ def make_case(name: str, ext: Dict[str, Any], domain, seed: int = 1337):
     arrays, origins = {}, {}
     for fname, (dt, boundary, (lo, hi)) in suite.fields.items():
         present = [ax for ax, name in enumerate("IJK") if name in suite.axes.get(fname, "IJK")]
-        shape = tuple(domain[ax] + boundary[ax][0] + boundary[ax][1] for ax in present)
+        shape = tuple(domain[ax] + boundary[ax][0] + boundary[ax][1] for ax in present) + tuple(suite.data_dims.get(fname, ()))
         if np.dtype(dt).kind in "iu":
             arrays[fname] = rng.integers(int(lo), int(hi) + 1, shape).astype(dt)
         else:
             arrays[fname] = rng.uniform(lo, hi, shape).astype(dt)
-        origins[fname] = tuple(boundary[ax][0] for ax in present)
+        origins[fname] = tuple(boundary[ax][0] for ax in present) + (0,) * len(suite.data_dims.get(fname, ()))
     params = {p: float(rng.uniform(lo, hi)) for p, (lo, hi) in suite.params.items()}
     expected = suite.expected({k: v.copy() for k, v in arrays.items()}, params, ext, domain)
     return arrays, origins, params, expected

@@ -115,7 +115,9 @@ def test_generated_source_compiles_for_gfx950(programs, name):
             assert kern.name.encode() in code
     # the argument block mirrors `struct gt_args`: pointers + 3 strides per array, scalars, 3 extents
     n_arrays = len(prog.plan.api_fields) + len(prog.plan.scratch)
-    assert len(prog.args_struct._fields_) == 4 * n_arrays + len(prog.plan.params) + 3
+    n_data = sum(len(d.data_dims) for d in (*prog.plan.api_fields, *prog.plan.stencil.temporaries)
+                 if d.name in prog.plan.scratch or d in prog.plan.api_fields)
+    assert len(prog.args_struct._fields_) == 4 * n_arrays + n_data + len(prog.plan.params) + 3
 
 
 def test_horizontal_stages_get_a_16_byte_lane_twin(programs):

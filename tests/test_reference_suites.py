@@ -61,8 +61,9 @@ def test_hip_backend_matches_reference_validation(name, ext, domain):
     import gt4py_amd.storage as gt_storage
 
     def to_device(arr, origin, axes):
+        n_data = arr.ndim - len(axes)
         return gt_storage.from_array(arr, dtype=arr.dtype, backend="hip:mi300", aligned_index=origin,
-                                     dimensions=tuple(axes))
+                                     dimensions=tuple(axes) + tuple(str(n) for n in range(n_data)))
 
     _run("hip:mi300", name, ext, domain, to_device)
 
@@ -85,4 +86,4 @@ def test_field_info_of_the_suites_matches_the_declared_boundaries():
                 present = suite.axes.get(fname, "IJK")
                 got = tuple(tuple(max(0, v) for v in b) for b, ax in zip(info.boundary, "IJK") if ax in present)
                 assert got == tuple(b for b, ax in zip(boundary, "IJK") if ax in present), (name, fname)
-                assert info.dtype == np.dtype(dt)
+                assert info.dtype == np.dtype(dt) and tuple(info.data_dims) == tuple(suite.data_dims.get(fname, ()))

@@ -512,6 +512,53 @@ def vector_vector_op(field_1: "Field[(np.float32, (2,))]", field_2: "Field[(np.f
         field_out = field_1 + field_2
 
 
+# ---- :1045-1092 ---------------------------------------------------------------------------------
+def combined_vector_scalar_op(field_1: "Field[(np.float64, (2,))]", field_2: "Field[(np.float64, (2,))]",
+                              field_out: "Field[(np.float64, (2,))]"):
+    with computation(PARALLEL), interval(...):
+        field_out = 3 * (field_1 + field_2 * field_2)
+
+
+def vectorized_temporary(field_in: "Field[(np.float32, (2,))]", field_out: "Field[(np.float32, (2,))]"):
+    tmp: Field[(np.float32, (2,))] = 0
+    with computation(PARALLEL), interval(...):
+        tmp[0, 0, 0][0] = 2
+        tmp[0, 0, 0][1] = 3
+        field_out = tmp * field_in
+
+
+def _vectorized_temporary_expected(a, p, ext, domain):
+    x = a["field_in"]
+    out = a["field_out"].copy()
+    out[:, :, :, 0] = 2 * x[:, :, :, 0]
+    out[:, :, :, 1] = 3 * x[:, :, :, 1]
+    return {"field_out": out}
+
+
+# ---- :564-611 with stencil_definitions.py:424-447 --------------------------------------------------
+def two_optional_fields(in_a: F64, in_b: F64, out_a: F64, out_b: F64, dyn_tend_a: F64, dyn_tend_b: F64,
+                        phys_tend_a: F64 = None, phys_tend_b: F64 = None, *, dt: float):
+    from __externals__ import PHYS_TEND_A, PHYS_TEND_B
+
+    with computation(PARALLEL), interval(...):
+        out_a = in_a + dt * dyn_tend_a
+        out_b = in_b + dt * dyn_tend_b
+        if __INLINED(PHYS_TEND_A):
+            out_a = out_a + dt * phys_tend_a
+        if __INLINED(PHYS_TEND_B):
+            out_b = out_b + dt * phys_tend_b
+
+
+def _two_optional_expected(a, p, ext, domain):
+    out_a = a["in_a"] + p["dt"] * a["dyn_tend_a"]
+    out_b = a["in_b"] + p["dt"] * a["dyn_tend_b"]
+    if ext["PHYS_TEND_A"]:
+        out_a = out_a + p["dt"] * a["phys_tend_a"]
+    if ext["PHYS_TEND_B"]:
+        out_b = out_b + p["dt"] * a["phys_tend_b"]
+    return {"out_a": out_a, "out_b": out_b}
+
+
 R10 = (-10.0, 10.0)
 R1 = (-1.0, 1.0)
 SUITES: Dict[str, Suite] = {
@@ -608,6 +655,23 @@ SUITES: Dict[str, Suite] = {
                               {"field_1": (np.float32, Z, R10), "field_2": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
                               lambda a, p, e, d: {"field_out": a["field_1"] + a["field_2"]}, domains=((2, 2, 2), (5, 4, 3)),
                               data_dims={"field_1": (2,), "field_2": (2,), "field_out": (2,)}),
+    "combined_vector_scalar_op": Suite(combined_vector_scalar_op,
+                                       {"field_1": (np.float64, Z, (1.0, 10.0)), "field_2": (np.float64, Z, (1.0, 10.0)),
+                                        "field_out": (np.float64, Z, (1.0, 10.0))},
+                                       lambda a, p, e, d: {"field_out": 3 * (a["field_1"] + a["field_2"] * a["field_2"])},
+                                       domains=((2, 2, 2), (5, 4, 3)),
+                                       data_dims={"field_1": (2,), "field_2": (2,), "field_out": (2,)}),
+    "vectorized_temporary": Suite(vectorized_temporary, {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
+                                  _vectorized_temporary_expected, domains=((2, 2, 2), (5, 4, 3)),
+                                  data_dims={"field_in": (2,), "field_out": (2,)}),
+    "two_optional_fields": Suite(two_optional_fields,
+                                 {n: (np.float64, Z, R10) for n in ("in_a", "in_b", "out_a", "out_b", "dyn_tend_a", "dyn_tend_b",
+                                                                    "phys_tend_a", "phys_tend_b")},
+                                 _two_optional_expected, params={"dt": (0, 100)},
+                                 externals=({"PHYS_TEND_A": False, "PHYS_TEND_B": False}, {"PHYS_TEND_A": False, "PHYS_TEND_B": True},
+                                            {"PHYS_TEND_A": True, "PHYS_TEND_B": True}),
+                                 optional={"phys_tend_a": "PHYS_TEND_A", "phys_tend_b": "PHYS_TEND_B"},
+                                 domains=((1, 1, 1), (7, 5, 3))),
     "horizontal_regions": Suite(horizontal_regions, {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
                                 _regions_expected, domains=((4, 4, 2), (9, 7, 3))),
     "horizontal_regions_partial_writes": Suite(horizontal_regions_partial_writes,

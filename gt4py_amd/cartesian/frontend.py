@@ -22,6 +22,7 @@ import ast
 import inspect
 import numbers
 import textwrap
+from dataclasses import replace
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -493,34 +494,85 @@ class _Parser(ast.NodeVisitor):
         if access.name not in self.fields and access.name not in self.temporaries:
             self.temporaries[access.name] = ir.FieldDecl(access.name, None, ("I", "J", "K"), (), False)
             access = ir.FieldAccess(access.name, access.offset, None, None, ())
-        # vector-valued statement: accesses to fields with data dimensions that carry no data index are
-        # replaced by every index in turn (all such fields must have the same data dimensions)
-        open_dims = {self._data_dims(e.name) for e in [access, *ir.walk(value)]
-                     if isinstance(e, ir.FieldAccess) and e.data_index is None}
-        if not open_dims:
+        # vector-valued statement: accesses to fields with data dimensions that carry no data index stand for
+        # the whole vector / matrix; the statement is unrolled into one assignment per element of the target
+        # (defir_to_gtir.py:160-192)
+        is_open = lambda e: isinstance(e, ir.FieldAccess) and e.data_index is None  # noqa: E731
+        if not is_open(access) and not any(is_open(e) for e in ir.walk(value)):
+            if any(getattr(e, "op", None) in ("@", "T") for e in ir.walk(value)):
+                raise self._err(node, "'@' and '.T' apply to whole fields with data dimensions")
             return [ir.Assign(access, value, mask, group, self._region, self._loops)]
-        if len(open_dims) != 1:
-            raise self._err(node, f"Fields with different data dimensions {sorted(open_dims)} in one vector assignment")
         if access.data_index is not None:
             raise self._err(node, "A vector-valued expression cannot be assigned to a single element")
         for extra in ([mask] if mask is not None else []) + [c for _, c in self._loops]:
-            if any(isinstance(e, ir.FieldAccess) and e.data_index is None for e in ir.walk(extra)):
+            if any(is_open(e) for e in ir.walk(extra)):
                 raise self._err(node, "Conditions must index the data dimensions of the fields they read")
-        (dims,) = open_dims
+        dims = self._data_dims(access.name)
+        shape = self._vector_shape(value, node)
+        if shape and shape != dims:
+            raise self._err(node, f"Assignment dimension mismatch: '{access.name}' has dim = {dims}; rhs has dim {shape}")
         if group < 0:
             group = self._groups
             self._groups += 1
-        out = []
         import itertools
 
-        for index in itertools.product(*(range(n) for n in dims)):
-            def pick(e, index=index):
-                if isinstance(e, ir.FieldAccess) and e.data_index is None:
-                    return ir.FieldAccess(e.name, e.offset, e.dtype, e.koffset, tuple(index))
-                return e
+        return [ir.Assign(ir.FieldAccess(access.name, access.offset, None, None, tuple(index)),
+                          self._vector_element(value, tuple(index) if shape else ()), mask, group, self._region,
+                          self._loops)
+                for index in itertools.product(*(range(n) for n in dims))]
 
-            out.append(ir.Assign(pick(access), ir.map_expr(value, pick), mask, group, self._region, self._loops))
-        return out
+    # ---- vector / matrix expressions (fields with data dimensions used without a data index) ------
+    # The reference unrolls them into nested lists of scalar expressions (UnrollVectorExpressions,
+    # defir_to_gtir.py:196-299).  Here the same unrolling is expressed as (shape, element(index)).
+    def _vector_shape(self, e: ir.Expr, node) -> Tuple[int, ...]:
+        if isinstance(e, ir.FieldAccess):
+            return self._data_dims(e.name) if e.data_index is None else ()
+        if isinstance(e, ir.UnaryOp) and e.op == "T":
+            shape = self._vector_shape(e.expr, node)
+            if len(shape) != 2:
+                raise self._err(node, "'.T' applies to fields with two data dimensions")
+            return shape[::-1]
+        if isinstance(e, ir.BinaryOp) and e.op == "@":
+            left, right = self._vector_shape(e.left, node), self._vector_shape(e.right, node)
+            if len(left) != 2 or len(right) != 1 or left[1] != right[0]:
+                raise self._err(node, f"'@' multiplies a matrix with a vector; got data dimensions {left} @ {right}")
+            return left[:1]
+        children = {
+            ir.UnaryOp: lambda: (e.expr,), ir.Cast: lambda: (e.expr,), ir.BinaryOp: lambda: (e.left, e.right),
+            ir.TernaryOp: lambda: (e.cond, e.true_expr, e.false_expr), ir.NativeCall: lambda: e.args,
+        }.get(type(e), lambda: ())()
+        shapes = {s for s in (self._vector_shape(c, node) for c in children) if s}
+        if len(shapes) > 1:
+            raise self._err(node, f"Fields with different data dimensions {sorted(shapes)} in one vector expression")
+        return shapes.pop() if shapes else ()
+
+    def _vector_element(self, e: ir.Expr, index: Tuple[int, ...]) -> ir.Expr:
+        """The scalar expression for element ``index`` of the vector-valued ``e`` (scalars broadcast)."""
+        el = self._vector_element
+        if isinstance(e, ir.FieldAccess):
+            if e.data_index is None:
+                return ir.FieldAccess(e.name, e.offset, e.dtype, e.koffset, index)
+            return e
+        if isinstance(e, ir.UnaryOp) and e.op == "T":
+            return el(e.expr, index[::-1])
+        if isinstance(e, ir.BinaryOp) and e.op == "@":
+            # row . vector accumulated left to right from the first product (defir_to_gtir.py:265-273)
+            (row,) = index
+            n = self._vector_shape(e.right, None)[0]
+            acc = ir.BinaryOp("*", el(e.left, (row, 0)), el(e.right, (0,)))
+            for i in range(1, n):
+                acc = ir.BinaryOp("+", acc, ir.BinaryOp("*", el(e.left, (row, i)), el(e.right, (i,))))
+            return acc
+        pick = lambda c: el(c, index if self._vector_shape(c, None) else ())  # noqa: E731
+        if isinstance(e, (ir.UnaryOp, ir.Cast)):
+            return replace(e, expr=pick(e.expr))
+        if isinstance(e, ir.BinaryOp):
+            return replace(e, left=pick(e.left), right=pick(e.right))
+        if isinstance(e, ir.TernaryOp):
+            return replace(e, cond=pick(e.cond), true_expr=pick(e.true_expr), false_expr=pick(e.false_expr))
+        if isinstance(e, ir.NativeCall):
+            return replace(e, args=tuple(pick(a) for a in e.args))
+        return e
 
     # ---- expressions ---------------------------------------------------------------------
     def generic_visit(self, node):
@@ -628,7 +680,14 @@ class _Parser(ast.NodeVisitor):
             raise self._err(node, "Unsupported unary operator")
         return ir.UnaryOp(op, self.visit(node.operand))
 
+    def visit_Attribute(self, node: ast.Attribute) -> ir.Expr:
+        if node.attr == "T":  # matrix transpose; removed again when the vector statement is unrolled
+            return ir.UnaryOp("T", self.visit(node.value))
+        raise self._err(node, f"Unsupported attribute access '.{node.attr}'")
+
     def visit_BinOp(self, node: ast.BinOp) -> ir.Expr:
+        if isinstance(node.op, ast.MatMult):  # only inside vector statements, see _vector_element
+            return ir.BinaryOp("@", self.visit(node.left), self.visit(node.right))
         if type(node.op) not in _BIN_OPS:
             raise self._err(node, f"Unsupported binary operator '{type(node.op).__name__}'")
         return ir.BinaryOp(_BIN_OPS[type(node.op)], self.visit(node.left), self.visit(node.right))

@@ -535,6 +535,45 @@ def _vectorized_temporary_expected(a, p, ext, domain):
     return {"field_out": out}
 
 
+# ---- :1097-1162 (matrix @ vector, matrix.T @ vector) -------------------------------------------------
+def matmul(matrix: "Field[(np.float64, (4, 6))]", field_1: "Field[(np.float64, (6,))]", field_2: "Field[(np.float64, (4,))]"):
+    with computation(PARALLEL):
+        with interval(0, 1):
+            field_2 = matrix @ field_1
+        with interval(1, 2):
+            field_1 = matrix.T @ field_2
+
+
+def masked_matmul(matrix: "Field[K, (np.float64, (4, 6))]", field_1: "Field[(np.float64, (6,))]",
+                  field_2: "Field[(np.float64, (4,))]"):
+    with computation(PARALLEL):
+        with interval(0, 1):
+            field_2 = matrix @ field_1
+        with interval(1, 2):
+            field_1 = matrix.T @ field_2
+
+
+def _ordered_dot(m, v):
+    """sum_c m[..., r, c] * v[..., c], accumulated left to right from the first product -- the order the
+    reference's unrolling of '@' fixes (defir_to_gtir.py:265-273); einsum may associate differently."""
+    acc = m[..., :, 0] * v[..., None, 0]
+    for c in range(1, m.shape[-1]):
+        acc = acc + m[..., :, c] * v[..., None, c]
+    return acc
+
+
+def _matmul_expected(a, p, ext, domain):
+    m, f1, f2 = a["matrix"], a["field_1"].copy(), a["field_2"].copy()
+    m0, m1 = (m[0], m[1]) if m.ndim == 3 else (m[:, :, 0], m[:, :, 1])
+    f2[:, :, 0] = _ordered_dot(m0, f1[:, :, 0])
+    f1[:, :, 1] = _ordered_dot(np.swapaxes(m1, -1, -2), f2[:, :, 1])
+    # the reference's own validation (einsum), to rounding
+    sub = "lm" if m.ndim == 3 else "ijlm"
+    np.testing.assert_allclose(f2[:, :, 0], np.einsum(sub + ",ijm->ijl", m0, a["field_1"][:, :, 0]), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(f1[:, :, 1], np.einsum(sub + ",ijl->ijm", m1, a["field_2"][:, :, 1]), rtol=1e-12, atol=1e-12)
+    return {"field_1": f1, "field_2": f2}
+
+
 # ---- :564-611 with stencil_definitions.py:424-447 --------------------------------------------------
 def two_optional_fields(in_a: F64, in_b: F64, out_a: F64, out_b: F64, dyn_tend_a: F64, dyn_tend_b: F64,
                         phys_tend_a: F64 = None, phys_tend_b: F64 = None, *, dt: float):
@@ -664,6 +703,13 @@ SUITES: Dict[str, Suite] = {
     "vectorized_temporary": Suite(vectorized_temporary, {"field_in": (np.float32, Z, R10), "field_out": (np.float32, Z, R10)},
                                   _vectorized_temporary_expected, domains=((2, 2, 2), (5, 4, 3)),
                                   data_dims={"field_in": (2,), "field_out": (2,)}),
+    "matmul": Suite(matmul, {"matrix": (np.float64, Z, R10), "field_1": (np.float64, Z, R10), "field_2": (np.float64, Z, R10)},
+                    _matmul_expected, domains=((2, 2, 2), (5, 4, 3)),
+                    data_dims={"matrix": (4, 6), "field_1": (6,), "field_2": (4,)}),
+    "masked_matmul": Suite(masked_matmul,
+                           {"matrix": (np.float64, Z, R10), "field_1": (np.float64, Z, R10), "field_2": (np.float64, Z, R10)},
+                           _matmul_expected, domains=((2, 2, 2), (5, 4, 3)), axes={"matrix": "K"},
+                           data_dims={"matrix": (4, 6), "field_1": (6,), "field_2": (4,)}),
     "two_optional_fields": Suite(two_optional_fields,
                                  {n: (np.float64, Z, R10) for n in ("in_a", "in_b", "out_a", "out_b", "dyn_tend_a", "dyn_tend_b",
                                                                     "phys_tend_a", "phys_tend_b")},

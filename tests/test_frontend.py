@@ -402,3 +402,55 @@ def test_typed_temporary_with_initial_value():
     assert first.target.name == "acc" and isinstance(first.value, (ir.Literal, ir.Cast)) and len(st.computations) == 2
     assert second.target.name == "acc" and isinstance(second.value, ir.Cast) and second.value.dtype == np.dtype("float32")
     assert third.value.dtype == np.dtype("float64")
+
+
+# ---- vector statements over data dimensions: '@' and '.T' (defir_to_gtir.py:196-299) -----------------
+def _mv(matrix: "Field[(np.float64, (2, 3))]", vec: "Field[(np.float64, (3,))]", out: "Field[(np.float64, (2,))]"):
+    with computation(PARALLEL), interval(...):
+        out = matrix @ vec
+
+
+def test_matmul_is_unrolled_row_by_row_left_to_right():
+    st = parse(_mv)
+    stmts = [s for _, _, s in st.statements()]
+    assert [s.target.data_index for s in stmts] == [(0,), (1,)]
+    assert ir.fmt(stmts[1].value) == ("(((matrix[0,0,0][1][0] * vec[0,0,0][0]) + (matrix[0,0,0][1][1] * vec[0,0,0][1]))"
+                                      " + (matrix[0,0,0][1][2] * vec[0,0,0][2]))")
+
+
+def test_transposed_matmul_swaps_the_data_index():
+    def defn(matrix: "Field[(np.float64, (2, 3))]", vec: "Field[(np.float64, (2,))]", out: "Field[(np.float64, (3,))]"):
+        with computation(PARALLEL), interval(...):
+            out = matrix.T @ vec
+
+    stmts = [s for _, _, s in parse(defn).statements()]
+    assert len(stmts) == 3
+    assert ir.fmt(stmts[2].value) == "((matrix[0,0,0][0][2] * vec[0,0,0][0]) + (matrix[0,0,0][1][2] * vec[0,0,0][1]))"
+
+
+def test_matmul_shape_errors():
+    def inner_mismatch(matrix: "Field[(np.float64, (2, 3))]", vec: "Field[(np.float64, (2,))]", out: "Field[(np.float64, (2,))]"):
+        with computation(PARALLEL), interval(...):
+            out = matrix @ vec
+
+    def target_mismatch(matrix: "Field[(np.float64, (2, 3))]", vec: "Field[(np.float64, (3,))]", out: "Field[(np.float64, (3,))]"):
+        with computation(PARALLEL), interval(...):
+            out = matrix @ vec
+
+    def scalar_fields(a: Field[np.float64], b: Field[np.float64]):
+        with computation(PARALLEL), interval(...):
+            b = a @ a
+
+    for defn in (inner_mismatch, target_mismatch, scalar_fields):
+        with pytest.raises(D.GTScriptSyntaxError):
+            parse(defn)
+
+
+def test_scalar_broadcasts_over_a_vector_target():
+    def defn(a: Field[np.float64], out: "Field[(np.float64, (3,))]"):
+        with computation(PARALLEL), interval(...):
+            out = 2.0 * a
+
+    stmts = [s for _, _, s in parse(defn).statements()]
+    assert [s.target.data_index for s in stmts] == [(0,), (1,), (2,)]
+    assert all(ir.fmt(s.value) == ir.fmt(stmts[0].value) for s in stmts)

@@ -165,8 +165,10 @@ def make_args_data(stencil: ir.Stencil) -> ArgsData:
         if kind != AccessKind.NONE:
             (ilo, ihi), (jlo, jhi) = extents.fields[decl.name]
             klo, khi = k_bounds[decl.name]
-            # extent -> boundary: lower = max(0, -lo), upper = max(0, hi); K boundary is NOT clamped
-            boundary = Boundary(((max(0, -ilo), max(0, ihi)), (max(0, -jlo), max(0, jhi)), (klo, khi)))
+            # extent -> boundary: (-lo, hi), NOT clamped at zero (gtc/definitions.py:565-566 Extent.to_boundary on the
+            # un-centred field extents): a field only read at [1, 0, 0] has boundary (-1, 1) in I, which is what
+            # allows origin -1 for it (test_code_generation.py:520-558)
+            boundary = Boundary(((-ilo, ihi), (-jlo, jhi), (klo, khi)))
         else:
             boundary = Boundary.zeros(3)
         field_info[decl.name] = FieldInfo(access=kind, boundary=boundary, axes=tuple(decl.axes),

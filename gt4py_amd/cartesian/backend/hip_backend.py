@@ -55,7 +55,9 @@ def canonical_form(stencil: ir.Stencil) -> Tuple[Tuple, Dict[str, str]]:
             return ("lit", repr(e.value), str(e.dtype))
         if isinstance(e, ir.FieldAccess):
             return ("field", canon(e.name), e.offset, str(e.dtype), expr(e.koffset) if e.koffset is not None else None,
-                    tuple(e.data_index or ()))
+                    tuple(expr(d) if isinstance(d, ir.Expr) else d for d in e.data_index or ()), e.absolute_k)
+        if isinstance(e, ir.AxisIndex):
+            return ("axis", e.axis, str(e.dtype))
         if isinstance(e, ir.ScalarAccess):
             return ("scalar", canon(e.name), str(e.dtype))
         if isinstance(e, ir.UnaryOp):

@@ -119,8 +119,17 @@ template <class T> GT_DEV T gt_mod(T a, T b) {
     T m = a % b;
     return (m != 0 && ((m < 0) != (b < 0))) ? m + b : m;
 }
-GT_DEV double gt_pow(double a, double b) { return __builtin_pow(a, b); }
-GT_DEV float gt_pow(float a, float b) { return __builtin_powf(a, b); }
+// device-library entry points the compiler has no builtin lowering for on amdgcn
+extern "C" __device__ double __ocml_pow_f64(double, double);
+extern "C" __device__ float __ocml_pow_f32(float, float);
+extern "C" __device__ double __ocml_erf_f64(double);
+extern "C" __device__ float __ocml_erf_f32(float);
+extern "C" __device__ double __ocml_erfc_f64(double);
+extern "C" __device__ float __ocml_erfc_f32(float);
+extern "C" __device__ double __ocml_tgamma_f64(double);
+extern "C" __device__ float __ocml_tgamma_f32(float);
+GT_DEV double gt_pow(double a, double b) { return __ocml_pow_f64(a, b); }
+GT_DEV float gt_pow(float a, float b) { return __ocml_pow_f32(a, b); }
 template <class T> GT_DEV T gt_pow(T a, T b) {
     T r = 1;
     for (T n = 0; n < b; ++n) r *= a;
@@ -132,26 +141,40 @@ template <class T> GT_DEV T gt_abs(T a) { return a < 0 ? -a : a; }
 #define GT_MATH1(name, fd, ff) \
     GT_DEV double gt_##name(double a) { return fd(a); } \
     GT_DEV float gt_##name(float a) { return ff(a); }
+// transcendental functions: the device library's (the ones HIP's <cmath> calls); the compiler's own builtins
+// either have no lowering on amdgcn (tan, pow, erf ...) or lower to the low-accuracy hardware instructions
+#define GT_OCML1(name) \
+    extern "C" __device__ double __ocml_##name##_f64(double); \
+    extern "C" __device__ float __ocml_##name##_f32(float); \
+    GT_DEV double gt_##name(double a) { return __ocml_##name##_f64(a); } \
+    GT_DEV float gt_##name(float a) { return __ocml_##name##_f32(a); }
 GT_MATH1(sqrt, __builtin_sqrt, __builtin_sqrtf)
 GT_MATH1(floor, __builtin_floor, __builtin_floorf)
 GT_MATH1(ceil, __builtin_ceil, __builtin_ceilf)
 GT_MATH1(trunc, __builtin_trunc, __builtin_truncf)
-GT_MATH1(sin, __builtin_sin, __builtin_sinf)
-GT_MATH1(cos, __builtin_cos, __builtin_cosf)
-GT_MATH1(tan, __builtin_tan, __builtin_tanf)
-GT_MATH1(asin, __builtin_asin, __builtin_asinf)
-GT_MATH1(acos, __builtin_acos, __builtin_acosf)
-GT_MATH1(atan, __builtin_atan, __builtin_atanf)
-GT_MATH1(sinh, __builtin_sinh, __builtin_sinhf)
-GT_MATH1(cosh, __builtin_cosh, __builtin_coshf)
-GT_MATH1(tanh, __builtin_tanh, __builtin_tanhf)
-GT_MATH1(asinh, __builtin_asinh, __builtin_asinhf)
-GT_MATH1(acosh, __builtin_acosh, __builtin_acoshf)
-GT_MATH1(atanh, __builtin_atanh, __builtin_atanhf)
-GT_MATH1(exp, __builtin_exp, __builtin_expf)
-GT_MATH1(log, __builtin_log, __builtin_logf)
-GT_MATH1(log10, __builtin_log10, __builtin_log10f)
-GT_MATH1(cbrt, __builtin_cbrt, __builtin_cbrtf)
+GT_OCML1(sin)
+GT_OCML1(cos)
+GT_OCML1(tan)
+GT_OCML1(asin)
+GT_OCML1(acos)
+GT_OCML1(atan)
+GT_OCML1(sinh)
+GT_OCML1(cosh)
+GT_OCML1(tanh)
+GT_OCML1(asinh)
+GT_OCML1(acosh)
+GT_OCML1(atanh)
+GT_OCML1(exp)
+GT_OCML1(log)
+GT_OCML1(log10)
+GT_OCML1(cbrt)
+GT_MATH1(erf, __ocml_erf_f64, __ocml_erf_f32)
+GT_MATH1(erfc, __ocml_erfc_f64, __ocml_erfc_f32)
+GT_MATH1(gamma, __ocml_tgamma_f64, __ocml_tgamma_f32)
+GT_MATH1(round, __builtin_rint, __builtin_rintf)  // ties to even, like np.round / std::nearbyint
+// ties away from zero the way the reference's numpy backend spells it (gtc/ufuncs.py:31-33)
+GT_DEV double gt_round_away_from_zero(double a) { return __builtin_copysign(__builtin_floor(__builtin_fabs(a) + 0.5), a); }
+GT_DEV float gt_round_away_from_zero(float a) { return __builtin_copysignf(__builtin_floorf(__builtin_fabsf(a) + 0.5f), a); }
 // Workgroup -> tile.  The dispatcher deals workgroups round-robin to the 8 XCDs in linear order (x
 // fastest); give each XCD runs of `rows` consecutive tile rows instead of every 8th tile.
 GT_DEV void gt_tile(unsigned rows, unsigned& bx, unsigned& by, unsigned& bz) {
@@ -192,7 +215,8 @@ template <class T> GT_DEV bool gt_isinf(T a) { return a == a && (a - a) != (a - 
 template <class T> GT_DEV bool gt_isfinite(T a) { return (a - a) == (a - a); }
 """
 
-_EXACT_CALLS = {"abs", "min", "max", "mod", "sqrt", "floor", "ceil", "trunc", "isfinite", "isinf", "isnan"}
+_EXACT_CALLS = {"abs", "min", "max", "mod", "sqrt", "floor", "ceil", "trunc", "isfinite", "isinf", "isnan", "round",
+                "round_away_from_zero"}
 
 
 def _c_ident(name: str) -> str:
@@ -249,7 +273,7 @@ class _Emitter:
         self.decl_dtype: Dict[str, np.dtype] = {}
         for d in (*plan.stencil.fields, *plan.stencil.temporaries):
             self.decl_dtype[d.name] = np.dtype(d.dtype)
-        self.axes: Dict[str, Tuple[str, ...]] = {f.name: tuple(f.axes) for f in plan.stencil.fields}
+        self.axes: Dict[str, Tuple[str, ...]] = {f.name: tuple(f.axes) for f in (*plan.stencil.fields, *plan.stencil.temporaries)}
         self.data_dims: Dict[str, Tuple[int, ...]] = {d.name: tuple(d.data_dims) for d in
                                                       (*plan.stencil.fields, *plan.stencil.temporaries)}
         self.global_names = [f.name for f in plan.api_fields] + list(plan.scratch)
@@ -266,15 +290,17 @@ class _Emitter:
         self.base_prefix = "b_"
 
     # -- expressions --------------------------------------------------------------------------
-    def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str]) -> str:
-        """C expression of a field read.  ``reg`` maps (name, k offset) -> register holding that level."""
+    def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str], store: bool = False) -> str:
+        """C expression of a field access.  ``reg`` maps (name, k offset) -> register holding that level; with
+        ``store`` the expression is the memory location itself (an lvalue), whatever is held in registers."""
         name = e.name
         if name in self.plan.locals:
             return f"l_{_c_ident(name)}{self.local_suffix}"
-        if self.vec_rows is not None and "I" in self.axes.get(name, ("I", "J", "K")):
-            return self.vec_rows[(name, e.offset[1] + self.vec_row, e.offset[2])][self.vec_component + e.offset[0]]
-        if (name, e.offset[2]) in reg and e.offset[:2] == (0, 0) and e.koffset is None:
-            return reg[(name, e.offset[2])]
+        if not store:
+            if self.vec_rows is not None and "I" in self.axes.get(name, ("I", "J", "K")):
+                return self.vec_rows[(name, e.offset[1] + self.vec_row, e.offset[2])][self.vec_component + e.offset[0]]
+            if (name, e.offset[2]) in reg and e.offset[:2] == (0, 0) and e.koffset is None:
+                return reg[(name, e.offset[2])]
         if name in self.plan.register_only:
             raise AssertionError(f"register-only temporary '{name}' needs memory at offset {e.offset}")
         c = _c_ident(name)
@@ -284,7 +310,9 @@ class _Emitter:
         if "K" in axes:
             if e.koffset is not None:
                 saved_rows, self.vec_rows = self.vec_rows, None  # the index itself is read from memory
-                terms.append(f"({k}{dk:+d} + (gt_i64)({self.expr(e.koffset, k, stage_index, reg)})) * a.{c}_sk")
+                level = f"(gt_i64)({self.expr(e.koffset, k, stage_index, reg)})"
+                # absolute: counted from the field's K origin, which is where the base pointer stands
+                terms.append(f"({level}) * a.{c}_sk" if e.absolute_k else f"({k}{dk:+d} + {level}) * a.{c}_sk")
                 self.vec_rows = saved_rows
             else:
                 terms.append(f"({k}{dk:+d}) * a.{c}_sk" if dk else f"{k} * a.{c}_sk")
@@ -293,7 +321,9 @@ class _Emitter:
         if dj and "J" in axes:
             terms.append(f"{dj} * a.{c}_sj")
         for n, d in enumerate(e.data_index or ()):
-            if d:
+            if isinstance(d, ir.Expr):  # run-time data index
+                terms.append(f"(gt_i64)({self.expr(d, k, stage_index, reg)}) * a.{c}_d{n}")
+            elif d:
                 terms.append(f"{d} * a.{c}_d{n}")
         return f"{self.base_prefix}{c}[{' + '.join(terms) if terms else '0'}]"
 
@@ -305,6 +335,8 @@ class _Emitter:
             return self.access(e, k, si, reg)
         if isinstance(e, ir.ScalarAccess):
             return f"a.p_{_c_ident(e.name)}"
+        if isinstance(e, ir.AxisIndex):  # the K level, counted from the start of the compute domain
+            return f"(({_CTYPE[np.dtype(e.dtype).name]})({k}))"
         if isinstance(e, ir.Cast):
             dt = np.dtype(e.dtype)
             inner = rec(e.expr)
@@ -387,12 +419,12 @@ class _Emitter:
         elif name in carry:  # keep the freshly written level for this iteration's later reads and the next one
             self.lines.append(f"{pad}n_{_c_ident(name)} = {value};")
             if name not in self.plan.register_only:
-                self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset, None, None, s.target.data_index), k, -1, {})} = n_{_c_ident(name)};")
+                self.lines.append(f"{pad}{self.access(s.target, k, si, reg, store=True)} = n_{_c_ident(name)};")
             reg[(name, 0)] = f"n_{_c_ident(name)}"
         elif name in self.streaming:
-            self.lines.append(f"{pad}__builtin_nontemporal_store({value}, &{self.access(ir.FieldAccess(name, s.target.offset, None, None, s.target.data_index), k, -1, {})});")
+            self.lines.append(f"{pad}__builtin_nontemporal_store({value}, &{self.access(s.target, k, si, reg, store=True)});")
         else:
-            self.lines.append(f"{pad}{self.access(ir.FieldAccess(name, s.target.offset, None, None, s.target.data_index), k, -1, {})} = {value};")
+            self.lines.append(f"{pad}{self.access(s.target, k, si, reg, store=True)} = {value};")
         if g:
             self.lines.append(f"{indent}}}")
 
@@ -586,7 +618,7 @@ def _vector_width(em: "_Emitter", stage: Stage) -> int:
             # to a horizontal region (whose reads need less halo than an unrestricted statement's would)
             if s.extent != stage.extent or s.region is not None or s.loops:
                 return 0
-            if s.target.offset != (0, 0, 0) or s.target.data_index:
+            if s.target.offset != (0, 0, 0) or s.target.data_index or s.target.koffset is not None:
                 return 0
             if s.target.name not in em.plan.locals:
                 if "I" not in em.axes.get(s.target.name, ("I", "J", "K")):

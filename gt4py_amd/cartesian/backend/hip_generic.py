@@ -201,6 +201,7 @@ class HipGenericStencilObject(StencilObject):
             if entry is None:
                 layout, total = {}, 0
                 temp_dims = {t.name: tuple(t.data_dims) for t in plan.stencil.temporaries}
+                temp_levels = {t.name: (max(dK, 1) if "K" in t.axes else 1) for t in plan.stencil.temporaries}
                 for name, (dt, ((ilo, ihi), (jlo, jhi))) in plan.scratch.items():
                     oi = -(-(-ilo) // 4) * 4  # the domain's first column on a 16-byte boundary
                     ni = -(-(dI + ihi + oi) // 32) * 32  # rows padded like the storage preset
@@ -210,7 +211,7 @@ class HipGenericStencilObject(StencilObject):
                     total += (len(layout) % 8) * (3 << 19)
                     layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
                     n_elem = int(np.prod(temp_dims.get(name, ()) or (1,)))  # data dimensions: outermost
-                    total += -(-(ni * nj * max(dK, 1) * n_elem * dt.itemsize) // 256) * 256
+                    total += -(-(ni * nj * temp_levels[name] * n_elem * dt.itemsize) // 256) * 256
                 buf = torch.empty(total, dtype=torch.uint8, device="cuda")
                 cls._gt_scratch_.clear()  # one domain at a time: scratch can be gigabytes ...
                 cls._gt_launch_cache_.clear()  # ... and cached launch plans keep theirs alive
@@ -222,13 +223,15 @@ class HipGenericStencilObject(StencilObject):
                 setattr(args, c, base + off + (oi + oj * ni) * isz)
                 setattr(args, f"{c}_si", 1)
                 setattr(args, f"{c}_sj", ni)
-                setattr(args, f"{c}_sk", ni * nj)
-                dims = tuple(next(t.data_dims for t in plan.stencil.temporaries if t.name == name))
-                stride = ni * nj * max(dK, 1)
+                decl = next(t for t in plan.stencil.temporaries if t.name == name)
+                levels = max(dK, 1) if "K" in decl.axes else 1  # 2-d temporaries: one level, K stride 0
+                setattr(args, f"{c}_sk", ni * nj if "K" in decl.axes else 0)
+                dims = tuple(decl.data_dims)
+                stride = ni * nj * levels
                 for dn in range(len(dims) - 1, -1, -1):  # last data dimension varies fastest among them
                     setattr(args, f"{c}_d{dn}", stride)
                     stride *= dims[dn]
-                geometry[name] = (base + off + (oi + oj * ni) * isz, ni, ni * nj, isz)
+                geometry[name] = (base + off + (oi + oj * ni) * isz, ni, ni * nj if "K" in decl.axes else 0, isz)
         for p in plan.params:
             setattr(args, f"p_{hip_codegen._c_ident(p.name)}", np.dtype(p.dtype).type(arguments[p.name]).item())
         args.dI, args.dJ, args.dK = dI, dJ, dK

@@ -12,7 +12,7 @@ built here):
 
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace
 from typing import Dict, List, Optional, Set, Tuple
 
 import numpy as np
@@ -30,8 +30,7 @@ class UnsupportedStencil(NotImplementedError):
 # 1. inlining of horizontally offset temporaries
 # ---------------------------------------------------------------------------------------------------
 def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
-    return ir.FieldAccess(e.name, (e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]), e.dtype, e.koffset,
-                          e.data_index)
+    return replace(e, offset=(e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]))
 
 
 def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[str]]:
@@ -61,6 +60,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
     cand = {
         n for n in temps
         if len(touched.get(n, ())) == 1 and n not in k_offset_read and n not in masked_write and not temps[n].data_dims
+        and tuple(temps[n].axes) == ("I", "J", "K")
         and stencil.computations[next(iter(touched[n]))[0]].order is ir.LoopOrder.PARALLEL
     }
     changed = True
@@ -101,7 +101,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                     if isinstance(e, ir.FieldAccess) and e.name in inline:
                         if e.name not in version:  # the frontend rejects this already
                             raise UnsupportedStencil(f"temporary '{e.name}' is read before it is assigned")
-                        return ir.FieldAccess(version[e.name], e.offset, e.dtype, e.koffset, e.data_index)
+                        return replace(e, name=version[e.name])
                     return e
 
                 return ir.map_expr(expr, fn)
@@ -117,7 +117,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                     version[name] = v
                     order.append(("def", v))
                 else:
-                    order.append(("stmt", ir.Assign(stmt.target, value, mask, stmt.group, stmt.region, loops)))
+                    order.append(("stmt", ir.Assign(to_versions(stmt.target), value, mask, stmt.group, stmt.region, loops)))
 
             memo: Dict[Tuple[str, Tuple[int, int]], ir.Expr] = {}
             needed: Set[str] = set()
@@ -159,7 +159,7 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                         ssa_locals[obj] = np.dtype(temps[obj.rsplit("__v", 1)[0]].dtype)
                         new_body.append(ir.Assign(ir.FieldAccess(obj, (0, 0, 0), ssa_locals[obj]), local_defs[obj]))
                 else:
-                    new_body.append(ir.Assign(obj.target, value[0], value[1], obj.group, obj.region, value[2]))
+                    new_body.append(ir.Assign(expand(obj.target, (0, 0)), value[0], value[1], obj.group, obj.region, value[2]))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     new_temps = tuple(t for t in stencil.temporaries if t.name not in inline) + tuple(
@@ -223,7 +223,14 @@ def _stmt_field_reads(s) -> List[ir.FieldAccess]:
         reads = _field_reads(s.mask) + reads
     for _, cond in getattr(s, "loops", ()):
         reads = _field_reads(cond) + reads
+    for sub in _target_exprs(s.target):  # run-time K offset / data index of the write
+        reads = reads + _field_reads(sub)
     return reads
+
+
+def _target_exprs(target: ir.FieldAccess) -> List[ir.Expr]:
+    out = [target.koffset] if target.koffset is not None else []
+    return out + [d for d in target.data_index or () if isinstance(d, ir.Expr)]
 
 
 def plan_stages(stencil_in: ir.Stencil) -> Plan:
@@ -309,7 +316,10 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
             if s.target.name in temp_names:
                 where.setdefault(s.target.name, set()).add(nid)
                 defined.add(s.target.name)
+                if s.target.offset != (0, 0, 0) or s.target.koffset is not None:
+                    bad_local.add(s.target.name)  # written at another level than the one being computed
     bad_local |= {t.name for t in stencil.temporaries if t.data_dims}  # several values per point: not a scalar
+    bad_local |= {t.name for t in stencil.temporaries if tuple(t.axes) != ("I", "J", "K")}  # 2-d: outlives the K level
     local_names = {n for n in temp_names if n in where and n not in bad_local}
     # a local that is written in one nest and never read anywhere is dead but harmless
     scratch: Dict[str, Tuple[np.dtype, Extent2]] = {}
@@ -342,7 +352,8 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                         extents_of.setdefault(e.name, set()).add(s.extent)
         with_data_dims = {d.name for d in (*stencil.fields, *stencil.temporaries) if d.data_dims}
         unsafe = with_data_dims | {s.target.name for nest in stage.nests for s in nest.stmts
-                  if s.mask is not None or s.region is not None or s.loops or s.target.offset != (0, 0, 0)}  # conditional / displaced writes
+                  if s.mask is not None or s.region is not None or s.loops or s.target.offset != (0, 0, 0)
+                  or s.target.koffset is not None}  # conditional / displaced writes
         for name, pats in patterns.items():
             if name in local_names or name in unsafe or len(extents_of.get(name, ())) != 1:
                 continue
@@ -407,7 +418,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     for _, nest in nest_list:
         for s in nest.stmts:
             used.add(s.target.name)
-            for ex in ([c for _, c in s.loops] + ([s.value] if s.mask is None else [s.mask, s.value])):
+            for ex in ([c for _, c in s.loops] + ([s.value] if s.mask is None else [s.mask, s.value]) + _target_exprs(s.target)):
                 for e in ir.walk(ex):
                     if isinstance(e, (ir.FieldAccess, ir.ScalarAccess)):
                         used.add(e.name)

@@ -60,6 +60,20 @@ _NATIVE_UFUNC = {
     "cbrt": np.cbrt, "isfinite": np.isfinite, "isinf": np.isinf, "isnan": np.isnan,
     "floor": np.floor, "ceil": np.ceil, "trunc": np.trunc,
 }
+
+
+class _FloatOnly:
+    """Signature of the reference's non-ufunc math functions: float32 -> float32, float64 -> float64
+    (gtc/ufuncs.py:16-40)."""
+
+    types = ["f->f", "d->d"]
+
+    def __init__(self, name):
+        self.__name__ = name
+
+
+for _name in ("erf", "erfc", "gamma", "round", "round_away_from_zero"):
+    _NATIVE_UFUNC[_name] = _FloatOnly(_name)
 _CAST_FUNCS = {"int32": np.dtype("int32"), "int64": np.dtype("int64"), "float32": np.dtype("float32"),
                "float64": np.dtype("float64")}
 
@@ -91,9 +105,10 @@ def _max_dtype(*dtypes: np.dtype) -> np.dtype:
 
 
 class _Parser(ast.NodeVisitor):
-    def __init__(self, definition, annotations, externals, options: gt_definitions.BuildOptions):
+    def __init__(self, definition, annotations, externals, options: gt_definitions.BuildOptions, dtypes=None):
         self.definition = definition
         self.externals = dict(externals)
+        self.dtypes = dict(dtypes or {})
         self.int_dtype = np.dtype(gt_definitions.get_integer_type(options.literal_int_precision))
         self.float_dtype = np.dtype(gt_definitions.get_float_type(options.literal_float_precision))
         self.fields: Dict[str, ir.FieldDecl] = {}
@@ -110,6 +125,9 @@ class _Parser(ast.NodeVisitor):
             if isinstance(ann, gtscript._FieldDescriptor):
                 axes = tuple(a.name if isinstance(a, gtscript.Axis) else str(a) for a in ann.axes)
                 self.fields[pname] = ir.FieldDecl(pname, np.dtype(ann.dtype), axes, tuple(ann.data_dims), True)
+            elif isinstance(ann, type) and ann in gtscript.ENUM_REGISTER.values():
+                # enums are passed as integers (gtscript_frontend.py:2181-2187)
+                self.params[pname] = ir.ScalarDecl(pname, self.int_dtype)
             else:
                 try:
                     dt = np.dtype(ann)
@@ -182,27 +200,60 @@ class _Parser(ast.NodeVisitor):
             computations=tuple(computations),
         )
 
-    def _declare_typed_temporary(self, node: ast.AnnAssign) -> Optional[ir.Computation]:
+    def _declare_annotated(self, node: ast.AnnAssign) -> ir.FieldDecl:
+        """Declare the temporary of ``name: <annotation>``.  The annotation is a dtype (``float``, ``np.int32``, a
+        key of ``dtypes=``) for a 3-d temporary, ``Field[dtype]`` / ``Field[(dtype, data_dims)]``, or
+        ``Field[IJ, dtype]`` for a 2-d temporary (one value per column, kept across K levels and computations;
+        the reference supports those on its debug, numpy and dace backends only)."""
         if not isinstance(node.target, ast.Name):
             raise self._err(node, "Only plain names can be annotated as temporaries")
         name = node.target.id
         if name in self.fields or name in self.params or name in self.temporaries:
             raise self._err(node, f"'{name}' is already defined")
         scope = {"Field": gtscript.Field, "np": np, "I": gtscript.I, "J": gtscript.J, "K": gtscript.K,
-                 "IJ": gtscript.IJ, "IK": gtscript.IK, "JK": gtscript.JK, "IJK": gtscript.IJK}
+                 "IJ": gtscript.IJ, "IK": gtscript.IK, "JK": gtscript.JK, "IJK": gtscript.IJK,
+                 "int32": np.int32, "int64": np.int64, "float32": np.float32, "float64": np.float64}
         scope.update(getattr(self.definition, "__globals__", {}))
         try:
-            descriptor = eval(ast.unparse(node.annotation), scope)  # noqa: S307 - the user's own annotation
+            closure = inspect.getclosurevars(self.definition)
+            scope.update(closure.nonlocals)
+        except (TypeError, ValueError):
+            pass
+        scope.update({k: v for k, v in self.dtypes.items() if isinstance(k, str)})
+        source = ast.unparse(node.annotation)
+        try:
+            descriptor = eval(source, scope)  # noqa: S307 - the user's own annotation
         except Exception as ex:
-            raise self._err(node, f"Cannot evaluate the annotation of temporary '{name}'") from ex
+            raise self._err(node, f"Failed to recognize type {source} for local symbol {name}.") from ex
+        descriptor = self.dtypes.get(descriptor, descriptor) if not isinstance(descriptor, gtscript._FieldDescriptor) else descriptor
         if not isinstance(descriptor, gtscript._FieldDescriptor):
-            raise self._err(node, f"Temporary '{name}' must be annotated with Field[...]")
+            if descriptor is int:
+                descriptor = self.int_dtype
+            elif descriptor is float:
+                descriptor = self.float_dtype
+            try:
+                descriptor = gtscript._FieldDescriptor(descriptor, gtscript.IJK)
+            except (ValueError, TypeError) as ex:
+                raise self._err(node, f"Failed to recognize type {source} for local symbol {name}.") from ex
         axes = tuple(a.name if isinstance(a, gtscript.Axis) else str(a) for a in descriptor.axes)
-        if axes != ("I", "J", "K"):
-            raise self._err(node, f"Found {''.join(axes)}, but only IJK is currently supported for temporaries")
-        dtype = np.dtype(descriptor.dtype)
+        if axes not in (("I", "J", "K"), ("I", "J")):
+            raise self._err(node, f"Typed temporaries must be IJ, temporaries for axes {axes} is not yet available. "
+                                  "Contact the team.")
+        dtype = descriptor.dtype
+        if isinstance(dtype, str):
+            if dtype not in self.dtypes:
+                raise self._err(node, f"Unknown dtype key '{dtype}' for temporary '{name}' (pass dtypes={{...}})")
+            dtype = self.dtypes[dtype]
         dims = tuple(int(n) for n in descriptor.data_dims)
-        self.temporaries[name] = ir.FieldDecl(name, dtype, ("I", "J", "K"), dims, False)
+        decl = ir.FieldDecl(name, np.dtype(dtype), axes, dims, False)
+        self.temporaries[name] = decl
+        return decl
+
+    def _declare_typed_temporary(self, node: ast.AnnAssign) -> Optional[ir.Computation]:
+        decl = self._declare_annotated(node)
+        name, dims = decl.name, decl.data_dims
+        if decl.axes != ("I", "J", "K"):
+            raise self._err(node, "2-d temporaries are declared where they are first assigned, inside a computation")
         if node.value is None:
             return None
         value = self._const(node.value)
@@ -317,6 +368,17 @@ class _Parser(ast.NodeVisitor):
             if len(node.targets) != 1:
                 raise self._err(node, "Chained assignment is not supported")
             return self._make_assign(node.targets[0], self.visit(node.value), node, mask, group)
+        if isinstance(node, ast.ImportFrom):  # `from __externals__ import X` inside a computation
+            self._visit_import(node)
+            return []
+        if isinstance(node, ast.AnnAssign):
+            # `tmp: float = 0` / `tmp: Field[IJ, float] = 0` inside a computation: declares the temporary on its
+            # first assignment (gtscript_frontend.py:1840-1905)
+            if not isinstance(node.target, ast.Name) or node.value is None:
+                raise self._err(node, "Only initialised plain names can be annotated inside a computation")
+            if node.target.id not in self.fields and node.target.id not in self.temporaries:
+                self._declare_annotated(node)
+            return self._make_assign(node.target, self.visit(node.value), node, mask, group)
         if isinstance(node, ast.AugAssign):
             if type(node.op) not in _BIN_OPS:
                 raise self._err(node, "Unsupported augmented assignment")
@@ -454,46 +516,70 @@ class _Parser(ast.NodeVisitor):
         return tuple(decl.data_dims) if decl is not None else ()
 
     def _split_data_index(self, node: ast.Subscript):
-        """``f[i, j, k][d0, d1]`` -> (the ``f[i, j, k]`` node, (d0, d1)); plain subscripts -> (node, None)."""
+        """``f[i, j, k][d0, d1]`` -> (the ``f[i, j, k]`` node, (d0, d1)); ``f.A[d0, d1]`` -> (the ``f`` name node,
+        (d0, d1)); plain subscripts -> (node, None).  Elements that are not compile-time constants are integer
+        expressions evaluated at run time (gtscript_frontend.py:1429-1455)."""
         inner = node.value
         if isinstance(inner, ast.Subscript) and isinstance(inner.value, ast.Name) and self._data_dims(inner.value.id):
-            dims = self._data_dims(inner.value.id)
-            elts = list(node.slice.elts) if isinstance(node.slice, ast.Tuple) else [node.slice]
-            index = tuple(self._const(e) for e in elts)
-            if len(index) != len(dims) or not all(isinstance(v, numbers.Integral) and 0 <= v < n for v, n in zip(index, dims)):
-                raise self._err(node, f"Invalid data index {list(index)} for field '{inner.value.id}' with data dimensions {dims}")
-            return inner, tuple(int(v) for v in index)
-        return node, None
+            name = inner.value.id
+        elif isinstance(inner, ast.Attribute) and inner.attr == "A" and isinstance(inner.value, ast.Name):
+            name, inner = inner.value.id, inner.value
+            if name not in self.fields and name not in self.temporaries:
+                raise GTScriptSymbolError(f"Unknown field '{name}' in stencil '{self.definition.__name__}'")
+        else:
+            return node, None
+        dims = self._data_dims(name)
+        elts = list(node.slice.elts) if isinstance(node.slice, ast.Tuple) else [node.slice]
+        index = []
+        for e in elts:
+            try:
+                v = self._const(e)
+            except (GTScriptSyntaxError, GTScriptSymbolError):
+                index.append(self.visit(e))
+                continue
+            if isinstance(v, (bool, np.bool_)) or not isinstance(v, numbers.Integral):
+                raise self._err(node, f"Invalid data index for field '{name}': {v!r}")
+            index.append(int(v))
+        if len(index) != len(dims):
+            raise self._err(node, f"Incorrect data index length {len(index)}. Invalid data dimension index. "
+                                  f"Field {name} has {len(dims)} data dimensions.")
+        if any(isinstance(v, int) and not 0 <= v < n for v, n in zip(index, dims)):
+            raise self._err(node, f"Data index out of bounds. Found index {index}, but field {name} has {dims} "
+                                  "data-dimensions")
+        return inner, tuple(index)
 
     def _target_access(self, target, node, reading=False) -> ir.FieldAccess:
         data_index: Optional[Tuple[int, ...]] = None
+        variable: list = []
         if isinstance(target, ast.Subscript):
+            if isinstance(target.value, ast.Attribute) and target.value.attr == "A":
+                raise self._err(node, "writing to an GlobalTable ('A' global indexation) is forbidden")
             target, data_index = self._split_data_index(target)
         if isinstance(target, ast.Name):
             name, offset = target.id, (0, 0, 0)
         elif isinstance(target, ast.Subscript) and isinstance(target.value, ast.Name):
             name = target.value.id
-            offset = self._parse_offset(target, name)
+            offset = self._parse_offset(target, name, variable)
         else:
             raise self._err(node, "Invalid assignment target")
         if data_index is None and not self._data_dims(name):
             data_index = ()
         if offset[0] != 0 or offset[1] != 0:
             raise self._err(node, "Assignment to non-zero offsets is not supported in IJ")
-        if offset[2] != 0 and self._order is ir.LoopOrder.PARALLEL:
+        if (offset[2] != 0 or variable) and self._order is ir.LoopOrder.PARALLEL:
             raise self._err(node, "Assignment to non-zero offsets in K is not available in PARALLEL. "
                                   "Choose FORWARD or BACKWARD.")
         if name in self.params or name in self.imported:
             raise self._err(node, f"Cannot assign to scalar parameter or external '{name}'")
         if reading and name not in self.fields and name not in self.temporaries:
             raise GTScriptSymbolError(f"Unknown symbol '{name}'")
-        return ir.FieldAccess(name, offset, None, None, data_index)
+        return ir.FieldAccess(name, offset, None, variable[0] if variable else None, data_index)
 
     def _make_assign(self, target, value: ir.Expr, node, mask: Optional[ir.Expr] = None, group: int = -1) -> List[ir.Assign]:
         access = self._target_access(target, node)
         if access.name not in self.fields and access.name not in self.temporaries:
             self.temporaries[access.name] = ir.FieldDecl(access.name, None, ("I", "J", "K"), (), False)
-            access = ir.FieldAccess(access.name, access.offset, None, None, ())
+            access = ir.FieldAccess(access.name, access.offset, None, access.koffset, ())
         # vector-valued statement: accesses to fields with data dimensions that carry no data index stand for
         # the whole vector / matrix; the statement is unrolled into one assignment per element of the target
         # (defir_to_gtir.py:160-192)
@@ -516,7 +602,7 @@ class _Parser(ast.NodeVisitor):
             self._groups += 1
         import itertools
 
-        return [ir.Assign(ir.FieldAccess(access.name, access.offset, None, None, tuple(index)),
+        return [ir.Assign(ir.FieldAccess(access.name, access.offset, None, access.koffset, tuple(index)),
                           self._vector_element(value, tuple(index) if shape else ()), mask, group, self._region,
                           self._loops)
                 for index in itertools.product(*(range(n) for n in dims))]
@@ -609,6 +695,10 @@ class _Parser(ast.NodeVisitor):
             return self._literal_from_python(self.imported[name], node)
         if name in ("True", "False"):
             return ir.Literal(name == "True", np.dtype("bool"))
+        if name == "K":  # the iteration index as a value (gtscript_frontend.py:874-886, 1312-1316)
+            return ir.AxisIndex("K", self.int_dtype)
+        if name in ("I", "J"):
+            raise self._err(node, f"Parallel axis {name} can't be queried - only K")
         raise GTScriptSymbolError(f"Unknown symbol '{name}' in stencil '{self.definition.__name__}'")
 
     def _parse_offset(self, node: ast.Subscript, name: str, variable: Optional[list] = None) -> Tuple[int, int, int]:
@@ -663,6 +753,8 @@ class _Parser(ast.NodeVisitor):
 
     def visit_Subscript(self, node: ast.Subscript) -> ir.Expr:
         node, data_index = self._split_data_index(node)
+        if isinstance(node, ast.Name):  # name.A[...]: centred access with a data index
+            return ir.FieldAccess(node.id, (0, 0, 0), None, None, data_index)
         if not isinstance(node.value, ast.Name):
             raise self._err(node, "Only fields can be subscripted")
         name = node.value.id
@@ -683,6 +775,9 @@ class _Parser(ast.NodeVisitor):
     def visit_Attribute(self, node: ast.Attribute) -> ir.Expr:
         if node.attr == "T":  # matrix transpose; removed again when the vector statement is unrolled
             return ir.UnaryOp("T", self.visit(node.value))
+        if isinstance(node.value, ast.Name) and node.value.id in gtscript.ENUM_REGISTER:
+            # MyEnum.A is its integer value (gtscript_frontend.py:449-459)
+            return ir.Literal(int(getattr(gtscript.ENUM_REGISTER[node.value.id], node.attr)), self.int_dtype)
         raise self._err(node, f"Unsupported attribute access '.{node.attr}'")
 
     def visit_BinOp(self, node: ast.BinOp) -> ir.Expr:
@@ -709,8 +804,43 @@ class _Parser(ast.NodeVisitor):
     def visit_IfExp(self, node: ast.IfExp) -> ir.Expr:
         return ir.TernaryOp(self.visit(node.test), self.visit(node.body), self.visit(node.orelse))
 
+    def _visit_absolute_k(self, node: ast.Call) -> ir.Expr:
+        """``field.at(K=<int expression>)``: read at an absolute K level (gtscript_frontend.py:1671-1731)."""
+        if not isinstance(node.func.value, ast.Name):
+            raise self._err(node, "Absolute K index: Bad syntax. Must be of the form `field.at(...)`")
+        if node.args or not node.keywords:
+            raise self._err(node, "Absolute K index: Bad syntax. Must be of the form`.at(K=...)`")
+        if node.keywords[0].arg != "K":
+            raise self._err(node, "Absolute K index: Bad syntax. First argument must be `K`, e.g. `.at(K=...)`.")
+        if len(node.keywords) > 2 or (len(node.keywords) == 2 and node.keywords[1].arg != "ddim"):
+            raise self._err(node, "Absolute K index: Bad syntax. Second argument (optional) must be `ddim`, "
+                                  "e.g. `.at(K=..., ddim=[...])`.")
+        if len(node.keywords) == 2 and not isinstance(node.keywords[1].value, ast.List):
+            raise self._err(node, "Absolute K index: Bad syntax. Second argument `ddim` (optional) must be a list of "
+                                  "values, e.g. `.at(K=..., ddim=[...])`.")
+        level = self.visit(node.keywords[0].value)
+        if isinstance(level, ir.AxisIndex):
+            raise self._err(node, "Absolute K index: bad syntax, you cannot write `.at(K=K)` since `.at` denotes an "
+                                  "absolute index, this is equivalent to `field[0, 0, 0]` or simply `field`.")
+        name = node.func.value.id
+        decl = self.fields.get(name) or self.temporaries.get(name)
+        if decl is None:
+            raise GTScriptSymbolError(f"Unknown field '{name}' in stencil '{self.definition.__name__}'")
+        if "K" not in decl.axes:
+            raise ValueError("Tried accessing a field with no K-dimensions with an absolute K-index.")
+        data_index: Tuple = ()
+        if len(node.keywords) == 2:
+            fake = ast.Subscript(value=ast.Attribute(value=node.func.value, attr="A", ctx=ast.Load()),
+                                 slice=ast.Tuple(elts=node.keywords[1].value.elts, ctx=ast.Load()), ctx=ast.Load())
+            _, data_index = self._split_data_index(ast.copy_location(fake, node))
+        elif decl.data_dims:
+            raise self._err(node, f"Absolute K index: field '{name}' has data dimensions, give `ddim=[...]`")
+        return ir.FieldAccess(name, (0, 0, 0), None, level, data_index, True)
+
     def visit_Call(self, node: ast.Call) -> ir.Expr:
         name = self._call_name(node)
+        if isinstance(node.func, ast.Attribute) and node.func.attr == "at":
+            return self._visit_absolute_k(node)
         if node.keywords:
             raise self._err(node, "Keyword arguments are not supported in calls")
         args = tuple(self.visit(a) for a in node.args)
@@ -743,14 +873,26 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
                 if koff is not None:  # already typed (map_expr is bottom-up); must be an integer
                     if np.dtype(koff.dtype).kind not in "iu":
                         raise GTScriptSyntaxError(f"Variable K offset of '{e.name}' must be an integer expression")
-                return ir.FieldAccess(e.name, e.offset, dt, koff, e.data_index)
-            if isinstance(e, (ir.Literal, ir.ScalarAccess, ir.Cast)):
+                for d in e.data_index or ():
+                    if isinstance(d, ir.Expr) and np.dtype(d.dtype).kind not in "iu":
+                        raise GTScriptSyntaxError(f"Data index of '{e.name}' must be an integer expression")
+                return ir.FieldAccess(e.name, e.offset, dt, koff, e.data_index, e.absolute_k)
+            if isinstance(e, (ir.Literal, ir.ScalarAccess, ir.Cast, ir.AxisIndex)):
                 return e
             if isinstance(e, ir.UnaryOp):
                 ufunc = _OP_UFUNC[{"-": "neg", "+": "pos", "not": "not"}[e.op]]
                 (target,) = ufunc_signature(ufunc, (e.expr.dtype,))
                 inner = e.expr if e.expr.dtype == target else ir.Cast(e.expr, target)
                 return ir.UnaryOp(e.op, inner, np.dtype("bool") if e.op == "not" else target)
+            if isinstance(e, ir.BinaryOp) and e.op == "**" and e.left.dtype.kind != e.right.dtype.kind \
+                    and "b" not in (e.left.dtype.kind, e.right.dtype.kind):
+                # The reference does not upcast the arguments of a power (gtir_upcaster.py:114-126), so a float
+                # base with an integer exponent reaches numpy / std::pow as it is; both promote the pair to
+                # double (np.result_type(float32, int32) is float64; std::pow(float, int) returns double).
+                compute = np.result_type(e.left.dtype, e.right.dtype)
+                left = e.left if e.left.dtype == compute else ir.Cast(e.left, compute)
+                right = e.right if e.right.dtype == compute else ir.Cast(e.right, compute)
+                return ir.BinaryOp("**", left, right, compute)
             if isinstance(e, ir.BinaryOp):
                 lt, rt = ufunc_signature(_OP_UFUNC[e.op], (e.left.dtype, e.right.dtype))
                 left = e.left if e.left.dtype == lt else ir.Cast(e.left, lt)
@@ -801,8 +943,8 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
                 for lid, cond in stmt.loops:
                     cond = typed(cond)
                     loops.append((lid, cond if cond.dtype == np.dtype("bool") else ir.Cast(cond, np.dtype("bool"))))
-                new_body.append(ir.Assign(ir.FieldAccess(name, stmt.target.offset, tdt, None, stmt.target.data_index), value,
-                                          mask, stmt.group, stmt.region, tuple(loops)))
+                target = typed(stmt.target)
+                new_body.append(ir.Assign(target, value, mask, stmt.group, stmt.region, tuple(loops)))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     temps = tuple(ir.FieldDecl(t.name, dtypes[t.name], t.axes, t.data_dims, False) for t in stencil.temporaries)
@@ -810,8 +952,40 @@ def _resolve_and_upcast(stencil: ir.Stencil) -> ir.Stencil:
 
 
 def _check_semantics(stencil: ir.Stencil) -> None:
+    """The legality checks of the reference's GTIR / OIR validators, with their messages."""
     api = {f.name for f in stencil.fields}
     written = {s.target.name for _, _, s in stencil.statements()}
+    horizontal = lambda e: e.offset[0] != 0 or e.offset[1] != 0  # noqa: E731
+    for comp, block, stmt in stencil.statements():
+        # gtir.py:96-110 (ParAssignStmt)
+        if any(isinstance(e, ir.FieldAccess) and e.name == stmt.target.name and horizontal(e) for e in ir.walk(stmt.value)):
+            raise ValueError("Self-assignment with offset in I or J is illegal.")
+    for comp in stencil.computations:
+        for block in comp.blocks:
+            # gtir.py:224-241 (VerticalLoop): an API field written and read with a horizontal offset in one loop
+            writes = {s.target.name for s in block.body}
+            offset_reads = {e.name for s in block.body for e in ir.stmt_reads(s) if isinstance(e, ir.FieldAccess) and horizontal(e)}
+            illegal = (writes & offset_reads) & api
+            if illegal:
+                raise ValueError(f"Illegal write and read with horizontal offset detected for {illegal}.")
+            # gtir.py:243-293: K offsets between a write and any other access to the same field in a PARALLEL loop
+            iv = block.interval
+            if comp.order is not ir.LoopOrder.PARALLEL or (iv.start.level == iv.end.level
+                                                           and abs(iv.end.offset - iv.start.offset) == 1):
+                continue
+            targets = {}
+            for s in block.body:
+                targets.setdefault(s.target.name, []).append(s.target)
+            for s in block.body:
+                for e in ir.stmt_reads(s):
+                    if not isinstance(e, ir.FieldAccess) or e.name not in targets:
+                        continue
+                    for w in targets[e.name]:
+                        if e.koffset is not None or w.koffset is not None:
+                            raise ValueError("Not allowed to write and read with `VariableKOffset` and/or "
+                                             f"`AbsoluteKIndex` in PARALLEL loops: `{e.name}`")
+                        if e.offset[2] != w.offset[2]:
+                            raise ValueError(f"Not allowed to write and read with k-offsets in PARALLEL loops: `{e.name}`")
     for comp, _, stmt in stencil.statements():
         for e in ir.stmt_reads(stmt):
             if not isinstance(e, ir.FieldAccess):
@@ -820,14 +994,8 @@ def _check_semantics(stencil: ir.Stencil) -> None:
                 # temporaries with K offsets in PARALLEL computations are a race in the reference too
                 raise GTScriptSyntaxError(f"Invalid K offset access to temporary '{e.name}' in a PARALLEL computation")
             # N5: a written API field may not be read with a horizontal offset (gtir_to_oir.py:19-46)
-            if e.name in api and e.name in written and (e.offset[0] != 0 or e.offset[1] != 0):
+            if e.name in api and e.name in written and horizontal(e):
                 raise ValueError(f"Found non-zero read extent on written fields: {e.name}")
-    for comp, _, stmt in stencil.statements():
-        if comp.order is ir.LoopOrder.PARALLEL:
-            for e in ir.stmt_reads(stmt):
-                if isinstance(e, ir.FieldAccess) and e.name == stmt.target.name and e.offset[2] != 0:
-                    raise GTScriptSyntaxError(
-                        f"Self-assignment with a K offset to '{e.name}' is not allowed in PARALLEL computations")
 
 
 def parse_stencil(definition, *, externals: Dict[str, Any], dtypes: Dict[Any, Any],
@@ -840,7 +1008,7 @@ def parse_stencil(definition, *, externals: Dict[str, Any], dtypes: Dict[Any, An
         if p.kind == inspect.Parameter.VAR_KEYWORD:
             raise GTScriptDefinitionError("'**kwargs' dict parameter is not supported in GTScript definitions")
     annotations = gtscript._resolve_annotations(definition, dtypes)
-    untyped = _Parser(definition, annotations, externals, options).parse()
+    untyped = _Parser(definition, annotations, externals, options, dtypes).parse()
     typed = _resolve_and_upcast(untyped)
     _check_semantics(typed)
     return typed

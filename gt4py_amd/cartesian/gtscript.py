@@ -129,6 +129,20 @@ class _FieldDescriptorMaker:
 Field = _FieldDescriptorMaker()
 
 
+class _GlobalTableDescriptorMaker(_FieldDescriptorMaker):
+    """``GlobalTable[(dtype, (n0, n1, ...))]``: a read-only array with data dimensions only, indexed
+    absolutely through ``table.A[i0, i1, ...]`` (gtscript.py:782-796 of the reference)."""
+
+    def __getitem__(self, field_spec):
+        if not isinstance(field_spec, collections.abc.Collection) or len(field_spec) != 2:
+            raise ValueError("GlobalTable is defined by a tuple (type, [axes_size..])")
+        dtype, data_dims = field_spec
+        return _FieldDescriptor(dtype, [], data_dims)
+
+
+GlobalTable = _GlobalTableDescriptorMaker()
+
+
 # ---- statements that only exist syntactically -------------------------------------------------
 class _NullContext:
     def __enter__(self):
@@ -191,8 +205,25 @@ def _math_stub(name):
 
 
 for _name in MATH_BUILTINS:
-    if _name not in ("abs", "min", "max", "round"):
+    if _name not in ("abs", "min", "max"):  # `round` shadows the builtin in this module, as in the reference
         globals()[_name] = _math_stub(_name)
+
+
+ENUM_REGISTER: Dict[str, type] = {}
+
+
+def enum(class_):
+    """Mark an ``IntEnum`` subclass as readable inside stencils: ``MyEnum.A`` becomes its integer value and
+    a parameter annotated with the enum is an integer scalar (gtscript.py:163-168, gtscript_frontend.py:2457-2468)."""
+    import enum as _enum
+
+    name = class_.__name__
+    if name in ENUM_REGISTER:
+        raise ValueError(f"Enum names must be unique. @gtscript.enum {name} is already taken.")
+    if not (isinstance(class_, type) and issubclass(class_, _enum.IntEnum)):
+        raise ValueError(f"Enum {name} needs to derive from `enum.IntEnum`.")
+    ENUM_REGISTER[name] = class_
+    return class_
 
 
 def function(func):
@@ -330,7 +361,7 @@ def lazy_stencil(backend, definition=None, *, eager=False, **stencil_kwargs):
 
 
 __all__ = [
-    "Axis", "BACKWARD", "FORWARD", "Field", "I", "IJ", "IJK", "IK", "J", "JK", "K", "PARALLEL",
+    "Axis", "BACKWARD", "FORWARD", "Field", "GlobalTable", "enum", "I", "IJ", "IJK", "IK", "J", "JK", "K", "PARALLEL",
     "__INLINED", "__externals__", "__gtscript__", "compile_assert", "computation", "externals",
     "float32", "float64", "function", "horizontal", "int32", "int64", "interval", "lazy_stencil",
     "region", "stencil",

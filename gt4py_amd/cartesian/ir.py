@@ -69,7 +69,9 @@ class Literal(Expr):
 class FieldAccess(Expr):
     """``name[i, j, k]``.  ``koffset`` is a run-time integer expression ADDED to the K index
     (``field[0, 0, index]``, the reference's VariableKOffset: gtc/common.py; numpy: ``lk + k``,
-    gtc/numpy/npir_codegen.py:110, 271-278); ``offset[2]`` is 0 then."""
+    gtc/numpy/npir_codegen.py:110, 271-278); ``offset[2]`` is 0 then.  With ``absolute_k`` the expression
+    IS the K index, counted from the field's K origin (``field.at(K=index)``, the reference's AbsoluteKIndex:
+    gtc/common.py:356-380, debug_codegen.py:300-311); I and J are centred and the access is read-only."""
 
     name: str
     offset: Tuple[int, int, int]
@@ -78,7 +80,18 @@ class FieldAccess(Expr):
     #: constant index into the field's data dimensions (``field[0, 0, 0][1, 0]``); () for plain fields.  Only
     #: inside the parser None stands for "not written": such statements are unrolled over every index
     #: (vector-valued assignments, /root/reference/tests/.../test_suites.py:980-1060).
-    data_index: Optional[Tuple[int, ...]] = ()
+    #: An element may also be an integer EXPRESSION evaluated at run time (``field[0, 0, 0][index]``).
+    data_index: Optional[Tuple[Union[int, Expr], ...]] = ()
+    absolute_k: bool = False
+
+
+@dataclass(frozen=True)
+class AxisIndex(Expr):
+    """The value of the K iteration index, counted from the start of the compute domain (``K`` used as a
+    value: the reference's IteratorAccess, gtscript_frontend.py:1312-1316; debug_codegen: the loop variable)."""
+
+    axis: str
+    dtype: Optional[np.dtype] = None
 
 
 @dataclass(frozen=True)
@@ -210,6 +223,12 @@ def stmt_exprs(stmt: "Assign"):
     if stmt.mask is not None:
         yield stmt.mask
     yield stmt.value
+    # run-time K offset / data index of the write itself
+    if stmt.target.koffset is not None:
+        yield stmt.target.koffset
+    for d in stmt.target.data_index or ():
+        if isinstance(d, Expr):
+            yield d
 
 
 def stmt_reads(stmt: "Assign"):
@@ -270,8 +289,12 @@ class Stencil:
 def walk(expr: Expr):
     """Pre-order traversal of an expression tree."""
     yield expr
-    if isinstance(expr, FieldAccess) and expr.koffset is not None:
-        yield from walk(expr.koffset)
+    if isinstance(expr, FieldAccess):
+        if expr.koffset is not None:
+            yield from walk(expr.koffset)
+        for d in expr.data_index or ():
+            if isinstance(d, Expr):
+                yield from walk(d)
     if isinstance(expr, (UnaryOp, Cast)):
         yield from walk(expr.expr)
     elif isinstance(expr, BinaryOp):
@@ -288,8 +311,11 @@ def walk(expr: Expr):
 
 def map_expr(expr: Expr, fn):
     """Rebuild ``expr`` bottom-up, applying ``fn`` to every rebuilt node."""
-    if isinstance(expr, FieldAccess) and expr.koffset is not None:
-        expr = replace(expr, koffset=map_expr(expr.koffset, fn))
+    if isinstance(expr, FieldAccess):
+        if expr.koffset is not None:
+            expr = replace(expr, koffset=map_expr(expr.koffset, fn))
+        if any(isinstance(d, Expr) for d in expr.data_index or ()):
+            expr = replace(expr, data_index=tuple(map_expr(d, fn) if isinstance(d, Expr) else d for d in expr.data_index))
     elif isinstance(expr, (UnaryOp, Cast)):
         expr = replace(expr, expr=map_expr(expr.expr, fn))
     elif isinstance(expr, BinaryOp):
@@ -307,9 +333,11 @@ def fmt(expr: Expr) -> str:
     if isinstance(expr, Literal):
         return f"{expr.dtype}({expr.value!r})" if expr.dtype is not None else repr(expr.value)
     if isinstance(expr, FieldAccess):
-        k = f"{expr.offset[2]}" if expr.koffset is None else fmt(expr.koffset)
-        data = "".join(f"[{d}]" for d in (expr.data_index or ()))
+        k = f"{expr.offset[2]}" if expr.koffset is None else ("K=" if expr.absolute_k else "") + fmt(expr.koffset)
+        data = "".join(f"[{fmt(d) if isinstance(d, Expr) else d}]" for d in (expr.data_index or ()))
         return f"{expr.name}[{expr.offset[0]},{expr.offset[1]},{k}]{data}"
+    if isinstance(expr, AxisIndex):
+        return expr.axis
     if isinstance(expr, ScalarAccess):
         return expr.name
     if isinstance(expr, UnaryOp):

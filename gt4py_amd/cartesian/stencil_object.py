@@ -390,6 +390,14 @@ class StencilObject(abc.ABC):
         if exec_info is not None:
             exec_info["call_run_start_time"] = time.perf_counter()
         device = gt_backend.from_name(self.backend).storage_info["device"]
+        # `gtscript.enum` members are passed as integers (stencil_object.py:575-583 of the reference)
+        from . import definitions as gt_definitions, gtscript as _gtscript
+
+        if _gtscript.ENUM_REGISTER:
+            int_type = gt_definitions.get_integer_type(self.options.get("literal_int_precision", gt_definitions.LITERAL_INT_PRECISION))
+            for pname, value in parameter_args.items():
+                if type(value) in _gtscript.ENUM_REGISTER.values():
+                    parameter_args[pname] = int_type(value.value)
         array_infos = _extract_array_infos(field_args, device)
         key = _cache_key(array_infos, parameter_args, domain, origin)
         cache = type(self)._domain_origin_cache

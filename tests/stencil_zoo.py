@@ -195,10 +195,13 @@ def backward_scan(a: F64, out: F64):
 
 
 def parallel_k_dependency(a: F64, b: F64):
-    """PARALLEL block that reads a field at a K offset and then overwrites it: statement by statement"""
+    """PARALLEL computations that read a field at a K offset, overwrite it, and read the new values at an
+    offset again (one computation each: within ONE parallel loop the reference forbids it, gtir.py:243-293)"""
     with computation(PARALLEL), interval(0, -1):
         tmp = a[0, 0, 1] * 2.0
+    with computation(PARALLEL), interval(0, -1):
         a = tmp + b
+    with computation(PARALLEL), interval(0, -2):
         b = a[0, 0, 1] - tmp
 
 

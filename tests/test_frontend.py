@@ -338,8 +338,17 @@ def test_runtime_if_is_flattened_into_masked_assignments():
 
 def test_rejections():
     # written API field read with a horizontal offset (gtir_to_oir.py:19-46; test_code_generation.py:1693)
-    with pytest.raises(ValueError, match="non-zero read extent on written fields"):
+    with pytest.raises(ValueError, match="Self-assignment with offset in I or J is illegal."):
         parse(race_stencil)
+
+    def race_across_computations(a: Field[np.float64], b: Field[np.float64]):
+        with computation(PARALLEL), interval(...):
+            b = a[1, 0, 0]
+        with computation(PARALLEL), interval(...):
+            a = b
+
+    with pytest.raises(ValueError, match="non-zero read extent on written fields"):
+        parse(race_across_computations)
     with pytest.raises(D.GTScriptSyntaxError, match="non-zero offsets"):
         parse(write_offset_stencil)
     with pytest.raises(D.GTScriptSymbolError):

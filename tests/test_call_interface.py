@@ -210,6 +210,46 @@ class TestAxesMismatch:
         assert (f == 1.0).all()
 
 
+class TestDataDimensions:
+    """test_call_interface.py:381-459."""
+
+    @pytest.fixture
+    def sample_stencil(self):
+        def _stencil(field_out: gtscript.Field[gtscript.IJK, (np.float64, (2,))]):
+            with computation(FORWARD), interval(...):
+                field_out[0, 0, 0][0] = 0.0
+                field_out[0, 0, 0][1] = 1.0
+
+        return gtscript.stencil(backend="numpy", definition=_stencil)
+
+    def test_mismatch(self, sample_stencil):
+        with pytest.raises(ValueError, match="Field '.*' expects data dimensions \\(2,\\) but got \\(3,\\)"):
+            sample_stencil(field_out=gt_storage.empty(shape=(3, 3, 1), dimensions=["I", "J", "K"], dtype=(np.float64, (3,)),
+                                                      backend="numpy", aligned_index=(0, 0, 0)))
+
+    @pytest.mark.parametrize("backend", ["numpy", pytest.param("hip:mi300", marks=pytest.mark.gpu)])
+    def test_data_dimension_1d(self, backend):
+        @gtscript.stencil(backend=backend)
+        def data_dimension_1d(field_out: gtscript.Field[gtscript.IJ, (np.float64, (1,))]):
+            with computation(FORWARD), interval(...):
+                field_out[0, 0][0] = 42.0
+
+        ones = gt_storage.ones(shape=(2, 3), dimensions=["I", "J"], dtype=(np.float64, (1,)), backend=backend,
+                               aligned_index=(0, 0))
+        data_dimension_1d(ones)
+        assert (gt_storage.asnumpy(ones) == 42.0).all() and ones.shape == (2, 3, 1)
+
+    def test_data_dimensions_1d_error(self):
+        from gt4py_amd.cartesian.definitions import GTScriptSyntaxError
+
+        with pytest.raises(GTScriptSyntaxError, match="Data index out of bounds."):
+
+            @gtscript.stencil(backend="numpy")
+            def data_dimension_1d_error(field_out: gtscript.Field[gtscript.IJ, (np.float64, (1,))]):
+                with computation(FORWARD), interval(...):
+                    field_out[0, 0][1] = 42.0
+
+
 def calc_damp(outp: Field[float], inp: Field[K, float]):
     with computation(FORWARD), interval(...):
         outp = inp

@@ -26,11 +26,116 @@ import inspect
 import textwrap
 from typing import Any, Dict, List, Optional, Set
 
-from .definitions import GTScriptSyntaxError
+import numbers
+
+import numpy as np
+
+from .definitions import GTScriptDefinitionError, GTScriptSyntaxError
+
+#: names that mean something to GTScript itself and are never looked up in the enclosing Python scope
+#: (the reference's ``gtscript.builtins``, gtscript.py:78-103)
+GTSCRIPT_BUILTINS = frozenset({
+    "I", "J", "K", "IJ", "IK", "JK", "IJK", "FORWARD", "BACKWARD", "PARALLEL", "Field", "GlobalTable", "Sequence",
+    "externals", "computation", "interval", "horizontal", "region", "__gtscript__", "__externals__", "__INLINED",
+    "compile_assert", "abs", "min", "max", "mod", "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh",
+    "asinh", "acosh", "atanh", "sqrt", "exp", "log", "log10", "gamma", "cbrt", "isfinite", "isinf", "isnan", "floor",
+    "ceil", "trunc", "erf", "erfc", "round", "round_away_from_zero", "int32", "int64", "float32", "float64", "int",
+    "float", "bool", "True", "False", "None",
+})
 
 
 def is_gtscript_function(obj: Any) -> bool:
     return callable(obj) and getattr(obj, "__gtscript_function__", False)
+
+
+def _unlazy(obj: Any) -> Any:
+    """``@gtscript.lazy_function()`` hands out a zero-argument callable that annotates and returns the function the
+    first time it is needed (gtscript_frontend.py:2349-2357)."""
+    if callable(obj) and not is_gtscript_function(obj) and getattr(obj, "__qualname__", "").startswith("lazy_function."):
+        return obj()
+    return obj
+
+
+def _is_constant(value: Any) -> bool:
+    return isinstance(value, (bool, np.bool_, numbers.Real)) or (isinstance(value, np.generic) and value.dtype.kind in "biuf")
+
+
+def _dotted(node: ast.AST) -> Optional[str]:
+    if isinstance(node, ast.Name):
+        return node.id
+    if isinstance(node, ast.Attribute):
+        base = _dotted(node.value)
+        return f"{base}.{node.attr}" if base else None
+    return None
+
+
+class _NonlocalBinder(ast.NodeTransformer):
+    """Replace names from the enclosing Python scope by their VALUES: numeric constants (``GRAV``, ``consts.A``,
+    ``Config.nested.B`` ...) become literals that keep their numpy type; gtscript functions stay names for the call
+    inliner; anything else is an error (GTScriptParser.collect_external_symbols / eval_external,
+    gtscript_frontend.py:2269-2375)."""
+
+    def __init__(self, context: Dict[str, Any], known: Set[str]):
+        self.context = context
+        self.known = known  # parameters, assigned names, names imported from __externals__
+
+    def _bind(self, node: ast.AST):
+        name = _dotted(node)
+        if name is None:
+            return self.generic_visit(node)
+        root = name.split(".")[0]
+        if root in self.known or root in GTSCRIPT_BUILTINS or root not in self.context:
+            return node
+        try:
+            value = self.context[root]
+            for attr in name.split(".")[1:]:
+                value = getattr(value, attr)
+        except AttributeError as ex:
+            raise GTScriptDefinitionError(f"Missing or invalid value for external symbol {name}") from ex
+        from . import gtscript
+
+        value = _unlazy(value)
+        if is_gtscript_function(value) or isinstance(value, gtscript.Axis) or (
+                isinstance(value, type) and value in gtscript.ENUM_REGISTER.values()):
+            return node
+        if isinstance(node, ast.Attribute) and isinstance(value, type) and root in gtscript.ENUM_REGISTER:
+            return node
+        if _is_constant(value):
+            return ast.copy_location(ast.Constant(value=value), node)
+        if value is None or isinstance(value, (type, type(np))) or callable(value):
+            return node  # classes / modules / plain callables: only legal as the root of something else
+        raise GTScriptDefinitionError(f"Missing or invalid value for external symbol {name} (a {type(value).__name__})")
+
+    def visit_Name(self, node: ast.Name):
+        return self._bind(node) if isinstance(node.ctx, ast.Load) else node
+
+    def visit_Attribute(self, node: ast.Attribute):
+        return self._bind(node) if isinstance(node.ctx, ast.Load) else node
+
+    def visit_AnnAssign(self, node: ast.AnnAssign):
+        if node.value is not None:
+            node.value = self.visit(node.value)
+        return node  # the annotation is evaluated as Python by the parser
+
+    def visit_ImportFrom(self, node):
+        return node
+
+
+def _assigned_names(fdef: ast.AST) -> Set[str]:
+    out: Set[str] = set()
+    for n in ast.walk(fdef):
+        if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+            out.add(n.id)
+        elif isinstance(n, ast.ImportFrom):
+            out.update(a.asname or a.name for a in n.names)
+        elif isinstance(n, ast.arg):
+            out.add(n.arg)
+    return out
+
+
+def bind_nonlocals(fdef: ast.FunctionDef, context: Dict[str, Any]) -> None:
+    binder = _NonlocalBinder(context, _assigned_names(fdef))
+    fdef.body = [binder.visit(s) for s in fdef.body]
 
 
 def _function_ast(func) -> ast.FunctionDef:
@@ -41,6 +146,9 @@ def _function_ast(func) -> ast.FunctionDef:
 
 
 def _context_of(func) -> Dict[str, Any]:
+    frozen = getattr(func, "__gtscript_context__", None)
+    if frozen is not None:  # what the names meant when `@gtscript.function` was applied
+        return dict(frozen)
     ctx = dict(getattr(func, "__globals__", {}))
     closure = getattr(func, "__closure__", None)
     if closure:
@@ -65,8 +173,9 @@ class _Renamer(ast.NodeTransformer):
 class CallInliner:
     """Rewrites a stencil's FunctionDef in place; ``imports`` collects ``from __externals__`` nodes of callees."""
 
-    def __init__(self, context: Dict[str, Any]):
+    def __init__(self, context: Dict[str, Any], function_externals: Optional[Dict[str, Any]] = None):
         self.context = context
+        self.function_externals = dict(function_externals or {})  # gtscript functions passed as externals
         self.imports: List[ast.ImportFrom] = []
         self._counter = 0
 
@@ -74,10 +183,10 @@ class CallInliner:
     @staticmethod
     def _resolve(node: ast.AST, context: Dict[str, Any]) -> Optional[Any]:
         if isinstance(node, ast.Name):
-            return context.get(node.id)
+            return _unlazy(context.get(node.id))
         if isinstance(node, ast.Attribute):
             base = CallInliner._resolve(node.value, context)
-            return getattr(base, node.attr, None) if base is not None else None
+            return _unlazy(getattr(base, node.attr, None)) if base is not None else None
         return None
 
     # -- statements ---------------------------------------------------------------------------
@@ -140,6 +249,9 @@ class CallInliner:
             kw.value = self._expr(kw.value, block, context, stack)
 
         fdef = copy.deepcopy(_function_ast(func))
+        callee_context = _context_of(func)
+        callee_context.update({k: v for k, v in self.function_externals.items()})
+        bind_nonlocals(fdef, callee_context)
         params = [a.arg for a in fdef.args.args] + [a.arg for a in fdef.args.kwonlyargs]
         positional = [a.arg for a in fdef.args.args]
         defaults: Dict[str, ast.expr] = {}
@@ -198,7 +310,7 @@ class CallInliner:
             else:
                 kept.append(_Renamer(mapping).visit(s))
         # nested calls resolve in the CALLEE's namespace
-        kept = self._process_stmts(kept, _context_of(func), stack | {func})
+        kept = self._process_stmts(kept, callee_context, stack | {func})
 
         if not kept or not isinstance(kept[-1], ast.Return) or kept[-1].value is None:
             raise GTScriptSyntaxError(f"gtscript function '{name}' must end with a 'return' of its value(s)")
@@ -242,8 +354,10 @@ def inline_calls(fdef: ast.FunctionDef, definition, externals: Optional[Dict[str
     arrive as externals (test_suites.py:264-285).  Returns the callees' ``from __externals__ import ...``
     nodes so the parser can bind them."""
     context = _context_of(definition)
-    context.update({k: v for k, v in (externals or {}).items() if is_gtscript_function(v)})
-    inliner = CallInliner(context)
+    functions = {k: _unlazy(v) for k, v in (externals or {}).items() if is_gtscript_function(_unlazy(v))}
+    context.update(functions)
+    bind_nonlocals(fdef, context)
+    inliner = CallInliner(context, functions)
     inliner.process_function(fdef)
     ast.fix_missing_locations(fdef)
     return inliner.imports

@@ -109,6 +109,7 @@ class _Parser(ast.NodeVisitor):
         self.definition = definition
         self.externals = dict(externals)
         self.dtypes = dict(dtypes or {})
+        self.context = call_inliner._context_of(definition)
         self.int_dtype = np.dtype(gt_definitions.get_integer_type(options.literal_int_precision))
         self.float_dtype = np.dtype(gt_definitions.get_float_type(options.literal_float_precision))
         self.fields: Dict[str, ir.FieldDecl] = {}
@@ -275,7 +276,7 @@ class _Parser(ast.NodeVisitor):
             raise self._err(node, f"Unsupported import from '{node.module}' inside a stencil")
         for alias in node.names:
             if alias.name not in self.externals:
-                raise GTScriptSymbolError(f"Missing value for external symbol '{alias.name}'")
+                raise GTScriptDefinitionError(f"Missing or invalid value for external symbol {alias.name}")
             self.imported[alias.asname or alias.name] = self.externals[alias.name]
 
     @staticmethod
@@ -666,6 +667,8 @@ class _Parser(ast.NodeVisitor):
 
     def visit_Constant(self, node: ast.Constant) -> ir.Expr:
         v = node.value
+        if isinstance(v, np.generic):  # a typed constant of the enclosing scope, bound by call_inliner.bind_nonlocals
+            return self._literal_from_python(v, node)
         if isinstance(v, bool):
             return ir.Literal(v, np.dtype("bool"))
         if isinstance(v, int):
@@ -674,7 +677,7 @@ class _Parser(ast.NodeVisitor):
             return ir.Literal(v, self.float_dtype)
         raise self._err(node, f"Unsupported literal {v!r}")
 
-    def _literal_from_python(self, value, node) -> ir.Expr:
+    def _literal_from_python(self, value, node, name: Optional[str] = None) -> ir.Expr:
         if isinstance(value, (bool, np.bool_)):
             return ir.Literal(bool(value), np.dtype("bool"))
         if isinstance(value, np.generic) and np.dtype(type(value)) in _RANK:
@@ -683,7 +686,8 @@ class _Parser(ast.NodeVisitor):
             return ir.Literal(int(value), self.int_dtype)
         if isinstance(value, numbers.Real):
             return ir.Literal(float(value), self.float_dtype)
-        raise self._err(node, f"External value {value!r} is not a supported constant")
+        raise GTScriptDefinitionError(f"Missing or invalid value for external symbol {name or ''}: {value!r} is not a "
+                                      f"supported constant (in '{self.definition.__name__}')")
 
     def visit_Name(self, node: ast.Name) -> ir.Expr:
         name = node.id
@@ -692,7 +696,7 @@ class _Parser(ast.NodeVisitor):
         if name in self.params:
             return ir.ScalarAccess(name, self.params[name].dtype)
         if name in self.imported:
-            return self._literal_from_python(self.imported[name], node)
+            return self._literal_from_python(self.imported[name], node, name)
         if name in ("True", "False"):
             return ir.Literal(name == "True", np.dtype("bool"))
         if name == "K":  # the iteration index as a value (gtscript_frontend.py:874-886, 1312-1316)
@@ -708,15 +712,28 @@ class _Parser(ast.NodeVisitor):
         elts = list(index.elts) if isinstance(index, ast.Tuple) else [index]
         offset = {"I": 0, "J": 0, "K": 0}
 
+        def axis_of(e) -> Optional[str]:
+            if isinstance(e, ast.Name):
+                if e.id in ("I", "J", "K") and e.id not in self.imported:
+                    return e.id
+                value = self.imported.get(e.id, self.context.get(e.id) if e.id not in self.fields else None)
+                if isinstance(value, gtscript.Axis):  # an axis handed in as an external
+                    return value.name
+            return None
+
         def axis_shift(e) -> Optional[Tuple[str, int]]:
-            if isinstance(e, ast.Name) and e.id in ("I", "J", "K"):
-                return e.id, 0
-            if (isinstance(e, ast.BinOp) and isinstance(e.op, (ast.Add, ast.Sub))
-                    and isinstance(e.left, ast.Name) and e.left.id in ("I", "J", "K")):
+            if axis_of(e) is not None:
+                return axis_of(e), 0
+            if isinstance(e, ast.BinOp) and any(axis_of(n) for n in ast.walk(e) if isinstance(n, ast.Name)):
+                # <axis> +- <integer constant>, nothing else (gtscript_frontend.py:303-373)
+                if not isinstance(e.op, (ast.Add, ast.Sub)) or axis_of(e.left) is None:
+                    raise self._err(node, "Invalid axis offset: expected <axis> + <integer> or <axis> - <integer>")
+                if any(axis_of(n) for n in ast.walk(e.right) if isinstance(n, ast.Name)):
+                    raise self._err(node, "Invalid axis offset: an axis may appear only once")
                 shift = self._const(e.right)
                 if not isinstance(shift, numbers.Integral):
                     raise self._err(node, "Axis offsets must be integer constants")
-                return e.left.id, int(shift) if isinstance(e.op, ast.Add) else -int(shift)
+                return axis_of(e.left), int(shift) if isinstance(e.op, ast.Add) else -int(shift)
             return None
 
         shifted = [axis_shift(e) for e in elts]
@@ -778,6 +795,15 @@ class _Parser(ast.NodeVisitor):
         if isinstance(node.value, ast.Name) and node.value.id in gtscript.ENUM_REGISTER:
             # MyEnum.A is its integer value (gtscript_frontend.py:449-459)
             return ir.Literal(int(getattr(gtscript.ENUM_REGISTER[node.value.id], node.attr)), self.int_dtype)
+        dotted = call_inliner._dotted(node)
+        if dotted is not None and dotted.split(".")[0] in self.imported:  # NAMESPACE.A with an imported external
+            value = self.imported[dotted.split(".")[0]]
+            try:
+                for attr in dotted.split(".")[1:]:
+                    value = getattr(value, attr)
+            except AttributeError as ex:
+                raise GTScriptDefinitionError(f"Missing or invalid value for external symbol {dotted}") from ex
+            return self._literal_from_python(value, node, dotted)
         raise self._err(node, f"Unsupported attribute access '.{node.attr}'")
 
     def visit_BinOp(self, node: ast.BinOp) -> ir.Expr:
@@ -851,6 +877,8 @@ class _Parser(ast.NodeVisitor):
             return ir.NativeCall(f"cast:{dt.name}", args, dt)
         if name in _NATIVE_UFUNC:
             return ir.NativeCall(name, args)
+        if isinstance(node.func, ast.Name) and callable(self.context.get(name, self.externals.get(name))):
+            raise TypeError(f"{name} is not a gtscript function")
         raise self._err(node, f"Unsupported call to '{name}'")
 
 

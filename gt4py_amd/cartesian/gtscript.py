@@ -204,9 +204,8 @@ def _math_stub(name):
     return stub
 
 
-for _name in MATH_BUILTINS:
-    if _name not in ("abs", "min", "max"):  # `round` shadows the builtin in this module, as in the reference
-        globals()[_name] = _math_stub(_name)
+for _name in MATH_BUILTINS:  # abs / min / max / round shadow the builtins in this module, as in the reference
+    globals()[_name] = _math_stub(_name)
 
 
 ENUM_REGISTER: Dict[str, type] = {}
@@ -227,9 +226,32 @@ def enum(class_):
 
 
 def function(func):
-    """``@gtscript.function`` marker (inlined by the frontend when called from a stencil)."""
+    """``@gtscript.function`` marker (inlined by the frontend when called from a stencil).  Like the reference's
+    ``annotate_definition`` it records what the names of the enclosing scope mean NOW
+    (gtscript_frontend.py:2121-2267): a constant rebound later does not change the function."""
+    from . import call_inliner
+
+    setattr(func, "__gtscript_context__", call_inliner._context_of(func))
     setattr(func, "__gtscript_function__", True)
     return func
+
+
+def lazy_function(*, before_annotation=None, after_annotation=None):
+    """Mark a GTScript function that is only annotated right before its first use; the hooks run before / after
+    (gtscript.py:179-215 of the reference)."""
+
+    def wrapper(func):
+        def inner_function():
+            if before_annotation is not None:
+                before_annotation(func)
+            function(func)
+            if after_annotation is not None:
+                after_annotation(func)
+            return func
+
+        return inner_function
+
+    return wrapper
 
 
 # ---- decorators --------------------------------------------------------------------------------
@@ -363,6 +385,6 @@ def lazy_stencil(backend, definition=None, *, eager=False, **stencil_kwargs):
 __all__ = [
     "Axis", "BACKWARD", "FORWARD", "Field", "GlobalTable", "enum", "I", "IJ", "IJK", "IK", "J", "JK", "K", "PARALLEL",
     "__INLINED", "__externals__", "__gtscript__", "compile_assert", "computation", "externals",
-    "float32", "float64", "function", "horizontal", "int32", "int64", "interval", "lazy_stencil",
+    "float32", "float64", "function", "lazy_function", "horizontal", "int32", "int64", "interval", "lazy_stencil",
     "region", "stencil",
 ]

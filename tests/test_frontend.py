@@ -263,7 +263,7 @@ def test_externals_and_inlined_if():
     assert stmt.value == ir.BinaryOp("*", ir.FieldAccess("a", (0, 0, 0), F64), ir.Literal(3.0, F64), F64)
     st = parse(with_externals, externals={"FACTOR": 3.0, "USE_A": False})
     assert [s.value for _, _, s in st.statements()] == [ir.Literal(3.0, F64)]
-    with pytest.raises(D.GTScriptSymbolError):
+    with pytest.raises(D.GTScriptDefinitionError, match="USE_A"):  # test_gtscript_frontend.py:660-670
         parse(with_externals, externals={"FACTOR": 3.0})
 
 

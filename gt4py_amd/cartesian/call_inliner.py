@@ -312,10 +312,10 @@ class CallInliner:
         # nested calls resolve in the CALLEE's namespace
         kept = self._process_stmts(kept, callee_context, stack | {func})
 
-        if not kept or not isinstance(kept[-1], ast.Return) or kept[-1].value is None:
-            raise GTScriptSyntaxError(f"gtscript function '{name}' must end with a 'return' of its value(s)")
-        if any(isinstance(n, ast.Return) for s in kept[:-1] for n in ast.walk(s)):
-            raise GTScriptSyntaxError(f"gtscript function '{name}': only a single trailing 'return' is supported")
+        n_returns = sum(isinstance(n, ast.Return) for s in kept for n in ast.walk(s))
+        if n_returns != 1 or not isinstance(kept[-1], ast.Return) or kept[-1].value is None:
+            raise GTScriptSyntaxError(f"Each gtscript function should have a single return statement as its last "
+                                      f"statement ('{name}' has {n_returns})")
         ret = kept.pop().value
         block.extend(pre)
         block.extend(kept)
@@ -332,7 +332,8 @@ class CallInliner:
                     "Only functions with a single return value can be used in expressions, including as call "
                     "arguments. Please assign the function results to symbols first.")
             if not isinstance(target, ast.Tuple) or len(target.elts) != len(ret.elts):
-                raise GTScriptSyntaxError(f"'{name}' returns {len(ret.elts)} values; the assignment target does not match")
+                raise GTScriptSyntaxError(f"Number of returns values does not match arguments on left side "
+                                          f"('{name}' returns {len(ret.elts)})")
             tmp_names = [f"RETURN_VALUE_{n}{suffix}" for n in range(len(ret.elts))]
             for tmp, value in zip(tmp_names, ret.elts):
                 block.append(ast.copy_location(ast.Assign(targets=[store(tmp)], value=value, lineno=call.lineno), call))
@@ -341,7 +342,8 @@ class CallInliner:
             return load(tmp_names[0])
         if target is not None:
             if isinstance(target, ast.Tuple):
-                raise GTScriptSyntaxError(f"'{name}' returns one value; the assignment target is a tuple")
+                raise GTScriptSyntaxError(f"Number of returns values does not match arguments on left side "
+                                          f"('{name}' returns one value)")
             block.append(ast.copy_location(ast.Assign(targets=[target], value=ret, lineno=call.lineno), call))
             return ret
         tmp = f"RETURN_VALUE{suffix}"

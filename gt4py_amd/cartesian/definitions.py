@@ -326,3 +326,12 @@ class GTScriptValueError(GTScriptDefinitionError):
 
 class GTScriptDataTypeError(GTScriptSyntaxError):
     pass
+
+
+class GTScriptAssertionError(GTError):
+    """A ``compile_assert(...)`` whose condition is false (frontend/exceptions.py:89-98 of the reference)."""
+
+    def __init__(self, source, *, loc=None):
+        where = f" at line {loc}" if loc else ""
+        super().__init__(f"Assertion failed{where}:\n{source}")
+        self.loc = loc

@@ -254,7 +254,9 @@ class _Parser(ast.NodeVisitor):
         decl = self._declare_annotated(node)
         name, dims = decl.name, decl.data_dims
         if decl.axes != ("I", "J", "K"):
-            raise self._err(node, "2-d temporaries are declared where they are first assigned, inside a computation")
+            del self.temporaries[name]
+            raise self._err(node, f"Found {''.join(decl.axes)}, but only IJK is currently supported for temporaries "
+                                  "declared at the top of a definition")
         if node.value is None:
             return None
         value = self._const(node.value)
@@ -296,6 +298,11 @@ class _Parser(ast.NodeVisitor):
             if len(names) == 2 and names[1] == "interval":
                 block = self._parse_interval_block(node.items[1].context_expr, node.body, order)
                 return [ir.Computation(order, (block,))]
+            if len(names) == 3 and names[1] == "interval" and names[2] == "horizontal":
+                # `with computation(...), interval(...), horizontal(region[...]):` (gtscript_frontend.py:1195-1199)
+                inner = ast.copy_location(ast.With(items=[node.items[2]], body=node.body), node)
+                block = self._parse_interval_block(node.items[1].context_expr, [inner], order)
+                return [ir.Computation(order, (block,))]
             if len(names) == 1:
                 blocks = []
                 for inner in node.body:
@@ -318,25 +325,60 @@ class _Parser(ast.NodeVisitor):
         except KeyError:
             raise self._err(call, "Invalid iteration order, expected PARALLEL, FORWARD or BACKWARD") from None
 
+    def _interval_bound(self, node, call):
+        """One bound of ``interval(a, b)``: an integer, None, an external integer or ``K[n] + m`` AxisIndex
+        (IntervalParser, gtscript_frontend.py:105-224).  Run-time bounds (a scalar parameter, an IJ field) are the
+        reference's experimental feature that only its debug backend implements."""
+        error = self._err(call, "Invalid interval range specification")
+        if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Name) and node.value.id in ("I", "J", "K") \
+                and node.value.id not in self.fields:
+            raise error  # K[2] written in place: two-argument intervals take plain integers
+        runtime = [n for n in ast.walk(node) if isinstance(n, ast.Name) and (n.id in self.fields or n.id in self.params
+                                                                            or n.id in self.temporaries)]
+        if runtime:
+            if isinstance(node, ast.Subscript):
+                elts = node.slice.elts if isinstance(node.slice, ast.Tuple) else [node.slice]
+                inner = node.value if isinstance(node.value, ast.Subscript) else node
+                elts = inner.slice.elts if isinstance(inner.slice, ast.Tuple) else [inner.slice]
+                if any(not (isinstance(e, ast.Constant) and e.value == 0) for e in elts):
+                    raise error  # an index field read at an offset
+            raise NotImplementedError("Runtime interval bounds not implemented yet.")
+        try:
+            value = self._const(node)
+        except (GTScriptSyntaxError, GTScriptSymbolError):
+            raise error from None
+        if isinstance(value, gtscript.AxisIndex):
+            if value.axis != "K":
+                raise error
+            return ir.AxisBound(ir.Level.START if value.index >= 0 else ir.Level.END, value.index + value.offset)
+        if value is None or (isinstance(value, numbers.Integral) and not isinstance(value, (bool, np.bool_))):
+            return None if value is None else int(value)
+        raise error
+
     def _parse_interval(self, call: ast.Call) -> ir.Interval:
-        args = call.args
+        args = list(call.args) or [kw.value for kw in call.keywords]
         if len(args) == 1 and isinstance(args[0], ast.Constant) and args[0].value is Ellipsis:
             return ir.Interval.full()
         if len(args) != 2:
-            raise self._err(call, "Invalid interval specification: expected interval(...) or interval(start, end)")
-        lo, hi = self._const(args[0]), self._const(args[1])
+            raise self._err(call, "Invalid interval range specification: expected interval(...) or interval(start, end)")
+        lo, hi = self._interval_bound(args[0], call), self._interval_bound(args[1], call)
         if lo is None:
-            lo = 0
-        if not isinstance(lo, numbers.Integral) or not (hi is None or isinstance(hi, numbers.Integral)):
             raise self._err(call, "Invalid interval range specification")
-        start = ir.AxisBound(ir.Level.START, int(lo)) if lo >= 0 else ir.AxisBound(ir.Level.END, int(lo))
-        if hi is None:
+        if isinstance(lo, ir.AxisBound):
+            start = lo
+        else:
+            start = ir.AxisBound(ir.Level.START, lo) if lo >= 0 else ir.AxisBound(ir.Level.END, lo)
+        if isinstance(hi, ir.AxisBound):
+            end = hi
+        elif hi is None:
             end = ir.AxisBound(ir.Level.END, 0)
         elif hi < 0:
-            end = ir.AxisBound(ir.Level.END, int(hi))
+            end = ir.AxisBound(ir.Level.END, hi)
         else:
-            end = ir.AxisBound(ir.Level.START, int(hi))
-        # reject intervals that are empty for every domain size
+            end = ir.AxisBound(ir.Level.START, hi)
+        # reject reversed intervals and those empty for every domain size (gtscript_frontend.py:1152-1165)
+        if start.level is ir.Level.END and end.level is ir.Level.START:
+            raise self._err(call, "Invalid interval range specification")
         if start.level == end.level and start.offset >= end.offset:
             raise self._err(call, "Invalid interval range specification")
         return ir.Interval(start, end)
@@ -352,8 +394,8 @@ class _Parser(ast.NodeVisitor):
         seq = ranges if order is not ir.LoopOrder.BACKWARD else list(reversed(ranges))
         for (a0, a1), (b0, b1) in zip(seq, seq[1:]):
             if a1 > b0:
-                raise self._err(node, "Overlapping or unordered intervals in computation "
-                                      "(intervals must be listed in order of execution)")
+                raise self._err(node, "Overlapping intervals detected in computation "
+                                      "(intervals must be disjoint and listed in order of execution)")
 
     def _parse_interval_block(self, call, body, order) -> ir.IntervalBlock:
         interval = self._parse_interval(call)
@@ -472,6 +514,19 @@ class _Parser(ast.NodeVisitor):
             return []
         if isinstance(node, ast.Expr) and isinstance(node.value, ast.Constant):
             return []
+        if isinstance(node, ast.Expr) and self._call_name(node.value) == "compile_assert":
+            # evaluated now, from constants and externals only (gtscript_frontend.py:774-806)
+            if len(node.value.args) != 1:
+                raise self._err(node, "Invalid assertion. Correct syntax: compile_assert(condition)")
+            try:
+                ok = self._const(node.value.args[0])
+            except Exception as ex:
+                raise self._err(node, "Evaluation of compile_assert condition failed at the preprocessing step") from ex
+            if not isinstance(ok, (bool, np.bool_)):
+                raise self._err(node, "Evaluation of compile_assert condition failed at the preprocessing step")
+            if not ok:
+                raise gt_definitions.GTScriptAssertionError(ast.unparse(node), loc=getattr(node, "lineno", None))
+            return []
         raise self._err(node, f"Unsupported statement '{type(node).__name__}' in stencil body")
 
     # ---- horizontal regions --------------------------------------------------------------
@@ -490,6 +545,15 @@ class _Parser(ast.NodeVisitor):
             """AxisIndex arithmetic: I[0] -> START+0, I[-1] -> END-1, +- integer constants."""
             if e is None:
                 return None
+            if isinstance(e, ast.Name):  # an AxisIndex handed in as an external: `i1 = I[0] + 1`
+                if e.id not in self.imported:
+                    raise GTScriptSymbolError(f"Unknown symbol '{e.id}' in a horizontal range specification")
+                value = self.imported[e.id]
+                if not isinstance(value, gtscript.AxisIndex) or value.axis != axis:
+                    raise self._err(e, f"Invalid horizontal range specification: '{e.id}' is not an index on axis {axis}")
+                return ir.AxisBound(ir.Level.START if value.index >= 0 else ir.Level.END, value.index + value.offset)
+            if isinstance(e, ast.Subscript) and isinstance(e.slice, ast.Slice):
+                raise self._err(e, "Invalid interval range specification")  # the retired I[0:2] spelling
             if isinstance(e, ast.Subscript) and isinstance(e.value, ast.Name):
                 if e.value.id != axis:
                     raise self._err(e, f"Invalid horizontal range specification: Expected axis {axis}, got {e.value.id}")
@@ -498,11 +562,21 @@ class _Parser(ast.NodeVisitor):
                     raise self._err(e, f"Invalid horizontal range specification: Expected specification {axis}[0] or {axis}[-1]")
                 return ir.AxisBound(ir.Level.START, 0) if index == 0 else ir.AxisBound(ir.Level.END, -1)
             if isinstance(e, ast.BinOp) and isinstance(e.op, (ast.Add, ast.Sub)):
-                left = bound(e.left)
-                shift = self._const(e.right)
-                if left is None or not isinstance(shift, int) or isinstance(shift, bool):
-                    raise self._err(e, "Invalid horizontal range specification")
-                return ir.AxisBound(left.level, left.offset + (shift if isinstance(e.op, ast.Add) else -shift))
+                def number(x):
+                    try:
+                        v = self._const(x)
+                    except (GTScriptSyntaxError, GTScriptSymbolError):
+                        return None
+                    return int(v) if isinstance(v, numbers.Integral) and not isinstance(v, (bool, np.bool_)) else None
+
+                shift = number(e.right)
+                if shift is not None:
+                    left = bound(e.left)
+                    return ir.AxisBound(left.level, left.offset + (shift if isinstance(e.op, ast.Add) else -shift))
+                shift = number(e.left)
+                if shift is not None and isinstance(e.op, ast.Add):  # n + <index>
+                    right = bound(e.right)
+                    return ir.AxisBound(right.level, right.offset + shift)
             raise self._err(e, "Invalid horizontal range specification")
 
         if isinstance(node, ast.Slice):
@@ -521,7 +595,8 @@ class _Parser(ast.NodeVisitor):
         (d0, d1)); plain subscripts -> (node, None).  Elements that are not compile-time constants are integer
         expressions evaluated at run time (gtscript_frontend.py:1429-1455)."""
         inner = node.value
-        if isinstance(inner, ast.Subscript) and isinstance(inner.value, ast.Name) and self._data_dims(inner.value.id):
+        if isinstance(inner, ast.Subscript) and isinstance(inner.value, ast.Name) and (
+                self._data_dims(inner.value.id) or inner.value.id in self.fields or inner.value.id in self.temporaries):
             name = inner.value.id
         elif isinstance(inner, ast.Attribute) and inner.attr == "A" and isinstance(inner.value, ast.Name):
             name, inner = inner.value.id, inner.value
@@ -572,6 +647,10 @@ class _Parser(ast.NodeVisitor):
                                   "Choose FORWARD or BACKWARD.")
         if name in self.params or name in self.imported:
             raise self._err(node, f"Cannot assign to scalar parameter or external '{name}'")
+        decl = self.fields.get(name) or self.temporaries.get(name)
+        if decl is not None and not reading and not {"I", "J"} <= set(decl.axes):
+            # gtscript_frontend.py:1811-1822
+            raise self._err(node, f"Cannot assign to field '{name}' as all parallel axes 'I, J' are not present")
         if reading and name not in self.fields and name not in self.temporaries:
             raise GTScriptSymbolError(f"Unknown symbol '{name}'")
         return ir.FieldAccess(name, offset, None, variable[0] if variable else None, data_index)

@@ -31,8 +31,62 @@ class ShiftedAxis:
         return f"ShiftedAxis(name={self.name}, shift={self.shift})"
 
 
+class AxisIndex:
+    """``I[0] + 2``, ``K[-1]``: a position relative to the start (index >= 0) or the end (index < 0) of an axis,
+    usable as an external for region and interval bounds (gtscript.py:557-590 of the reference)."""
+
+    def __init__(self, axis: str, index: int, offset: int = 0):
+        self.axis, self.index, self.offset = axis, index, offset
+
+    def __repr__(self):
+        return f"AxisIndex(axis={self.axis}, index={self.index}, offset={self.offset})"
+
+    def __str__(self):
+        return f"{self.axis}[{self.index}] + {self.offset}"
+
+    def __eq__(self, other):
+        return repr(self) == repr(other)
+
+    def __hash__(self):
+        return hash(repr(self))
+
+    def __add__(self, offset):
+        import numbers
+
+        if not isinstance(offset, numbers.Integral):
+            raise TypeError("Offset should be an integer type")
+        return self if offset == 0 else AxisIndex(self.axis, self.index, self.offset + int(offset))
+
+    __radd__ = __add__
+
+    def __sub__(self, offset):
+        return self.__add__(-offset)
+
+    def __rsub__(self, offset):
+        return self.__add__(-offset)
+
+
+class AxisInterval:
+    def __init__(self, axis: str, start: int, end: int):
+        assert start < end
+        self.axis, self.start, self.end = axis, start, end
+
+    def __repr__(self):
+        return f"AxisInterval(axis={self.axis}, start={self.start}, end={self.end})"
+
+    def __len__(self):
+        return self.end - self.start
+
+
 class Axis:
-    """A cartesian axis symbol; ``Axis + n`` spells a field offset (``f[I + 1]``)."""
+    """A cartesian axis symbol; ``Axis + n`` spells a field offset (``f[I + 1]``), ``Axis[n]`` an ``AxisIndex``."""
+
+    def __getitem__(self, interval):
+        if isinstance(interval, slice):
+            return AxisInterval(self.name, interval.start, interval.stop)
+        if isinstance(interval, int):
+            return AxisIndex(self.name, interval)
+        raise TypeError("Unrecognized index type")
 
     def __init__(self, name: str):
         assert name
@@ -383,7 +437,7 @@ def lazy_stencil(backend, definition=None, *, eager=False, **stencil_kwargs):
 
 
 __all__ = [
-    "Axis", "BACKWARD", "FORWARD", "Field", "GlobalTable", "enum", "I", "IJ", "IJK", "IK", "J", "JK", "K", "PARALLEL",
+    "Axis", "AxisIndex", "BACKWARD", "FORWARD", "Field", "GlobalTable", "enum", "I", "IJ", "IJK", "IK", "J", "JK", "K", "PARALLEL",
     "__INLINED", "__externals__", "__gtscript__", "compile_assert", "computation", "externals",
     "float32", "float64", "function", "lazy_function", "horizontal", "int32", "int64", "interval", "lazy_stencil",
     "region", "stencil",

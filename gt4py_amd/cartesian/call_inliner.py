@@ -199,9 +199,10 @@ class CallInliner:
         for s in stmts:
             if isinstance(s, (ast.With, ast.If, ast.While)):
                 if isinstance(s, ast.If):
-                    pre: List[ast.stmt] = []
-                    s.test = self._expr(s.test, pre, context, stack)
-                    out.extend(pre)
+                    if any(isinstance(n, ast.Call) and is_gtscript_function(self._resolve(n.func, context))
+                           for n in ast.walk(s.test)):
+                        # gtscript_frontend.py:552-566 (CallInliner.visit_If)
+                        raise GTScriptSyntaxError("Using function calls in the condition of an if is not allowed")
                 s.body = self._process_stmts(s.body, context, stack)
                 if getattr(s, "orelse", None):
                     s.orelse = self._process_stmts(s.orelse, context, stack)

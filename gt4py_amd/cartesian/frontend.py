@@ -112,6 +112,11 @@ class _Parser(ast.NodeVisitor):
         self.context = call_inliner._context_of(definition)
         self.int_dtype = np.dtype(gt_definitions.get_integer_type(options.literal_int_precision))
         self.float_dtype = np.dtype(gt_definitions.get_float_type(options.literal_float_precision))
+        # `dtypes={float: np.float32}` also retypes the literals (test_gtscript_frontend.py:1666-1686)
+        if float in self.dtypes:
+            self.float_dtype = np.dtype(self.dtypes[float])
+        if int in self.dtypes:
+            self.int_dtype = np.dtype(self.dtypes[int])
         self.fields: Dict[str, ir.FieldDecl] = {}
         self.params: Dict[str, ir.ScalarDecl] = {}
         self.temporaries: Dict[str, ir.FieldDecl] = {}
@@ -177,6 +182,8 @@ class _Parser(ast.NodeVisitor):
             if isinstance(stmt, ast.ImportFrom):
                 self._visit_import(stmt)
                 continue
+            if isinstance(stmt, ast.Import):
+                raise self._err(stmt, f"Invalid 'import' statements ({[a.name for a in stmt.names]})")
             if isinstance(stmt, ast.AnnAssign):
                 # typed temporary, optionally initialised: `tmp: Field[np.float32] = 0` at the top of the
                 # definition (gtscript_frontend.py:2245-2263); the initial value becomes a PARALLEL
@@ -272,10 +279,12 @@ class _Parser(ast.NodeVisitor):
         return ir.Computation(ir.LoopOrder.PARALLEL, (ir.IntervalBlock(ir.Interval.full(), inits),))
 
     def _visit_import(self, node: ast.ImportFrom) -> None:
-        if node.module not in ("__externals__", "gt4py.cartesian.__externals__", "gtscript.__externals__"):
-            if node.module and (node.module.strip("_").endswith("gtscript") or node.module.startswith("gt4py")):
-                return  # importing gtscript names inside the body is harmless
-            raise self._err(node, f"Unsupported import from '{node.module}' inside a stencil")
+        # only `from [gt4py.cartesian.]__externals__ / __gtscript__ import ...` (gtscript_frontend.py:2279-2307)
+        roots = ("", "gt4py.cartesian.", "gt4py_amd.cartesian.")
+        if node.module in tuple(r + "__gtscript__" for r in roots):
+            return
+        if node.module not in tuple(r + "__externals__" for r in roots):
+            raise self._err(node, f"Invalid 'import' statements (['{node.module}'])")
         for alias in node.names:
             if alias.name not in self.externals:
                 raise GTScriptDefinitionError(f"Missing or invalid value for external symbol {alias.name}")
@@ -391,11 +400,14 @@ class _Parser(ast.NodeVisitor):
             return b.offset if b.level is ir.Level.START else big + b.offset
 
         ranges = [(key(b.interval.start), key(b.interval.end)) for b in blocks]
+        for n, (a0, a1) in enumerate(ranges):
+            for b0, b1 in ranges[n + 1:]:
+                if a0 < b1 and b0 < a1:
+                    raise self._err(node, "Overlapping intervals detected in computation")
         seq = ranges if order is not ir.LoopOrder.BACKWARD else list(reversed(ranges))
         for (a0, a1), (b0, b1) in zip(seq, seq[1:]):
             if a1 > b0:
-                raise self._err(node, "Overlapping intervals detected in computation "
-                                      "(intervals must be disjoint and listed in order of execution)")
+                raise self._err(node, "Intervals must be specified in order of execution")
 
     def _parse_interval_block(self, call, body, order) -> ir.IntervalBlock:
         interval = self._parse_interval(call)
@@ -668,11 +680,19 @@ class _Parser(ast.NodeVisitor):
             if any(getattr(e, "op", None) in ("@", "T") for e in ir.walk(value)):
                 raise self._err(node, "'@' and '.T' apply to whole fields with data dimensions")
             return [ir.Assign(access, value, mask, group, self._region, self._loops)]
+        def not_indexed(e: ir.FieldAccess):
+            # DataDimensionsChecker, defir_to_gtir.py:102-121: only statements whose TARGET is a whole vector are unrolled
+            decl = self.fields.get(e.name) or self.temporaries.get(e.name)
+            cdims, ddims = [0] * len(decl.axes), ["x"] * len(decl.data_dims)
+            return self._err(node, f"Field {e.name} has data dimensions but no data dimensions index is specified. "
+                                   f"Use `{e.name}.A{ddims}` or `{e.name}{cdims}{ddims}`.")
+
         if access.data_index is not None:
-            raise self._err(node, "A vector-valued expression cannot be assigned to a single element")
+            raise not_indexed(next(e for e in ir.walk(value) if is_open(e)))
         for extra in ([mask] if mask is not None else []) + [c for _, c in self._loops]:
-            if any(is_open(e) for e in ir.walk(extra)):
-                raise self._err(node, "Conditions must index the data dimensions of the fields they read")
+            for e in ir.walk(extra):
+                if is_open(e):
+                    raise not_indexed(e)
         dims = self._data_dims(access.name)
         shape = self._vector_shape(value, node)
         if shape and shape != dims:
@@ -839,8 +859,9 @@ class _Parser(ast.NodeVisitor):
                     variable.append(self.visit(e))
                     values.append(0)
             if len(values) != len(axes):
+                hint = f" Did you mean absolute indexing via .A{values}?" if not axes else ""
                 raise self._err(node, f"Incorrect offset specification detected for field '{name}'. "
-                                      f"Found {values} but the field has dimensions ({', '.join(axes)})")
+                                      f"Found {values} but the field has dimensions ({', '.join(axes)}).{hint}")
             for ax, v in zip(axes, values):
                 if not isinstance(v, numbers.Integral):
                     raise self._err(node, "Field offsets must be integer constants")
@@ -939,7 +960,8 @@ class _Parser(ast.NodeVisitor):
                                  slice=ast.Tuple(elts=node.keywords[1].value.elts, ctx=ast.Load()), ctx=ast.Load())
             _, data_index = self._split_data_index(ast.copy_location(fake, node))
         elif decl.data_dims:
-            raise self._err(node, f"Absolute K index: field '{name}' has data dimensions, give `ddim=[...]`")
+            raise self._err(node, f"Field {name} has data dimensions but no data dimensions index is specified. "
+                                  f"Use `{name}.at(K=..., ddim=[...])`.")
         return ir.FieldAccess(name, (0, 0, 0), None, level, data_index, True)
 
     def visit_Call(self, node: ast.Call) -> ir.Expr:

@@ -810,6 +810,10 @@ class _Parser(ast.NodeVisitor):
         index = node.slice
         elts = list(index.elts) if isinstance(index, ast.Tuple) else [index]
         offset = {"I": 0, "J": 0, "K": 0}
+        if any(isinstance(e, ast.Constant) and e.value is Ellipsis for e in elts):
+            return 0, 0, 0  # field[...]: the point itself (gtscript_frontend.py:1381-1382)
+        if any(isinstance(e, ast.Slice) for e in elts):
+            raise self._err(node, "Invalid target in assignment.")
 
         def axis_of(e) -> Optional[str]:
             if isinstance(e, ast.Name):

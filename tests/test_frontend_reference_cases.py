@@ -1219,3 +1219,217 @@ class TestNativeFunctions:
 
         with pytest.raises(GTScriptSyntaxError, match="Using function calls in the condition of an if is not allowed"):
             parse_definition(func)
+
+
+# ---- TestAnnotations (:2077-2179) --------------------------------------------------------------------------
+def sumdiff_defs(in_a: Field["dtype_in"], in_b: Field["dtype_in"], out_c: Field["dtype_out"], out_d: Field[float], *,  # noqa: F821
+                 wa: "dtype_scalar", wb: int):  # noqa: F821
+    with computation(PARALLEL), interval(...):
+        out_c = wa * in_a + wb * in_b
+        out_d = wa * in_a - wb * in_b
+
+
+class TestAnnotations:
+    @pytest.mark.parametrize("dtype_in", [int, np.float32, np.float64])
+    @pytest.mark.parametrize("dtype_out", [int, np.float32, np.float64])
+    @pytest.mark.parametrize("dtype_scalar", [int, np.float32, np.float64])
+    def test_parsing(self, dtype_in, dtype_out, dtype_scalar):
+        st = parse_definition(sumdiff_defs, dtypes={"dtype_in": dtype_in, "dtype_out": dtype_out, "dtype_scalar": dtype_scalar})
+        assert [f.dtype for f in st.fields] == [np.dtype(t) for t in (dtype_in, dtype_in, dtype_out, float)]
+        assert [p.dtype for p in st.params] == [np.dtype(dtype_scalar), np.dtype(int)]
+        # the definition's own annotations are left as they were written
+        ann = sumdiff_defs.__annotations__
+        assert ann["in_a"].dtype == "dtype_in" and ann["out_c"].dtype == "dtype_out" and ann["wa"] == "dtype_scalar"
+        assert ann["out_d"].dtype == np.dtype(float) and ann["wb"] is int and len(ann) == 6
+
+
+# ---- TestAbsoluteIndex (:2182-2218) ------------------------------------------------------------------------
+class TestAbsoluteIndex:
+    def test_good_syntax(self):
+        def definition_func(in_field: Field[float], out_field: Field[float]):
+            with computation(PARALLEL), interval(...):
+                out_field = in_field.at(K=0) + in_field.at(K=1)
+
+        (stmt,) = statements(parse_definition(definition_func))
+        reads = [e for e in ir.walk(stmt.value) if isinstance(e, ir.FieldAccess)]
+        assert [(e.absolute_k, e.koffset.value) for e in reads] == [(True, 0), (True, 1)]
+
+    def test_bad_syntax(self):
+        def not_specifying_k(in_field: Field[float], out_field: Field[float]):
+            with computation(PARALLEL), interval(...):
+                out_field = in_field.at(2)
+
+        def specifying_i(in_field: Field[float], out_field: Field[float]):
+            with computation(PARALLEL), interval(...):
+                out_field = in_field.at(I=1, K=0)
+
+        for definition in (not_specifying_k, specifying_i):
+            with pytest.raises(GTScriptSyntaxError, match=r".*Absolute K index: Bad syntax.*"):
+                parse_definition(definition)
+
+
+# ---- TestLiteralCasts / TestTemporaryTypes / TestNumpyTypedConstants (:2221-2397) ---------------------------
+class TestLiteralCasts:
+    @pytest.mark.parametrize("precision", [32, 64])
+    def test_explicit_casts_follow_the_literal_precision(self, precision):
+        def float_cast(field: Field[float]):
+            with computation(PARALLEL), interval(0, 1):
+                field[0, 0, 0] = float(0)
+
+        def int_cast(field: Field[float]):
+            with computation(PARALLEL), interval(0, 1):
+                field[0, 0, 0] = int(0)
+
+        def cast_of(stencil):
+            (stmt,) = statements(stencil)
+            return next(e for e in ir.walk(stmt.value) if isinstance(e, ir.NativeCall))
+
+        assert cast_of(parse_definition(int_cast, literal_int_precision=precision)).func == f"cast:int{precision}"
+        assert cast_of(parse_definition(float_cast, literal_float_precision=precision)).func == f"cast:float{precision}"
+
+
+class TestTemporaryTypes:
+    @pytest.mark.parametrize("precision", [32, 64])
+    def test_python_types_follow_the_literal_precision(self, precision):
+        def temporary_int_stencil(field: Field[float]):
+            with computation(PARALLEL), interval(0, 1):
+                temporary: int = 12
+                field[0, 0, 0] = temporary
+
+        def temporary_float_stencil(field: Field[float]):
+            with computation(PARALLEL), interval(0, 1):
+                temporary: float = 12
+                field[0, 0, 0] = temporary
+
+        (tmp,) = parse_definition(temporary_int_stencil, literal_int_precision=precision).temporaries
+        assert tmp.dtype == np.dtype(f"int{precision}")
+        (tmp,) = parse_definition(temporary_float_stencil, literal_float_precision=precision).temporaries
+        assert tmp.dtype == np.dtype(f"float{precision}")
+
+    def test_explicit_precisions(self):
+        def floats(field: Field[float]):
+            with computation(PARALLEL), interval(0, 1):
+                temporary32: float32 = 12.12
+                temporary64: float64 = 34.34
+                field[0, 0, 0] = temporary32 + temporary64
+
+        def ints(field: Field[float]):
+            with computation(PARALLEL), interval(0, 1):
+                temporary32: int32 = 12
+                temporary64: int64 = 34
+                field[0, 0, 0] = temporary32 + temporary64
+
+        assert [t.dtype for t in parse_definition(floats).temporaries] == [np.dtype("float32"), np.dtype("float64")]
+        assert [t.dtype for t in parse_definition(ints).temporaries] == [np.dtype("int32"), np.dtype("int64")]
+
+
+class TestNumpyTypedConstants:
+    def test_assign_constant_numpy_typed(self):
+        self.constant = np.float32(42.0)
+
+        def assign_constant(field: Field[float]):
+            with computation(PARALLEL), interval(0, 1):
+                field[0, 0, 0] = self.constant
+
+        (stmt,) = statements(parse_definition(assign_constant))
+        (lit,) = literals(stmt.value)
+        assert lit.dtype == np.float32 and lit.value == 42.0
+
+
+# ---- TestIteratorAccess (:2400-2480) -----------------------------------------------------------------------
+class TestIteratorAccess:
+    @pytest.mark.parametrize("precision", [32, 64])
+    def test_read_in_K_iterator(self, precision):
+        def stencil(field: Field[float]):
+            with computation(PARALLEL), interval(...):
+                field[0, 0, 0] = K
+
+        (stmt,) = statements(parse_definition(stencil, literal_int_precision=precision))
+        (axis,) = [e for e in ir.walk(stmt.value) if isinstance(e, ir.AxisIndex)]
+        assert axis.axis == "K" and axis.dtype == np.dtype(f"int{precision}")
+
+    def test_K_as_cond_iterator(self):
+        def stencil(field: Field[float]):
+            with computation(PARALLEL), interval(...):
+                if K == 2:
+                    field[0, 0, 0] = 42
+
+        (stmt,) = statements(parse_definition(stencil))
+        assert any(isinstance(e, ir.AxisIndex) for e in ir.walk(stmt.mask))
+
+    def test_iterator_in_offsets_is_left_alone(self):
+        def stencil(in_field: Field[float], out_field: Field[float]):
+            with computation(PARALLEL), interval(1, None):
+                out_field[0, 0, 0] = in_field[K - 1]
+
+        (stmt,) = statements(parse_definition(stencil))
+        assert stmt.value.offset == (0, 0, -1) and stmt.value.koffset is None
+
+    def test_bad_syntax(self):
+        def with_i(field: Field[float]):
+            with computation(PARALLEL), interval(...):
+                if I == 2:
+                    field[0, 0, 0] = 42
+
+        def absolute(in_field: Field[float], out_field: Field[float]):
+            with computation(PARALLEL), interval(...):
+                out_field = in_field.at(K=K)
+
+        with pytest.raises(GTScriptSyntaxError, match=r".*Parallel axis I can't be queried - only K.*"):
+            parse_definition(with_i)
+        with pytest.raises(GTScriptSyntaxError, match=r".*Absolute K index: bad syntax, you cannot write.*"):
+            parse_definition(absolute)
+
+
+def test_ellipsis_index_parses():
+    """:2483-2500"""
+
+    def stencil(field_a: Field[np.float64], field_b: Field[np.float64]):
+        with computation(PARALLEL), interval(...):
+            field_b[...] = field_a
+
+    (stmt,) = statements(parse_definition(stencil))
+    assert stmt.target.offset == (0, 0, 0)
+
+
+# ---- TestEnum (:2503-2560) ---------------------------------------------------------------------------------
+@gtscript.enum
+class LocalEnum(IntEnum):
+    A = 42
+    B = 1000
+
+
+class TestEnum:
+    @pytest.mark.parametrize("precision", [32, 64])
+    def test_enum_in_stencil(self, precision):
+        def enum(field: Field[float], order: LocalEnum):
+            with computation(PARALLEL), interval(0, 1):
+                if order > LocalEnum.A:
+                    field[0, 0, 0] = LocalEnum.B
+
+        st = parse_definition(enum, literal_int_precision=precision)
+        (stmt,) = statements(st)
+        assert [lit.value for lit in literals(stmt.mask)] == [42] and [lit.value for lit in literals(stmt.value)] == [1000]
+        assert st.params[0].dtype == np.dtype(f"int{precision}")
+
+    def test_enum_bad_definitions(self):
+        from enum import Enum
+
+        @gtscript.enum
+        class MyTestEnum(IntEnum):
+            A = 0
+
+        try:
+            with pytest.raises(ValueError, match="Enum names must be unique. @gtscript.enum MyTestEnum is already taken*"):
+
+                @gtscript.enum
+                class MyTestEnum(IntEnum):  # noqa: F811
+                    B = 0
+
+            with pytest.raises(ValueError, match="Enum BadEnumTestEnum needs to derive from `enum.IntEnum`*"):
+
+                @gtscript.enum
+                class BadEnumTestEnum(Enum):
+                    B = 0.0
+        finally:
+            gtscript.ENUM_REGISTER.pop("MyTestEnum", None)

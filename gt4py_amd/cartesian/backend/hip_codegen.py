@@ -66,6 +66,10 @@ TUNING = {
     # (measured neutral-to-negative for thread-per-point kernels, profiles/r1_codegen_sweep.log: off)
     "xcd_rows": _env_tuple("GT4MI_CODEGEN_XCD_ROWS", (0,))[0],
     "nontemporal": _env_tuple("GT4MI_CODEGEN_NONTEMPORAL", (1,))[0],  # streaming stores for write-only outputs
+    # column stages: issue the loads of up to this many K levels ahead of the dependent arithmetic (0 = off),
+    # as long as the chunk needs no more than `prefetch_loads` values in flight per thread
+    "prefetch": _env_tuple("GT4MI_CODEGEN_PREFETCH", (8,))[0],
+    "prefetch_loads": _env_tuple("GT4MI_CODEGEN_PREFETCH_LOADS", (40,))[0],
     "vector": _env_tuple("GT4MI_CODEGEN_VECTOR", (1,))[0],  # 16-byte lanes for horizontal stages
     # ... and consecutive J rows per lane in those kernels: rows (and recomputed temporaries) shared by
     # neighbouring output rows are loaded (computed) once per strip
@@ -288,6 +292,9 @@ class _Emitter:
         self.vec_row = 0
         self.local_suffix = ""
         self.base_prefix = "b_"
+        # loads issued ahead of a chunk of K levels: (name, offset, data index) -> register, per statement
+        self.prefetched: Dict[Tuple, str] = {}
+        self.prefetch_for: Dict[int, Dict[Tuple, str]] = {}
 
     # -- expressions --------------------------------------------------------------------------
     def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str], store: bool = False) -> str:
@@ -297,6 +304,10 @@ class _Emitter:
         if name in self.plan.locals:
             return f"l_{_c_ident(name)}{self.local_suffix}"
         if not store:
+            if self.prefetched and e.koffset is None:
+                hit = self.prefetched.get((name, tuple(e.offset), tuple(e.data_index or ())))
+                if hit is not None:
+                    return hit
             if self.vec_rows is not None and "I" in self.axes.get(name, ("I", "J", "K")):
                 return self.vec_rows[(name, e.offset[1] + self.vec_row, e.offset[2])][self.vec_component + e.offset[0]]
             if (name, e.offset[2]) in reg and e.offset[:2] == (0, 0) and e.koffset is None:
@@ -407,6 +418,13 @@ class _Emitter:
         return g
 
     def statement(self, s: Stmt, stage: Stage, si: int, k: str, reg: Dict, indent: str, carry: Sequence[str] = ()) -> None:
+        self.prefetched = self.prefetch_for.get(id(s), {})
+        try:
+            self._statement(s, stage, si, k, reg, indent, carry)
+        finally:
+            self.prefetched = {}
+
+    def _statement(self, s: Stmt, stage: Stage, si: int, k: str, reg: Dict, indent: str, carry: Sequence[str] = ()) -> None:
         value = self.expr(s.value, k, si, reg)
         name = s.target.name
         g = self.full_guard(s, stage, si, k, reg)
@@ -484,6 +502,67 @@ class _Emitter:
         return f"{b.offset}" if b.level is ir.Level.START else f"(a.dK + ({b.offset}))"
 
     # -- kernels ------------------------------------------------------------------------------
+    def prefetch_chunk(self, group: Sequence[Stmt], stage: Stage, nest: Nest, active: Sequence[str], back: int):
+        """Which reads of a column loop may be issued a whole chunk of K levels early, and how deep the chunk is.
+
+        Returns (depth, {(name, (di, dj), level relative to the chunk's first level, data index): register},
+        {id(statement): [(name, offset, data index), ...]}) or None.  A read is hoistable when nothing the chunk
+        stores can be the value it is meant to see: fields the nest does not write; for fields it does write
+        (level-by-level, at offset 0 only), the levels AHEAD of the sweep, and the current level for reads that
+        come before the first write in statement order.  Statements under a narrower extent, a horizontal region
+        or a `while` keep the plain loop (their reads are only inside the arrays where they execute)."""
+        depth = int(TUNING["prefetch"])
+        iv = nest.interval
+        if iv.start.level is iv.end.level:  # statically short interval: no deeper than it is long
+            while depth > iv.end.offset - iv.start.offset:
+                depth //= 2
+        if depth < 2:
+            return None
+        for s in group:
+            if s.extent != stage.extent or s.region is not None or s.loops:
+                return None
+        written = {s.target.name for s in group}
+        displaced = {s.target.name for s in group if s.target.offset != (0, 0, 0) or s.target.koffset is not None
+                     or any(isinstance(d, ir.Expr) for d in s.target.data_index or ())}
+        ahead = 1 if nest.order is ir.LoopOrder.FORWARD else -1 if nest.order is ir.LoopOrder.BACKWARD else 0
+        per_statement: Dict[int, List[Tuple]] = {}
+        done: Set[str] = set()  # written by an earlier statement of the level
+        for s in group:
+            keys = []
+            for e in _stmt_field_reads(s):
+                name = e.name
+                if (e.koffset is not None or name in self.plan.locals or name in self.plan.register_only
+                        or any(isinstance(d, ir.Expr) for d in e.data_index or ())):
+                    continue
+                if e.offset[:2] == (0, 0) and name in active and e.offset[2] == back:
+                    continue  # served by the forwarded register
+                if name in written:
+                    dk = e.offset[2]
+                    if name in displaced or "K" not in self.axes.get(name, ("I", "J", "K")):
+                        continue
+                    if not ((ahead and dk * ahead > 0) or (dk == 0 and name not in done)):
+                        continue
+                key = (name, tuple(e.offset), tuple(e.data_index or ()))
+                if key not in keys:
+                    keys.append(key)
+            per_statement[id(s)] = keys
+            done.add(s.target.name)
+        if not any(per_statement.values()):
+            return None
+        while depth >= 2:
+            loads: Dict[Tuple, str] = {}
+            for u in range(depth):
+                step = -u if nest.order is ir.LoopOrder.BACKWARD else u
+                for keys in per_statement.values():
+                    for name, off, data in keys:
+                        slot = (name, off[:2], off[2] + step, data)
+                        if slot not in loads:
+                            loads[slot] = f"pf{len(loads)}_{_c_ident(name)}"
+            if len(loads) <= int(TUNING["prefetch_loads"]):
+                return depth, loads, per_statement
+            depth //= 2
+        return None
+
     def stage_globals(self, stage: Stage) -> List[str]:
         names = []
         for nest in stage.nests:
@@ -570,24 +649,63 @@ class _Emitter:
                     L.append(f"        if ({' && '.join(conds)}) r_{_c_ident(n)} = "
                              f"{self.access(ir.FieldAccess(n, (0, 0, back)), first, -1, {})};")
                 for group in groups:
-                    if TUNING["unroll"] > 1:
-                        L.append(f"        #pragma unroll {TUNING['unroll']}")
-                    L.append(f"        {loop} {{")
-                    self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), "            ")
-                    carry = [n for n in active if any(s.target.name == n for s in group)]
-                    reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
-                    for n in carry:
-                        L.append(f"            {_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
-                    self.statements(group, stage, si, "k", reg, "            ", carry)
-                    for n in active:
-                        c = _c_ident(n)
-                        if n in carry:
-                            L.append(f"            r_{c} = n_{c};")
-                        else:  # only read in this nest: rotate in the level just passed
-                            cond = self.column_in_extent(n, stage)
-                            load = self.access(ir.FieldAccess(n, (0, 0, 0)), "k", -1, {})
-                            L.append(f"            {'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
+                    def level(kexpr: str, pad: str, group=group) -> None:
+                        """One K level of the sweep: locals, statements, rotation of the forwarded registers."""
+                        self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), pad)
+                        carry = [n for n in active if any(s.target.name == n for s in group)]
+                        reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
+                        for n in carry:
+                            L.append(f"{pad}{_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
+                        self.statements(group, stage, si, kexpr, reg, pad, carry)
+                        for n in active:
+                            c = _c_ident(n)
+                            if n in carry:
+                                L.append(f"{pad}r_{c} = n_{c};")
+                            else:  # only read in this nest: rotate in the level just passed
+                                cond = self.column_in_extent(n, stage)
+                                load = self.access(ir.FieldAccess(n, (0, 0, 0)), kexpr, -1, {})
+                                L.append(f"{pad}{'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
+
+                    def plain_loop(header: str) -> None:
+                        if TUNING["unroll"] > 1:
+                            L.append(f"        #pragma unroll {TUNING['unroll']}")
+                        L.append(f"        {header} {{")
+                        level("k", "            ")
+                        L.append("        }")
+
+                    chunk = None if nest.split_statements else self.prefetch_chunk(group, stage, nest, active, back)
+                    if chunk is None:
+                        plain_loop(loop)
+                        continue
+                    # Loads of `depth` levels are issued before the arithmetic that depends on them.  Only valid when
+                    # no store of the chunk can alias a hoisted load: the host has proven the arrays disjoint
+                    # (GT4MI_NO_ALIAS), and within one array the levels of a chunk are different addresses.
+                    depth, loads, per_statement = chunk
+                    backward = nest.order is ir.LoopOrder.BACKWARD
+                    L.append("#if GT4MI_NO_ALIAS")
+                    L.append("        {")
+                    L.append(f"        gt_i64 k = {'k1 - 1' if backward else 'k0'};")
+                    L.append(f"        for (; {'k - ' + str(depth - 1) + ' >= k0' if backward else 'k + ' + str(depth) + ' <= k1'}; "
+                             f"k {'-' if backward else '+'}= {depth}) {{")
+                    for (name, off, rel, data), var in loads.items():
+                        e = ir.FieldAccess(name, (off[0], off[1], rel), None, None, data)
+                        L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, 'k', -1, {})};")
+                    for u in range(depth):
+                        step = -u if backward else u
+                        self.prefetch_for = {sid: {key: loads[(key[0], key[1][:2], key[1][2] + step, key[2])] for key in keys}
+                                             for sid, keys in per_statement.items()}
+                        L.append("            {")
+                        level(f"(k {'-' if backward else '+'} {u})", "                ")
+                        L.append("            }")
+                    self.prefetch_for = {}
                     L.append("        }")
+                    L.append(f"        for (; {'k >= k0; --k' if backward else 'k < k1; ++k'}) {{")
+                    level("k", "            ")
+                    L.append("        }")
+                    L.append("        }")
+                    L.append("#else")
+                    plain_loop(loop)
+                    L.append("#endif")
                 L.append("    }")
         if j_per_thread > 1:
             L.append("    }")

@@ -145,7 +145,77 @@ def other_kernels(steps: int = 10):
              "(timing only, values are checked in tests/)")
     del fields
     torch.cuda.empty_cache()
+
+    # the generic executor (stencils outside the three kernel families are compiled, not rejected): the reference's
+    # vertical advection and the Laplacian again, this time through the code generator
+    dom = (1024, 1024, 160)
+    obj = gtscript.stencil(backend="hip:mi300", definition=_vertical_advection_dycore, externals={"BET_M": 0.5, "BET_P": 0.5},
+                           device_sync=False)
+    shape = (dom[0] + 1, dom[1], dom[2] + 1)
+    fields = {n: field(shape, np.float64, (0, 0, 0)) for n in ("utens_stage", "u_stage", "wcon", "u_pos", "utens")}
+    run("generated_vertical_advection_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 48.0,
+        scalars={"dtr_stage": 3.0 / 20.0},
+        note="one generated column kernel (forward + backward sweep); 5 fields read, 1 written; the forward sweep's "
+             "ccol / dcol make a round trip through scratch on top of the 48 algorithmic B/LUP")
+    del fields
+    torch.cuda.empty_cache()
+    dom = (512, 512, 512)
+    obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
+                           device_sync=False, use_kernel_library=False)
+    shape = (dom[0] + 2, dom[1] + 2, dom[2])
+    fields = {"inp": field(shape, np.float64, (1, 1, 0)), "out": field(shape, np.float64, (1, 1, 0))}
+    run("generated_laplacian_f64_512x512x512", obj, fields, {k: (1, 1, 0) for k in fields}, dom, 16.0,
+        note="the headline stencil through the code generator instead of the hand-written kernel")
+    del fields
+    torch.cuda.empty_cache()
     return out
+
+
+def _vertical_advection_dycore(utens_stage: Field[np.float64], u_stage: Field[np.float64], wcon: Field[np.float64],  # noqa: F821
+                               u_pos: Field[np.float64], utens: Field[np.float64], *, dtr_stage: float):  # noqa: F821
+    """/root/reference/tests/cartesian_tests/integration_tests/multi_feature_tests/stencil_definitions.py:235-313."""
+    from __externals__ import BET_M, BET_P
+
+    with computation(FORWARD):  # noqa: F821
+        with interval(0, 1):  # noqa: F821
+            gcv = 0.25 * (wcon[1, 0, 1] + wcon[0, 0, 1])
+            cs = gcv * BET_M
+            ccol = gcv * BET_P
+            bcol = dtr_stage - ccol[0, 0, 0]
+            correction_term = -cs * (u_stage[0, 0, 1] - u_stage[0, 0, 0])
+            dcol = dtr_stage * u_pos[0, 0, 0] + utens[0, 0, 0] + utens_stage[0, 0, 0] + correction_term
+            divided = 1.0 / bcol[0, 0, 0]
+            ccol = ccol[0, 0, 0] * divided
+            dcol = dcol[0, 0, 0] * divided
+        with interval(1, -1):  # noqa: F821
+            gav = -0.25 * (wcon[1, 0, 0] + wcon[0, 0, 0])
+            gcv = 0.25 * (wcon[1, 0, 1] + wcon[0, 0, 1])
+            as_ = gav * BET_M
+            cs = gcv * BET_M
+            acol = gav * BET_P
+            ccol = gcv * BET_P
+            bcol = dtr_stage - acol[0, 0, 0] - ccol[0, 0, 0]
+            correction_term = -as_ * (u_stage[0, 0, -1] - u_stage[0, 0, 0]) - cs * (u_stage[0, 0, 1] - u_stage[0, 0, 0])
+            dcol = dtr_stage * u_pos[0, 0, 0] + utens[0, 0, 0] + utens_stage[0, 0, 0] + correction_term
+            divided = 1.0 / (bcol[0, 0, 0] - ccol[0, 0, -1] * acol[0, 0, 0])
+            ccol = ccol[0, 0, 0] * divided
+            dcol = (dcol[0, 0, 0] - (dcol[0, 0, -1]) * acol[0, 0, 0]) * divided
+        with interval(-1, None):  # noqa: F821
+            gav = -0.25 * (wcon[1, 0, 0] + wcon[0, 0, 0])
+            as_ = gav * BET_M
+            acol = gav * BET_P
+            bcol = dtr_stage - acol[0, 0, 0]
+            correction_term = -as_ * (u_stage[0, 0, -1] - u_stage[0, 0, 0])
+            dcol = dtr_stage * u_pos[0, 0, 0] + utens[0, 0, 0] + utens_stage[0, 0, 0] + correction_term
+            divided = 1.0 / (bcol[0, 0, 0] - ccol[0, 0, -1] * acol[0, 0, 0])
+            dcol = (dcol[0, 0, 0] - (dcol[0, 0, -1]) * acol[0, 0, 0]) * divided
+    with computation(BACKWARD):  # noqa: F821
+        with interval(-1, None):  # noqa: F821
+            datacol = dcol[0, 0, 0]
+            utens_stage = dtr_stage * (datacol - u_pos[0, 0, 0])
+        with interval(0, -1):  # noqa: F821
+            datacol = dcol[0, 0, 0] - ccol[0, 0, 0] * datacol[0, 0, 1]
+            utens_stage = dtr_stage * (datacol - u_pos[0, 0, 0])
 
 
 def cpu_baseline(seconds_budget: float = 12.0):

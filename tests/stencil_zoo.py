@@ -351,6 +351,8 @@ def make_inputs(stencil_object, domain, seed=1337):
             lo, hi = (max(0, int(b)) for b in info.boundary["IJK".index(axis)])
             shape.append(int(d) + lo + hi)
             origin.append(lo)
+        shape += [int(n) for n in info.data_dims]  # data dimensions: whole, origin 0
+        origin += [0] * len(info.data_dims)
         dt = np.dtype(info.dtype)
         if dt.kind == "f":
             data = rng.uniform(-1.0, 1.0, shape).astype(dt)

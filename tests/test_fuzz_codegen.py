@@ -75,7 +75,8 @@ def test_generated_kernels_match_the_oracle_on_random_stencils(seed, tmp_path):
         expect = {k: v.copy() for k, v in arrays.items()}
         ref(**expect, **scalars, origin=origins, domain=domain)
         dev = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=origins[k],
-                                        dimensions=hip.field_info[k].axes) for k, v in arrays.items()}
+                                        dimensions=tuple(hip.field_info[k].axes) + tuple(str(n) for n in range(len(hip.field_info[k].data_dims))))
+               for k, v in arrays.items()}
         hip(**dev, **scalars, origin=origins, domain=domain)
         for k in arrays:
             np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"seed {seed} {domain}, field {k}\n{text}")

@@ -254,6 +254,7 @@ class KernelSource:
     vec: int = 0  # > 0: a `<name>_vec` kernel exists in which every lane owns `vec` consecutive I points
     vec_fields: Tuple[str, ...] = ()  # arrays whose alignment / strides decide whether it may be launched
     vec_rows: int = 1  # consecutive J rows per lane in the `_vec` kernel
+    plane: Optional[Tuple[int, str, ir.Interval]] = None  # launched once per K level by the host (Stage.plane)
 
 
 @dataclass
@@ -608,11 +609,11 @@ class _Emitter:
             if k_per_thread > 1:
                 L.append(f"    #pragma unroll")
                 L.append(f"    for (int kk = 0; kk < {k_per_thread}; ++kk) {{")
-                L.append(f"    const gt_i64 k = (gt_i64)gt_bz * {k_per_thread} + kk;")
+                L.append(f"    const gt_i64 k = a.k_lo + (gt_i64)gt_bz * {k_per_thread} + kk;")
             else:
-                L.append("    const gt_i64 k = gt_bz;")
+                L.append("    const gt_i64 k = a.k_lo + gt_bz;")
             for nest in stage.nests:
-                L.append(f"    if (k >= {self.bound(nest.interval.start)} && k < {self.bound(nest.interval.end)}) {{")
+                L.append(f"    if (k >= {self.bound(nest.interval.start)} && k < {self.bound(nest.interval.end)} && k < a.k_hi) {{")
                 self.local_decls(nest, "        ")
                 self.statements(nest.stmts, stage, si, "k", {}, "        ")
                 L.append("    }")
@@ -716,8 +717,9 @@ class _Emitter:
         vec_rows = max(1, TUNING["vector_rows"])
         if vec:
             vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread)
+        plane = None if stage.plane is None else (stage.plane[0], stage.plane[1].value, stage.plane[2])
         return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
-                            vec_rows if vec else 1)
+                            vec_rows if vec else 1, plane)
 
 
 def _vector_width(em: "_Emitter", stage: Stage) -> int:
@@ -794,11 +796,11 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
     if k_per_thread > 1:
         L.append("    #pragma unroll")
         L.append(f"    for (int kk = 0; kk < {k_per_thread}; ++kk) {{")
-        L.append(f"    const gt_i64 k = (gt_i64)gt_bz * {k_per_thread} + kk;")
+        L.append(f"    const gt_i64 k = a.k_lo + (gt_i64)gt_bz * {k_per_thread} + kk;")
     else:
-        L.append("    const gt_i64 k = gt_bz;")
+        L.append("    const gt_i64 k = a.k_lo + gt_bz;")
     for nest in stage.nests:
-        L.append(f"    if (k >= {em.bound(nest.interval.start)} && k < {em.bound(nest.interval.end)}) {{")
+        L.append(f"    if (k >= {em.bound(nest.interval.start)} && k < {em.bound(nest.interval.end)} && k < a.k_hi) {{")
         L.append("      if (whole) {")
         # rows: every (array, row offset, dk) read for the strip, with the element offsets needed around the lane
         rows: Dict[Tuple[str, int, int], Set[int]] = {}
@@ -921,8 +923,10 @@ def generate(stencil: ir.Stencil) -> GeneratedProgram:
         struct_lines.append(f"    {_CTYPE[dt.name]} p_{_c_ident(p.name)};")
         fields_c.append((f"p_{_c_ident(p.name)}", _CTYPES_TYPE[dt.name]))
     struct_lines.append("    gt_i64 dI, dJ, dK;")
+    struct_lines.append("    gt_i64 k_lo, k_hi;  // thread-per-point kernels cover the levels [k_lo, k_hi) of this launch")
     struct_lines.append("};")
-    fields_c += [("dI", ctypes.c_int64), ("dJ", ctypes.c_int64), ("dK", ctypes.c_int64)]
+    fields_c += [("dI", ctypes.c_int64), ("dJ", ctypes.c_int64), ("dK", ctypes.c_int64), ("k_lo", ctypes.c_int64),
+                 ("k_hi", ctypes.c_int64)]
     args_struct = type("gt_args", (ctypes.Structure,), {"_fields_": fields_c})
 
     kernels = []

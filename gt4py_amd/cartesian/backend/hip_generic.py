@@ -149,8 +149,8 @@ class HipGenericStencilObject(StencilObject):
         info = _lib.ExecInfo() if exec_info is not None else None
         info_ref = ctypes.byref(info) if info is not None else None
         t0 = t1 = None
-        args_ref, args_size = ctypes.byref(args), ctypes.sizeof(args)
-        for fn, grid, block in launches:
+        args_size = ctypes.sizeof(args)
+        for fn, grid, block, args_ref in launches:
             rc = lib.gt4mi_launch(fn, grid, block, args_ref, args_size, stream, info_ref)
             if rc:
                 _lib.check("gt4mi_launch", rc)
@@ -235,6 +235,7 @@ class HipGenericStencilObject(StencilObject):
         for p in plan.params:
             setattr(args, f"p_{hip_codegen._c_ident(p.name)}", np.dtype(p.dtype).type(arguments[p.name]).item())
         args.dI, args.dJ, args.dK = dI, dJ, dK
+        args.k_lo, args.k_hi = 0, dK
 
         vkey = (unit_i, _ranges_disjoint(spans))
         variant = cls._gt_variants_.get(vkey)
@@ -242,18 +243,54 @@ class HipGenericStencilObject(StencilObject):
             variant = cls._gt_variants_[vkey] = _Variant(program, *vkey)
 
         launches = []
-        for kern, fn, vfn in zip(program.kernels, variant.functions, variant.vec_functions):
+        args_ref = ctypes.byref(args)
+        keep_args = [args]
+        per_level: Dict[int, Any] = {}  # K level -> copy of the argument block restricted to that level
+
+        def level_args(k: int):
+            if k not in per_level:
+                copy = type(args).from_buffer_copy(args)
+                copy.k_lo, copy.k_hi = k, k + 1
+                keep_args.append(copy)
+                per_level[k] = ctypes.byref(copy)
+            return per_level[k]
+
+        def geometry_of(kern, fn, vfn, levels: int):
             (ilo, ihi), (jlo, jhi) = kern.extent
             ni, nj = dI + ihi - ilo, dJ + jhi - jlo
-            if ni <= 0 or nj <= 0 or dK <= 0:
-                continue
-            nk = -(-dK // kern.k_per_thread) if kern.mapping == "ijk" else 1
+            if ni <= 0 or nj <= 0 or levels <= 0:
+                return None
+            nk = -(-levels // kern.k_per_thread) if kern.mapping == "ijk" else 1
             lanes = rows = 1
             if vfn is not None and all(
                     geometry[n][0] % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0
                     and geometry[n][2] % kern.vec == 0 for n in kern.vec_fields):
                 fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned
             grid = _U3(-(-ni // (kern.block[0] * lanes)), -(-nj // (kern.block[1] * kern.j_per_thread * rows)), nk)
-            launches.append((fn, grid, _U3(*kern.block)))
+            return fn, grid, _U3(*kern.block)
+
+        triples = list(zip(program.kernels, variant.functions, variant.vec_functions))
+        n = 0
+        while n < len(triples):
+            kern = triples[n][0]
+            if kern.plane is None:
+                g = geometry_of(*triples[n], dK)
+                if g is not None:
+                    launches.append((*g, args_ref))
+                n += 1
+                continue
+            # the stages of one sequential block with cross-column dependencies: once per K level, in sweep order
+            m = n
+            while m < len(triples) and triples[m][0].plane is not None and triples[m][0].plane[0] == kern.plane[0]:
+                m += 1
+            _, order, interval = kern.plane
+            k0, k1 = interval.range(dK)
+            levels = range(k0, k1) if order != "backward" else range(k1 - 1, k0 - 1, -1)
+            body = [geometry_of(*t, 1) for t in triples[n:m]]
+            for k in levels:
+                for g in body:
+                    if g is not None:
+                        launches.append((*g, level_args(k)))
+            n = m
         # the scratch buffer must outlive every cached plan that points into it
-        return args, launches, cls._gt_scratch_.get((dI, dJ, dK))
+        return args, launches, (cls._gt_scratch_.get((dI, dJ, dK)), keep_args)

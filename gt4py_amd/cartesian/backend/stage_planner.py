@@ -196,6 +196,10 @@ class Stage:
     offset_reads: Set[str] = field(default_factory=set)
     mapping: str = "ijk"
     extent: Extent2 = analysis.ZERO_EXTENT
+    #: stages of a sequential interval block whose columns depend on each other run PLANE BY PLANE: the host
+    #: loops over the K levels in sweep order and launches the block's stages once per level.
+    #: (loop id, order, interval); consecutive stages with the same loop id are one such loop's body.
+    plane: Optional[Tuple[int, ir.LoopOrder, ir.Interval]] = None
 
 
 @dataclass
@@ -244,15 +248,31 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     for ci, comp in enumerate(stencil.computations):
         for bi, block in enumerate(comp.blocks):
             stmts = [Stmt(s.target, s.value, next(ext_iter), s.mask, s.region, s.loops) for s in block.body]
-            if comp.order is ir.LoopOrder.PARALLEL:
+            def per_statement():
                 units = []  # one statement each, except that the body of a `while` stays together
                 for st in stmts:
                     if st.loops and units and units[-1][-1].loops and units[-1][-1].loops[0][0] == st.loops[0][0]:
                         units[-1].append(st)
                     else:
                         units.append([st])
+                return units
+
+            plane = None
+            if comp.order is ir.LoopOrder.PARALLEL:
+                units = per_statement()
             else:
                 units = [stmts]
+                block_writes = {s.target.name for s in stmts}
+                block_offreads = {e.name for s in stmts for e in _stmt_field_reads(s) if e.offset[0] != 0 or e.offset[1] != 0}
+                if block_writes & block_offreads:
+                    # A sequential block that reads, at a horizontal offset, what it writes: the columns are not
+                    # independent, so the sweep cannot live inside one thread.  It is executed the way the
+                    # reference's numpy backend executes every sequential block: level by level, statement by
+                    # statement over the plane (npir_codegen.py:243-248) -- stages cut at the cross-column
+                    # dependencies as in a PARALLEL block, launched once per K level by the host.
+                    units = per_statement()
+                    plane = (len(stages), comp.order, block.interval)
+                    cur = None
             for unit in units:
                 if not unit:
                     continue
@@ -263,12 +283,12 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                 }
                 if writes & offreads:
                     raise UnsupportedStencil(
-                        f"{sorted(writes & offreads)} written and read at a horizontal offset inside one "
-                        f"{comp.order.value} interval block: columns are not independent")
+                        f"{sorted(writes & offreads)} written and read at a horizontal offset inside one statement "
+                        f"(or one `while` body) of a {comp.order.value} interval block")
                 if cur is not None and ((offreads & cur.written) or (writes & cur.offset_reads)):
                     cur = None
                 if cur is None:
-                    cur = Stage()
+                    cur = Stage(plane=plane)
                     stages.append(cur)
                 if cur.nests and cur.nests[-1].block_id == (ci, bi):
                     cur.nests[-1].stmts.extend(unit)
@@ -276,11 +296,15 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                     cur.nests.append(Nest(comp.order, block.interval, list(unit), (ci, bi)))
                 cur.written |= writes
                 cur.offset_reads |= offreads
+            if plane is not None:
+                cur = None  # nothing after the block joins the per-level loop
 
     # mapping, statement splitting, extents
     for stage in stages:
         column = False
         for nest in stage.nests:
+            if stage.plane is not None:
+                break  # one level per launch: every other level is complete in memory, threads are points
             nest_writes = {s.target.name for s in nest.stmts}
             if nest.order is not ir.LoopOrder.PARALLEL:
                 column = True

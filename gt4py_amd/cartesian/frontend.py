@@ -1126,7 +1126,11 @@ def _check_semantics(stencil: ir.Stencil) -> None:
             if e.offset[2] != 0 and e.name not in api and comp.order is ir.LoopOrder.PARALLEL and e.name in written:
                 # temporaries with K offsets in PARALLEL computations are a race in the reference too
                 raise GTScriptSyntaxError(f"Invalid K offset access to temporary '{e.name}' in a PARALLEL computation")
-            # N5: a written API field may not be read with a horizontal offset (gtir_to_oir.py:19-46)
+            # N5: a written API field may not be read with a horizontal offset.  The reference applies this to the
+            # read EXTENT (validate_stencil_memory_accesses, gtir_to_oir.py:19-46), which also rejects reads that
+            # reach the field through a temporary; its reason is a race in the GridTools backends.  Here stages
+            # are cut at exactly those dependencies, so only the direct form is an error: every program the
+            # reference accepts is accepted, and the indirect ones run with the numpy backend's semantics.
             if e.name in api and e.name in written and horizontal(e):
                 raise ValueError(f"Found non-zero read extent on written fields: {e.name}")
 

@@ -205,6 +205,23 @@ def parallel_k_dependency(a: F64, b: F64):
         b = a[0, 0, 1] - tmp
 
 
+def cross_column_recurrence(a: F64, b: F64, c: F64):
+    """Sequential blocks whose columns depend on each other through a temporary read at horizontal offsets
+    (legal in the reference: gtir.py:224-241 only forbids it for API fields): forward, then backward with a mask."""
+    with computation(FORWARD), interval(1, None):
+        t = b[0, 0, -1] * 0.5 + b
+        a = a[0, 0, -1] * 0.5 + t[1, 0, 0] * 0.5 + t[-1, 0, 0] * 0.25
+    with computation(BACKWARD):
+        with interval(-1, None):
+            c = a
+        with interval(0, -1):
+            u = b[0, 0, 1] - b
+            if u[0, 1, 0] > 0.0:
+                c = u[0, -1, 0] + c[0, 0, 1]
+            else:
+                c = u + a
+
+
 def lower_dimensional(a: F64, surf: "Field[IJ, np.float64]", prof: "Field[K, np.float64]", out: F64):
     """test_code_generation.py:178-314 shape: IJ and K fields broadcast against a 3-d field"""
     with computation(PARALLEL), interval(...):
@@ -312,6 +329,7 @@ ZOO = {
     # name: (definition, externals, scalars, backend options)
     "copy_stencil": (copy_stencil, {}, {}, {}),
     "native_functions": (native_functions, {}, {}, {}),
+    "cross_column_recurrence": (cross_column_recurrence, {}, {}, {}),
     "ternary_mix": (ternary_mix, {}, {}, {}),
     "mixed_precision": (mixed_precision, {}, {"w": np.float32(0.7)}, {}),
     "int_fields": (int_fields, {}, {}, {}),

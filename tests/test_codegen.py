@@ -80,14 +80,29 @@ def test_parallel_computations_with_vertical_dependency_run_one_after_the_other(
     assert stage.mapping == "column" and len(stage.nests) == 3
 
 
-def test_unsupported_shapes_are_rejected_loudly():
-    def cross_column_recurrence(a: "Field[np.float64]", b: "Field[np.float64]"):  # noqa: F821
-        with computation(FORWARD), interval(1, None):  # noqa: F821
-            t = a[0, 0, -1] + b  # noqa: F841
-            a = t[1, 0, 0] + t[-1, 0, 0]  # noqa: F841
+def test_sequential_blocks_with_cross_column_dependencies_run_plane_by_plane(programs):
+    """A FORWARD block that reads, at a horizontal offset, a temporary it writes: thread-per-point stages (cut
+    between the two statements) that the host launches once per K level."""
+    stages = programs["cross_column_recurrence"].plan.stages
+    assert [st.mapping for st in stages] == ["ijk", "ijk", "column", "ijk", "ijk"]
+    assert [st.plane and (st.plane[0], st.plane[1].value) for st in stages] == [
+        (0, "forward"), (0, "forward"), None, (3, "backward"), (3, "backward")]
+    assert [k.plane is not None for k in programs["cross_column_recurrence"].kernels] == [True, True, False, True, True]
 
-    with pytest.raises(NotImplementedError, match="columns are not independent"):
-        gtscript.stencil(backend="hip:mi300", definition=cross_column_recurrence)
+
+def test_unsupported_shapes_are_rejected_loudly():
+    def neighbours_inside_a_while(a: "Field[np.float64]", b: "Field[np.float64]"):  # noqa: F821
+        with computation(PARALLEL), interval(...):  # noqa: F821
+            t = a
+            n = 0
+            while n < 2:
+                u = t[1, 0, 0]
+                t = u + b
+                n = n + 1
+            a = t
+
+    with pytest.raises(NotImplementedError, match="written and read at a horizontal offset inside one statement"):
+        gtscript.stencil(backend="hip:mi300", definition=neighbours_inside_a_while)
 
 
 @pytest.mark.parametrize("name", sorted(zoo.ZOO))
@@ -118,7 +133,7 @@ def test_generated_source_compiles_for_gfx950(programs, name):
     n_arrays = len(prog.plan.api_fields) + len(prog.plan.scratch)
     n_data = sum(len(d.data_dims) for d in (*prog.plan.api_fields, *prog.plan.stencil.temporaries)
                  if d.name in prog.plan.scratch or d in prog.plan.api_fields)
-    assert len(prog.args_struct._fields_) == 4 * n_arrays + n_data + len(prog.plan.params) + 3
+    assert len(prog.args_struct._fields_) == 4 * n_arrays + n_data + len(prog.plan.params) + 5
 
 
 def test_horizontal_stages_get_a_16_byte_lane_twin(programs):

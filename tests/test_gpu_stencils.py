@@ -99,11 +99,16 @@ def test_host_arrays_are_rejected_and_unknown_stencils_raise():
         stencil(np.ones((8, 8, 2)), np.zeros((8, 8, 2)))
 
     def other(a: gtscript.Field[np.float64], b: gtscript.Field[np.float64]):
-        with computation(FORWARD), interval(1, None):  # noqa: F821
-            t = a[0, 0, -1] + b  # noqa: F841
-            a = t[1, 0, 0] + t[-1, 0, 0]  # noqa: F841
+        with computation(PARALLEL), interval(...):  # noqa: F821
+            t = a
+            n = 0
+            while n < 2:
+                u = t[1, 0, 0]
+                t = u + b
+                n = n + 1
+            a = t
 
-    # columns depend on each other inside one sequential block: neither the kernel library nor the
+    # points depend on their neighbours INSIDE one `while` body: neither the kernel library nor the
     # generic executor can run it exactly -> loud failure at decoration time, never a CPU fallback
     with pytest.raises(NotImplementedError, match="no CPU fallback"):
         gtscript.stencil(definition=other, backend=BACKEND)

@@ -378,36 +378,53 @@ def main() -> None:
             pinned = "GT4MI_BENCH_HALO" in os.environ or "GT4MI_BENCH_OVERLAP" in os.environ
             halo = max(1, int(os.environ.get("GT4MI_BENCH_HALO", "2")))
             if not pinned:
-                calibration = {}
-                for cand_halo in (1, 2, 4):
-                    if (grid[1] > 1 and total[1] // grid[1] < 2 * cand_halo) or (grid[0] > 1 and total[0] // grid[0] < 2 * cand_halo):
-                        continue
-                    cdec = Decomposition(total, grid, rank, halo=cand_halo,
-                                         periodic=(False, True) if selfloop else (False, False))
-                    cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
-                    for cand_overlap in (True, False):
-                        ca, cb = cpairs[0][0], cpairs[1][0]
-                        ca.tensor.mul_(1e-150)
-                        cex = NativeHaloExchanger(cdec, np.float64, comm)
-                        cstep = cex.make_time_stepper_lap5(ca, cb, cdec.origin, overlap=cand_overlap)
-                        for _ in range(2 * cand_halo):
-                            cstep()
-                        torch.cuda.synchronize()
-                        if distributed:
-                            dist.barrier()
-                        t0 = time.perf_counter()
-                        for _ in range(24):
-                            cstep()
-                        torch.cuda.synchronize()
-                        dt = torch.tensor([(time.perf_counter() - t0) / 24], dtype=torch.float64, device="cuda")
-                        if distributed:
-                            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                        calibration[f"halo{cand_halo}_{'overlap' if cand_overlap else 'sequential'}"] = round(float(dt.item()) * 1e3, 5)
-                        cex.close()
-                    del cpairs
-                torch.cuda.empty_cache()
-                best = min(calibration, key=calibration.get)
-                halo, overlap = int(best.split("_")[0][4:]), best.endswith("overlap")
+                def calibrate():
+                    calibration = {}
+                    for cand_halo in (1, 2, 4):
+                        if (grid[1] > 1 and total[1] // grid[1] < 2 * cand_halo) or (grid[0] > 1 and total[0] // grid[0] < 2 * cand_halo):
+                            continue
+                        cdec = Decomposition(total, grid, rank, halo=cand_halo,
+                                             periodic=(False, True) if selfloop else (False, False))
+                        cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
+                        for cand_overlap in (True, False):
+                            ca, cb = cpairs[0][0], cpairs[1][0]
+                            ca.tensor.mul_(1e-150)
+                            cex = NativeHaloExchanger(cdec, np.float64, comm)
+                            cstep = cex.make_time_stepper_lap5(ca, cb, cdec.origin, overlap=cand_overlap)
+                            for _ in range(2 * cand_halo):
+                                cstep()
+                            torch.cuda.synchronize()
+                            if distributed:
+                                dist.barrier()
+                            t0 = time.perf_counter()
+                            for _ in range(24):
+                                cstep()
+                            torch.cuda.synchronize()
+                            dt = torch.tensor([(time.perf_counter() - t0) / 24], dtype=torch.float64, device="cuda")
+                            if distributed:
+                                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                            calibration[f"halo{cand_halo}_{'overlap' if cand_overlap else 'sequential'}"] = round(float(dt.item()) * 1e3, 5)
+                            cex.close()
+                        del cpairs
+                    torch.cuda.empty_cache()
+                    best = min(calibration, key=calibration.get)
+                    return calibration, int(best.split("_")[0][4:]), best.endswith("overlap")
+
+                # A transport that creates its communicator but cannot move data must not take the run down:
+                # every rank reports whether its calibration went through, and all fall back together.
+                ok = 1
+                try:
+                    calibration, halo, overlap = calibrate()
+                except Exception as ex:
+                    ok, calibration = 0, None
+                    print(f"rank {rank}: native RCCL halo exchange failed during calibration ({ex!r})", file=sys.stderr)
+                if distributed:
+                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    ok = int(flag.item())
+                if not ok:
+                    transport, comm, halo, overlap = "torch", None, 1, True
+                    print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
         dec = Decomposition(total, grid, rank, halo=halo, periodic=(False, True) if selfloop else (False, False))
         origin = {"inp": dec.origin, "out": dec.origin}
         pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank, origin=dec.origin)

@@ -51,6 +51,8 @@ def main():
                 dev[k].tensor.uniform_(-1.0, 1.0) if v.dtype.kind == "f" else None
                 if k == "diag":
                     dev[k].tensor.add_(4.5)
+            if os.environ.get("GT4MI_PRINT_PTRS"):
+                print("   field addresses mod 16 MiB (MiB):", {k: round((v.ptr % (1 << 24)) / 2**20, 3) for k, v in dev.items()})
             frozen = obj.freeze(origin=origins, domain=domain)
             for _ in range(3):
                 frozen(**dev, **scalars)

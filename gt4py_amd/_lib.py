@@ -52,6 +52,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_module_unload",
     "gt4mi_module_function",
     "gt4mi_launch",
+    "gt4mi_launch_batch",
     "gt4mi_stream_copy",
 )
 
@@ -193,6 +194,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     U3 = ctypes.POINTER(ctypes.c_uint32)
     lib.gt4mi_launch.restype = I
     lib.gt4mi_launch.argtypes = [P, U3, U3, P, SZ, P, EI]
+    lib.gt4mi_launch_batch.restype = I
+    lib.gt4mi_launch_batch.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), U3, U3, ctypes.POINTER(ctypes.c_void_p),
+                                       SZ, P, EI]
 
 
 def load() -> ctypes.CDLL:

@@ -137,7 +137,8 @@ class HipGenericStencilObject(StencilObject):
         if entry is not None and all(r() is arguments[n] for n, r in entry[0]):
             _, args, launches, _keep = entry
         else:
-            args, launches, keep = self._prepare(arguments, origin, (dI, dJ, dK))
+            args, launches, _keep = self._prepare(arguments, origin, (dI, dJ, dK))
+            keep = _keep
             if ckey is not None:
                 try:
                     refs = [(d.name, weakref.ref(arguments[d.name])) for d in plan.api_fields]
@@ -150,13 +151,18 @@ class HipGenericStencilObject(StencilObject):
         info_ref = ctypes.byref(info) if info is not None else None
         t0 = t1 = None
         args_size = ctypes.sizeof(args)
-        for fn, grid, block, args_ref in launches:
+        if len(launches) == 1:
+            fn, grid, block, args_ref = launches[0]
             rc = lib.gt4mi_launch(fn, grid, block, args_ref, args_size, stream, info_ref)
             if rc:
                 _lib.check("gt4mi_launch", rc)
-            if info is not None:
-                t0 = info.run_cpp_start_time if t0 is None else t0
-                t1 = info.run_cpp_end_time
+        elif launches:  # every stage (and every K level of a plane-by-plane block) in one crossing of the C ABI
+            n, fns, grids, blocks, arg_ptrs = _keep[2]
+            rc = lib.gt4mi_launch_batch(n, fns, grids, blocks, arg_ptrs, args_size, stream, info_ref)
+            if rc:
+                _lib.check("gt4mi_launch_batch", rc)
+        if info is not None and launches:
+            t0, t1 = info.run_cpp_start_time, info.run_cpp_end_time
         if cls._gt_device_sync_:
             _lib.check("gt4mi_stream_sync", lib.gt4mi_stream_sync(stream))
         if exec_info is not None and t0 is not None:
@@ -293,4 +299,11 @@ class HipGenericStencilObject(StencilObject):
                         launches.append((*g, level_args(k)))
             n = m
         # the scratch buffer must outlive every cached plan that points into it
-        return args, launches, (cls._gt_scratch_.get((dI, dJ, dK)), keep_args)
+        n = len(launches)
+        batch = None
+        if n > 1:
+            batch = (n, (ctypes.c_void_p * n)(*[f.value if isinstance(f, ctypes.c_void_p) else f for f, _, _, _ in launches]),
+                     (ctypes.c_uint32 * (3 * n))(*[v for _, g, _, _ in launches for v in g]),
+                     (ctypes.c_uint32 * (3 * n))(*[v for _, _, b, _ in launches for v in b]),
+                     (ctypes.c_void_p * n)(*[ctypes.addressof(a._obj) for _, _, _, a in launches]))
+        return args, launches, (cls._gt_scratch_.get((dI, dJ, dK)), keep_args, batch)

@@ -457,4 +457,16 @@ int gt4mi_launch(void* function, const uint32_t grid[3], const uint32_t block[3]
     return GT4MI_OK;
 }
 
+int gt4mi_launch_batch(int n, void* const* functions, const uint32_t* grids, const uint32_t* blocks,
+                       const void* const* args, size_t args_size, void* stream, gt4mi_exec_info* info) {
+    Timer timer(info);
+    if (n < 0 || (n > 0 && (functions == nullptr || grids == nullptr || blocks == nullptr || args == nullptr)))
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "launch_batch: null argument");
+    for (int l = 0; l < n; ++l) {
+        const int rc = gt4mi_launch(functions[l], grids + 3 * l, blocks + 3 * l, args[l], args_size, stream, nullptr);
+        if (rc != GT4MI_OK) return rc;
+    }
+    return GT4MI_OK;
+}
+
 }  // extern "C"

@@ -226,6 +226,12 @@ int gt4mi_module_unload(gt4mi_module* module);
 int gt4mi_module_function(gt4mi_module* module, const char* name, void** function);
 int gt4mi_launch(void* function, const uint32_t grid[3], const uint32_t block[3], const void* args,
                  size_t args_size, void* stream, gt4mi_exec_info* info);
+/* The launches of one stencil call in one crossing of the boundary, in order, on one stream: n kernels,
+ * grids / blocks as n consecutive triples, one argument block (of the same size) per launch.  A stencil of
+ * several stages -- or one whose sequential block runs plane by plane, two launches per K level -- otherwise
+ * pays the host language's call overhead per kernel.  Stops at the first failing launch. */
+int gt4mi_launch_batch(int n, void* const* functions, const uint32_t* grids, const uint32_t* blocks,
+                       const void* const* args, size_t args_size, void* stream, gt4mi_exec_info* info);
 
 /* ---- measurement helper ---------------------------------------------------------------------
  * Streaming device copy of nbytes (multiple of 16) with 16-byte lanes: the "achievable HBM"

@@ -4,9 +4,9 @@ import numpy as np, torch
 import gt4py_amd.storage as gt_storage
 from gt4py_amd.cartesian import gtscript
 import stencil_zoo as zoo
-for name in ("laplacian","vertical_advection_dycore","horizontal_diffusion"):
+for name in ("laplacian","vertical_advection_dycore","horizontal_diffusion","two_stage_written_input","cross_column_recurrence"):
     defn, ext, scal, opts = zoo.ZOO[name]
-    for use_lib in ((True, False) if name!="vertical_advection_dycore" else (False,)):
+    for use_lib in ((True, False) if name in ("laplacian", "horizontal_diffusion") else (False,)):
         obj = gtscript.stencil(backend="hip:mi300", definition=defn, externals=ext, device_sync=False, use_kernel_library=use_lib)
         domain=(16,16,8)
         arrays, origins = zoo.make_inputs(obj, domain)

@@ -237,6 +237,47 @@ def _target_exprs(target: ir.FieldAccess) -> List[ir.Expr]:
     return out + [d for d in target.data_index or () if isinstance(d, ir.Expr)]
 
 
+def _loop_invariant_statements(stmts: List[Stmt], temporaries: Set[str]) -> Tuple[List[Stmt], List[Stmt]]:
+    """Split a sequential block's statements into (those that can run before the loop, the rest).
+
+    A statement qualifies when it is an unconditional, unrestricted assignment (no mask, region or `while`) to a
+    3-d temporary at the current level that is the ONLY write of that temporary in the block, reads nothing the
+    block writes except temporaries that qualified before it, and whose temporary is read in the block only after
+    it, at K offset 0: then the value of every level is the same whether it is computed inside the sweep or up
+    front."""
+    writes_of: Dict[str, int] = {}
+    for s in stmts:
+        writes_of[s.target.name] = writes_of.get(s.target.name, 0) + 1
+    hoisted: List[Stmt] = []
+    names: Set[str] = set()
+    changed = True
+    while changed:
+        changed = False
+        for idx, s in enumerate(stmts):
+            t = s.target.name
+            if any(s is h for h in hoisted) or t not in temporaries or writes_of[t] != 1:
+                continue
+            if s.mask is not None or s.region is not None or s.loops or s.target.offset != (0, 0, 0) \
+                    or s.target.koffset is not None or s.target.data_index:
+                continue
+            reads = _stmt_field_reads(s)
+            if any(e.name in writes_of and e.name not in names for e in reads):
+                continue  # depends on the sweep
+            if any(e.name in names and (e.offset[2] != 0 or e.koffset is not None) for e in reads):
+                continue
+            ok = True
+            for jdx, other in enumerate(stmts):
+                for e in _stmt_field_reads(other):
+                    if e.name == t and (jdx <= idx or e.offset[2] != 0 or e.koffset is not None):
+                        ok = False
+            if ok:
+                hoisted.append(s)
+                names.add(t)
+                changed = True
+    hoisted.sort(key=lambda s: next(i for i, x in enumerate(stmts) if x is s))
+    return hoisted, [s for s in stmts if not any(s is h for h in hoisted)]
+
+
 def plan_stages(stencil_in: ir.Stencil) -> Plan:
     stencil, ssa_locals = inline_horizontal_temporaries(stencil_in)
     extents = analysis.compute_extents(stencil)
@@ -248,7 +289,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     for ci, comp in enumerate(stencil.computations):
         for bi, block in enumerate(comp.blocks):
             stmts = [Stmt(s.target, s.value, next(ext_iter), s.mask, s.region, s.loops) for s in block.body]
-            def per_statement():
+            def per_statement(stmts):
                 units = []  # one statement each, except that the body of a `while` stays together
                 for st in stmts:
                     if st.loops and units and units[-1][-1].loops and units[-1][-1].loops[0][0] == st.loops[0][0]:
@@ -257,47 +298,60 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                         units.append([st])
                 return units
 
-            plane = None
+            def add(units, order, block_id, plane):
+                nonlocal cur
+                for unit in units:
+                    if not unit:
+                        continue
+                    writes = {s.target.name for s in unit}
+                    offreads = {
+                        e.name for s in unit for e in _stmt_field_reads(s)
+                        if (e.offset[0] != 0 or e.offset[1] != 0) and e.name in written_anywhere
+                    }
+                    if writes & offreads:
+                        raise UnsupportedStencil(
+                            f"{sorted(writes & offreads)} written and read at a horizontal offset inside one statement "
+                            f"(or one `while` body) of a {comp.order.value} interval block")
+                    if cur is not None and ((offreads & cur.written) or (writes & cur.offset_reads)):
+                        cur = None
+                    if cur is None:
+                        cur = Stage(plane=plane)
+                        stages.append(cur)
+                    if cur.nests and cur.nests[-1].block_id == block_id:
+                        cur.nests[-1].stmts.extend(unit)
+                    else:
+                        cur.nests.append(Nest(order, block.interval, list(unit), block_id))
+                    cur.written |= writes
+                    cur.offset_reads |= offreads
+
+            def cross_column(body) -> bool:
+                writes = {s.target.name for s in body}
+                return bool(writes & {e.name for s in body for e in _stmt_field_reads(s) if e.offset[0] != 0 or e.offset[1] != 0})
+
             if comp.order is ir.LoopOrder.PARALLEL:
-                units = per_statement()
-            else:
-                units = [stmts]
-                block_writes = {s.target.name for s in stmts}
-                block_offreads = {e.name for s in stmts for e in _stmt_field_reads(s) if e.offset[0] != 0 or e.offset[1] != 0}
-                if block_writes & block_offreads:
-                    # A sequential block that reads, at a horizontal offset, what it writes: the columns are not
-                    # independent, so the sweep cannot live inside one thread.  It is executed the way the
-                    # reference's numpy backend executes every sequential block: level by level, statement by
-                    # statement over the plane (npir_codegen.py:243-248) -- stages cut at the cross-column
-                    # dependencies as in a PARALLEL block, launched once per K level by the host.
-                    units = per_statement()
-                    plane = (len(stages), comp.order, block.interval)
-                    cur = None
-            for unit in units:
-                if not unit:
-                    continue
-                writes = {s.target.name for s in unit}
-                offreads = {
-                    e.name for s in unit for e in _stmt_field_reads(s)
-                    if (e.offset[0] != 0 or e.offset[1] != 0) and e.name in written_anywhere
-                }
-                if writes & offreads:
-                    raise UnsupportedStencil(
-                        f"{sorted(writes & offreads)} written and read at a horizontal offset inside one statement "
-                        f"(or one `while` body) of a {comp.order.value} interval block")
-                if cur is not None and ((offreads & cur.written) or (writes & cur.offset_reads)):
-                    cur = None
-                if cur is None:
-                    cur = Stage(plane=plane)
-                    stages.append(cur)
-                if cur.nests and cur.nests[-1].block_id == (ci, bi):
-                    cur.nests[-1].stmts.extend(unit)
-                else:
-                    cur.nests.append(Nest(comp.order, block.interval, list(unit), (ci, bi)))
-                cur.written |= writes
-                cur.offset_reads |= offreads
-            if plane is not None:
+                add(per_statement(stmts), comp.order, (ci, bi), None)
+                continue
+            if cross_column(stmts):
+                # A sequential block that reads, at a horizontal offset, what it writes: the columns are not
+                # independent, so the sweep cannot live inside one thread.
+                # (1) Temporaries that do not take part in the sweep at all -- computed from fields the block does
+                # not write, read at their own level only -- are the usual reason (a horizontal stencil of the
+                # inputs feeding a vertical recurrence).  Their statements are taken out of the loop and run as a
+                # PARALLEL block over the same interval first; every level holds the value the loop would have
+                # put there.
+                hoisted, rest = _loop_invariant_statements(stmts, {t.name for t in stencil.temporaries})
+                if hoisted:
+                    add(per_statement(hoisted), ir.LoopOrder.PARALLEL, (ci, bi, "invariant"), None)
+                    stmts = rest
+            if cross_column(stmts):
+                # (2) What remains is executed the way the reference's numpy backend executes every sequential block:
+                # level by level, statement by statement over the plane (npir_codegen.py:243-248) -- stages cut at
+                # the cross-column dependencies as in a PARALLEL block, launched once per K level by the host.
+                cur = None
+                add(per_statement(stmts), comp.order, (ci, bi), (len(stages), comp.order, block.interval))
                 cur = None  # nothing after the block joins the per-level loop
+            else:
+                add([stmts], comp.order, (ci, bi), None)
 
     # mapping, statement splitting, extents
     for stage in stages:

@@ -222,6 +222,19 @@ def cross_column_recurrence(a: F64, b: F64, c: F64):
                 c = u + a
 
 
+def plane_recurrence(b: F64, out: F64):
+    """A vertical recurrence over a TEMPORARY that the same block reads at horizontal offsets: nothing can be taken
+    out of the loop, the block runs plane by plane (legal in the reference: only temporaries cross columns)."""
+    with computation(FORWARD):
+        with interval(0, 1):
+            s = b
+            out = s
+        with interval(1, None):
+            s = s[0, 0, -1] * 0.5 + b
+            t = s * 2.0
+            out = t[1, 0, 0] + s[-1, 0, 0] + out[0, 0, -1] * 0.25
+
+
 def lower_dimensional(a: F64, surf: "Field[IJ, np.float64]", prof: "Field[K, np.float64]", out: F64):
     """test_code_generation.py:178-314 shape: IJ and K fields broadcast against a 3-d field"""
     with computation(PARALLEL), interval(...):
@@ -330,6 +343,7 @@ ZOO = {
     "copy_stencil": (copy_stencil, {}, {}, {}),
     "native_functions": (native_functions, {}, {}, {}),
     "cross_column_recurrence": (cross_column_recurrence, {}, {}, {}),
+    "plane_recurrence": (plane_recurrence, {}, {}, {}),
     "ternary_mix": (ternary_mix, {}, {}, {}),
     "mixed_precision": (mixed_precision, {}, {"w": np.float32(0.7)}, {}),
     "int_fields": (int_fields, {}, {}, {}),

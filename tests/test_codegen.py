@@ -80,14 +80,24 @@ def test_parallel_computations_with_vertical_dependency_run_one_after_the_other(
     assert stage.mapping == "column" and len(stage.nests) == 3
 
 
-def test_sequential_blocks_with_cross_column_dependencies_run_plane_by_plane(programs):
-    """A FORWARD block that reads, at a horizontal offset, a temporary it writes: thread-per-point stages (cut
-    between the two statements) that the host launches once per K level."""
+def test_loop_invariant_temporaries_leave_the_sequential_block(programs):
+    """A FORWARD block that reads, at a horizontal offset, a temporary computed from fields the block does not write:
+    the temporary becomes a PARALLEL stage of its own and the sweep stays a thread per column."""
     stages = programs["cross_column_recurrence"].plan.stages
-    assert [st.mapping for st in stages] == ["ijk", "ijk", "column", "ijk", "ijk"]
-    assert [st.plane and (st.plane[0], st.plane[1].value) for st in stages] == [
-        (0, "forward"), (0, "forward"), None, (3, "backward"), (3, "backward")]
-    assert [k.plane is not None for k in programs["cross_column_recurrence"].kernels] == [True, True, False, True, True]
+    assert all(st.plane is None for st in stages)
+    assert [(st.mapping, [(n.order.value, [s.target.name for s in n.stmts]) for n in st.nests]) for st in stages][:2] == [
+        ("ijk", [("parallel", ["t"])]),
+        ("column", [("forward", ["a"]), ("backward", ["c"]), ("parallel", ["u"])])]
+
+
+def test_sequential_blocks_with_cross_column_dependencies_run_plane_by_plane(programs):
+    """... and when the temporary takes part in the sweep: thread-per-point stages (cut between producer and
+    offset reader) that the host launches once per K level."""
+    stages = programs["plane_recurrence"].plan.stages
+    assert [st.mapping for st in stages] == ["column", "ijk", "ijk"]
+    assert [st.plane and (st.plane[0], st.plane[1].value) for st in stages] == [None, (1, "forward"), (1, "forward")]
+    assert [[s.target.name for n in st.nests for s in n.stmts] for st in stages[1:]] == [["s", "t"], ["out"]]
+    assert [k.plane is not None for k in programs["plane_recurrence"].kernels] == [False, True, True]
 
 
 def test_unsupported_shapes_are_rejected_loudly():

@@ -209,7 +209,7 @@ class StencilObject(abc.ABC):
                        validate_args=validate_args, exec_info=exec_info)
         if exec_info is not None:
             exec_info["call_end_time"] = time.perf_counter()
-            if exec_info.get("__aggregate_data", False):
+            if exec_info.setdefault("__aggregate_data", False):
                 self._aggregate(exec_info)
 
     def _aggregate(self, exec_info: Dict[str, Any]) -> None:
@@ -217,6 +217,8 @@ class StencilObject(abc.ABC):
         stats = exec_info.setdefault(type(self).__name__, {})
         call_time = exec_info["call_end_time"] - exec_info["call_start_time"]
         run_time = exec_info["run_end_time"] - exec_info["run_start_time"]
+        stats["call_start_time"] = exec_info["call_start_time"]
+        stats["call_end_time"] = exec_info["call_end_time"]
         stats["ncalls"] = stats.get("ncalls", 0) + 1
         stats["call_time"] = call_time
         stats["total_call_time"] = stats.get("total_call_time", 0.0) + call_time

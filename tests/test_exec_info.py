@@ -1,0 +1,120 @@
+"""``exec_info`` bookkeeping of stencil calls, as /root/reference/tests/cartesian_tests/integration_tests/
+feature_tests/test_exec_info.py pins it: per-call timestamps, the normalised origin / domain, and the per-stencil
+aggregates kept when ``exec_info["__aggregate_data"]`` is set.  Same two stencils (upwind advection, fourth-order
+diffusion), same call sequence; sizes are fixed instead of drawn by hypothesis.  Oracle on the CPU, ``hip:mi300`` on the
+GPU (where the native launch timestamps ``run_cpp_*`` must be there as well)."""
+
+import numpy as np
+import pytest
+
+import gt4py_amd.storage as gt_storage
+import oracle.numpy_backend  # noqa: F401 - registers backend "numpy"
+from gt4py_amd.cartesian import gtscript
+from gt4py_amd.cartesian.gtscript import PARALLEL, Field, computation, interval  # noqa: F401
+
+BACKENDS = ["numpy", pytest.param("hip:mi300", marks=pytest.mark.gpu)]
+
+
+def advection_def(in_phi: Field[float], in_u: Field[float], in_v: Field[float], out_phi: Field[float]):
+    with computation(PARALLEL), interval(...):
+        u = 0.5 * (in_u[-1, 0, 0] + in_u[0, 0, 0])
+        flux_x = u[0, 0, 0] * (in_phi[-1, 0, 0] if u[0, 0, 0] > 0 else in_phi[0, 0, 0])
+        v = 0.5 * (in_v[0, -1, 0] + in_v[0, 0, 0])
+        flux_y = v[0, 0, 0] * (in_phi[0, -1, 0] if v[0, 0, 0] > 0 else in_phi[0, 0, 0])
+        out_phi = in_phi - (flux_x[1, 0, 0] - flux_x[0, 0, 0]) - (flux_y[0, 1, 0] - flux_y[0, 0, 0])
+
+
+def diffusion_def(in_phi: Field[float], out_phi: Field[float], *, alpha: float):
+    with computation(PARALLEL), interval(...):
+        lap1 = -4 * in_phi[0, 0, 0] + in_phi[-1, 0, 0] + in_phi[1, 0, 0] + in_phi[0, -1, 0] + in_phi[0, 1, 0]
+        lap2 = -4 * lap1[0, 0, 0] + lap1[-1, 0, 0] + lap1[1, 0, 0] + lap1[0, -1, 0] + lap1[0, 1, 0]
+        flux_x = lap2[1, 0, 0] - lap2[0, 0, 0]
+        flux_y = lap2[0, 1, 0] - lap2[0, 0, 0]
+        out_phi = in_phi + alpha * (flux_x[0, 0, 0] - flux_x[-1, 0, 0] + flux_y[0, 0, 0] - flux_y[0, -1, 0])
+
+
+NX, NY, NZ = 17, 11, 6
+
+
+def _setup(backend):
+    rng = np.random.default_rng(5)
+    advection = gtscript.stencil(backend=backend, definition=advection_def)
+    diffusion = gtscript.stencil(backend=backend, definition=diffusion_def)
+
+    def field(aligned):
+        return gt_storage.from_array(rng.uniform(-1, 1, (NX, NY, NZ)), backend=backend, aligned_index=aligned, dtype=float)
+
+    fields = {"in_phi": field((0, 0, 0)), "in_u": field((0, 0, 0)), "in_v": field((0, 0, 0)), "tmp_phi": field((1, 1, 0)),
+              "out_phi": field((3, 3, 0))}
+    return advection, diffusion, fields
+
+
+def _run(advection, diffusion, f, exec_info, nt):
+    for _ in range(nt):
+        advection(f["in_phi"], f["in_u"], f["in_v"], f["tmp_phi"], origin=(1, 1, 0), domain=(NX - 2, NY - 2, NZ),
+                  exec_info=exec_info)
+        diffusion(f["in_phi"], f["out_phi"], alpha=1 / 32, origin=(3, 3, 0), domain=(NX - 6, NY - 6, NZ), exec_info=exec_info)
+
+
+def _check_exec_info(exec_info, native):
+    """test_exec_info.py:119-145: the entries of the LAST call."""
+    assert exec_info["call_end_time"] > exec_info["call_start_time"]
+    assert exec_info["run_start_time"] > exec_info["call_start_time"]
+    assert exec_info["run_end_time"] > exec_info["run_start_time"]
+    assert exec_info["call_end_time"] > exec_info["run_end_time"]
+    if native:
+        assert exec_info["run_cpp_end_time"] >= exec_info["run_cpp_start_time"]
+    assert exec_info["origin"] == {"_all_": (3, 3, 0), "in_phi": (3, 3, 0), "out_phi": (3, 3, 0)}
+    assert exec_info["domain"] == (NX - 6, NY - 6, NZ)
+
+
+def _check_stencil_info(exec_info, info, nt, native, last_called_stencil=False):
+    """test_exec_info.py:147-192: the aggregates of one stencil."""
+    assert info["ncalls"] == nt
+    assert info["call_end_time"] > info["call_start_time"]
+    assert np.isclose(info["call_time"], info["call_end_time"] - info["call_start_time"])
+    assert info["total_call_time"] == info["call_time"] if nt == 1 else info["total_call_time"] > info["call_time"]
+    if last_called_stencil:
+        assert info["call_start_time"] == exec_info["call_start_time"] and info["call_end_time"] == exec_info["call_end_time"]
+        assert np.isclose(info["run_time"], exec_info["run_end_time"] - exec_info["run_start_time"])
+    assert info["call_time"] > info["run_time"]
+    assert info["total_run_time"] == info["run_time"] if nt == 1 else info["total_run_time"] > info["run_time"]
+    if native:
+        if last_called_stencil:
+            assert np.isclose(info["run_cpp_time"], exec_info["run_cpp_end_time"] - exec_info["run_cpp_start_time"])
+        assert info["run_time"] > info["run_cpp_time"]
+        assert info["total_run_cpp_time"] == info["run_cpp_time"] if nt == 1 else info["total_run_cpp_time"] > info["run_cpp_time"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("nt", [1, 3])
+def test_backcompatibility(backend, nt):
+    advection, diffusion, fields = _setup(backend)
+    exec_info = {}
+    _run(advection, diffusion, fields, exec_info, nt)
+    _check_exec_info(exec_info, native=backend != "numpy")
+    assert exec_info["__aggregate_data"] is False
+    assert type(advection).__name__ not in exec_info and type(diffusion).__name__ not in exec_info
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("nt", [1, 3])
+def test_aggregate(backend, nt):
+    advection, diffusion, fields = _setup(backend)
+    exec_info = {"__aggregate_data": True}
+    _run(advection, diffusion, fields, exec_info, nt)
+    native = backend != "numpy"
+    _check_exec_info(exec_info, native)
+    _check_stencil_info(exec_info, exec_info[type(advection).__name__], nt, native)
+    _check_stencil_info(exec_info, exec_info[type(diffusion).__name__], nt, native, last_called_stencil=True)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_results_of_the_two_stencils(backend):
+    """... and the values: oracle == hip:mi300 is covered by the suites; here the two backends see the same call."""
+    advection, diffusion, fields = _setup(backend)
+    _run(advection, diffusion, fields, None, 1)
+    ref_adv, ref_diff, ref_fields = _setup("numpy")
+    _run(ref_adv, ref_diff, ref_fields, None, 1)
+    for name in ("tmp_phi", "out_phi"):
+        np.testing.assert_array_equal(gt_storage.asnumpy(fields[name]), np.asarray(ref_fields[name]))

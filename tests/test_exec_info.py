@@ -118,3 +118,56 @@ def test_results_of_the_two_stencils(backend):
     _run(ref_adv, ref_diff, ref_fields, None, 1)
     for name in ("tmp_phi", "out_phi"):
         np.testing.assert_array_equal(gt_storage.asnumpy(fields[name]), np.asarray(ref_fields[name]))
+
+
+# ---- test_field_layouts.py:33-95 (arrays that did not come from gt4py.storage) -----------------------------------
+def copy_stencil(field_a: Field[float], field_b: Field[float]):
+    with computation(PARALLEL), interval(...):
+        field_b = field_a
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_numpy_allocators(order):
+    rng = np.random.default_rng(0)
+    inp = np.array(rng.standard_normal((20, 10, 5)), order=order, dtype=np.float64)
+    outp = np.zeros((20, 10, 5), order=order, dtype=np.float64)
+    gtscript.stencil(definition=copy_stencil, backend="numpy")(field_a=inp, field_b=outp)
+    np.testing.assert_array_equal(outp, inp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_foreign_device_arrays_of_either_order(order):
+    """The reference skips this on ROCm (no `__hip_array_interface__` on cupy arrays there); here torch tensors of any
+    stride order are accepted as they are (any-stride kernels), with the layout warning for the non-preferred one."""
+    import warnings
+
+    import torch
+
+    host = np.random.default_rng(0).standard_normal((20, 10, 5))
+    inp = torch.as_tensor(host, device="cuda")
+    outp = torch.zeros((20, 10, 5), dtype=torch.float64, device="cuda")
+    if order == "F":  # I contiguous: the layout hip:mi300 prefers
+        inp = inp.permute(2, 1, 0).contiguous().permute(2, 1, 0)
+        outp = outp.permute(2, 1, 0).contiguous().permute(2, 1, 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        gtscript.stencil(definition=copy_stencil, backend="hip:mi300")(field_a=inp, field_b=outp)
+    np.testing.assert_array_equal(outp.cpu().numpy(), host)
+
+
+def test_bad_layout_warns():
+    inp = np.transpose(np.random.default_rng(1).standard_normal((10, 10, 10)), axes=(1, 2, 0))
+    outp = gt_storage.zeros(backend="numpy", shape=(10, 10, 10), dtype=np.float64, aligned_index=(0, 0, 0))
+    with pytest.warns(UserWarning, match="The layout of the field 'field_a' is not recommended for this backend."
+                                         "This may lead to performance degradation. Please consider using the"
+                                         "provided allocators in `gt4py.storage`."):
+        gtscript.stencil(definition=copy_stencil, backend="numpy")(field_a=inp, field_b=outp)
+
+
+@pytest.mark.parametrize("backend", ["numpy", "gt:cpu_ifirst", "gt:cpu_kfirst", pytest.param("hip:mi300", marks=pytest.mark.gpu)])
+def test_data_dimensions_stride_is_always_higher_than_cartesian(backend):
+    a4 = gt_storage.zeros(backend=backend, shape=(2, 2, 2, 2), dtype=np.float64, aligned_index=(0, 0, 0, 0))
+    assert a4.strides[3] > max(a4.strides[0:3])
+    a5 = gt_storage.zeros(backend=backend, shape=(2, 2, 2, 2, 2), dtype=np.float64, aligned_index=(0, 0, 0, 0, 0))
+    assert a5.strides[4] > max(a5.strides[0:3]) and a5.strides[3] > max(a5.strides[0:3])

@@ -1,4 +1,6 @@
-"""``exec_info`` bookkeeping of stencil calls, as /root/reference/tests/cartesian_tests/integration_tests/
+"""Feature tests of the reference around the call path: ``exec_info`` bookkeeping, foreign array layouts, lazy stencils.
+
+``exec_info`` bookkeeping of stencil calls, as /root/reference/tests/cartesian_tests/integration_tests/
 feature_tests/test_exec_info.py pins it: per-call timestamps, the normalised origin / domain, and the per-stencil
 aggregates kept when ``exec_info["__aggregate_data"]`` is set.  Same two stencils (upwind advection, fourth-order
 diffusion), same call sequence; sizes are fixed instead of drawn by hypothesis.  Oracle on the CPU, ``hip:mi300`` on the
@@ -171,3 +173,48 @@ def test_data_dimensions_stride_is_always_higher_than_cartesian(backend):
     assert a4.strides[3] > max(a4.strides[0:3])
     a5 = gt_storage.zeros(backend=backend, shape=(2, 2, 2, 2, 2), dtype=np.float64, aligned_index=(0, 0, 0, 0, 0))
     assert a5.strides[4] > max(a5.strides[0:3]) and a5.strides[3] > max(a5.strides[0:3])
+
+
+# ---- test_gtcnumpy.py:14-33 and unit_tests/test_lazy_stencil.py:52-90 ---------------------------------------------
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_masked_vector_assignment(backend):
+    from gt4py_amd.cartesian.gtscript import FORWARD, IJ
+
+    @gtscript.stencil(backend)
+    def masked_vector_assignment(fld2D: Field[IJ, np.float64]):
+        with computation(FORWARD), interval(0, None):
+            fld2D += fld2D
+            if fld2D >= 1.0:
+                fld2D = 0.0
+
+    fld2D = gt_storage.ones(shape=(2, 3), dtype=np.float64, backend=backend, aligned_index=(0, 0), dimensions="IJ")
+    masked_vector_assignment(fld2D, domain=(2, 3, 4))
+    assert (gt_storage.asnumpy(fld2D) == 0).all()
+
+
+def copy_stencil_definition(out_f: Field[float], in_f: Field[float]):
+    with computation(PARALLEL), interval(...):
+        out_f = in_f
+
+
+def wrong_syntax_stencil_definition(out_f: Field[float], in_f: Field[float]):
+    from __externals__ import undefined
+
+    with computation(PARALLEL), interval(...):
+        out_f = undefined(in_f)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_lazy_stencil_builds_on_first_use_and_is_callable(backend):
+    from gt4py_amd.cartesian.definitions import GTScriptDefinitionError
+
+    lazy = gtscript.lazy_stencil(backend=backend, definition=copy_stencil_definition, rebuild=True)
+    assert lazy.backend == backend  # building it now
+    a = gt_storage.from_array(np.array([[[1.0]]]), aligned_index=(0, 0, 0), backend=backend, dtype=float)
+    b = gt_storage.from_array(np.array([[[0.0]]]), aligned_index=(0, 0, 0), backend=backend, dtype=float)
+    lazy(b, a)
+    assert gt_storage.asnumpy(b)[0, 0, 0] == 1.0
+    # a definition with a GTScript error: nothing happens until it is needed, then the frontend's error
+    broken = gtscript.lazy_stencil(backend=backend, definition=wrong_syntax_stencil_definition)
+    with pytest.raises(GTScriptDefinitionError):
+        broken.implementation  # noqa: B018

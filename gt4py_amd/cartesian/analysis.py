@@ -114,18 +114,27 @@ def compute_access_kinds(stencil: ir.Stencil) -> Dict[str, AccessKind]:
 
 
 def compute_k_boundary(stencil: ir.Stencil) -> Dict[str, Tuple[int, int]]:
+    """K boundary per field; ``TypeError`` for a temporary accessed outside the K range it exists on.
+
+    gtir_k_boundary.py:39-70 raises for the interval block that declares the temporary (= first assigns it,
+    defir_to_gtir.py:433-451).  A temporary read beyond the domain from a LATER block is not caught there but
+    fails in the numpy backend at run time (temporaries hold exactly ``_dK_`` levels, npir_codegen.py:88-104);
+    here scratch arrays hold exactly the domain's levels too, so that form is rejected with the same message
+    instead of reading outside the buffer."""
     neg_inf = float("-inf")
     bounds: Dict[str, Tuple[float, float]] = {d.name: (neg_inf, neg_inf) for d in (*stencil.fields, *stencil.temporaries)}
+    temporaries = {t.name for t in stencil.temporaries}
     for _, block, stmt in stencil.statements():
         accesses = [stmt.target] + [e for e in ir.stmt_reads(stmt) if isinstance(e, ir.FieldAccess)]
         for acc in accesses:
-            if acc.koffset is not None:  # gtir_k_boundary.py:52: variable offsets do not bound anything
-                continue
             lo, hi = bounds[acc.name]
-            if block.interval.start.level is ir.Level.START:
-                lo = max(-block.interval.start.offset - acc.offset[2], lo)
-            if block.interval.end.level is ir.Level.END:
-                hi = max(block.interval.end.offset + acc.offset[2], hi)
+            if acc.koffset is None:  # gtir_k_boundary.py:52: variable offsets do not bound anything
+                if block.interval.start.level is ir.Level.START:
+                    lo = max(-block.interval.start.offset - acc.offset[2], lo)
+                if block.interval.end.level is ir.Level.END:
+                    hi = max(block.interval.end.offset + acc.offset[2], hi)
+            if acc.name in temporaries and (lo > 0 or hi > 0):
+                raise TypeError(f"Invalid access with offset in k to temporary field {acc.name}.")
             bounds[acc.name] = (lo, hi)
     return {n: (int(lo) if lo != neg_inf else 0, int(hi) if hi != neg_inf else 0) for n, (lo, hi) in bounds.items()}
 

@@ -1123,9 +1123,6 @@ def _check_semantics(stencil: ir.Stencil) -> None:
         for e in ir.stmt_reads(stmt):
             if not isinstance(e, ir.FieldAccess):
                 continue
-            if e.offset[2] != 0 and e.name not in api and comp.order is ir.LoopOrder.PARALLEL and e.name in written:
-                # temporaries with K offsets in PARALLEL computations are a race in the reference too
-                raise GTScriptSyntaxError(f"Invalid K offset access to temporary '{e.name}' in a PARALLEL computation")
             # N5: a written API field may not be read with a horizontal offset.  The reference applies this to the
             # read EXTENT (validate_stencil_memory_accesses, gtir_to_oir.py:19-46), which also rejects reads that
             # reach the field through a temporary; its reason is a race in the GridTools backends.  Here stages

@@ -367,20 +367,27 @@ static void tridiag_variant(DevField<T>& a, DevField<T>& d, DevField<T>& s, DevF
     report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
 }
 
-template <int RL, int LL, int U>
+template <int RL, int LL, int U, bool PIPE = false>
 static void tridiag_stack_variant(DevField<double>& a, DevField<double>& d, DevField<double>& s, DevField<double>& r,
                                   DevField<double>& o, DevField<double>& s2, DevField<double>& r2, DevField<double>& o2,
                                   int dI, int dJ, int dK) {
     const unsigned ti = (unsigned)cdiv(dI, 64);
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "stack RL=%d LL=%d U=%d (mem levels %d)", RL, LL, U, dK - RL - LL);
+    snprintf(cfg, sizeof cfg, "%s RL=%d LL=%d U=%d (mem levels %d)", PIPE ? "pipe " : "stack", RL, LL, U, dK - RL - LL);
     if (dK - RL - LL < 1) return;
+    auto launch = [&]() {
+        if constexpr (PIPE)
+            hipLaunchKernelGGL((tridiag_pipe_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+        else
+            hipLaunchKernelGGL((tridiag_stack_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+    };
     // correctness against the two-sweep kernel from identical inputs
     fill(s, 3, -1.0, 1.0);
     fill(r, 4, -10.0, 10.0);
     fill(s2, 3, -1.0, 1.0);
     fill(r2, 4, -10.0, 10.0);
-    hipLaunchKernelGGL((tridiag_stack_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+    CK(hipMemset(o.raw, 0xff, o.bytes));
+    launch();
     {
         const unsigned t2 = (unsigned)cdiv(dI, 256);
         hipLaunchKernelGGL((tridiag_kernel<double, 1, 8>), dim3(t2 * dJ), dim3(256), 0, 0, a.cview(), d.cview(), s2.view(), r2.view(), o2.view(), dI, dJ, dK, t2);
@@ -388,10 +395,58 @@ static void tridiag_stack_variant(DevField<double>& a, DevField<double>& d, DevF
     CK(hipDeviceSynchronize());
     printf("           check %s: out %llu sup %llu rhs %llu mismatches\n", cfg, count_diff(o, o2, dI, dJ, dK),
            count_diff(s, s2, dI, dJ, dK), count_diff(r, r2, dI, dJ, dK));
-    const double ms = time_ms([&](int) {
-        hipLaunchKernelGGL((tridiag_stack_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
-    }, 5, 1);
+    const double ms = time_ms([&](int) { launch(); }, 5, 1);
     report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
+}
+
+// a few launches of each column kernel and of the Laplacian, for counter passes (rocprofv3 --pmc ...)
+static void section_tripmc() {
+    {
+        const int dI = 1024, dJ = 1024, dK = 160;
+        DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
+        DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+        printf("tripmc     fields at %p %p %p %p %p\n", (void*)a.data, (void*)d.data, (void*)s.data, (void*)r.data, (void*)o.data);
+        fill(a, 1, -1.0, 1.0);
+        fill(d, 2, 4.0, 5.0);
+        tridiag_stack_variant<32, 40, 8, false>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_variant<double, 1, 8>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
+    }
+    lap_suite(512, 512, 512, 0, "512^3");
+}
+
+// pipelined vs plain on-chip-stack kernel, also on column counts / depths that exercise the head and odd-batch paths
+static void section_tripipe() {
+    for (int rep = 0; rep < 2; ++rep) {
+        const int dI = 1024, dJ = 1024, dK = 160;
+        DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
+        DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+        fill(a, 1, -1.0, 1.0);
+        fill(d, 2, 4.0, 5.0);
+        tridiag_stack_variant<32, 40, 8, false>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 40, 4, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<16, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<24, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<40, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<48, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<64, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 32, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 16, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<16, 16, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 0, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 48, 16, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    }
+    for (int dK : {73, 74, 80, 81, 87, 88, 89, 96, 97, 105, 33, 34, 40, 41, 47, 48, 49, 72}) {  // every head / parity case
+        const int dI = 200, dJ = 37;
+        DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
+        DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+        fill(a, 1, -1.0, 1.0);
+        fill(d, 2, 4.0, 5.0);
+        printf("           dK = %d\n", dK);
+        tridiag_stack_variant<32, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 0, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    }
 }
 
 static void section_tridiag() {
@@ -446,6 +501,66 @@ static void section_tridiag() {
     tridiag_stack_variant<28, 40, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
     tridiag_stack_variant<36, 40, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
     tridiag_stack_variant<32, 40, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Placement study for the tridiagonal solve: the five equally shaped fields live in ONE allocation at
+// controlled relative offsets, field f at f * (field bytes rounded up to `round`) + f * delta.  Shows how the
+// solve's speed depends on the fields' addresses relative to each other (the bimodal 84 / 95 GLUPS of round 1).
+static void section_triplace(int argc_extra, const std::vector<std::string>& extra) {
+    const int dI = 1024, dJ = 1024, dK = 160;
+    const int64_t sj = dI, sk = (int64_t)dI * dJ;
+    const size_t fbytes = (size_t)sk * dK * sizeof(double);
+    const size_t MiB = 1 << 20;
+    const size_t max_delta = 40 * MiB, round = 32 * MiB;
+    const size_t slot = (fbytes + round - 1) / round * round;
+    const size_t total = 5 * (slot + max_delta) + round;
+    char* raw = nullptr;
+    CK(hipMalloc(&raw, total));
+    char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(raw) + round - 1) / round * round);
+    printf("triplace   one allocation of %.1f MiB at %p (base rounded to 32 MiB: %p), field %.1f MiB, slot %.1f MiB\n",
+           total / (double)MiB, (void*)raw, (void*)base, fbytes / (double)MiB, slot / (double)MiB);
+    {  // where would five separate hipMallocs land?
+        void* q[5];
+        for (int f = 0; f < 5; ++f) CK(hipMalloc(&q[f], fbytes + 512));
+        printf("triplace   five separate hipMalloc(%zu): ", fbytes + 512);
+        for (int f = 0; f < 5; ++f) printf("%p%s", q[f], f < 4 ? " " : "\n");
+        printf("triplace   differences to the first, in MiB:");
+        for (int f = 1; f < 5; ++f) printf(" %.4f", ((char*)q[f] - (char*)q[0]) / (double)MiB);
+        printf("\n");
+        for (int f = 0; f < 5; ++f) hipFree(q[f]);
+    }
+    const size_t deltas_kib[] = {0,    4,    16,   64,   128,  256,  384,  512,  768,  1024, 1280, 1536, 1792,
+                                 2048, 2560, 3072, 3584, 4096, 5120, 6144, 8192, 12288, 16384, 24576, 32768,
+                                 1536 + 64, 1536 + 4, 1024 + 4, 2048 + 4, 2048 + 64, 4096 + 64};
+    const unsigned ti = (unsigned)cdiv(dI, 64);
+    for (int rep = 0; rep < 2; ++rep)
+        for (size_t dk_ : deltas_kib) {
+            const size_t delta = dk_ * 1024;
+            double* p[5];
+            for (int f = 0; f < 5; ++f) p[f] = reinterpret_cast<double*>(base + f * (slot + delta));
+            const size_t n = (size_t)sk * dK;
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(4096), dim3(256), 0, 0, p[0], n, 1u, -1.0, 1.0);
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(4096), dim3(256), 0, 0, p[1], n, 2u, 4.0, 5.0);
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(4096), dim3(256), 0, 0, p[2], n, 3u, -1.0, 1.0);
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(4096), dim3(256), 0, 0, p[3], n, 4u, -10.0, 10.0);
+            CK(hipDeviceSynchronize());
+            View<const double> a{p[0], 1, sj, sk}, d{p[1], 1, sj, sk};
+            View<double> s{p[2], 1, sj, sk}, r{p[3], 1, sj, sk}, o{p[4], 1, sj, sk};
+            const double ms = time_ms([&](int) {
+                hipLaunchKernelGGL((tridiag_stack_kernel<double, 32, 40, 8>), dim3(ti * dJ), dim3(64), 0, 0, a, d, s, r, o, dI, dJ, dK, ti);
+            }, 5, 1);
+            const double ms2 = time_ms([&](int) {
+                const unsigned t2 = (unsigned)cdiv(dI, 256);
+                hipLaunchKernelGGL((tridiag_kernel<double, 1, 8>), dim3(t2 * dJ), dim3(256), 0, 0, a, d, s, r, o, dI, dJ, dK, t2);
+            }, 5, 1);
+            char cfg[96];
+            snprintf(cfg, sizeof cfg, "delta %6zu KiB  stack<32,40,8>", dk_);
+            report("triplace", cfg, ms, (double)dI * dJ * dK, 56.0);
+            snprintf(cfg, sizeof cfg, "delta %6zu KiB  two-sweep<1,8>", dk_);
+            report("triplace", cfg, ms2, (double)dI * dJ * dK, 56.0);
+        }
+    hipFree(raw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -534,6 +649,9 @@ int main(int argc, char** argv) {
     }
     if (on("hdiff")) section_hdiff();
     if (on("tridiag")) section_tridiag();
+    if (!want.empty() && on("triplace")) section_triplace(0, want);
+    if (!want.empty() && on("tripipe")) section_tripipe();
+    if (!want.empty() && on("tripmc")) section_tripmc();
     if (!want.empty() && on("events")) section_events();
     return ok ? 0 : 1;
 }

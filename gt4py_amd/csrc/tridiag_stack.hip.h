@@ -173,4 +173,194 @@ tridiag_stack_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<T>
     }
 }
 
+// ---- software-pipelined form -----------------------------------------------------------------------
+// tridiag_stack_kernel issues the loads of a batch of U levels, waits, computes (two IEEE divides per level:
+// ~30 instructions x U), stores, and only then issues the next batch: with one wave per SIMD (the on-chip stack
+// leaves room for no more) nothing is in flight while it computes, and the solve ran at 79-87 GLUPS on some
+// boxes and 94-97 on others whatever the placement of the fields (profiles/r2_tridiag_placement_study.log).
+// Here the loads of batch n + 1 are in flight while batch n is computed, in both sweeps, across the boundaries
+// between the memory / LDS / register ranges, and the first loads of the backward sweep are issued before its
+// on-chip part.  Same arithmetic, same order: level 0 goes through the general formula with inf := 0 and
+// sup'[-1] = rhs'[-1] := 0, which is exact (d - 0*0 = d, r - 0*0 = r for every d, r including -0, inf, nan).
+template <typename T, int U>
+struct TridiagFwdBatch {
+    T a[U], d[U], s[U], r[U];
+};
+template <typename T, int U>
+struct TridiagBwdBatch {
+    T s[U], r[U];
+};
+
+template <typename T, int RL, int LL, int U>
+__global__ void __launch_bounds__(64)
+tridiag_pipe_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<T> rhs, View<T> out, int dI, int dJ,
+                    int dK, unsigned tiles_i) {
+    static_assert(RL % U == 0 && LL % U == 0 && RL >= U, "level ranges are processed in batches of U");
+    __shared__ T lds[LL > 0 ? LL * 2 * 64 : 1];
+    const unsigned bi = blockIdx.x % tiles_i;
+    const unsigned j = blockIdx.x / tiles_i;
+    const int lane = threadIdx.x;
+    const int i0 = (int)(bi * 64) + lane;
+    if (i0 >= dI) return;
+
+    const T* __restrict__ p_inf = inf.p + (int64_t)j * inf.sj + i0;
+    const T* __restrict__ p_diag = diag.p + (int64_t)j * diag.sj + i0;
+    T* __restrict__ p_sup = sup.p + (int64_t)j * sup.sj + i0;
+    T* __restrict__ p_rhs = rhs.p + (int64_t)j * rhs.sj + i0;
+    T* __restrict__ p_out = out.p + (int64_t)j * out.sj + i0;
+
+    const int A = dK - LL - RL;  // levels [0, A) live in memory only; A >= 1 (checked by the host)
+    T sp = T(0), rp = T(0);      // sup'[k-1], rhs'[k-1]
+    T S[RL], R[RL];              // the last RL levels; only ever indexed by compile-time constants
+
+    using FB = TridiagFwdBatch<T, U>;
+    using BB = TridiagBwdBatch<T, U>;
+    auto level = [&](T a, T d, T s, T r) {
+        const T den1 = d - (sp * a);
+        const T ns = s / den1;
+        const T num = r - (a * rp);
+        const T den2 = d - (sp * a);
+        const T nr = num / den2;
+        sp = ns;
+        rp = nr;
+    };
+    auto load = [&](FB& b, int k) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            b.a[u] = p_inf[(int64_t)(k + u) * inf.sk];
+            b.d[u] = p_diag[(int64_t)(k + u) * diag.sk];
+            b.s[u] = p_sup[(int64_t)(k + u) * sup.sk];
+            b.r[u] = p_rhs[(int64_t)(k + u) * rhs.sk];
+        }
+    };
+    auto forward_mem = [&](const FB& b, int k) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            level(b.a[u], b.d[u], b.s[u], b.r[u]);
+            p_sup[(int64_t)(k + u) * sup.sk] = sp;  // read again by the backward sweep: keep cacheable
+            p_rhs[(int64_t)(k + u) * rhs.sk] = rp;
+        }
+    };
+
+    // ---- FORWARD ----------------------------------------------------------------------------------
+    FB B[2];
+    const int head = A % U;  // levels [0, head) come first so that whole batches end exactly at A
+    {
+        FB h;
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < head) {  // wave-uniform
+                h.a[u] = u == 0 ? T(0) : p_inf[(int64_t)u * inf.sk];
+                h.d[u] = p_diag[(int64_t)u * diag.sk];
+                h.s[u] = p_sup[(int64_t)u * sup.sk];
+                h.r[u] = p_rhs[(int64_t)u * rhs.sk];
+            }
+        load(B[0], head);  // the first whole batch (of the memory range, or of the on-chip ranges when A < U)
+        if (head == 0) B[0].a[0] = T(0);
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < head) {
+                level(h.a[u], h.d[u], h.s[u], h.r[u]);
+                p_sup[(int64_t)u * sup.sk] = sp;
+                p_rhs[(int64_t)u * rhs.sk] = rp;
+            }
+    }
+    int k = head;
+    // invariant: B[0] holds (or is receiving) the batch that starts at level k
+    while (k + 2 * U <= A) {
+        load(B[1], k + U);
+        forward_mem(B[0], k);
+        load(B[0], k + 2 * U);  // may already be the first on-chip batch: same form, levels are contiguous
+        forward_mem(B[1], k + U);
+        k += 2 * U;
+    }
+    if (k + U <= A) {  // an odd number of memory batches
+        load(B[1], k + U);
+        forward_mem(B[0], k);
+        B[0] = B[1];
+        k += U;
+    }
+    // k == A: the LL + RL on-chip levels, fully unrolled, B[b & 1] is a compile-time choice
+    constexpr int NBC = (LL + RL) / U;
+#pragma unroll
+    for (int b = 0; b < NBC; ++b) {
+        if (b + 1 < NBC) load(B[(b + 1) & 1], A + (b + 1) * U);
+        const FB& c = B[b & 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = b * U + u;  // level A + l
+            level(c.a[u], c.d[u], c.s[u], c.r[u]);
+            __builtin_nontemporal_store(sp, p_sup + (int64_t)(A + l) * sup.sk);
+            __builtin_nontemporal_store(rp, p_rhs + (int64_t)(A + l) * rhs.sk);
+            if (l < LL) {
+                lds[(l * 2 + 0) * 64 + lane] = sp;
+                lds[(l * 2 + 1) * 64 + lane] = rp;
+            } else {
+                S[l - LL] = sp;
+                R[l - LL] = rp;
+            }
+        }
+    }
+
+    // ---- BACKWARD ---------------------------------------------------------------------------------
+    auto loadb = [&](BB& b, int kb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            b.s[u] = p_sup[(int64_t)(kb - u) * sup.sk];
+            b.r[u] = p_rhs[(int64_t)(kb - u) * rhs.sk];
+        }
+    };
+    T o;
+    auto backward_mem = [&](const BB& b, int kb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            o = b.r[u] - (b.s[u] * o);
+            __builtin_nontemporal_store(o, p_out + (int64_t)(kb - u) * out.sk);
+        }
+    };
+    BB C[2];
+    int kb = A - 1;
+    if (kb - U + 1 >= 0) loadb(C[0], kb);  // in flight during the on-chip part of the sweep
+    o = R[RL - 1];  // out[K-1] = rhs'[K-1]
+    __builtin_nontemporal_store(o, p_out + (int64_t)(dK - 1) * out.sk);
+#pragma unroll
+    for (int l = RL - 2; l >= 0; --l) {
+        o = R[l] - (S[l] * o);
+        __builtin_nontemporal_store(o, p_out + (int64_t)(A + LL + l) * out.sk);
+    }
+#pragma unroll 4
+    for (int l = LL - 1; l >= 0; --l) {
+        const T s = lds[(l * 2 + 0) * 64 + lane], r = lds[(l * 2 + 1) * 64 + lane];
+        o = r - (s * o);
+        __builtin_nontemporal_store(o, p_out + (int64_t)(A + l) * out.sk);
+    }
+    // invariant: C[0] holds the batch kb, kb - 1, ... whenever a whole batch is left
+    while (kb - 2 * U + 1 >= 0) {
+        loadb(C[1], kb - U);
+        backward_mem(C[0], kb);
+        if (kb - 3 * U + 1 >= 0) loadb(C[0], kb - 2 * U);
+        backward_mem(C[1], kb - U);
+        kb -= 2 * U;
+    }
+    if (kb - U + 1 >= 0) {
+        backward_mem(C[0], kb);
+        kb -= U;
+    }
+    {  // the `head` levels at the bottom, loaded together
+        BB t;
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u <= kb) {
+                t.s[u] = p_sup[(int64_t)(kb - u) * sup.sk];
+                t.r[u] = p_rhs[(int64_t)(kb - u) * rhs.sk];
+            }
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u <= kb) {
+                o = t.r[u] - (t.s[u] * o);
+                __builtin_nontemporal_store(o, p_out + (int64_t)(kb - u) * out.sk);
+            }
+    }
+}
+
 }  // namespace gt4mi

@@ -205,6 +205,17 @@ def parallel_k_dependency(a: F64, b: F64):
         b = a[0, 0, 1] - tmp
 
 
+def temporary_read_at_k_offset_in_later_loop(a: F64, out: F64):
+    """A temporary written in one PARALLEL loop and read at a K offset in a LATER one: legal in the reference
+    (gtir.py:243-293 only looks inside one VerticalLoop; K boundary 0 for both, gtir_k_boundary.py:39-70)."""
+    with computation(PARALLEL), interval(...):
+        tmp = a * 2.0
+    with computation(PARALLEL), interval(0, -1):
+        out = tmp[0, 0, 1] - tmp
+    with computation(PARALLEL), interval(-1, None):
+        out = tmp[0, 0, -1]
+
+
 def cross_column_recurrence(a: F64, b: F64, c: F64):
     """Sequential blocks whose columns depend on each other through a temporary read at horizontal offsets
     (legal in the reference: gtir.py:224-241 only forbids it for API fields): forward, then backward with a mask."""
@@ -356,6 +367,7 @@ ZOO = {
     "column_sum_then_gradient": (column_sum_then_gradient, {}, {}, {}),
     "backward_scan": (backward_scan, {}, {}, {}),
     "parallel_k_dependency": (parallel_k_dependency, {}, {}, {}),
+    "temporary_read_at_k_offset_in_later_loop": (temporary_read_at_k_offset_in_later_loop, {}, {}, {}),
     "lower_dimensional": (lower_dimensional, {}, {}, {}),
     "two_stage_written_input": (two_stage_written_input, {}, {}, {}),
     "variable_k_offsets": (variable_k_offsets, {}, {}, {}),

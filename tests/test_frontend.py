@@ -377,6 +377,58 @@ def suite_hdiff(u: Field[np.float64], diffusion: Field[np.float64], *, weight: n
         diffusion = u[0, 0, 0] - weight * (flux_i[0, 0, 0] - flux_i[-1, 0, 0] + flux_j[0, 0, 0] - flux_j[0, -1, 0])
 
 
+def test_temporary_k_offsets_across_and_inside_loops():
+    """The K-offset rules for temporaries are per vertical loop (gtir.py:243-293) and per declaring loop
+    (gtir_k_boundary.py:64-68), not stencil-wide."""
+
+    def later_loop(inp: Field[np.float64], out: Field[np.float64]):
+        with computation(PARALLEL), interval(...):
+            tmp = inp * 2.0
+        with computation(PARALLEL), interval(0, -1):
+            out = tmp[0, 0, 1]
+
+    st = parse(later_loop)  # accepted by the reference: the read is in another loop and stays inside the domain
+    assert analysis.compute_k_boundary(st)["tmp"] == (0, 0)
+
+    def same_parallel_loop(inp: Field[np.float64], out: Field[np.float64]):
+        with computation(PARALLEL), interval(0, -1):
+            tmp = inp * 2.0
+            out = tmp[0, 0, 1]
+
+    with pytest.raises(ValueError, match="Not allowed to write and read with k-offsets in PARALLEL loops: `tmp`"):
+        parse(same_parallel_loop)
+
+    def below_the_declaring_loop(inp: Field[np.float64], out: Field[np.float64]):
+        with computation(FORWARD), interval(...):
+            tmp = inp * 2.0
+            out = tmp[0, 0, -1]
+
+    with pytest.raises(TypeError, match="Invalid access with offset in k to temporary field tmp."):
+        analysis.compute_k_boundary(parse(below_the_declaring_loop))
+
+    def beyond_the_domain_from_a_later_loop(inp: Field[np.float64], out: Field[np.float64]):
+        with computation(PARALLEL), interval(...):
+            tmp = inp * 2.0
+        with computation(PARALLEL), interval(...):
+            out = tmp[0, 0, 1]
+
+    # not caught at build time by the reference; its numpy backend then fails on the slice (temporaries hold
+    # exactly _dK_ levels).  Rejected here, so that no kernel reads outside its scratch buffer.
+    with pytest.raises(TypeError, match="Invalid access with offset in k to temporary field tmp."):
+        analysis.compute_k_boundary(parse(beyond_the_domain_from_a_later_loop))
+
+    def in_bounds_inside_the_declaring_loop(inp: Field[np.float64], out: Field[np.float64]):
+        with computation(FORWARD):
+            with interval(0, 1):
+                tmp = inp
+                out = tmp
+            with interval(1, None):
+                tmp = inp * 2.0
+                out = tmp[0, 0, -1]
+
+    assert analysis.compute_k_boundary(parse(in_bounds_inside_the_declaring_loop))["tmp"] == (0, 0)
+
+
 def test_recognise_is_alpha_equivalence_not_text():
     opts = D.BuildOptions(name="x", module=__name__, backend_opts={})
     b = hip_backend.recognise(parse(user_laplacian), opts)

@@ -7,40 +7,93 @@ path (gt4py_amd.storage -> @gtscript.stencil(backend="hip:mi300") -> FrozenStenc
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one apply of the stencil over the whole 512^3 grid on synthetic input that is already
-resident in HBM.  With N > 1 the SAME 512^3 grid is split over the ranks along J (strong scaling);
-a step is then halo exchange (RCCL send/recv on a side stream) overlapped with the interior kernel,
-followed by the boundary-strip kernels.  Rank 0 prints ONE JSON line.
+resident in HBM.  With N > 1 the SAME 512^3 grid is split over the ranks (strong scaling); a step is
+then halo exchange (RCCL send/recv) + kernel(s), see DESIGN.md section 6.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line (see DESIGN.md "Measurement"):
-  roofline      HBM roofline of the dominant kernel (lap5_strip_kernel): algorithmic bytes
-                (16 B per lattice update) / mean launch duration measured with HIP events on the
-                launch stream, against the 8.0 TB/s nominal peak; `traffic` = HBM bytes per launch
-                from rocprofv3 PMC counters when a committed measurement exists, else null.
-  cpu_baseline  the oracle's C/OpenMP restatement of gt:cpu_ifirst semantics (kind "port") timed on
-                this host's cores on a bounded sample (N == 1 only).
+  roofline      HBM roofline of the dominant kernel: algorithmic bytes (16 B per lattice update) / launch
+                duration measured with HIP events on the launch stream (mean, median and minimum over the
+                timed launches), against the 8.0 TB/s nominal peak; `traffic` = HBM bytes per launch from the
+                committed rocprofv3 PMC measurement IF it was taken on the kernel sources of this tree
+                (profiles/hbm_traffic.json carries their hash), else null.
+  cpu_baseline  the oracle's C/OpenMP restatement of gt:cpu_ifirst semantics (kind "port") timed on this
+                host's cores, threads pinned, in a child process (N == 1 only).
+
+`--workload hdiff2048` runs BASELINE.json configs[4] instead (horizontal diffusion fp64, 512 x 1024 x 80
+per rank = 2048 x 2048 x 80 on the 4 x 2 grid of 8 ranks, ghost depth 2; weak scaling); the default and the
+headline metric stay the Laplacian.
+
+Every phase of an N > 1 run has a deadline: a rank that is stuck in a collective prints where and exits with
+status 3 (and the launcher takes the other ranks down) instead of hanging the node.
 """
 
 from __future__ import annotations
 
 import argparse
+import datetime
+import hashlib
 import json
 import os
 import pathlib
+import statistics
+import subprocess
 import sys
+import threading
 import time
+
+import numpy as np  # noqa: F401 - also resolves the annotations of the stencil definition below
 
 ROOT = pathlib.Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 BYTES_PER_LUP = 16.0  # fp64: one read + one write per lattice update (SURVEY.md section 8d)
 PEAK_GBS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md)
 GRID = (512, 512, 512)
+HDIFF_SHARE = (512, 1024, 80)  # per-rank share of BASELINE.json configs[4]
+HDIFF_GLOBAL = (2048, 2048, 80)
+KERNEL_SOURCES = {  # the files whose contents decide what a kernel does, per profiled workload
+    "lap5_f64_512": ("gt4py_amd/csrc/lap5.hip.h", "gt4py_amd/csrc/common.hip.h", "gt4py_amd/csrc/Makefile"),
+}
 
 
+def kernel_source_hash(workload: str) -> str:
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES[workload]:
+        h.update(rel.encode())
+        h.update((ROOT / rel).read_bytes())
+    return h.hexdigest()[:16]
+
+
+class Watchdog:
+    """Deadline per phase: when one expires the process says where it was and exits with status 3.
+
+    A rank that hangs inside a collective (communicator set-up, a send without its receive, a peer that died)
+    would otherwise sit there until the node's own limit; nothing is re-executed, the process just ends."""
+
+    def __init__(self, rank: int):
+        self.rank, self._timer = rank, None
+
+    def arm(self, seconds: float, what: str) -> None:
+        self.disarm()
+        self._timer = threading.Timer(seconds, self._fire, (seconds, what))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self) -> None:
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def _fire(self, seconds, what):
+        try:
+            os.write(2, f"bench.py: rank {self.rank} exceeded the {seconds:.0f} s deadline of phase '{what}'; "
+                        f"exiting with status 3\n".encode())
+        finally:
+            os._exit(3)
+
+
+# ---------------------------------------------------------------------------------------------------------
 def _lap_definition():
     from gt4py_amd.cartesian.backend import hip_templates
 
@@ -49,6 +102,9 @@ def _lap_definition():
 
 def _device_fields(shape, n_pairs, seed, origin=(1, 1, 0)):
     """`n_pairs` (inp, out) pairs in HBM with the hip:mi300 layout; inp ~ U[-1, 1), seeded on device."""
+    import numpy as np
+    import torch
+
     import gt4py_amd.storage as gt_storage
 
     pairs = []
@@ -62,19 +118,26 @@ def _device_fields(shape, n_pairs, seed, origin=(1, 1, 0)):
 
 
 def _time_launches(fn, steps):
-    """Mean duration (ms) of `steps` back-to-back launches, from HIP events on the launch stream."""
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
+    """Durations (ms) of `steps` back-to-back launches from HIP events on the launch stream, one event between
+    every two launches: {"mean", "median", "min", "max", "n"} (median and minimum)."""
+    import torch
+
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    events[0].record()
     for i in range(steps):
         fn(i)
-    stop.record()
-    stop.synchronize()
-    return start.elapsed_time(stop) / steps
+        events[i + 1].record()
+    events[-1].synchronize()
+    per = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
+    return {"mean": events[0].elapsed_time(events[-1]) / steps, "median": statistics.median(per), "min": min(per),
+            "max": max(per), "n": steps}
 
 
 def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30) -> float:
     """Streaming device copy (gt4mi_stream_copy, 16-byte lanes) of 1 GiB, read + write bytes per second:
     the achievable-HBM yardstick SURVEY.md section 8d asks to report from the same run."""
+    import torch
+
     from gt4py_amd import _lib
 
     lib = _lib.load()
@@ -89,13 +152,16 @@ def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30) -> float:
     for i in range(2):
         call(i)
     torch.cuda.synchronize()
-    ms = _time_launches(call, steps)
+    ms = _time_launches(call, steps)["median"]
     return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
-def other_kernels(steps: int = 10):
+def other_kernels(steps: int = 20):
     """The other kernels of the north star at their BASELINE.json sizes, through the same call path
     (storage -> stencil -> FrozenStencil), HIP-event timed.  Informational: `value` stays the Laplacian."""
+    import numpy as np
+    import torch
+
     import gt4py_amd.storage as gt_storage
     from gt4py_amd.cartesian import gtscript
     from gt4py_amd.cartesian.backend import hip_templates
@@ -112,20 +178,21 @@ def other_kernels(steps: int = 10):
     def run(name, obj, fields, origin, domain, bytes_per_lup, scalars=None, note=None):
         frozen = obj.freeze(origin=origin, domain=domain)
         call = lambda i: frozen(**fields, **(scalars or {}))  # noqa: E731
-        for i in range(2):
+        for i in range(3):
             call(i)
         torch.cuda.synchronize()
-        ms = _time_launches(call, steps)
+        t = _time_launches(call, steps)
+        ms = t["median"]
         lups = float(np.prod(domain))
         gbs = bytes_per_lup * lups / (ms * 1e-3) / 1e9
-        out[name] = {"domain": list(domain), "ms": round(ms, 4), "glups": round(lups / ms / 1e6, 1),
-                     "algorithmic_bytes_per_lup": bytes_per_lup, "achieved_gbs": round(gbs, 1),
-                     "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4)}
+        out[name] = {"domain": list(domain), "ms": round(ms, 4), "ms_min": round(t["min"], 4), "ms_mean": round(t["mean"], 4),
+                     "glups": round(lups / ms / 1e6, 1), "algorithmic_bytes_per_lup": bytes_per_lup,
+                     "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4)}
         if note:
             out[name]["note"] = note
 
     for tag, dt, dom in (("hdiff_limiter_f32_1024x1024x80", np.float32, (1024, 1024, 80)),
-                         ("hdiff_limiter_f64_512x1024x80", np.float64, (512, 1024, 80))):
+                         ("hdiff_limiter_f64_512x1024x80", np.float64, HDIFF_SHARE)):
         obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": dt},
                                device_sync=False)
         shape = (dom[0] + 4, dom[1] + 4, dom[2])
@@ -142,7 +209,9 @@ def other_kernels(steps: int = 10):
     run("tridiagonal_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 56.0,
         note="the backward sweep re-reads the part of sup', rhs' that does not fit on chip (72 of 160 levels stay in "
              "registers + LDS): 64.8 B/LUP moved; inputs are whatever the previous launch left in sup/rhs "
-             "(timing only, values are checked in tests/)")
+             "(timing only, values are checked in tests/); speed depends on the box by +-10 % (address translation, "
+             "profiles/r2_tridiag_translation_counters.txt)")
+    out["tridiagonal_f64_1024x1024x160"]["field_addresses_mod_4MiB"] = [int(f.ptr % (4 << 20)) for f in fields.values()]
     del fields
     torch.cuda.empty_cache()
 
@@ -218,11 +287,40 @@ def _vertical_advection_dycore(utens_stage: Field[np.float64], u_stage: Field[np
             utens_stage = dtr_stage * (datacol - u_pos[0, 0, 0])
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """Time the oracle's C/OpenMP port on the same 512^3 workload for a bounded number of applies.
+# ---- CPU baseline: a child process with pinned OpenMP threads -------------------------------------------
+def usable_cores() -> int:
+    """min(affinity mask, cgroup CPU quota): the cores this container may really keep busy."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        cores = os.cpu_count() or 1
+    try:  # CFS bandwidth quota of the container, e.g. "1600000 100000" = 16 cores
+        quota, period = pathlib.Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def host_model() -> str:
+    try:
+        for line in pathlib.Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_child(seconds_budget: float) -> None:
+    """Runs in its own process (no GPU, no torch: the OpenMP runtime starts with the binding set by the
+    parent): the oracle's C/OpenMP port on the full 512^3 grid in batches; prints one JSON object.
 
     The whole grid is used on purpose: a 512x512x64 slab (2 x 135 MB) stays resident in the 512 MB of
     L3 of a dual EPYC 9575F host and reports a cache bandwidth, not the workload's."""
+    import numpy as np
+
     from oracle import cpu_ifirst
 
     lib = None
@@ -233,158 +331,136 @@ def cpu_baseline(seconds_budget: float = 12.0):
         if cpu_ifirst.available():
             lib = cpu_ifirst.load()
     if lib is None:
-        return None
-    try:  # the cores this process may actually run on (cgroup / affinity), not the machine total
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:  # pragma: no cover
-        cores = os.cpu_count() or 1
-    try:  # CFS bandwidth quota of the container, e.g. "1600000 100000" = 16 cores
-        quota, period = pathlib.Path("/sys/fs/cgroup/cpu.max").read_text().split()
-        if quota != "max":
-            cores = max(1, min(cores, int(int(quota) / int(period))))
-    except Exception:
-        pass
+        print(json.dumps(None))
+        return
+    cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
     lib.oracle_set_threads(cores)
     dom = GRID
     rng = np.random.default_rng(1337)
     inp = np.asfortranarray(rng.uniform(-1, 1, (dom[0] + 2, dom[1] + 2, dom[2])))
     out = np.asfortranarray(np.zeros_like(inp))
-    cpu_ifirst.lap5_f64(inp, out, (1, 1, 0), (1, 1, 0), dom, lib=lib)  # warm-up / page touch
-    reps, t0 = 0, time.perf_counter()
-    while True:
+    for _ in range(3):  # page touch + warm-up
         cpu_ifirst.lap5_f64(inp, out, (1, 1, 0), (1, 1, 0), dom, lib=lib)
-        reps += 1
-        if time.perf_counter() - t0 > seconds_budget or reps >= 400:
+    batch, rates, t_start = 10, [], time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(batch):
+            cpu_ifirst.lap5_f64(inp, out, (1, 1, 0), (1, 1, 0), dom, lib=lib)
+        rates.append(dom[0] * dom[1] * dom[2] * batch / (time.perf_counter() - t0) / 1e9)
+        if time.perf_counter() - t_start > seconds_budget or len(rates) >= 60:
             break
-    dt = time.perf_counter() - t0
-    glups = dom[0] * dom[1] * dom[2] * reps / dt / 1e9
-    return {
-        "value": round(glups, 4),
+    dt = time.perf_counter() - t_start
+    med = statistics.median(rates)
+    print(json.dumps({
+        "value": round(med, 4),
         "unit": "GLUPS",
         "cores": lib.oracle_max_threads(),
         "kind": "port",
-        "sample": f"fp64 5-pt Laplacian on the full {dom[0]}x{dom[1]}x{dom[2]} grid, {reps} applies in "
-                  f"{dt:.1f} s, C/OpenMP restatement of gt:cpu_ifirst semantics (oracle/cpu_ifirst.c), I-contiguous",
-        "gb_per_s": round(glups * BYTES_PER_LUP, 2),
-    }
+        "sample": f"fp64 5-pt Laplacian on the full {dom[0]}x{dom[1]}x{dom[2]} grid, {len(rates)} batches of {batch} "
+                  f"applies in {dt:.1f} s (median batch), C/OpenMP restatement of gt:cpu_ifirst semantics "
+                  f"(oracle/cpu_ifirst.c), I-contiguous, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores)",
+        "gb_per_s": round(med * BYTES_PER_LUP, 2),
+        "batch_glups_min_max": [round(min(rates), 3), round(max(rates), 3)],
+        "spread_pct": round(100.0 * (max(rates) - min(rates)) / med, 1),
+        "host": host_model(),
+    }))
+
+
+def cpu_baseline(seconds_budget: float = 12.0):
+    cores = usable_cores()
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
+    proc = subprocess.run([sys.executable, str(pathlib.Path(__file__).resolve()), "--cpu-baseline-child", str(seconds_budget)],
+                          env=env, capture_output=True, text=True, timeout=seconds_budget * 6 + 120)
+    if proc.returncode != 0:
+        raise RuntimeError(f"cpu baseline child failed: {proc.stderr[-500:]}")
+    return json.loads(proc.stdout.strip().splitlines()[-1])
 
 
 def _committed_traffic(workload: str):
+    """HBM bytes per launch from the committed PMC measurement -- only when it was taken on these kernel sources."""
     f = ROOT / "profiles" / "hbm_traffic.json"
-    if f.exists():
-        try:
-            return json.loads(f.read_text()).get(workload)
-        except Exception:
-            return None
-    return None
+    try:
+        entry = json.loads(f.read_text()).get(workload)
+    except Exception:
+        return None, "no committed measurement"
+    if not isinstance(entry, dict):
+        return None, "committed measurement carries no kernel-source hash"
+    if entry.get("kernel_source_sha") != kernel_source_hash(workload):
+        return None, (f"committed measurement was taken on other kernel sources ({entry.get('kernel_source_sha')} at "
+                      f"{entry.get('git_sha')}, tree has {kernel_source_hash(workload)}): re-run scripts/profile_bench.sh")
+    return entry.get("bytes_per_launch"), f"rocprofv3 PMC, {entry.get('source')}, git {entry.get('git_sha')}"
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-kernels", action="store_true",
-                    help="skip the informational hdiff / tridiagonal lines (N=1 only)")
-    ap.add_argument("--dist-selfloop", action="store_true",
-                    help="1-GPU rehearsal of the N>1 step: periodic-in-J domain whose halo messages go to the "
-                         "rank itself through RCCL (not the headline metric)")
-    ap.add_argument("--selfloop-ranks", type=int, default=1,
-                    help="with --dist-selfloop: shrink J to 512/N, the per-rank share of an N-GPU run")
-    args = ap.parse_args()
+# ---- N > 1: the Laplacian on a decomposed 512^3 grid ----------------------------------------------------
+def _setup_distributed_laplacian(args, ctx):
+    """Returns (step, kernel_step, local_domain, config, extras) for the decomposed headline workload."""
+    import numpy as np
+    import torch
 
-    # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on
-    # stdout, so everything else is routed to stderr until the final print.
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if distributed else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; running on {n_gpus} GPU(s)", file=sys.stderr)
-
-    from gt4py_amd import _lib
     from gt4py_amd.cartesian import gtscript
     from gt4py_amd.distributed import (Decomposition, HaloExchanger, NativeComm, NativeHaloExchanger,
-                                       choose_process_grid, overlapped_apply)
+                                       choose_process_grid, overlapped_apply, process_grid_candidates)
 
-    decomposed = distributed or args.dist_selfloop
+    world, rank, local_rank, distributed, dog = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["distributed"], ctx["dog"]
+    dist = ctx.get("dist")
+    selfloop = args.dist_selfloop and world == 1
+    total = (GRID[0], GRID[1] // max(args.selfloop_ranks, 1), GRID[2]) if selfloop else GRID
+    lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64}, device_sync=False)
+    transport = os.environ.get("GT4MI_BENCH_COMM", "native")
+    mode = os.environ.get("GT4MI_BENCH_MODE", "timestep")
 
-    lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64},
-                           device_sync=False)
-    origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}
+    def agree(ok: int) -> int:  # every rank learns whether ALL ranks succeeded
+        if distributed:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        return ok
 
-    if not decomposed:
-        shape = (GRID[0] + 2, GRID[1] + 2, GRID[2])
-        pairs = _device_fields(shape, n_pairs=2, seed=1337)  # rotate pairs: nothing survives in MALL/L2
-        frozen = lap.freeze(origin=origin, domain=GRID)
+    comm = None
+    if transport == "native":
+        # RCCL communicator owned by libgt4py_amd.  Creating it is collective; should it fail on any
+        # rank, every rank falls back to the torch.distributed transport together.
+        dog.arm(180, "native RCCL communicator (ncclCommInitRank)")
+        ok = 1
+        try:
+            comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
+        except Exception as ex:
+            ok = 0
+            print(f"rank {rank}: native RCCL communicator failed ({ex!r})", file=sys.stderr)
+        if not agree(ok):
+            transport, comm = "torch", None
+            print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
 
-        def step(i):
-            inp, out = pairs[i % len(pairs)]
-            frozen(inp=inp, out=out)
+    def grid_of(name):
+        pi, pj = name.split("x")
+        return int(pi), int(pj)
 
-        local_domain = GRID
-        kernel_step = step
-        config = {"workload": "fp64 5-point Laplacian 512x512x512 (examples/lap_cartesian_vs_next.ipynb cell 7), "
-                              "origin (1,1,0), hip:mi300 storage layout", "grid": list(GRID), "decomposition": "1x1",
-                  "call_path": "FrozenStencil"}
-    else:
-        selfloop = args.dist_selfloop and world == 1
-        grid = (1, 1) if selfloop else choose_process_grid(world, GRID)
-        total = (GRID[0], GRID[1] // max(args.selfloop_ranks, 1), GRID[2]) if selfloop else GRID
-        transport = os.environ.get("GT4MI_BENCH_COMM", "native")
-        mode = os.environ.get("GT4MI_BENCH_MODE", "timestep")
-        comm = None
-        if transport == "native":
-            # RCCL communicator owned by libgt4py_amd.  Creating it is collective; should it fail on any
-            # rank, every rank falls back to the torch.distributed transport together.
-            ok = 1
-            try:
-                comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
-            except Exception as ex:
-                ok = 0
-                print(f"rank {rank}: native RCCL communicator failed ({ex!r})", file=sys.stderr)
-            if distributed:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if not ok:
-                transport, comm = "torch", None
-                print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
-        # ghost depth = steps served by one exchange (communication-avoiding time stepping) and whether that
-        # exchange runs next to the last step's interior kernel or after a full-domain kernel.  Which
-        # combination wins depends on how long the links take: in the 1-GPU rehearsal (on-device self-copy)
-        # "depth 4, not overlapped" is fastest (58.9 us per 512x64x512 step vs 70.4 for depth 2 overlapped,
-        # profiles/r1_dist_selfloop_seq_vs_overlap.log), on slow links overlap and a smaller depth should win.
-        # So unless pinned through the environment, a short calibration BEFORE the warm-up picks it, with all
-        # ranks agreeing on the slowest rank's timings.
-        calibration = None
-        overlap = os.environ.get("GT4MI_BENCH_OVERLAP", "1") != "0"
-        halo = 1
-        if transport == "native" and mode == "timestep":
-            pinned = "GT4MI_BENCH_HALO" in os.environ or "GT4MI_BENCH_OVERLAP" in os.environ
-            halo = max(1, int(os.environ.get("GT4MI_BENCH_HALO", "2")))
-            if not pinned:
-                def calibrate():
-                    calibration = {}
-                    for cand_halo in (1, 2, 4):
-                        if (grid[1] > 1 and total[1] // grid[1] < 2 * cand_halo) or (grid[0] > 1 and total[0] // grid[0] < 2 * cand_halo):
-                            continue
-                        cdec = Decomposition(total, grid, rank, halo=cand_halo,
-                                             periodic=(False, True) if selfloop else (False, False))
+    # What is measured before the warm-up (all ranks agreeing on the slowest rank's time), unless pinned through
+    # the environment: the process grid (xGMI is point-to-point, so the largest message of an exchange is what
+    # costs: 1x8 sends 2.1 MB faces, 4x2 and 2x4 at most 1.05 MB), the ghost depth = steps served by one exchange
+    # (communication-avoiding time stepping) and whether that exchange runs next to the last step's interior
+    # kernel or after a full-domain kernel.  In the 1-GPU rehearsal (on-device self-copy) "depth 4, not
+    # overlapped" is fastest (profiles/r1_dist_selfloop_seq_vs_overlap.log); on real links it is not known.
+    periodic = (False, True) if selfloop else (False, False)
+    calibration = None
+    grid = (1, 1) if selfloop else choose_process_grid(world, total)
+    if "GT4MI_BENCH_GRID" in os.environ:
+        grid = grid_of(os.environ["GT4MI_BENCH_GRID"])
+    overlap = os.environ.get("GT4MI_BENCH_OVERLAP", "1") != "0"
+    halo = 1
+    if transport == "native" and mode == "timestep":
+        pinned = any(k in os.environ for k in ("GT4MI_BENCH_HALO", "GT4MI_BENCH_OVERLAP"))
+        halo = max(1, int(os.environ.get("GT4MI_BENCH_HALO", "2")))
+        if not pinned:
+            def calibrate():
+                table = {}
+                for cand_halo in (1, 2, 4):
+                    grids = [(1, 1)] if selfloop else ([grid] if "GT4MI_BENCH_GRID" in os.environ else
+                                                       process_grid_candidates(world, total, cand_halo))
+                    if selfloop and total[1] < 2 * cand_halo:
+                        continue
+                    for cand_grid in grids:
+                        cdec = Decomposition(total, cand_grid, rank, halo=cand_halo, periodic=periodic)
                         cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
                         for cand_overlap in (True, False):
                             ca, cb = cpairs[0][0], cpairs[1][0]
@@ -403,83 +479,260 @@ def main() -> None:
                             dt = torch.tensor([(time.perf_counter() - t0) / 24], dtype=torch.float64, device="cuda")
                             if distributed:
                                 dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                            calibration[f"halo{cand_halo}_{'overlap' if cand_overlap else 'sequential'}"] = round(float(dt.item()) * 1e3, 5)
+                            key = f"{cand_grid[0]}x{cand_grid[1]}_halo{cand_halo}_{'overlap' if cand_overlap else 'sequential'}"
+                            table[key] = round(float(dt.item()) * 1e3, 5)
                             cex.close()
                         del cpairs
-                    torch.cuda.empty_cache()
-                    best = min(calibration, key=calibration.get)
-                    return calibration, int(best.split("_")[0][4:]), best.endswith("overlap")
+                torch.cuda.empty_cache()
+                best = min(table, key=table.get)
+                g, h, o = best.split("_")
+                return table, grid_of(g), int(h[4:]), o == "overlap"
 
-                # A transport that creates its communicator but cannot move data must not take the run down:
-                # every rank reports whether its calibration went through, and all fall back together.
-                ok = 1
-                try:
-                    calibration, halo, overlap = calibrate()
-                except Exception as ex:
-                    ok, calibration = 0, None
-                    print(f"rank {rank}: native RCCL halo exchange failed during calibration ({ex!r})", file=sys.stderr)
-                if distributed:
-                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                    ok = int(flag.item())
-                if not ok:
-                    transport, comm, halo, overlap = "torch", None, 1, True
-                    print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
-        dec = Decomposition(total, grid, rank, halo=halo, periodic=(False, True) if selfloop else (False, False))
-        origin = {"inp": dec.origin, "out": dec.origin}
-        pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank, origin=dec.origin)
-        local_domain = dec.local_domain
-        frozen = lap.freeze(origin=origin, domain=local_domain)
-        if transport == "native":
-            # whole step (pack, RCCL send/recv, unpack, interior, strips, 2 streams) = one C call
-            exchangers = [NativeHaloExchanger(dec, np.float64, comm) for _ in pairs]
-            if mode == "timestep":
-                # time stepping u <- lap(u) between two buffers.  Ghost regions are `halo` deep and one
-                # exchange serves `halo` steps (the steps in between grow their domain into the ghost
-                # region instead of communicating); the exchange of the freshly written field travels
-                # next to that step's interior kernel and is joined `halo` steps later.
-                # The amplitude starts at 1e-150 so that ~8x growth per step stays finite for 600 steps.
-                a, b = pairs[0][0], pairs[1][0]
-                a.tensor.mul_(1e-150)
-                stepper = exchangers[0].make_time_stepper_lap5(a, b, origin["inp"], overlap=overlap)
-
-                def step(i):
-                    stepper()
-            else:  # independent applies on fixed inputs: exchange the input, then apply
-                steps_bound = [ex.make_dist_lap5(inp, out, origin["inp"], origin["out"]) for ex, (inp, out) in
-                               zip(exchangers, pairs)]
-
-                def step(i):
-                    steps_bound[i % len(pairs)]()
-        else:  # torch.distributed point-to-point ops driven from Python
-            exchangers = [HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank)) for _ in pairs]
+            # A transport that creates its communicator but cannot move data must not take the run down:
+            # every rank reports whether its calibration went through, and all fall back together.
+            dog.arm(420, "calibration of process grid x ghost depth x overlap")
+            ok = 1
+            try:
+                calibration, grid, halo, overlap = calibrate()
+            except Exception as ex:
+                ok, calibration = 0, None
+                print(f"rank {rank}: native RCCL halo exchange failed during calibration ({ex!r})", file=sys.stderr)
+            if not agree(ok):
+                transport, comm, halo, overlap = "torch", None, 1, True
+                grid = (1, 1) if selfloop else choose_process_grid(world, total)
+                print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
+    dog.arm(180, "set-up of the decomposed fields and exchangers")
+    dec = Decomposition(total, grid, rank, halo=halo, periodic=periodic)
+    origin = {"inp": dec.origin, "out": dec.origin}
+    pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank, origin=dec.origin)
+    local_domain = dec.local_domain
+    frozen = lap.freeze(origin=origin, domain=local_domain)
+    if transport == "native":
+        # whole step (pack, RCCL send/recv, unpack, interior, strips, 2 streams) = one C call
+        exchangers = [NativeHaloExchanger(dec, np.float64, comm) for _ in pairs]
+        if mode == "timestep":
+            # time stepping u <- lap(u) between two buffers.  Ghost regions are `halo` deep and one
+            # exchange serves `halo` steps (the steps in between grow their domain into the ghost
+            # region instead of communicating); the exchange of the freshly written field travels
+            # next to that step's interior kernel and is joined `halo` steps later.
+            # The amplitude starts at 1e-150 so that ~8x growth per step stays finite for 600 steps.
+            a, b = pairs[0][0], pairs[1][0]
+            a.tensor.mul_(1e-150)
+            stepper = exchangers[0].make_time_stepper_lap5(a, b, origin["inp"], overlap=overlap)
 
             def step(i):
-                inp, out = pairs[i % len(pairs)]
-                overlapped_apply(lap, dec, origin, {"inp": inp, "out": out}, {"inp": exchangers[i % len(pairs)]})
+                stepper()
+        else:  # independent applies on fixed inputs: exchange the input, then apply
+            steps_bound = [ex.make_dist_lap5(inp, out, origin["inp"], origin["out"]) for ex, (inp, out) in
+                           zip(exchangers, pairs)]
 
-        def kernel_step(i):  # the local kernel alone, for the per-GPU roofline figure
+            def step(i):
+                steps_bound[i % len(pairs)]()
+    else:  # torch.distributed point-to-point ops driven from Python
+        exchangers = [HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank)) for _ in pairs]
+
+        def step(i):
+            inp, out = pairs[i % len(pairs)]
+            overlapped_apply(lap, dec, origin, {"inp": inp, "out": out}, {"inp": exchangers[i % len(pairs)]})
+
+    def kernel_step(i):  # the local kernel alone, for the per-GPU roofline figure
+        inp, out = pairs[i % len(pairs)]
+        frozen(inp=inp, out=out)
+
+    config = {"workload": "fp64 5-point Laplacian 512x512x512 split over the ranks (strong scaling); "
+                          + ("time stepping u <- lap(u), ghost regions %d deep: one RCCL send/recv exchange per %d "
+                             "steps" % (halo, halo) if mode == "timestep"
+                             and transport == "native" else "independent applies, ghost cells exchanged every step"),
+              "grid": list(total), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(local_domain),
+              "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange,
+              "transport": transport, "mode": mode, "selfloop": bool(selfloop),
+              "exchange_overlapped_with_interior": bool(overlap) if mode == "timestep" and transport == "native" else None,
+              "calibration_ms_per_step": calibration}
+    extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen)}
+    return step, kernel_step, local_domain, config, extras
+
+
+# ---- BASELINE.json configs[4]: horizontal diffusion, 512 x 1024 x 80 per rank, ghost depth 2 --------------
+def _setup_hdiff2048(args, ctx):
+    import numpy as np
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.distributed import (Decomposition, HaloExchanger, NativeComm, NativeHaloExchanger, TunedApply,
+                                       choose_process_grid)
+
+    world, rank, local_rank, distributed, dog = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["distributed"], ctx["dog"]
+    dist = ctx.get("dist")
+    selfloop = args.dist_selfloop and world == 1
+    halo = 2
+    grid = choose_process_grid(world, HDIFF_GLOBAL, halo)  # 8 ranks -> 4 x 2
+    if "GT4MI_BENCH_GRID" in os.environ:
+        pi, pj = os.environ["GT4MI_BENCH_GRID"].split("x")
+        grid = (int(pi), int(pj))
+    total = (HDIFF_SHARE[0] * grid[0], HDIFF_SHARE[1] * grid[1], HDIFF_SHARE[2])  # weak scaling: fixed share per rank
+    periodic = (True, True) if selfloop else (False, False)
+    dec = Decomposition(total, grid, rank, halo=halo, periodic=periodic)
+    hd = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64},
+                          device_sync=False)
+    gen = torch.Generator(device="cuda").manual_seed(4242 + rank)
+
+    def field(lo, hi):
+        f = gt_storage.empty(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin)
+        f.tensor.copy_(torch.rand(dec.local_shape, dtype=torch.float64, device="cuda", generator=gen) * (hi - lo) + lo)
+        return f
+
+    fields = {"in_field": field(0.0, 10.0), "coeff": field(0.0, 0.05), "out_field": field(-1.0, 1.0)}
+    origin = {k: dec.origin for k in fields}
+    frozen = hd.freeze(origin=origin, domain=dec.local_domain)
+    decomposed = distributed or selfloop
+    transport, comm, exchangers, tuned = "none", None, [], None
+    if decomposed:
+        transport = os.environ.get("GT4MI_BENCH_COMM", "native")
+        if transport == "native":
+            dog.arm(180, "native RCCL communicator (ncclCommInitRank)")
+            ok = 1
+            try:
+                comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
+                ex = NativeHaloExchanger(dec, np.float64, comm)
+            except Exception as exn:
+                ok = 0
+                print(f"rank {rank}: native RCCL set-up failed ({exn!r})", file=sys.stderr)
+            if distributed:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                transport, comm = "torch", None
+                print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
+        if transport != "native":
+            ex = HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank))
+        exchangers = [ex]
+        tuned = TunedApply(hd, dec, origin, {"in_field": ex})
+        if "GT4MI_BENCH_OVERLAP" in os.environ:
+            tuned.choice = "overlapped" if os.environ["GT4MI_BENCH_OVERLAP"] != "0" else "sequential"
+        else:
+            dog.arm(300, "calibration overlapped vs sequential apply")
+            tuned.calibrate(fields, iters=12)  # on a clone of out_field; all ranks adopt the slowest rank's verdict
+
+        def step(i):
+            tuned(fields)
+    else:
+        def step(i):
+            frozen(**fields)
+
+    def kernel_step(i):
+        frozen(**fields)
+
+    config = {"workload": "BASELINE.json configs[4]: fp64 horizontal diffusion (lap-of-lap + flux limiter), "
+                          f"{HDIFF_SHARE[0]}x{HDIFF_SHARE[1]}x{HDIFF_SHARE[2]} per rank (weak scaling; 8 ranks = 2048x2048x80 on the "
+                          "4x2 grid), ghost depth 2, in_field's ghost cells exchanged every apply",
+              "grid": list(total), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(dec.local_domain),
+              "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange if exchangers else 0,
+              "transport": transport, "selfloop": bool(selfloop),
+              "apply_form": tuned.choice if tuned is not None else "single launch",
+              "calibration_ms_per_step": {k: round(v, 5) for k, v in tuned.timings_ms.items()} if tuned is not None else None}
+    extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen, tuned)}
+    return step, kernel_step, dec.local_domain, config, extras
+
+
+def main() -> None:
+    if len(sys.argv) >= 2 and sys.argv[1] == "--cpu-baseline-child":
+        cpu_baseline_child(float(sys.argv[2]) if len(sys.argv) > 2 else 12.0)
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=("lap512", "hdiff2048"), default="lap512",
+                    help="lap512 (default, the headline metric) or hdiff2048 = BASELINE.json configs[4] (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-kernels", action="store_true",
+                    help="skip the informational hdiff / tridiagonal lines (N=1 only)")
+    ap.add_argument("--dist-selfloop", action="store_true",
+                    help="1-GPU rehearsal of the N>1 step: periodic domain whose halo messages go to the "
+                         "rank itself through RCCL (not the headline metric)")
+    ap.add_argument("--selfloop-ranks", type=int, default=1,
+                    help="with --dist-selfloop and lap512: shrink J to 512/N, the per-rank share of an N-GPU run")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on
+    # stdout, so everything else is routed to stderr until the final print.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dog = Watchdog(rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "distributed": distributed, "dog": dog}
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dog.arm(300, "torch.distributed rendezvous (init_process_group)")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
+        ctx["dist"] = dist
+        dog.arm(180, "first collective (barrier)")
+        dist.barrier()
+    n_gpus = world if distributed else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; running on {n_gpus} GPU(s)", file=sys.stderr)
+
+    from gt4py_amd import _lib
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.distributed import NativeHaloExchanger
+
+    decomposed = distributed or args.dist_selfloop
+    extras = {"exchangers": []}
+    if args.workload == "hdiff2048":
+        step, kernel_step, local_domain, config, extras = _setup_hdiff2048(args, ctx)
+        bytes_per_lup, kernel_name = 24.0, "hdiff_jmarch_kernel<double,...>"
+        metric = "GLUPS (lattice updates/s) fp64 horizontal diffusion 2048x2048x80 on the 4x2 grid (BASELINE.json configs[4])"
+        scaling, total_lups = "weak", extras["total_lups"]
+    elif not decomposed:
+        lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64},
+                               device_sync=False)
+        origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}
+        shape = (GRID[0] + 2, GRID[1] + 2, GRID[2])
+        pairs = _device_fields(shape, n_pairs=2, seed=1337)  # rotate pairs: nothing survives in MALL/L2
+        frozen = lap.freeze(origin=origin, domain=GRID)
+
+        def step(i):
             inp, out = pairs[i % len(pairs)]
             frozen(inp=inp, out=out)
 
-        config = {"workload": "fp64 5-point Laplacian 512x512x512 split over ranks along J (strong scaling); "
-                              + ("time stepping u <- lap(u), ghost regions %d deep: one RCCL send/recv exchange per %d "
-                                 "steps, overlapped with the interior kernel" % (halo, halo) if mode == "timestep"
-                                 and transport == "native" else "independent applies, ghost cells exchanged every step"),
-                  "grid": list(GRID), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(local_domain),
-                  "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange,
-                  "transport": transport, "mode": mode, "selfloop": bool(selfloop),
-                  "exchange_overlapped_with_interior": bool(overlap) if mode == "timestep" and transport == "native" else None,
-                  "calibration_ms_per_step": calibration}
+        local_domain = GRID
+        kernel_step = step
+        config = {"workload": "fp64 5-point Laplacian 512x512x512 (examples/lap_cartesian_vs_next.ipynb cell 7), "
+                              "origin (1,1,0), hip:mi300 storage layout", "grid": list(GRID), "decomposition": "1x1",
+                  "call_path": "FrozenStencil"}
+        bytes_per_lup, kernel_name = BYTES_PER_LUP, "lap5_strip_kernel<double,double,0,2,8,*>"
+        metric, scaling, total_lups = "GLUPS (lattice updates/s) fp64 5-pt Laplacian 512^3", "strong", float(np.prod(GRID))
+    else:
+        step, kernel_step, local_domain, config, extras = _setup_distributed_laplacian(args, ctx)
+        bytes_per_lup, kernel_name = BYTES_PER_LUP, "lap5_strip_kernel<double,double,0,2,8,*>"
+        metric, scaling, total_lups = "GLUPS (lattice updates/s) fp64 5-pt Laplacian 512^3", "strong", extras["total_lups"]
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
+    dog.arm(120 + 2.0 * args.warmup, "warm-up steps")
     for i in range(args.warmup):
         step(i)
     barrier()
+    dog.arm(120 + 2.0 * args.steps, "timed steps")
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -490,21 +743,28 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: mean launch duration from HIP events on the launch stream
+    # dominant kernel: launch durations from HIP events on the launch stream (>= 50 launches when --steps allows)
+    dog.arm(300, "kernel timing")
     torch.cuda.synchronize()
-    kernel_ms = _time_launches(kernel_step, args.steps)
+    for i in range(3):
+        kernel_step(i)
+    torch.cuda.synchronize()
+    kt = _time_launches(kernel_step, max(args.steps, 10))
+    kernel_ms = kt["median"]
     local_lups = float(np.prod(local_domain))
-    achieved = BYTES_PER_LUP * local_lups / (kernel_ms * 1e-3) / 1e9
+    achieved = bytes_per_lup * local_lups / (kernel_ms * 1e-3) / 1e9
     ms_per_step = elapsed / args.steps * 1e3
-    total_lups = float(np.prod(dec.global_domain)) if decomposed else float(np.prod(GRID))
     glups = total_lups * args.steps / elapsed / 1e9
 
-    if decomposed and isinstance(exchangers[0], NativeHaloExchanger):
+    exchangers = extras.get("exchangers") or []
+    if exchangers and isinstance(exchangers[0], NativeHaloExchanger):
         config["side_stream_concurrent"] = exchangers[0].concurrent
     if rank == 0:
-        traffic =_committed_traffic("lap5_f64_512") if not decomposed else None
+        dog.arm(900, "informational kernels and CPU baseline")
+        headline = args.workload == "lap512" and not decomposed
+        traffic, traffic_source = _committed_traffic("lap5_f64_512") if headline else (None, "not the profiled workload")
         line = {
-            "metric": "GLUPS (lattice updates/s) fp64 5-pt Laplacian 512^3",
+            "metric": metric,
             "value": round(glups, 2),
             "unit": "GLUPS",
             "n_gpus": n_gpus,
@@ -512,34 +772,36 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": config,
-            "pct_hbm_roofline": round(100.0 * glups * BYTES_PER_LUP / (PEAK_GBS * n_gpus), 2),
+            "pct_hbm_roofline": round(100.0 * glups * bytes_per_lup / (PEAK_GBS * n_gpus), 2),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "lap5_strip_kernel<double,double,0,2,8,*>",
+                "kernel": kernel_name,
                 "achieved": round(achieved, 1),
                 "peak": PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel_ms": round(kernel_ms, 5),
-                "algorithmic_bytes_per_launch": BYTES_PER_LUP * local_lups,
+                "kernel_ms_stats": {k: (round(v, 5) if k != "n" else v) for k, v in kt.items()},
+                "algorithmic_bytes_per_launch": bytes_per_lup * local_lups,
                 # what a plain streaming copy reaches on this device in this run (not the bar, the context)
                 "measured_copy_gbs": round(copy_ceiling_gbs(), 1) if not decomposed else None,
             },
             "device": _lib.device_info(),
         }
-        if not decomposed and not args.no_other_kernels:
+        if headline and not args.no_other_kernels:
             try:
                 line["other_kernels"] = other_kernels()
             except Exception as ex:
                 line["other_kernels"] = None
                 print(f"other_kernels failed: {ex!r}", file=sys.stderr)
-        if not decomposed and not args.no_cpu_baseline:
+        if headline and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as ex:  # the baseline must never take the GPU number down with it
@@ -550,7 +812,10 @@ def main() -> None:
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)  # anything native code prints while tearing down goes to stderr again
     if distributed:
+        dog.arm(120, "final barrier and process-group teardown")
+        dist.barrier()
         dist.destroy_process_group()
+    dog.disarm()
 
 
 if __name__ == "__main__":

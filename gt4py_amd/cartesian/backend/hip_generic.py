@@ -18,6 +18,7 @@ import numpy as np
 from . import hip_codegen
 from ..stencil_object import StencilObject
 from ... import _lib
+from ...storage.allocators import PLACEMENT_MIN_BYTES, PLACEMENT_PERIOD, PLACEMENT_STEP
 
 _U3 = ctypes.c_uint32 * 3
 
@@ -212,18 +213,21 @@ class HipGenericStencilObject(StencilObject):
                     oi = -(-(-ilo) // 4) * 4  # the domain's first column on a 16-byte boundary
                     ni = -(-(dI + ihi + oi) // 32) * 32  # rows padded like the storage preset
                     nj = dJ + jhi - jlo
-                    # equally shaped temporaries must not sit a multiple of 2 MiB apart (HBM channel aliasing,
-                    # see storage/allocators.py:_channel_skew): stagger them by 1.5 MiB steps
-                    total += (len(layout) % 8) * (3 << 19)
-                    layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
+                    # equally shaped temporaries must not sit at the same address modulo 4 MiB (see
+                    # storage/allocators.py:_placement_shift): temporary n starts at n * 1 MiB (mod 4 MiB) of a
+                    # buffer whose base is brought to a 4 MiB boundary below
                     n_elem = int(np.prod(temp_dims.get(name, ()) or (1,)))  # data dimensions: outermost
-                    total += -(-(ni * nj * temp_levels[name] * n_elem * dt.itemsize) // 256) * 256
-                buf = torch.empty(total, dtype=torch.uint8, device="cuda")
+                    nbytes = -(-(ni * nj * temp_levels[name] * n_elem * dt.itemsize) // 256) * 256
+                    if nbytes >= PLACEMENT_MIN_BYTES:
+                        total = -(-total // PLACEMENT_PERIOD) * PLACEMENT_PERIOD + (len(layout) % 4) * PLACEMENT_STEP
+                    layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
+                    total += nbytes
+                buf = torch.empty(total + PLACEMENT_PERIOD, dtype=torch.uint8, device="cuda")
                 cls._gt_scratch_.clear()  # one domain at a time: scratch can be gigabytes ...
                 cls._gt_launch_cache_.clear()  # ... and cached launch plans keep theirs alive
                 entry = cls._gt_scratch_[key] = (buf, layout)
             buf, layout = entry
-            base = buf.data_ptr()
+            base = -(-buf.data_ptr() // PLACEMENT_PERIOD) * PLACEMENT_PERIOD
             for name, (off, ni, nj, isz, oi, oj) in layout.items():
                 c = hip_codegen._c_ident(name)
                 setattr(args, c, base + off + (oi + oj * ni) * isz)

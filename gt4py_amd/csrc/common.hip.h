@@ -77,6 +77,39 @@ inline int make_view(const char* name, const gt4mi_field* f, const int64_t domai
     return GT4MI_OK;
 }
 
+// ---- aliasing ---------------------------------------------------------------------------------
+// The reference's numpy backend evaluates a statement's right-hand side completely before it assigns
+// (/root/reference/src/gt4py/cartesian/gtc/numpy/npir_codegen.py:205-210), so a call whose output array is also
+// an input is well defined there.  The kernels here read and write concurrently and promise the compiler
+// `__restrict__` pointers; every entry point therefore compares the byte ranges its fields touch and either
+// routes an alias whose result is the same in any evaluation order to an order-preserving kernel, or refuses
+// the call (GT4MI_ERR_UNSUPPORTED) -- never a silently different answer.
+struct ByteSpan {
+    uintptr_t lo, hi;  // [lo, hi): smallest range that holds every element the kernel touches
+};
+
+template <typename V>
+inline ByteSpan span_of(const V& v, const int64_t domain[3], const int halo_lo[3], const int halo_hi[3]) {
+    const int64_t strides[3] = {v.si, v.sj, v.sk};
+    int64_t lo = 0, hi = 0;  // element offsets relative to v.p
+    for (int a = 0; a < 3; ++a) {
+        const int64_t first = -(int64_t)halo_lo[a], last = domain[a] - 1 + halo_hi[a];
+        const int64_t x = first * strides[a], y = last * strides[a];
+        lo += x < y ? x : y;
+        hi += x < y ? y : x;
+    }
+    const uintptr_t base = reinterpret_cast<uintptr_t>(v.p);
+    return ByteSpan{base + (uintptr_t)(lo * (int64_t)sizeof(*v.p)), base + (uintptr_t)((hi + 1) * (int64_t)sizeof(*v.p))};
+}
+
+inline bool spans_overlap(const ByteSpan& a, const ByteSpan& b) { return a.lo < b.hi && b.lo < a.hi; }
+
+// the same elements, one to one (same origin element, same strides)
+template <typename V1, typename V2>
+inline bool same_view(const V1& a, const V2& b) {
+    return (const void*)a.p == (const void*)b.p && a.si == b.si && a.sj == b.sj && a.sk == b.sk;
+}
+
 inline int check_domain(const int64_t domain[3]) {
     if (domain == nullptr) return fail(GT4MI_ERR_INVALID_ARGUMENT, "domain is null");
     for (int a = 0; a < 3; ++a) {

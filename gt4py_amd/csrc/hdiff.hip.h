@@ -94,7 +94,7 @@ hdiff_generic_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_s
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD>
 inline int hdiff_launch(const View<const T>& in, const View<T>& out, const View<const T>& cf,
-                        PW coeff_scalar, const int64_t d[3], hipStream_t stream);
+                        PW coeff_scalar, const int64_t d[3], hipStream_t stream, bool point_per_thread = false);
 
 }  // namespace gt4mi
 
@@ -104,8 +104,10 @@ namespace gt4mi {
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD>
 inline int hdiff_launch(const View<const T>& in, const View<T>& out, const View<const T>& cf,
-                        PW coeff_scalar, const int64_t d[3], hipStream_t stream) {
-    const bool contiguous = in.si == 1 && out.si == 1 && (!COEFF_FIELD || cf.si == 1);
+                        PW coeff_scalar, const int64_t d[3], hipStream_t stream, bool point_per_thread) {
+    // point_per_thread: `coeff` IS `out` (same elements): hdiff_generic_kernel reads a point's coefficient and
+    // then writes that point, nothing else touches the element and no pointer is declared __restrict__
+    const bool contiguous = !point_per_thread && in.si == 1 && out.si == 1 && (!COEFF_FIELD || cf.si == 1);
     // Domains only a few columns wide (the west / east boundary strips of an IJ-decomposed apply) would use
     // 2 of the 128-256 columns of a wave-wide tile: one thread per point is 5-10x faster there.
     const bool skinny = d[0] < 32;
@@ -128,13 +130,13 @@ inline int hdiff_launch(const View<const T>& in, const View<T>& out, const View<
 template <typename T, typename W, typename PW>
 inline int hdiff_dispatch(const View<const T>& in, const View<T>& out, const View<const T>& cf,
                           bool coeff_field, PW coeff_scalar, bool limiter, const int64_t d[3],
-                          hipStream_t stream) {
+                          hipStream_t stream, bool point_per_thread = false) {
     if (limiter) {
-        if (coeff_field) return hdiff_launch<T, W, PW, true, true>(in, out, cf, coeff_scalar, d, stream);
-        return hdiff_launch<T, W, PW, true, false>(in, out, cf, coeff_scalar, d, stream);
+        if (coeff_field) return hdiff_launch<T, W, PW, true, true>(in, out, cf, coeff_scalar, d, stream, point_per_thread);
+        return hdiff_launch<T, W, PW, true, false>(in, out, cf, coeff_scalar, d, stream, point_per_thread);
     }
-    if (coeff_field) return hdiff_launch<T, W, PW, false, true>(in, out, cf, coeff_scalar, d, stream);
-    return hdiff_launch<T, W, PW, false, false>(in, out, cf, coeff_scalar, d, stream);
+    if (coeff_field) return hdiff_launch<T, W, PW, false, true>(in, out, cf, coeff_scalar, d, stream, point_per_thread);
+    return hdiff_launch<T, W, PW, false, false>(in, out, cf, coeff_scalar, d, stream, point_per_thread);
 }
 
 template <typename T>
@@ -149,6 +151,18 @@ inline int hdiff_run(const int64_t domain[3], const gt4mi_field* in_field,
     if (coeff != nullptr)
         if (int rc = make_view<T>("coeff", coeff, domain, h0, h0, &cf_v)) return rc;
     if (domain[0] == 0 || domain[1] == 0 || domain[2] == 0) return GT4MI_OK;
+    const ByteSpan out_span = span_of(out_v, domain, h0, h0);
+    if (spans_overlap(span_of(in_v, domain, h2, h2), out_span))
+        return fail(GT4MI_ERR_UNSUPPORTED,
+                    "hdiff: 'in_field' and 'out_field' overlap in memory; every point reads its neighbours' OLD values "
+                    "(the reference evaluates the right-hand side before it assigns), which an in-place kernel cannot "
+                    "provide -- pass a separate output array");
+    bool alias = false;  // out_field IS coeff: a point's coefficient is read before that point is written
+    if (coeff != nullptr && spans_overlap(span_of(cf_v, domain, h0, h0), out_span)) {
+        if (!same_view(cf_v, out_v))
+            return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: 'coeff' and 'out_field' overlap in memory without being the same elements");
+        alias = true;
+    }
     const View<const T> in_c{in_v.p, in_v.si, in_v.sj, in_v.sk};
     const View<const T> cf_c{cf_v.p, cf_v.si, cf_v.sj, cf_v.sk};
     const bool limiter = (flags & GT4MI_HDIFF_LIMITER) != 0;
@@ -156,17 +170,17 @@ inline int hdiff_run(const int64_t domain[3], const gt4mi_field* in_field,
     int rc;
     if constexpr (sizeof(T) == 8) {
         double cs = (flags & GT4MI_HDIFF_COEFF_F32) ? (double)(float)coeff_scalar : coeff_scalar;
-        rc = hdiff_dispatch<T, double, double>(in_c, out_v, cf_c, has_field, cs, limiter, domain, stream);
+        rc = hdiff_dispatch<T, double, double>(in_c, out_v, cf_c, has_field, cs, limiter, domain, stream, alias);
     } else {
         const bool w32 = (flags & GT4MI_HDIFF_INTERNAL_F32) != 0;
         const bool c32 = (flags & GT4MI_HDIFF_COEFF_F32) != 0;
         if (!w32) {
             double cs = c32 ? (double)(float)coeff_scalar : coeff_scalar;
-            rc = hdiff_dispatch<T, double, double>(in_c, out_v, cf_c, has_field, cs, limiter, domain, stream);
+            rc = hdiff_dispatch<T, double, double>(in_c, out_v, cf_c, has_field, cs, limiter, domain, stream, alias);
         } else if (has_field || c32) {
-            rc = hdiff_dispatch<T, float, float>(in_c, out_v, cf_c, has_field, (float)coeff_scalar, limiter, domain, stream);
+            rc = hdiff_dispatch<T, float, float>(in_c, out_v, cf_c, has_field, (float)coeff_scalar, limiter, domain, stream, alias);
         } else {
-            rc = hdiff_dispatch<T, float, double>(in_c, out_v, cf_c, has_field, coeff_scalar, limiter, domain, stream);
+            rc = hdiff_dispatch<T, float, double>(in_c, out_v, cf_c, has_field, coeff_scalar, limiter, domain, stream, alias);
         }
     }
     if (rc) return rc;

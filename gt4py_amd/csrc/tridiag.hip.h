@@ -176,7 +176,10 @@ struct TridiagTuning {
     static constexpr int UNROLL = 8;
     // on-chip stack of the forward sweep's results (tridiag_stack.hip.h): the last 32 levels in registers,
     // the 40 before them in LDS; 16/24/48 register levels and 0..64 LDS levels measured within 2 % of each
-    // other, more than 48 register levels slower (profiles/r1_microbench_i_tridiag_stack.log)
+    // other, more than 48 register levels slower (profiles/r1_microbench_i_tridiag_stack.log).  The launched
+    // kernel is the software-pipelined form (tridiag_pipe_kernel, +2 % on the same box and bit-identical:
+    // profiles/r2_tridiag_pipelined.log); for it 40 LDS levels are also what keeps ONE wave per SIMD, fewer were
+    // 15-25 % slower.
     static constexpr int STACK_REG = 32, STACK_LDS = 40, STACK_U = 8;
 };
 
@@ -196,17 +199,41 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
     if (int rc = make_view<T>("rhs", rhs, domain, h0, h0, &r)) return rc;
     if (int rc = make_view<T>("out", out, domain, h0, h0, &o)) return rc;
     if (domain[0] == 0 || domain[1] == 0) return GT4MI_OK;
+    // Aliases.  Every access is at zero horizontal offset and a thread owns its column, so what matters is the
+    // order of accesses within a column.  `out` may BE one of the other fields (same elements): out[k] is written
+    // after everything that level still needs of the aliased field has been read, level by level as the
+    // reference does -- by the column-at-a-time kernel without __restrict__ and without on-chip copies.  Any
+    // other overlap with a written field (sup with rhs, sup or rhs with inf / diag, shifted views) changes what
+    // the reference's statement-by-statement evaluation reads and is refused.
+    bool alias = false;
+    {
+        const View<T>* views[5] = {&a, &d, &s, &r, &o};
+        const char* names[5] = {"inf", "diag", "sup", "rhs", "out"};
+        ByteSpan spans[5];
+        for (int f = 0; f < 5; ++f) spans[f] = span_of(*views[f], domain, h0, h0);
+        for (int w = 2; w < 5; ++w)          // written fields: sup, rhs, out
+            for (int x = 0; x < 5; ++x) {
+                if (x == w || (x > w && x >= 2)) continue;  // written/written pairs once
+                if (!spans_overlap(spans[w], spans[x])) continue;
+                if (w == 4 && same_view(*views[w], *views[x])) {
+                    alias = true;
+                    continue;
+                }
+                return fail(GT4MI_ERR_UNSUPPORTED, "tridiag: '%s' and '%s' overlap in memory; only 'out' may share its array "
+                                                   "(element for element) with another field", names[w], names[x]);
+            }
+    }
     const View<const T> ac{a.p, a.si, a.sj, a.sk}, dc{d.p, d.si, d.sj, d.sk};
-    const bool contiguous = a.si == 1 && d.si == 1 && s.si == 1 && r.si == 1 && o.si == 1;
+    const bool contiguous = !alias && a.si == 1 && d.si == 1 && s.si == 1 && r.si == 1 && o.si == 1;
     if (contiguous && domain[2] > TridiagTuning::STACK_REG) {
         // keep the top of the column on chip between the sweeps
         const unsigned ti = (unsigned)cdiv(domain[0], 64);
         if (domain[2] > TridiagTuning::STACK_REG + TridiagTuning::STACK_LDS) {
-            hipLaunchKernelGGL((tridiag_stack_kernel<T, TridiagTuning::STACK_REG, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
                                dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);
         } else {
-            hipLaunchKernelGGL((tridiag_stack_kernel<T, TridiagTuning::STACK_REG, 0, TridiagTuning::STACK_U>),
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG, 0, TridiagTuning::STACK_U>),
                                dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);
         }

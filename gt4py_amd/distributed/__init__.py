@@ -7,11 +7,13 @@ from __future__ import annotations
 
 from typing import Any, Dict, Mapping, Sequence
 
-from .halo import Decomposition, HaloExchanger, HipPacker, choose_process_grid, halo_boxes, scatter_global
+from .halo import (Decomposition, HaloExchanger, HipPacker, choose_process_grid, exchange_cost, halo_boxes,
+                   process_grid_candidates, scatter_global)
 from .native import NativeComm, NativeHaloExchanger
 
 __all__ = ["Decomposition", "HaloExchanger", "HipPacker", "NativeComm", "NativeHaloExchanger", "TunedApply",
-           "choose_process_grid", "halo_boxes", "overlapped_apply", "scatter_global", "sequential_apply"]
+           "choose_process_grid", "exchange_cost", "halo_boxes", "overlapped_apply", "process_grid_candidates",
+           "scatter_global", "sequential_apply"]
 
 
 def _shifted(origin: Mapping[str, Sequence[int]], shift: Sequence[int]) -> Dict[str, tuple]:
@@ -78,13 +80,28 @@ class TunedApply:
     Which of ``overlapped_apply`` / ``sequential_apply`` wins depends on the stencil (how expensive its strips
     are), the local domain and the links, none of which is known up front.  ``calibrate()`` times a few
     applies of each on the current stream; with an initialised ``torch.distributed`` group every rank adopts
-    the choice that is best for the slowest rank.  Calibration applies are real applies (they overwrite the
-    outputs with the same values an ordinary apply would)."""
+    the choice that is best for the slowest rank.  The timed applies run on CLONES of every field the stencil
+    writes, so the caller's data is not touched (an in/out field of a time-stepping stencil would otherwise
+    advance by the number of calibration applies); read-only fields are used in place, and their ghost cells
+    are refreshed by the exchanges, which an ordinary apply does as well."""
 
     def __init__(self, stencil, decomp: Decomposition, origin: Mapping[str, Sequence[int]], exchange: Mapping[str, Any]):
         self.stencil, self.decomp, self.origin, self.exchange = stencil, decomp, origin, exchange
         self.choice = None
         self.timings_ms: Dict[str, float] = {}
+
+    def _scratch_arguments(self, arguments: Dict[str, Any]) -> Dict[str, Any]:
+        from ..cartesian.definitions import AccessKind
+
+        out = dict(arguments)
+        info = getattr(self.stencil, "field_info", {}) or {}
+        for name, fi in info.items():
+            if name in arguments and fi is not None and fi.access in (AccessKind.WRITE, AccessKind.READ_WRITE):
+                if name in self.exchange:
+                    raise ValueError(f"field '{name}' is written by the stencil AND exchanged: calibrate() cannot keep it "
+                                     "untouched; choose the form explicitly (TunedApply.choice = ...)")
+                out[name] = arguments[name].copy() if hasattr(arguments[name], "copy") else arguments[name].clone()
+        return out
 
     def calibrate(self, arguments: Dict[str, Any], iters: int = 8) -> str:
         import time
@@ -92,16 +109,17 @@ class TunedApply:
         import torch
 
         group = torch.distributed.is_available() and torch.distributed.is_initialized()
+        scratch = self._scratch_arguments(arguments)
         forms = {"overlapped": overlapped_apply, "sequential": sequential_apply}
         for name, fn in forms.items():
             for _ in range(2):
-                fn(self.stencil, self.decomp, self.origin, arguments, self.exchange)
+                fn(self.stencil, self.decomp, self.origin, scratch, self.exchange)
             torch.cuda.synchronize()
             if group:
                 torch.distributed.barrier()
             t0 = time.perf_counter()
             for _ in range(iters):
-                fn(self.stencil, self.decomp, self.origin, arguments, self.exchange)
+                fn(self.stencil, self.decomp, self.origin, scratch, self.exchange)
             torch.cuda.synchronize()
             dt = torch.tensor([(time.perf_counter() - t0) / iters * 1e3], dtype=torch.float64, device="cuda")
             if group:

@@ -30,28 +30,56 @@ except Exception:  # pragma: no cover
     dist = None  # type: ignore
 
 
-def choose_process_grid(n: int, domain: Sequence[int], prefer_j: bool = True) -> Tuple[int, int]:
-    """(PI, PJ) with PI * PJ == n.
-
-    With I-contiguous storage a J face is a set of contiguous rows while an I face is a strided
-    column block, and the kernels are most efficient on long I rows; so J is cut first and I only
-    when J would get thinner than 32 rows per rank.
-    """
-    best = None
+def process_grid_candidates(n: int, domain: Sequence[int], halo: int = 1, min_rows: int = 8):
+    """Every (PI, PJ) with PI * PJ == n whose smallest local block is at least ``2 * halo`` points wide
+    along a cut axis (so that a ghost zone is filled by ONE neighbour) and at least ``min_rows`` rows high."""
+    out = []
     for pi in range(1, n + 1):
         if n % pi:
             continue
         pj = n // pi
-        if domain[0] // pi < 1 or domain[1] // pj < 1:
+        li, lj = domain[0] // pi, domain[1] // pj  # the smallest block of an even split
+        if li < 1 or lj < 1:
             continue
-        thin_j = (domain[1] // pj) < 32
-        # cost: prefer few I cuts, avoid thin J slabs
-        key = (thin_j, pi if prefer_j else pj)
-        if best is None or key < best[0]:
-            best = (key, (pi, pj))
-    if best is None:
+        if (pi > 1 and li < 2 * halo) or (pj > 1 and lj < max(2 * halo, min_rows)):
+            continue
+        out.append((pi, pj))
+    return out
+
+
+def exchange_cost(grid: Tuple[int, int], domain: Sequence[int], halo: int = 1):
+    """(largest message in points, number of sequential phases) of one ghost-cell exchange on ``grid``.
+
+    xGMI is point-to-point: every neighbour has its own link, so an exchange takes as long as its LARGEST
+    message per phase (not the sum), plus one latency per phase (I faces, then J faces)."""
+    pi, pj = grid
+    li, lj = -(-domain[0] // pi), -(-domain[1] // pj)
+    # I faces also carry the ghost rows on sides without a J neighbour (halo_boxes)
+    i_face = halo * (lj + (2 * halo if pj == 1 else halo)) * domain[2] if pi > 1 else 0
+    j_face = halo * (li + 2 * halo) * domain[2] if pj > 1 else 0
+    return max(i_face, j_face), (pi > 1) + (pj > 1)
+
+
+def choose_process_grid(n: int, domain: Sequence[int], halo: int = 1) -> Tuple[int, int]:
+    """(PI, PJ) with PI * PJ == n: the static default; ``bench.py`` measures the candidates instead.
+
+    Link-aware: minimise the largest message of an exchange (``exchange_cost``), then the number of phases.
+    1 x 8 on a 512^3 grid sends two 2.1 MB faces per rank, 4 x 2 and 2 x 4 send at most 1.05 MB.  Exact ties
+    (a square domain cut along both axes) go to the grid with more cuts along I, which is the 4 x 2 that
+    BASELINE.json configs[4] names for the 2048 x 2048 x 80 horizontal diffusion; with a single cut axis the
+    cut goes along J, whose faces are contiguous rows of the I-contiguous storage.
+    """
+    candidates = process_grid_candidates(n, domain, halo)
+    if not candidates:
         raise ValueError(f"cannot split domain {tuple(domain)} over {n} ranks")
-    return best[1]
+
+    def key(grid):
+        largest, phases = exchange_cost(grid, domain, halo)
+        pi, pj = grid
+        one_axis = pi == 1 or pj == 1
+        return (largest, phases, pi if one_axis else -pi)
+
+    return min(candidates, key=key)
 
 
 def _split(n: int, parts: int, index: int) -> Tuple[int, int]:
@@ -230,9 +258,14 @@ class HaloExchanger:
         ops = []
         for m, (_, send_lo, _, ext) in enumerate(phase):
             self.packer.pack(tensor, send_lo, ext, self.buffers[(p, m, "send")])
+        # NCCL / gloo match the k-th send to a peer with the k-th receive posted for that peer, so the ORDER is
+        # part of the protocol: sends go low side first, receives HIGH side first.  On a periodic axis with 1
+        # or 2 ranks both faces of a phase go to the same peer, and my low-side face must land in the peer's
+        # high-side ghost zone (NativeHaloExchanger.message_tables does the same).
         for m, (peer, _, _, _) in enumerate(phase):
             ops.append(dist.P2POp(dist.isend, self.buffers[(p, m, "send")], peer, self.group))
-            ops.append(dist.P2POp(dist.irecv, self.buffers[(p, m, "recv")], peer, self.group))
+        for m in reversed(range(len(phase))):
+            ops.append(dist.P2POp(dist.irecv, self.buffers[(p, m, "recv")], phase[m][0], self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         for m, (_, _, recv_lo, ext) in enumerate(phase):
@@ -244,8 +277,11 @@ class HaloExchanger:
             self._run_phase(tensor, p)
 
     def start(self, tensor):
-        """Launch the exchange on the side stream; returns an event to wait on (GPU only)."""
-        assert self.stream is not None
+        """Launch the exchange on the side stream; returns an event to wait on.  On a CPU device (gloo, the
+        tests) there are no streams: the exchange completes here and the handle is None."""
+        if self.stream is None:
+            self.exchange(tensor)
+            return None
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
             self.exchange(tensor)
@@ -254,7 +290,8 @@ class HaloExchanger:
         return done
 
     def finish(self, done) -> None:
-        torch.cuda.current_stream(self.device).wait_event(done)
+        if done is not None:
+            torch.cuda.current_stream(self.device).wait_event(done)
 
 
 def scatter_global(global_array: np.ndarray, decomp: Decomposition) -> np.ndarray:

@@ -90,28 +90,37 @@ def allocate_cpu(shape, layout_map, dtype, alignment_bytes, aligned_index) -> Tu
     return raw, view
 
 
-_SKEW_COUNTER = [0]
+#: Placement of big device buffers: period and step of the address pattern, smallest buffer it applies to.
+PLACEMENT_PERIOD = 4 << 20
+PLACEMENT_STEP = 1 << 20
+PLACEMENT_MIN_BYTES = 64 << 20
+_PLACEMENT_SLOT = [0]
 
 
-def _channel_skew(alignment_bytes: int) -> int:
-    """Bytes by which the next big device allocation is shifted.
+def _placement_shift(base_address: int, alignment_bytes: int) -> int:
+    """Bytes to skip at the start of a big device allocation so that the buffer begins at
+    ``slot * 1 MiB (mod 4 MiB)``, ``slot`` = 1, 2, 3, 0, 1, ... for successive allocations.
 
-    Equally shaped fields that a stencil streams side by side (five 1.34 GB arrays in the tridiagonal
-    solve) otherwise sit at addresses that differ by a multiple of a large power of two, so the same (i, j, k)
-    of every field lands in the same HBM channel.  Rotating the start over a few steps spreads them.  The
-    layout contract is untouched: strides, padding and the alignment of `aligned_index` are the reference's
+    Equally shaped fields that a column kernel streams side by side (five 1.34 GB arrays in the tridiagonal
+    solve, K planes exactly 8 MiB apart) are slowest when they sit at the same address modulo 4 MiB and
+    fastest when address bits 20 and 21 differ between them: measured on MI355X with the fields at controlled
+    offsets inside one allocation (profiles/r2_tridiag_placement_study.log) 79 GLUPS with offsets that are
+    multiples of 2 MiB, 83-84 with 0.25-0.75 MiB steps, 85 with 1.5 MiB, 86.6 with 1 / 3 / 5 MiB steps; the
+    pattern repeats with a period of 2 MiB in the step.  The shift is DERIVED FROM THE ADDRESS the allocator
+    returned, so where the caching allocator happens to put a block does not matter (round 1 added a rotating
+    offset to whatever address came back, which only works when all blocks start equally aligned).  The layout
+    contract is untouched: strides, padding and the alignment of `aligned_index` are the reference's
     (storage/allocators.py:187-273); only where the buffer begins inside its (over-)allocation changes.
-    ``GT4PY_AMD_ALLOC_SKEW_BYTES`` sets the step (0 = off).  Default 1.5 MiB: on MI355X the tridiagonal
-    solve on five 1024x1024x160 fp64 fields runs at 79-85 GLUPS without a skew, 88-92 with 128 KiB-1 MiB
-    steps, 96-97 with 1.25-1.5 MiB, 92 with 3 MiB; the two-field kernels do not care."""
+    ``GT4PY_AMD_ALLOC_SKEW_BYTES`` overrides the step (0 = off)."""
     import os
 
-    step = int(os.environ.get("GT4PY_AMD_ALLOC_SKEW_BYTES", str(3 << 19)))
+    step = int(os.environ.get("GT4PY_AMD_ALLOC_SKEW_BYTES", str(PLACEMENT_STEP)))
     if step <= 0:
         return 0
     step = -(-step // alignment_bytes) * alignment_bytes
-    _SKEW_COUNTER[0] = (_SKEW_COUNTER[0] + 1) % 8
-    return _SKEW_COUNTER[0] * step
+    _PLACEMENT_SLOT[0] = (_PLACEMENT_SLOT[0] + 1) % 4
+    want = (_PLACEMENT_SLOT[0] * step) % PLACEMENT_PERIOD
+    return (want - base_address) % PLACEMENT_PERIOD
 
 
 def allocate_gpu(shape, layout_map, dtype, alignment_bytes, aligned_index) -> Tuple["torch.Tensor", DeviceArray]:
@@ -123,8 +132,12 @@ def allocate_gpu(shape, layout_map, dtype, alignment_bytes, aligned_index) -> Tu
     dtype = np.dtype(dtype)
     tdt = torch_dtype(dtype)
     plan = plan_buffer(shape, dtype, layout_map, alignment_bytes, aligned_index)
-    skew = _channel_skew(alignment_bytes) if plan.total_bytes >= (1 << 24) else 0
-    raw = torch.empty((plan.total_bytes + skew,), dtype=torch.uint8, device="cuda")
+    if plan.total_bytes >= PLACEMENT_MIN_BYTES:
+        raw = torch.empty((plan.total_bytes + PLACEMENT_PERIOD,), dtype=torch.uint8, device="cuda")
+        skew = _placement_shift(raw.data_ptr(), alignment_bytes)
+    else:
+        raw = torch.empty((plan.total_bytes,), dtype=torch.uint8, device="cuda")
+        skew = 0
     offset = skew + plan.byte_offset(raw.data_ptr() + skew)
     assert offset % plan.itemsize == 0, "device allocation is not item-aligned"
     n_items = math.prod(plan.padded_shape)

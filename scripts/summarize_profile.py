@@ -15,7 +15,10 @@ import sys
 
 out = pathlib.Path(sys.argv[1])
 tag = sys.argv[2]
+git_sha = sys.argv[3] if len(sys.argv) > 3 else "unknown"  # the GPU box has no .git: the caller passes HEAD
 KERNEL = "lap5_strip_kernel"
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+import bench  # noqa: E402 - kernel_source_hash: the same function bench.py checks the committed number with
 
 
 def counter_mean(path, counter, needle):
@@ -44,11 +47,18 @@ if fetch is not None and write is not None:
     summary["hbm_bytes_per_launch"] = traffic
     summary["algorithmic_bytes_per_launch"] = 16.0 * 512**3
     summary["traffic_over_algorithmic"] = traffic / (16.0 * 512**3)
+    kernel_names = sorted({r["Kernel_Name"].split("(")[0] for r in csv.DictReader(open(out / "fetch" / "lap_counter_collection.csv"))
+                           if KERNEL in r["Kernel_Name"]})
     (out / f"hbm_traffic_{tag}.json").write_text(json.dumps({
-        "lap5_f64_512": round(traffic),
+        "lap5_f64_512": {"bytes_per_launch": round(traffic), "kernel": kernel_names, "git_sha": git_sha,
+                         "kernel_source_sha": bench.kernel_source_hash("lap5_f64_512"),
+                         "source": f"profiles/{tag}_bench_lap512_summary.json"},
         "_note": "bytes per launch of lap5_strip_kernel on 512^3 fp64 = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, "
                  "rocprofv3 --pmc, separate passes; factor 2 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts "
-                 "128-B requests as 64 B), checked against a torch kernel of known size in the same run",
-        "_source": f"profiles/{tag}_bench_lap512_summary.json"}, indent=1))
+                 "128-B requests as 64 B), checked against a torch kernel of known size in the same run.  bench.py "
+                 "reports the number only while kernel_source_sha equals the hash of the kernel sources in the tree "
+                 "(bench.KERNEL_SOURCES)"}, indent=1))
+    summary["git_sha"] = git_sha
+    summary["kernel_source_sha"] = bench.kernel_source_hash("lap5_f64_512")
 (out / f"summary_{tag}.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary, indent=1))

@@ -33,11 +33,25 @@ class TorchSlicePacker:
         self._box(tensor, lo, ext).copy_(buffer.reshape(ext[2], ext[1], ext[0]).permute(2, 1, 0))
 
 
-def test_choose_process_grid_prefers_j_cuts():
+def test_choose_process_grid_is_link_aware():
+    """Smallest largest message first (xGMI is point-to-point: neighbours do not share a link), then fewer
+    phases; a single cut goes along J (contiguous faces); BASELINE.json configs[4] gets its 4 x 2."""
+    from gt4py_amd.distributed import exchange_cost, process_grid_candidates
+
     assert choose_process_grid(1, (512, 512, 512)) == (1, 1)
     assert choose_process_grid(2, (512, 512, 512)) == (1, 2)
-    assert choose_process_grid(8, (512, 512, 512)) == (1, 8)
-    assert choose_process_grid(8, (2048, 64, 80)) == (4, 2)  # J would get thinner than 32 rows
+    assert choose_process_grid(4, (512, 512, 512)) == (2, 2)
+    assert choose_process_grid(8, (512, 512, 512)) == (4, 2)
+    assert choose_process_grid(8, (2048, 2048, 80), halo=2) == (4, 2)
+    assert choose_process_grid(8, (2048, 64, 80)) == (8, 1)  # J slabs of 8 rows would send 2 x 2050 x 80 points
+    assert choose_process_grid(8, (64, 2048, 80)) == (1, 8)
+    # the largest message is what the choice halves: 1 x 8 sends 514 x 512 points, 4 x 2 at most 258 x 512
+    assert exchange_cost((1, 8), (512, 512, 512))[0] == 514 * 512 and exchange_cost((4, 2), (512, 512, 512))[0] == 257 * 512
+    assert exchange_cost((1, 8), (512, 512, 512))[1] == 1 and exchange_cost((4, 2), (512, 512, 512))[1] == 2
+    assert process_grid_candidates(8, (512, 512, 512)) == [(1, 8), (2, 4), (4, 2), (8, 1)]
+    assert process_grid_candidates(8, (512, 16, 8), halo=2) == [(4, 2), (8, 1)]  # J blocks need >= max(2 halo, 8) rows
+    with pytest.raises(ValueError):
+        choose_process_grid(8, (3, 3, 3))
 
 
 @pytest.mark.parametrize("grid", [(1, 1), (2, 1), (1, 2), (4, 2), (3, 3)])
@@ -115,6 +129,99 @@ def test_in_process_4x2_exchange_and_hdiff():
                 R.hdiff(blk, out, cf, origin_in=org, origin_out=org, origin_coeff=org, domain=dom)
         got[d.global_slices(with_halo=False)] = out[h:-h, h:-h]
     assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h])
+
+
+@pytest.mark.parametrize("grid,periodic", [((1, 1), (True, True)), ((1, 2), (False, True)), ((2, 1), (True, False)),
+                                           ((2, 2), (True, True)), ((1, 2), (True, True)), ((3, 2), (True, True))])
+@pytest.mark.parametrize("halo", [1, 2])
+def test_torch_transport_message_order_on_periodic_axes(grid, periodic, halo):
+    """HaloExchanger posts sends low side first and receives HIGH side first.  With 1 or 2 ranks on a periodic
+    axis both faces of a phase go to the same peer and the k-th send is matched with the k-th receive (NCCL and
+    gloo alike): replay every rank's operation list with that rule -- no transport needed -- and compare the
+    ghost cells with the periodic global array."""
+    gd = (6 * grid[0] + 1, 5 * grid[1] + 2, 2)
+    n = grid[0] * grid[1]
+    rng = np.random.default_rng(8)
+    full = rng.uniform(-1, 1, (gd[0] + 2 * halo, gd[1] + 2 * halo, gd[2]))
+    if periodic[0]:
+        full[:halo], full[-halo:] = full[-2 * halo:-halo].copy(), full[halo:2 * halo].copy()
+    if periodic[1]:
+        full[:, :halo], full[:, -halo:] = full[:, -2 * halo:-halo].copy(), full[:, halo:2 * halo].copy()
+    decs = [Decomposition(gd, grid, r, halo, periodic=periodic) for r in range(n)]
+    have, want = [], []
+    for d in decs:
+        w = scatter_global(full, d).copy()
+        h = w.copy()
+        nb = d.neighbours
+        if nb["W"] is not None:
+            h[:halo] = np.nan
+        if nb["E"] is not None:
+            h[-halo:] = np.nan
+        if nb["S"] is not None:
+            h[:, :halo] = np.nan
+        if nb["N"] is not None:
+            h[:, -halo:] = np.nan
+        have.append(torch.from_numpy(h))
+        want.append(w)
+
+    class Recorder:
+        """stands in for torch.distributed: records the P2P operations of one batch"""
+
+        def __init__(self):
+            self.ops = []
+
+    recorded = {}
+    real_batch, real_p2p = dist.batch_isend_irecv, dist.P2POp
+
+    class FakeOp:
+        def __init__(self, op, tensor, peer, group=None):
+            self.kind = "send" if op is dist.isend else "recv"
+            self.tensor, self.peer = tensor, peer
+
+    class Done:
+        def wait(self):
+            return None
+
+    exchangers = [HaloExchanger(d, torch.float64, "cpu", packer=TorchSlicePacker()) for d in decs]
+    try:
+        dist.P2POp = FakeOp
+        for phase in (0, 1):
+            # every rank packs and "posts" its batch; unpack is deferred until the mail has been delivered
+            batches = {}
+            for r, ex in enumerate(exchangers):
+                def fake_batch(ops, r=r):
+                    batches[r] = list(ops)
+                    return [Done() for _ in ops]
+
+                dist.batch_isend_irecv = fake_batch
+                box = ex.phases[phase]
+                if not box:
+                    continue
+                for m, (_, send_lo, _, ext) in enumerate(box):
+                    ex.packer.pack(have[r], send_lo, ext, ex.buffers[(phase, m, "send")])
+                # the product's own posting order
+                ops = []
+                real_unpack = ex.packer.unpack
+                ex.packer.unpack = lambda *a, **k: None
+                ex._run_phase(have[r], phase)
+                ex.packer.unpack = real_unpack
+            mailbox = {}
+            for r, ops in batches.items():
+                for op in ops:
+                    if op.kind == "send":
+                        mailbox.setdefault((r, op.peer), []).append(op.tensor.clone())
+            for r, ops in batches.items():
+                for op in ops:
+                    if op.kind == "recv":
+                        op.tensor.copy_(mailbox[(op.peer, r)].pop(0))
+            assert all(not q for q in mailbox.values())
+            for r, ex in enumerate(exchangers):
+                for m, (_, _, recv_lo, ext) in enumerate(ex.phases[phase]):
+                    ex.packer.unpack(have[r], recv_lo, ext, ex.buffers[(phase, m, "recv")])
+    finally:
+        dist.batch_isend_irecv, dist.P2POp = real_batch, real_p2p
+    for r in range(n):
+        np.testing.assert_array_equal(have[r].numpy(), want[r], err_msg=f"rank {r}")
 
 
 def _free_port() -> int:

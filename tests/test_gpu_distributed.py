@@ -315,3 +315,61 @@ def test_one_sided_rank(comm, halo, side, overlap):
     got = step.result().get()
     assert np.array_equal(got[H:H + li, H:H + lj], u[H:H + li, H:H + lj])
     ex.close()
+
+
+@pytest.mark.parametrize("form", ["overlapped", "sequential"])
+def test_baseline_config4_share_with_all_four_neighbours(comm, form):
+    """BASELINE.json configs[4] at the size ONE rank of the 4 x 2 grid holds: fp64 horizontal diffusion on
+    512 x 1024 x 80 with ghost depth 2.  The domain is periodic along both axes, so W, E, S and N (and, through the
+    two-phase exchange, the four corners) are all live -- each is the rank itself over RCCL.  Slabs of the result
+    are compared with the oracle on the periodically wrapped field: horizontal diffusion is PARALLEL in K, so a
+    few levels of the full 512 x 1024 plane -- including every boundary strip and corner -- check the kernels,
+    the strips and the exchange without a multi-gigabyte numpy evaluation."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger, overlapped_apply, sequential_apply
+    from oracle import ref_numpy as R
+
+    hd = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field,
+                          dtypes={"T": np.float64}, device_sync=False)
+    gd, h = (512, 1024, 80), 2
+    dec = Decomposition(gd, (1, 1), 0, h, periodic=(True, True))
+    assert dec.local_shape == (516, 1028, 80) and all(v == 0 for v in dec.neighbours.values())
+    gen = torch.Generator(device="cuda").manual_seed(20262)
+    fields = {}
+    for name, lo, hi in (("in_field", -10.0, 10.0), ("coeff", 0.0, 0.5), ("out_field", 0.0, 0.0)):
+        f = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+        if hi > lo:
+            f.tensor.copy_(torch.rand(dec.local_shape, dtype=torch.float64, device="cuda", generator=gen) * (hi - lo) + lo)
+        fields[name] = f
+    levels = [0, 1, 39, 78, 79]
+    host_in = fields["in_field"].tensor[:, :, levels].cpu().numpy()  # ghost cells still hold their random values
+    host_cf = fields["coeff"].tensor[:, :, levels].cpu().numpy()
+    ex = NativeHaloExchanger(dec, np.float64, comm)
+    assert ex.bytes_per_exchange == 2 * (2 * 1024 * 80 * 8) + 2 * (516 * 2 * 80 * 8)  # 3.94 MB: 2 I faces + 2 J faces (with the fresh I-halo columns)
+    origin = {n: dec.origin for n in fields}
+    apply = overlapped_apply if form == "overlapped" else sequential_apply
+    apply(hd, dec, origin, fields, {"in_field": ex})
+    torch.cuda.synchronize()
+    want = np.zeros_like(host_in)
+    wrapped = _wrap(host_in, h)
+    R.hdiff(wrapped, want, host_cf, domain=(gd[0], gd[1], len(levels)))
+    got = fields["out_field"].tensor[:, :, levels].cpu().numpy()
+    assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h])
+    # the exchange refreshed the input's ghost cells with the periodic images, corners included
+    assert np.array_equal(fields["in_field"].tensor[:, :, levels].cpu().numpy(), wrapped)
+    # size-independent property on ALL 80 levels: a field that is linear in i and j has lap == 0, hence out == in
+    # exactly; with the periodic wrap that holds away from the seam, and the seam rows / columns must differ
+    ii = torch.arange(dec.local_shape[0], dtype=torch.float64, device="cuda")[:, None, None]
+    jj = torch.arange(dec.local_shape[1], dtype=torch.float64, device="cuda")[None, :, None]
+    fields["in_field"].tensor.copy_((3.0 * ii + 5.0 * jj + 7.0).expand(dec.local_shape))
+    apply(hd, dec, origin, fields, {"in_field": ex})
+    torch.cuda.synchronize()
+    out, inp = fields["out_field"].tensor, fields["in_field"].tensor
+    inner = (slice(h + 2, -(h + 2)), slice(h + 2, -(h + 2)), slice(None))
+    assert torch.equal(out[inner], inp[inner])
+    assert not torch.equal(out[h:-h, h:-h], inp[h:-h, h:-h])  # the periodic seam is not linear: diffusion acts there
+    ex.close()

@@ -1,0 +1,280 @@
+"""Tighten the parity evidence of the oracle (CPU, no GPU needed).
+
+1. Three structurally different restatements of the three hot stencils must agree BIT FOR BIT on seeded inputs and
+   with the golden vectors produced on the reference's own ``Field`` shim (tests/golden/stencils_small.npz):
+     * ``oracle.ref_numpy``          whole-array slices, statement by statement (the numpy backend's schedule),
+     * ``oracle.ref_numpy.*_loops``  one column / one point at a time,
+     * ``oracle.ref_debug_order``    scalar operations in the loop order of the reference's debug backend
+                                     (debug_codegen.py:93-124: IJ outermost, K innermost, one statement at a time).
+   Flux-limited horizontal diffusion and the tridiagonal solve have no reference-held answers,
+   so agreement between independent derivations is what pins them.
+2. The generic oracle (``oracle.numpy_backend.run_stencil``) normally interprets IR that the PRODUCT's frontend
+   built, which makes every oracle-vs-HIP comparison through it blind to a parsing / dtype-promotion bug.  Here the
+   IR of the three stencils -- node by node, with the casts the reference's upcasting rules prescribe
+   (gtir_upcaster.py:43-143), and their block extents (oir_optimizations/utils.py:293-313) -- is written BY HAND
+   and must reproduce the golden vectors, and the frontend's IR must be that very tree.
+"""
+
+import pathlib
+
+import numpy as np
+import pytest
+
+from gt4py_amd.cartesian import analysis, definitions as D, frontend, ir
+from gt4py_amd.cartesian.backend import hip_templates
+from oracle import numpy_backend, ref_debug_order as DBG, ref_numpy as R
+
+GOLD = np.load(pathlib.Path(__file__).parent / "golden" / "stencils_small.npz")
+F64, F32, I64, BOOL = np.dtype("float64"), np.dtype("float32"), np.dtype("int64"), np.dtype("bool")
+
+
+def _same(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+# ---- 1. three restatements ------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_laplacian_three_ways(dtype):
+    rng = np.random.default_rng(11)
+    inp = rng.uniform(-1, 1, (9, 8, 4)).astype(dtype)
+    o_in, o_out, dom = (2, 1, 1), (1, 3, 0), (6, 4, 3)
+    outs = [rng.uniform(-1, 1, (8, 9, 3)).astype(dtype)]
+    outs += [outs[0].copy(), outs[0].copy()]
+    R.laplacian(inp, outs[0], origin_inp=o_in, origin_out=o_out, domain=dom)
+    R.laplacian_loops(inp, outs[1], origin_inp=o_in, origin_out=o_out, domain=dom)
+    # ref_numpy.laplacian keeps float32 fields in float32 (literal_float_precision=32); for float64 fields the
+    # option makes no difference
+    DBG.laplacian_debug_order(inp, outs[2], origin_inp=o_in, origin_out=o_out, domain=dom,
+                              literal_float_precision=32 if dtype == np.float32 else 64)
+    assert _same(outs[0], outs[1]) and _same(outs[0], outs[2])
+
+
+def test_laplacian_debug_order_reproduces_the_golden_vector():
+    out = GOLD["lap_out0"].copy()
+    DBG.laplacian_debug_order(GOLD["lap_inp"], out, origin_inp=tuple(GOLD["lap_origin_inp"]),
+                              origin_out=tuple(GOLD["lap_origin_out"]), domain=tuple(GOLD["lap_domain"]))
+    assert _same(out, GOLD["lap_out"])
+
+
+@pytest.mark.parametrize("limiter", [True, False])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_hdiff_three_ways(dtype, limiter, seed):
+    rng = np.random.default_rng(seed)
+    # smooth + noise: both signs of res * gradient occur, so the limiter really switches
+    x, y = np.meshgrid(np.arange(12.0), np.arange(11.0), indexing="ij")
+    base = (np.sin(x * 0.7) + np.cos(y * 0.9))[:, :, None] * np.array([1.0, 2.0, -1.5])[None, None, :]
+    in_a = (base + rng.uniform(-0.3, 0.3, base.shape)).astype(dtype)
+    cf_a = rng.uniform(0, 0.5, (9, 8, 4)).astype(dtype)
+    o_in, o_cf, o_out, dom = (3, 2, 1), (1, 1, 2), (0, 1, 0), (7, 6, 2)
+    outs = [np.zeros((8, 8, 3), dtype) for _ in range(3)]
+    R.hdiff(in_a, outs[0], cf_a, origin_in=o_in, origin_out=o_out, origin_coeff=o_cf, domain=dom, limiter=limiter)
+    R.hdiff_loops(in_a, outs[1], cf_a, origin_in=o_in, origin_out=o_out, origin_coeff=o_cf, domain=dom, limiter=limiter)
+    DBG.hdiff_debug_order(in_a, outs[2], cf_a, origin_in=o_in, origin_out=o_out, origin_coeff=o_cf, domain=dom, limiter=limiter)
+    assert _same(outs[0], outs[1]) and _same(outs[0], outs[2])
+    if limiter:  # the case is a real test of the limiter: it fires somewhere, and not everywhere
+        plain = np.zeros((8, 8, 3), dtype)
+        R.hdiff(in_a, plain, cf_a, origin_in=o_in, origin_out=o_out, origin_coeff=o_cf, domain=dom, limiter=False)
+        changed = (plain != outs[0]).mean()
+        assert 0.02 < changed < 0.98
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_hdiff_debug_order_reproduces_the_golden_vector(tag):
+    o_in, o_cf, o_out = (tuple(o) for o in GOLD[f"hd_{tag}_origins"])
+    out = GOLD[f"hd_{tag}_out0"].copy()
+    DBG.hdiff_debug_order(GOLD[f"hd_{tag}_in"], out, GOLD[f"hd_{tag}_coeff"], origin_in=o_in, origin_out=o_out,
+                          origin_coeff=o_cf, domain=tuple(GOLD[f"hd_{tag}_domain"]))
+    assert _same(out, GOLD[f"hd_{tag}_out"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("seed", [5, 6])
+def test_tridiag_three_ways(dtype, seed):
+    rng = np.random.default_rng(seed)
+    shape = (4, 3, 11)
+    inf, sup = rng.uniform(-1, 1, shape).astype(dtype), rng.uniform(-1, 1, shape).astype(dtype)
+    diag, rhs = rng.uniform(4, 5, shape).astype(dtype), rng.uniform(-10, 10, shape).astype(dtype)
+    runs = []
+    for fn in (R.tridiag, R.tridiag_loops, lambda *a: DBG.tridiag_debug_order(*a, domain=shape)):
+        s, r, o = sup.copy(), rhs.copy(), np.zeros(shape, dtype)
+        fn(inf, diag, s, r, o)
+        runs.append((s, r, o))
+    for other in runs[1:]:
+        assert all(_same(x, y) for x, y in zip(runs[0], other))
+
+
+def test_tridiag_debug_order_reproduces_the_golden_vector():
+    o, dom = tuple(GOLD["tri_origin"]), tuple(GOLD["tri_domain"])
+    sup, rhs, out = GOLD["tri_sup0"].copy(), GOLD["tri_rhs0"].copy(), np.zeros_like(GOLD["tri_out"])
+    DBG.tridiag_debug_order(GOLD["tri_inf"], GOLD["tri_diag"], sup, rhs, out,
+                            origins={n: o for n in ("inf", "diag", "sup", "rhs", "out")}, domain=dom)
+    assert _same(sup, GOLD["tri_sup"]) and _same(rhs, GOLD["tri_rhs"]) and _same(out, GOLD["tri_out"])
+
+
+# ---- 2. hand-built IR -----------------------------------------------------------------------------------
+def A(name, di=0, dj=0, dk=0, dt=F64):
+    return ir.FieldAccess(name, (di, dj, dk), dt)
+
+
+def B(op, left, right, dt):
+    return ir.BinaryOp(op, left, right, dt)
+
+
+FULL = ir.Interval(ir.AxisBound(ir.Level.START, 0), ir.AxisBound(ir.Level.END, 0))
+
+
+def interval(a, b):
+    def bound(v, is_end):
+        if v is None:
+            return ir.AxisBound(ir.Level.END, 0)
+        return ir.AxisBound(ir.Level.START, v) if v >= 0 else ir.AxisBound(ir.Level.END, v)
+
+    return ir.Interval(bound(a, False), bound(b, True))
+
+
+def hand_built_laplacian(dt):
+    """out = -4.0 * inp + inp[-1,0,0] + inp[1,0,0] + inp[0,-1,0] + inp[0,1,0]; the float64 literal widens every
+    float32 operand it meets (one cast per operand), the sum is rounded once to the field's dtype."""
+    def w(e):
+        return e if dt == F64 else ir.Cast(e, F64)
+
+    v = B("*", ir.UnaryOp("-", ir.Literal(4.0, F64), F64), w(A("inp", dt=dt)), F64)
+    for off in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+        v = B("+", v, w(A("inp", off[0], off[1], 0, dt)), F64)
+    if dt != F64:
+        v = ir.Cast(v, dt)
+    st = ir.Stencil("lap_by_hand", (ir.FieldDecl("inp", dt), ir.FieldDecl("out", dt)), (), (),
+                    (ir.Computation(ir.LoopOrder.PARALLEL, (ir.IntervalBlock(FULL, (ir.Assign(A("out", dt=dt), v),)),)),))
+    ext = analysis.ExtentInfo({"inp": ((-1, 1), (-1, 1)), "out": ((0, 0), (0, 0))}, [((0, 0), (0, 0))])
+    return st, ext
+
+
+def hand_built_hdiff(dt):
+    """stencil_definitions.py:316-328 with the casts of a float32 field under float64 literals."""
+    def w(e):
+        return e if dt == F64 else ir.Cast(e, F64)
+
+    def f(di=0, dj=0):
+        return A("in_field", di, dj, 0, dt)
+
+    zero = ir.Cast(ir.Literal(0, I64), F64)
+    neigh = B("+", B("+", B("+", f(1, 0), f(-1, 0), dt), f(0, 1), dt), f(0, -1), dt)
+    lap = B("-", B("*", ir.Literal(4.0, F64), w(f()), F64), w(neigh), F64)
+
+    def flux(di, dj):
+        cond = B(">", B("*", A("res"), w(B("-", f(di, dj), f(), dt)), F64), zero, BOOL)
+        return ir.TernaryOp(cond, zero, A("res"), F64)
+
+    div = B("-", B("+", B("-", A("flx_field"), A("flx_field", -1, 0), F64), A("fly_field"), F64), A("fly_field", 0, -1), F64)
+    out = B("-", w(f()), B("*", w(A("coeff", dt=dt)), div, F64), F64)
+    if dt != F64:
+        out = ir.Cast(out, dt)
+    body = (
+        ir.Assign(A("lap_field"), lap),
+        ir.Assign(A("res"), B("-", A("lap_field", 1, 0), A("lap_field"), F64)),
+        ir.Assign(A("flx_field"), flux(1, 0)),
+        ir.Assign(A("res"), B("-", A("lap_field", 0, 1), A("lap_field"), F64)),
+        ir.Assign(A("fly_field"), flux(0, 1)),
+        ir.Assign(A("out_field", dt=dt), out),
+    )
+    st = ir.Stencil("hdiff_by_hand",
+                    (ir.FieldDecl("in_field", dt), ir.FieldDecl("out_field", dt), ir.FieldDecl("coeff", dt)), (),
+                    tuple(ir.FieldDecl(n, F64, is_api=False) for n in ("lap_field", "res", "flx_field", "fly_field")),
+                    (ir.Computation(ir.LoopOrder.PARALLEL, (ir.IntervalBlock(FULL, body),)),))
+    z = ((0, 0), (0, 0))
+    # block extent of every statement (utils.py:293-313, visited last to first) and the extents read of every field.
+    # The ONE symbol `res` accumulates what both of its readers need, so its first assignment runs on the union
+    # I(-1, 0) x J(-1, 0) -- a superset of what flx reads of it; values are unaffected.
+    blocks = [((-1, 1), (-1, 1)), ((-1, 0), (-1, 0)), ((-1, 0), (0, 0)), ((0, 0), (-1, 0)), ((0, 0), (-1, 0)), z]
+    fields = {"in_field": ((-2, 2), (-2, 2)), "coeff": z, "out_field": z, "lap_field": ((-1, 1), (-1, 1)),
+              "res": ((-1, 0), (-1, 0)), "flx_field": ((-1, 0), (0, 0)), "fly_field": ((0, 0), (-1, 0))}
+    return st, analysis.ExtentInfo(fields, blocks)
+
+
+def hand_built_tridiag(dt=F64):
+    def den():
+        return B("-", A("diag", dt=dt), B("*", A("sup", 0, 0, -1, dt), A("inf", dt=dt), dt), dt)
+
+    fwd = ir.Computation(ir.LoopOrder.FORWARD, (
+        ir.IntervalBlock(interval(0, 1), (ir.Assign(A("sup", dt=dt), B("/", A("sup", dt=dt), A("diag", dt=dt), dt)),
+                                          ir.Assign(A("rhs", dt=dt), B("/", A("rhs", dt=dt), A("diag", dt=dt), dt)))),
+        ir.IntervalBlock(interval(1, None), (
+            ir.Assign(A("sup", dt=dt), B("/", A("sup", dt=dt), den(), dt)),
+            ir.Assign(A("rhs", dt=dt), B("/", B("-", A("rhs", dt=dt), B("*", A("inf", dt=dt), A("rhs", 0, 0, -1, dt), dt), dt), den(), dt)))),
+    ))
+    bwd = ir.Computation(ir.LoopOrder.BACKWARD, (
+        ir.IntervalBlock(interval(-1, None), (ir.Assign(A("out", dt=dt), A("rhs", dt=dt)),)),
+        ir.IntervalBlock(interval(0, -1), (
+            ir.Assign(A("out", dt=dt), B("-", A("rhs", dt=dt), B("*", A("sup", dt=dt), A("out", 0, 0, 1, dt), dt), dt)),)),
+    ))
+    st = ir.Stencil("tridiag_by_hand", tuple(ir.FieldDecl(n, dt) for n in ("inf", "diag", "sup", "rhs", "out")), (), (), (fwd, bwd))
+    z = ((0, 0), (0, 0))
+    return st, analysis.ExtentInfo({n: z for n in ("inf", "diag", "sup", "rhs", "out")}, [z] * 6)
+
+
+def test_hand_built_ir_reproduces_the_golden_vectors():
+    st, ext = hand_built_laplacian(F64)
+    out = GOLD["lap_out0"].copy()
+    numpy_backend.run_stencil(st, ext, tuple(GOLD["lap_domain"]),
+                              {"inp": tuple(GOLD["lap_origin_inp"]), "out": tuple(GOLD["lap_origin_out"])},
+                              {"inp": GOLD["lap_inp"], "out": out}, {})
+    assert _same(out, GOLD["lap_out"])
+    for tag, dt in (("f64", F64), ("f32", F32)):
+        st, ext = hand_built_hdiff(dt)
+        o_in, o_cf, o_out = (tuple(o) for o in GOLD[f"hd_{tag}_origins"])
+        out = GOLD[f"hd_{tag}_out0"].copy()
+        numpy_backend.run_stencil(st, ext, tuple(GOLD[f"hd_{tag}_domain"]), {"in_field": o_in, "coeff": o_cf, "out_field": o_out},
+                                  {"in_field": GOLD[f"hd_{tag}_in"], "coeff": GOLD[f"hd_{tag}_coeff"], "out_field": out}, {})
+        assert _same(out, GOLD[f"hd_{tag}_out"])
+    st, ext = hand_built_tridiag()
+    o = tuple(GOLD["tri_origin"])
+    arrays = {"inf": GOLD["tri_inf"], "diag": GOLD["tri_diag"], "sup": GOLD["tri_sup0"].copy(), "rhs": GOLD["tri_rhs0"].copy(),
+              "out": np.zeros_like(GOLD["tri_out"])}
+    numpy_backend.run_stencil(st, ext, tuple(GOLD["tri_domain"]), {n: o for n in arrays}, arrays, {})
+    assert _same(arrays["sup"], GOLD["tri_sup"]) and _same(arrays["rhs"], GOLD["tri_rhs"]) and _same(arrays["out"], GOLD["tri_out"])
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_hand_built_ir_agrees_with_the_handwritten_restatements(seed):
+    rng = np.random.default_rng(seed)
+    for dt in (F64, F32):
+        inp = rng.uniform(-1, 1, (12, 11, 3)).astype(dt)
+        want, got = np.zeros_like(inp), np.zeros_like(inp)
+        if dt == F64:
+            R.laplacian(inp, want)
+        else:  # default float64 literals on float32 fields: ref_numpy.laplacian restates the float32-literal form
+            DBG.laplacian_debug_order(inp, want, domain=(10, 9, 3))
+        st, ext = hand_built_laplacian(dt)
+        numpy_backend.run_stencil(st, ext, (10, 9, 3), {"inp": (1, 1, 0), "out": (1, 1, 0)}, {"inp": inp, "out": got}, {})
+        assert _same(got, want)
+        u = rng.uniform(-10, 10, (13, 12, 2)).astype(dt)
+        c = rng.uniform(0, 0.5, u.shape).astype(dt)
+        want, got = np.zeros_like(u), np.zeros_like(u)
+        R.hdiff(u, want, c)
+        st, ext = hand_built_hdiff(dt)
+        numpy_backend.run_stencil(st, ext, (9, 8, 2), {n: (2, 2, 0) for n in ("in_field", "coeff", "out_field")},
+                                  {"in_field": u, "coeff": c, "out_field": got}, {})
+        assert _same(got, want)
+
+
+def test_the_frontend_builds_exactly_the_hand_written_trees():
+    """If this fails the parser or the upcaster changed what the three hot stencils MEAN."""
+    opts = D.BuildOptions(name="x", module="m", backend_opts={})
+
+    def statements(st):
+        return [(comp.order, block.interval, ir.fmt(stmt.target), ir.fmt(stmt.value), np.dtype(stmt.value.dtype))
+                for comp, block, stmt in st.statements()]
+
+    for defn, build, dts in ((hip_templates.lap_notebook, hand_built_laplacian, (F64, F32)),
+                             (hip_templates.hdiff_limiter_field, hand_built_hdiff, (F64, F32)),
+                             (hip_templates.tridiagonal_solver, hand_built_tridiag, (F64, F32))):
+        for dt in dts:
+            parsed = frontend.parse_stencil(defn, externals={}, dtypes={"T": dt.type}, options=opts)
+            by_hand, ext = build(dt)
+            assert statements(parsed) == statements(by_hand), (defn.__name__, dt)
+            assert [(f.name, f.dtype) for f in parsed.fields] == [(f.name, f.dtype) for f in by_hand.fields]
+            assert {(t.name, np.dtype(t.dtype)) for t in parsed.temporaries} == {(t.name, np.dtype(t.dtype)) for t in by_hand.temporaries}
+            # ... and the extent analysis finds the block extents written down by hand above
+            found = analysis.compute_extents(parsed)
+            assert found.blocks == ext.blocks and {k: found.fields[k] for k in ext.fields} == ext.fields

@@ -56,7 +56,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_stream_copy",
 )
 
-GT4MI_ABI_VERSION = 1
+GT4MI_ABI_VERSION = 2
 
 # gt4mi_status
 OK = 0
@@ -103,9 +103,11 @@ class HaloMsg(ctypes.Structure):
 
 
 class ExecInfo(ctypes.Structure):
-    """``gt4mi_exec_info``: host timestamps of the native call (run_cpp_start/end_time)."""
+    """``gt4mi_exec_info``: host timestamps of the native call (run_cpp_start/end_time) and the interval its kernels
+    spent on the device (run_hip_start/end_time, from a hipEvent pair; both 0.0 when nothing was launched)."""
 
-    _fields_ = [("run_cpp_start_time", ctypes.c_double), ("run_cpp_end_time", ctypes.c_double)]
+    _fields_ = [("run_cpp_start_time", ctypes.c_double), ("run_cpp_end_time", ctypes.c_double),
+                ("run_hip_start_time", ctypes.c_double), ("run_hip_end_time", ctypes.c_double)]
 
 
 class NativeError(RuntimeError):

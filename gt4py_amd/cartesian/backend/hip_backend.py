@@ -233,6 +233,9 @@ class HipStencilObject(StencilObject):
         if exec_info is not None:
             exec_info["run_cpp_start_time"] = info.run_cpp_start_time
             exec_info["run_cpp_end_time"] = info.run_cpp_end_time
+            if info.run_hip_end_time > 0.0:  # device-side interval of this call's kernels (hipEvent pair)
+                exec_info["run_hip_start_time"] = info.run_hip_start_time
+                exec_info["run_hip_end_time"] = info.run_hip_end_time
 
 
 @base.register

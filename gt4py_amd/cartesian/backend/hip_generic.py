@@ -162,13 +162,19 @@ class HipGenericStencilObject(StencilObject):
             rc = lib.gt4mi_launch_batch(n, fns, grids, blocks, arg_ptrs, args_size, stream, info_ref)
             if rc:
                 _lib.check("gt4mi_launch_batch", rc)
+        h0 = h1 = None
         if info is not None and launches:
             t0, t1 = info.run_cpp_start_time, info.run_cpp_end_time
+            if info.run_hip_end_time > 0.0:
+                h0, h1 = info.run_hip_start_time, info.run_hip_end_time
         if cls._gt_device_sync_:
             _lib.check("gt4mi_stream_sync", lib.gt4mi_stream_sync(stream))
         if exec_info is not None and t0 is not None:
             exec_info["run_cpp_start_time"] = t0
             exec_info["run_cpp_end_time"] = t1
+            if h0 is not None:  # device-side interval of all stages of this call (hipEvent pair on the launch stream)
+                exec_info["run_hip_start_time"] = h0
+                exec_info["run_hip_end_time"] = h1
 
     def _prepare(self, arguments: Dict[str, Any], origin, domain):
         """Argument block + launch list [(function, grid, block)] for one (arrays, origins, domain, scalars)."""

@@ -228,6 +228,10 @@ class StencilObject(abc.ABC):
             cpp = exec_info["run_cpp_end_time"] - exec_info["run_cpp_start_time"]
             stats["run_cpp_time"] = cpp
             stats["total_run_cpp_time"] = stats.get("total_run_cpp_time", 0.0) + cpp
+        if "run_hip_end_time" in exec_info:  # hip:mi300 only: time the kernels of the call spent on the device
+            hip = exec_info["run_hip_end_time"] - exec_info["run_hip_start_time"]
+            stats["run_hip_time"] = hip
+            stats["total_run_hip_time"] = stats.get("total_run_hip_time", 0.0) + hip
 
     # ---- the generated wrapper: run --------------------------------------------------------
     def run(self, _domain_, _origin_, exec_info, **fields_and_params) -> None:

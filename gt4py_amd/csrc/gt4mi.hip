@@ -22,13 +22,44 @@ inline double now_seconds() {
     return std::chrono::duration<double>(clock::now().time_since_epoch()).count();
 }
 
+// Brackets one entry point: host timestamps of the (asynchronous) call and, from a hipEvent pair on the launch
+// stream, the time its kernels spent on the device.  Costs nothing when the caller passes no exec_info.
 struct Timer {
     gt4mi_exec_info* info;
-    explicit Timer(gt4mi_exec_info* i) : info(i) {
-        if (info) info->run_cpp_start_time = now_seconds();
+    hipStream_t stream;
+    Timer(gt4mi_exec_info* i, void* s) : info(i), stream(static_cast<hipStream_t>(s)) {
+        if (!info) return;
+        info->run_cpp_start_time = now_seconds();
+        info->run_hip_start_time = info->run_hip_end_time = 0.0;
+        if (events_ready()) (void)hipEventRecord(events()[0], stream);
     }
     ~Timer() {
-        if (info) info->run_cpp_end_time = now_seconds();
+        if (!info) return;
+        info->run_cpp_end_time = now_seconds();
+        if (!events_ready() || hipEventRecord(events()[1], stream) != hipSuccess ||
+            hipEventSynchronize(events()[1]) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        float ms = 0.0f;
+        const double end = now_seconds();
+        if (hipEventElapsedTime(&ms, events()[0], events()[1]) == hipSuccess) {
+            info->run_hip_end_time = end;
+            info->run_hip_start_time = end - (double)ms * 1e-3;
+        }
+    }
+    static hipEvent_t* events() {
+        static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+        return ev;
+    }
+    static bool events_ready() {
+        hipEvent_t* ev = events();
+        if (ev[0] == nullptr)
+            if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
+                ev[0] = ev[1] = nullptr;
+                (void)hipGetLastError();
+            }
+        return ev[0] != nullptr;
     }
 };
 
@@ -60,13 +91,13 @@ int gt4mi_stream_sync(void* stream) {
 int gt4mi_lap5_f64(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int variant,
                    int flags, void* stream, gt4mi_exec_info* info) {
     (void)flags;
-    Timer t(info);
+    Timer t(info, stream);
     return gt4mi::lap5_run<double, double>(domain, inp, out, variant, static_cast<hipStream_t>(stream));
 }
 
 int gt4mi_lap5_f32(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int variant,
                    int flags, void* stream, gt4mi_exec_info* info) {
-    Timer t(info);
+    Timer t(info, stream);
     if (flags & GT4MI_LAP_LITERAL_F32)
         return gt4mi::lap5_run<float, float>(domain, inp, out, variant, static_cast<hipStream_t>(stream));
     return gt4mi::lap5_run<float, double>(domain, inp, out, variant, static_cast<hipStream_t>(stream));
@@ -75,7 +106,7 @@ int gt4mi_lap5_f32(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_
 int gt4mi_hdiff_f64(const int64_t domain[3], const gt4mi_field* in_field, const gt4mi_field* out_field,
                     const gt4mi_field* coeff, double coeff_scalar, int flags, void* stream,
                     gt4mi_exec_info* info) {
-    Timer t(info);
+    Timer t(info, stream);
     return gt4mi::hdiff_run<double>(domain, in_field, out_field, coeff, coeff_scalar, flags,
                                     static_cast<hipStream_t>(stream));
 }
@@ -83,7 +114,7 @@ int gt4mi_hdiff_f64(const int64_t domain[3], const gt4mi_field* in_field, const 
 int gt4mi_hdiff_f32(const int64_t domain[3], const gt4mi_field* in_field, const gt4mi_field* out_field,
                     const gt4mi_field* coeff, double coeff_scalar, int flags, void* stream,
                     gt4mi_exec_info* info) {
-    Timer t(info);
+    Timer t(info, stream);
     return gt4mi::hdiff_run<float>(domain, in_field, out_field, coeff, coeff_scalar, flags,
                                    static_cast<hipStream_t>(stream));
 }
@@ -91,14 +122,14 @@ int gt4mi_hdiff_f32(const int64_t domain[3], const gt4mi_field* in_field, const 
 int gt4mi_tridiag_f64(const int64_t domain[3], const gt4mi_field* inf, const gt4mi_field* diag,
                       const gt4mi_field* sup, const gt4mi_field* rhs, const gt4mi_field* out, void* stream,
                       gt4mi_exec_info* info) {
-    Timer t(info);
+    Timer t(info, stream);
     return gt4mi::tridiag_run<double>(domain, inf, diag, sup, rhs, out, static_cast<hipStream_t>(stream));
 }
 
 int gt4mi_tridiag_f32(const int64_t domain[3], const gt4mi_field* inf, const gt4mi_field* diag,
                       const gt4mi_field* sup, const gt4mi_field* rhs, const gt4mi_field* out, void* stream,
                       gt4mi_exec_info* info) {
-    Timer t(info);
+    Timer t(info, stream);
     return gt4mi::tridiag_run<float>(domain, inf, diag, sup, rhs, out, static_cast<hipStream_t>(stream));
 }
 
@@ -440,7 +471,7 @@ int gt4mi_module_function(gt4mi_module* module, const char* name, void** functio
 
 int gt4mi_launch(void* function, const uint32_t grid[3], const uint32_t block[3], const void* args,
                  size_t args_size, void* stream, gt4mi_exec_info* info) {
-    Timer timer(info);
+    Timer timer(info, stream);
     if (function == nullptr || grid == nullptr || block == nullptr || (args == nullptr && args_size != 0))
         return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "launch: null argument");
     if (grid[0] == 0 || grid[1] == 0 || grid[2] == 0) return GT4MI_OK;  // empty iteration space
@@ -459,7 +490,7 @@ int gt4mi_launch(void* function, const uint32_t grid[3], const uint32_t block[3]
 
 int gt4mi_launch_batch(int n, void* const* functions, const uint32_t* grids, const uint32_t* blocks,
                        const void* const* args, size_t args_size, void* stream, gt4mi_exec_info* info) {
-    Timer timer(info);
+    Timer timer(info, stream);
     if (n < 0 || (n > 0 && (functions == nullptr || grids == nullptr || blocks == nullptr || args == nullptr)))
         return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "launch_batch: null argument");
     for (int l = 0; l < n; ++l) {

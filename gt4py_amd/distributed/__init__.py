@@ -34,11 +34,11 @@ def overlapped_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequen
     ``arguments`` holds the device arrays / scalars by parameter name; ``origin`` the per-field origin
     of the LOCAL compute domain.
     """
-    events = []
+    pending = []  # (exchanger, is_native, handle)
     native = [(name, ex) for name, ex in exchange.items() if isinstance(ex, NativeHaloExchanger)]
     for name, ex in exchange.items():
         if not isinstance(ex, NativeHaloExchanger):
-            events.append((ex, ex.start(arguments[name].tensor)))
+            pending.append((ex, False, ex.start(arguments[name].tensor)))
     # The exchange is enqueued BEFORE the interior kernel: its pack and send/recv kernels get onto the device
     # while it is idle.  Once the interior kernel saturates HBM, the few workgroups of a send/recv kernel see
     # loaded-memory latency and crawl (measured: 13 us alone, 170 us next to a 185 us hdiff interior), so
@@ -46,15 +46,15 @@ def overlapped_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequen
     for name, ex in native:  # pack + RCCL + unpack on the side stream inside one C call
         ex.fork()
         ex.begin(arguments[name])
-        events.append((ex, None))
+        pending.append((ex, True, None))
     (shift, sub), strips = decomp.interior_and_strips()
     if all(d > 0 for d in sub):
         stencil.run(_domain_=tuple(sub), _origin_=_shifted(origin, shift), exec_info=None, **arguments)
-    for ex, done in events:
-        if done is None:
+    for ex, is_native, handle in pending:
+        if is_native:
             ex.end()
         else:
-            ex.finish(done)
+            ex.finish(handle)
     for shift, sub in strips:
         stencil.run(_domain_=tuple(sub), _origin_=_shifted(origin, shift), exec_info=None, **arguments)
 

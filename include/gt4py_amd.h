@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GT4MI_ABI_VERSION 1
+#define GT4MI_ABI_VERSION 2
 
 typedef enum gt4mi_status {
     GT4MI_OK = 0,
@@ -52,11 +52,18 @@ typedef struct gt4mi_field {
     int64_t origin[3]; /* index of the first compute-domain point (the `_origin_[name]` entry) */
 } gt4mi_field;
 
-/* Optional host-side timestamps, the counterpart of exec_info["run_cpp_start_time"/"..end_time"]
- * (gtc_common.py:83-99).  Seconds from a monotonic clock. May be NULL. */
+/* Optional timestamps, seconds of the monotonic clock (CLOCK_MONOTONIC = Python's time.perf_counter()).  May be NULL.
+ *   run_cpp_*  the counterpart of exec_info["run_cpp_start_time"/"..end_time"] (gtc_common.py:83-99): they bracket
+ *              the native call.  Launches are asynchronous here, so this is the time to ENQUEUE the work.
+ *   run_hip_*  the time the work spent on the device, from a hipEvent pair on the launch stream: the interval ends
+ *              when the host saw the stop event complete and is as long as the events measured.  Passing a
+ *              non-NULL struct therefore makes the call wait for its own kernels (and only then).
+ * Invariant: run_cpp_start_time <= run_hip_start_time <= run_hip_end_time. */
 typedef struct gt4mi_exec_info {
     double run_cpp_start_time;
     double run_cpp_end_time;
+    double run_hip_start_time;
+    double run_hip_end_time;
 } gt4mi_exec_info;
 
 /* ---- library ------------------------------------------------------------------------------- */

@@ -57,8 +57,16 @@ def test_argument_errors_are_reported_without_touching_the_gpu():
     assert rc == _lib.ERR_OUT_OF_BOUNDS and b"origin" in lib.gt4mi_last_error()
     # bad variant
     h = _lib.Field.make(0x1000, (8, 8, 4), (8, 64, 512), (1, 1, 0))
-    rc = lib.gt4mi_lap5_f64(dom, ctypes.byref(h), ctypes.byref(h), 99, 0, None, None)
+    h_out = _lib.Field.make(0x100000, (8, 8, 4), (8, 64, 512), (1, 1, 0))
+    rc = lib.gt4mi_lap5_f64(dom, ctypes.byref(h), ctypes.byref(h_out), 99, 0, None, None)
     assert rc == _lib.ERR_INVALID_ARGUMENT
+    # output overlapping the input: refused before anything is launched (the reference evaluates the right-hand
+    # side before it assigns, npir_codegen.py:205-210; an in-place kernel cannot)
+    rc = lib.gt4mi_lap5_f64(dom, ctypes.byref(h), ctypes.byref(h), 0, 0, None, None)
+    assert rc == _lib.ERR_UNSUPPORTED and b"overlap in memory" in lib.gt4mi_last_error()
+    shifted = _lib.Field.make(0x1000 + 8 * 64 * 2, (8, 8, 4), (8, 64, 512), (1, 1, 0))
+    rc = lib.gt4mi_lap5_f64(dom, ctypes.byref(h), ctypes.byref(shifted), 0, 0, None, None)
+    assert rc == _lib.ERR_UNSUPPORTED and b"overlap in memory" in lib.gt4mi_last_error()
     # tridiagonal needs at least two levels (min_sequential_axis_size)
     t = _lib.Field.make(0x1000, (4, 4, 1), (8, 32, 128), (0, 0, 0))
     refs = [ctypes.byref(t)] * 5

@@ -66,6 +66,10 @@ def _check_exec_info(exec_info, native):
     assert exec_info["call_end_time"] > exec_info["run_end_time"]
     if native:
         assert exec_info["run_cpp_end_time"] >= exec_info["run_cpp_start_time"]
+        # device-side interval of the call's kernels (hipEvent pair), nested in the run bracket like run_cpp_*
+        assert exec_info["run_start_time"] <= exec_info["run_cpp_start_time"] <= exec_info["run_hip_start_time"]
+        assert exec_info["run_hip_start_time"] < exec_info["run_hip_end_time"] <= exec_info["run_end_time"]
+        assert 1e-6 < exec_info["run_hip_end_time"] - exec_info["run_hip_start_time"] < 1.0
     assert exec_info["origin"] == {"_all_": (3, 3, 0), "in_phi": (3, 3, 0), "out_phi": (3, 3, 0)}
     assert exec_info["domain"] == (NX - 6, NY - 6, NZ)
 
@@ -86,6 +90,10 @@ def _check_stencil_info(exec_info, info, nt, native, last_called_stencil=False):
             assert np.isclose(info["run_cpp_time"], exec_info["run_cpp_end_time"] - exec_info["run_cpp_start_time"])
         assert info["run_time"] > info["run_cpp_time"]
         assert info["total_run_cpp_time"] == info["run_cpp_time"] if nt == 1 else info["total_run_cpp_time"] > info["run_cpp_time"]
+        if last_called_stencil:
+            assert np.isclose(info["run_hip_time"], exec_info["run_hip_end_time"] - exec_info["run_hip_start_time"])
+        assert info["run_time"] > info["run_hip_time"] > 0.0
+        assert info["total_run_hip_time"] == info["run_hip_time"] if nt == 1 else info["total_run_hip_time"] > info["run_hip_time"]
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -218,3 +226,30 @@ def test_lazy_stencil_builds_on_first_use_and_is_callable(backend):
     broken = gtscript.lazy_stencil(backend=backend, definition=wrong_syntax_stencil_definition)
     with pytest.raises(GTScriptDefinitionError):
         broken.implementation  # noqa: B018
+
+
+@pytest.mark.gpu
+def test_exec_info_device_time_scales_with_the_work():
+    """``run_hip_*`` is time on the DEVICE: for the 512^3 Laplacian it is the kernel's 0.3-0.5 ms, while ``run_cpp_*``
+    (an asynchronous launch) stays in the tens of microseconds; without ``exec_info`` no event is recorded and the call
+    does not wait (covered by the hipGraph capture test, which would fail on a synchronising call)."""
+    from gt4py_amd.cartesian.backend import hip_templates
+
+    lap = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64}, device_sync=False)
+    big = gt_storage.zeros((514, 514, 512), backend="hip:mi300", aligned_index=(1, 1, 0))
+    out = gt_storage.zeros((514, 514, 512), backend="hip:mi300", aligned_index=(1, 1, 0))
+    small = gt_storage.zeros((34, 34, 4), backend="hip:mi300", aligned_index=(1, 1, 0))
+    out_small = gt_storage.zeros((34, 34, 4), backend="hip:mi300", aligned_index=(1, 1, 0))
+    times = {}
+    for name, (a, b) in (("big", (big, out)), ("small", (small, out_small))):
+        best = None
+        for _ in range(5):
+            info = {}
+            lap(a, b, origin=(1, 1, 0), exec_info=info)
+            hip = info["run_hip_end_time"] - info["run_hip_start_time"]
+            cpp = info["run_cpp_end_time"] - info["run_cpp_start_time"]
+            best = (hip, cpp) if best is None or hip < best[0] else best
+        times[name] = best
+    assert 2.5e-4 < times["big"][0] < 2e-3, times           # ~0.36 ms of kernel
+    assert times["small"][0] < times["big"][0] / 5, times    # a 32 x 32 x 4 domain is launch latency only
+    assert times["big"][1] < times["big"][0], times          # the launch call returns before the kernel has finished

@@ -105,6 +105,56 @@ def _ranges_disjoint(ranges: List[Tuple[int, int]]) -> bool:
     return all(ranges[n][1] <= ranges[n + 1][0] for n in range(len(ranges) - 1))
 
 
+def _access_profile(plan):
+    """(names the stencil writes, names it accesses anywhere at a non-zero or run-time offset); cached on the plan."""
+    cached = getattr(plan, "_gt_access_profile", None)
+    if cached is None:
+        from .. import ir
+
+        written, shifted = set(), set()
+        for _, _, stmt in plan.stencil.statements():
+            written.add(stmt.target.name)
+            for e in (stmt.target, *ir.stmt_reads(stmt)):
+                if isinstance(e, ir.FieldAccess) and (any(e.offset) or e.koffset is not None or e.absolute_k):
+                    shifted.add(e.name)
+        cached = (frozenset(written), frozenset(shifted))
+        try:
+            plan._gt_access_profile = cached
+        except AttributeError:  # a frozen plan object: recompute next time
+            pass
+    return cached
+
+
+def _check_aliases(plan, names: List[str], spans: List[Tuple[int, int]], views) -> bool:
+    """Arguments whose memory overlaps.  The reference's numpy backend evaluates a right-hand side completely before it
+    assigns (npir_codegen.py:205-210), so a call like ``stencil(a, a)`` is well defined there.  The kernels here read
+    and write concurrently and keep values in registers by NAME, so only what cannot depend on the order of evaluation
+    is run: read-only arguments may overlap freely (returns True: nothing written is involved); a WRITTEN field may
+    share its elements one to one with a read-only field when the stencil touches both at zero offsets only (returns
+    False: the variant without ``__restrict__`` and without loads hoisted ahead of stores).  Everything else raises
+    instead of returning a different answer."""
+    written, shifted = _access_profile(plan)
+    involved = False
+    for a in range(len(names)):
+        for b in range(a + 1, len(names)):
+            na, nb = names[a], names[b]
+            if not (spans[a][0] < spans[b][1] and spans[b][0] < spans[a][1]):
+                continue
+            if na not in written and nb not in written:
+                continue
+            involved = True
+            w, x = (na, nb) if na in written else (nb, na)
+            if views[na] != views[nb]:
+                raise ValueError(f"fields '{na}' and '{nb}' overlap in memory without being the same elements, and the "
+                                 f"stencil writes '{w}': the result would depend on the order of evaluation")
+            if x in written or w in shifted or x in shifted:
+                raise ValueError(f"fields '{na}' and '{nb}' are the same array, and the stencil "
+                                 + (f"writes both" if x in written else f"writes '{w}' and reads at an offset")
+                                 + ": the reference evaluates each right-hand side before it assigns, which kernels that "
+                                   "read and write concurrently cannot reproduce -- pass separate arrays")
+    return not involved
+
+
 class HipGenericStencilObject(StencilObject):
     """StencilObject whose ``run`` launches run-time compiled gfx950 kernels, one per stage."""
 
@@ -130,7 +180,8 @@ class HipGenericStencilObject(StencilObject):
         # 20-50 us of Python, a cached call ~10 us.  Arrays are remembered by identity through weak
         # references, so a recycled id() can never alias a dead array.
         try:
-            ckey = (dI, dJ, dK, tuple(id(arguments[d.name]) for d in plan.api_fields),
+            # ... and per stream: temporaries live in a scratch buffer that concurrent streams must not share
+            ckey = (stream, dI, dJ, dK, tuple(id(arguments[d.name]) for d in plan.api_fields),
                     tuple(tuple(origin[d.name]) for d in plan.api_fields), tuple(arguments[p.name] for p in plan.params))
             entry = cls._gt_launch_cache_.get(ckey)
         except TypeError:  # an unhashable scalar
@@ -138,7 +189,7 @@ class HipGenericStencilObject(StencilObject):
         if entry is not None and all(r() is arguments[n] for n, r in entry[0]):
             _, args, launches, _keep = entry
         else:
-            args, launches, _keep = self._prepare(arguments, origin, (dI, dJ, dK))
+            args, launches, _keep = self._prepare(arguments, origin, (dI, dJ, dK), stream)
             keep = _keep
             if ckey is not None:
                 try:
@@ -176,8 +227,8 @@ class HipGenericStencilObject(StencilObject):
                 exec_info["run_hip_start_time"] = h0
                 exec_info["run_hip_end_time"] = h1
 
-    def _prepare(self, arguments: Dict[str, Any], origin, domain):
-        """Argument block + launch list [(function, grid, block)] for one (arrays, origins, domain, scalars)."""
+    def _prepare(self, arguments: Dict[str, Any], origin, domain, stream=None):
+        """Argument block + launch list [(function, grid, block)] for one (arrays, origins, domain, scalars, stream)."""
         cls = type(self)
         program = cls._gt_program_
         plan = program.plan
@@ -187,6 +238,7 @@ class HipGenericStencilObject(StencilObject):
         args = program.args_struct()
         unit_i = True
         spans: List[Tuple[int, int]] = []
+        views: Dict[str, Tuple[int, Tuple[int, ...], int]] = {}  # name -> (origin pointer, byte strides, itemsize)
         geometry: Dict[str, Tuple[int, int, int, int]] = {}  # name -> (origin pointer, sj, sk, itemsize)
         for decl in plan.api_fields:
             arr = arguments[decl.name]
@@ -208,8 +260,12 @@ class HipGenericStencilObject(StencilObject):
             hi = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s > 0) + isz
             lo = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s < 0)
             spans.append((arr.ptr + lo, arr.ptr + hi))
+            views[decl.name] = (ptr, tuple(arr.strides), isz)
         if plan.scratch:
-            key = (dI, dJ, dK)
+            # One scratch buffer per (stream, domain): two calls of the stencil enqueued on different HIP streams run
+            # concurrently and must not write each other's temporaries.  The buffer is allocated while `stream` is
+            # the current stream, which is also the stream PyTorch's caching allocator orders its reuse on.
+            key = (stream, dI, dJ, dK)
             entry = cls._gt_scratch_.get(key)
             if entry is None:
                 layout, total = {}, 0
@@ -229,8 +285,11 @@ class HipGenericStencilObject(StencilObject):
                     layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
                     total += nbytes
                 buf = torch.empty(total + PLACEMENT_PERIOD, dtype=torch.uint8, device="cuda")
-                cls._gt_scratch_.clear()  # one domain at a time: scratch can be gigabytes ...
-                cls._gt_launch_cache_.clear()  # ... and cached launch plans keep theirs alive
+                # one domain at a time per stream: scratch can be gigabytes, and cached launch plans keep theirs alive
+                for old_key in [k for k in cls._gt_scratch_ if k[0] == stream]:
+                    del cls._gt_scratch_[old_key]
+                for old_key in [k for k in cls._gt_launch_cache_ if k[0] == stream]:
+                    del cls._gt_launch_cache_[old_key]
                 entry = cls._gt_scratch_[key] = (buf, layout)
             buf, layout = entry
             base = -(-buf.data_ptr() // PLACEMENT_PERIOD) * PLACEMENT_PERIOD
@@ -253,7 +312,8 @@ class HipGenericStencilObject(StencilObject):
         args.dI, args.dJ, args.dK = dI, dJ, dK
         args.k_lo, args.k_hi = 0, dK
 
-        vkey = (unit_i, _ranges_disjoint(spans))
+        no_alias = _ranges_disjoint(spans) or _check_aliases(plan, [d.name for d in plan.api_fields], spans, views)
+        vkey = (unit_i, no_alias)
         variant = cls._gt_variants_.get(vkey)
         if variant is None:
             variant = cls._gt_variants_[vkey] = _Variant(program, *vkey)
@@ -278,7 +338,7 @@ class HipGenericStencilObject(StencilObject):
                 return None
             nk = -(-levels // kern.k_per_thread) if kern.mapping == "ijk" else 1
             lanes = rows = 1
-            if vfn is not None and all(
+            if vfn is not None and no_alias and all(
                     geometry[n][0] % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0
                     and geometry[n][2] % kern.vec == 0 for n in kern.vec_fields):
                 fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned
@@ -316,4 +376,4 @@ class HipGenericStencilObject(StencilObject):
                      (ctypes.c_uint32 * (3 * n))(*[v for _, g, _, _ in launches for v in g]),
                      (ctypes.c_uint32 * (3 * n))(*[v for _, _, b, _ in launches for v in b]),
                      (ctypes.c_void_p * n)(*[ctypes.addressof(a._obj) for _, _, _, a in launches]))
-        return args, launches, (cls._gt_scratch_.get((dI, dJ, dK)), keep_args, batch)
+        return args, launches, (cls._gt_scratch_.get((stream, dI, dJ, dK)), keep_args, batch)

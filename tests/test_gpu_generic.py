@@ -150,3 +150,105 @@ def test_exec_info_and_frozen_call_on_the_generic_path():
     dev2 = {k: gt_storage.from_array(v, backend="hip:mi300", aligned_index=origins[k]) for k, v in arrays.items()}
     frozen(**dev2, **scalars)
     assert np.array_equal(dev2["utens_stage"].get(), first)
+
+
+# ---- arguments that overlap in memory, calls on several streams -------------------------------------------------
+def _alias_definitions():
+    from gt4py_amd.cartesian.gtscript import FORWARD, PARALLEL, Field, computation, interval  # noqa: F401
+
+    def pointwise(a: Field[np.float64], w: Field[np.float64], out: Field[np.float64]):
+        with computation(PARALLEL), interval(...):
+            t = a * 2.0 + w
+            out = t - a if w > 0.0 else t + a
+
+    def shifted(a: Field[np.float64], out: Field[np.float64]):
+        with computation(PARALLEL), interval(...):
+            out = a[1, 0, 0] - a
+
+    def two_outputs(a: Field[np.float64], b: Field[np.float64], c: Field[np.float64]):
+        with computation(PARALLEL), interval(...):
+            b = a + 1.0
+            c = a - 1.0
+
+    return pointwise, shifted, two_outputs
+
+
+def test_aliased_arguments_follow_the_reference_or_raise():
+    """npir_codegen.py:205-210: the numpy backend evaluates a right-hand side before it assigns, so passing one array
+    for two fields is well defined there.  The generic executor reproduces it where the order of evaluation cannot
+    matter (a written field sharing its elements with a read-only one, all accesses at zero offset) and raises
+    otherwise -- compared with the oracle called on the SAME aliased arrays."""
+    import oracle.numpy_backend  # noqa: F401
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+
+    pointwise, shifted, two_outputs = _alias_definitions()
+    rng = np.random.default_rng(9)
+    a, w = rng.uniform(-1, 1, (40, 9, 5)), rng.uniform(-1, 1, (40, 9, 5))
+    ref = gtscript.stencil(backend="numpy", definition=pointwise)
+    hip = gtscript.stencil(backend="hip:mi300", definition=pointwise)
+    for shared in ("a", "w"):
+        host = {"a": a.copy(), "w": w.copy()}
+        host["out"] = host[shared]
+        ref(host["a"], host["w"], host["out"])
+        dev = {"a": gt_storage.from_array(a, backend="hip:mi300"), "w": gt_storage.from_array(w, backend="hip:mi300")}
+        dev["out"] = dev[shared]
+        hip(dev["a"], dev["w"], dev["out"])
+        for n in ("a", "w"):
+            np.testing.assert_array_equal(dev[n].get(), host[n], err_msg=f"out is {shared}: field {n}")
+    # read-only arguments may be the same array
+    dev_a = gt_storage.from_array(a, backend="hip:mi300")
+    dev_o = gt_storage.zeros(a.shape, backend="hip:mi300")
+    want = np.zeros_like(a)
+    ref(a, a, want)
+    hip(dev_a, dev_a, dev_o)
+    np.testing.assert_array_equal(dev_o.get(), want)
+    # a written field that is read at an offset through its alias: refused, untouched
+    sh = gtscript.stencil(backend="hip:mi300", definition=shifted)
+    dev_a = gt_storage.from_array(a, backend="hip:mi300")
+    with pytest.raises(ValueError, match="same array"):
+        sh(dev_a, dev_a, origin=(0, 0, 0), domain=(39, 9, 5))
+    # ... or through a shifted view of the same buffer
+    pw = gtscript.stencil(backend="hip:mi300", definition=pointwise)
+    with pytest.raises(ValueError, match="overlap in memory"):
+        pw(dev_a, dev_o, dev_a, origin={"a": (0, 0, 0), "w": (0, 0, 0), "out": (1, 0, 0)}, domain=(39, 9, 5))
+    # two outputs in one array: the reference keeps the second assignment; refused here
+    two = gtscript.stencil(backend="hip:mi300", definition=two_outputs)
+    with pytest.raises(ValueError, match="writes both"):
+        two(dev_a, dev_o, dev_o)
+    np.testing.assert_array_equal(dev_a.get(), a)
+
+
+def test_calls_on_two_streams_do_not_share_scratch():
+    """A stencil with temporaries in scratch memory, launched on two HIP streams at once with different inputs: each
+    stream has its own scratch buffer, so both results equal the oracle's."""
+    import torch
+
+    import oracle.numpy_backend  # noqa: F401
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+
+    defn, externals, scalars, opts = zoo.ZOO["two_stage_written_input"]
+    ref = gtscript.stencil(backend="numpy", definition=defn, externals=externals)
+    hip = gtscript.stencil(backend="hip:mi300", definition=defn, externals=externals, device_sync=False, **opts)
+    assert type(hip)._gt_program_.plan.scratch, "the case must use scratch memory"
+    domain = (256, 192, 24)
+    for round_ in range(3):
+        cases = []
+        for seed in (10 * round_ + 1, 10 * round_ + 2):
+            arrays, origins = zoo.make_inputs(ref, domain, seed)
+            expect = {k: v.copy() for k, v in arrays.items()}
+            ref(**expect, **scalars, origin=origins, domain=domain)
+            dev = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=origins[k])
+                   for k, v in arrays.items()}
+            cases.append((expect, dev, origins))
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()] if round_ == 0 else streams
+        torch.cuda.synchronize()
+        for (expect, dev, origins), st in zip(cases, streams):
+            with torch.cuda.stream(st):
+                hip(**dev, **scalars, origin=origins, domain=domain)
+        torch.cuda.synchronize()
+        for expect, dev, _ in cases:
+            for k in expect:
+                np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"round {round_}: field {k}")
+    assert len({k[0] for k in type(hip)._gt_scratch_}) == 2, "one scratch buffer per stream"

@@ -195,22 +195,22 @@ GT_DEV void gt_tile(unsigned rows, unsigned& bx, unsigned& by, unsigned& bz) {
 }
 // 16-byte lanes: a lane owns N consecutive I points; the points next to them sit in the neighbouring
 // lanes' registers and are fetched with whole-wave DPP shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1,
-// no LDS).  Lanes shifted in from outside the wave read 0 -- callers overwrite those lanes.
+// no LDS).  bound_ctrl: lanes shifted in from outside the wave read 0 without an extra move -- callers overwrite those lanes.
 template <class T, int N> using gt_vec = T __attribute__((ext_vector_type(N)));
 template <class T, bool FROM_BELOW> GT_DEV T gt_shift(T v) {
     if constexpr (sizeof(T) == 4) {
         const int b = __builtin_bit_cast(int, v);
-        const int r = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, b, 0x138, 0xF, 0xF, false)
-                                 : __builtin_amdgcn_update_dpp(0, b, 0x130, 0xF, 0xF, false);
+        const int r = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, b, 0x138, 0xF, 0xF, true)
+                                 : __builtin_amdgcn_update_dpp(0, b, 0x130, 0xF, 0xF, true);
         return __builtin_bit_cast(T, r);
     } else {
         static_assert(sizeof(T) == 8, "gt_shift: 4- or 8-byte types");
         const long long b = __builtin_bit_cast(long long, v);
         int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
-        lo = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, false)
-                        : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, false);
-        hi = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, false)
-                        : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, false);
+        lo = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xF, 0xF, true)
+                        : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, true);
+        hi = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, true)
+                        : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, true);
         return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned int)lo);
     }
 }

@@ -349,6 +349,57 @@ static void hdiff_suite(int dI, int dJ, int dK, const char* tag) {
     }
 }
 
+template <typename T, typename W, int VEC, int LJ, int PF, int XCDG>
+static void hdiff_variant_w(const DevField<T>& in, DevField<T>& out, const DevField<T>& cf, int dI, int dJ, int dK, const char* tag) {
+    constexpr int H = (VEC >= 2) ? 1 : 2;
+    const unsigned waves_i = (unsigned)cdiv(dI, (64 - 2 * H) * VEC), tiles_j = (unsigned)cdiv(dJ, LJ);
+    const unsigned groups_j = (unsigned)cdiv(tiles_j, 4);
+    const unsigned nb = waves_i * groups_j * dK;
+    char cfg[96];
+    snprintf(cfg, sizeof cfg, "%s %s-internal VEC=%d LJ=%d PF=%d xcd=%d", tag, sizeof(W) == 4 ? "f32" : "f64", VEC, LJ, PF, XCDG);
+    const double ms = time_ms([&](int) {
+        hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, W, true, true, VEC, LJ, PF, XCDG>), dim3(nb), dim3(256), 0, 0,
+                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, groups_j);
+    }, 20);
+    report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, 3.0 * sizeof(T));
+}
+
+// f32 fields with f32 literals (literal_float_precision=32) next to the default f64 internals, and short queues
+static void section_hdiff2() {
+    {
+        const int dI = 1024, dJ = 1024, dK = 80;
+        DevField<float> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+        fill(in, 2024, 1.0, 9.0);
+        fill(cf, 7, 0.0, 0.05);
+        for (int rep = 0; rep < 2; ++rep) {
+            hdiff_variant_w<float, double, 4, 6, 6, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 8, 8, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 8, 6, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 8, 4, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 4, 4, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 8, 8, 2>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, float, 4, 6, 6, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, float, 4, 8, 8, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, float, 4, 16, 8, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, float, 4, 12, 12, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+        }
+    }
+    {
+        const int dI = 512, dJ = 1024, dK = 80;
+        DevField<double> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+        fill(in, 2024, 1.0, 9.0);
+        fill(cf, 7, 0.0, 0.05);
+        for (int rep = 0; rep < 2; ++rep) {
+            hdiff_variant_w<double, double, 2, 8, 8, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 8, 8, 2>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 8, 6, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 8, 4, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 4, 4, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 16, 16, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
+        }
+    }
+}
+
 static void section_hdiff() {
     hdiff_suite<float>(1024, 1024, 80, "1024x1024x80");
     hdiff_suite<double>(512, 1024, 80, "512x1024x80");
@@ -648,6 +699,7 @@ int main(int argc, char** argv) {
         }
     }
     if (on("hdiff")) section_hdiff();
+    if (!want.empty() && on("hdiff2")) section_hdiff2();
     if (on("tridiag")) section_tridiag();
     if (!want.empty() && on("triplace")) section_triplace(0, want);
     if (!want.empty() && on("tripipe")) section_tripipe();

@@ -11,9 +11,9 @@ resident in HBM.  With N > 1 the SAME 512^3 grid is split over the ranks (strong
 then halo exchange (RCCL send/recv) + kernel(s), see DESIGN.md section 6.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line (see DESIGN.md "Measurement"):
-  roofline      HBM roofline of the dominant kernel: algorithmic bytes (16 B per lattice update) / launch
-                duration measured with HIP events on the launch stream (mean, median and minimum over the
-                timed launches), against the 8.0 TB/s nominal peak; `traffic` = HBM bytes per launch from the
+  roofline      HBM roofline of the dominant kernel: algorithmic bytes (16 B per lattice update) / average launch
+                duration measured with HIP events on the launch stream over K back-to-back launches (median and
+                minimum of a second, per-launch-event pass are reported next to it), against the 8.0 TB/s nominal peak; `traffic` = HBM bytes per launch from the
                 committed rocprofv3 PMC measurement IF it was taken on the kernel sources of this tree
                 (profiles/hbm_traffic.json carries their hash), else null.
   cpu_baseline  the oracle's C/OpenMP restatement of gt:cpu_ifirst semantics (kind "port") timed on this
@@ -53,7 +53,8 @@ GRID = (512, 512, 512)
 HDIFF_SHARE = (512, 1024, 80)  # per-rank share of BASELINE.json configs[4]
 HDIFF_GLOBAL = (2048, 2048, 80)
 KERNEL_SOURCES = {  # the files whose contents decide what a kernel does, per profiled workload
-    "lap5_f64_512": ("gt4py_amd/csrc/lap5.hip.h", "gt4py_amd/csrc/common.hip.h", "gt4py_amd/csrc/Makefile"),
+    "lap5_f64_512": ("gt4py_amd/csrc/lap5.hip.h", "gt4py_amd/csrc/lane_shift.hip.h", "gt4py_amd/csrc/common.hip.h",
+                     "gt4py_amd/csrc/Makefile"),
 }
 
 
@@ -118,10 +119,22 @@ def _device_fields(shape, n_pairs, seed, origin=(1, 1, 0)):
 
 
 def _time_launches(fn, steps):
-    """Durations (ms) of `steps` back-to-back launches from HIP events on the launch stream, one event between
-    every two launches: {"mean", "median", "min", "max", "n"} (median and minimum)."""
+    """Launch durations (ms) from HIP events on the launch stream.
+
+    "mean": `steps` launches back to back between ONE event pair -- the average launch duration the roofline is
+    computed from (what `rocprofv3 --kernel-trace --stats` reports as the kernel's average).  "median" / "min" /
+    "max": a second pass with an event between every two launches (SURVEY.md section 8d asks for median and
+    minimum); an event is a barrier packet, so consecutive kernels cannot overlap their tail and head there and
+    these run 1-3 % above the back-to-back mean for kernels of 0.2-0.4 ms."""
     import torch
 
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(steps):
+        fn(i)
+    b.record()
+    b.synchronize()
+    mean = a.elapsed_time(b) / steps
     events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     events[0].record()
     for i in range(steps):
@@ -129,8 +142,7 @@ def _time_launches(fn, steps):
         events[i + 1].record()
     events[-1].synchronize()
     per = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
-    return {"mean": events[0].elapsed_time(events[-1]) / steps, "median": statistics.median(per), "min": min(per),
-            "max": max(per), "n": steps}
+    return {"mean": mean, "median": statistics.median(per), "min": min(per), "max": max(per), "n": steps}
 
 
 def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30) -> float:
@@ -152,7 +164,7 @@ def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30) -> float:
     for i in range(2):
         call(i)
     torch.cuda.synchronize()
-    ms = _time_launches(call, steps)["median"]
+    ms = _time_launches(call, steps)["mean"]
     return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
@@ -178,27 +190,33 @@ def other_kernels(steps: int = 20):
     def run(name, obj, fields, origin, domain, bytes_per_lup, scalars=None, note=None):
         frozen = obj.freeze(origin=origin, domain=domain)
         call = lambda i: frozen(**fields, **(scalars or {}))  # noqa: E731
-        for i in range(3):
+        for i in range(10):
             call(i)
         torch.cuda.synchronize()
         t = _time_launches(call, steps)
-        ms = t["median"]
+        ms = t["mean"]
         lups = float(np.prod(domain))
         gbs = bytes_per_lup * lups / (ms * 1e-3) / 1e9
-        out[name] = {"domain": list(domain), "ms": round(ms, 4), "ms_min": round(t["min"], 4), "ms_mean": round(t["mean"], 4),
+        out[name] = {"domain": list(domain), "ms": round(ms, 4), "ms_median": round(t["median"], 4), "ms_min": round(t["min"], 4),
                      "glups": round(lups / ms / 1e6, 1), "algorithmic_bytes_per_lup": bytes_per_lup,
                      "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4)}
         if note:
             out[name]["note"] = note
 
-    for tag, dt, dom in (("hdiff_limiter_f32_1024x1024x80", np.float32, (1024, 1024, 80)),
-                         ("hdiff_limiter_f64_512x1024x80", np.float64, HDIFF_SHARE)):
+    for tag, dt, dom, lit, note in (
+            ("hdiff_limiter_f32_1024x1024x80", np.float32, (1024, 1024, 80), 64,
+             "BASELINE.json configs[2] with the reference's default float64 literals: lap / flx / fly are float64 "
+             "temporaries, every float32 operand is widened where it meets one (gtir_upcaster.py:43-143)"),
+            ("hdiff_limiter_f32_literal32_1024x1024x80", np.float32, (1024, 1024, 80), 32,
+             "the same stencil built with literal_float_precision=32: float32 throughout (what a model that runs in "
+             "single precision sets); different arithmetic, so a different stencil -- shown next to the default"),
+            ("hdiff_limiter_f64_512x1024x80", np.float64, HDIFF_SHARE, 64, "the per-rank share of BASELINE.json configs[4]")):
         obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": dt},
-                               device_sync=False)
+                               device_sync=False, literal_float_precision=lit)
         shape = (dom[0] + 4, dom[1] + 4, dom[2])
         fields = {"in_field": field(shape, dt, (2, 2, 0), 0.0, 10.0), "coeff": field(shape, dt, (2, 2, 0), 0.0, 0.05),
                   "out_field": field(shape, dt, (2, 2, 0))}
-        run(tag, obj, fields, {k: (2, 2, 0) for k in fields}, dom, 3.0 * np.dtype(dt).itemsize)
+        run(tag, obj, fields, {k: (2, 2, 0) for k in fields}, dom, 3.0 * np.dtype(dt).itemsize, note=note)
         del fields
     dom = (1024, 1024, 160)
     obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64},
@@ -750,7 +768,7 @@ def main() -> None:
         kernel_step(i)
     torch.cuda.synchronize()
     kt = _time_launches(kernel_step, max(args.steps, 10))
-    kernel_ms = kt["median"]
+    kernel_ms = kt["mean"]
     local_lups = float(np.prod(local_domain))
     achieved = bytes_per_lup * local_lups / (kernel_ms * 1e-3) / 1e9
     ms_per_step = elapsed / args.steps * 1e3

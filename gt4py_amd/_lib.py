@@ -51,6 +51,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_module_load",
     "gt4mi_module_unload",
     "gt4mi_module_function",
+    "gt4mi_function_info",
     "gt4mi_launch",
     "gt4mi_launch_batch",
     "gt4mi_stream_copy",
@@ -193,6 +194,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_module_unload.argtypes = [P]
     lib.gt4mi_module_function.restype = I
     lib.gt4mi_module_function.argtypes = [P, ctypes.c_char_p, PP]
+    lib.gt4mi_function_info.restype = I
+    lib.gt4mi_function_info.argtypes = [P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     U3 = ctypes.POINTER(ctypes.c_uint32)
     lib.gt4mi_launch.restype = I
     lib.gt4mi_launch.argtypes = [P, U3, U3, P, SZ, P, EI]

@@ -74,7 +74,16 @@ TUNING = {
     # ... and consecutive J rows per lane in those kernels: rows (and recomputed temporaries) shared by
     # neighbouring output rows are loaded (computed) once per strip
     "vector_rows": _env_tuple("GT4MI_CODEGEN_VECTOR_ROWS", (4,))[0],
+    # two-sweep column stages (stage_planner.TopCache): levels of the forward sweep's results kept in registers and,
+    # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup); (0, 0) = off
+    # 16 register levels: the vertical advection needs 344 of the 512 registers a lone wave per SIMD may use; from 24
+    # levels on the compiler spills to scratch (it keeps ~10 values per unrolled level alive, addresses included).  The
+    # host checks the compiled kernel and does not launch a variant that spills (hip_generic._Variant).
+    "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (16, 160 * 1024)),
 }
+
+#: levels of the register range of a `_tc` kernel between two scheduling fences (loads may move up within a group)
+TC_SCHED_LEVELS = 4
 
 from .stage_planner import (Nest, Plan, Stage, Stmt, UnsupportedStencil, _field_reads, _stmt_field_reads,  # noqa: F401
                             inline_horizontal_temporaries, plan_stages)
@@ -255,6 +264,9 @@ class KernelSource:
     vec_fields: Tuple[str, ...] = ()  # arrays whose alignment / strides decide whether it may be launched
     vec_rows: int = 1  # consecutive J rows per lane in the `_vec` kernel
     plane: Optional[Tuple[int, str, ir.Interval]] = None  # launched once per K level by the host (Stage.plane)
+    #: (register levels, LDS levels, smallest domain K): a `<name>_tc` kernel exists that keeps the top levels of a
+    #: two-sweep column stage on chip; the host launches it when the domain has at least that many levels
+    top_cache: Optional[Tuple[int, int, int]] = None
 
 
 @dataclass
@@ -296,6 +308,12 @@ class _Emitter:
         # loads issued ahead of a chunk of K levels: (name, offset, data index) -> register, per statement
         self.prefetched: Dict[Tuple, str] = {}
         self.prefetch_for: Dict[int, Dict[Tuple, str]] = {}
+        # top-of-column cache (kernel variant `_tc`): None, or (TopCache, register levels, LDS levels, threads per
+        # workgroup), and where the level being emitted lives: ("mem",) | ("lds",) | ("reg", slot)
+        self.tc: Optional[Tuple] = None
+        self.tc_mode: Tuple = ("mem",)
+        self.tc_sweep2 = False  # emitting the backward sweep: every cached field is complete, reads come from the cache
+        self.tc_written: Set[str] = set()  # forward sweep: cached fields already assigned at the level being emitted
 
     # -- expressions --------------------------------------------------------------------------
     def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str], store: bool = False) -> str:
@@ -316,6 +334,11 @@ class _Emitter:
         if name in self.plan.register_only:
             raise AssertionError(f"register-only temporary '{name}' needs memory at offset {e.offset}")
         c = _c_ident(name)
+        if (not store and self.tc is not None and self.tc_mode[0] != "mem" and name in self.tc[0].names
+                and tuple(e.offset) == (0, 0, 0) and e.koffset is None and (self.tc_sweep2 or name in self.tc_written)):
+            # the level lives on chip.  (Forward sweep: only once this level has been assigned -- an in/out field is
+            # first READ at the level, and that old value is in memory.)
+            return self.tc_slot(name, k)
         di, dj, dk = e.offset
         axes = self.axes.get(name, ("I", "J", "K"))
         terms = []
@@ -433,17 +456,26 @@ class _Emitter:
         if g:
             self.lines.append(f"{indent}if ({g}) {{")
             pad = indent + "    "
+        on_chip = self.tc is not None and self.tc_mode[0] != "mem" and name in self.tc[0].names
         if name in self.plan.locals:
             self.lines.append(f"{pad}l_{_c_ident(name)}{self.local_suffix} = {value};")
         elif name in carry:  # keep the freshly written level for this iteration's later reads and the next one
             self.lines.append(f"{pad}n_{_c_ident(name)} = {value};")
-            if name not in self.plan.register_only:
+            if on_chip:
+                self.lines.append(f"{pad}{self.tc_slot(name, k)} = n_{_c_ident(name)};")
+            if name not in self.plan.register_only and (not on_chip or name in self.tc[0].store_through):
                 self.lines.append(f"{pad}{self.access(s.target, k, si, reg, store=True)} = n_{_c_ident(name)};")
             reg[(name, 0)] = f"n_{_c_ident(name)}"
+        elif on_chip:
+            self.lines.append(f"{pad}{self.tc_slot(name, k)} = {value};")
+            if name in self.tc[0].store_through:
+                self.lines.append(f"{pad}{self.access(s.target, k, si, reg, store=True)} = {self.tc_slot(name, k)};")
         elif name in self.streaming:
             self.lines.append(f"{pad}__builtin_nontemporal_store({value}, &{self.access(s.target, k, si, reg, store=True)});")
         else:
             self.lines.append(f"{pad}{self.access(s.target, k, si, reg, store=True)} = {value};")
+        if on_chip:
+            self.tc_written.add(name)
         if g:
             self.lines.append(f"{indent}}}")
 
@@ -474,6 +506,14 @@ class _Emitter:
         while open_loops:
             open_loops.pop()
             self.lines.append(f"{indent}{'    ' * len(open_loops)}}}")
+
+    def tc_slot(self, name: str, k: str) -> str:
+        """Where level ``k`` of a cached field lives in the current range of a `_tc` kernel (an lvalue)."""
+        cache, n_reg, n_lds, threads = self.tc
+        c = _c_ident(name)
+        if self.tc_mode[0] == "reg":
+            return f"tc_{c}_{self.tc_mode[1]}"
+        return f"tc_lds_{c}[(({k}) - (a.dK - {n_reg + n_lds})) * {threads} + tc_tid]"
 
     def column_in_extent(self, name: str, stage: Stage) -> Optional[str]:
         """Condition for the thread's column to lie inside the extent ``name`` is accessed on."""
@@ -535,6 +575,9 @@ class _Emitter:
                 if (e.koffset is not None or name in self.plan.locals or name in self.plan.register_only
                         or any(isinstance(d, ir.Expr) for d in e.data_index or ())):
                     continue
+                if (self.tc is not None and self.tc_sweep2 and self.tc_mode[0] != "mem" and name in self.tc[0].names
+                        and tuple(e.offset) == (0, 0, 0)):
+                    continue  # on chip in this range of the backward sweep: nothing to fetch
                 if e.offset[:2] == (0, 0) and name in active and e.offset[2] == back:
                     continue  # served by the forwarded register
                 if name in written:
@@ -573,14 +616,10 @@ class _Emitter:
                         names.append(n)
         return names
 
-    def kernel(self, si: int, stage: Stage, kname: str) -> KernelSource:
+    def _kernel_header(self, stage: Stage, kname: str, block, j_per_thread: int) -> None:
+        """Signature, tile -> (i, j), base pointers of the fields the stage touches."""
         L = self.lines
         (ilo, ihi), (jlo, jhi) = stage.extent
-        if stage.mapping == "ijk":
-            bi, bj, k_per_thread, j_per_thread = (tuple(TUNING["block_ijk"]) + (1,))[:4]
-        else:
-            (bi, bj), k_per_thread, j_per_thread = TUNING["block_column"], 1, 1
-        block = (bi, bj, 1)
         L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}(const gt_args a) {{')
         L.append("    unsigned gt_bx, gt_by, gt_bz;")
         L.append(f"    gt_tile({TUNING['xcd_rows']}u, gt_bx, gt_by, gt_bz);")
@@ -605,6 +644,190 @@ class _Emitter:
             qual = " __restrict__" if n in self.plan.scratch else " GT_RESTRICT"
             off = " + ".join(t for t in (f"i * GT_SI(a.{c}_si)" if "I" in axes else "", f"j * a.{c}_sj" if "J" in axes else "") if t) or "0"
             L.append(f"    {const}{ct}* const{qual} b_{c} = a.{c} + {off};")
+
+    def _column_range(self, si: int, stage: Stage, nest: Nest, group: Sequence[Stmt], active: Sequence[str], back: int,
+                      lo: str, hi: str) -> None:
+        """The K loop of one statement group of a column nest over the levels [lo, hi) (C expressions), in sweep
+        order: chunks of levels whose loads are issued ahead where that is provably safe, else level by level."""
+        L = self.lines
+        backward = nest.order is ir.LoopOrder.BACKWARD
+        stage_fwd = {n: d for (s_i, n), d in self.plan.forwarded.items() if s_i == si}
+
+        def level(kexpr: str, pad: str) -> None:
+            """One K level of the sweep: locals, statements, rotation of the forwarded registers."""
+            self.tc_written = set()
+            self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), pad)
+            carry = [n for n in active if any(s.target.name == n for s in group)]
+            reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
+            for n in carry:
+                L.append(f"{pad}{_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
+            self.statements(group, stage, si, kexpr, reg, pad, carry)
+            for n in active:
+                c = _c_ident(n)
+                if n in carry:
+                    L.append(f"{pad}r_{c} = n_{c};")
+                else:  # only read in this nest: rotate in the level just passed
+                    cond = self.column_in_extent(n, stage)
+                    load = self.access(ir.FieldAccess(n, (0, 0, 0)), kexpr, -1, {})
+                    L.append(f"{pad}{'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
+
+        self._level = level  # (the register range of a `_tc` kernel emits single levels)
+        loop = (f"for (gt_i64 k = ({hi}) - 1; k >= ({lo}); --k)" if backward else f"for (gt_i64 k = ({lo}); k < ({hi}); ++k)")
+
+        def plain_loop() -> None:
+            if TUNING["unroll"] > 1:
+                L.append(f"        #pragma unroll {TUNING['unroll']}")
+            L.append(f"        {loop} {{")
+            level("k", "            ")
+            L.append("        }")
+
+        chunk = None if nest.split_statements else self.prefetch_chunk(group, stage, nest, active, back)
+        if chunk is None:
+            plain_loop()
+            return
+        # Loads of `depth` levels are issued before the arithmetic that depends on them.  Only valid when
+        # no store of the chunk can alias a hoisted load: the host has proven the arrays disjoint
+        # (GT4MI_NO_ALIAS), and within one array the levels of a chunk are different addresses.
+        depth, loads, per_statement = chunk
+        L.append("#if GT4MI_NO_ALIAS")
+        L.append("        {")
+        L.append(f"        gt_i64 k = {'(' + hi + ') - 1' if backward else '(' + lo + ')'};")
+        L.append(f"        for (; {'k - ' + str(depth - 1) + ' >= (' + lo + ')' if backward else 'k + ' + str(depth) + ' <= (' + hi + ')'}; "
+                 f"k {'-' if backward else '+'}= {depth}) {{")
+        for (name, off, rel, data), var in loads.items():
+            e = ir.FieldAccess(name, (off[0], off[1], rel), None, None, data)
+            L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, 'k', -1, {})};")
+        for u in range(depth):
+            step = -u if backward else u
+            self.prefetch_for = {sid: {key: loads[(key[0], key[1][:2], key[1][2] + step, key[2])] for key in keys}
+                                 for sid, keys in per_statement.items()}
+            L.append("            {")
+            level(f"(k {'-' if backward else '+'} {u})", "                ")
+            L.append("            }")
+        self.prefetch_for = {}
+        L.append("        }")
+        L.append(f"        for (; {'k >= (' + lo + '); --k' if backward else 'k < (' + hi + '); ++k'}) {{")
+        level("k", "            ")
+        L.append("        }")
+        L.append("        }")
+        L.append("#else")
+        plain_loop()
+        L.append("#endif")
+
+    def _column_body(self, si: int, stage: Stage) -> None:
+        """Thread per column: the nests of the stage one after the other, K serial per thread.  With ``self.tc`` set
+        (the `_tc` variant of a two-sweep stage) every nest is cut into up to three ranges of levels -- memory, LDS,
+        registers -- and the cached fields are stored / read where the level lives (stage_planner.TopCache)."""
+        L = self.lines
+        stage_fwd = {n: d for (s_i, n), d in self.plan.forwarded.items() if s_i == si}
+        for n in stage_fwd:  # r_<n>: the level behind the sweep, alive across the stage's nests
+            L.append(f"    {_CTYPE[self.decl_dtype[n].name]} r_{_c_ident(n)} = {_CTYPE[self.decl_dtype[n].name]}();")
+        if self.tc is not None:
+            cache, n_reg, n_lds, threads = self.tc
+            L.append(f"    const unsigned tc_tid = threadIdx.y * {threads // max(1, TUNING['block_column'][1])} + threadIdx.x;")
+            for name in cache.names:
+                c, ct = _c_ident(name), _CTYPE[self.decl_dtype[name].name]
+                if n_lds:
+                    L.append(f"    __shared__ {ct} tc_lds_{c}[{n_lds * threads}];")
+                if n_reg:  # every slot is written by the forward sweep before the backward sweep reads it
+                    L.append(f"    {ct} {', '.join(f'tc_{c}_{u}' for u in range(n_reg))};")
+        for ni, nest in enumerate(stage.nests):
+            L.append("    {")
+            L.append(f"        const gt_i64 k0 = {self.bound(nest.interval.start)}, k1 = {self.bound(nest.interval.end)};")
+            back = -1 if nest.order is ir.LoopOrder.FORWARD else 1
+            active = [n for n, d in stage_fwd.items() if nest.order is not ir.LoopOrder.PARALLEL and d == back
+                      and any(s.target.name == n or any(e.name == n for e in _stmt_field_reads(s)) for s in nest.stmts)]
+            groups = [[s] for s in nest.stmts] if nest.split_statements else [nest.stmts]
+            first = "k0" if nest.order is ir.LoopOrder.FORWARD else "(k1 - 1)"
+            for n in active:
+                mode, prev = self.plan.prime.get((si, ni, n), (None, None))
+                if mode in (None, "carried"):
+                    continue
+                # Priming from memory: the first iteration's read of the level behind is an access the
+                # stencil makes anyway, so it is inside the array whenever the loop runs at all and the
+                # column lies in the extent the field is accessed on.
+                conds = ["k1 > k0"]
+                if mode == "prime_if_prev_empty":
+                    piv = stage.nests[prev].interval
+                    conds.append(f"!({self.bound(piv.end)} > {self.bound(piv.start)})")
+                cond = self.column_in_extent(n, stage)
+                if cond:
+                    conds.append(cond)
+                L.append(f"        if ({' && '.join(conds)}) r_{_c_ident(n)} = "
+                         f"{self.access(ir.FieldAccess(n, (0, 0, back)), first, -1, {})};")
+            for group in groups:
+                if self.tc is None:
+                    self._column_range(si, stage, nest, group, active, back, "k0", "k1")
+                    continue
+                cache, n_reg, n_lds, threads = self.tc
+                self.tc_sweep2 = ni >= cache.first_sweep_nests
+                iv = nest.interval
+                if iv.end.level is ir.Level.START:  # ends below the cached range (the host guarantees it)
+                    self.tc_mode = ("mem",)
+                    self._column_range(si, stage, nest, group, active, back, "k0", "k1")
+                    continue
+                # relative to dK: the nest covers [lo_rel (None: somewhere below the cache), hi_rel)
+                hi_rel = iv.end.offset
+                lo_rel = iv.start.offset if iv.start.level is ir.Level.END else None
+                ranges = []  # in ascending order of levels
+                if lo_rel is None or lo_rel < -(n_reg + n_lds):
+                    ranges.append((("mem",), "k0", f"gt_min(k1, a.dK - {n_reg + n_lds})"))
+                if n_lds and hi_rel > -(n_reg + n_lds) and (lo_rel is None or lo_rel < -n_reg):
+                    ranges.append((("lds",), f"gt_max(k0, a.dK - {n_reg + n_lds})", f"gt_min(k1, a.dK - {n_reg})"))
+                slots = [u for u in range(n_reg) if -n_reg + u < hi_rel and (lo_rel is None or -n_reg + u >= lo_rel)]
+                if slots:
+                    ranges.append((("reg", slots), None, None))
+                if nest.order is ir.LoopOrder.BACKWARD:
+                    ranges.reverse()
+                for mode, lo, hi in ranges:
+                    if mode[0] != "reg":
+                        self.tc_mode = mode
+                        L.append("        {")
+                        self._column_range(si, stage, nest, group, active, back, lo, hi)
+                        L.append("        }")
+                        continue
+                    order = list(reversed(mode[1])) if nest.order is ir.LoopOrder.BACKWARD else list(mode[1])
+                    for pos, u in enumerate(order):  # compile-time slots: straight-line code, one level each
+                        if pos % TC_SCHED_LEVELS == 0:
+                            # without a fence the scheduler hoists the loads of ALL unrolled levels to the top of the
+                            # straight-line region (31 levels x 7 loads of the vertical advection: 512 registers + spills)
+                            L.append("        __builtin_amdgcn_sched_barrier(0);")
+                        self.tc_mode = ("reg", u)
+                        L.append("        {")
+                        L.append(f"            const gt_i64 k = a.dK - {n_reg - u};")
+                        self.tc_range_level(si, stage, nest, group, active, back)
+                        L.append("        }")
+                    L.append("        __builtin_amdgcn_sched_barrier(0);")
+                self.tc_mode = ("mem",)
+            L.append("    }")
+
+    def tc_range_level(self, si: int, stage: Stage, nest: Nest, group, active, back) -> None:
+        """One level of the register range of a `_tc` kernel (k is a local constant of the enclosing block)."""
+        L = self.lines
+        self.tc_written = set()
+        self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), "            ")
+        carry = [n for n in active if any(s.target.name == n for s in group)]
+        reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
+        for n in carry:
+            L.append(f"            {_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
+        self.statements(group, stage, si, "k", reg, "            ", carry)
+        for n in active:
+            c = _c_ident(n)
+            if n in carry:
+                L.append(f"            r_{c} = n_{c};")
+            else:
+                cond = self.column_in_extent(n, stage)
+                load = self.access(ir.FieldAccess(n, (0, 0, 0)), "k", -1, {})
+                L.append(f"            {'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
+
+    def kernel(self, si: int, stage: Stage, kname: str) -> KernelSource:
+        L = self.lines
+        if stage.mapping == "ijk":
+            bi, bj, k_per_thread, j_per_thread = (tuple(TUNING["block_ijk"]) + (1,))[:4]
+        else:
+            (bi, bj), k_per_thread, j_per_thread = TUNING["block_column"], 1, 1
+        block = (bi, bj, 1)
+        self._kernel_header(stage, kname, block, j_per_thread)
         if stage.mapping == "ijk":
             if k_per_thread > 1:
                 L.append(f"    #pragma unroll")
@@ -620,98 +843,32 @@ class _Emitter:
             if k_per_thread > 1:
                 L.append("    }")
         else:
-            stage_fwd = {n: d for (s_i, n), d in self.plan.forwarded.items() if s_i == si}
-            for n in stage_fwd:  # r_<n>: the level behind the sweep, alive across the stage's nests
-                L.append(f"    {_CTYPE[self.decl_dtype[n].name]} r_{_c_ident(n)} = {_CTYPE[self.decl_dtype[n].name]}();")
-            for ni, nest in enumerate(stage.nests):
-                L.append("    {")
-                L.append(f"        const gt_i64 k0 = {self.bound(nest.interval.start)}, k1 = {self.bound(nest.interval.end)};")
-                back = -1 if nest.order is ir.LoopOrder.FORWARD else 1
-                active = [n for n, d in stage_fwd.items() if nest.order is not ir.LoopOrder.PARALLEL and d == back
-                          and any(s.target.name == n or any(e.name == n for e in _stmt_field_reads(s)) for s in nest.stmts)]
-                loop = ("for (gt_i64 k = k1 - 1; k >= k0; --k)" if nest.order is ir.LoopOrder.BACKWARD
-                        else "for (gt_i64 k = k0; k < k1; ++k)")
-                groups = [[s] for s in nest.stmts] if nest.split_statements else [nest.stmts]
-                first = "k0" if nest.order is ir.LoopOrder.FORWARD else "(k1 - 1)"
-                for n in active:
-                    mode, prev = self.plan.prime.get((si, ni, n), (None, None))
-                    if mode in (None, "carried"):
-                        continue
-                    # Priming from memory: the first iteration's read of the level behind is an access the
-                    # stencil makes anyway, so it is inside the array whenever the loop runs at all and the
-                    # column lies in the extent the field is accessed on.
-                    conds = ["k1 > k0"]
-                    if mode == "prime_if_prev_empty":
-                        piv = stage.nests[prev].interval
-                        conds.append(f"!({self.bound(piv.end)} > {self.bound(piv.start)})")
-                    cond = self.column_in_extent(n, stage)
-                    if cond:
-                        conds.append(cond)
-                    L.append(f"        if ({' && '.join(conds)}) r_{_c_ident(n)} = "
-                             f"{self.access(ir.FieldAccess(n, (0, 0, back)), first, -1, {})};")
-                for group in groups:
-                    def level(kexpr: str, pad: str, group=group) -> None:
-                        """One K level of the sweep: locals, statements, rotation of the forwarded registers."""
-                        self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), pad)
-                        carry = [n for n in active if any(s.target.name == n for s in group)]
-                        reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
-                        for n in carry:
-                            L.append(f"{pad}{_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
-                        self.statements(group, stage, si, kexpr, reg, pad, carry)
-                        for n in active:
-                            c = _c_ident(n)
-                            if n in carry:
-                                L.append(f"{pad}r_{c} = n_{c};")
-                            else:  # only read in this nest: rotate in the level just passed
-                                cond = self.column_in_extent(n, stage)
-                                load = self.access(ir.FieldAccess(n, (0, 0, 0)), kexpr, -1, {})
-                                L.append(f"{pad}{'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
-
-                    def plain_loop(header: str) -> None:
-                        if TUNING["unroll"] > 1:
-                            L.append(f"        #pragma unroll {TUNING['unroll']}")
-                        L.append(f"        {header} {{")
-                        level("k", "            ")
-                        L.append("        }")
-
-                    chunk = None if nest.split_statements else self.prefetch_chunk(group, stage, nest, active, back)
-                    if chunk is None:
-                        plain_loop(loop)
-                        continue
-                    # Loads of `depth` levels are issued before the arithmetic that depends on them.  Only valid when
-                    # no store of the chunk can alias a hoisted load: the host has proven the arrays disjoint
-                    # (GT4MI_NO_ALIAS), and within one array the levels of a chunk are different addresses.
-                    depth, loads, per_statement = chunk
-                    backward = nest.order is ir.LoopOrder.BACKWARD
-                    L.append("#if GT4MI_NO_ALIAS")
-                    L.append("        {")
-                    L.append(f"        gt_i64 k = {'k1 - 1' if backward else 'k0'};")
-                    L.append(f"        for (; {'k - ' + str(depth - 1) + ' >= k0' if backward else 'k + ' + str(depth) + ' <= k1'}; "
-                             f"k {'-' if backward else '+'}= {depth}) {{")
-                    for (name, off, rel, data), var in loads.items():
-                        e = ir.FieldAccess(name, (off[0], off[1], rel), None, None, data)
-                        L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, 'k', -1, {})};")
-                    for u in range(depth):
-                        step = -u if backward else u
-                        self.prefetch_for = {sid: {key: loads[(key[0], key[1][:2], key[1][2] + step, key[2])] for key in keys}
-                                             for sid, keys in per_statement.items()}
-                        L.append("            {")
-                        level(f"(k {'-' if backward else '+'} {u})", "                ")
-                        L.append("            }")
-                    self.prefetch_for = {}
-                    L.append("        }")
-                    L.append(f"        for (; {'k >= k0; --k' if backward else 'k < k1; ++k'}) {{")
-                    level("k", "            ")
-                    L.append("        }")
-                    L.append("        }")
-                    L.append("#else")
-                    plain_loop(loop)
-                    L.append("#endif")
-                L.append("    }")
+            self._column_body(si, stage)
         if j_per_thread > 1:
             L.append("    }")
         L.append("}")
         L.append("")
+        top_cache = None
+        cache = self.plan.top_cache.get(si) if stage.mapping == "column" else None
+        n_reg, lds_bytes = (tuple(TUNING["top_cache"]) + (0,))[:2]
+        if cache is not None and (n_reg > 0 or lds_bytes > 0):
+            threads = block[0] * block[1]
+            per_level = sum(self.decl_dtype[n].itemsize for n in cache.names) * threads
+            n_lds = min(int(lds_bytes) // per_level, 64)
+            if n_reg + n_lds > 0:
+                # every START-relative interval bound must lie below the cached range, and every nest that is not
+                # statically empty must hold at least one level there -> the smallest domain the variant may run on
+                top_cache = (int(n_reg), int(n_lds), int(n_reg) + int(n_lds) + cache.start_margin + 1)
+                L.append("#if GT4MI_NO_ALIAS")  # the cached copies stand in for memory: only with disjoint arguments
+                self._kernel_header(stage, kname + "_tc", block, 1)
+                self.tc = (cache, int(n_reg), int(n_lds), threads)
+                try:
+                    self._column_body(si, stage)
+                finally:
+                    self.tc, self.tc_mode, self.tc_sweep2, self.tc_written = None, ("mem",), False, set()
+                L.append("}")
+                L.append("#endif")
+                L.append("")
         vec = _vector_width(self, stage) if j_per_thread == 1 and block[0] % 64 == 0 else 0
         vec_fields: Tuple[str, ...] = ()
         vec_rows = max(1, TUNING["vector_rows"])
@@ -719,7 +876,7 @@ class _Emitter:
             vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread)
         plane = None if stage.plane is None else (stage.plane[0], stage.plane[1].value, stage.plane[2])
         return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
-                            vec_rows if vec else 1, plane)
+                            vec_rows if vec else 1, plane, top_cache)
 
 
 def _vector_width(em: "_Emitter", stage: Stage) -> int:

@@ -87,6 +87,7 @@ class _Variant:
         self.module = module
         self.functions: List[ctypes.c_void_p] = []
         self.vec_functions: List[Any] = []  # the 16-byte-lane twin of a stage kernel, or None
+        self.tc_functions: List[Any] = []  # the top-of-column-cache twin of a two-sweep column kernel, or None
         for kern in program.kernels:
             fn = ctypes.c_void_p()
             _lib.check("gt4mi_module_function",
@@ -98,6 +99,16 @@ class _Variant:
                 _lib.check("gt4mi_module_function",
                            lib.gt4mi_module_function(module, (kern.name + "_vec").encode(), ctypes.byref(vfn)))
             self.vec_functions.append(vfn)
+            tfn = None
+            if kern.top_cache is not None and no_alias:  # emitted under GT4MI_NO_ALIAS only
+                tfn = ctypes.c_void_p()
+                _lib.check("gt4mi_module_function",
+                           lib.gt4mi_module_function(module, (kern.name + "_tc").encode(), ctypes.byref(tfn)))
+                scratch = ctypes.c_int(0)
+                _lib.check("gt4mi_function_info", lib.gt4mi_function_info(tfn, None, ctypes.byref(scratch), None))
+                if scratch.value > 0:  # the register levels did not fit: spills would cost more than the cache saves
+                    tfn = None
+            self.tc_functions.append(tfn)
 
 
 def _ranges_disjoint(ranges: List[Tuple[int, int]]) -> bool:
@@ -331,8 +342,10 @@ class HipGenericStencilObject(StencilObject):
                 per_level[k] = ctypes.byref(copy)
             return per_level[k]
 
-        def geometry_of(kern, fn, vfn, levels: int):
+        def geometry_of(kern, fn, vfn, tfn, levels: int):
             (ilo, ihi), (jlo, jhi) = kern.extent
+            if tfn is not None and dK >= kern.top_cache[2]:
+                fn = tfn  # deep enough for the top levels to stay in registers + LDS between the two sweeps
             ni, nj = dI + ihi - ilo, dJ + jhi - jlo
             if ni <= 0 or nj <= 0 or levels <= 0:
                 return None
@@ -345,7 +358,7 @@ class HipGenericStencilObject(StencilObject):
             grid = _U3(-(-ni // (kern.block[0] * lanes)), -(-nj // (kern.block[1] * kern.j_per_thread * rows)), nk)
             return fn, grid, _U3(*kern.block)
 
-        triples = list(zip(program.kernels, variant.functions, variant.vec_functions))
+        triples = list(zip(program.kernels, variant.functions, variant.vec_functions, variant.tc_functions))
         n = 0
         while n < len(triples):
             kern = triples[n][0]

@@ -203,6 +203,23 @@ class Stage:
 
 
 @dataclass
+class TopCache:
+    """Fields of a two-sweep column stage whose TOP levels can stay on chip between the sweeps.
+
+    A FORWARD sweep up to the last level followed by a BACKWARD sweep from it (a Thomas solve) writes a value per
+    level and reads it back at the same level on the way down; the levels written last are read first.  For
+    ``names`` every access of the stage is at the thread's own column and level (or the level behind, through the
+    forwarded register), so the last levels can live in registers and LDS instead of making a round trip through
+    HBM -- what tridiag_stack.hip.h does by hand.  ``store_through``: fields that must be in memory afterwards
+    anyway (API fields, temporaries another stage reads); for the others the cached levels are never stored."""
+
+    names: Tuple[str, ...]
+    store_through: Set[str]
+    first_sweep_nests: int  # nests [0, n) are the FORWARD sweep, the rest the BACKWARD one
+    start_margin: int  # largest START-relative interval bound: the cached range must begin above it
+
+
+@dataclass
 class Plan:
     stencil: ir.Stencil  # after inlining
     stages: List[Stage]
@@ -214,6 +231,7 @@ class Plan:
     register_only: Set[str]  # forwarded temporaries that never need memory
     api_fields: List[ir.FieldDecl]  # API fields a kernel touches
     params: List[ir.ScalarDecl]  # scalar parameters a kernel reads
+    top_cache: Dict[int, TopCache] = field(default_factory=dict)  # stage index -> what may stay on chip
 
 
 def _field_reads(expr: ir.Expr):
@@ -502,5 +520,77 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                         used.add(e.name)
     api_fields = [f for f in stencil.fields if f.name in used]
     params = [p for p in stencil.params if p.name in used]
+    top_cache = _plan_top_cache(stencil, stages, scratch, forwarded, prime, local_names, register_only, touched_in)
     return Plan(stencil, stages, {**extents.fields, **temp_extents}, local_names, scratch, forwarded, prime, register_only,
-                api_fields, params)
+                api_fields, params, top_cache)
+
+
+def _plan_top_cache(stencil: ir.Stencil, stages: List[Stage], scratch, forwarded, prime, local_names, register_only,
+                    touched_in) -> Dict[int, TopCache]:
+    """Which fields of which column stages qualify for ``TopCache`` (see there)."""
+    END0 = ir.AxisBound(ir.Level.END, 0)
+    decls = {d.name: d for d in (*stencil.fields, *stencil.temporaries)}
+    out: Dict[int, TopCache] = {}
+    for si, stage in enumerate(stages):
+        if stage.mapping != "column" or stage.plane is not None or len(stage.nests) < 2:
+            continue
+        if any(n.split_statements or n.order is ir.LoopOrder.PARALLEL for n in stage.nests):
+            continue
+        n_first = 0
+        while n_first < len(stage.nests) and stage.nests[n_first].order is ir.LoopOrder.FORWARD:
+            n_first += 1
+        if n_first == 0 or n_first == len(stage.nests):
+            continue
+        if any(n.order is not ir.LoopOrder.BACKWARD for n in stage.nests[n_first:]):
+            continue
+        first, second = stage.nests[:n_first], stage.nests[n_first:]
+        # the forward sweep ends at the last level, the backward sweep starts there; intervals adjacent within a sweep
+        if first[-1].interval.end != END0 or second[0].interval.end != END0:
+            continue
+        if any(a.interval.end != b.interval.start for a, b in zip(first, first[1:])):
+            continue
+        if any(a.interval.start != b.interval.end for a, b in zip(second, second[1:])):
+            continue
+        written_first = {s.target.name for n in first for s in n.stmts}
+        written_second = {s.target.name for n in second for s in n.stmts}
+        names: List[str] = []
+        for name in sorted(written_first - written_second):
+            d = decls.get(name)
+            if (d is None or name in local_names or name in register_only or tuple(d.axes) != ("I", "J", "K") or d.data_dims
+                    or np.dtype(d.dtype).itemsize not in (4, 8)):
+                continue
+            ok = True
+            read_back = False
+            for ni, nest in enumerate(stage.nests):
+                for st in nest.stmts:
+                    if st.target.name == name and (st.target.offset != (0, 0, 0) or st.target.koffset is not None
+                                                   or st.mask is not None or st.region is not None or st.loops
+                                                   or st.extent != stage.extent):
+                        ok = False
+                    for e in _stmt_field_reads(st):
+                        if e.name != name:
+                            continue
+                        if e.koffset is not None or e.offset[:2] != (0, 0) or st.extent != stage.extent or st.region is not None or st.loops:
+                            ok = False
+                        elif ni >= n_first:
+                            read_back = True
+                            if e.offset != (0, 0, 0):
+                                ok = False
+                        elif e.offset == (0, 0, -1):
+                            # the level behind the sweep: only through the forwarded register, never from memory
+                            if forwarded.get((si, name)) != -1 or prime.get((si, ni, name), ("carried", None))[0] == "prime":
+                                ok = False
+                        elif e.offset != (0, 0, 0):
+                            ok = False
+            if ok and read_back:
+                names.append(name)
+        if not names or len(names) > 4:
+            continue
+        margin = 0
+        for n in stage.nests:
+            for b in (n.interval.start, n.interval.end):
+                if b.level is ir.Level.START:
+                    margin = max(margin, b.offset)
+        store_through = {n for n in names if n not in scratch or touched_in.get(n, set()) != {si}}
+        out[si] = TopCache(tuple(names), store_through, n_first, margin)
+    return out

@@ -469,6 +469,25 @@ int gt4mi_module_function(gt4mi_module* module, const char* name, void** functio
     return GT4MI_OK;
 }
 
+int gt4mi_function_info(void* function, int* registers, int* scratch_bytes, int* lds_bytes) {
+    if (function == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "function_info: null function");
+    hipFunction_t fn = static_cast<hipFunction_t>(function);
+    int v = 0;
+    if (registers) {
+        GT4MI_HIP_CHECK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn));
+        *registers = v;
+    }
+    if (scratch_bytes) {
+        GT4MI_HIP_CHECK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn));
+        *scratch_bytes = v;
+    }
+    if (lds_bytes) {
+        GT4MI_HIP_CHECK(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn));
+        *lds_bytes = v;
+    }
+    return GT4MI_OK;
+}
+
 int gt4mi_launch(void* function, const uint32_t grid[3], const uint32_t block[3], const void* args,
                  size_t args_size, void* stream, gt4mi_exec_info* info) {
     Timer timer(info, stream);

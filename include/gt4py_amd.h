@@ -231,6 +231,9 @@ int gt4mi_rtc_free(void* code);
 int gt4mi_module_load(const void* code, gt4mi_module** module);
 int gt4mi_module_unload(gt4mi_module* module);
 int gt4mi_module_function(gt4mi_module* module, const char* name, void** function);
+/* What the compiler made of a loaded kernel: registers per lane, bytes of scratch (spills) per lane, static LDS bytes
+ * per workgroup.  The host uses it to refuse kernel variants that spill.  Any pointer may be NULL. */
+int gt4mi_function_info(void* function, int* registers, int* scratch_bytes, int* lds_bytes);
 int gt4mi_launch(void* function, const uint32_t grid[3], const uint32_t block[3], const void* args,
                  size_t args_size, void* stream, gt4mi_exec_info* info);
 /* The launches of one stencil call in one crossing of the boundary, in order, on one stream: n kernels,

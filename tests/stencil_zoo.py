@@ -216,6 +216,33 @@ def temporary_read_at_k_offset_in_later_loop(a: F64, out: F64):
         out = tmp[0, 0, -1]
 
 
+def two_sweep_three_carried(a: F64, w: F32, x: F64, y: F32, out: F64, *, alpha: float):
+    """A forward recurrence over three values -- a float64 temporary, a float32 temporary and the float64 API field `x`
+    (in/out: its old value is read at the level before it is overwritten) -- that the backward sweep reads back level by
+    level: the top of the column stays in registers + LDS between the sweeps (stage_planner.TopCache, mixed item sizes,
+    one store-through field, five interval blocks)."""
+    with computation(FORWARD):
+        with interval(0, 2):
+            p = a * alpha
+            q = w
+            x = x + p
+        with interval(2, -3):
+            p = a * alpha + p[0, 0, -1] * 0.5
+            q = w - q[0, 0, -1] * 0.25
+            x = x * 0.5 + p - x[0, 0, -1] * 0.125
+        with interval(-3, None):
+            p = p[0, 0, -1] - a
+            q = q[0, 0, -1] * w
+            x = x[0, 0, -1] + p
+    with computation(BACKWARD):
+        with interval(-1, None):
+            out = p + q + x
+            y = q
+        with interval(0, -1):
+            out = p * out[0, 0, 1] + q - x
+            y = q + w if p > 0.0 else q - w
+
+
 def cross_column_recurrence(a: F64, b: F64, c: F64):
     """Sequential blocks whose columns depend on each other through a temporary read at horizontal offsets
     (legal in the reference: gtir.py:224-241 only forbids it for API fields): forward, then backward with a mask."""
@@ -367,6 +394,7 @@ ZOO = {
     "column_sum_then_gradient": (column_sum_then_gradient, {}, {}, {}),
     "backward_scan": (backward_scan, {}, {}, {}),
     "parallel_k_dependency": (parallel_k_dependency, {}, {}, {}),
+    "two_sweep_three_carried": (two_sweep_three_carried, {}, {"alpha": 0.375}, {}),
     "temporary_read_at_k_offset_in_later_loop": (temporary_read_at_k_offset_in_later_loop, {}, {}, {}),
     "lower_dimensional": (lower_dimensional, {}, {}, {}),
     "two_stage_written_input": (two_stage_written_input, {}, {}, {}),

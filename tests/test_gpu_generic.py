@@ -252,3 +252,88 @@ def test_calls_on_two_streams_do_not_share_scratch():
             for k in expect:
                 np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"round {round_}: field {k}")
     assert len({k[0] for k in type(hip)._gt_scratch_}) == 2, "one scratch buffer per stream"
+
+
+# ---- two-sweep column stages with the top of the column kept on chip (the `_tc` kernel variant) -------------------
+TWO_SWEEP = ["tridiagonal_solver", "vertical_advection_dycore", "two_sweep_three_carried"]
+
+
+def _run_pair_rebuilt(name, domain, seed=4242):
+    """like _run_pair, but the hip:mi300 stencil is rebuilt (the generator's tuning knobs are not part of the cache key)"""
+    import oracle.numpy_backend  # noqa: F401
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+
+    defn, externals, scalars, opts = zoo.ZOO[name]
+    ref = gtscript.stencil(backend="numpy", definition=defn, externals=externals)
+    hip = gtscript.stencil(backend="hip:mi300", definition=defn, externals=externals, rebuild=True, **opts)
+    arrays, origins = zoo.make_inputs(ref, domain, seed)
+    expect = {k: v.copy() for k, v in arrays.items()}
+    ref(**expect, **scalars, origin=origins, domain=domain)
+    dev = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=origins[k],
+                                    dimensions=hip.field_info[k].axes) for k, v in arrays.items()}
+    hip(**dev, **scalars, origin=origins, domain=domain)
+    return expect, {k: d.get() for k, d in dev.items()}, hip
+
+
+@pytest.mark.parametrize("name", TWO_SWEEP)
+@pytest.mark.parametrize("domain", [(70, 5, 100), (130, 3, 161), (64, 8, 58), (64, 8, 59), (33, 2, 57)])
+def test_top_of_column_cache_default_depths(name, domain):
+    """Deep domains take the `_tc` kernel (registers + LDS hold the top levels between the sweeps), shallower ones the
+    plain kernel; both must reproduce the oracle bit for bit on every field."""
+    from gt4py_amd.cartesian.backend import hip_codegen
+
+    expect, got, hip = _run_pair_rebuilt(name, domain)
+    kern = type(hip)._gt_program_.kernels[0]
+    assert kern.top_cache is not None and kern.top_cache[:2] == (hip_codegen.TUNING["top_cache"][0], kern.top_cache[1])
+    for k in expect:
+        np.testing.assert_array_equal(got[k], expect[k], err_msg=f"{name} {domain}: field {k}")
+
+
+@pytest.mark.parametrize("name", TWO_SWEEP)
+@pytest.mark.parametrize("depths", [(3, 5), (1, 0), (0, 4), (5, 1), (8, 8)])
+@pytest.mark.parametrize("levels", [8, 9, 10, 11, 12, 13, 18, 19, 40])
+def test_top_of_column_cache_every_range_boundary(name, depths, levels):
+    """Shallow caches (a few register levels, a few LDS levels) on domains around the smallest one the variant accepts:
+    every combination of empty / one-level / several-level memory, LDS and register ranges in both sweeps."""
+    from gt4py_amd.cartesian.backend import hip_codegen
+
+    saved = hip_codegen.TUNING["top_cache"]
+    items = {"two_sweep_three_carried": 8 + 4 + 8}.get(name, 2 * 8)  # bytes per column and level of the cached fields
+    per_level = items * 256  # 256 threads per workgroup
+    hip_codegen.TUNING["top_cache"] = (depths[0], depths[1] * per_level)
+    try:
+        expect, got, hip = _run_pair_rebuilt(name, (66, 5, levels), seed=levels)
+        kern = type(hip)._gt_program_.kernels[0]
+        margin = {"two_sweep_three_carried": 2}.get(name, 1)
+        assert kern.top_cache == (depths[0], depths[1], depths[0] + depths[1] + margin + 1)
+    finally:
+        hip_codegen.TUNING["top_cache"] = saved
+        # leave no class built with the shallow depths in the cache
+        defn, externals, _, opts = zoo.ZOO[name]
+        from gt4py_amd.cartesian import gtscript
+
+        gtscript.stencil(backend="hip:mi300", definition=defn, externals=externals, rebuild=True, **opts)
+    for k in expect:
+        np.testing.assert_array_equal(got[k], expect[k], err_msg=f"{name} depths {depths} K={levels}: field {k}")
+
+
+def test_top_of_column_cache_is_what_runs_and_does_not_spill():
+    """The deep variant is really the one launched for K = 160, uses no scratch memory, and a stencil object that was
+    first called on a shallow domain switches to it when the domain grows."""
+    import ctypes
+
+    from gt4py_amd import _lib
+
+    expect, got, hip = _run_pair_rebuilt("vertical_advection_dycore", (64, 4, 20))
+    for k in expect:
+        np.testing.assert_array_equal(got[k], expect[k])
+    variant = next(iter(type(hip)._gt_variants_.values()))
+    tfn = variant.tc_functions[0]
+    assert tfn is not None, "the `_tc` kernel was refused (spills?)"
+    regs, scratch, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check("gt4mi_function_info", _lib.load().gt4mi_function_info(tfn, ctypes.byref(regs), ctypes.byref(scratch), ctypes.byref(lds)))
+    assert scratch.value == 0 and lds.value == 160 * 1024 and regs.value <= 512
+    expect, got, hip2 = _run_pair_rebuilt("vertical_advection_dycore", (64, 4, 160))
+    for k in expect:
+        np.testing.assert_array_equal(got[k], expect[k])

@@ -243,7 +243,8 @@ def other_kernels(steps: int = 20):
     run("generated_vertical_advection_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 48.0,
         scalars={"dtr_stage": 3.0 / 20.0},
         note="one generated column kernel (forward + backward sweep); 5 fields read, 1 written; the forward sweep's "
-             "ccol / dcol make a round trip through scratch on top of the 48 algorithmic B/LUP")
+             "ccol / dcol are read back by the backward sweep: the top 56 of 160 levels stay in registers + LDS "
+             "(stage_planner.TopCache), the rest makes a round trip through scratch on top of the 48 algorithmic B/LUP")
     del fields
     torch.cuda.empty_cache()
     dom = (512, 512, 512)

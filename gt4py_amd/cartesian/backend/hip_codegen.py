@@ -82,9 +82,6 @@ TUNING = {
     "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (16, 160 * 1024)),
 }
 
-#: levels of the register range of a `_tc` kernel between two scheduling fences (loads may move up within a group)
-TC_SCHED_LEVELS = 4
-
 from .stage_planner import (Nest, Plan, Stage, Stmt, UnsupportedStencil, _field_reads, _stmt_field_reads,  # noqa: F401
                             inline_horizontal_temporaries, plan_stages)
 
@@ -654,24 +651,8 @@ class _Emitter:
         stage_fwd = {n: d for (s_i, n), d in self.plan.forwarded.items() if s_i == si}
 
         def level(kexpr: str, pad: str) -> None:
-            """One K level of the sweep: locals, statements, rotation of the forwarded registers."""
-            self.tc_written = set()
-            self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), pad)
-            carry = [n for n in active if any(s.target.name == n for s in group)]
-            reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
-            for n in carry:
-                L.append(f"{pad}{_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
-            self.statements(group, stage, si, kexpr, reg, pad, carry)
-            for n in active:
-                c = _c_ident(n)
-                if n in carry:
-                    L.append(f"{pad}r_{c} = n_{c};")
-                else:  # only read in this nest: rotate in the level just passed
-                    cond = self.column_in_extent(n, stage)
-                    load = self.access(ir.FieldAccess(n, (0, 0, 0)), kexpr, -1, {})
-                    L.append(f"{pad}{'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
+            self._emit_level(si, stage, nest, group, active, back, kexpr, pad)
 
-        self._level = level  # (the register range of a `_tc` kernel emits single levels)
         loop = (f"for (gt_i64 k = ({hi}) - 1; k >= ({lo}); --k)" if backward else f"for (gt_i64 k = ({lo}); k < ({hi}); ++k)")
 
         def plain_loop() -> None:
@@ -694,6 +675,7 @@ class _Emitter:
         L.append(f"        gt_i64 k = {'(' + hi + ') - 1' if backward else '(' + lo + ')'};")
         L.append(f"        for (; {'k - ' + str(depth - 1) + ' >= (' + lo + ')' if backward else 'k + ' + str(depth) + ' <= (' + hi + ')'}; "
                  f"k {'-' if backward else '+'}= {depth}) {{")
+        self.tc_written = set()  # hoisted loads see what memory held BEFORE the chunk's levels are assigned
         for (name, off, rel, data), var in loads.items():
             e = ir.FieldAccess(name, (off[0], off[1], rel), None, None, data)
             L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, 'k', -1, {})};")
@@ -786,39 +768,68 @@ class _Emitter:
                         self._column_range(si, stage, nest, group, active, back, lo, hi)
                         L.append("        }")
                         continue
-                    order = list(reversed(mode[1])) if nest.order is ir.LoopOrder.BACKWARD else list(mode[1])
-                    for pos, u in enumerate(order):  # compile-time slots: straight-line code, one level each
-                        if pos % TC_SCHED_LEVELS == 0:
-                            # without a fence the scheduler hoists the loads of ALL unrolled levels to the top of the
-                            # straight-line region (31 levels x 7 loads of the vertical advection: 512 registers + spills)
-                            L.append("        __builtin_amdgcn_sched_barrier(0);")
-                        self.tc_mode = ("reg", u)
-                        L.append("        {")
-                        L.append(f"            const gt_i64 k = a.dK - {n_reg - u};")
-                        self.tc_range_level(si, stage, nest, group, active, back)
-                        L.append("        }")
-                    L.append("        __builtin_amdgcn_sched_barrier(0);")
+                    self._register_range(si, stage, nest, group, active, back, mode[1], n_reg)
                 self.tc_mode = ("mem",)
             L.append("    }")
 
-    def tc_range_level(self, si: int, stage: Stage, nest: Nest, group, active, back) -> None:
-        """One level of the register range of a `_tc` kernel (k is a local constant of the enclosing block)."""
+    def _emit_level(self, si: int, stage: Stage, nest: Nest, group, active, back: int, kexpr: str, pad: str) -> None:
+        """One K level of a column sweep: locals, statements, rotation of the forwarded registers."""
         L = self.lines
         self.tc_written = set()
-        self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), "            ")
+        self.local_decls(Nest(nest.order, nest.interval, group, nest.block_id), pad)
         carry = [n for n in active if any(s.target.name == n for s in group)]
         reg: Dict[Tuple[str, int], str] = {(n, back): f"r_{_c_ident(n)}" for n in active}
         for n in carry:
-            L.append(f"            {_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
-        self.statements(group, stage, si, "k", reg, "            ", carry)
+            L.append(f"{pad}{_CTYPE[self.decl_dtype[n].name]} n_{_c_ident(n)} = r_{_c_ident(n)};")
+        self.statements(group, stage, si, kexpr, reg, pad, carry)
         for n in active:
             c = _c_ident(n)
             if n in carry:
-                L.append(f"            r_{c} = n_{c};")
-            else:
+                L.append(f"{pad}r_{c} = n_{c};")
+            else:  # only read in this nest: rotate in the level just passed
                 cond = self.column_in_extent(n, stage)
-                load = self.access(ir.FieldAccess(n, (0, 0, 0)), "k", -1, {})
-                L.append(f"            {'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
+                load = self.access(ir.FieldAccess(n, (0, 0, 0)), kexpr, -1, {})
+                L.append(f"{pad}{'if (' + cond + ') ' if cond else ''}r_{c} = {load};")
+
+    def _register_range(self, si: int, stage: Stage, nest: Nest, group, active, back: int, slots: Sequence[int], n_reg: int) -> None:
+        """The levels of a nest that live in register slots (compile-time indices): straight-line code, in sweep
+        order, in batches whose loads are issued ahead of the arithmetic exactly as in the loops (prefetch_chunk)."""
+        L = self.lines
+        backward = nest.order is ir.LoopOrder.BACKWARD
+        order = list(reversed(slots)) if backward else list(slots)
+        self.tc_mode = ("reg", order[0])
+        chunk = None if nest.split_statements else self.prefetch_chunk(group, stage, nest, active, back)
+        depth = chunk[0] if chunk is not None else 1
+        pos = 0
+        while pos < len(order):
+            batch = order[pos:pos + depth]
+            # a fence per batch: otherwise the scheduler hoists the loads of ALL unrolled levels to the top of the
+            # straight-line region and runs out of registers
+            L.append("        __builtin_amdgcn_sched_barrier(0);")
+            L.append("        {")
+            L.append(f"            const gt_i64 k = a.dK - {n_reg - batch[0]};")
+            if chunk is not None and len(batch) == depth:
+                _, loads, per_statement = chunk
+                self.tc_written = set()  # hoisted loads see what memory held BEFORE the batch's levels are assigned
+                for (name, off, rel, data), var in loads.items():
+                    e = ir.FieldAccess(name, (off[0], off[1], rel), None, None, data)
+                    L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, 'k', -1, {})};")
+                for u, slot in enumerate(batch):
+                    step = -u if backward else u
+                    self.prefetch_for = {sid: {key: loads[(key[0], key[1][:2], key[1][2] + step, key[2])] for key in keys}
+                                         for sid, keys in per_statement.items()}
+                    self.tc_mode = ("reg", slot)
+                    L.append("            {")
+                    self._emit_level(si, stage, nest, group, active, back, f"(k {'-' if backward else '+'} {u})", "                ")
+                    L.append("            }")
+                self.prefetch_for = {}
+                pos += depth
+            else:  # the levels that do not fill a batch: one at a time
+                self.tc_mode = ("reg", batch[0])
+                self._emit_level(si, stage, nest, group, active, back, "k", "            ")
+                pos += 1
+            L.append("        }")
+        L.append("        __builtin_amdgcn_sched_barrier(0);")
 
     def kernel(self, si: int, stage: Stage, kname: str) -> KernelSource:
         L = self.lines

@@ -861,11 +861,11 @@ class _Emitter:
         L.append("")
         top_cache = None
         cache = self.plan.top_cache.get(si) if stage.mapping == "column" else None
-        n_reg, lds_bytes = (tuple(TUNING["top_cache"]) + (0,))[:2]
+        n_reg, lds_bytes, lds_cap = (tuple(TUNING["top_cache"]) + (0, 64))[:3] if len(TUNING["top_cache"]) < 3 else tuple(TUNING["top_cache"])[:3]
         if cache is not None and (n_reg > 0 or lds_bytes > 0):
             threads = block[0] * block[1]
             per_level = sum(self.decl_dtype[n].itemsize for n in cache.names) * threads
-            n_lds = min(int(lds_bytes) // per_level, 64)
+            n_lds = min(int(lds_bytes) // per_level, int(lds_cap))
             if n_reg + n_lds > 0:
                 # every START-relative interval bound must lie below the cached range, and every nest that is not
                 # statically empty must hold at least one level there -> the smallest domain the variant may run on

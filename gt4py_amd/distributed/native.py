@@ -42,14 +42,21 @@ class NativeComm:
                 rank, world_size = 0, 1
         self.rank, self.world_size = int(rank), int(world_size)
         uid = ctypes.create_string_buffer(128)
+        failure = None
         if self.rank == 0:
-            _lib.check("gt4mi_comm_unique_id", lib.gt4mi_comm_unique_id(uid))
+            try:
+                _lib.check("gt4mi_comm_unique_id", lib.gt4mi_comm_unique_id(uid))
+            except Exception as ex:  # the other ranks are waiting for the broadcast: tell them instead of leaving them there
+                failure = f"rank 0 could not create the RCCL unique id: {ex}"
         if self.world_size > 1:
             import torch.distributed as dist
 
-            box = [uid.raw if self.rank == 0 else None]
+            box = [(uid.raw, failure) if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
-            uid = ctypes.create_string_buffer(box[0], 128)
+            raw, failure = box[0]
+            uid = ctypes.create_string_buffer(raw, 128)
+        if failure is not None:
+            raise RuntimeError(failure)
         handle = ctypes.c_void_p()
         _lib.check("gt4mi_comm_create", lib.gt4mi_comm_create(uid, self.world_size, self.rank, ctypes.byref(handle)))
         self._handle = handle

@@ -152,7 +152,22 @@ class DeviceArray:
         return self._t.detach().cpu().numpy()
 
     def copy(self) -> "DeviceArray":
-        return DeviceArray(self._t.clone())
+        """A copy with the SAME strides and the same alignment of its first element (modulo 512 bytes).
+
+        ``torch.Tensor.clone`` keeps the strides only of dense tensors; a storage with padded rows would come back
+        K-contiguous, i.e. in a layout the kernels take their any-stride path for (and a float32 field could lose the
+        16-byte alignment of its origin column).  Padding elements between the rows are not copied."""
+        t = self._t
+        if t.numel() == 0 or t.dim() == 0:
+            return DeviceArray(t.clone())
+        isz = t.element_size()
+        span = sum((n - 1) * s for n, s in zip(t.shape, t.stride())) + 1  # elements from the first to the last one
+        raw = torch.empty(span * isz + 512, dtype=torch.uint8, device=t.device)
+        offset = (t.data_ptr() - raw.data_ptr()) % 512
+        flat = raw[offset: offset + span * isz].view(t.dtype)
+        new = torch.as_strided(flat, tuple(t.shape), tuple(t.stride()))
+        new.copy_(t)
+        return DeviceArray(new, owner=raw)
 
     def fill(self, value) -> None:
         self._t.fill_(value)

@@ -53,6 +53,25 @@ def test_storage_allocation_on_device():
     assert (d[0, 0] == -1).all()
 
 
+def test_device_array_copy_keeps_layout_and_alignment():
+    """`copy()` of a storage with padded rows: same strides, same alignment of the origin column, same values --
+    so a stencil runs on the copy exactly as on the original (distributed.TunedApply calibrates on such copies)."""
+    gt_storage, _ = _imports()
+    from gt4py_amd.storage import layout as gt_layout
+
+    rng = np.random.default_rng(3)
+    for dtype, aligned in ((np.float32, (2, 2, 0)), (np.float64, (1, 1, 0)), (np.float64, (0, 0, 0))):
+        host = rng.uniform(-1, 1, (37, 21, 5)).astype(dtype)
+        a = gt_storage.from_array(host, dtype, backend=BACKEND, aligned_index=aligned)
+        b = a.copy()
+        assert b.strides == a.strides and b.shape == a.shape and b.dtype == a.dtype and b.ptr != a.ptr
+        assert b.ptr % 512 == a.ptr % 512
+        assert gt_layout.from_name(BACKEND)["is_optimal_layout"](b, ("I", "J", "K"))
+        assert np.array_equal(b.get(), host)
+        b[3, 4, :] = 7
+        assert np.array_equal(a.get(), host)  # the copy owns its memory
+
+
 def test_notebook_known_answer():
     """examples/lap_cartesian_vs_next.ipynb cells 5-9 on hip:mi300."""
     gt_storage, gtscript = _imports()

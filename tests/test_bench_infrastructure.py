@@ -1,0 +1,82 @@
+"""CPU: the parts of bench.py that must work on the first multi-GPU run nobody can rehearse -- the per-phase deadline
+(a rank stuck in a collective exits with status 3 instead of hanging the node), the tie between a committed PMC traffic
+figure and the kernel sources it was measured on, the pinned CPU-baseline child, and the HIP-event statistics contract."""
+
+import json
+import os
+import pathlib
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+
+def test_watchdog_ends_a_stuck_process_with_status_3():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "dog = bench.Watchdog(5); dog.arm(0.5, 'a collective that never returns')\n"
+            "time.sleep(60)\n") % str(ROOT)
+    t0 = time.perf_counter()
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=50)
+    assert proc.returncode == 3 and time.perf_counter() - t0 < 30
+    assert "rank 5" in proc.stderr and "a collective that never returns" in proc.stderr and "status 3" in proc.stderr
+
+
+def test_watchdog_rearm_and_disarm():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "dog = bench.Watchdog(0)\n"
+            "dog.arm(0.3, 'first'); dog.arm(30, 'second'); time.sleep(0.8)\n"  # re-arming cancels the first deadline
+            "dog.arm(0.3, 'third'); dog.disarm(); time.sleep(0.8)\n"
+            "print('alive')\n") % str(ROOT)
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=50)
+    assert proc.returncode == 0 and "alive" in proc.stdout
+
+
+def test_committed_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    real = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())["lap5_f64_512"]
+    assert set(real) >= {"bytes_per_launch", "kernel", "git_sha", "kernel_source_sha", "source"}
+    assert any("lap5_strip_kernel" in k for k in real["kernel"])
+    # the committed figure is reported exactly when it belongs to the kernel sources in the tree (after touching
+    # gt4py_amd/csrc/{lap5,lane_shift,common}.hip.h or the Makefile: scripts/profile_bench.sh on the GPU)
+    value, why = bench._committed_traffic("lap5_f64_512")
+    if real["kernel_source_sha"] == bench.kernel_source_hash("lap5_f64_512"):
+        assert value == real["bytes_per_launch"] and 1.0 < value / (16.0 * 512**3) < 1.2 and "git" in why
+    else:
+        assert value is None and "other kernel sources" in why
+    # a stale or hash-less record is not reported
+    fake_root = tmp_path / "repo"
+    (fake_root / "profiles").mkdir(parents=True)
+    for rel in bench.KERNEL_SOURCES["lap5_f64_512"]:
+        (fake_root / rel).parent.mkdir(parents=True, exist_ok=True)
+        (fake_root / rel).write_bytes((ROOT / rel).read_bytes())
+    monkeypatch.setattr(bench, "ROOT", fake_root)
+    (fake_root / "profiles" / "hbm_traffic.json").write_text(json.dumps({"lap5_f64_512": real}))
+    assert bench._committed_traffic("lap5_f64_512")[0] == real["bytes_per_launch"]
+    (fake_root / bench.KERNEL_SOURCES["lap5_f64_512"][0]).write_text("// a different kernel\n")
+    value, why = bench._committed_traffic("lap5_f64_512")
+    assert value is None and "other kernel sources" in why
+    (fake_root / "profiles" / "hbm_traffic.json").write_text(json.dumps({"lap5_f64_512": 123}))
+    assert bench._committed_traffic("lap5_f64_512") == (None, "committed measurement carries no kernel-source hash")
+
+
+def test_cpu_baseline_child_reports_pinned_threads_and_spread():
+    env = dict(os.environ, OMP_NUM_THREADS="2", OMP_PROC_BIND="close", OMP_PLACES="cores")
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-child", "1.0"], env=env, capture_output=True,
+                          text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-500:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["kind"] == "port" and line["unit"] == "GLUPS" and line["cores"] == 2 and line["value"] > 0
+    assert {"sample", "spread_pct", "batch_glups_min_max", "host", "gb_per_s"} <= set(line)
+    assert "512x512x512" in line["sample"] and "pinned" in line["sample"]
+    assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+
+
+def test_bench_module_has_no_gpu_side_effects_on_import():
+    """`import bench` (scripts/summarize_profile.py does it on the GPU box for the source hash) must not touch torch."""
+    proc = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print('torch' in sys.modules)" % str(ROOT)],
+                          capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0 and proc.stdout.strip() == "False"

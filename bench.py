@@ -190,15 +190,25 @@ def other_kernels(steps: int = 20):
     def run(name, obj, fields, origin, domain, bytes_per_lup, scalars=None, note=None):
         frozen = obj.freeze(origin=origin, domain=domain)
         call = lambda i: frozen(**fields, **(scalars or {}))  # noqa: E731
-        for i in range(10):
-            call(i)
+        # Warm up and time for a fixed amount of device time, not a fixed count: the clocks need a few milliseconds of
+        # load to settle, and 10 + 20 launches of a 0.18 ms kernel measured it 7-12 % slow (scripts/hdiff_bench_context.py
+        # next to scripts/hdiff_api_timing.py on one box: 0.206 vs 0.182 ms)
+        t0 = time.perf_counter()
+        n_warm = 0
+        while n_warm < 10 or time.perf_counter() - t0 < 0.05:
+            call(n_warm)
+            n_warm += 1
+            if n_warm % 16 == 0:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
-        t = _time_launches(call, steps)
+        est = max((time.perf_counter() - t0) / n_warm, 1e-5)
+        n = int(min(400, max(steps, 0.04 / est)))
+        t = _time_launches(call, n)
         ms = t["mean"]
         lups = float(np.prod(domain))
         gbs = bytes_per_lup * lups / (ms * 1e-3) / 1e9
         out[name] = {"domain": list(domain), "ms": round(ms, 4), "ms_median": round(t["median"], 4), "ms_min": round(t["min"], 4),
-                     "glups": round(lups / ms / 1e6, 1), "algorithmic_bytes_per_lup": bytes_per_lup,
+                     "launches_timed": t["n"], "glups": round(lups / ms / 1e6, 1), "algorithmic_bytes_per_lup": bytes_per_lup,
                      "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4)}
         if note:
             out[name]["note"] = note

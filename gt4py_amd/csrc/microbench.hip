@@ -482,6 +482,8 @@ static void section_tripipe() {
         tridiag_stack_variant<40, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<48, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<64, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<80, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<56, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<32, 32, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<32, 16, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<16, 16, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);

@@ -181,6 +181,10 @@ struct TridiagTuning {
     // profiles/r2_tridiag_pipelined.log); for it 40 LDS levels are also what keeps ONE wave per SIMD, fewer were
     // 15-25 % slower.
     static constexpr int STACK_REG = 32, STACK_LDS = 40, STACK_U = 8;
+    // round 2: with a scheduling fence per unrolled batch more register levels pay again -- 80 + 40 levels on chip
+    // (478 registers, no scratch): 84.5 GLUPS next to 81.4 for 32 + 40 on the same box, 60 instead of 64.8 B/LUP moved
+    // (profiles/r2_tridiag_pipelined_deep.log).  Used when the column is deeper than 120 levels.
+    static constexpr int STACK_REG_DEEP = 80;
 };
 
 template <typename T>
@@ -228,7 +232,14 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
     if (contiguous && domain[2] > TridiagTuning::STACK_REG) {
         // keep the top of the column on chip between the sweeps
         const unsigned ti = (unsigned)cdiv(domain[0], 64);
-        if (domain[2] > TridiagTuning::STACK_REG + TridiagTuning::STACK_LDS) {
+        // (8-byte items only: for float the LDS share allows two waves per SIMD, the compiler then budgets 256 registers
+        // and the deep variant spills)
+        constexpr int DEEP = sizeof(T) == 8 ? TridiagTuning::STACK_REG_DEEP : TridiagTuning::STACK_REG;
+        if (sizeof(T) == 8 && domain[2] > DEEP + TridiagTuning::STACK_LDS) {
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, DEEP, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
+                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+                               (int)domain[1], (int)domain[2], ti);
+        } else if (domain[2] > TridiagTuning::STACK_REG + TridiagTuning::STACK_LDS) {
             hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
                                dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);

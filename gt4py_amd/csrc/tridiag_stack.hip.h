@@ -284,6 +284,9 @@ tridiag_pipe_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<T> 
     constexpr int NBC = (LL + RL) / U;
 #pragma unroll
     for (int b = 0; b < NBC; ++b) {
+        // a fence per batch: without it the scheduler may hoist the loads of several unrolled batches to the top of the
+        // straight-line region (registers), which is what made more than 32-48 register levels slower in round 1
+        __builtin_amdgcn_sched_barrier(0);
         if (b + 1 < NBC) load(B[(b + 1) & 1], A + (b + 1) * U);
         const FB& c = B[b & 1];
 #pragma unroll

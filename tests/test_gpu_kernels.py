@@ -218,7 +218,8 @@ def _tridiag_inputs(shape, dtype, seed=7):
 @pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(1, 1, 2), (3, 5, 2), (17, 33, 5), (64, 64, 8), (65, 63, 7), (40, 9, 160), (514, 3, 19),
-                                   (34, 5, 50), (130, 3, 73), (70, 2, 33), (66, 4, 72)])  # K around the on-chip stack sizes
+                                   (34, 5, 50), (130, 3, 73), (70, 2, 33), (66, 4, 72),  # K around the on-chip stack sizes
+                                   (66, 3, 120), (66, 3, 121), (70, 2, 122), (65, 2, 128), (64, 2, 129), (130, 2, 135)])
 def test_tridiag_parity(shape, dtype, layout):
     import gpu_util as G
 

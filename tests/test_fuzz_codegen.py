@@ -80,3 +80,74 @@ def test_generated_kernels_match_the_oracle_on_random_stencils(seed, tmp_path):
         hip(**dev, **scalars, origin=origins, domain=domain)
         for k in arrays:
             np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"seed {seed} {domain}, field {k}\n{text}")
+
+
+# ---- two-sweep column programs: the top-of-column cache of the code generator (stage_planner.TopCache) -----------
+TWO_SWEEP_SEEDS = list(range(_N or 60))
+
+
+def _two_sweep(seed, tmp_path, backend, **opts):
+    import oracle.numpy_backend  # noqa: F401
+    from gt4py_amd.cartesian import gtscript
+
+    defn, scalars, text = fuzz_stencils.make_two_sweep_stencil(seed, tmp_path)
+    return gtscript.stencil(backend=backend, definition=defn, **opts), scalars, text
+
+
+@pytest.mark.parametrize("seed", TWO_SWEEP_SEEDS[::3])
+def test_two_sweep_programs_plan_and_compile(seed, tmp_path):
+    """CPU: most random Thomas-like programs qualify for the cache, and the `_tc` kernel compiles (shallow depths, so
+    that every range is emitted)."""
+    from gt4py_amd import _lib
+    from gt4py_amd.cartesian.backend import hip_codegen
+
+    saved = hip_codegen.TUNING["top_cache"]
+    hip_codegen.TUNING["top_cache"] = (3, 4 * 8 * 3 * 256)
+    try:
+        hip, _, text = _two_sweep(seed, tmp_path, "hip:mi300", rebuild=True)
+    finally:
+        hip_codegen.TUNING["top_cache"] = saved
+    program = type(hip)._gt_program_
+    if program.plan.top_cache:
+        assert any(k.top_cache is not None for k in program.kernels) and "_tc(const gt_args a)" in program.source, text
+    assert _lib.rtc_compile(program.source, f"two_sweep_{seed}.hip", ["-DGT4MI_UNIT_I_STRIDE=1", "-DGT4MI_NO_ALIAS=1"])[:4] == b"\x7fELF"
+
+
+def test_most_two_sweep_programs_qualify(tmp_path):
+    n = sum(bool(type(_two_sweep(seed, tmp_path, "hip:mi300")[0])._gt_program_.plan.top_cache) for seed in TWO_SWEEP_SEEDS[:30])
+    assert n >= 20, f"only {n} of 30 random two-sweep programs are served by the top-of-column cache"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", TWO_SWEEP_SEEDS)
+def test_two_sweep_programs_match_the_oracle(seed, tmp_path):
+    """GPU: random Thomas-like programs with shallow, seed-dependent cache depths on domains around the smallest one the
+    `_tc` variant accepts, and with the default depths on a deep domain; every field bit for bit."""
+    import random
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian.backend import hip_codegen
+
+    rnd = random.Random(seed)
+    ref, scalars, text = _two_sweep(seed, tmp_path, "numpy")
+    for depths, levels in (((rnd.randint(0, 6), rnd.randint(0, 6)), None), (None, rnd.choice([64, 97, 130]))):
+        saved = hip_codegen.TUNING["top_cache"]
+        if depths is not None:
+            hip_codegen.TUNING["top_cache"] = (depths[0], depths[1] * 8 * 3 * 256, 64)
+        try:
+            hip, _, _ = _two_sweep(seed, tmp_path, "hip:mi300", rebuild=True)
+        finally:
+            hip_codegen.TUNING["top_cache"] = saved
+        kern = type(hip)._gt_program_.kernels[0]
+        k_values = [levels] if levels else sorted({max(ref.domain_info.min_sequential_axis_size, k) for k in
+                                                   ((kern.top_cache[2] if kern.top_cache else 8) + d for d in (-1, 0, 1, 7))})
+        for nk in k_values:
+            domain = (66, 3, nk)
+            arrays, origins = zoo.make_inputs(ref, domain, seed)
+            expect = {k: v.copy() for k, v in arrays.items()}
+            ref(**expect, **scalars, origin=origins, domain=domain)
+            dev = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=origins[k]) for k, v in arrays.items()}
+            hip(**dev, **scalars, origin=origins, domain=domain)
+            for k in arrays:
+                np.testing.assert_array_equal(dev[k].get(), expect[k],
+                                              err_msg=f"seed {seed} depths {depths} {domain} (cache {kern.top_cache}), field {k}\n{text}")

@@ -78,8 +78,9 @@ TUNING = {
     # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup); (0, 0) = off
     # 16 register levels: the vertical advection needs 344 of the 512 registers a lone wave per SIMD may use; from 24
     # levels on the compiler spills to scratch (it keeps ~10 values per unrolled level alive, addresses included).  The
-    # host checks the compiled kernel and does not launch a variant that spills (hip_generic._Variant).
-    "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (16, 160 * 1024)),
+    # host checks the compiled kernel and does not launch a variant that spills (hip_generic._Variant).  Third item: cap
+    # on the LDS levels (deeper caches on fewer, narrower workgroups were not faster: r2_codegen_top_cache_block_shapes.log)
+    "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (16, 160 * 1024, 64)),
 }
 
 from .stage_planner import (Nest, Plan, Stage, Stmt, UnsupportedStencil, _field_reads, _stmt_field_reads,  # noqa: F401
@@ -861,7 +862,7 @@ class _Emitter:
         L.append("")
         top_cache = None
         cache = self.plan.top_cache.get(si) if stage.mapping == "column" else None
-        n_reg, lds_bytes, lds_cap = (tuple(TUNING["top_cache"]) + (0, 64))[:3] if len(TUNING["top_cache"]) < 3 else tuple(TUNING["top_cache"])[:3]
+        n_reg, lds_bytes, lds_cap = (tuple(TUNING["top_cache"]) + (0, 0, 64)[len(TUNING["top_cache"]):])[:3]
         if cache is not None and (n_reg > 0 or lds_bytes > 0):
             threads = block[0] * block[1]
             per_level = sum(self.decl_dtype[n].itemsize for n in cache.names) * threads
@@ -882,9 +883,9 @@ class _Emitter:
                 L.append("")
         vec = _vector_width(self, stage) if j_per_thread == 1 and block[0] % 64 == 0 else 0
         vec_fields: Tuple[str, ...] = ()
-        vec_rows = max(1, TUNING["vector_rows"])
+        vec_rows, xcd_rows = _strip_shape(self, stage) if vec else (max(1, TUNING["vector_rows"]), TUNING["xcd_rows"])
         if vec:
-            vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread)
+            vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread, xcd_rows)
         plane = None if stage.plane is None else (stage.plane[0], stage.plane[1].value, stage.plane[2])
         return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
                             vec_rows if vec else 1, plane, top_cache)
@@ -931,8 +932,28 @@ def _vector_width(em: "_Emitter", stage: Stage) -> int:
     return vec
 
 
+def _strip_shape(em: "_Emitter", stage: Stage) -> Tuple[int, int]:
+    """(J rows per lane, rows per XCD run) of a stage's strip kernel.  Measured in round 1
+    (profiles/r1_codegen_sweep.log, r1_codegen_xcd_rows_strip_kernels.log): 8 rows per lane and XCD runs of 4 tile rows
+    help the Laplacian (+2 % and +4 %) and hurt horizontal diffusion (-8 % registers, -5 %), so the tall, XCD-grouped shape
+    is for LIGHT stages only: one statement reading one 8-byte array within one row / column of the point.  Explicit
+    settings of GT4MI_CODEGEN_VECTOR_ROWS / _XCD_ROWS win."""
+    import os
+
+    rows, xcd = max(1, TUNING["vector_rows"]), TUNING["xcd_rows"]
+    if "GT4MI_CODEGEN_VECTOR_ROWS" in os.environ or "GT4MI_CODEGEN_XCD_ROWS" in os.environ:
+        return rows, xcd
+    stmts = [s for nest in stage.nests for s in nest.stmts]
+    reads = [e for s in stmts for e in _stmt_field_reads(s) if e.name not in em.plan.locals]
+    arrays = {e.name for e in reads}
+    light = (len(stmts) == 1 and len(stage.nests) == 1 and len(arrays) == 1
+             and all(max(abs(e.offset[0]), abs(e.offset[1])) <= 1 and e.offset[2] == 0 for e in reads)
+             and all(em.decl_dtype[n].itemsize == 8 for n in arrays | {stmts[0].target.name}))
+    return (8, 4) if light else (rows, xcd)
+
+
 def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block,
-                        k_per_thread: int) -> Tuple[str, ...]:
+                        k_per_thread: int, xcd_rows: int = 0) -> Tuple[str, ...]:
     """``<kname>_vec``: a lane owns ``vec`` consecutive I points times ``rows_per_lane`` consecutive J rows.
     Returns the arrays it touches."""
     L = em.lines
@@ -946,7 +967,7 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
 
     L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}_vec(const gt_args a) {{')
     L.append("    unsigned gt_bx, gt_by, gt_bz;")
-    L.append(f"    gt_tile({TUNING['xcd_rows']}u, gt_bx, gt_by, gt_bz);")
+    L.append(f"    gt_tile({xcd_rows}u, gt_bx, gt_by, gt_bz);")
     L.append("    const int lane = threadIdx.x & 63;  // waves lie along I: blockDim.x is a multiple of 64")
     L.append(f"    const gt_i64 i0 = ((gt_i64)gt_bx * {block[0]} + threadIdx.x) * {vec};")
     L.append(f"    const gt_i64 iend = a.dI + ({ihi}), jend = a.dJ + ({jhi});")

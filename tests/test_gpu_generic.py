@@ -285,7 +285,8 @@ def test_top_of_column_cache_default_depths(name, domain):
 
     expect, got, hip = _run_pair_rebuilt(name, domain)
     kern = type(hip)._gt_program_.kernels[0]
-    assert kern.top_cache is not None and kern.top_cache[:2] == (hip_codegen.TUNING["top_cache"][0], kern.top_cache[1])
+    # 16 register levels; LDS levels = 160 KB / (bytes per column and level x 256 threads); smallest domain = both + margin + 1
+    assert kern.top_cache == {"two_sweep_three_carried": (16, 32, 51)}.get(name, (16, 40, 58)), hip_codegen.TUNING["top_cache"]
     for k in expect:
         np.testing.assert_array_equal(got[k], expect[k], err_msg=f"{name} {domain}: field {k}")
 

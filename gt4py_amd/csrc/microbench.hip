@@ -450,6 +450,45 @@ static void tridiag_stack_variant(DevField<double>& a, DevField<double>& d, DevF
     report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
 }
 
+// The same solve on fields whose K levels are one ROW PITCH apart (layout I, K, J from fastest to slowest) instead of one
+// plane apart: a column's 160 levels then lie inside one or two 2 MiB pages.  Tests the address-translation hypothesis.
+static void section_trilayout() {
+    const int dI = 1024, dJ = 1024, dK = 160;
+    const size_t n = (size_t)dI * dJ * dK;
+    double* p[5];
+    for (int f = 0; f < 5; ++f) CK(hipMalloc(&p[f], n * sizeof(double) + 4096));
+    const unsigned ti = (unsigned)cdiv(dI, 64), t2 = (unsigned)cdiv(dI, 256);
+    for (int rep = 0; rep < 2; ++rep)
+        for (int layout = 0; layout < 2; ++layout) {
+            const int64_t sj = layout == 0 ? dI : (int64_t)dI * dK, sk = layout == 0 ? (int64_t)dI * dJ : dI;
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(4096), dim3(256), 0, 0, p[0], n, 1u, -1.0, 1.0);
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(4096), dim3(256), 0, 0, p[1], n, 2u, 4.0, 5.0);
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(4096), dim3(256), 0, 0, p[2], n, 3u, -1.0, 1.0);
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(4096), dim3(256), 0, 0, p[3], n, 4u, -10.0, 10.0);
+            CK(hipDeviceSynchronize());
+            View<const double> a{p[0], 1, sj, sk}, d{p[1], 1, sj, sk};
+            View<double> s{p[2], 1, sj, sk}, r{p[3], 1, sj, sk}, o{p[4], 1, sj, sk};
+            const char* tag = layout == 0 ? "planes: K stride 8 MiB (I,J,K)" : "rows:   K stride 8 KiB (I,K,J)";
+            char cfg[96];
+            double ms = time_ms([&](int) {
+                hipLaunchKernelGGL((tridiag_pipe_kernel<double, 80, 40, 8>), dim3(ti * dJ), dim3(64), 0, 0, a, d, s, r, o, dI, dJ, dK, ti);
+            }, 5, 2);
+            snprintf(cfg, sizeof cfg, "%s pipe<80,40,8>", tag);
+            report("trilayout", cfg, ms, (double)n, 56.0);
+            ms = time_ms([&](int) {
+                hipLaunchKernelGGL((tridiag_pipe_kernel<double, 32, 40, 8>), dim3(ti * dJ), dim3(64), 0, 0, a, d, s, r, o, dI, dJ, dK, ti);
+            }, 5, 2);
+            snprintf(cfg, sizeof cfg, "%s pipe<32,40,8>", tag);
+            report("trilayout", cfg, ms, (double)n, 56.0);
+            ms = time_ms([&](int) {
+                hipLaunchKernelGGL((tridiag_kernel<double, 1, 8>), dim3(t2 * dJ), dim3(256), 0, 0, a, d, s, r, o, dI, dJ, dK, t2);
+            }, 5, 2);
+            snprintf(cfg, sizeof cfg, "%s two-sweep<1,8>", tag);
+            report("trilayout", cfg, ms, (double)n, 56.0);
+        }
+    for (int f = 0; f < 5; ++f) hipFree(p[f]);
+}
+
 // a few launches of each column kernel and of the Laplacian, for counter passes (rocprofv3 --pmc ...)
 static void section_tripmc() {
     {
@@ -706,6 +745,7 @@ int main(int argc, char** argv) {
     if (!want.empty() && on("triplace")) section_triplace(0, want);
     if (!want.empty() && on("tripipe")) section_tripipe();
     if (!want.empty() && on("tripmc")) section_tripmc();
+    if (!want.empty() && on("trilayout")) section_trilayout();
     if (!want.empty() && on("events")) section_events();
     return ok ? 0 : 1;
 }

@@ -168,6 +168,54 @@ def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30) -> float:
     return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
+def hdiff_input(shape, dtype, gen, origin=(2, 2, 0)):
+    """the demo notebook's field (docs/.../demo_horizontal_diffusion.ipynb cell 9) plus noise, so that
+    the flux limiter fires on a non-trivial subset: 5 + 8 (2 + cos(pi (x + 1.5 y)) + sin(2 pi (x + 1.5 y))) / 4 + 0.1 U[-1, 1),
+    x = i / N, y = j / N; the same on every level."""
+    import math
+
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+
+    f = gt_storage.empty(shape, dtype, backend="hip:mi300", aligned_index=origin)
+    x = torch.arange(shape[0], dtype=torch.float64, device="cuda")[:, None, None] / shape[0]
+    y = torch.arange(shape[1], dtype=torch.float64, device="cuda")[None, :, None] / shape[1]
+    s = x + 1.5 * y
+    base = 5.0 + 8.0 * (2.0 + torch.cos(math.pi * s) + torch.sin(2.0 * math.pi * s)) / 4.0
+    noise = 0.1 * (torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen) * 2.0 - 1.0)
+    f.tensor.copy_((base + noise).to(f.tensor.dtype))
+    return f
+
+
+def host_cost_per_call(lap, n: int = 300):
+    """Microseconds of host time per call (SURVEY.md section 8d asks for the end-to-end Python cost next to the kernel
+    time): `FrozenStencil.__call__` and the validating `StencilObject.__call__` on a small domain (the cost does not
+    depend on the domain; a small one keeps the device queue from filling up), launches left asynchronous."""
+    import numpy as np
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+
+    inp = gt_storage.ones((34, 34, 8), np.float64, backend="hip:mi300", aligned_index=(1, 1, 0))
+    out = gt_storage.zeros((34, 34, 8), np.float64, backend="hip:mi300", aligned_index=(1, 1, 0))
+    origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}
+    frozen = lap.freeze(origin=origin, domain=(32, 32, 8))
+    res = {}
+    for name, fn in (("frozen_call", lambda: frozen(inp=inp, out=out)),
+                     ("validated_call", lambda: lap(inp, out, origin=(1, 1, 0), domain=(32, 32, 8)))):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        res[name + "_us"] = round(host / n * 1e6, 2)
+    return res
+
+
 def other_kernels(steps: int = 20):
     """The other kernels of the north star at their BASELINE.json sizes, through the same call path
     (storage -> stencil -> FrozenStencil), HIP-event timed.  Informational: `value` stays the Laplacian."""
@@ -224,7 +272,7 @@ def other_kernels(steps: int = 20):
         obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": dt},
                                device_sync=False, literal_float_precision=lit)
         shape = (dom[0] + 4, dom[1] + 4, dom[2])
-        fields = {"in_field": field(shape, dt, (2, 2, 0), 0.0, 10.0), "coeff": field(shape, dt, (2, 2, 0), 0.0, 0.05),
+        fields = {"in_field": hdiff_input(shape, dt, gen), "coeff": field(shape, dt, (2, 2, 0), 0.025, 0.025),
                   "out_field": field(shape, dt, (2, 2, 0))}
         run(tag, obj, fields, {k: (2, 2, 0) for k in fields}, dom, 3.0 * np.dtype(dt).itemsize, note=note)
         del fields
@@ -612,7 +660,8 @@ def _setup_hdiff2048(args, ctx):
         f.tensor.copy_(torch.rand(dec.local_shape, dtype=torch.float64, device="cuda", generator=gen) * (hi - lo) + lo)
         return f
 
-    fields = {"in_field": field(0.0, 10.0), "coeff": field(0.0, 0.05), "out_field": field(-1.0, 1.0)}
+    fields = {"in_field": hdiff_input(dec.local_shape, np.float64, gen, dec.origin), "coeff": field(0.025, 0.025),
+              "out_field": field(-1.0, 1.0)}
     origin = {k: dec.origin for k in fields}
     frozen = hd.freeze(origin=origin, domain=dec.local_domain)
     decomposed = distributed or selfloop
@@ -824,6 +873,11 @@ def main() -> None:
             },
             "device": _lib.device_info(),
         }
+        if headline:
+            try:
+                line["host_cost_per_call"] = host_cost_per_call(lap)
+            except Exception as ex:
+                print(f"host_cost_per_call failed: {ex!r}", file=sys.stderr)
         if headline and not args.no_other_kernels:
             try:
                 line["other_kernels"] = other_kernels()

@@ -27,6 +27,6 @@ for n in (1, 2, 4, 8):
             t = bench._time_launches(lambda i: frozen(inp=pairs[i % 4][0], out=pairs[i % 4][1]), 200)
             ideal = 16.0 * np.prod(dom) / 8e12 * 1e6
             print(f"{n} ranks, grid {pi}x{pj}, local {dom}, ghost depth {halo}: {t['mean'] * 1e3:7.1f} us per apply "
-                  f"({16.0 * np.prod(dom) / t['mean'] / 1e9:6.0f} GB/s, {ideal / (t['mean'] * 1e3):.2f} of the HBM roofline)", flush=True)
+                  f"({16.0 * np.prod(dom) / (t['mean'] * 1e-3) / 1e9:6.0f} GB/s, {ideal / (t['mean'] * 1e3):.2f} of the HBM roofline)", flush=True)
             del pairs
             torch.cuda.empty_cache()

@@ -150,8 +150,13 @@ def test_horizontal_stages_get_a_16_byte_lane_twin(programs):
     """Thread-per-point stages that only read arrays they do not write also exist as `<name>_vec`: a lane
     owns 2 fp64 (4 fp32) consecutive I points and several J rows; neighbours come from DPP lane shifts."""
     lap = programs["laplacian"]
-    assert [(k.vec, k.vec_rows, k.vec_fields) for k in lap.kernels] == [(2, 4, ("out", "inp"))]
+    # a light stage (one statement, one 8-byte array, offsets within one row / column): 8 rows per lane, XCD runs of 4
+    assert [(k.vec, k.vec_rows, k.vec_fields) for k in lap.kernels] == [(2, 8, ("out", "inp"))]
     assert "gt4mi_laplacian_stage0_vec" in lap.source and "gt_shift<double, true>" in lap.source
+    assert "gt_tile(4u, gt_bx, gt_by, gt_bz);" in lap.source[lap.source.index("gt4mi_laplacian_stage0_vec"):]
+    # everything heavier keeps 4 rows and the plain tile order
+    hd = programs["horizontal_diffusion"]
+    assert [(k.vec, k.vec_rows) for k in hd.kernels] == [(2, 4)] and "gt_tile(4u" not in hd.source
     assert [k.vec for k in programs["horizontal_diffusion_f32"].kernels] == [4]
     assert [k.vec for k in programs["mixed_precision"].kernels] == [2]  # widest element decides
     # not vectorised: sequential stages, stages that read what they write, arrays without an I axis as target

@@ -385,3 +385,35 @@ def test_generic_evaluator_equals_handwritten_restatements():
     assert np.array_equal(o1, o2) and np.array_equal(s1, s2) and np.array_equal(r1, r2)
     with pytest.raises(ValueError, match="Compute domain too small"):
         tri(inf[:, :, :1], diag[:, :, :1], s1[:, :, :1], r1[:, :, :1], o1[:, :, :1])
+
+
+def test_every_call_validation_message():
+    """The remaining branches of stencil_object.py:342-494 of the reference, message by message: a zero-sized
+    domain, a domain the fields cannot serve (with the offending fields named), an origin inside the stencil's
+    reach, a missing field and a missing parameter."""
+    stencil = gtscript.stencil(definition=avg_stencil, backend="numpy")
+    in_field, out_field = _in_out("numpy")
+    with pytest.raises(ValueError, match="Compute domain contains zero sizes"):
+        stencil(in_field=in_field, out_field=out_field, origin=(1, 1, 0), domain=(0, 0, 0))
+    # ... which, by the partial order of Shape (gtc/definitions.py:141-171: "no element smaller, any element
+    # larger"), only refuses the all-zero domain: one empty axis passes and the call writes nothing
+    stencil(in_field=in_field, out_field=out_field, origin=(1, 1, 0), domain=(0, 4, 4))
+    stencil(in_field=in_field, out_field=out_field, origin=(1, 1, 0), domain=(4, 4, 0))
+    assert (out_field.array == 0).all()
+    with pytest.raises(ValueError, match="Invalid 'domain' value"):
+        stencil(in_field=in_field, out_field=out_field, origin=(1, 1, 0), domain=(4, 4))
+    with pytest.raises(ValueError, match=r"Compute domain too large for stencil[\s\S]*Offending fields[\s\S]*in_field"):
+        stencil(in_field=in_field, out_field=out_field, origin=(1, 1, 0), domain=(21, 20, 10))
+    with pytest.raises(ValueError, match="Origin for field in_field too small. Must be at least"):
+        stencil(in_field=in_field, out_field=out_field, origin={"in_field": (0, 1, 0), "out_field": (1, 1, 0)},
+                domain=(4, 4, 4))
+    with pytest.raises((ValueError, TypeError), match="in_field|out_field"):
+        stencil(in_field=in_field, domain=(4, 4, 4), origin=(1, 1, 0))
+    pstencil = gtscript.stencil(definition=base_stencil, backend="numpy")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        A, B, C = _abc()
+        with pytest.raises((ValueError, TypeError), match="param"):
+            pstencil(A, B, C, domain=(1, 1, 1))
+    # nothing was written by any of the refused calls
+    assert (out_field.array == 0).all() and (A == 1).all()

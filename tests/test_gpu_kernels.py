@@ -314,3 +314,26 @@ def test_stream_copy():
     G.call("gt4mi_stream_copy", src.data_ptr(), dst.data_ptr(), src.numel() * 8, G.stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(src, dst)
+
+
+@pytest.mark.parametrize("domain", [(0, 6, 4), (6, 0, 4), (6, 6, 0)])
+def test_empty_domains_are_no_ops_at_the_boundary(domain):
+    """One empty axis: every entry point returns GT4MI_OK without a launch and without a write (the numpy backend's
+    slices are empty, stencil_object.py:370-373 only refuses the all-zero domain).  The tridiagonal entry point keeps
+    its own contract for K (min_sequential_axis_size 2)."""
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((10, 10, 6))
+    d_in, d_out, d_cf = G.DevArray(a, "ifirst", (2, 2, 0)), G.DevArray(np.full_like(a, 7.0), "ifirst", (2, 2, 0)), \
+        G.DevArray(a * 0.1, "ifirst", (2, 2, 0))
+    G.lap5(d_in, d_out, (2, 2, 0), (2, 2, 0), domain, 0)
+    G.hdiff(d_in, d_out, d_cf, (2, 2, 0), (2, 2, 0), (2, 2, 0), domain, _lib.HDIFF_LIMITER)
+    G.hdiff(d_in, d_out, 0.25, (2, 2, 0), (2, 2, 0), None, domain, 0)
+    assert (d_out.get() == 7.0).all() and (d_in.get() == a).all()
+    if domain[2] >= 2:
+        d = [G.DevArray(np.full((10, 10, 6), float(n + 1)), "ifirst") for n in range(5)]
+        G.tridiag(*d, {n: (0, 0, 0) for n in ("inf", "diag", "sup", "rhs", "out")}, domain)
+        for n, arr in enumerate(d):
+            assert (arr.get() == float(n + 1)).all()

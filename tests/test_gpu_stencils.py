@@ -377,3 +377,34 @@ def test_stencil_calls_can_be_captured_in_a_hip_graph():
         got_b, got_c = b.get(), c.get()
         assert np.array_equal(got_b[1:-1, 1:-1], want_b[1:-1, 1:-1])
         assert np.array_equal(got_c[2:-2, 2:-2], want_c[2:-2, 2:-2])
+
+
+def column_sum(a: "Field[np.float64]", s: "Field[np.float64]"):  # noqa: F821
+    with computation(FORWARD):  # noqa: F821
+        with interval(0, 1):  # noqa: F821
+            s = a  # noqa: F841
+        with interval(1, None):  # noqa: F821
+            s = s[0, 0, -1] + a  # noqa: F841
+
+
+def test_an_empty_axis_is_a_call_that_writes_nothing():
+    """The reference refuses only the ALL-zero domain (stencil_object.py:370-373 with the partial order of
+    gtc/definitions.py:141-171); a domain with one empty axis passes validation and the numpy backend's slices are
+    empty.  Same here, through the hand-written kernels, a generated horizontal kernel and a generated column
+    kernel: no launch, no write, no error."""
+    gt_storage, gtscript = _imports()
+    lap = gtscript.stencil(backend=BACKEND, definition=lap_cartesian)        # kernel library
+    avg = gtscript.stencil(backend=BACKEND, definition=avg_stencil)          # generated, horizontal
+    col = gtscript.stencil(backend=BACKEND, definition=column_sum)           # generated, column
+    mk = lambda fill: gt_storage.full((12, 12, 6), fill, backend=BACKEND, aligned_index=(1, 1, 0), dtype=np.float64)  # noqa: E731
+    for stencil in (lap, avg, col):
+        for domain in ((0, 4, 4), (4, 0, 4), (4, 4, 0)):
+            a, b = mk(1.0), mk(7.0)
+            if stencil is col and domain[2] == 0:  # its two intervals need two levels (min_sequential_axis_size)
+                with pytest.raises(ValueError, match="Compute domain too small. Sequential axis is 0"):
+                    stencil(a, b, origin=(1, 1, 0), domain=domain)
+            else:
+                stencil(a, b, origin=(1, 1, 0), domain=domain)
+            assert (b.get() == 7.0).all() and (a.get() == 1.0).all(), (stencil.options["name"], domain)
+        with pytest.raises(ValueError, match="Compute domain contains zero sizes"):
+            stencil(mk(1.0), mk(7.0), origin=(1, 1, 0), domain=(0, 0, 0))

@@ -75,12 +75,17 @@ TUNING = {
     # neighbouring output rows are loaded (computed) once per strip
     "vector_rows": _env_tuple("GT4MI_CODEGEN_VECTOR_ROWS", (4,))[0],
     # two-sweep column stages (stage_planner.TopCache): levels of the forward sweep's results kept in registers and,
-    # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup); (0, 0) = off
-    # 16 register levels: the vertical advection needs 344 of the 512 registers a lone wave per SIMD may use; from 24
-    # levels on the compiler spills to scratch (it keeps ~10 values per unrolled level alive, addresses included).  The
-    # host checks the compiled kernel and does not launch a variant that spills (hip_generic._Variant).  Third item: cap
-    # on the LDS levels (deeper caches on fewer, narrower workgroups were not faster: r2_codegen_top_cache_block_shapes.log)
-    "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (16, 160 * 1024, 64)),
+    # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup, cap on the LDS levels).
+    # Register levels < 0 (the default): one `_tc<n>` kernel per depth n = n_max, n_max - step, ... >= 16, where n_max
+    # is what `top_cache_auto` = (register budget in dwords per lane, step in levels) allows for the cached fields of
+    # the stage (vertical advection: 2 fp64 fields = 4 dwords per level -> 112, 80, 48, 16 levels + 40 in LDS); the
+    # host launches the deepest variant the domain's K has room for and that compiled without spilling
+    # (hip_generic._Variant).  A lone wave per SIMD owns 512 registers; a cached level costs exactly its dwords once the
+    # register levels are pinned (_pin_register_level) and the second sweep has its own bases (_second_sweep_bases) --
+    # before that it cost three times as much and 24 levels already spilled (profiles/r2_codegen_top_cache_deep_*.log).
+    # (0, 0) = off; an explicit depth (GT4MI_CODEGEN_TOP_CACHE=80,163840) emits that one variant only.
+    "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (-1, 160 * 1024, 64)),
+    "top_cache_auto": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_AUTO", (448, 32)),
 }
 
 from .stage_planner import (Nest, Plan, Stage, Stmt, UnsupportedStencil, _field_reads, _stmt_field_reads,  # noqa: F401
@@ -262,9 +267,10 @@ class KernelSource:
     vec_fields: Tuple[str, ...] = ()  # arrays whose alignment / strides decide whether it may be launched
     vec_rows: int = 1  # consecutive J rows per lane in the `_vec` kernel
     plane: Optional[Tuple[int, str, ir.Interval]] = None  # launched once per K level by the host (Stage.plane)
-    #: (register levels, LDS levels, smallest domain K): a `<name>_tc` kernel exists that keeps the top levels of a
-    #: two-sweep column stage on chip; the host launches it when the domain has at least that many levels
-    top_cache: Optional[Tuple[int, int, int]] = None
+    #: ((register levels, LDS levels, smallest domain K), ...), deepest first: for each a `<name>_tc<register levels>`
+    #: kernel exists that keeps that many top levels of a two-sweep column stage on chip; the host launches the first
+    #: one the domain has enough levels for
+    top_cache: Optional[Tuple[Tuple[int, int, int], ...]] = None
 
 
 @dataclass
@@ -715,6 +721,8 @@ class _Emitter:
                 if n_reg:  # every slot is written by the forward sweep before the backward sweep reads it
                     L.append(f"    {ct} {', '.join(f'tc_{c}_{u}' for u in range(n_reg))};")
         for ni, nest in enumerate(stage.nests):
+            if self.tc is not None and ni == self.tc[0].first_sweep_nests:
+                self._second_sweep_bases(stage)
             L.append("    {")
             L.append(f"        const gt_i64 k0 = {self.bound(nest.interval.start)}, k1 = {self.bound(nest.interval.end)};")
             back = -1 if nest.order is ir.LoopOrder.FORWARD else 1
@@ -772,6 +780,29 @@ class _Emitter:
                     self._register_range(si, stage, nest, group, active, back, mode[1], n_reg)
                 self.tc_mode = ("mem",)
             L.append("    }")
+        if self.tc is not None:
+            L.append("    }")  # the scope _second_sweep_bases opened
+
+    def _second_sweep_bases(self, stage: Stage) -> None:
+        """The second sweep of a `_tc` kernel addresses its arrays through base pointers the optimiser cannot relate to
+        the first sweep's (base + an opaque zero).  A field both sweeps touch at the same levels (u_pos and
+        utens_stage of the vertical advection) otherwise has every register-range address of the first sweep kept
+        alive -- in accumulator registers -- for its reuse by the second: 2 registers per field and level, as much
+        as the cached values themselves."""
+        L = self.lines
+        names = [n for n in self.stage_globals(stage) if n not in self.plan.register_only]
+        L.append("    gt_i64 tc_zero = 0;")
+        L.append('    asm volatile("" : "+s"(tc_zero));')
+        for n in names:
+            c = _c_ident(n)
+            L.append(f"    const auto tc_b_{c} = b_{c} + tc_zero;")
+        L.append("    {")
+        for n in names:
+            c = _c_ident(n)
+            ct = _CTYPE[self.decl_dtype[n].name]
+            const = "" if n in stage.written else "const "
+            qual = " __restrict__" if n in self.plan.scratch else " GT_RESTRICT"
+            L.append(f"    {const}{ct}* const{qual} b_{c} = tc_b_{c};")
 
     def _emit_level(self, si: int, stage: Stage, nest: Nest, group, active, back: int, kexpr: str, pad: str) -> None:
         """One K level of a column sweep: locals, statements, rotation of the forwarded registers."""
@@ -823,14 +854,28 @@ class _Emitter:
                     L.append("            {")
                     self._emit_level(si, stage, nest, group, active, back, f"(k {'-' if backward else '+'} {u})", "                ")
                     L.append("            }")
+                    self._pin_register_level(slot)
                 self.prefetch_for = {}
                 pos += depth
             else:  # the levels that do not fill a batch: one at a time
                 self.tc_mode = ("reg", batch[0])
                 self._emit_level(si, stage, nest, group, active, back, "k", "            ")
+                self._pin_register_level(batch[0])
                 pos += 1
             L.append("        }")
         L.append("        __builtin_amdgcn_sched_barrier(0);")
+
+    def _pin_register_level(self, slot: int) -> None:
+        """A level whose results only go to register slots has no side effect, and instruction selection sinks its
+        arithmetic to the first use of those slots -- the other sweep -- across every sched_barrier in between (they
+        order the scheduler, not the selector).  All loads of all register levels would then stay live until the second
+        sweep starts (measured: 12 registers per cached level instead of 4, spills from 24 levels on).  An empty
+        volatile asm that takes the slots as inputs pins the arithmetic to the level it belongs to."""
+        if self.tc_sweep2 or not self.tc_written:
+            return
+        names = sorted(self.tc_written)
+        constraints = ", ".join(f'"v"(tc_{_c_ident(n)}_{slot})' for n in names)
+        self.lines.append(f"            asm volatile(\"\" :: {constraints});")
 
     def kernel(self, si: int, stage: Stage, kname: str) -> KernelSource:
         L = self.lines
@@ -862,17 +907,27 @@ class _Emitter:
         L.append("")
         top_cache = None
         cache = self.plan.top_cache.get(si) if stage.mapping == "column" else None
-        n_reg, lds_bytes, lds_cap = (tuple(TUNING["top_cache"]) + (0, 0, 64)[len(TUNING["top_cache"]):])[:3]
-        if cache is not None and (n_reg > 0 or lds_bytes > 0):
+        n_reg_cfg, lds_bytes, lds_cap = (tuple(TUNING["top_cache"]) + (0, 0, 64)[len(TUNING["top_cache"]):])[:3]
+        if cache is not None and (n_reg_cfg != 0 or lds_bytes > 0):
             threads = block[0] * block[1]
             per_level = sum(self.decl_dtype[n].itemsize for n in cache.names) * threads
             n_lds = min(int(lds_bytes) // per_level, int(lds_cap))
-            if n_reg + n_lds > 0:
+            if n_reg_cfg >= 0:
+                depths = [int(n_reg_cfg)]
+            else:
+                budget, step = (tuple(TUNING["top_cache_auto"]) + (448, 32)[len(TUNING["top_cache_auto"]):])[:2]
+                n_max = min(int(budget) // sum(self.decl_dtype[n].itemsize // 4 for n in cache.names), 128)
+                n_max -= n_max % 8
+                depths = list(range(n_max, 15, -max(8, int(step)))) or [n_max]
+            variants = []
+            for n_reg in depths:
+                if n_reg + n_lds <= 0:
+                    continue
                 # every START-relative interval bound must lie below the cached range, and every nest that is not
                 # statically empty must hold at least one level there -> the smallest domain the variant may run on
-                top_cache = (int(n_reg), int(n_lds), int(n_reg) + int(n_lds) + cache.start_margin + 1)
+                variants.append((int(n_reg), int(n_lds), int(n_reg) + int(n_lds) + cache.start_margin + 1))
                 L.append("#if GT4MI_NO_ALIAS")  # the cached copies stand in for memory: only with disjoint arguments
-                self._kernel_header(stage, kname + "_tc", block, 1)
+                self._kernel_header(stage, f"{kname}_tc{n_reg}", block, 1)
                 self.tc = (cache, int(n_reg), int(n_lds), threads)
                 try:
                     self._column_body(si, stage)
@@ -881,6 +936,7 @@ class _Emitter:
                 L.append("}")
                 L.append("#endif")
                 L.append("")
+            top_cache = tuple(variants) or None
         vec = _vector_width(self, stage) if j_per_thread == 1 and block[0] % 64 == 0 else 0
         vec_fields: Tuple[str, ...] = ()
         vec_rows, xcd_rows = _strip_shape(self, stage) if vec else (max(1, TUNING["vector_rows"]), TUNING["xcd_rows"])

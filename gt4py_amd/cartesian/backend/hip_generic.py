@@ -87,7 +87,7 @@ class _Variant:
         self.module = module
         self.functions: List[ctypes.c_void_p] = []
         self.vec_functions: List[Any] = []  # the 16-byte-lane twin of a stage kernel, or None
-        self.tc_functions: List[Any] = []  # the top-of-column-cache twin of a two-sweep column kernel, or None
+        self.tc_functions: List[Any] = []  # per kernel: the top-of-column-cache twins of a two-sweep column kernel
         for kern in program.kernels:
             fn = ctypes.c_void_p()
             _lib.check("gt4mi_module_function",
@@ -99,16 +99,17 @@ class _Variant:
                 _lib.check("gt4mi_module_function",
                            lib.gt4mi_module_function(module, (kern.name + "_vec").encode(), ctypes.byref(vfn)))
             self.vec_functions.append(vfn)
-            tfn = None
+            tfns = []  # [(function, smallest domain K)], deepest cache first
             if kern.top_cache is not None and no_alias:  # emitted under GT4MI_NO_ALIAS only
-                tfn = ctypes.c_void_p()
-                _lib.check("gt4mi_module_function",
-                           lib.gt4mi_module_function(module, (kern.name + "_tc").encode(), ctypes.byref(tfn)))
-                scratch = ctypes.c_int(0)
-                _lib.check("gt4mi_function_info", lib.gt4mi_function_info(tfn, None, ctypes.byref(scratch), None))
-                if scratch.value > 0:  # the register levels did not fit: spills would cost more than the cache saves
-                    tfn = None
-            self.tc_functions.append(tfn)
+                for n_reg, _, min_k in kern.top_cache:
+                    tfn = ctypes.c_void_p()
+                    _lib.check("gt4mi_module_function",
+                               lib.gt4mi_module_function(module, f"{kern.name}_tc{n_reg}".encode(), ctypes.byref(tfn)))
+                    scratch = ctypes.c_int(0)
+                    _lib.check("gt4mi_function_info", lib.gt4mi_function_info(tfn, None, ctypes.byref(scratch), None))
+                    if scratch.value == 0:  # else the register levels did not fit: spills cost more than the cache saves
+                        tfns.append((tfn, int(min_k)))
+            self.tc_functions.append(tfns)
 
 
 def _ranges_disjoint(ranges: List[Tuple[int, int]]) -> bool:
@@ -342,10 +343,12 @@ class HipGenericStencilObject(StencilObject):
                 per_level[k] = ctypes.byref(copy)
             return per_level[k]
 
-        def geometry_of(kern, fn, vfn, tfn, levels: int):
+        def geometry_of(kern, fn, vfn, tfns, levels: int):
             (ilo, ihi), (jlo, jhi) = kern.extent
-            if tfn is not None and dK >= kern.top_cache[2]:
-                fn = tfn  # deep enough for the top levels to stay in registers + LDS between the two sweeps
+            for tfn, min_k in tfns:  # deepest first: the most levels that stay in registers + LDS between the two sweeps
+                if dK >= min_k:
+                    fn = tfn
+                    break
             ni, nj = dI + ihi - ilo, dJ + jhi - jlo
             if ni <= 0 or nj <= 0 or levels <= 0:
                 return None

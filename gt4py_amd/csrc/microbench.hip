@@ -14,6 +14,7 @@
 #include "hdiff.hip.h"
 #include "lap5.hip.h"
 #include "tridiag.hip.h"
+#include "vadv_stack.hip.h"
 
 using namespace gt4mi;
 
@@ -541,6 +542,96 @@ static void section_tripipe() {
     }
 }
 
+
+// ---- vertical advection with the top of the column on chip (vadv_stack.hip.h) ---------------------
+struct VadvSet {
+    DevField<double> wcon, u_stage, u_pos, utens, ts0, ts, ts_ref, ccol, dcol;
+    int dI, dJ, dK;
+    VadvSet(int dI_, int dJ_, int dK_)
+        : wcon(dI_, dJ_, dK_, 1, 0), u_stage(dI_, dJ_, dK_, 0, 0), u_pos(dI_, dJ_, dK_, 0, 0), utens(dI_, dJ_, dK_, 0, 0),
+          ts0(dI_, dJ_, dK_, 0, 0), ts(dI_, dJ_, dK_, 0, 0), ts_ref(dI_, dJ_, dK_, 0, 0), ccol(dI_, dJ_, dK_, 0, 0),
+          dcol(dI_, dJ_, dK_, 0, 0), dI(dI_), dJ(dJ_), dK(dK_) {
+        fill(wcon, 11, -1.0, 1.0);
+        fill(u_stage, 12, -1.0, 1.0);
+        fill(u_pos, 13, -1.0, 1.0);
+        fill(utens, 14, -1.0, 1.0);
+        fill(ts0, 15, -1.0, 1.0);
+    }
+    VadvFields fields(DevField<double>& out) {
+        return VadvFields{wcon.cview(), u_stage.cview(), u_pos.cview(), utens.cview(), out.view(), ccol.view(), dcol.view()};
+    }
+    void reset(DevField<double>& out) { CK(hipMemcpy(out.raw, ts0.raw, ts0.bytes, hipMemcpyDeviceToDevice)); }
+};
+
+static constexpr double VADV_DTR = 3.0 / 20.0;
+
+static void vadv_plain(VadvSet& s, DevField<double>& out) {
+    hipLaunchKernelGGL(vadv_plain_kernel, dim3((unsigned)cdiv(s.dI, 64), (unsigned)cdiv(s.dJ, 4)), dim3(64, 4), 0, 0, s.fields(out),
+                       VADV_DTR, 0.5, 0.5, s.dI, s.dJ, s.dK);
+}
+
+template <int RL, int LL, int U>
+static void vadv_variant(VadvSet& s, bool time_it = true) {
+    const unsigned tiles_i = (unsigned)cdiv(s.dI, 64);
+    auto launch = [&](DevField<double>& out) {
+        hipLaunchKernelGGL((vadv_pipe_kernel<RL, LL, U>), dim3(tiles_i * (unsigned)s.dJ), dim3(64), 0, 0, s.fields(out), VADV_DTR, 0.5,
+                           0.5, s.dI, s.dJ, s.dK, tiles_i);
+    };
+    char cfg[96];
+    snprintf(cfg, sizeof cfg, "%dx%dx%d regs %d lds %d batch %d", s.dI, s.dJ, s.dK, RL, LL, U);
+    if (s.dK - RL - LL < 1) {
+        printf("vadv       %-44s skipped (needs dK > %d)\n", cfg, RL + LL);
+        return;
+    }
+    s.reset(s.ts);
+    launch(s.ts);
+    CK(hipDeviceSynchronize());
+    const unsigned long long bad = count_diff(s.ts, s.ts_ref, s.dI, s.dJ, s.dK);
+    if (bad) printf("vadv       %-44s MISMATCH in %llu points\n", cfg, bad);
+    if (time_it) {
+        const double ms = time_ms([&](int) { launch(s.ts); }, 20);
+        report(bad ? "vadv BAD" : "vadv", cfg, ms, (double)s.dI * s.dJ * s.dK, 48.0);
+    } else if (!bad) {
+        printf("vadv       %-44s identical\n", cfg);
+    }
+}
+
+static void section_vadv() {
+    {
+        VadvSet s(1024, 1024, 160);
+        s.reset(s.ts_ref);
+        vadv_plain(s, s.ts_ref);
+        CK(hipDeviceSynchronize());
+        for (int rep = 0; rep < 2; ++rep) {
+            const double ms = time_ms([&](int) { vadv_plain(s, s.ts); }, 20);
+            report("vadv", "1024x1024x160 plain (no cache, 64x4 blocks)", ms, (double)s.dI * s.dJ * s.dK, 48.0);
+            vadv_variant<16, 40, 4>(s);
+            vadv_variant<16, 40, 8>(s);
+            vadv_variant<32, 40, 4>(s);
+            vadv_variant<32, 40, 8>(s);
+            vadv_variant<48, 40, 4>(s);
+            vadv_variant<48, 40, 8>(s);
+            vadv_variant<64, 40, 4>(s);
+            vadv_variant<64, 40, 8>(s);
+            vadv_variant<80, 40, 4>(s);
+            vadv_variant<80, 40, 8>(s);
+            vadv_variant<96, 40, 4>(s);
+            vadv_variant<64, 0, 4>(s);
+            vadv_variant<32, 0, 8>(s);
+        }
+    }
+    for (int dK : {58, 59, 60, 61, 62, 63, 64, 65, 66, 73, 80, 81}) {  // every head / parity / leftover case
+        VadvSet s(200, 37, dK);
+        s.reset(s.ts_ref);
+        vadv_plain(s, s.ts_ref);
+        CK(hipDeviceSynchronize());
+        vadv_variant<16, 40, 4>(s, false);
+        vadv_variant<16, 40, 8>(s, false);
+        vadv_variant<16, 0, 8>(s, false);
+        vadv_variant<8, 0, 4>(s, false);
+    }
+}
+
 static void section_tridiag() {
     const int dI = 1024, dJ = 1024, dK = 160;
     DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
@@ -746,6 +837,7 @@ int main(int argc, char** argv) {
     if (!want.empty() && on("tripipe")) section_tripipe();
     if (!want.empty() && on("tripmc")) section_tripmc();
     if (!want.empty() && on("trilayout")) section_trilayout();
+    if (!want.empty() && on("vadv")) section_vadv();
     if (!want.empty() && on("events")) section_events();
     return ok ? 0 : 1;
 }

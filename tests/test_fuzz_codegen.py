@@ -109,7 +109,7 @@ def test_two_sweep_programs_plan_and_compile(seed, tmp_path):
         hip_codegen.TUNING["top_cache"] = saved
     program = type(hip)._gt_program_
     if program.plan.top_cache:
-        assert any(k.top_cache is not None for k in program.kernels) and "_tc(const gt_args a)" in program.source, text
+        assert any(k.top_cache is not None for k in program.kernels) and "_tc3(const gt_args a)" in program.source, text
     assert _lib.rtc_compile(program.source, f"two_sweep_{seed}.hip", ["-DGT4MI_UNIT_I_STRIDE=1", "-DGT4MI_NO_ALIAS=1"])[:4] == b"\x7fELF"
 
 
@@ -130,7 +130,7 @@ def test_two_sweep_programs_match_the_oracle(seed, tmp_path):
 
     rnd = random.Random(seed)
     ref, scalars, text = _two_sweep(seed, tmp_path, "numpy")
-    for depths, levels in (((rnd.randint(0, 6), rnd.randint(0, 6)), None), (None, rnd.choice([64, 97, 130]))):
+    for depths, levels in (((rnd.randint(0, 6), rnd.randint(0, 6)), None), (None, rnd.choice([64, 97, 130, 161]))):
         saved = hip_codegen.TUNING["top_cache"]
         if depths is not None:
             hip_codegen.TUNING["top_cache"] = (depths[0], depths[1] * 8 * 3 * 256, 64)
@@ -140,7 +140,7 @@ def test_two_sweep_programs_match_the_oracle(seed, tmp_path):
             hip_codegen.TUNING["top_cache"] = saved
         kern = type(hip)._gt_program_.kernels[0]
         k_values = [levels] if levels else sorted({max(ref.domain_info.min_sequential_axis_size, k) for k in
-                                                   ((kern.top_cache[2] if kern.top_cache else 8) + d for d in (-1, 0, 1, 7))})
+                                                   ((kern.top_cache[-1][2] if kern.top_cache else 8) + d for d in (-1, 0, 1, 7))})
         for nk in k_values:
             domain = (66, 3, nk)
             arrays, origins = zoo.make_inputs(ref, domain, seed)

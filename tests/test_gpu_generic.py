@@ -277,16 +277,21 @@ def _run_pair_rebuilt(name, domain, seed=4242):
 
 
 @pytest.mark.parametrize("name", TWO_SWEEP)
-@pytest.mark.parametrize("domain", [(70, 5, 100), (130, 3, 161), (64, 8, 58), (64, 8, 59), (33, 2, 57)])
+@pytest.mark.parametrize("domain", [(70, 5, 100), (130, 3, 161), (64, 8, 58), (64, 8, 59), (33, 2, 57), (66, 3, 89), (66, 3, 90),
+                                    (66, 3, 121), (66, 3, 122), (66, 3, 123), (66, 3, 153), (66, 3, 154), (66, 3, 155), (64, 2, 200)])
 def test_top_of_column_cache_default_depths(name, domain):
-    """Deep domains take the `_tc` kernel (registers + LDS hold the top levels between the sweeps), shallower ones the
-    plain kernel; both must reproduce the oracle bit for bit on every field."""
+    """Deep domains take a `_tc<n>` kernel (registers + LDS hold the top levels between the sweeps) -- the deepest one
+    the domain has room for --, shallower ones the plain kernel; every one must reproduce the oracle bit for bit on
+    every field.  The domains sit on both sides of every variant's smallest K."""
     from gt4py_amd.cartesian.backend import hip_codegen
 
     expect, got, hip = _run_pair_rebuilt(name, domain)
     kern = type(hip)._gt_program_.kernels[0]
-    # 16 register levels; LDS levels = 160 KB / (bytes per column and level x 256 threads); smallest domain = both + margin + 1
-    assert kern.top_cache == {"two_sweep_three_carried": (16, 32, 51)}.get(name, (16, 40, 58)), hip_codegen.TUNING["top_cache"]
+    # register levels: 448 dwords per lane / dwords per cached level, rounded down to a multiple of 8, then every 32 levels
+    # down to 16; LDS levels = 160 KB / (bytes per column and level x 256 threads); smallest domain = both + margin + 1
+    want = {"two_sweep_three_carried": tuple((n, 32, n + 32 + 3) for n in (88, 56, 24))}.get(
+        name, tuple((n, 40, n + 40 + 2) for n in (112, 80, 48, 16)))
+    assert kern.top_cache == want, hip_codegen.TUNING["top_cache"]
     for k in expect:
         np.testing.assert_array_equal(got[k], expect[k], err_msg=f"{name} {domain}: field {k}")
 
@@ -307,7 +312,7 @@ def test_top_of_column_cache_every_range_boundary(name, depths, levels):
         expect, got, hip = _run_pair_rebuilt(name, (66, 5, levels), seed=levels)
         kern = type(hip)._gt_program_.kernels[0]
         margin = {"two_sweep_three_carried": 2}.get(name, 1)
-        assert kern.top_cache == (depths[0], depths[1], depths[0] + depths[1] + margin + 1)
+        assert kern.top_cache == ((depths[0], depths[1], depths[0] + depths[1] + margin + 1),)
     finally:
         hip_codegen.TUNING["top_cache"] = saved
         # leave no class built with the shallow depths in the cache
@@ -330,11 +335,12 @@ def test_top_of_column_cache_is_what_runs_and_does_not_spill():
     for k in expect:
         np.testing.assert_array_equal(got[k], expect[k])
     variant = next(iter(type(hip)._gt_variants_.values()))
-    tfn = variant.tc_functions[0]
-    assert tfn is not None, "the `_tc` kernel was refused (spills?)"
-    regs, scratch, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _lib.check("gt4mi_function_info", _lib.load().gt4mi_function_info(tfn, ctypes.byref(regs), ctypes.byref(scratch), ctypes.byref(lds)))
-    assert scratch.value == 0 and lds.value == 160 * 1024 and regs.value <= 512
+    tfns = variant.tc_functions[0]
+    assert [min_k for _, min_k in tfns] == [154, 122, 90, 58], "a `_tc<n>` kernel was refused (spills?)"
+    for tfn, _ in tfns:
+        regs, scratch, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check("gt4mi_function_info", _lib.load().gt4mi_function_info(tfn, ctypes.byref(regs), ctypes.byref(scratch), ctypes.byref(lds)))
+        assert scratch.value == 0 and lds.value == 160 * 1024 and regs.value <= 512
     expect, got, hip2 = _run_pair_rebuilt("vertical_advection_dycore", (64, 4, 160))
     for k in expect:
         np.testing.assert_array_equal(got[k], expect[k])

@@ -76,16 +76,21 @@ TUNING = {
     "vector_rows": _env_tuple("GT4MI_CODEGEN_VECTOR_ROWS", (4,))[0],
     # two-sweep column stages (stage_planner.TopCache): levels of the forward sweep's results kept in registers and,
     # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup, cap on the LDS levels).
-    # Register levels < 0 (the default): one `_tc<n>` kernel per depth n = n_max, n_max - step, ... >= 16, where n_max
+    # Register levels < 0 (the default): one `_tc<n>` kernel per depth n = n_max, n_max - step, ... and 16, where n_max
     # is what `top_cache_auto` = (register budget in dwords per lane, step in levels) allows for the cached fields of
-    # the stage (vertical advection: 2 fp64 fields = 4 dwords per level -> 112, 80, 48, 16 levels + 40 in LDS); the
+    # the stage (vertical advection: 2 fp64 fields = 4 dwords per level -> 104, 72, 40, 16 levels + 40 in LDS); the
     # host launches the deepest variant the domain's K has room for and that compiled without spilling
     # (hip_generic._Variant).  A lone wave per SIMD owns 512 registers; a cached level costs exactly its dwords once the
     # register levels are pinned (_pin_register_level) and the second sweep has its own bases (_second_sweep_bases) --
     # before that it cost three times as much and 24 levels already spilled (profiles/r2_codegen_top_cache_deep_*.log).
     # (0, 0) = off; an explicit depth (GT4MI_CODEGEN_TOP_CACHE=80,163840) emits that one variant only.
     "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (-1, 160 * 1024, 64)),
-    "top_cache_auto": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_AUTO", (448, 32)),
+    "top_cache_auto": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_AUTO", (416, 32)),
+    # register levels of a `_tc` kernel: issue the loads of batch n + 1 before the arithmetic of batch n (1) or each
+    # batch's loads right before its own arithmetic (0).  Measured (profiles/r2_codegen_top_cache_pipeline.log): +1..3 %
+    # at equal depth for the vertical advection, but the second buffer costs ~40 registers = 10 cached levels, which
+    # are worth as much; the generated tridiagonal solve loses its 96 / 104 level variants to spills with it.  Off.
+    "top_cache_pipeline": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_PIPELINE", (0,))[0],
 }
 
 from .stage_planner import (Nest, Plan, Stage, Stmt, UnsupportedStencil, _field_reads, _stmt_field_reads,  # noqa: F401
@@ -825,44 +830,67 @@ class _Emitter:
 
     def _register_range(self, si: int, stage: Stage, nest: Nest, group, active, back: int, slots: Sequence[int], n_reg: int) -> None:
         """The levels of a nest that live in register slots (compile-time indices): straight-line code, in sweep
-        order, in batches whose loads are issued ahead of the arithmetic exactly as in the loops (prefetch_chunk)."""
+        order, in batches whose loads are issued ahead of the arithmetic exactly as in the loops (prefetch_chunk) -- and
+        one batch further: the loads of batch n + 1 are issued before the arithmetic of batch n, so that a lone wave per
+        SIMD always has a batch of loads in flight while it computes (hoisting them over the stores of batch n is safe
+        for the same reason hoisting within a batch is: prefetch_chunk only hoists reads of levels the sweep has not
+        stored yet)."""
         L = self.lines
         backward = nest.order is ir.LoopOrder.BACKWARD
         order = list(reversed(slots)) if backward else list(slots)
         self.tc_mode = ("reg", order[0])
         chunk = None if nest.split_statements else self.prefetch_chunk(group, stage, nest, active, back)
         depth = chunk[0] if chunk is not None else 1
-        pos = 0
-        while pos < len(order):
-            batch = order[pos:pos + depth]
+        batches = [order[pos:pos + depth] for pos in range(0, len(order), depth)]
+        sign = "-" if backward else "+"
+
+        def base(batch) -> str:
+            return f"(a.dK - {n_reg - batch[0]})"
+
+        def full(batch) -> bool:
+            return chunk is not None and len(batch) == depth
+
+        def issue_loads(bi: int) -> Dict[Tuple, str]:
+            """Declare and issue the hoisted loads of batch `bi` (names unique per batch: one scope holds them all)."""
+            _, loads, _ = chunk
+            named = {slot: f"q{bi}_{var}" for slot, var in loads.items()}
+            self.tc_written = set()  # hoisted loads see what memory held BEFORE the batch's levels are assigned
+            for (name, off, rel, data), var in named.items():
+                e = ir.FieldAccess(name, (off[0], off[1], rel), None, None, data)
+                L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, base(batches[bi]), -1, {})};")
+            return named
+
+        L.append("        {")
+        pending = issue_loads(0) if full(batches[0]) and TUNING["top_cache_pipeline"] else None
+        for bi, batch in enumerate(batches):
             # a fence per batch: otherwise the scheduler hoists the loads of ALL unrolled levels to the top of the
             # straight-line region and runs out of registers
             L.append("        __builtin_amdgcn_sched_barrier(0);")
-            L.append("        {")
-            L.append(f"            const gt_i64 k = a.dK - {n_reg - batch[0]};")
-            if chunk is not None and len(batch) == depth:
-                _, loads, per_statement = chunk
-                self.tc_written = set()  # hoisted loads see what memory held BEFORE the batch's levels are assigned
-                for (name, off, rel, data), var in loads.items():
-                    e = ir.FieldAccess(name, (off[0], off[1], rel), None, None, data)
-                    L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, 'k', -1, {})};")
+            named, pending = pending, None
+            if not TUNING["top_cache_pipeline"]:
+                named = issue_loads(bi) if full(batch) else None
+            elif bi + 1 < len(batches) and full(batches[bi + 1]):
+                pending = issue_loads(bi + 1)
+            if named is not None:
+                _, _, per_statement = chunk
                 for u, slot in enumerate(batch):
                     step = -u if backward else u
-                    self.prefetch_for = {sid: {key: loads[(key[0], key[1][:2], key[1][2] + step, key[2])] for key in keys}
+                    self.prefetch_for = {sid: {key: named[(key[0], key[1][:2], key[1][2] + step, key[2])] for key in keys}
                                          for sid, keys in per_statement.items()}
                     self.tc_mode = ("reg", slot)
                     L.append("            {")
-                    self._emit_level(si, stage, nest, group, active, back, f"(k {'-' if backward else '+'} {u})", "                ")
+                    self._emit_level(si, stage, nest, group, active, back, f"({base(batch)} {sign} {u})", "                ")
                     L.append("            }")
                     self._pin_register_level(slot)
                 self.prefetch_for = {}
-                pos += depth
             else:  # the levels that do not fill a batch: one at a time
-                self.tc_mode = ("reg", batch[0])
-                self._emit_level(si, stage, nest, group, active, back, "k", "            ")
-                self._pin_register_level(batch[0])
-                pos += 1
-            L.append("        }")
+                for u, slot in enumerate(batch):
+                    self.tc_mode = ("reg", slot)
+                    L.append("            {")
+                    self._emit_level(si, stage, nest, group, active, back, f"({base(batch)} {sign} {u})", "                ")
+                    L.append("            }")
+                    self._pin_register_level(slot)
+        L.append("        }")
         L.append("        __builtin_amdgcn_sched_barrier(0);")
 
     def _pin_register_level(self, slot: int) -> None:
@@ -915,10 +943,10 @@ class _Emitter:
             if n_reg_cfg >= 0:
                 depths = [int(n_reg_cfg)]
             else:
-                budget, step = (tuple(TUNING["top_cache_auto"]) + (448, 32)[len(TUNING["top_cache_auto"]):])[:2]
+                budget, step = (tuple(TUNING["top_cache_auto"]) + (416, 32)[len(TUNING["top_cache_auto"]):])[:2]
                 n_max = min(int(budget) // sum(self.decl_dtype[n].itemsize // 4 for n in cache.names), 128)
                 n_max -= n_max % 8
-                depths = list(range(n_max, 15, -max(8, int(step)))) or [n_max]
+                depths = list(range(n_max, 16, -max(8, int(step)))) + [min(16, n_max)]
             variants = []
             for n_reg in depths:
                 if n_reg + n_lds <= 0:

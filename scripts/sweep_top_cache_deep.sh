@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 export GT4PY_AMD_CACHE_DIR=""
 for rep in 1 2; do
-for tc in "16,163840" "32,163840" "48,163840" "64,163840" "80,163840" "96,163840"; do
+for tc in "16,163840" "48,163840" "80,163840" "96,163840" "104,163840" "112,163840" "120,163840" "-1,163840"; do
   for only in vertical_advection tridiagonal; do
     echo -n "top_cache=$tc  "
     GT4MI_CODEGEN_TOP_CACHE=$tc python3 scripts/bench_generic.py --iters 20 --only $only 2>/dev/null | grep -E "generated|library" | tr '\n' '|'

@@ -529,6 +529,10 @@ static void section_tripipe() {
         tridiag_stack_variant<16, 16, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<32, 0, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<32, 48, 16, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<80, 40, 4, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<96, 40, 4, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<112, 40, 4, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
     }
     for (int dK : {73, 74, 80, 81, 87, 88, 89, 96, 97, 105, 33, 34, 40, 41, 47, 48, 49, 72}) {  // every head / parity case
         const int dI = 200, dJ = 37;

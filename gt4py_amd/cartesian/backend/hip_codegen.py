@@ -91,6 +91,9 @@ TUNING = {
     # at equal depth for the vertical advection, but the second buffer costs ~40 registers = 10 cached levels, which
     # are worth as much; the generated tridiagonal solve loses its 96 / 104 level variants to spills with it.  Off.
     "top_cache_pipeline": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_PIPELINE", (0,))[0],
+    # `_tc` kernels: streaming (nontemporal) stores for what the kernel itself never reads back from memory -- the
+    # second sweep's results, and the store-through copies of cached in/out fields at the levels that stay on chip
+    "top_cache_streaming": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_STREAMING", (1,))[0],
 }
 
 from .stage_planner import (Nest, Plan, Stage, Stmt, UnsupportedStencil, _field_reads, _stmt_field_reads,  # noqa: F401
@@ -473,20 +476,41 @@ class _Emitter:
             if on_chip:
                 self.lines.append(f"{pad}{self.tc_slot(name, k)} = n_{_c_ident(name)};")
             if name not in self.plan.register_only and (not on_chip or name in self.tc[0].store_through):
-                self.lines.append(f"{pad}{self.access(s.target, k, si, reg, store=True)} = n_{_c_ident(name)};")
+                self._global_store(s, k, si, reg, f"n_{_c_ident(name)}", pad, self._tc_streams(name, stage, on_chip))
             reg[(name, 0)] = f"n_{_c_ident(name)}"
         elif on_chip:
             self.lines.append(f"{pad}{self.tc_slot(name, k)} = {value};")
             if name in self.tc[0].store_through:
-                self.lines.append(f"{pad}{self.access(s.target, k, si, reg, store=True)} = {self.tc_slot(name, k)};")
-        elif name in self.streaming:
-            self.lines.append(f"{pad}__builtin_nontemporal_store({value}, &{self.access(s.target, k, si, reg, store=True)});")
+                self._global_store(s, k, si, reg, self.tc_slot(name, k), pad, self._tc_streams(name, stage, True))
+        elif name in self.streaming or self._tc_streams(name, stage, False):
+            self._global_store(s, k, si, reg, value, pad, True)
         else:
             self.lines.append(f"{pad}{self.access(s.target, k, si, reg, store=True)} = {value};")
         if on_chip:
             self.tc_written.add(name)
         if g:
             self.lines.append(f"{indent}}}")
+
+    def _global_store(self, s: Stmt, k: str, si: int, reg: Dict, value: str, pad: str, streaming: bool) -> None:
+        target = self.access(s.target, k, si, reg, store=True)
+        if streaming:
+            self.lines.append(f"{pad}__builtin_nontemporal_store({value}, &{target});")
+        else:
+            self.lines.append(f"{pad}{target} = {value};")
+
+    def _tc_streams(self, name: str, stage: Stage, on_chip: bool) -> bool:
+        """In a `_tc` kernel: may this store bypass the caches?  Yes for a level the kernel never loads again: any store
+        of the second sweep to a field that sweep does not read at another level, and the first sweep's store-through
+        copy of a cached field at a level that stays on chip (the second sweep reads the slot, not memory)."""
+        if self.tc is None or not TUNING["top_cache_streaming"] or name in self.plan.scratch:
+            return False
+        first = self.tc[0].first_sweep_nests
+        second_reads_elsewhere = any(
+            e.name == name and (tuple(e.offset) != (0, 0, 0) or e.koffset is not None)
+            for nest in stage.nests[first:] for st in nest.stmts for e in _stmt_field_reads(st))
+        if self.tc_sweep2:
+            return not second_reads_elsewhere
+        return on_chip and not second_reads_elsewhere
 
     def statements(self, stmts: Sequence[Stmt], stage: Stage, si: int, k: str, reg: Dict, indent: str,
                    carry: Sequence[str] = ()) -> None:

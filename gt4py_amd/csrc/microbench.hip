@@ -574,15 +574,16 @@ static void vadv_plain(VadvSet& s, DevField<double>& out) {
                        VADV_DTR, 0.5, 0.5, s.dI, s.dJ, s.dK);
 }
 
-template <int RL, int LL, int U>
+template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true>
 static void vadv_variant(VadvSet& s, bool time_it = true) {
     const unsigned tiles_i = (unsigned)cdiv(s.dI, 64);
     auto launch = [&](DevField<double>& out) {
-        hipLaunchKernelGGL((vadv_pipe_kernel<RL, LL, U>), dim3(tiles_i * (unsigned)s.dJ), dim3(64), 0, 0, s.fields(out), VADV_DTR, 0.5,
+        hipLaunchKernelGGL((vadv_pipe_kernel<RL, LL, U, PIPE, SADDR>), dim3(tiles_i * (unsigned)s.dJ), dim3(64), 0, 0, s.fields(out), VADV_DTR, 0.5,
                            0.5, s.dI, s.dJ, s.dK, tiles_i);
     };
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%dx%dx%d regs %d lds %d batch %d", s.dI, s.dJ, s.dK, RL, LL, U);
+    snprintf(cfg, sizeof cfg, "%dx%dx%d regs %d lds %d batch %d%s%s", s.dI, s.dJ, s.dK, RL, LL, U, PIPE ? "" : " nopipe",
+             SADDR ? "" : " vaddr");
     if (s.dK - RL - LL < 1) {
         printf("vadv       %-44s skipped (needs dK > %d)\n", cfg, RL + LL);
         return;
@@ -620,6 +621,13 @@ static void section_vadv() {
             vadv_variant<80, 40, 4>(s);
             vadv_variant<80, 40, 8>(s);
             vadv_variant<96, 40, 4>(s);
+            vadv_variant<104, 40, 4>(s);
+            vadv_variant<112, 40, 4>(s);
+            vadv_variant<104, 40, 4, false, true>(s);
+            vadv_variant<104, 40, 4, true, false>(s);
+            vadv_variant<104, 40, 4, false, false>(s);
+            vadv_variant<16, 40, 4, false, true>(s);
+            vadv_variant<16, 40, 4, true, false>(s);
             vadv_variant<64, 0, 4>(s);
             vadv_variant<32, 0, 8>(s);
         }

@@ -117,7 +117,10 @@ __device__ __forceinline__ void pin_here(double a, double b) { asm volatile("" :
 // batch n is computed.  Needs dK - RL - LL >= 1 (level 0 goes through memory; the host picks a smaller variant
 // otherwise) and unit I stride.  Every access is <running scalar row pointer>[lane]: the per-level address arithmetic
 // is two scalar adds per field and no address lives in a vector register.
-template <int RL, int LL, int U>
+// PIPE = false waits for every batch of loads right after issuing it (no load is in flight during arithmetic: what a
+// loop that loads, then computes, does); SADDR = false folds the lane into the row pointers (one 64-bit vector address
+// per access instead of scalar base + lane) -- both only for the ablation in the micro-benchmark.
+template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true>
 __global__ void __launch_bounds__(64)
 vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, int dJ, int dK, unsigned tiles_i) {
     static_assert(RL % U == 0 && LL % U == 0 && RL >= U, "level ranges are processed in batches of U");
@@ -125,9 +128,13 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     __shared__ double lds[LL > 0 ? LL * 2 * 64 : 1];
     const unsigned bi = blockIdx.x % tiles_i;
     const unsigned j = blockIdx.x / tiles_i;
-    const unsigned lane = threadIdx.x;
-    if ((int)(bi * 64 + lane) >= dI) return;
-    const int64_t ib = (int64_t)bi * 64;
+    const unsigned lane_id = threadIdx.x;
+    if ((int)(bi * 64 + lane_id) >= dI) return;
+    const unsigned lane = SADDR ? lane_id : 0u;
+    const int64_t ib = (int64_t)bi * 64 + (SADDR ? 0u : lane_id);
+    auto issued = [&]() {
+        if (!PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     const int64_t w_sk = f.wcon.sk, us_sk = f.u_stage.sk, up_sk = f.u_pos.sk, ut_sk = f.utens.sk, ts_sk = f.utens_stage.sk,
                   cc_sk = f.ccol.sk, dc_sk = f.dcol.sk;
 
@@ -217,6 +224,7 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
         for (int u = 0; u < U - 1; ++u)
             if (u < head) load_level(h.w0[u], h.w1[u], h.us[u], h.up[u], h.ut[u], h.ts[u]);  // wave-uniform
         load(B[0]);  // the first whole batch
+        issued();
         {  // interval(0, 1)
             const double wsn = w1a + w0a;
             const double gcv = 0.25 * wsn;
@@ -246,13 +254,16 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     // invariant: B[0] holds (or is receiving) the batch that starts at level k
     while (k + 2 * U <= A) {
         load(B[1]);
+        issued();
         forward_mem(B[0]);
         load(B[0]);  // may already be the first on-chip batch: same form, levels are contiguous
+        issued();
         forward_mem(B[1]);
         k += 2 * U;
     }
     if (k + U <= A) {  // an odd number of memory batches
         load(B[1]);
+        issued();
         forward_mem(B[0]);
         B[0] = B[1];
         k += U;
@@ -263,6 +274,7 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     for (int b = 0; b < NBC; ++b) {
         __builtin_amdgcn_sched_barrier(0);  // keeps the loads of later batches out of this one (registers)
         if (b + 1 < NBC) load(B[(b + 1) & 1], b + 2 == NBC);
+        issued();
         const FB& c = B[b & 1];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -281,8 +293,8 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
                 mid(c.w0[u], c.w1[u], c.us[u], c.up[u], c.ut[u], c.ts[u]);
             }
             if (l < LL) {
-                lds[(l * 2 + 0) * 64 + lane] = cp;
-                lds[(l * 2 + 1) * 64 + lane] = dp;
+                lds[(l * 2 + 0) * 64 + lane_id] = cp;
+                lds[(l * 2 + 1) * 64 + lane_id] = dp;
             } else {
                 C[l - LL] = cp;
                 D[l - LL] = dp;
@@ -335,10 +347,12 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     BB Cb[2];
     int kb = A - 1;
     if (kb - U + 1 >= 0) loadb(Cb[0]);  // in flight during the on-chip part of the sweep
+    issued();
 #pragma unroll
     for (int b = 0; b < NBC; ++b) {
         __builtin_amdgcn_sched_barrier(0);
         if (b + 2 < NBC) loadp(P[(b + 2) % 3]);
+        issued();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int l = LL + RL - 1 - (b * U + u);  // level A + l
@@ -347,7 +361,7 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
             } else if (l >= LL) {
                 data = D[l - LL] - (C[l - LL] * data);
             } else {
-                const double c = lds[(l * 2 + 0) * 64 + lane], d = lds[(l * 2 + 1) * 64 + lane];
+                const double c = lds[(l * 2 + 0) * 64 + lane_id], d = lds[(l * 2 + 1) * 64 + lane_id];
                 data = d - (c * data);
             }
             emit(P[b % 3][u]);
@@ -356,8 +370,10 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     // invariant: Cb[0] holds the batch kb, kb - 1, ... whenever a whole batch is left
     while (kb - 2 * U + 1 >= 0) {
         loadb(Cb[1]);
+        issued();
         backward_mem(Cb[0]);
         if (kb - 3 * U + 1 >= 0) loadb(Cb[0]);
+        issued();
         backward_mem(Cb[1]);
         kb -= 2 * U;
     }

@@ -29,6 +29,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         asm = pathlib.Path(tmp) / "k.s"
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-w",
+                        "-mllvm", "-pragma-unroll-threshold=262144",  # as csrc/Makefile
                         f"-I{ROOT / 'include'}", f"-I{ROOT / 'gt4py_amd' / 'csrc'}", "--cuda-device-only", "-S", "-o",
                         str(asm), str(src)], check=True)
         text = asm.read_text()

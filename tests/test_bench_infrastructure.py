@@ -54,7 +54,8 @@ def test_committed_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
         (fake_root / rel).parent.mkdir(parents=True, exist_ok=True)
         (fake_root / rel).write_bytes((ROOT / rel).read_bytes())
     monkeypatch.setattr(bench, "ROOT", fake_root)
-    (fake_root / "profiles" / "hbm_traffic.json").write_text(json.dumps({"lap5_f64_512": real}))
+    current = dict(real, kernel_source_sha=bench.kernel_source_hash("lap5_f64_512"))  # a record of exactly these sources
+    (fake_root / "profiles" / "hbm_traffic.json").write_text(json.dumps({"lap5_f64_512": current}))
     assert bench._committed_traffic("lap5_f64_512")[0] == real["bytes_per_launch"]
     (fake_root / bench.KERNEL_SOURCES["lap5_f64_512"][0]).write_text("// a different kernel\n")
     value, why = bench._committed_traffic("lap5_f64_512")

@@ -283,8 +283,8 @@ def other_kernels(steps: int = 20):
               "sup": field(dom, np.float64, (0, 0, 0)), "rhs": field(dom, np.float64, (0, 0, 0), -10.0, 10.0),
               "out": field(dom, np.float64, (0, 0, 0))}
     run("tridiagonal_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 56.0,
-        note="the backward sweep re-reads the part of sup', rhs' that does not fit on chip (72 of 160 levels stay in "
-             "registers + LDS): 64.8 B/LUP moved; inputs are whatever the previous launch left in sup/rhs "
+        note="the backward sweep re-reads the part of sup', rhs' that does not fit on chip (120 of 160 levels stay in "
+             "registers + LDS): 60.2 B/LUP moved (PMC, profiles/r2_kernel_hbm_traffic_pmc.txt); inputs are whatever the previous launch left in sup/rhs "
              "(timing only, values are checked in tests/); speed depends on the box by +-10 % (address translation, "
              "profiles/r2_tridiag_translation_counters.txt)")
     out["tridiagonal_f64_1024x1024x160"]["field_addresses_mod_4MiB"] = [int(f.ptr % (4 << 20)) for f in fields.values()]
@@ -301,8 +301,9 @@ def other_kernels(steps: int = 20):
     run("generated_vertical_advection_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 48.0,
         scalars={"dtr_stage": 3.0 / 20.0},
         note="one generated column kernel (forward + backward sweep); 5 fields read, 1 written; the forward sweep's "
-             "ccol / dcol are read back by the backward sweep: the top 56 of 160 levels stay in registers + LDS "
-             "(stage_planner.TopCache), the rest makes a round trip through scratch on top of the 48 algorithmic B/LUP")
+             "ccol / dcol are read back by the backward sweep: the top 152 of 160 levels stay in registers + LDS "
+             "(stage_planner.TopCache, 112 + 40), the rest makes a round trip through scratch and u_pos is read by both "
+             "sweeps: 61 B/LUP moved for 48 algorithmic (PMC, profiles/r2_kernel_hbm_traffic_pmc.txt)")
     del fields
     torch.cuda.empty_cache()
     dom = (512, 512, 512)

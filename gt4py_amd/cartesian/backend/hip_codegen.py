@@ -76,16 +76,17 @@ TUNING = {
     "vector_rows": _env_tuple("GT4MI_CODEGEN_VECTOR_ROWS", (4,))[0],
     # two-sweep column stages (stage_planner.TopCache): levels of the forward sweep's results kept in registers and,
     # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup, cap on the LDS levels).
-    # Register levels < 0 (the default): one `_tc<n>` kernel per depth n = n_max, n_max - step, ... and 16, where n_max
-    # is what `top_cache_auto` = (register budget in dwords per lane, step in levels) allows for the cached fields of
-    # the stage (vertical advection: 2 fp64 fields = 4 dwords per level -> 104, 72, 40, 16 levels + 40 in LDS); the
+    # Register levels < 0 (the default): one `_tc<n>` kernel per depth n = n_max, n_max - 8, n_max - 8 - step, ... and 16,
+    # where n_max is what `top_cache_auto` = (register budget in dwords per lane, step in levels) allows for the cached
+    # fields of the stage (vertical advection: 2 fp64 fields = 4 dwords per level -> 112, 104, 72, 40, 16 levels + 40 in
+    # LDS; 112 fits for it, the generated tridiagonal solve spills there and runs the 104-level variant); the
     # host launches the deepest variant the domain's K has room for and that compiled without spilling
     # (hip_generic._Variant).  A lone wave per SIMD owns 512 registers; a cached level costs exactly its dwords once the
     # register levels are pinned (_pin_register_level) and the second sweep has its own bases (_second_sweep_bases) --
     # before that it cost three times as much and 24 levels already spilled (profiles/r2_codegen_top_cache_deep_*.log).
     # (0, 0) = off; an explicit depth (GT4MI_CODEGEN_TOP_CACHE=80,163840) emits that one variant only.
     "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (-1, 160 * 1024, 64)),
-    "top_cache_auto": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_AUTO", (416, 32)),
+    "top_cache_auto": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_AUTO", (448, 32)),
     # register levels of a `_tc` kernel: issue the loads of batch n + 1 before the arithmetic of batch n (1) or each
     # batch's loads right before its own arithmetic (0).  Measured (profiles/r2_codegen_top_cache_pipeline.log): +1..3 %
     # at equal depth for the vertical advection, but the second buffer costs ~40 registers = 10 cached levels, which
@@ -874,14 +875,24 @@ class _Emitter:
         def full(batch) -> bool:
             return chunk is not None and len(batch) == depth
 
+        nest_writes = {s.target.name for s in nest.stmts}
+        loaded: Dict[Tuple, str] = {}  # (field, (di, dj), slot of the level, data index) -> register that holds it
+
         def issue_loads(bi: int) -> Dict[Tuple, str]:
-            """Declare and issue the hoisted loads of batch `bi` (names unique per batch: one scope holds them all)."""
+            """Declare and issue the hoisted loads of batch `bi` (names unique per batch: one scope holds them all).
+            A value an earlier batch of this range already fetched (wcon[k+1] of one batch is wcon[k] of the next)
+            is taken from its register when nothing in the nest writes the field."""
             _, loads, _ = chunk
-            named = {slot: f"q{bi}_{var}" for slot, var in loads.items()}
+            named = {}
             self.tc_written = set()  # hoisted loads see what memory held BEFORE the batch's levels are assigned
-            for (name, off, rel, data), var in named.items():
+            for (name, off, rel, data), var in loads.items():
+                where = (name, off, batches[bi][0] + rel, data)  # slots count levels from a.dK - n_reg, in K order
+                if name not in nest_writes and where in loaded:
+                    named[(name, off, rel, data)] = loaded[where]
+                    continue
                 e = ir.FieldAccess(name, (off[0], off[1], rel), None, None, data)
-                L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, base(batches[bi]), -1, {})};")
+                L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} q{bi}_{var} = {self.access(e, base(batches[bi]), -1, {})};")
+                named[(name, off, rel, data)] = loaded[where] = f"q{bi}_{var}"
             return named
 
         L.append("        {")
@@ -967,10 +978,12 @@ class _Emitter:
             if n_reg_cfg >= 0:
                 depths = [int(n_reg_cfg)]
             else:
-                budget, step = (tuple(TUNING["top_cache_auto"]) + (416, 32)[len(TUNING["top_cache_auto"]):])[:2]
+                budget, step = (tuple(TUNING["top_cache_auto"]) + (448, 32)[len(TUNING["top_cache_auto"]):])[:2]
                 n_max = min(int(budget) // sum(self.decl_dtype[n].itemsize // 4 for n in cache.names), 128)
                 n_max -= n_max % 8
-                depths = list(range(n_max, 16, -max(8, int(step)))) + [min(16, n_max)]
+                # the deepest one is the likeliest to spill (the host then takes the next): a close second, then coarse steps
+                depths = [n_max] + list(range(n_max - 8, 16, -max(8, int(step)))) + [min(16, n_max)]
+                depths = sorted({d for d in depths if d > 0}, reverse=True)
             variants = []
             for n_reg in depths:
                 if n_reg + n_lds <= 0:

@@ -185,6 +185,11 @@ struct TridiagTuning {
     // (478 registers, no scratch): 84.5 GLUPS next to 81.4 for 32 + 40 on the same box, 60 instead of 64.8 B/LUP moved
     // (profiles/r2_tridiag_pipelined_deep.log).  Used when the column is deeper than 120 levels.
     static constexpr int STACK_REG_DEEP = 80;
+    // ... and 104 + 40 in batches of 4 (502 registers, no scratch) for columns deeper than 144 levels: 95.8 GLUPS next to
+    // 94.0 for 80 + 40 on the same box, 1.03x instead of 1.07x the algorithmic traffic (profiles/r2_microbench_tripipe_deep.log).
+    // Needs the larger -pragma-unroll-threshold of the Makefile: with LLVM's default the 36-batch level loop stays
+    // rolled and the register arrays become scratch (tests/test_c_abi.py reads the compiler's resource remarks).
+    static constexpr int STACK_REG_DEEPER = 104, STACK_U_DEEPER = 4;
 };
 
 template <typename T>
@@ -235,7 +240,12 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
         // (8-byte items only: for float the LDS share allows two waves per SIMD, the compiler then budgets 256 registers
         // and the deep variant spills)
         constexpr int DEEP = sizeof(T) == 8 ? TridiagTuning::STACK_REG_DEEP : TridiagTuning::STACK_REG;
-        if (sizeof(T) == 8 && domain[2] > DEEP + TridiagTuning::STACK_LDS) {
+        if (sizeof(T) == 8 && domain[2] > TridiagTuning::STACK_REG_DEEPER + TridiagTuning::STACK_LDS) {
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, sizeof(T) == 8 ? TridiagTuning::STACK_REG_DEEPER : TridiagTuning::STACK_REG,
+                                                    TridiagTuning::STACK_LDS, TridiagTuning::STACK_U_DEEPER>),
+                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+                               (int)domain[1], (int)domain[2], ti);
+        } else if (sizeof(T) == 8 && domain[2] > DEEP + TridiagTuning::STACK_LDS) {
             hipLaunchKernelGGL((tridiag_pipe_kernel<T, DEEP, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
                                dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);

@@ -84,3 +84,23 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setenv("GT4PY_AMD_LIB", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_no_hot_kernel_of_the_library_spills():
+    """The build keeps the compiler's per-kernel resource remarks (csrc/Makefile -> lib/libgt4py_amd.resources.log).
+    The column kernels keep up to 104 levels of two fields in registers: one level too many, or the `#pragma unroll`ed
+    level loop left rolled (LLVM's default unroll budget), and the register arrays silently become scratch memory --
+    a 30 % slower kernel with identical results, which no parity test would notice."""
+    log = _lib.LIB_PATH.with_name("libgt4py_amd.resources.log")
+    assert log.exists(), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    text = log.read_text()
+    kernels = re.findall(r"remark: Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", text, re.S)
+    by_name = {name: (int(scratch), int(waves)) for name, scratch, waves in kernels}
+    hot = {n: v for n, v in by_name.items() if any(k in n for k in ("lap5_strip_kernel", "hdiff_jmarch_kernel", "tridiag_pipe_kernel",
+                                                                   "tridiag_kernel", "halo_copy_kernel"))}
+    assert len(hot) >= 20, sorted(by_name)[:5]
+    spilling = {n: v for n, v in hot.items() if v[0] != 0}
+    assert not spilling, spilling
+    # the deep tridiagonal variants are built for one wave per SIMD (all 512 registers of a lane)
+    deep = [v for n, v in hot.items() if "tridiag_pipe_kernelIdLi104ELi40ELi4E" in n or "tridiag_pipe_kernelIdLi80ELi40ELi8E" in n]
+    assert len(deep) == 2 and all(w == 1 for _, w in deep)

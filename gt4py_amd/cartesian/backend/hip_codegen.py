@@ -78,15 +78,16 @@ TUNING = {
     # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup, cap on the LDS levels).
     # Register levels < 0 (the default): one `_tc<n>` kernel per depth n = n_max, n_max - 8, n_max - 8 - step, ... and 16,
     # where n_max is what `top_cache_auto` = (register budget in dwords per lane, step in levels) allows for the cached
-    # fields of the stage (vertical advection: 2 fp64 fields = 4 dwords per level -> 112, 104, 72, 40, 16 levels + 40 in
-    # LDS; 112 fits for it, the generated tridiagonal solve spills there and runs the 104-level variant); the
+    # fields of the stage (vertical advection: 2 fp64 fields = 4 dwords per level -> 112, 104, 80, 56, 32, 16 levels + 40
+    # in LDS, i.e. smallest K 154, 146, 122, 98, 74, 58: K = 80 keeps 72 levels on chip, K = 137 120, K = 60 56; 112
+    # fits for it, the generated tridiagonal solve spills there and runs the 104-level variant); the
     # host launches the deepest variant the domain's K has room for and that compiled without spilling
     # (hip_generic._Variant).  A lone wave per SIMD owns 512 registers; a cached level costs exactly its dwords once the
     # register levels are pinned (_pin_register_level) and the second sweep has its own bases (_second_sweep_bases) --
     # before that it cost three times as much and 24 levels already spilled (profiles/r2_codegen_top_cache_deep_*.log).
     # (0, 0) = off; an explicit depth (GT4MI_CODEGEN_TOP_CACHE=80,163840) emits that one variant only.
     "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (-1, 160 * 1024, 64)),
-    "top_cache_auto": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_AUTO", (448, 32)),
+    "top_cache_auto": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_AUTO", (448, 24)),
     # register levels of a `_tc` kernel: issue the loads of batch n + 1 before the arithmetic of batch n (1) or each
     # batch's loads right before its own arithmetic (0).  Measured (profiles/r2_codegen_top_cache_pipeline.log): +1..3 %
     # at equal depth for the vertical advection, but the second buffer costs ~40 registers = 10 cached levels, which
@@ -978,7 +979,7 @@ class _Emitter:
             if n_reg_cfg >= 0:
                 depths = [int(n_reg_cfg)]
             else:
-                budget, step = (tuple(TUNING["top_cache_auto"]) + (448, 32)[len(TUNING["top_cache_auto"]):])[:2]
+                budget, step = (tuple(TUNING["top_cache_auto"]) + (448, 24)[len(TUNING["top_cache_auto"]):])[:2]
                 n_max = min(int(budget) // sum(self.decl_dtype[n].itemsize // 4 for n in cache.names), 128)
                 n_max -= n_max % 8
                 # the deepest one is the likeliest to spill (the host then takes the next): a close second, then coarse steps

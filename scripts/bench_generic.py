@@ -26,6 +26,8 @@ CASES = [
     ("horizontal_diffusion_f32", (1024, 1024, 80), 12, (True, False)),
     ("tridiagonal_solver", (1024, 1024, 160), 56, (True, False)),
     ("vertical_advection_dycore", (1024, 1024, 160), 48, (False,)),  # 5 reads + 1 write; temporaries extra
+    ("vertical_advection_dycore", (1024, 1024, 80), 48, (False,)),  # the usual number of levels of a regional model
+    ("vertical_advection_dycore", (1024, 1024, 60), 48, (False,)),
     ("column_sum_then_gradient", (1024, 1024, 80), 16, (False,)),
 ]
 

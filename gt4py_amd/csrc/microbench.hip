@@ -419,17 +419,17 @@ static void tridiag_variant(DevField<T>& a, DevField<T>& d, DevField<T>& s, DevF
     report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
 }
 
-template <int RL, int LL, int U, bool PIPE = false>
+template <int RL, int LL, int U, bool PIPE = false, int WPB = 1>
 static void tridiag_stack_variant(DevField<double>& a, DevField<double>& d, DevField<double>& s, DevField<double>& r,
                                   DevField<double>& o, DevField<double>& s2, DevField<double>& r2, DevField<double>& o2,
                                   int dI, int dJ, int dK) {
     const unsigned ti = (unsigned)cdiv(dI, 64);
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%s RL=%d LL=%d U=%d (mem levels %d)", PIPE ? "pipe " : "stack", RL, LL, U, dK - RL - LL);
+    snprintf(cfg, sizeof cfg, "%s RL=%d LL=%d U=%d WPB=%d (mem levels %d)", PIPE ? "pipe " : "stack", RL, LL, U, WPB, dK - RL - LL);
     if (dK - RL - LL < 1) return;
     auto launch = [&]() {
         if constexpr (PIPE)
-            hipLaunchKernelGGL((tridiag_pipe_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+            hipLaunchKernelGGL((tridiag_pipe_kernel<double, RL, LL, U, WPB>), dim3(ti * (unsigned)cdiv(dJ, WPB)), dim3(64, WPB), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
         else
             hipLaunchKernelGGL((tridiag_stack_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
     };
@@ -533,6 +533,10 @@ static void section_tripipe() {
         tridiag_stack_variant<96, 40, 4, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<104, 40, 4, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<112, 40, 4, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<80, 40, 8, true, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 40, 8, true, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
     }
     for (int dK : {73, 74, 80, 81, 87, 88, 89, 96, 97, 105, 33, 34, 40, 41, 47, 48, 49, 72}) {  // every head / parity case
         const int dI = 200, dJ = 37;
@@ -543,6 +547,7 @@ static void section_tripipe() {
         printf("           dK = %d\n", dK);
         tridiag_stack_variant<32, 40, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<32, 0, 8, true>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<32, 40, 8, true, 4>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
     }
 }
 

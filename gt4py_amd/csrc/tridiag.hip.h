@@ -190,6 +190,7 @@ struct TridiagTuning {
     // Needs the larger -pragma-unroll-threshold of the Makefile: with LLVM's default the 36-batch level loop stays
     // rolled and the register arrays become scratch (tests/test_c_abi.py reads the compiler's resource remarks).
     static constexpr int STACK_REG_DEEPER = 104, STACK_U_DEEPER = 4;
+    static constexpr int STACK_REG_SHALLOW = 16;  // + 40 LDS levels, for columns of 57 ... 72 levels
 };
 
 template <typename T>
@@ -251,6 +252,11 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
                                (int)domain[1], (int)domain[2], ti);
         } else if (domain[2] > TridiagTuning::STACK_REG + TridiagTuning::STACK_LDS) {
             hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
+                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+                               (int)domain[1], (int)domain[2], ti);
+        } else if (sizeof(T) == 8 && domain[2] > TridiagTuning::STACK_REG_SHALLOW + TridiagTuning::STACK_LDS) {
+            // 57 ... 72 levels (K = 60 is a common column depth): 16 + 40 on chip instead of 32 in registers only
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG_SHALLOW, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
                                dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);
         } else {

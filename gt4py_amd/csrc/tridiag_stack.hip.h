@@ -191,14 +191,18 @@ struct TridiagBwdBatch {
     T s[U], r[U];
 };
 
-template <typename T, int RL, int LL, int U>
-__global__ void __launch_bounds__(64)
+// WPB waves per workgroup, one J row each (threadIdx.y): the waves that share a CU then work on adjacent rows of the
+// same I tile -- the same pages at every level -- instead of whatever tiles the dispatcher hands the CU.
+template <typename T, int RL, int LL, int U, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB)
 tridiag_pipe_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<T> rhs, View<T> out, int dI, int dJ,
                     int dK, unsigned tiles_i) {
     static_assert(RL % U == 0 && LL % U == 0 && RL >= U, "level ranges are processed in batches of U");
-    __shared__ T lds[LL > 0 ? LL * 2 * 64 : 1];
+    __shared__ T lds_all[LL > 0 ? LL * 2 * 64 * WPB : 1];
+    T* const lds = lds_all + (LL > 0 ? threadIdx.y * (LL * 2 * 64) : 0);
     const unsigned bi = blockIdx.x % tiles_i;
-    const unsigned j = blockIdx.x / tiles_i;
+    const unsigned j = (blockIdx.x / tiles_i) * WPB + threadIdx.y;
+    if ((int)j >= dJ) return;
     const int lane = threadIdx.x;
     const int i0 = (int)(bi * 64) + lane;
     if (i0 >= dI) return;

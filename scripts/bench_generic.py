@@ -25,6 +25,8 @@ CASES = [
     ("horizontal_diffusion", (512, 1024, 80), 24, (True, False)),
     ("horizontal_diffusion_f32", (1024, 1024, 80), 12, (True, False)),
     ("tridiagonal_solver", (1024, 1024, 160), 56, (True, False)),
+    ("tridiagonal_solver", (1024, 1024, 80), 56, (True, False)),
+    ("tridiagonal_solver", (1024, 1024, 60), 56, (True, False)),
     ("vertical_advection_dycore", (1024, 1024, 160), 48, (False,)),  # 5 reads + 1 write; temporaries extra
     ("vertical_advection_dycore", (1024, 1024, 80), 48, (False,)),  # the usual number of levels of a regional model
     ("vertical_advection_dycore", (1024, 1024, 60), 48, (False,)),

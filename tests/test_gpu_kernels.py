@@ -219,6 +219,7 @@ def _tridiag_inputs(shape, dtype, seed=7):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(1, 1, 2), (3, 5, 2), (17, 33, 5), (64, 64, 8), (65, 63, 7), (40, 9, 160), (514, 3, 19),
                                    (34, 5, 50), (130, 3, 73), (70, 2, 33), (66, 4, 72),  # K around the on-chip stack sizes
+                                   (66, 3, 56), (66, 3, 57), (70, 2, 58), (65, 2, 60), (130, 2, 64), (64, 2, 65), (66, 2, 71),
                                    (66, 3, 120), (66, 3, 121), (70, 2, 122), (65, 2, 128), (64, 2, 129), (130, 2, 135),
                                    (66, 2, 144), (66, 2, 145), (70, 2, 146), (65, 2, 147), (64, 2, 148), (130, 2, 149), (64, 3, 161)])
 def test_tridiag_parity(shape, dtype, layout):

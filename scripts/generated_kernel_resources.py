@@ -15,17 +15,16 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-import oracle.numpy_backend  # noqa: E402,F401  (only to obtain the IR without a GPU; scripts are not product code)
 import stencil_zoo as zoo  # noqa: E402
 from gt4py_amd.cartesian import gtscript  # noqa: E402
-from gt4py_amd.cartesian.backend import hip_codegen  # noqa: E402
 
 
 def main():
     name = sys.argv[1]
     defn, externals, _, _ = zoo.ZOO[name]
-    obj = gtscript.stencil(backend="numpy", definition=defn, externals=externals)
-    prog = hip_codegen.generate(obj._oracle_ir_)
+    # building the stencil class generates the source; nothing is compiled by hiprtc or launched before the first call
+    obj = gtscript.stencil(backend="hip:mi300", definition=defn, externals=externals, use_kernel_library=False, rebuild=True)
+    prog = type(obj)._gt_program_
     src = pathlib.Path(f"/tmp/gt4mi_gen_{name}.hip")
     asm = src.with_suffix(".s")
     src.write_text(prog.source)

@@ -88,11 +88,17 @@ TUNING = {
     # (0, 0) = off; an explicit depth (GT4MI_CODEGEN_TOP_CACHE=80,163840) emits that one variant only.
     "top_cache": _env_tuple("GT4MI_CODEGEN_TOP_CACHE", (-1, 160 * 1024, 64)),
     "top_cache_auto": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_AUTO", (448, 24)),
-    # register levels of a `_tc` kernel: issue the loads of batch n + 1 before the arithmetic of batch n (1) or each
-    # batch's loads right before its own arithmetic (0).  Measured (profiles/r2_codegen_top_cache_pipeline.log): +1..3 %
-    # at equal depth for the vertical advection, but the second buffer costs ~40 registers = 10 cached levels, which
-    # are worth as much; the generated tridiagonal solve loses its 96 / 104 level variants to spills with it.  Off.
-    "top_cache_pipeline": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_PIPELINE", (0,))[0],
+    # register levels of a `_tc` kernel: 0 = batches, each batch's loads right before its own arithmetic; 1 = the loads
+    # of batch n + 1 issued before the arithmetic of batch n (+1..3 %, but a second batch of registers: as much as 10
+    # cached levels are worth, profiles/r2_codegen_top_cache_pipeline.log); 2 = rolling: level n issues the loads of
+    # level n + D and computes itself, D levels of loads always in flight for the registers of ONE more level --
+    # vertical advection +8 % at equal depth, +3..5 % with the ladder (its 112-level variant no longer fits, 104 runs),
+    # the generated tridiagonal solve unchanged (profiles/r2_codegen_top_cache_rolling.log, _onchip.log).
+    "top_cache_pipeline": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_PIPELINE", (2,))[0],
+    "top_cache_lookahead": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_LOOKAHEAD", (0,))[0],  # rolling prefetch distance (0: chunk depth)
+    # the LDS levels of a `_tc` kernel as straight-line code like the register levels (1) or as a loop (0): within the
+    # noise at K = 160 / 80 / 60 for 5x the source (profiles/r2_codegen_top_cache_onchip.log)
+    "top_cache_unroll_lds": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_UNROLL_LDS", (0,))[0],
     # `_tc` kernels: streaming (nontemporal) stores for what the kernel itself never reads back from memory -- the
     # second sweep's results, and the store-through copies of cached in/out fields at the levels that stay on chip
     "top_cache_streaming": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_STREAMING", (1,))[0],
@@ -547,7 +553,10 @@ class _Emitter:
         cache, n_reg, n_lds, threads = self.tc
         c = _c_ident(name)
         if self.tc_mode[0] == "reg":
-            return f"tc_{c}_{self.tc_mode[1]}"
+            slot = self.tc_mode[1]
+            if slot < 0:  # an LDS level of the straight-line on-chip range (top_cache_unroll_lds): constant index
+                return f"tc_lds_{c}[{(slot + n_lds) * threads} + tc_tid]"
+            return f"tc_{c}_{slot}"
         return f"tc_lds_{c}[(({k}) - (a.dK - {n_reg + n_lds})) * {threads} + tc_tid]"
 
     def column_in_extent(self, name: str, stage: Stage) -> Optional[str]:
@@ -794,9 +803,12 @@ class _Emitter:
                 ranges = []  # in ascending order of levels
                 if lo_rel is None or lo_rel < -(n_reg + n_lds):
                     ranges.append((("mem",), "k0", f"gt_min(k1, a.dK - {n_reg + n_lds})"))
-                if n_lds and hi_rel > -(n_reg + n_lds) and (lo_rel is None or lo_rel < -n_reg):
+                first_slot = 0
+                if n_lds and TUNING["top_cache_unroll_lds"]:
+                    first_slot = -n_lds  # the LDS levels are straight-line code too: slots -n_lds .. -1
+                elif n_lds and hi_rel > -(n_reg + n_lds) and (lo_rel is None or lo_rel < -n_reg):
                     ranges.append((("lds",), f"gt_max(k0, a.dK - {n_reg + n_lds})", f"gt_min(k1, a.dK - {n_reg})"))
-                slots = [u for u in range(n_reg) if -n_reg + u < hi_rel and (lo_rel is None or -n_reg + u >= lo_rel)]
+                slots = [u for u in range(first_slot, n_reg) if -n_reg + u < hi_rel and (lo_rel is None or -n_reg + u >= lo_rel)]
                 if slots:
                     ranges.append((("reg", slots), None, None))
                 if nest.order is ir.LoopOrder.BACKWARD:
@@ -896,6 +908,9 @@ class _Emitter:
                 named[(name, off, rel, data)] = loaded[where] = f"q{bi}_{var}"
             return named
 
+        if chunk is not None and TUNING["top_cache_pipeline"] == 2:
+            self._register_range_rolling(si, stage, nest, group, active, back, order, n_reg, chunk, nest_writes)
+            return
         L.append("        {")
         pending = issue_loads(0) if full(batches[0]) and TUNING["top_cache_pipeline"] else None
         for bi, batch in enumerate(batches):
@@ -929,13 +944,62 @@ class _Emitter:
         L.append("        }")
         L.append("        __builtin_amdgcn_sched_barrier(0);")
 
+    def _register_range_rolling(self, si: int, stage: Stage, nest: Nest, group, active, back: int, order: Sequence[int],
+                                n_reg: int, chunk, nest_writes: Set[str]) -> None:
+        """Register levels with a rolling prefetch: level n issues the loads of level n + D (D = the chunk depth of
+        prefetch_chunk) and then computes itself, so D levels of loads are always in flight and every level's arithmetic
+        overlaps with them -- the registers of one more level instead of a second batch buffer.  Values the sweep
+        already holds (wcon[k + 1] of one level is wcon[k] of the next) are not fetched again."""
+        L = self.lines
+        depth, _, per_statement = chunk
+        if TUNING["top_cache_lookahead"] > 0:
+            depth = int(TUNING["top_cache_lookahead"])
+        keys = []  # (field, (di, dj, dk), data index) read through hoisted loads, in statement order
+        for ks in per_statement.values():
+            for key in ks:
+                if key not in keys:
+                    keys.append(key)
+        loaded: Dict[Tuple, str] = {}
+
+        def kexpr(slot: int) -> str:
+            return f"(a.dK - {n_reg - slot})"
+
+        def issue(slot: int) -> None:
+            self.tc_written = set()  # hoisted loads see what memory held BEFORE the levels in between are assigned
+            for name, off, data in keys:
+                where = (name, tuple(off[:2]), slot + off[2], data)
+                if where in loaded and name not in nest_writes:
+                    continue
+                var = f"q{len(loaded)}_{_c_ident(name)}"
+                e = ir.FieldAccess(name, tuple(off), None, None, data)
+                L.append(f"            const {_CTYPE[self.decl_dtype[name].name]} {var} = {self.access(e, kexpr(slot), -1, {})};")
+                loaded[where] = var
+
+        L.append("        {")
+        for slot in order[:depth]:
+            issue(slot)
+        for n, slot in enumerate(order):
+            L.append("        __builtin_amdgcn_sched_barrier(0);")
+            if n + depth < len(order):
+                issue(order[n + depth])
+            self.prefetch_for = {sid: {key: loaded[(key[0], tuple(key[1][:2]), slot + key[1][2], key[2])] for key in ks}
+                                 for sid, ks in per_statement.items()}
+            self.tc_mode = ("reg", slot)
+            L.append("            {")
+            self._emit_level(si, stage, nest, group, active, back, kexpr(slot), "                ")
+            L.append("            }")
+            self._pin_register_level(slot)
+        self.prefetch_for = {}
+        L.append("        }")
+        L.append("        __builtin_amdgcn_sched_barrier(0);")
+
     def _pin_register_level(self, slot: int) -> None:
         """A level whose results only go to register slots has no side effect, and instruction selection sinks its
         arithmetic to the first use of those slots -- the other sweep -- across every sched_barrier in between (they
         order the scheduler, not the selector).  All loads of all register levels would then stay live until the second
         sweep starts (measured: 12 registers per cached level instead of 4, spills from 24 levels on).  An empty
         volatile asm that takes the slots as inputs pins the arithmetic to the level it belongs to."""
-        if self.tc_sweep2 or not self.tc_written:
+        if self.tc_sweep2 or not self.tc_written or slot < 0:  # (an LDS level's store is its own anchor)
             return
         names = sorted(self.tc_written)
         constraints = ", ".join(f'"v"(tc_{_c_ident(n)}_{slot})' for n in names)

@@ -301,8 +301,8 @@ def other_kernels(steps: int = 20):
     run("generated_vertical_advection_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 48.0,
         scalars={"dtr_stage": 3.0 / 20.0},
         note="one generated column kernel (forward + backward sweep); 5 fields read, 1 written; the forward sweep's "
-             "ccol / dcol are read back by the backward sweep: the top 152 of 160 levels stay in registers + LDS "
-             "(stage_planner.TopCache, 112 + 40), the rest makes a round trip through scratch and u_pos is read by both "
+             "ccol / dcol are read back by the backward sweep: the top 144 of 160 levels stay in registers + LDS "
+             "(stage_planner.TopCache, 104 + 40), the rest makes a round trip through scratch and u_pos is read by both "
              "sweeps: 61 B/LUP moved for 48 algorithmic (PMC, profiles/r2_kernel_hbm_traffic_pmc.txt)")
     del fields
     torch.cuda.empty_cache()

@@ -41,11 +41,24 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
     // strip boundaries (4 shared rows each) are re-read inside one CU; workgroups are ordered along
     // J, then I, then K, and runs of XCDG of them share an XCD (see lap5.hip.h).
     unsigned wg = blockIdx.x;
-    if constexpr (XCDG > 0) wg = xcd_remap_grouped<(unsigned)XCDG>(wg, gridDim.x);
-    const unsigned tj = (wg % groups_j) * 4 + (threadIdx.x >> 6);
+    unsigned jg, column;
+    if constexpr (XCDG < 0) {
+        // chunked: every (I column, K level) is dealt to the 8 XCDs as 8 contiguous chunks of workgroups along J
+        // (the launch pads groups_j to a multiple of 8; hardware deals workgroups to XCDs round-robin in linear order)
+        const unsigned padded = ((groups_j + 7u) / 8u) * 8u, per = padded / 8u;
+        column = wg / padded;
+        const unsigned r = wg % padded;
+        jg = (r % 8u) * per + r / 8u;
+        if (jg >= groups_j) return;
+    } else {
+        if constexpr (XCDG > 0) wg = xcd_remap_grouped<(unsigned)XCDG>(wg, gridDim.x);
+        jg = wg % groups_j;
+        column = wg / groups_j;
+    }
+    const unsigned tj = jg * 4 + (threadIdx.x >> 6);
     if (tj >= tiles_j) return;
-    const unsigned wi = (wg / groups_j) % waves_i;
-    const unsigned k = wg / (groups_j * waves_i);
+    const unsigned wi = column % waves_i;
+    const unsigned k = column / waves_i;
 
     const int col = ((int)(wi * OUT_LANES) - H + (int)lane) * VEC;  // first column of this lane
     const int j0 = (int)tj * LJ;

@@ -355,7 +355,7 @@ static void hdiff_variant_w(const DevField<T>& in, DevField<T>& out, const DevFi
     constexpr int H = (VEC >= 2) ? 1 : 2;
     const unsigned waves_i = (unsigned)cdiv(dI, (64 - 2 * H) * VEC), tiles_j = (unsigned)cdiv(dJ, LJ);
     const unsigned groups_j = (unsigned)cdiv(tiles_j, 4);
-    const unsigned nb = waves_i * groups_j * dK;
+    const unsigned nb = waves_i * (XCDG < 0 ? (unsigned)cdiv(groups_j, 8) * 8u : groups_j) * dK;
     char cfg[96];
     snprintf(cfg, sizeof cfg, "%s %s-internal VEC=%d LJ=%d PF=%d xcd=%d", tag, sizeof(W) == 4 ? "f32" : "f64", VEC, LJ, PF, XCDG);
     const double ms = time_ms([&](int) {
@@ -397,6 +397,40 @@ static void section_hdiff2() {
             hdiff_variant_w<double, double, 2, 8, 4, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
             hdiff_variant_w<double, double, 2, 4, 4, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
             hdiff_variant_w<double, double, 2, 16, 16, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
+        }
+    }
+}
+
+// workgroup -> XCD mappings of the J-march kernel: runs of G workgroups (0, 2, 4, 8) and contiguous chunks per column (-1)
+static void section_hdiffxcd() {
+    {
+        const int dI = 1024, dJ = 1024, dK = 80;
+        DevField<float> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+        fill(in, 2024, 1.0, 9.0);
+        fill(cf, 7, 0.0, 0.05);
+        for (int rep = 0; rep < 2; ++rep) {
+            hdiff_variant_w<float, double, 4, 6, 6, 0>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 6, 6, 2>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 6, 6, 4>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 6, 6, 8>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 6, 6, -1>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 8, 8, -1>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 8, 4, -1>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, double, 4, 4, 4, -1>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_w<float, float, 4, 6, 6, -1>(in, out, cf, dI, dJ, dK, "1024x1024x80");
+        }
+    }
+    {
+        const int dI = 512, dJ = 1024, dK = 80;
+        DevField<double> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+        fill(in, 2024, 1.0, 9.0);
+        fill(cf, 7, 0.0, 0.05);
+        for (int rep = 0; rep < 2; ++rep) {
+            hdiff_variant_w<double, double, 2, 8, 8, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 8, 8, -1>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 6, 6, 4>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 6, 6, -1>(in, out, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_w<double, double, 2, 4, 4, -1>(in, out, cf, dI, dJ, dK, "512x1024x80");
         }
     }
 }
@@ -849,6 +883,7 @@ int main(int argc, char** argv) {
     }
     if (on("hdiff")) section_hdiff();
     if (!want.empty() && on("hdiff2")) section_hdiff2();
+    if (!want.empty() && on("hdiffxcd")) section_hdiffxcd();
     if (on("tridiag")) section_tridiag();
     if (!want.empty() && on("triplace")) section_triplace(0, want);
     if (!want.empty() && on("tripipe")) section_tripipe();

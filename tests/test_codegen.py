@@ -165,6 +165,39 @@ def test_horizontal_stages_get_a_16_byte_lane_twin(programs):
     assert [k.vec for k in programs["column_sum_then_gradient"].kernels] == [0, 2]
 
 
+def test_two_sweep_column_stages_get_a_ladder_of_cached_variants(programs):
+    """FORWARD-then-BACKWARD column stages also exist as `<name>_tc<n>`: the top n + LDS levels of the fields the second
+    sweep reads back stay on chip (stage_planner.TopCache).  What keeps a cached level at the cost of its own registers
+    is pinned here, because no parity test notices when it is lost (the kernels only get slower, or spill and fall back):
+    the register ladder, the pin after every register level, the opaque bases of the second sweep, streaming stores
+    and the rolling prefetch."""
+    import re
+
+    vadv = programs["vertical_advection_dycore"]
+    (kern,) = vadv.kernels
+    assert kern.top_cache == tuple((n, 40, n + 42) for n in (112, 104, 80, 56, 32, 16))  # 2 fp64 fields, 448 dwords, 160 KB LDS
+    assert [k.top_cache for k in programs["tridiagonal_solver"].kernels] == [kern.top_cache]
+    assert programs["two_sweep_three_carried"].kernels[0].top_cache == tuple((n, 32, n + 35) for n in (88, 80, 56, 32, 16))
+    assert all(k.top_cache is None for k in programs["column_sum_then_gradient"].kernels)  # one sweep: nothing to keep
+    src = vadv.source
+    tc = src[src.index("gt4mi_vertical_advection_dycore_stage0_tc104("):src.index("gt4mi_vertical_advection_dycore_stage0_tc80(")]
+    # every register level of the first sweep is pinned where it is computed (levels 0 .. 102 write ccol and dcol, the last only dcol)
+    assert len(re.findall(r'asm volatile\("" :: "v"\(tc_ccol_\d+\), "v"\(tc_dcol_\d+\)\);', tc)) == 103
+    assert 'asm volatile("" :: "v"(tc_dcol_103));' in tc
+    # the second sweep addresses its arrays through bases the optimiser cannot relate to the first sweep's
+    assert 'asm volatile("" : "+s"(tc_zero));' in tc and "const auto tc_b_u_pos = b_u_pos + tc_zero;" in tc
+    second = tc[tc.index("tc_zero"):]
+    # its results are never read again by the kernel: streaming stores; spilled ccol / dcol levels are ordinary stores
+    assert re.search(r"__builtin_nontemporal_store\(.*&b_utens_stage\[", second)
+    first = tc[:tc.index("tc_zero")]
+    assert re.search(r"\bb_ccol\[.*\] = ", first) and not re.search(r"__builtin_nontemporal_store\(.*&b_ccol\[", first)
+    # rolling prefetch over the register levels: loads are named q<n>_<field>, one barrier per level, and a value the
+    # sweep already holds (wcon of the level above) is not loaded a second time
+    reg = first[first.rindex("gt_min(k1, a.dK - 104)"):]
+    assert len(re.findall(r"const double q\d+_wcon = ", reg)) <= 2 * 105 + 2
+    assert reg.count("__builtin_amdgcn_sched_barrier(0);") >= 104
+
+
 def test_compiler_errors_surface_with_the_log():
     with pytest.raises(_lib.NativeError, match="expected ';'"):
         _lib.rtc_compile('extern "C" __global__ void k(double* a) { a[0] = 1.0 }')

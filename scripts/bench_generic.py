@@ -56,7 +56,8 @@ def main():
                 if k == "diag":
                     dev[k].tensor.add_(4.5)
             if os.environ.get("GT4MI_PRINT_PTRS"):
-                print("   field addresses mod 16 MiB (MiB):", {k: round((v.ptr % (1 << 24)) / 2**20, 3) for k, v in dev.items()})
+                print("   field addresses mod 16 MiB (MiB):", {k: round((v.ptr % (1 << 24)) / 2**20, 3) for k, v in dev.items()},
+                      " full:", {k: hex(v.ptr) for k, v in dev.items()})
             frozen = obj.freeze(origin=origins, domain=domain)
             for _ in range(3):
                 frozen(**dev, **scalars)

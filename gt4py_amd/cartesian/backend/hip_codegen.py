@@ -74,6 +74,16 @@ TUNING = {
     # ... and consecutive J rows per lane in those kernels: rows (and recomputed temporaries) shared by
     # neighbouring output rows are loaded (computed) once per strip
     "vector_rows": _env_tuple("GT4MI_CODEGEN_VECTOR_ROWS", (4,))[0],
+    # strip kernels of stages whose temporaries were inlined: compute every temporary ONCE per point and pass it to the
+    # neighbouring lanes with DPP shifts (waves overlap by a halo lane or two) instead of re-deriving it at every
+    # offset it is read at (1), or only the recomputing form (0)
+    "shared_temporaries": _env_tuple("GT4MI_CODEGEN_SHARED_TEMPORARIES", (1,))[0],
+    # J rows per lane of that kernel (0: as `vector_rows`) and its XCD-aware tile order (see xcd_rows); measured on the
+    # horizontal diffusion, fp64 / fp32 GLUPS: rows 2 / 3 / 4 / 5 / 6 / 8 = 213 / 219 / 212 / 217 / 213 / 186 and 348 / 358 /
+    # 385 / 408 / 396 / 350; XCD runs of 0 / 2 / 4 / 8 tile rows at 5 rows = 217 / 220 / 221 / 221 and 408 / 410 / 414 / 414
+    # (profiles/r2_codegen_shared_rows.log, r2_codegen_shared_xcd.log)
+    "shared_rows": _env_tuple("GT4MI_CODEGEN_SHARED_ROWS", (5,))[0],
+    "shared_xcd_rows": _env_tuple("GT4MI_CODEGEN_SHARED_XCD_ROWS", (4,))[0],
     # two-sweep column stages (stage_planner.TopCache): levels of the forward sweep's results kept in registers and,
     # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup, cap on the LDS levels).
     # Register levels < 0 (the default): one `_tc<n>` kernel per depth n = n_max, n_max - 8, n_max - 8 - step, ... and 16,
@@ -287,6 +297,11 @@ class KernelSource:
     #: kernel exists that keeps that many top levels of a two-sweep column stage on chip; the host launches the first
     #: one the domain has enough levels for
     top_cache: Optional[Tuple[Tuple[int, int, int], ...]] = None
+    #: halo lanes per side of the `<name>_vecs` kernel (strip kernel whose temporaries are computed once per point and
+    #: passed between lanes), or 0: none.  Its waves overlap by 2 * shared_halo lanes; the host sizes the grid for
+    #: (64 - 2 * shared_halo) * vec output columns per wave.
+    shared_halo: int = 0
+    shared_rows: int = 0  # J rows per lane of the `_vecs` kernel
 
 
 @dataclass
@@ -325,6 +340,7 @@ class _Emitter:
         self.vec_row = 0
         self.local_suffix = ""
         self.base_prefix = "b_"
+        self.shared_lookup = None  # strip kernel with shared temporaries: FieldAccess -> register, or None
         # loads issued ahead of a chunk of K levels: (name, offset, data index) -> register, per statement
         self.prefetched: Dict[Tuple, str] = {}
         self.prefetch_for: Dict[int, Dict[Tuple, str]] = {}
@@ -340,6 +356,10 @@ class _Emitter:
         """C expression of a field access.  ``reg`` maps (name, k offset) -> register holding that level; with
         ``store`` the expression is the memory location itself (an lvalue), whatever is held in registers."""
         name = e.name
+        if not store and self.shared_lookup is not None:
+            hit = self.shared_lookup(e)
+            if hit is not None:
+                return hit
         if name in self.plan.locals:
             return f"l_{_c_ident(name)}{self.local_suffix}"
         if not store:
@@ -1072,9 +1092,14 @@ class _Emitter:
         vec_rows, xcd_rows = _strip_shape(self, stage) if vec else (max(1, TUNING["vector_rows"]), TUNING["xcd_rows"])
         if vec:
             vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread, xcd_rows)
+        shared_halo = 0
+        if vec:
+            form = _shared_form(self, stage, vec, k_per_thread)
+            if form is not None:
+                shared_halo = _emit_shared_kernel(self, si, stage, kname, vec, TUNING["shared_rows"] or vec_rows, block, form)
         plane = None if stage.plane is None else (stage.plane[0], stage.plane[1].value, stage.plane[2])
         return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
-                            vec_rows if vec else 1, plane, top_cache)
+                            vec_rows if vec else 1, plane, top_cache, shared_halo, (TUNING["shared_rows"] or vec_rows) if shared_halo else 0)
 
 
 def _vector_width(em: "_Emitter", stage: Stage) -> int:
@@ -1136,6 +1161,243 @@ def _strip_shape(em: "_Emitter", stage: Stage) -> Tuple[int, int]:
              and all(max(abs(e.offset[0]), abs(e.offset[1])) <= 1 and e.offset[2] == 0 for e in reads)
              and all(em.decl_dtype[n].itemsize == 8 for n in arrays | {stmts[0].target.name}))
     return (8, 4) if light else (rows, xcd)
+
+
+def _shared_form(em: "_Emitter", stage: Stage, vec: int, k_per_thread: int):
+    """(order, defs, rows needed per version, I reach of the inputs, halo lanes) when the stage may get a `_vecs` kernel
+    -- a strip kernel whose inlined temporaries are computed ONCE per point and handed to the neighbouring lanes --, else
+    None.  Eligible: one PARALLEL interval block with inlined temporaries that the stage holds completely; plain
+    (unmasked, unshifted) assignments to arrays nobody in the block reads; every operand a full I, J, K array read at a
+    compile-time offset of at most `vec` points in I."""
+    if not TUNING["shared_temporaries"] or vec <= 0 or k_per_thread != 1 or len(stage.nests) != 1:
+        return None
+    if stage.extent != analysis.ZERO_EXTENT:
+        return None
+    nest = stage.nests[0]
+    form = em.plan.shared_forms.get(nest.block_id)
+    if form is None:
+        return None
+    order, defs = form
+    stmts = [obj for kind, obj in order if kind == "stmt"]
+    if sorted(s.target.name for s in nest.stmts if s.target.name not in em.plan.locals) != sorted(st.target.name for st in stmts):
+        return None  # the block was cut into several stages
+    full = ("I", "J", "K")
+    written = {st.target.name for st in stmts}
+    for st in stmts:
+        t = st.target
+        if (st.mask is not None or st.region is not None or st.loops or tuple(t.offset) != (0, 0, 0) or t.koffset is not None
+                or t.data_index or t.name not in em.global_names or tuple(em.axes.get(t.name, full)) != full):
+            return None
+    exprs = [(None, st.value) for st in stmts] + list(defs.items())
+    for _, expr in exprs:
+        for e in ir.walk(expr):
+            if not isinstance(e, ir.FieldAccess):
+                continue
+            if e.koffset is not None or e.data_index or abs(e.offset[0]) > vec:
+                return None
+            if e.name in defs:
+                if e.offset[2] != 0:
+                    return None
+            elif (e.name in written or e.name not in em.global_names or e.name in em.plan.register_only
+                  or tuple(em.axes.get(e.name, full)) != full):
+                return None
+    # rows (J extent) every version is needed on, and the reach of the inputs, from the outputs backwards
+    need: Dict[str, List[int]] = {}  # version -> [ilo, ihi, jlo, jhi] relative to the output point
+    reach = [0, 0]
+
+    def visit(expr: ir.Expr, ext) -> None:
+        for e in ir.walk(expr):
+            if isinstance(e, ir.FieldAccess):
+                shifted = [ext[0] + e.offset[0], ext[1] + e.offset[0], ext[2] + e.offset[1], ext[3] + e.offset[1]]
+                if e.name in defs:
+                    cur = need.setdefault(e.name, list(shifted))
+                    cur[0], cur[1] = min(cur[0], shifted[0]), max(cur[1], shifted[1])
+                    cur[2], cur[3] = min(cur[2], shifted[2]), max(cur[3], shifted[3])
+                else:
+                    reach[0], reach[1] = min(reach[0], shifted[0]), max(reach[1], shifted[1])
+
+    for kind, obj in reversed(order):
+        if kind == "stmt":
+            visit(obj.value, [0, 0, 0, 0])
+        elif obj in need:
+            visit(defs[obj], need[obj])
+    width = max(-reach[0], reach[1])
+    if width == 0 or not need:
+        return None  # nothing to pass between lanes
+    halo = -(-width // vec)
+    if halo > 4:
+        return None
+    return order, defs, need, halo
+
+
+def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block, form) -> int:
+    """``<kname>_vecs``: the strip kernel of a stage with inlined temporaries, with every temporary computed once per
+    point.  A lane owns ``vec`` consecutive I points times ``rows_per_lane`` J rows and evaluates each temporary (in the
+    single-assignment form the planner kept, stage_planner.inline_horizontal_temporaries_with_forms) at its OWN columns
+    only, on the rows its consumers need; a read at an I offset that leaves the lane's columns is a DPP shift of the
+    neighbouring lane's value.  The first and last `halo` lanes of a wave are halo lanes: they load and compute like
+    every other lane but store nothing (some of what they compute is garbage: the lane beyond the wave does not exist),
+    and consecutive waves overlap by 2 * halo lanes -- the design of the hand-written hdiff_jmarch_kernel.  Returns halo."""
+    order, defs, need, halo = form
+    L = em.lines
+    plan = em.plan
+    JT = rows_per_lane
+    nest = stage.nests[0]
+    out_lanes = 64 - 2 * halo
+    globals_ = [n for n in em.stage_globals(stage) if n not in plan.register_only]
+    stmts = [obj for kind, obj in order if kind == "stmt"]
+    written = {st.target.name for st in stmts}
+
+    L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}_vecs(const gt_args a) {{')
+    L.append("    unsigned gt_bx, gt_by, gt_bz;")
+    L.append(f"    gt_tile({int(TUNING['shared_xcd_rows'])}u, gt_bx, gt_by, gt_bz);")
+    L.append("    const int lane = threadIdx.x & 63;  // waves lie along I and overlap by the halo lanes")
+    L.append(f"    const gt_i64 wave_x = (gt_i64)gt_bx * {block[0] // 64} + (threadIdx.x >> 6);")
+    L.append(f"    const gt_i64 i0 = (wave_x * {out_lanes} - {halo} + lane) * {vec};")
+    L.append("    const gt_i64 iend = a.dI, jend = a.dJ;")
+    L.append(f"    const gt_i64 j0 = ((gt_i64)gt_by * {block[1]} + threadIdx.y) * {JT};")
+    L.append(f"    if (wave_x * {out_lanes * vec} >= iend || j0 >= jend) return;  // whole waves only: DPP needs every lane")
+    L.append(f"    const bool out_lane = lane >= {halo} && lane < {64 - halo};")
+    for n in globals_:
+        c = _c_ident(n)
+        ct = _CTYPE[em.decl_dtype[n].name]
+        const = "" if n in stage.written else "const "
+        qual = " __restrict__" if n in plan.scratch else " GT_RESTRICT"
+        L.append(f"    {const}{ct}* const{qual} b_{c} = a.{c} + i0 + j0 * a.{c}_sj;")
+    L.append(f"    const bool whole = j0 + {JT} <= jend;  // else: a partial strip, point by point")
+    L.append("    const gt_i64 k = a.k_lo + gt_bz;")
+    L.append(f"    if (k >= {em.bound(nest.interval.start)} && k < {em.bound(nest.interval.end)} && k < a.k_hi) {{")
+    L.append("      if (whole) {")
+
+    rows: Dict[Tuple[str, int, int], str] = {}  # (input, row, dk) -> vector register
+    values: Dict[Tuple[str, int], List[str]] = {}  # (version, row) -> registers of the lane's own components
+    shifts: Dict[Tuple, str] = {}
+    guards: Dict[Tuple[int, int], str] = {}
+    state = {"row": 0, "comp": 0}
+
+    def tag(n: int) -> str:
+        return f"m{-n}" if n < 0 else f"p{n}"
+
+    def input_row(name: str, row: int, dk: int) -> str:
+        key = (name, row, dk)
+        if key not in rows:
+            c, ct = _c_ident(name), _CTYPE[em.decl_dtype[name].name]
+            var = f"r{len(rows)}"
+            (ilo, ihi), _ = plan.field_extents.get(name, analysis.ZERO_EXTENT)
+            if (ilo, ihi) not in guards:  # which of the lane's columns lie inside what the array is accessed on: once
+                g = f"g{len(guards)}"
+                L.append(f"        const bool {g} = i0 >= {ilo} && i0 + {vec} <= iend + ({ihi});")
+                for v in range(vec):
+                    L.append(f"        const bool {g}_{v} = i0 + {v} >= {ilo} && i0 + {v} < iend + ({ihi});")
+                guards[(ilo, ihi)] = g
+            g = guards[(ilo, ihi)]
+            kterm = f"(k{dk:+d})" if dk else "k"
+            L.append(f"        const {ct}* const p_{var} = b_{c} + ({kterm} * a.{c}_sk + {row} * a.{c}_sj);")
+            L.append(f"        gt_vec<{ct}, {vec}> {var};")
+            L.append(f"        if ({g}) {var} = *reinterpret_cast<const gt_vec<{ct}, {vec}>*>(p_{var});")
+            L.append("        else {")
+            for v in range(vec):
+                L.append(f"          {var}[{v}] = {g}_{v} ? p_{var}[{v}] : ({ct})0;")
+            L.append("        }")
+            rows[key] = var
+        return rows[key]
+
+    def component(kind: str, ident, ct: str, regs, comp: int) -> str:
+        """Component `comp` of a row of values held per lane in `regs` (own components 0 .. vec-1)."""
+        if 0 <= comp < vec:
+            return regs(comp)
+        key = (kind, ident, comp)
+        if key not in shifts:
+            var = f"s{len(shifts)}"
+            if comp < 0:  # from the lane below: its component vec + comp
+                L.append(f"        const {ct} {var} = gt_shift<{ct}, true>({regs(vec + comp)});")
+            else:  # from the lane above: its component comp - vec
+                L.append(f"        const {ct} {var} = gt_shift<{ct}, false>({regs(comp - vec)});")
+            shifts[key] = var
+        return shifts[key]
+
+    def ensure(version: str, row: int) -> None:
+        """Emit the lane's own components of `version` on `row` (and, through the lookups, whatever they depend on)
+        the first time somebody asks: values are computed in the order the output rows need them, so a row of a
+        temporary is dead as soon as the last output row that reads it is done -- not kept until every row of every
+        temporary exists."""
+        if (version, row) in values:
+            return
+        ct = _CTYPE[np.dtype(defs[version].dtype).name]
+        saved = dict(state)
+        regs = []
+        for v in range(vec):
+            state["row"], state["comp"] = row, v
+            val = em.expr(defs[version], "k", si, {})
+            var = f"t_{_c_ident(version)}_{tag(row)}_{v}"
+            L.append(f"        const {ct} {var} = {val};")
+            regs.append(var)
+        values[(version, row)] = regs
+        state.update(saved)
+
+    def lookup(e: ir.FieldAccess):
+        row, comp = state["row"] + e.offset[1], state["comp"] + e.offset[0]
+        if e.name in defs:
+            ensure(e.name, row)
+            regs = values[(e.name, row)]
+            ct = _CTYPE[np.dtype(defs[e.name].dtype).name]
+            return component("t", (e.name, row), ct, lambda c: regs[c], comp)
+        if e.name in written or e.name not in em.global_names:
+            return None
+        var = input_row(e.name, row, e.offset[2])
+        ct = _CTYPE[em.decl_dtype[e.name].name]
+        return component("r", var, ct, lambda c: f"{var}[{c}]", comp)
+
+    em.shared_lookup = lookup
+    try:
+        for row in range(JT):
+            for obj in stmts:
+                tname = obj.target.name
+                c, ct = _c_ident(tname), _CTYPE[em.decl_dtype[tname].name]
+                vals = []
+                for v in range(vec):
+                    state["row"], state["comp"] = row, v
+                    vals.append(em.expr(obj.value, "k", si, {}))
+                names = []
+                for v, val in enumerate(vals):
+                    L.append(f"        const {ct} w_{c}_{row}_{v} = {val};")
+                    names.append(f"w_{c}_{row}_{v}")
+                ptr = f"b_{c} + (k * a.{c}_sk + {row} * a.{c}_sj)"
+                store = (f"__builtin_nontemporal_store(gt_vec<{ct}, {vec}>{{{', '.join(names)}}}, reinterpret_cast<gt_vec<{ct}, {vec}>*>({ptr}))"
+                         if tname in em.streaming else
+                         f"*reinterpret_cast<gt_vec<{ct}, {vec}>*>({ptr}) = gt_vec<{ct}, {vec}>{{{', '.join(names)}}}")
+                L.append("        if (out_lane) {")
+                L.append(f"          if (i0 + {vec} <= iend) {store};")
+                L.append("          else {")
+                for v in range(vec):
+                    L.append(f"            if (i0 + {v} < iend) ({ptr})[{v}] = {names[v]};")
+                L.append("          }")
+                L.append("        }")
+    finally:
+        em.shared_lookup = None
+    L.append("      } else if (out_lane) {")
+    L.append(f"        for (int jv = 0; jv < {JT}; ++jv) {{")
+    L.append("          const gt_i64 j = j0 + jv;")
+    L.append("          if (j >= jend) break;")
+    L.append(f"          for (int v = 0; v < {vec}; ++v) {{")
+    L.append("            const gt_i64 i = i0 + v;")
+    L.append("            if (i >= iend) break;")
+    for n in globals_:
+        c = _c_ident(n)
+        ct = _CTYPE[em.decl_dtype[n].name]
+        const = "" if n in stage.written else "const "
+        L.append(f"            {const}{ct}* const t_{c} = b_{c} + v + jv * a.{c}_sj;")
+    em.base_prefix = "t_"
+    em.local_decls(nest, "            ")
+    em.statements(nest.stmts, stage, si, "k", {}, "            ")
+    em.base_prefix = "b_"
+    L.append("          }")
+    L.append("        }")
+    L.append("      }")
+    L.append("    }")
+    L.append("}")
+    L.append("")
+    return halo
 
 
 def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block,

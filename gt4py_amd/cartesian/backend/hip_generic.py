@@ -87,6 +87,7 @@ class _Variant:
         self.module = module
         self.functions: List[ctypes.c_void_p] = []
         self.vec_functions: List[Any] = []  # the 16-byte-lane twin of a stage kernel, or None
+        self.shared_functions: List[Any] = []  # ... and its form with temporaries shared between lanes (`_vecs`), or None
         self.tc_functions: List[Any] = []  # per kernel: the top-of-column-cache twins of a two-sweep column kernel
         for kern in program.kernels:
             fn = ctypes.c_void_p()
@@ -99,6 +100,12 @@ class _Variant:
                 _lib.check("gt4mi_module_function",
                            lib.gt4mi_module_function(module, (kern.name + "_vec").encode(), ctypes.byref(vfn)))
             self.vec_functions.append(vfn)
+            sfn = None
+            if kern.vec and unit_i and no_alias and getattr(kern, "shared_halo", 0):
+                sfn = ctypes.c_void_p()
+                _lib.check("gt4mi_module_function",
+                           lib.gt4mi_module_function(module, (kern.name + "_vecs").encode(), ctypes.byref(sfn)))
+            self.shared_functions.append(sfn)
             tfns = []  # [(function, smallest domain K)], deepest cache first
             if kern.top_cache is not None and no_alias:  # emitted under GT4MI_NO_ALIAS only
                 for n_reg, _, min_k in kern.top_cache:
@@ -343,7 +350,7 @@ class HipGenericStencilObject(StencilObject):
                 per_level[k] = ctypes.byref(copy)
             return per_level[k]
 
-        def geometry_of(kern, fn, vfn, tfns, levels: int):
+        def geometry_of(kern, fn, vfn, tfns, sfn, levels: int):
             (ilo, ihi), (jlo, jhi) = kern.extent
             for tfn, min_k in tfns:  # deepest first: the most levels that stay in registers + LDS between the two sweeps
                 if dK >= min_k:
@@ -358,10 +365,15 @@ class HipGenericStencilObject(StencilObject):
                     geometry[n][0] % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0
                     and geometry[n][2] % kern.vec == 0 for n in kern.vec_fields):
                 fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned
+                if sfn is not None:  # temporaries shared between lanes: waves overlap by the halo lanes
+                    per_wave = (64 - 2 * kern.shared_halo) * kern.vec
+                    grid = _U3(-(-ni // (per_wave * (kern.block[0] // 64))), -(-nj // (kern.block[1] * kern.shared_rows)), nk)
+                    return sfn, grid, _U3(*kern.block)
             grid = _U3(-(-ni // (kern.block[0] * lanes)), -(-nj // (kern.block[1] * kern.j_per_thread * rows)), nk)
             return fn, grid, _U3(*kern.block)
 
-        triples = list(zip(program.kernels, variant.functions, variant.vec_functions, variant.tc_functions))
+        triples = list(zip(program.kernels, variant.functions, variant.vec_functions, variant.tc_functions,
+                           variant.shared_functions))
         n = 0
         while n < len(triples):
             kern = triples[n][0]

@@ -35,6 +35,15 @@ def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
 
 def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[str]]:
     """Returns (rewritten stencil, names of SSA values that are thread-local by construction)."""
+    new_stencil, ssa_locals, _ = inline_horizontal_temporaries_with_forms(stencil)
+    return new_stencil, ssa_locals
+
+
+def inline_horizontal_temporaries_with_forms(stencil: ir.Stencil):
+    """As ``inline_horizontal_temporaries``, plus {(computation, block): (order, defs)}: the single-assignment form of
+    every interval block whose temporaries were inlined -- ``order`` lists ("def", version name) and ("stmt", Assign) in
+    program order, ``defs`` maps a version name to its defining expression over fields and earlier versions (offsets
+    as written).  The strip kernels with shared temporaries (hip_codegen) are generated from this form."""
     written = {s.target.name for _, _, s in stencil.statements()}
     pure_inputs = {f.name for f in stencil.fields if f.name not in written}
     temps = {t.name: t for t in stencil.temporaries}
@@ -85,13 +94,14 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                         inline.add(e.name)
                         changed = True
     if not inline:
-        return stencil, set()
+        return stencil, set(), {}
 
+    forms: Dict[Tuple[int, int], Tuple[List[Tuple[str, object]], Dict[str, ir.Expr]]] = {}
     ssa_locals: Dict[str, np.dtype] = {}
     new_comps = []
-    for comp in stencil.computations:
+    for ci, comp in enumerate(stencil.computations):
         new_blocks = []
-        for block in comp.blocks:
+        for bi, block in enumerate(comp.blocks):
             version: Dict[str, str] = {}
             defs: Dict[str, ir.Expr] = {}
             order: List[Tuple[str, object]] = []  # ("def", version) | ("stmt", Assign)
@@ -161,10 +171,12 @@ def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[
                 else:
                     new_body.append(ir.Assign(expand(obj.target, (0, 0)), value[0], value[1], obj.group, obj.region, value[2]))
             new_blocks.append(ir.IntervalBlock(block.interval, tuple(new_body)))
+            if defs:
+                forms[(ci, bi)] = (order, defs)
         new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
     new_temps = tuple(t for t in stencil.temporaries if t.name not in inline) + tuple(
         ir.FieldDecl(n, dt, ("I", "J", "K"), (), False) for n, dt in ssa_locals.items())
-    return ir.Stencil(stencil.name, stencil.fields, stencil.params, new_temps, tuple(new_comps)), set(ssa_locals)
+    return ir.Stencil(stencil.name, stencil.fields, stencil.params, new_temps, tuple(new_comps)), set(ssa_locals), forms
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -232,6 +244,9 @@ class Plan:
     api_fields: List[ir.FieldDecl]  # API fields a kernel touches
     params: List[ir.ScalarDecl]  # scalar parameters a kernel reads
     top_cache: Dict[int, TopCache] = field(default_factory=dict)  # stage index -> what may stay on chip
+    #: (computation, block) -> single-assignment form of a block whose temporaries were inlined (see
+    #: inline_horizontal_temporaries_with_forms)
+    shared_forms: Dict[Tuple[int, int], Tuple[list, dict]] = field(default_factory=dict)
 
 
 def _field_reads(expr: ir.Expr):
@@ -297,7 +312,7 @@ def _loop_invariant_statements(stmts: List[Stmt], temporaries: Set[str]) -> Tupl
 
 
 def plan_stages(stencil_in: ir.Stencil) -> Plan:
-    stencil, ssa_locals = inline_horizontal_temporaries(stencil_in)
+    stencil, ssa_locals, shared_forms = inline_horizontal_temporaries_with_forms(stencil_in)
     extents = analysis.compute_extents(stencil)
     written_anywhere = {s.target.name for _, _, s in stencil.statements()}
 
@@ -522,7 +537,7 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     params = [p for p in stencil.params if p.name in used]
     top_cache = _plan_top_cache(stencil, stages, scratch, forwarded, prime, local_names, register_only, touched_in)
     return Plan(stencil, stages, {**extents.fields, **temp_extents}, local_names, scratch, forwarded, prime, register_only,
-                api_fields, params, top_cache)
+                api_fields, params, top_cache, shared_forms)
 
 
 def _plan_top_cache(stencil: ir.Stencil, stages: List[Stage], scratch, forwarded, prime, local_names, register_only,

@@ -156,13 +156,34 @@ def test_horizontal_stages_get_a_16_byte_lane_twin(programs):
     assert "gt_tile(4u, gt_bx, gt_by, gt_bz);" in lap.source[lap.source.index("gt4mi_laplacian_stage0_vec"):]
     # everything heavier keeps 4 rows and the plain tile order
     hd = programs["horizontal_diffusion"]
-    assert [(k.vec, k.vec_rows) for k in hd.kernels] == [(2, 4)] and "gt_tile(4u" not in hd.source
+    vec_part = hd.source[hd.source.index("gt4mi_horizontal_diffusion_stage0_vec("):hd.source.index("gt4mi_horizontal_diffusion_stage0_vecs(")]
+    assert [(k.vec, k.vec_rows) for k in hd.kernels] == [(2, 4)] and "gt_tile(4u" not in vec_part
     assert [k.vec for k in programs["horizontal_diffusion_f32"].kernels] == [4]
     assert [k.vec for k in programs["mixed_precision"].kernels] == [2]  # widest element decides
     # not vectorised: sequential stages, stages that read what they write, arrays without an I axis as target
     assert [k.vec for k in programs["tridiagonal_solver"].kernels] == [0]
     assert [k.vec for k in programs["two_stage_written_input"].kernels] == [0, 2]
     assert [k.vec for k in programs["column_sum_then_gradient"].kernels] == [0, 2]
+
+
+def test_stages_with_inlined_temporaries_get_a_strip_kernel_that_shares_them(programs):
+    """`<name>_vecs`: every inlined temporary is computed once per point, at the lane's own columns, and read at an I
+    offset through a DPP shift of the neighbouring lane's value; waves overlap by a halo lane on each side."""
+    import re
+
+    for name, vec in (("horizontal_diffusion", 2), ("horizontal_diffusion_f32", 4)):
+        prog = programs[name]
+        (kern,) = prog.kernels
+        assert (kern.vec, kern.shared_halo, kern.shared_rows) == (vec, 1, 5), name  # inputs reach 2 columns: one halo lane
+        src = prog.source[prog.source.index(f"gt4mi_{name}_stage0_vecs("):]
+        assert f"const gt_i64 i0 = (wave_x * 62 - 1 + lane) * {vec};" in src and "const bool out_lane = lane >= 1 && lane < 63;" in src
+        # lap on rows -1 .. 5 (7 rows x vec components), each exactly once; the recomputing kernel derives it per consumer
+        laps = re.findall(r"const double (t_lap\w*?__v0_[mp]\d_\d) = ", src)
+        assert len(laps) == len(set(laps)) == 7 * vec, laps
+        assert "gt_shift<double, true>(t_lap" in src or "gt_shift<double, false>(t_lap" in src  # a temporary crosses lanes
+    # nothing to share: no temporaries (Laplacian), or no horizontal offsets on them
+    assert [k.shared_halo for k in programs["laplacian"].kernels] == [0]
+    assert all(k.shared_halo == 0 for k in programs["vertical_advection_dycore"].kernels)
 
 
 def test_two_sweep_column_stages_get_a_ladder_of_cached_variants(programs):

@@ -347,3 +347,21 @@ def test_top_of_column_cache_is_what_runs_and_does_not_spill():
     expect, got, hip2 = _run_pair_rebuilt("vertical_advection_dycore", (64, 4, 160))
     for k in expect:
         np.testing.assert_array_equal(got[k], expect[k])
+
+
+# ---- strip kernels whose inlined temporaries are shared between lanes (the `_vecs` kernel variant) -------------------
+@pytest.mark.parametrize("name", ["horizontal_diffusion", "horizontal_diffusion_f32"])
+@pytest.mark.parametrize("domain", [(1, 5, 2), (2, 6, 2), (123, 5, 3), (124, 10, 2), (125, 11, 2), (247, 9, 2), (248, 15, 3), (249, 4, 2),
+                                    (300, 23, 3), (496, 5, 1), (497, 7, 2), (1000, 26, 2)])
+def test_shared_temporaries_strip_kernel_at_every_edge(name, domain):
+    """Waves of the `_vecs` kernel cover 62 lanes x 2 (fp64) or 4 (fp32) columns and overlap by a halo lane on each side;
+    strips are 5 rows.  Domains on both sides of one, two and four waves in I, with whole and partial strips in J: the
+    halo lanes at the domain edge read only what the arrays hold, the last wave stores only inside the domain, the rows
+    that do not fill a strip take the point-by-point path -- all bit-identical to the oracle."""
+    expect, got, hip = _run_pair(name, domain, seed=sum(domain))
+    kern = type(hip)._gt_program_.kernels[0]
+    assert kern.shared_halo == 1 and kern.shared_rows == 5
+    variant = next(iter(type(hip)._gt_variants_.values()))
+    assert variant.shared_functions[0] is not None, "the `_vecs` kernel must be what a call with aligned storages launches"
+    for k in expect:
+        np.testing.assert_array_equal(got[k], expect[k], err_msg=f"{name} {domain}: field {k}")

@@ -235,11 +235,16 @@ GT_DEV void gt_tile(unsigned rows, unsigned& bx, unsigned& by, unsigned& bz) {
 // lanes' registers and are fetched with whole-wave DPP shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1,
 // no LDS).  bound_ctrl: lanes shifted in from outside the wave read 0 without an extra move -- callers overwrite those lanes.
 template <class T, int N> using gt_vec = T __attribute__((ext_vector_type(N)));
-template <class T, bool FROM_BELOW> GT_DEV T gt_shift(T v) {
+// OPAQUE: the result goes through an empty asm, so that the DPP-combine pass cannot fold the move into its consumer.
+// It does that to a float that is widened next (v_cvt_f64_f32_dpp), which gfx950 cannot encode with a wave shift ("DP ALU
+// dpp only support row_newbcast": the compilation fails; found by the fuzzer).  The `_vecs` kernels use it; the `_vec`
+// kernels overwrite the edge lanes' value after the shift, which keeps the pass away as a side effect.
+template <class T, bool FROM_BELOW, bool OPAQUE = false> GT_DEV T gt_shift(T v) {
     if constexpr (sizeof(T) == 4) {
         const int b = __builtin_bit_cast(int, v);
-        const int r = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, b, 0x138, 0xF, 0xF, true)
-                                 : __builtin_amdgcn_update_dpp(0, b, 0x130, 0xF, 0xF, true);
+        int r = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, b, 0x138, 0xF, 0xF, true)
+                           : __builtin_amdgcn_update_dpp(0, b, 0x130, 0xF, 0xF, true);
+        if constexpr (OPAQUE) asm("" : "+v"(r));
         return __builtin_bit_cast(T, r);
     } else {
         static_assert(sizeof(T) == 8, "gt_shift: 4- or 8-byte types");
@@ -249,6 +254,7 @@ template <class T, bool FROM_BELOW> GT_DEV T gt_shift(T v) {
                         : __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xF, 0xF, true);
         hi = FROM_BELOW ? __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, true)
                         : __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xF, 0xF, true);
+        if constexpr (OPAQUE) asm("" : "+v"(lo), "+v"(hi));
         return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned int)lo);
     }
 }
@@ -1178,6 +1184,38 @@ def _shared_form(em: "_Emitter", stage: Stage, vec: int, k_per_thread: int):
     if form is None:
         return None
     order, defs = form
+    # temporaries of the block that were NOT inlined (read at their own point only) become versions as well
+    from dataclasses import replace as _replace
+
+    current: Dict[str, str] = {}
+
+    def renamed(expr: ir.Expr) -> ir.Expr:
+        def fn(e):
+            if isinstance(e, ir.FieldAccess) and e.name in current:
+                return _replace(e, name=current[e.name])
+            return e
+
+        return ir.map_expr(expr, fn)
+
+    new_order: List[Tuple[str, object]] = []
+    new_defs: Dict[str, ir.Expr] = {}
+    for kind, obj in order:
+        if kind == "def":
+            new_defs[obj] = renamed(defs[obj])
+            new_order.append(("def", obj))
+        elif obj.target.name in em.global_names and obj.target.name not in em.plan.locals:
+            if obj.mask is not None or obj.region is not None or obj.loops:
+                return None
+            new_order.append(("stmt", _replace(obj, value=renamed(obj.value))))
+        else:  # a thread-local temporary
+            t = obj.target
+            if obj.mask is not None or obj.region is not None or obj.loops or tuple(t.offset) != (0, 0, 0) or t.koffset is not None or t.data_index:
+                return None
+            version = f"{t.name}__w{len(new_defs)}"
+            new_defs[version] = renamed(obj.value)
+            new_order.append(("def", version))
+            current[t.name] = version
+    order, defs = new_order, new_defs
     stmts = [obj for kind, obj in order if kind == "stmt"]
     if sorted(s.target.name for s in nest.stmts if s.target.name not in em.plan.locals) != sorted(st.target.name for st in stmts):
         return None  # the block was cut into several stages
@@ -1310,9 +1348,9 @@ def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
         if key not in shifts:
             var = f"s{len(shifts)}"
             if comp < 0:  # from the lane below: its component vec + comp
-                L.append(f"        const {ct} {var} = gt_shift<{ct}, true>({regs(vec + comp)});")
+                L.append(f"        const {ct} {var} = gt_shift<{ct}, true, true>({regs(vec + comp)});")
             else:  # from the lane above: its component comp - vec
-                L.append(f"        const {ct} {var} = gt_shift<{ct}, false>({regs(comp - vec)});")
+                L.append(f"        const {ct} {var} = gt_shift<{ct}, false, true>({regs(comp - vec)});")
             shifts[key] = var
         return shifts[key]
 

@@ -180,7 +180,7 @@ def test_stages_with_inlined_temporaries_get_a_strip_kernel_that_shares_them(pro
         # lap on rows -1 .. 5 (7 rows x vec components), each exactly once; the recomputing kernel derives it per consumer
         laps = re.findall(r"const double (t_lap\w*?__v0_[mp]\d_\d) = ", src)
         assert len(laps) == len(set(laps)) == 7 * vec, laps
-        assert "gt_shift<double, true>(t_lap" in src or "gt_shift<double, false>(t_lap" in src  # a temporary crosses lanes
+        assert "gt_shift<double, true, true>(t_lap" in src or "gt_shift<double, false, true>(t_lap" in src  # a temporary crosses lanes
     # nothing to share: no temporaries (Laplacian), or no horizontal offsets on them
     assert [k.shared_halo for k in programs["laplacian"].kernels] == [0]
     assert all(k.shared_halo == 0 for k in programs["vertical_advection_dycore"].kernels)

@@ -315,6 +315,17 @@ def other_kernels(steps: int = 20):
         note="the headline stencil through the code generator instead of the hand-written kernel")
     del fields
     torch.cuda.empty_cache()
+    dom = HDIFF_SHARE
+    obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64},
+                           device_sync=False, use_kernel_library=False)
+    shape = (dom[0] + 4, dom[1] + 4, dom[2])
+    fields = {"in_field": hdiff_input(shape, np.float64, gen), "coeff": field(shape, np.float64, (2, 2, 0), 0.025, 0.025),
+              "out_field": field(shape, np.float64, (2, 2, 0))}
+    run("generated_hdiff_limiter_f64_512x1024x80", obj, fields, {k: (2, 2, 0) for k in fields}, dom, 24.0,
+        note="the flux-limited horizontal diffusion through the code generator: one strip kernel, lap / flx / fly computed "
+             "once per point and passed between lanes with DPP shifts (hip_codegen._emit_shared_kernel)")
+    del fields
+    torch.cuda.empty_cache()
     return out
 
 

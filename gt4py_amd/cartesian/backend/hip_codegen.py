@@ -1170,19 +1170,38 @@ def _strip_shape(em: "_Emitter", stage: Stage) -> Tuple[int, int]:
 
 
 def _shared_form(em: "_Emitter", stage: Stage, vec: int, k_per_thread: int):
-    """(order, defs, rows needed per version, I reach of the inputs, halo lanes) when the stage may get a `_vecs` kernel
-    -- a strip kernel whose inlined temporaries are computed ONCE per point and handed to the neighbouring lanes --, else
-    None.  Eligible: one PARALLEL interval block with inlined temporaries that the stage holds completely; plain
-    (unmasked, unshifted) assignments to arrays nobody in the block reads; every operand a full I, J, K array read at a
-    compile-time offset of at most `vec` points in I."""
-    if not TUNING["shared_temporaries"] or vec <= 0 or k_per_thread != 1 or len(stage.nests) != 1:
+    """([(nest, order, defs, rows needed per version), ...], halo lanes) when the stage may get a `_vecs` kernel -- a
+    strip kernel whose inlined temporaries are computed ONCE per point and handed to the neighbouring lanes --, else
+    None.  Eligible: PARALLEL interval blocks the stage holds completely, at least one of them with inlined temporaries;
+    plain (unmasked, unshifted) assignments to arrays nobody in the stage reads; every operand a full I, J, K array read
+    at a compile-time offset of at most `vec` points in I."""
+    if not TUNING["shared_temporaries"] or vec <= 0 or k_per_thread != 1 or not stage.nests:
         return None
     if stage.extent != analysis.ZERO_EXTENT:
         return None
-    nest = stage.nests[0]
-    form = em.plan.shared_forms.get(nest.block_id)
-    if form is None:
+    stage_written = {s.target.name for nest in stage.nests for s in nest.stmts}
+    forms, width = [], 0
+    for nest in stage.nests:
+        if nest.order is not ir.LoopOrder.PARALLEL or nest.split_statements:
+            return None
+        one = _shared_nest_form(em, nest, vec, stage_written)
+        if one is None:
+            return None
+        forms.append((nest,) + one[:3])
+        width = max(width, one[3])
+    if width == 0 or not any(need for _, _, _, need in forms):
+        return None  # nothing to pass between lanes
+    halo = -(-width // vec)
+    if halo > 4:
         return None
+    return forms, halo
+
+
+def _shared_nest_form(em: "_Emitter", nest: Nest, vec: int, stage_written: Set[str]):
+    """(order, defs, need, I reach of the inputs) of one nest of a `_vecs` kernel, or None (see _shared_form)."""
+    form = em.plan.shared_forms.get(nest.block_id)
+    if form is None:  # a block without inlined temporaries (a boundary interval, say): its statements as they are
+        form = ([("stmt", s) for s in nest.stmts], {})
     order, defs = form
     # temporaries of the block that were NOT inlined (read at their own point only) become versions as well
     from dataclasses import replace as _replace
@@ -1220,7 +1239,7 @@ def _shared_form(em: "_Emitter", stage: Stage, vec: int, k_per_thread: int):
     if sorted(s.target.name for s in nest.stmts if s.target.name not in em.plan.locals) != sorted(st.target.name for st in stmts):
         return None  # the block was cut into several stages
     full = ("I", "J", "K")
-    written = {st.target.name for st in stmts}
+    written = {st.target.name for st in stmts} | set(stage_written)
     for st in stmts:
         t = st.target
         if (st.mask is not None or st.region is not None or st.loops or tuple(t.offset) != (0, 0, 0) or t.koffset is not None
@@ -1259,13 +1278,7 @@ def _shared_form(em: "_Emitter", stage: Stage, vec: int, k_per_thread: int):
             visit(obj.value, [0, 0, 0, 0])
         elif obj in need:
             visit(defs[obj], need[obj])
-    width = max(-reach[0], reach[1])
-    if width == 0 or not need:
-        return None  # nothing to pass between lanes
-    halo = -(-width // vec)
-    if halo > 4:
-        return None
-    return order, defs, need, halo
+    return order, defs, need, max(-reach[0], reach[1])
 
 
 def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block, form) -> int:
@@ -1276,15 +1289,12 @@ def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
     neighbouring lane's value.  The first and last `halo` lanes of a wave are halo lanes: they load and compute like
     every other lane but store nothing (some of what they compute is garbage: the lane beyond the wave does not exist),
     and consecutive waves overlap by 2 * halo lanes -- the design of the hand-written hdiff_jmarch_kernel.  Returns halo."""
-    order, defs, need, halo = form
+    forms, halo = form
     L = em.lines
     plan = em.plan
     JT = rows_per_lane
-    nest = stage.nests[0]
     out_lanes = 64 - 2 * halo
     globals_ = [n for n in em.stage_globals(stage) if n not in plan.register_only]
-    stmts = [obj for kind, obj in order if kind == "stmt"]
-    written = {st.target.name for st in stmts}
 
     L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}_vecs(const gt_args a) {{')
     L.append("    unsigned gt_bx, gt_by, gt_bz;")
@@ -1304,6 +1314,19 @@ def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
         L.append(f"    {const}{ct}* const{qual} b_{c} = a.{c} + i0 + j0 * a.{c}_sj;")
     L.append(f"    const bool whole = j0 + {JT} <= jend;  // else: a partial strip, point by point")
     L.append("    const gt_i64 k = a.k_lo + gt_bz;")
+    for nest, order, defs, need in forms:
+        _emit_shared_nest(em, si, stage, nest, order, defs, need, vec, JT, globals_)
+    L.append("}")
+    L.append("")
+    return halo
+
+
+def _emit_shared_nest(em: "_Emitter", si: int, stage: Stage, nest: Nest, order, defs, need, vec: int, JT: int, globals_) -> None:
+    """One interval block of a `_vecs` kernel (see _emit_shared_kernel)."""
+    L = em.lines
+    plan = em.plan
+    stmts = [obj for kind, obj in order if kind == "stmt"]
+    written = {s.target.name for n in stage.nests for s in n.stmts}
     L.append(f"    if (k >= {em.bound(nest.interval.start)} && k < {em.bound(nest.interval.end)} && k < a.k_hi) {{")
     L.append("      if (whole) {")
 
@@ -1433,9 +1456,6 @@ def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
     L.append("        }")
     L.append("      }")
     L.append("    }")
-    L.append("}")
-    L.append("")
-    return halo
 
 
 def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block,

@@ -33,6 +33,64 @@ def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
     return replace(e, offset=(e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]))
 
 
+def split_block_local_temporaries(stencil: ir.Stencil) -> ir.Stencil:
+    """A temporary that several interval blocks use, each for itself -- every block that touches it assigns it (plainly:
+    no mask, region or loop) before it reads it, and nobody reads it at a K offset -- is one temporary per block under one
+    name: no value flows between the blocks (at a level, a block only ever sees what it assigned itself).  Give every
+    block its own name, so that the passes below treat them as what they are (inlined or thread-local per block instead
+    of one scratch array that forces a stage per statement).  Typical: the same `lap` / `flx` names in the boundary
+    interval and in the interior interval of a horizontal operator."""
+    temps = {t.name: t for t in stencil.temporaries}
+    first_is_write: Dict[str, Dict[Tuple[int, int], bool]] = {}
+    shared_between_blocks: Set[str] = set()
+    for ci, comp in enumerate(stencil.computations):
+        for bi, block in enumerate(comp.blocks):
+            seen: Set[str] = set()
+            for stmt in block.body:
+                for e in ir.stmt_reads(stmt):
+                    if isinstance(e, ir.FieldAccess) and e.name in temps:
+                        if e.offset[2] != 0 or e.koffset is not None:
+                            shared_between_blocks.add(e.name)
+                        if e.name not in seen:
+                            seen.add(e.name)
+                            first_is_write.setdefault(e.name, {})[(ci, bi)] = False
+                t = stmt.target
+                if t.name in temps and t.name not in seen:
+                    seen.add(t.name)
+                    plain = (stmt.mask is None and stmt.region is None and not stmt.loops and tuple(t.offset) == (0, 0, 0)
+                             and t.koffset is None and not t.data_index)
+                    first_is_write.setdefault(t.name, {})[(ci, bi)] = plain
+    split = {n for n, blocks in first_is_write.items()
+             if len(blocks) > 1 and all(blocks.values()) and n not in shared_between_blocks and not temps[n].data_dims
+             and tuple(temps[n].axes) == ("I", "J", "K")}
+    if not split:
+        return stencil
+    new_temps: List[ir.FieldDecl] = [t for t in stencil.temporaries if t.name not in split]
+    new_comps = []
+    for ci, comp in enumerate(stencil.computations):
+        new_blocks = []
+        for bi, block in enumerate(comp.blocks):
+            names = {n: f"{n}__b{ci}_{bi}" for n in split if (ci, bi) in first_is_write[n]}
+            if not names:
+                new_blocks.append(block)
+                continue
+            new_temps.extend(replace(temps[n], name=new) for n, new in names.items())
+
+            def fn(e, names=names):
+                if isinstance(e, ir.FieldAccess) and e.name in names:
+                    return replace(e, name=names[e.name])
+                return e
+
+            body = []
+            for stmt in block.body:
+                body.append(ir.Assign(ir.map_expr(stmt.target, fn), ir.map_expr(stmt.value, fn),
+                                      ir.map_expr(stmt.mask, fn) if stmt.mask is not None else None, stmt.group, stmt.region,
+                                      tuple((lid, ir.map_expr(c, fn)) for lid, c in stmt.loops)))
+            new_blocks.append(ir.IntervalBlock(block.interval, tuple(body)))
+        new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
+    return ir.Stencil(stencil.name, stencil.fields, stencil.params, tuple(new_temps), tuple(new_comps))
+
+
 def inline_horizontal_temporaries(stencil: ir.Stencil) -> Tuple[ir.Stencil, Set[str]]:
     """Returns (rewritten stencil, names of SSA values that are thread-local by construction)."""
     new_stencil, ssa_locals, _ = inline_horizontal_temporaries_with_forms(stencil)
@@ -44,6 +102,7 @@ def inline_horizontal_temporaries_with_forms(stencil: ir.Stencil):
     every interval block whose temporaries were inlined -- ``order`` lists ("def", version name) and ("stmt", Assign) in
     program order, ``defs`` maps a version name to its defining expression over fields and earlier versions (offsets
     as written).  The strip kernels with shared temporaries (hip_codegen) are generated from this form."""
+    stencil = split_block_local_temporaries(stencil)
     written = {s.target.name for _, _, s in stencil.statements()}
     pure_inputs = {f.name for f in stencil.fields if f.name not in written}
     temps = {t.name: t for t in stencil.temporaries}

@@ -308,6 +308,8 @@ class KernelSource:
     #: (64 - 2 * shared_halo) * vec output columns per wave.
     shared_halo: int = 0
     shared_rows: int = 0  # J rows per lane of the `_vecs` kernel
+    shared_vec: int = 0  # I points per lane of the `_vecs` kernel (it may exist where no `_vec` kernel does)
+    shared_fields: Tuple[str, ...] = ()  # arrays whose alignment / strides decide whether it may be launched
 
 
 @dataclass
@@ -1098,18 +1100,23 @@ class _Emitter:
         vec_rows, xcd_rows = _strip_shape(self, stage) if vec else (max(1, TUNING["vector_rows"]), TUNING["xcd_rows"])
         if vec:
             vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread, xcd_rows)
-        shared_halo = 0
-        if vec:
-            form = _shared_form(self, stage, vec, k_per_thread)
+        shared_halo, shared_vec, shared_fields = 0, 0, ()
+        svec = vec or (_vector_width(self, stage, any_reach=True) if j_per_thread == 1 and block[0] % 64 == 0 else 0)
+        if svec:
+            form = _shared_form(self, stage, svec, k_per_thread)
             if form is not None:
-                shared_halo = _emit_shared_kernel(self, si, stage, kname, vec, TUNING["shared_rows"] or vec_rows, block, form)
+                shared_vec = svec
+                shared_halo, shared_fields = _emit_shared_kernel(self, si, stage, kname, svec, TUNING["shared_rows"] or vec_rows, block, form)
         plane = None if stage.plane is None else (stage.plane[0], stage.plane[1].value, stage.plane[2])
         return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
-                            vec_rows if vec else 1, plane, top_cache, shared_halo, (TUNING["shared_rows"] or vec_rows) if shared_halo else 0)
+                            vec_rows if vec else 1, plane, top_cache, shared_halo, (TUNING["shared_rows"] or vec_rows) if shared_halo else 0,
+                            shared_vec, shared_fields)
 
 
-def _vector_width(em: "_Emitter", stage: Stage) -> int:
-    """How many consecutive I points a lane may own in this stage (0 = keep one point per thread).
+def _vector_width(em: "_Emitter", stage: Stage, any_reach: bool = False) -> int:
+    """How many consecutive I points a lane may own in this stage (0 = keep one point per thread).  ``any_reach``: do
+    not insist that every (inlined) read stays within one lane of the point -- the `_vecs` form reaches further through
+    its temporaries, one lane per link of the chain.
 
     Needs: thread-per-point mapping, the stage starting at the domain's first column, reads only of arrays
     the stage does not write (so rows can be loaded once, up front), every statement on the full stage
@@ -1142,6 +1149,8 @@ def _vector_width(em: "_Emitter", stage: Stage) -> int:
     if not sizes or not sizes <= {4, 8}:
         return 0
     vec = 16 // max(sizes)
+    if any_reach:
+        return vec
     for nest in stage.nests:
         for s in nest.stmts:
             if any(abs(e.offset[0]) > vec for e in _stmt_field_reads(s) if e.name not in em.plan.locals):
@@ -1281,14 +1290,15 @@ def _shared_nest_form(em: "_Emitter", nest: Nest, vec: int, stage_written: Set[s
     return order, defs, need, max(-reach[0], reach[1])
 
 
-def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block, form) -> int:
+def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block, form):
     """``<kname>_vecs``: the strip kernel of a stage with inlined temporaries, with every temporary computed once per
     point.  A lane owns ``vec`` consecutive I points times ``rows_per_lane`` J rows and evaluates each temporary (in the
     single-assignment form the planner kept, stage_planner.inline_horizontal_temporaries_with_forms) at its OWN columns
     only, on the rows its consumers need; a read at an I offset that leaves the lane's columns is a DPP shift of the
     neighbouring lane's value.  The first and last `halo` lanes of a wave are halo lanes: they load and compute like
     every other lane but store nothing (some of what they compute is garbage: the lane beyond the wave does not exist),
-    and consecutive waves overlap by 2 * halo lanes -- the design of the hand-written hdiff_jmarch_kernel.  Returns halo."""
+    and consecutive waves overlap by 2 * halo lanes -- the design of the hand-written hdiff_jmarch_kernel.  Returns
+    (halo, arrays it touches)."""
     forms, halo = form
     L = em.lines
     plan = em.plan
@@ -1318,7 +1328,7 @@ def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
         _emit_shared_nest(em, si, stage, nest, order, defs, need, vec, JT, globals_)
     L.append("}")
     L.append("")
-    return halo
+    return halo, tuple(globals_)
 
 
 def _emit_shared_nest(em: "_Emitter", si: int, stage: Stage, nest: Nest, order, defs, need, vec: int, JT: int, globals_) -> None:

@@ -101,7 +101,7 @@ class _Variant:
                            lib.gt4mi_module_function(module, (kern.name + "_vec").encode(), ctypes.byref(vfn)))
             self.vec_functions.append(vfn)
             sfn = None
-            if kern.vec and unit_i and no_alias and getattr(kern, "shared_halo", 0):
+            if unit_i and no_alias and getattr(kern, "shared_halo", 0):
                 sfn = ctypes.c_void_p()
                 _lib.check("gt4mi_module_function",
                            lib.gt4mi_module_function(module, (kern.name + "_vecs").encode(), ctypes.byref(sfn)))
@@ -361,14 +361,17 @@ class HipGenericStencilObject(StencilObject):
                 return None
             nk = -(-levels // kern.k_per_thread) if kern.mapping == "ijk" else 1
             lanes = rows = 1
+            if sfn is not None and no_alias and all(
+                    geometry[n][0] % (kern.shared_vec * geometry[n][3]) == 0 and geometry[n][1] % kern.shared_vec == 0
+                    and geometry[n][2] % kern.shared_vec == 0 for n in kern.shared_fields):
+                # temporaries shared between lanes: waves overlap by the halo lanes
+                per_wave = (64 - 2 * kern.shared_halo) * kern.shared_vec
+                grid = _U3(-(-ni // (per_wave * (kern.block[0] // 64))), -(-nj // (kern.block[1] * kern.shared_rows)), nk)
+                return sfn, grid, _U3(*kern.block)
             if vfn is not None and no_alias and all(
                     geometry[n][0] % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0
                     and geometry[n][2] % kern.vec == 0 for n in kern.vec_fields):
                 fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned
-                if sfn is not None:  # temporaries shared between lanes: waves overlap by the halo lanes
-                    per_wave = (64 - 2 * kern.shared_halo) * kern.vec
-                    grid = _U3(-(-ni // (per_wave * (kern.block[0] // 64))), -(-nj // (kern.block[1] * kern.shared_rows)), nk)
-                    return sfn, grid, _U3(*kern.block)
             grid = _U3(-(-ni // (kern.block[0] * lanes)), -(-nj // (kern.block[1] * kern.j_per_thread * rows)), nk)
             return fn, grid, _U3(*kern.block)
 

@@ -361,7 +361,8 @@ def test_shared_temporaries_strip_kernel_at_every_edge(name, domain):
     expect, got, hip = _run_pair(name, domain, seed=sum(domain))
     kern = type(hip)._gt_program_.kernels[0]
     assert kern.shared_halo == 1 and kern.shared_rows == 5
-    variant = next(iter(type(hip)._gt_variants_.values()))
-    assert variant.shared_functions[0] is not None, "the `_vecs` kernel must be what a call with aligned storages launches"
+    # (the class may hold other flavours from earlier calls -- strided or aliased arguments --, which have no `_vecs` twin)
+    assert any(v.shared_functions[0] is not None for v in type(hip)._gt_variants_.values()), \
+        "the `_vecs` kernel must be what a call with aligned, disjoint storages launches"
     for k in expect:
         np.testing.assert_array_equal(got[k], expect[k], err_msg=f"{name} {domain}: field {k}")

@@ -91,6 +91,22 @@ def laplacian(inp: F64, out: F64):
         out = -4.0 * inp[0, 0, 0] + inp[-1, 0, 0] + inp[1, 0, 0] + inp[0, -1, 0] + inp[0, 1, 0]
 
 
+def hyperdiffusion_6th(inp: F64, out: F64, *, nu: float):
+    """Laplacian applied three times (a sixth-order filter), with a boundary level of its own that uses the same
+    temporaries: the inputs are read up to 3 points away through a chain of temporaries (two halo lanes in the strip
+    kernel with shared temporaries), and `l1` / `l2` are one temporary per interval block."""
+    with computation(PARALLEL):
+        with interval(0, 1):
+            l1 = -4.0 * inp + inp[1, 0, 0] + inp[-1, 0, 0] + inp[0, 1, 0] + inp[0, -1, 0]
+            l2 = -4.0 * l1 + l1[1, 0, 0] + l1[-1, 0, 0] + l1[0, 1, 0] + l1[0, -1, 0]
+            out = inp + 0.5 * nu * l2
+        with interval(1, None):
+            l1 = -4.0 * inp + inp[1, 0, 0] + inp[-1, 0, 0] + inp[0, 1, 0] + inp[0, -1, 0]
+            l2 = -4.0 * l1 + l1[1, 0, 0] + l1[-1, 0, 0] + l1[0, 1, 0] + l1[0, -1, 0]
+            l3 = -4.0 * l2 + l2[1, 0, 0] + l2[-1, 0, 0] + l2[0, 1, 0] + l2[0, -1, 0]
+            out = inp + nu * l3
+
+
 def tridiagonal_solver(inf: F64, diag: F64, sup: F64, rhs: F64, out: F64):
     """stencil_definitions.py:219-232"""
     with computation(FORWARD):
@@ -389,6 +405,7 @@ ZOO = {
     "horizontal_diffusion": (horizontal_diffusion, {}, {}, {"use_kernel_library": False}),
     "horizontal_diffusion_f32": (horizontal_diffusion_f32, {}, {}, {"use_kernel_library": False}),
     "laplacian": (laplacian, {}, {}, {"use_kernel_library": False}),
+    "hyperdiffusion_6th": (hyperdiffusion_6th, {}, {"nu": 0.01}, {}),
     "tridiagonal_solver": (tridiagonal_solver, {}, {}, {"use_kernel_library": False}),
     "vertical_advection_dycore": (vertical_advection_dycore, {"BET_M": 0.5, "BET_P": 0.5}, {"dtr_stage": 3.0 / 20.0}, {}),
     "column_sum_then_gradient": (column_sum_then_gradient, {}, {}, {}),

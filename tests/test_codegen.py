@@ -181,6 +181,12 @@ def test_stages_with_inlined_temporaries_get_a_strip_kernel_that_shares_them(pro
         laps = re.findall(r"const double (t_lap\w*?__v0_[mp]\d_\d) = ", src)
         assert len(laps) == len(set(laps)) == 7 * vec, laps
         assert "gt_shift<double, true, true>(t_lap" in src or "gt_shift<double, false, true>(t_lap" in src  # a temporary crosses lanes
+    # a chain that reaches 3 columns: no recomputing strip kernel (its fix-ups reach one lane), but the sharing one with two
+    # halo lanes; two interval blocks that use the same temporary names: one stage, no scratch
+    hyper = programs["hyperdiffusion_6th"]
+    assert [(k.vec, k.shared_vec, k.shared_halo) for k in hyper.kernels] == [(0, 2, 2)] and not hyper.plan.scratch
+    assert len(hyper.plan.stages) == 1 and len(hyper.plan.stages[0].nests) == 2
+    assert "const gt_i64 i0 = (wave_x * 60 - 2 + lane) * 2;" in hyper.source
     # nothing to share: no temporaries (Laplacian), or no horizontal offsets on them
     assert [k.shared_halo for k in programs["laplacian"].kernels] == [0]
     assert all(k.shared_halo == 0 for k in programs["vertical_advection_dycore"].kernels)

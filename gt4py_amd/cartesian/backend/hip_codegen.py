@@ -1264,6 +1264,8 @@ def _shared_nest_form(em: "_Emitter", nest: Nest, vec: int, stage_written: Set[s
             if e.name in defs:
                 if e.offset[2] != 0:
                     return None
+                if e.offset[0] != 0 and np.dtype(defs[e.name].dtype).itemsize not in (4, 8):
+                    return None  # (a boolean that crosses lanes: the DPP shifts move 4- or 8-byte values)
             elif (e.name in written or e.name not in em.global_names or e.name in em.plan.register_only
                   or tuple(em.axes.get(e.name, full)) != full):
                 return None

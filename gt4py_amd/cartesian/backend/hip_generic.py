@@ -303,7 +303,11 @@ class HipGenericStencilObject(StencilObject):
                         total = -(-total // PLACEMENT_PERIOD) * PLACEMENT_PERIOD + (len(layout) % 4) * PLACEMENT_STEP
                     layout[name] = (total, ni, nj, dt.itemsize, oi, -jlo)
                     total += nbytes
-                buf = torch.empty(total + PLACEMENT_PERIOD, dtype=torch.uint8, device="cuda")
+                # zeros, not empty: a temporary that is assigned under a condition only is read (and ignored) where the
+                # condition does not hold, and a byte that is neither 0 nor 1 read as a C++ bool is undefined behaviour
+                # the compiler builds on -- stale memory made a mask temporary of an `elif` chain produce wrong stores
+                # (found when such temporaries moved from registers to scratch).  Kernels only ever store 0 / 1 there.
+                buf = torch.zeros(total + PLACEMENT_PERIOD, dtype=torch.uint8, device="cuda")
                 # one domain at a time per stream: scratch can be gigabytes, and cached launch plans keep theirs alive
                 for old_key in [k for k in cls._gt_scratch_ if k[0] == stream]:
                     del cls._gt_scratch_[old_key]

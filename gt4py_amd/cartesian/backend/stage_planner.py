@@ -33,6 +33,11 @@ def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
     return replace(e, offset=(e.offset[0] + shift[0], e.offset[1] + shift[1], e.offset[2]))
 
 
+#: substitute temporaries that are assigned under a run-time `if` as selects (GT4MI_PLAN_INLINE_MASKED=0: keep them in
+#: memory as before)
+INLINE_MASKED = __import__("os").environ.get("GT4MI_PLAN_INLINE_MASKED", "1") != "0"
+
+
 def split_block_local_temporaries(stencil: ir.Stencil) -> ir.Stencil:
     """A temporary that several interval blocks use, each for itself -- every block that touches it assigns it (plainly:
     no mask, region or loop) before it reads it, and nobody reads it at a K offset -- is one temporary per block under one
@@ -40,6 +45,8 @@ def split_block_local_temporaries(stencil: ir.Stencil) -> ir.Stencil:
     block its own name, so that the passes below treat them as what they are (inlined or thread-local per block instead
     of one scratch array that forces a stage per statement).  Typical: the same `lap` / `flx` names in the boundary
     interval and in the interior interval of a horizontal operator."""
+    if __import__("os").environ.get("GT4MI_PLAN_SPLIT_BLOCK_LOCAL", "1") == "0":
+        return stencil
     temps = {t.name: t for t in stencil.temporaries}
     first_is_write: Dict[str, Dict[Tuple[int, int], bool]] = {}
     shared_between_blocks: Set[str] = set()
@@ -115,7 +122,10 @@ def inline_horizontal_temporaries_with_forms(stencil: ir.Stencil):
         for bi, block in enumerate(comp.blocks):
             for stmt in block.body:
                 touched.setdefault(stmt.target.name, set()).add((ci, bi))
-                if stmt.mask is not None or stmt.region is not None or stmt.loops:
+                # a run-time `if` (mask only) is a select against the value assigned before -- it can be substituted like
+                # any other definition; inside a horizontal region or a `while` the old value shows through by position
+                # or by iteration: no substitution
+                if stmt.region is not None or stmt.loops or (stmt.mask is not None and not INLINE_MASKED):
                     masked_write.add(stmt.target.name)
                 for e in ir.stmt_reads(stmt):
                     if isinstance(e, ir.FieldAccess):
@@ -182,6 +192,14 @@ def inline_horizontal_temporaries_with_forms(stencil: ir.Stencil):
                 name = stmt.target.name
                 if name in inline:
                     v = f"{name}__v{sum(1 for k in defs if k.rsplit('__v', 1)[0] == name)}"
+                    if mask is not None:
+                        # target = where(mask, value, target): a select against the version assigned so far (a temporary
+                        # that was not assigned before holds nothing defined -- the reference allocates it with
+                        # Field.empty, gtc/numpy/npir_codegen.py:104-107 --: 0 stands in)
+                        dt = np.dtype(temps[name].dtype)
+                        old = (ir.FieldAccess(version[name], (0, 0, 0), dt) if name in version
+                               else ir.Literal(False if dt == np.dtype("bool") else dt.type(0).item(), dt))
+                        value = ir.TernaryOp(mask, value, old, dt)
                     defs[v] = value
                     version[name] = v
                     order.append(("def", v))
@@ -477,17 +495,37 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
     bad_local: Set[str] = set()
     for nid, (si, nest) in enumerate(nest_list):
         defined: Set[str] = set()
+        partial: Dict[str, ir.Expr] = {}  # assigned under a condition only so far: name -> that condition
         for s in nest.stmts:
             for e in _stmt_field_reads(s):
                 if e.name in temp_names:
                     where.setdefault(e.name, set()).add(nid)
                     if e.offset != (0, 0, 0) or e.koffset is not None or e.name not in defined or nest.split_statements:
                         bad_local.add(e.name)
-            if s.target.name in temp_names:
-                where.setdefault(s.target.name, set()).add(nid)
-                defined.add(s.target.name)
+            name = s.target.name
+            if name in temp_names:
+                where.setdefault(name, set()).add(nid)
                 if s.target.offset != (0, 0, 0) or s.target.koffset is not None:
-                    bad_local.add(s.target.name)  # written at another level than the one being computed
+                    bad_local.add(name)  # written at another level than the one being computed
+                if name in defined:
+                    continue
+                # A conditional assignment keeps the old value where the condition is false: unless the nest itself
+                # assigned the name before, that is a value from an earlier nest or stage -- no thread-local register
+                # holds it.  (Found by the fuzzer: `t = a` ended up one stage before `if c: t = b` and its reader.)
+                # The two branches of one `if` / `else` together are a full assignment.
+                if s.region is not None or s.loops:
+                    bad_local.add(name)
+                elif s.mask is None:
+                    defined.add(name)
+                    partial.pop(name, None)
+                elif name in partial and s.mask == ir.UnaryOp("not", partial[name], s.mask.dtype):
+                    defined.add(name)
+                    del partial[name]
+                elif name in partial:
+                    bad_local.add(name)
+                else:
+                    partial[name] = s.mask
+        bad_local |= set(partial)  # assigned under a condition only: what it held before shows through
     bad_local |= {t.name for t in stencil.temporaries if t.data_dims}  # several values per point: not a scalar
     bad_local |= {t.name for t in stencil.temporaries if tuple(t.axes) != ("I", "J", "K")}  # 2-d: outlives the K level
     local_names = {n for n in temp_names if n in where and n not in bad_local}

@@ -366,3 +366,53 @@ def test_shared_temporaries_strip_kernel_at_every_edge(name, domain):
         "the `_vecs` kernel must be what a call with aligned, disjoint storages launches"
     for k in expect:
         np.testing.assert_array_equal(got[k], expect[k], err_msg=f"{name} {domain}: field {k}")
+
+
+@pytest.mark.parametrize("inline_masked", [False, True])
+def test_conditionally_assigned_temporaries_across_a_stage_cut(inline_masked, monkeypatch):
+    """Two planner bugs the shared-temporaries fuzzer found (seed 793 and the `elif` chain of the reference's
+    set_inner_as_kord), pinned on a small program: (1) `t = a` and, further down, `if c: t = b` with a stage cut in
+    between -- the old value shows through where c is false, so `t` is no thread-local register; (2) such temporaries
+    live in scratch memory that is read where the condition does not hold: it must not hold stale bytes (a byte that is
+    neither 0 nor 1 read as a C++ bool is undefined behaviour)."""
+    import torch
+
+    import oracle.numpy_backend  # noqa: F401
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.gtscript import PARALLEL, Field, computation, interval  # noqa: F401
+
+    def program(a: Field[np.float64], flag: Field[np.bool_], out: Field[np.float64]):  # noqa: F821
+        with computation(PARALLEL), interval(...):
+            t0 = a * 2.0
+            t2 = a[1, 0, 0] + 1.0
+            u = t0[1, 0, 0] - t0[-1, 0, 0]      # t0 is read at an offset below: a stage cut after its definition ...
+            if flag and flag[0, 1, 0]:
+                t0 = u
+            elif flag and a > 0.0:              # (an `elif`: its mask temporary is assigned under the first condition only)
+                t2 = u * 3.0                    # ... with `t2 = ...` above and this conditional update below the cut
+            else:
+                t2 = t2 - u
+            out = t2 + t0[0, 1, 0]
+
+    from gt4py_amd.cartesian.backend import stage_planner
+
+    # without the substitution of conditionally assigned temporaries `t0` stays in memory and cuts the block in stages
+    monkeypatch.setattr(stage_planner, "INLINE_MASKED", inline_masked)
+    junk = torch.full((1 << 27,), 171, dtype=torch.uint8, device="cuda")  # whatever the scratch buffer gets is stale
+    del junk
+    ref = gtscript.stencil(backend="numpy", definition=program)
+    hip = gtscript.stencil(backend="hip:mi300", definition=program, rebuild=True)
+    plan = type(hip)._gt_program_.plan
+    if inline_masked:
+        assert len(plan.stages) == 1 and sorted(plan.scratch) == ["mask_1"], (len(plan.stages), sorted(plan.scratch))
+    else:
+        assert len(plan.stages) > 1 and "t2" in plan.scratch, (len(plan.stages), sorted(plan.scratch), sorted(plan.locals))
+    domain = (70, 9, 4)
+    arrays, origins = zoo.make_inputs(ref, domain, 5)
+    expect = {k: v.copy() for k, v in arrays.items()}
+    ref(**expect, origin=origins, domain=domain)
+    dev = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=origins[k]) for k, v in arrays.items()}
+    hip(**dev, origin=origins, domain=domain)
+    for k in arrays:
+        np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=k)

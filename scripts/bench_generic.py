@@ -24,6 +24,7 @@ CASES = [
     ("laplacian", (512, 512, 512), 16, (True, False)),
     ("horizontal_diffusion", (512, 1024, 80), 24, (True, False)),
     ("horizontal_diffusion_f32", (1024, 1024, 80), 12, (True, False)),
+    ("horizontal_diffusion_if", (512, 1024, 80), 24, (False,)),  # the limiter as if / else blocks
     ("hyperdiffusion_6th", (512, 1024, 80), 16, (False,)),  # three nested Laplacians: 1 array read, 1 written
     ("tridiagonal_solver", (1024, 1024, 160), 56, (True, False)),
     ("tridiagonal_solver", (1024, 1024, 80), 56, (True, False)),

@@ -91,6 +91,25 @@ def laplacian(inp: F64, out: F64):
         out = -4.0 * inp[0, 0, 0] + inp[-1, 0, 0] + inp[1, 0, 0] + inp[0, -1, 0] + inp[0, 1, 0]
 
 
+def horizontal_diffusion_if(in_field: F64, out_field: F64, coeff: F64):
+    """The flux-limited horizontal diffusion with its limiter written as `if` / `else` blocks (the way hand-ported Fortran
+    operators are) instead of the conditional expressions of stencil_definitions.py:316-328: same values."""
+    with computation(PARALLEL), interval(...):
+        lap_field = 4.0 * in_field[0, 0, 0] - (in_field[1, 0, 0] + in_field[-1, 0, 0] + in_field[0, 1, 0] + in_field[0, -1, 0])
+        res = lap_field[1, 0, 0] - lap_field[0, 0, 0]
+        if res * (in_field[1, 0, 0] - in_field[0, 0, 0]) > 0:
+            flx_field = 0.0
+        else:
+            flx_field = res
+        res = lap_field[0, 1, 0] - lap_field[0, 0, 0]
+        if res * (in_field[0, 1, 0] - in_field[0, 0, 0]) > 0:
+            fly_field = 0.0
+        else:
+            fly_field = res
+        out_field = in_field[0, 0, 0] - coeff[0, 0, 0] * (
+            flx_field[0, 0, 0] - flx_field[-1, 0, 0] + fly_field[0, 0, 0] - fly_field[0, -1, 0])
+
+
 def hyperdiffusion_6th(inp: F64, out: F64, *, nu: float):
     """Laplacian applied three times (a sixth-order filter), with a boundary level of its own that uses the same
     temporaries: the inputs are read up to 3 points away through a chain of temporaries (two halo lanes in the strip
@@ -406,6 +425,7 @@ ZOO = {
     "horizontal_diffusion_f32": (horizontal_diffusion_f32, {}, {}, {"use_kernel_library": False}),
     "laplacian": (laplacian, {}, {}, {"use_kernel_library": False}),
     "hyperdiffusion_6th": (hyperdiffusion_6th, {}, {"nu": 0.01}, {}),
+    "horizontal_diffusion_if": (horizontal_diffusion_if, {}, {}, {}),
     "tridiagonal_solver": (tridiagonal_solver, {}, {}, {"use_kernel_library": False}),
     "vertical_advection_dycore": (vertical_advection_dycore, {"BET_M": 0.5, "BET_P": 0.5}, {"dtr_stage": 3.0 / 20.0}, {}),
     "column_sum_then_gradient": (column_sum_then_gradient, {}, {}, {}),

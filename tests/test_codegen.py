@@ -187,6 +187,9 @@ def test_stages_with_inlined_temporaries_get_a_strip_kernel_that_shares_them(pro
     assert [(k.vec, k.shared_vec, k.shared_halo) for k in hyper.kernels] == [(0, 2, 2)] and not hyper.plan.scratch
     assert len(hyper.plan.stages) == 1 and len(hyper.plan.stages[0].nests) == 2
     assert "const gt_i64 i0 = (wave_x * 60 - 2 + lane) * 2;" in hyper.source
+    # the limiter written as if / else blocks: the conditionally assigned fluxes are selects, one stage, no scratch
+    hd_if = programs["horizontal_diffusion_if"]
+    assert len(hd_if.plan.stages) == 1 and not hd_if.plan.scratch and [(k.vec, k.shared_halo) for k in hd_if.kernels] == [(2, 1)]
     # nothing to share: no temporaries (Laplacian), or no horizontal offsets on them
     assert [k.shared_halo for k in programs["laplacian"].kernels] == [0]
     assert all(k.shared_halo == 0 for k in programs["vertical_advection_dycore"].kernels)

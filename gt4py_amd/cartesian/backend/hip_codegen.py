@@ -1232,15 +1232,22 @@ def _shared_nest_form(em: "_Emitter", nest: Nest, vec: int, stage_written: Set[s
             new_defs[obj] = renamed(defs[obj])
             new_order.append(("def", obj))
         elif obj.target.name in em.global_names and obj.target.name not in em.plan.locals:
-            if obj.mask is not None or obj.region is not None or obj.loops:
+            if obj.region is not None or obj.loops:
                 return None
-            new_order.append(("stmt", _replace(obj, value=renamed(obj.value))))
+            # (a run-time `if` around an assignment to an array: stored point by point where the condition holds)
+            new_order.append(("stmt", _replace(obj, value=renamed(obj.value), mask=renamed(obj.mask) if obj.mask is not None else None)))
         else:  # a thread-local temporary
             t = obj.target
-            if obj.mask is not None or obj.region is not None or obj.loops or tuple(t.offset) != (0, 0, 0) or t.koffset is not None or t.data_index:
+            if obj.region is not None or obj.loops or tuple(t.offset) != (0, 0, 0) or t.koffset is not None or t.data_index:
                 return None
             version = f"{t.name}__w{len(new_defs)}"
-            new_defs[version] = renamed(obj.value)
+            value = renamed(obj.value)
+            if obj.mask is not None:  # where(mask, value, what it held): a select, as in the planner's substitution
+                dt = np.dtype(em.decl_dtype[t.name])
+                old = (ir.FieldAccess(current[t.name], (0, 0, 0), dt) if t.name in current
+                       else ir.Literal(False if dt == np.dtype("bool") else dt.type(0).item(), dt))
+                value = ir.TernaryOp(renamed(obj.mask), value, old, dt)
+            new_defs[version] = value
             new_order.append(("def", version))
             current[t.name] = version
     order, defs = new_order, new_defs
@@ -1251,10 +1258,10 @@ def _shared_nest_form(em: "_Emitter", nest: Nest, vec: int, stage_written: Set[s
     written = {st.target.name for st in stmts} | set(stage_written)
     for st in stmts:
         t = st.target
-        if (st.mask is not None or st.region is not None or st.loops or tuple(t.offset) != (0, 0, 0) or t.koffset is not None
+        if (st.region is not None or st.loops or tuple(t.offset) != (0, 0, 0) or t.koffset is not None
                 or t.data_index or t.name not in em.global_names or tuple(em.axes.get(t.name, full)) != full):
             return None
-    exprs = [(None, st.value) for st in stmts] + list(defs.items())
+    exprs = [(None, st.value) for st in stmts] + [(None, st.mask) for st in stmts if st.mask is not None] + list(defs.items())
     for _, expr in exprs:
         for e in ir.walk(expr):
             if not isinstance(e, ir.FieldAccess):
@@ -1287,9 +1294,15 @@ def _shared_nest_form(em: "_Emitter", nest: Nest, vec: int, stage_written: Set[s
     for kind, obj in reversed(order):
         if kind == "stmt":
             visit(obj.value, [0, 0, 0, 0])
+            if obj.mask is not None:
+                visit(obj.mask, [0, 0, 0, 0])
         elif obj in need:
             visit(defs[obj], need[obj])
-    return order, defs, need, max(-reach[0], reach[1])
+    # the halo lanes must hold every value a stored point depends on: the inputs AND the temporaries, which may sit further
+    # out than any input (t2[-1] <- t1[-1] <- t0[-1] <- in[+1]: the input two columns away, t0 three -- found by the fuzzer)
+    lo = min([reach[0]] + [n[0] for n in need.values()])
+    hi = max([reach[1]] + [n[1] for n in need.values()])
+    return order, defs, need, max(-lo, hi)
 
 
 def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: int, rows_per_lane: int, block, form):
@@ -1427,15 +1440,24 @@ def _emit_shared_nest(em: "_Emitter", si: int, stage: Stage, nest: Nest, order, 
             for obj in stmts:
                 tname = obj.target.name
                 c, ct = _c_ident(tname), _CTYPE[em.decl_dtype[tname].name]
-                vals = []
+                vals, conds = [], []
                 for v in range(vec):
                     state["row"], state["comp"] = row, v
                     vals.append(em.expr(obj.value, "k", si, {}))
+                    if obj.mask is not None:
+                        conds.append(em.expr(obj.mask, "k", si, {}))
+                sid = stmts.index(obj)
                 names = []
                 for v, val in enumerate(vals):
-                    L.append(f"        const {ct} w_{c}_{row}_{v} = {val};")
-                    names.append(f"w_{c}_{row}_{v}")
+                    L.append(f"        const {ct} w{sid}_{c}_{row}_{v} = {val};")
+                    names.append(f"w{sid}_{c}_{row}_{v}")
                 ptr = f"b_{c} + (k * a.{c}_sk + {row} * a.{c}_sj)"
+                if obj.mask is not None:  # under a run-time `if`: point by point where the condition holds
+                    L.append("        if (out_lane) {")
+                    for v in range(vec):
+                        L.append(f"          if (i0 + {v} < iend && ({conds[v]})) ({ptr})[{v}] = {names[v]};")
+                    L.append("        }")
+                    continue
                 store = (f"__builtin_nontemporal_store(gt_vec<{ct}, {vec}>{{{', '.join(names)}}}, reinterpret_cast<gt_vec<{ct}, {vec}>*>({ptr}))"
                          if tname in em.streaming else
                          f"*reinterpret_cast<gt_vec<{ct}, {vec}>*>({ptr}) = gt_vec<{ct}, {vec}>{{{', '.join(names)}}}")

@@ -28,4 +28,7 @@ for k in arrays:
     bad = (got != expect[k]) & ~(np.isnan(got) & np.isnan(expect[k]))
     where = np.argwhere(bad)
     print(f"seed {seed} {domain} {env} field {k}: {int(bad.sum())} mismatches", "" if not bad.any() else f"first at {where[0].tolist()} i in [{where[:,0].min()},{where[:,0].max()}] j in [{where[:,1].min()},{where[:,1].max()}] k in {sorted(set(where[:,2].tolist()))}")
+    if bad.any():
+        for w in where[:8]:
+            print("      at", w.tolist(), "got", got[tuple(w)], "want", expect[k][tuple(w)])
 print("   stages:", [(s.mapping, s.extent, k.vec, k.shared_vec, k.shared_halo) for s, k in zip(prog.plan.stages, prog.kernels)])

@@ -1,9 +1,10 @@
 """One program of tests/fuzz_stencils.make_shared_temporaries_stencil on the GPU against the oracle (debugging aid):
-    python scripts/fuzz_shared_one.py <seed> [ni nj nk]"""
+    python tests/debug_fuzz_shared_one.py <seed> [ni nj nk]
+(lives under tests/ because it uses the oracle as the checker)"""
 import os, sys, tempfile, pathlib, warnings
 warnings.simplefilter("ignore")
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))  # noqa: E702
 import numpy as np
 import fuzz_stencils, stencil_zoo as zoo
 import oracle.numpy_backend  # noqa: F401  (debugging script: the oracle is the checker)

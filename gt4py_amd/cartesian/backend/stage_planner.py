@@ -53,20 +53,32 @@ def split_block_local_temporaries(stencil: ir.Stencil) -> ir.Stencil:
     for ci, comp in enumerate(stencil.computations):
         for bi, block in enumerate(comp.blocks):
             seen: Set[str] = set()
+            partial: Dict[str, ir.Expr] = {}  # assigned in the first branch of an `if` so far: name -> its condition
             for stmt in block.body:
                 for e in ir.stmt_reads(stmt):
                     if isinstance(e, ir.FieldAccess) and e.name in temps:
                         if e.offset[2] != 0 or e.koffset is not None:
                             shared_between_blocks.add(e.name)
-                        if e.name not in seen:
+                        if e.name not in seen or e.name in partial:  # read before the block has assigned it everywhere
                             seen.add(e.name)
+                            partial.pop(e.name, None)
                             first_is_write.setdefault(e.name, {})[(ci, bi)] = False
                 t = stmt.target
-                if t.name in temps and t.name not in seen:
+                if t.name not in temps:
+                    continue
+                simple = (stmt.region is None and not stmt.loops and tuple(t.offset) == (0, 0, 0) and t.koffset is None
+                          and not t.data_index)
+                if t.name in partial:  # the `else` branch completes the assignment; anything else leaves it partial
+                    cond = partial.pop(t.name)
+                    complete = simple and stmt.mask is not None and stmt.mask == ir.UnaryOp("not", cond, stmt.mask.dtype)
+                    first_is_write[t.name][(ci, bi)] = complete
+                elif t.name not in seen:
                     seen.add(t.name)
-                    plain = (stmt.mask is None and stmt.region is None and not stmt.loops and tuple(t.offset) == (0, 0, 0)
-                             and t.koffset is None and not t.data_index)
-                    first_is_write.setdefault(t.name, {})[(ci, bi)] = plain
+                    if simple and stmt.mask is not None:
+                        partial[t.name] = stmt.mask  # decided by what follows
+                        first_is_write.setdefault(t.name, {})[(ci, bi)] = False
+                    else:
+                        first_is_write.setdefault(t.name, {})[(ci, bi)] = simple and stmt.mask is None
     split = {n for n, blocks in first_is_write.items()
              if len(blocks) > 1 and all(blocks.values()) and n not in shared_between_blocks and not temps[n].data_dims
              and tuple(temps[n].axes) == ("I", "J", "K")}

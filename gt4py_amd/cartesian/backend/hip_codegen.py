@@ -78,11 +78,11 @@ TUNING = {
     # neighbouring lanes with DPP shifts (waves overlap by a halo lane or two) instead of re-deriving it at every
     # offset it is read at (1), or only the recomputing form (0)
     "shared_temporaries": _env_tuple("GT4MI_CODEGEN_SHARED_TEMPORARIES", (1,))[0],
-    # J rows per lane of that kernel (0: as `vector_rows`) and its XCD-aware tile order (see xcd_rows); measured on the
-    # horizontal diffusion, fp64 / fp32 GLUPS: rows 2 / 3 / 4 / 5 / 6 / 8 = 213 / 219 / 212 / 217 / 213 / 186 and 348 / 358 /
-    # 385 / 408 / 396 / 350; XCD runs of 0 / 2 / 4 / 8 tile rows at 5 rows = 217 / 220 / 221 / 221 and 408 / 410 / 414 / 414
-    # (profiles/r2_codegen_shared_rows.log, r2_codegen_shared_xcd.log)
-    "shared_rows": _env_tuple("GT4MI_CODEGEN_SHARED_ROWS", (5,))[0],
+    # J rows per lane of that kernel (0 = by element size: 4 rows for 8-byte elements, 8 for 4-byte ones) and its XCD-aware
+    # tile order (see xcd_rows).  Measured on the horizontal diffusion with XCD runs of 4, fp64 / fp32 GLUPS: rows 4 / 5 / 6 /
+    # 7 / 8 = 226 / 221 / 218 / 212 / 219 and 386 / 390 / 403 / 410 / 424; runs of 2 / 4 / 8 tile rows differ by < 1 %, no
+    # grouping costs 2 % (profiles/r2_codegen_shared_rows_xcd.log, r2_codegen_shared_xcd.log)
+    "shared_rows": _env_tuple("GT4MI_CODEGEN_SHARED_ROWS", (0,))[0],
     "shared_xcd_rows": _env_tuple("GT4MI_CODEGEN_SHARED_XCD_ROWS", (4,))[0],
     # two-sweep column stages (stage_planner.TopCache): levels of the forward sweep's results kept in registers and,
     # below those, in LDS for the backward sweep -- (register levels, LDS bytes per workgroup, cap on the LDS levels).
@@ -1100,16 +1100,17 @@ class _Emitter:
         vec_rows, xcd_rows = _strip_shape(self, stage) if vec else (max(1, TUNING["vector_rows"]), TUNING["xcd_rows"])
         if vec:
             vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread, xcd_rows)
-        shared_halo, shared_vec, shared_fields = 0, 0, ()
+        shared_halo, shared_vec, shared_fields, shared_rows = 0, 0, (), 0
         svec = vec or (_vector_width(self, stage, any_reach=True) if j_per_thread == 1 and block[0] % 64 == 0 else 0)
         if svec:
             form = _shared_form(self, stage, svec, k_per_thread)
             if form is not None:
                 shared_vec = svec
-                shared_halo, shared_fields = _emit_shared_kernel(self, si, stage, kname, svec, TUNING["shared_rows"] or vec_rows, block, form)
+                shared_rows = int(TUNING["shared_rows"]) or (8 if svec >= 4 else 4)
+                shared_halo, shared_fields = _emit_shared_kernel(self, si, stage, kname, svec, shared_rows, block, form)
         plane = None if stage.plane is None else (stage.plane[0], stage.plane[1].value, stage.plane[2])
         return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
-                            vec_rows if vec else 1, plane, top_cache, shared_halo, (TUNING["shared_rows"] or vec_rows) if shared_halo else 0,
+                            vec_rows if vec else 1, plane, top_cache, shared_halo, shared_rows if shared_halo else 0,
                             shared_vec, shared_fields)
 
 

@@ -355,12 +355,12 @@ def test_top_of_column_cache_is_what_runs_and_does_not_spill():
                                     (300, 23, 3), (496, 5, 1), (497, 7, 2), (1000, 26, 2)])
 def test_shared_temporaries_strip_kernel_at_every_edge(name, domain):
     """Waves of the `_vecs` kernel cover 62 lanes x 2 (fp64) or 4 (fp32) columns and overlap by a halo lane on each side;
-    strips are 5 rows.  Domains on both sides of one, two and four waves in I, with whole and partial strips in J: the
+    strips are 4 (fp64) or 8 (fp32) rows.  Domains on both sides of one, two and four waves in I, with whole and partial strips in J: the
     halo lanes at the domain edge read only what the arrays hold, the last wave stores only inside the domain, the rows
     that do not fill a strip take the point-by-point path -- all bit-identical to the oracle."""
     expect, got, hip = _run_pair(name, domain, seed=sum(domain))
     kern = type(hip)._gt_program_.kernels[0]
-    assert kern.shared_halo == 1 and kern.shared_rows == 5
+    assert kern.shared_halo == 1 and kern.shared_rows == (8 if name.endswith("f32") else 4)
     # (the class may hold other flavours from earlier calls -- strided or aliased arguments --, which have no `_vecs` twin)
     assert any(v.shared_functions[0] is not None for v in type(hip)._gt_variants_.values()), \
         "the `_vecs` kernel must be what a call with aligned, disjoint storages launches"

@@ -310,6 +310,10 @@ class KernelSource:
     shared_rows: int = 0  # J rows per lane of the `_vecs` kernel
     shared_vec: int = 0  # I points per lane of the `_vecs` kernel (it may exist where no `_vec` kernel does)
     shared_fields: Tuple[str, ...] = ()  # arrays whose alignment / strides decide whether it may be launched
+    #: launch `_vecs` rather than `_vec` when both exist: yes when the shared temporaries are 8-byte values (their
+    #: arithmetic is what binds the recomputing kernel); with 4-byte temporaries recomputing is cheaper than passing
+    #: them around (all-float32 hdiff: 466 GLUPS recomputing, 441 sharing; fp64 internals: 418 and 434)
+    shared_preferred: bool = False
 
 
 @dataclass
@@ -1100,7 +1104,7 @@ class _Emitter:
         vec_rows, xcd_rows = _strip_shape(self, stage) if vec else (max(1, TUNING["vector_rows"]), TUNING["xcd_rows"])
         if vec:
             vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread, xcd_rows)
-        shared_halo, shared_vec, shared_fields, shared_rows = 0, 0, (), 0
+        shared_halo, shared_vec, shared_fields, shared_rows, shared_preferred = 0, 0, (), 0, False
         svec = vec or (_vector_width(self, stage, any_reach=True) if j_per_thread == 1 and block[0] % 64 == 0 else 0)
         if svec:
             form = _shared_form(self, stage, svec, k_per_thread)
@@ -1108,10 +1112,11 @@ class _Emitter:
                 shared_vec = svec
                 shared_rows = int(TUNING["shared_rows"]) or (8 if svec >= 4 else 4)
                 shared_halo, shared_fields = _emit_shared_kernel(self, si, stage, kname, svec, shared_rows, block, form)
+                shared_preferred = not vec or any(np.dtype(defs[v].dtype).itemsize == 8 for _, _, defs, need in form[0] for v in need)
         plane = None if stage.plane is None else (stage.plane[0], stage.plane[1].value, stage.plane[2])
         return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
                             vec_rows if vec else 1, plane, top_cache, shared_halo, shared_rows if shared_halo else 0,
-                            shared_vec, shared_fields)
+                            shared_vec, shared_fields, shared_preferred)
 
 
 def _vector_width(em: "_Emitter", stage: Stage, any_reach: bool = False) -> int:

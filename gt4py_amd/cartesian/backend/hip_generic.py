@@ -365,7 +365,7 @@ class HipGenericStencilObject(StencilObject):
                 return None
             nk = -(-levels // kern.k_per_thread) if kern.mapping == "ijk" else 1
             lanes = rows = 1
-            if sfn is not None and no_alias and all(
+            if sfn is not None and no_alias and (kern.shared_preferred or vfn is None) and all(
                     geometry[n][0] % (kern.shared_vec * geometry[n][3]) == 0 and geometry[n][1] % kern.shared_vec == 0
                     and geometry[n][2] % kern.shared_vec == 0 for n in kern.shared_fields):
                 # temporaries shared between lanes: waves overlap by the halo lanes

@@ -15,8 +15,9 @@ import os
 
 # GT4MI_FUZZ_SEEDS=<n> widens both sweeps (one-off campaigns; results under profiles/)
 _N = int(os.environ.get("GT4MI_FUZZ_SEEDS", "0"))
-CPU_SEEDS = list(range(_N or 150))
-GPU_SEEDS = list(range(_N or 200))
+_FIRST = int(os.environ.get("GT4MI_FUZZ_FIRST_SEED", "0"))  # campaigns on fresh programs: seeds _FIRST .. _FIRST + _N - 1
+CPU_SEEDS = list(range(_FIRST, _FIRST + (_N or 150)))
+GPU_SEEDS = list(range(_FIRST, _FIRST + (_N or 200)))
 DOMAINS = [(9, 7, 5), (66, 5, 4), (3, 3, 2)]
 
 
@@ -83,7 +84,7 @@ def test_generated_kernels_match_the_oracle_on_random_stencils(seed, tmp_path):
 
 
 # ---- two-sweep column programs: the top-of-column cache of the code generator (stage_planner.TopCache) -----------
-TWO_SWEEP_SEEDS = list(range(_N or 60))
+TWO_SWEEP_SEEDS = list(range(_FIRST, _FIRST + (_N or 60)))
 
 
 def _two_sweep(seed, tmp_path, backend, **opts):
@@ -154,7 +155,7 @@ def test_two_sweep_programs_match_the_oracle(seed, tmp_path):
 
 
 # ---- chains of horizontally offset temporaries: the strip kernel that shares them between lanes (`_vecs`) -----------
-SHARED_SEEDS = list(range(_N or 60))
+SHARED_SEEDS = list(range(_FIRST, _FIRST + (_N or 60)))
 
 
 def _shared(seed, tmp_path, backend, **opts):

@@ -203,3 +203,25 @@ def test_shared_temporaries_programs_match_the_oracle(seed, tmp_path):
         hip(**dev, **scalars, origin=origins, domain=domain)
         for k in arrays:
             np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"seed {seed} {domain}, field {k}\n{text}")
+
+
+@pytest.mark.parametrize("seed", SHARED_SEEDS)
+def test_shared_temporaries_rewritten_ir_matches_original_under_the_oracle(seed, tmp_path):
+    """CPU: what the planner makes of these programs -- one temporary per interval block, conditionally assigned
+    temporaries substituted as selects, everything inlined into one stage -- evaluated by the oracle against the
+    original program, every field bit for bit."""
+    import oracle.numpy_backend as oracle_backend
+    from gt4py_amd.cartesian import analysis
+
+    ref, scalars, text = _shared(seed, tmp_path, "numpy")
+    hip, _, _ = _shared(seed, tmp_path, "hip:mi300")
+    program = type(hip)._gt_program_
+    domain = (9, 7, max(3, ref.domain_info.min_sequential_axis_size))
+    arrays, origins = zoo.make_inputs(ref, domain, seed)
+    expect = {k: v.copy() for k, v in arrays.items()}
+    ref(**expect, **scalars, origin=origins, domain=domain)
+    got = {k: v.copy() for k, v in arrays.items()}
+    rewritten = program.plan.stencil
+    oracle_backend.run_stencil(rewritten, analysis.compute_extents(rewritten), domain, origins, got, scalars)
+    for k in arrays:
+        np.testing.assert_array_equal(got[k], expect[k], err_msg=f"seed {seed}, field {k}\n{text}")

@@ -38,6 +38,51 @@ def _shift_access(e: ir.FieldAccess, shift: Tuple[int, int]) -> ir.FieldAccess:
 INLINE_MASKED = __import__("os").environ.get("GT4MI_PLAN_INLINE_MASKED", "1") != "0"
 
 
+def merge_if_else_assignments(stencil: ir.Stencil) -> ir.Stencil:
+    """`if c: x = a` ... `else: x = b` arrives as two conditional assignments, `x = where(c, a, x)` and
+    `x = where(not c, b, x)`.  When nothing in between touches `x`, `c` or what `a` reads, the pair IS
+    `x = a if c else b`: one plain assignment (stored as whole vectors with streaming stores by the strip kernels, a full
+    definition for the passes below) instead of two stores point by point under a condition."""
+    if __import__("os").environ.get("GT4MI_PLAN_MERGE_IF_ELSE", "1") == "0":
+        return stencil
+    changed = False
+    new_comps = []
+    for comp in stencil.computations:
+        new_blocks = []
+        for block in comp.blocks:
+            body = list(block.body)
+            i = 0
+            while i < len(body):
+                first = body[i]
+                t = first.target
+                ok = (first.mask is not None and first.region is None and not first.loops and tuple(t.offset) == (0, 0, 0)
+                      and t.koffset is None and not t.data_index)
+                if ok:
+                    needs = {e.name for e in ir.stmt_reads(first) if isinstance(e, ir.FieldAccess)}  # of the value and of c
+                    for j in range(i + 1, len(body)):
+                        other = body[j]
+                        if other.target.name == t.name:
+                            if (other.region is None and not other.loops and other.target == t and other.mask is not None
+                                    and other.mask == ir.UnaryOp("not", first.mask, other.mask.dtype)
+                                    and not any(isinstance(e, ir.FieldAccess) and e.name == t.name for e in ir.walk(other.value))):
+                                dt = np.dtype(stencil.decl(t.name).dtype)
+                                body[j] = ir.Assign(t, ir.TernaryOp(first.mask, first.value, other.value, dt), None, other.group,
+                                                    None, ())
+                                del body[i]
+                                changed = True
+                                i -= 1
+                            break
+                        reads = {e.name for e in ir.stmt_reads(other) if isinstance(e, ir.FieldAccess)}
+                        if t.name in reads or other.target.name in needs:
+                            break
+                i += 1
+            new_blocks.append(ir.IntervalBlock(block.interval, tuple(body)))
+        new_comps.append(ir.Computation(comp.order, tuple(new_blocks)))
+    if not changed:
+        return stencil
+    return ir.Stencil(stencil.name, stencil.fields, stencil.params, stencil.temporaries, tuple(new_comps))
+
+
 def split_block_local_temporaries(stencil: ir.Stencil) -> ir.Stencil:
     """A temporary that several interval blocks use, each for itself -- every block that touches it assigns it (plainly:
     no mask, region or loop) before it reads it, and nobody reads it at a K offset -- is one temporary per block under one
@@ -121,7 +166,7 @@ def inline_horizontal_temporaries_with_forms(stencil: ir.Stencil):
     every interval block whose temporaries were inlined -- ``order`` lists ("def", version name) and ("stmt", Assign) in
     program order, ``defs`` maps a version name to its defining expression over fields and earlier versions (offsets
     as written).  The strip kernels with shared temporaries (hip_codegen) are generated from this form."""
-    stencil = split_block_local_temporaries(stencil)
+    stencil = split_block_local_temporaries(merge_if_else_assignments(stencil))
     written = {s.target.name for _, _, s in stencil.statements()}
     pure_inputs = {f.name for f in stencil.fields if f.name not in written}
     temps = {t.name: t for t in stencil.temporaries}

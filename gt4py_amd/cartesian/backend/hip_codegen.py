@@ -36,7 +36,7 @@ from __future__ import annotations
 
 import ctypes
 import hashlib
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace as _replace
 from typing import Dict, List, Optional, Sequence, Set, Tuple
 
 import numpy as np
@@ -1219,8 +1219,6 @@ def _shared_nest_form(em: "_Emitter", nest: Nest, vec: int, stage_written: Set[s
         form = ([("stmt", s) for s in nest.stmts], {})
     order, defs = form
     # temporaries of the block that were NOT inlined (read at their own point only) become versions as well
-    from dataclasses import replace as _replace
-
     current: Dict[str, str] = {}
 
     def renamed(expr: ir.Expr) -> ir.Expr:

@@ -39,11 +39,11 @@ summary = {"tag": tag}
 stats = out / "stats" / "lap_kernel_stats.csv"
 if stats.exists():
     rows = [r for r in csv.DictReader(open(stats)) if KERNEL in r["Name"]]
-    for r in sorted(rows, key=lambda r: float(r["AverageNs"]))[-1:]:  # the 512^3 instance, not the host-cost probe's
-        if True:
-            summary["kernel_stats"] = {"name": r["Name"].split("(")[0], "calls": int(r["Calls"]),
-                                       "average_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
-                                       "max_ns": float(r["MaxNs"]), "percentage": float(r["Percentage"])}
+    if rows:
+        r = max(rows, key=lambda r: float(r["AverageNs"]))  # the 512^3 instance, not the host-cost probe's
+        summary["kernel_stats"] = {"name": r["Name"].split("(")[0], "calls": int(r["Calls"]),
+                                   "average_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                   "max_ns": float(r["MaxNs"]), "percentage": float(r["Percentage"])}
 fetch, nf, fmin, fmax = counter_mean(out / "fetch" / "lap_counter_collection.csv", "FETCH_SIZE", KERNEL)
 write, nw, wmin, wmax = counter_mean(out / "write" / "lap_counter_collection.csv", "WRITE_SIZE", KERNEL)
 # calibration: a torch elementwise kernel that reads one 514x514x512 fp64 tensor (1,056,800 KiB)

@@ -252,3 +252,52 @@ def test_code_objects_are_cached_on_disk(programs, tmp_path, monkeypatch):
     monkeypatch.setenv("GT4PY_AMD_CACHE_DIR", "")
     hip_generic._compile_cached(prog.source, "copy.hip", [])
     assert len(calls) == 3  # caching switched off: compiled again
+
+
+# ---- the planner's rewriting passes on programs written for them (tests/planner_cases/programs.py) -------------------
+def _planned(defn):
+    obj = gtscript.stencil(backend="hip:mi300", definition=defn)
+    return obj, type(obj)._gt_program_.plan
+
+
+def _statements(plan):
+    return [(s.target.name, s.mask is not None) for c in plan.stencil.computations for b in c.blocks for s in b.body]
+
+
+def _rewrite_matches_the_original(defn, domain=(7, 6, 4)):
+    ref = gtscript.stencil(backend="numpy", definition=defn)
+    _, plan = _planned(defn)
+    arrays, origins = zoo.make_inputs(ref, domain, 3)
+    expect = {k: v.copy() for k, v in arrays.items()}
+    ref(**expect, origin=origins, domain=domain)
+    got = {k: v.copy() for k, v in arrays.items()}
+    oracle_backend.run_stencil(plan.stencil, analysis.compute_extents(plan.stencil), domain, origins, got, {})
+    for k in arrays:
+        np.testing.assert_array_equal(got[k], expect[k], err_msg=k)
+
+
+def test_temporaries_that_blocks_use_each_for_itself_are_split_per_block():
+    from planner_cases import programs as P
+
+    _, plan = _planned(P.boundary_and_interior)
+    names = [n for n, _ in _statements(plan)]
+    assert len(plan.stages) == 1 and not plan.scratch  # one kernel, nothing through memory
+    assert any(n.startswith("lap__b0_0") for n in names) and any(n.startswith("lap__b0_1") for n in names), names
+    _rewrite_matches_the_original(P.boundary_and_interior)
+    # a value that does flow from one block into another stays one temporary, in memory, with a stage cut
+    _, plan = _planned(P.value_crosses_blocks)
+    assert sorted(plan.scratch) == ["t"] and len(plan.stages) == 2
+    _rewrite_matches_the_original(P.value_crosses_blocks)
+
+
+def test_if_else_pairs_become_one_conditional_expression_unless_something_interferes():
+    from planner_cases import programs as P
+
+    _, plan = _planned(P.if_else_pair)
+    # `out` assigned by both branches: one plain statement; `other` by one branch only: still conditional
+    assert _statements(plan) == [("mask_0", False), ("other", True), ("out", False)]
+    _rewrite_matches_the_original(P.if_else_pair)
+    _, plan = _planned(P.if_else_with_interference)
+    # the else branch of `out` reads the `t` the if branch assigned in between, and vice versa: nothing may be merged
+    assert _statements(plan) == [("t", False), ("mask_0", False), ("out", True), ("t", True), ("out", True), ("t", True)]
+    _rewrite_matches_the_original(P.if_else_with_interference)

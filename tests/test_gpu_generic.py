@@ -416,3 +416,25 @@ def test_conditionally_assigned_temporaries_across_a_stage_cut(inline_masked, mo
     hip(**dev, origin=origins, domain=domain)
     for k in arrays:
         np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["boundary_and_interior", "value_crosses_blocks", "if_else_pair", "if_else_with_interference"])
+@pytest.mark.parametrize("domain", [(130, 11, 3), (5, 4, 2)])
+def test_planner_case_programs_on_the_device(name, domain):
+    """The programs written for the planner's rewriting passes (tests/planner_cases/programs.py; their plans are pinned in
+    tests/test_codegen.py) run on the device: every field bit for bit against the oracle."""
+    import oracle.numpy_backend  # noqa: F401
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from planner_cases import programs as P
+
+    defn = getattr(P, name)
+    ref = gtscript.stencil(backend="numpy", definition=defn)
+    hip = gtscript.stencil(backend="hip:mi300", definition=defn)
+    arrays, origins = zoo.make_inputs(ref, domain, 17)
+    expect = {k: v.copy() for k, v in arrays.items()}
+    ref(**expect, origin=origins, domain=domain)
+    dev = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=origins[k]) for k, v in arrays.items()}
+    hip(**dev, origin=origins, domain=domain)
+    for k in arrays:
+        np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"{name} {domain}: field {k}")

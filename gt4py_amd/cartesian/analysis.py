@@ -113,18 +113,30 @@ def compute_access_kinds(stencil: ir.Stencil) -> Dict[str, AccessKind]:
     return access
 
 
+class TemporaryReadOutsideDomain(NotImplementedError):
+    """A temporary is read beyond the K range of the domain from a vertical loop other than the one that declares it.
+
+    The reference's GTIR accepts this (gtir_k_boundary.py:64-67 checks only temporaries declared in the current vertical
+    loop) and its numpy backend then fails at run time on the slice; here scratch arrays hold exactly the domain's
+    levels, so the stencil is refused at build time -- a divergence from the reference, hence not its ``TypeError``."""
+
+
 def compute_k_boundary(stencil: ir.Stencil) -> Dict[str, Tuple[int, int]]:
     """K boundary per field; ``TypeError`` for a temporary accessed outside the K range it exists on.
 
-    gtir_k_boundary.py:39-70 raises for the interval block that declares the temporary (= first assigns it,
-    defir_to_gtir.py:433-451).  A temporary read beyond the domain from a LATER block is not caught there but
-    fails in the numpy backend at run time (temporaries hold exactly ``_dK_`` levels, npir_codegen.py:88-104);
-    here scratch arrays hold exactly the domain's levels too, so that form is rejected with the same message
-    instead of reading outside the buffer."""
+    gtir_k_boundary.py:39-70 raises for the vertical loop that declares the temporary (= first assigns it,
+    defir_to_gtir.py:433-451): the reference's ``TypeError`` and message.  A temporary read beyond the domain from a
+    LATER loop is not caught there but fails in the numpy backend at run time (temporaries hold exactly ``_dK_``
+    levels, npir_codegen.py:88-104); scratch arrays here hold exactly the domain's levels too, so that form is
+    rejected as well, with ``TemporaryReadOutsideDomain`` (not the reference's error, because the
+    reference accepts the program)."""
     neg_inf = float("-inf")
     bounds: Dict[str, Tuple[float, float]] = {d.name: (neg_inf, neg_inf) for d in (*stencil.fields, *stencil.temporaries)}
     temporaries = {t.name for t in stencil.temporaries}
-    for _, block, stmt in stencil.statements():
+    declared_in: Dict[str, int] = {}  # temporary -> id of the vertical loop (computation) that first assigns it
+    for comp, block, stmt in stencil.statements():
+        if stmt.target.name in temporaries:
+            declared_in.setdefault(stmt.target.name, id(comp))
         accesses = [stmt.target] + [e for e in ir.stmt_reads(stmt) if isinstance(e, ir.FieldAccess)]
         for acc in accesses:
             lo, hi = bounds[acc.name]
@@ -134,7 +146,12 @@ def compute_k_boundary(stencil: ir.Stencil) -> Dict[str, Tuple[int, int]]:
                 if block.interval.end.level is ir.Level.END:
                     hi = max(block.interval.end.offset + acc.offset[2], hi)
             if acc.name in temporaries and (lo > 0 or hi > 0):
-                raise TypeError(f"Invalid access with offset in k to temporary field {acc.name}.")
+                if declared_in.get(acc.name, id(comp)) == id(comp):
+                    raise TypeError(f"Invalid access with offset in k to temporary field {acc.name}.")
+                raise TemporaryReadOutsideDomain(
+                    f"temporary field {acc.name} is read beyond the K range of the domain from a later vertical loop: the "
+                    f"reference accepts this at build time (gtir_k_boundary.py:64-67) and fails in its numpy backend at run "
+                    f"time; backend temporaries here hold exactly the domain's levels")
             bounds[acc.name] = (lo, hi)
     return {n: (int(lo) if lo != neg_inf else 0, int(hi) if hi != neg_inf else 0) for n, (lo, hi) in bounds.items()}
 

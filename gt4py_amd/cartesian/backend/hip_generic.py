@@ -119,6 +119,10 @@ class _Variant:
             self.tc_functions.append(tfns)
 
 
+#: scratch buffers (and the launch plans that point into them) are kept for this many HIP streams per stencil
+MAX_SCRATCH_STREAMS = 4
+
+
 def _ranges_disjoint(ranges: List[Tuple[int, int]]) -> bool:
     ranges = sorted(ranges)
     return all(ranges[n][1] <= ranges[n + 1][0] for n in range(len(ranges) - 1))
@@ -144,7 +148,52 @@ def _access_profile(plan):
     return cached
 
 
-def _check_aliases(plan, names: List[str], spans: List[Tuple[int, int]], views) -> bool:
+def elements_disjoint(ptr_a: int, shape_a, ptr_b: int, shape_b, strides, itemsize: int) -> bool:
+    """True when two arrays with the SAME byte strides provably share no element although their byte ranges overlap:
+    interleaved slices of one buffer (``vel[..., 0]`` / ``vel[..., 1]``), the J halves of an I-contiguous parent.
+    An element of ``a`` at index x is an element of ``b`` at index y iff ``sum (x - y) * stride == ptr_b - ptr_a``; with
+    nested strides (each larger than everything the smaller ones can add up to) the differences are solved axis by axis
+    from the largest stride down.  False = could not be shown (the caller treats the arrays as overlapping).  The same
+    rule guards the kernel library's entry points (csrc/common.hip.h: elements_disjoint)."""
+    if len(shape_a) != len(shape_b) or len(shape_a) != len(strides):
+        return False
+    delta = ptr_b - ptr_a
+    axes = []  # (|stride|, lowest n, highest n) with n = x - y (sign folded into the bounds)
+    for na, nb, st in zip(shape_a, shape_b, strides):
+        if na <= 0 or nb <= 0:
+            return True  # an empty array has no elements
+        lo, hi = -(nb - 1), na - 1
+        if st < 0:
+            st, lo, hi = -st, -hi, -lo
+        if st == 0:
+            if lo or hi:
+                return False
+            continue
+        axes.append((st, lo, hi))
+    axes.sort()
+    below, acc = [], 0
+    for r, (st, lo, hi) in enumerate(axes):
+        if r and st <= acc:
+            return False  # strides not nested
+        below.append(acc)
+        acc += max(hi, -lo) * st
+    if delta % itemsize or any(st % itemsize for st, _, _ in axes):
+        return False  # elements could straddle each other
+
+    def hit(r: int, rest: int) -> bool:
+        if r < 0:
+            return rest == 0
+        st, lo, hi = axes[r]
+        q = rest // st
+        for n in (q, q + 1):
+            if lo <= n <= hi and abs(rest - n * st) <= below[r] and hit(r - 1, rest - n * st):
+                return True
+        return False
+
+    return not hit(len(axes) - 1, delta)
+
+
+def _check_aliases(plan, names: List[str], spans: List[Tuple[int, int]], views, boxes=None) -> bool:
     """Arguments whose memory overlaps.  The reference's numpy backend evaluates a right-hand side completely before it
     assigns (npir_codegen.py:205-210), so a call like ``stencil(a, a)`` is well defined there.  The kernels here read
     and write concurrently and keep values in registers by NAME, so only what cannot depend on the order of evaluation
@@ -164,6 +213,9 @@ def _check_aliases(plan, names: List[str], spans: List[Tuple[int, int]], views) 
             involved = True
             w, x = (na, nb) if na in written else (nb, na)
             if views[na] != views[nb]:
+                if boxes is not None and boxes[na][2:] == boxes[nb][2:] and elements_disjoint(
+                        boxes[na][0], boxes[na][1], boxes[nb][0], boxes[nb][1], boxes[na][2], boxes[na][3]):
+                    continue  # element-disjoint views of one buffer: the variant without __restrict__ runs them
                 raise ValueError(f"fields '{na}' and '{nb}' overlap in memory without being the same elements, and the "
                                  f"stencil writes '{w}': the result would depend on the order of evaluation")
             if x in written or w in shifted or x in shifted:
@@ -259,6 +311,7 @@ class HipGenericStencilObject(StencilObject):
         spans: List[Tuple[int, int]] = []
         views: Dict[str, Tuple[int, Tuple[int, ...], int]] = {}  # name -> (origin pointer, byte strides, itemsize)
         geometry: Dict[str, Tuple[int, int, int, int]] = {}  # name -> (origin pointer, sj, sk, itemsize)
+        boxes: Dict[str, Tuple[int, Tuple[int, ...], Tuple[int, ...], int]] = {}  # name -> (base pointer, shape, byte strides, itemsize)
         for decl in plan.api_fields:
             arr = arguments[decl.name]
             c = hip_codegen._c_ident(decl.name)
@@ -280,6 +333,7 @@ class HipGenericStencilObject(StencilObject):
             lo = sum((n - 1) * s for n, s in zip(arr.shape, arr.strides) if s < 0)
             spans.append((arr.ptr + lo, arr.ptr + hi))
             views[decl.name] = (ptr, tuple(arr.strides), isz)
+            boxes[decl.name] = (arr.ptr, tuple(arr.shape), tuple(arr.strides), isz)
         if plan.scratch:
             # One scratch buffer per (stream, domain): two calls of the stencil enqueued on different HIP streams run
             # concurrently and must not write each other's temporaries.  The buffer is allocated while `stream` is
@@ -313,6 +367,14 @@ class HipGenericStencilObject(StencilObject):
                     del cls._gt_scratch_[old_key]
                 for old_key in [k for k in cls._gt_launch_cache_ if k[0] == stream]:
                     del cls._gt_launch_cache_[old_key]
+                # ... and a bounded number of streams (least recently created first): buffers made for short-lived
+                # streams would otherwise never be released, and a recycled stream handle must not find a buffer the
+                # caching allocator ordered on the stream that had the handle before
+                streams = list(dict.fromkeys(k[0] for k in cls._gt_scratch_))
+                for old_stream in streams[:max(0, len(streams) - (MAX_SCRATCH_STREAMS - 1))]:
+                    for cache in (cls._gt_scratch_, cls._gt_launch_cache_):
+                        for old_key in [k for k in cache if k[0] == old_stream]:
+                            del cache[old_key]
                 entry = cls._gt_scratch_[key] = (buf, layout)
             buf, layout = entry
             base = -(-buf.data_ptr() // PLACEMENT_PERIOD) * PLACEMENT_PERIOD
@@ -335,7 +397,7 @@ class HipGenericStencilObject(StencilObject):
         args.dI, args.dJ, args.dK = dI, dJ, dK
         args.k_lo, args.k_hi = 0, dK
 
-        no_alias = _ranges_disjoint(spans) or _check_aliases(plan, [d.name for d in plan.api_fields], spans, views)
+        no_alias = _ranges_disjoint(spans) or _check_aliases(plan, [d.name for d in plan.api_fields], spans, views, boxes)
         vkey = (unit_i, no_alias)
         variant = cls._gt_variants_.get(vkey)
         if variant is None:

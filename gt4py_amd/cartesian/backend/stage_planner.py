@@ -109,6 +109,11 @@ def split_block_local_temporaries(stencil: ir.Stencil) -> ir.Stencil:
                             partial.pop(e.name, None)
                             first_is_write.setdefault(e.name, {})[(ci, bi)] = False
                 t = stmt.target
+                # a statement between the two branches that writes what the condition reads: `not c` is no longer the
+                # complement of the `c` the first branch saw (merge_if_else_assignments checks the same through `needs`)
+                for name in [n for n, c in partial.items() if n != t.name
+                             and any(isinstance(e, ir.FieldAccess) and e.name == t.name for e in ir.walk(c))]:
+                    del partial[name]  # first_is_write stays False
                 if t.name not in temps:
                     continue
                 simple = (stmt.region is None and not stmt.loops and tuple(t.offset) == (0, 0, 0) and t.koffset is None
@@ -560,6 +565,12 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                     if e.offset != (0, 0, 0) or e.koffset is not None or e.name not in defined or nest.split_statements:
                         bad_local.add(e.name)
             name = s.target.name
+            # written between the two branches and read by the condition: `not c` no longer complements the `c` the first
+            # branch saw, the pair is not a full assignment
+            for other in [n for n, c in partial.items() if n != name
+                          and any(isinstance(e, ir.FieldAccess) and e.name == name for e in ir.walk(c))]:
+                bad_local.add(other)
+                del partial[other]
             if name in temp_names:
                 where.setdefault(name, set()).add(nid)
                 if s.target.offset != (0, 0, 0) or s.target.koffset is not None:
@@ -694,6 +705,30 @@ def plan_stages(stencil_in: ir.Stencil) -> Plan:
                 api_fields, params, top_cache, shared_forms)
 
 
+def _end_relative(iv: ir.Interval) -> Optional[Tuple[Optional[int], int]]:
+    """The part of ``iv`` that can overlap the levels counted from the END of the column: (first, one past the last) as
+    offsets <= 0 from END, first = None when the interval starts at a START-relative level (below all of them); None when
+    the interval ends at a START-relative level."""
+    if iv.end.level is not ir.Level.END:
+        return None
+    return (iv.start.offset if iv.start.level is ir.Level.END else None), iv.end.offset
+
+
+def _levels_covered(reads, writes) -> bool:
+    """True when every END-relative level of ``reads`` lies in one of ``writes`` (ranges of ``_end_relative``)."""
+    finite = [b for r in (*reads, *writes) for b in r if b is not None]
+    if not finite:
+        return True
+    floor = min(finite) - 1  # stands for every level below the lowest END-relative bound
+
+    def levels(rng):
+        lo, hi = rng
+        return range(floor if lo is None else lo, hi)
+
+    covered = {k for w in writes for k in levels(w)}
+    return all(k in covered for r in reads for k in levels(r))
+
+
 def _plan_top_cache(stencil: ir.Stencil, stages: List[Stage], scratch, forwarded, prime, local_names, register_only,
                     touched_in) -> Dict[int, TopCache]:
     """Which fields of which column stages qualify for ``TopCache`` (see there)."""
@@ -730,6 +765,17 @@ def _plan_top_cache(stencil: ir.Stencil, stages: List[Stage], scratch, forwarded
                 continue
             ok = True
             read_back = False
+            # Every cached level must be WRITTEN by the first sweep: the second sweep reads the cache, not memory.  The
+            # cached levels lie above every START-relative interval bound (`margin` below), so exactly the first-sweep
+            # nests whose interval has an END-relative bound can cover them: every END-relative level the second sweep
+            # reads must lie in such a nest that assigns the field (the loop below rejects conditional / displaced
+            # assignments).  A field written at the first level only and read back on all of them keeps its caller's
+            # values above that level: not cacheable.
+            written_levels = [_end_relative(n.interval) for n in first if any(st.target.name == name for st in n.stmts)]
+            read_levels = [_end_relative(n.interval) for n in second
+                           if any(e.name == name for st in n.stmts for e in _stmt_field_reads(st))]
+            if not _levels_covered([r for r in read_levels if r], [w for w in written_levels if w]):
+                ok = False
             for ni, nest in enumerate(stage.nests):
                 for st in nest.stmts:
                     if st.target.name == name and (st.target.offset != (0, 0, 0) or st.target.koffset is not None

@@ -104,6 +104,70 @@ inline ByteSpan span_of(const V& v, const int64_t domain[3], const int halo_lo[3
 
 inline bool spans_overlap(const ByteSpan& a, const ByteSpan& b) { return a.lo < b.hi && b.lo < a.hi; }
 
+// Two views whose byte ranges overlap may still touch disjoint ELEMENTS: interleaved slices of one buffer
+// (vel[..., 0] / vel[..., 1]), the J halves of an I-contiguous parent.  Provable when both views have the same strides and
+// those strides are nested (each larger than everything the smaller axes can add up to): an element of `a` at index x
+// coincides with an element of `b` at index y iff  sum_axis (x - y) * stride == b.p - a.p, and with nested strides the
+// differences n = x - y can be solved axis by axis from the largest stride down (two candidates per axis).
+// Returns true only when NO pair of touched elements can coincide; false = cannot be shown (treat as overlapping).
+template <typename VA, typename VB>
+inline bool elements_disjoint(const VA& a, const int alo[3], const int ahi[3], const VB& b, const int blo[3], const int bhi[3],
+                              const int64_t domain[3]) {
+    if (sizeof(*a.p) != sizeof(*b.p) || a.si != b.si || a.sj != b.sj || a.sk != b.sk) return false;
+    const int64_t bytes = (int64_t)(reinterpret_cast<uintptr_t>(b.p) - reinterpret_cast<uintptr_t>(a.p));
+    if (bytes % (int64_t)sizeof(*a.p) != 0) return false;  // elements straddle each other
+    const int64_t delta = bytes / (int64_t)sizeof(*a.p);
+    int64_t s[3] = {a.si, a.sj, a.sk}, nlo[3], nhi[3];
+    for (int x = 0; x < 3; ++x) {
+        // x in [-alo, d-1+ahi], y in [-blo, d-1+bhi]  =>  n = x - y in [nlo, nhi]
+        nlo[x] = -(int64_t)alo[x] - (domain[x] - 1 + bhi[x]);
+        nhi[x] = domain[x] - 1 + ahi[x] + (int64_t)blo[x];
+        if (s[x] < 0) { s[x] = -s[x]; const int64_t t = nlo[x]; nlo[x] = -nhi[x]; nhi[x] = -t; }
+        if (s[x] == 0 && (nlo[x] != 0 || nhi[x] != 0)) return false;  // a broadcast axis: many indices, one element
+    }
+    int order[3] = {0, 1, 2};  // ascending stride
+    for (int x = 0; x < 3; ++x)
+        for (int y = x + 1; y < 3; ++y)
+            if (s[order[y]] < s[order[x]]) { const int t = order[x]; order[x] = order[y]; order[y] = t; }
+    int64_t below[3];  // what the axes with smaller strides can contribute at most (absolute value)
+    int64_t acc = 0;
+    for (int r = 0; r < 3; ++r) {
+        const int x = order[r];
+        below[r] = acc;
+        if (r > 0 && s[x] != 0 && s[x] <= acc) return false;  // strides not nested: no unique decomposition
+        const int64_t m = nhi[x] > -nlo[x] ? nhi[x] : -nlo[x];
+        acc += m * s[x];
+    }
+    // depth-first over (at most) two candidates per axis, largest stride first
+    struct Solver {
+        const int64_t *s, *nlo, *nhi, *below;
+        const int* order;
+        bool hit(int r, int64_t rest) const {
+            if (r < 0) return rest == 0;
+            const int x = order[r];
+            if (s[x] == 0) return hit(r - 1, rest);
+            int64_t q = rest / s[x];
+            if (rest % s[x] != 0 && rest < 0) --q;  // floor
+            for (int64_t n = q; n <= q + 1; ++n) {
+                if (n < nlo[x] || n > nhi[x]) continue;
+                const int64_t left = rest - n * s[x];
+                if ((left < 0 ? -left : left) > below[r]) continue;
+                if (hit(r - 1, left)) return true;
+            }
+            return false;
+        }
+    } solver{s, nlo, nhi, below, order};
+    return !solver.hit(2, delta);
+}
+
+// the views' touched elements (compute domain grown by the halos) may coincide somewhere
+template <typename VA, typename VB>
+inline bool views_overlap(const VA& a, const int alo[3], const int ahi[3], const VB& b, const int blo[3], const int bhi[3],
+                          const int64_t domain[3]) {
+    if (!spans_overlap(span_of(a, domain, alo, ahi), span_of(b, domain, blo, bhi))) return false;
+    return !elements_disjoint(a, alo, ahi, b, blo, bhi, domain);
+}
+
 // the same elements, one to one (same origin element, same strides)
 template <typename V1, typename V2>
 inline bool same_view(const V1& a, const V2& b) {

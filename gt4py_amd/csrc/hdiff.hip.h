@@ -151,14 +151,13 @@ inline int hdiff_run(const int64_t domain[3], const gt4mi_field* in_field,
     if (coeff != nullptr)
         if (int rc = make_view<T>("coeff", coeff, domain, h0, h0, &cf_v)) return rc;
     if (domain[0] == 0 || domain[1] == 0 || domain[2] == 0) return GT4MI_OK;
-    const ByteSpan out_span = span_of(out_v, domain, h0, h0);
-    if (spans_overlap(span_of(in_v, domain, h2, h2), out_span))
+    if (views_overlap(in_v, h2, h2, out_v, h0, h0, domain))
         return fail(GT4MI_ERR_UNSUPPORTED,
                     "hdiff: 'in_field' and 'out_field' overlap in memory; every point reads its neighbours' OLD values "
                     "(the reference evaluates the right-hand side before it assigns), which an in-place kernel cannot "
                     "provide -- pass a separate output array");
     bool alias = false;  // out_field IS coeff: a point's coefficient is read before that point is written
-    if (coeff != nullptr && spans_overlap(span_of(cf_v, domain, h0, h0), out_span)) {
+    if (coeff != nullptr && views_overlap(cf_v, h0, h0, out_v, h0, h0, domain)) {
         if (!same_view(cf_v, out_v))
             return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: 'coeff' and 'out_field' overlap in memory without being the same elements");
         alias = true;

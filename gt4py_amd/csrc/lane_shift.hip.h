@@ -4,24 +4,18 @@
 // v_mov_b32_dpp per dword with no LDS traffic.  With bound_ctrl lanes shifted in from outside the wave read 0
 // and the compiler needs no `v_mov_b32 dst, 0` in front of every shift (50 of 1434 vector instructions of the
 // f32 horizontal-diffusion kernel; callers overwrite the edge lanes).  Verified on MI355X by `microbench dpp`.
-// Define GT4MI_NO_DPP to fall back to ds_bpermute (`__shfl_up/down`).
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 namespace gt4mi {
 
-#ifndef GT4MI_NO_DPP
 __device__ __forceinline__ int lane_from_prev(int v) {  // lane l receives lane l-1
     return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
 }
 __device__ __forceinline__ int lane_from_next(int v) {  // lane l receives lane l+1
     return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
 }
-#else
-__device__ __forceinline__ int lane_from_prev(int v) { return __shfl_up(v, 1); }
-__device__ __forceinline__ int lane_from_next(int v) { return __shfl_down(v, 1); }
-#endif
 
 template <typename X, bool FROM_PREV>
 __device__ __forceinline__ X lane_shift(X v) {

@@ -211,7 +211,7 @@ inline int lap5_run(const int64_t domain[3], const gt4mi_field* inp, const gt4mi
     if (int rc = make_view<T>("inp", inp, domain, h1, h1, &in_v)) return rc;
     if (int rc = make_view<T>("out", outf, domain, h0, h0, &out_v)) return rc;
     if (domain[0] == 0 || domain[1] == 0 || domain[2] == 0) return GT4MI_OK;
-    if (spans_overlap(span_of(in_v, domain, h1, h1), span_of(out_v, domain, h0, h0)))
+    if (views_overlap(in_v, h1, h1, out_v, h0, h0, domain))
         return fail(GT4MI_ERR_UNSUPPORTED,
                     "lap5: 'inp' and 'out' overlap in memory; every point reads its neighbours' OLD values (the "
                     "reference evaluates the right-hand side before it assigns), which an in-place kernel cannot "
@@ -254,7 +254,7 @@ inline int lap5_run_rows(const int64_t domain[3], const gt4mi_field* inp, const 
     View<T> in_v, out_v;
     if (int rc = make_view<T>("inp", inp, domain, h1, h1, &in_v)) return rc;
     if (int rc = make_view<T>("out", outf, domain, h0, h0, &out_v)) return rc;
-    if (spans_overlap(span_of(in_v, domain, h1, h1), span_of(out_v, domain, h0, h0)))
+    if (views_overlap(in_v, h1, h1, out_v, h0, h0, domain))
         return fail(GT4MI_ERR_UNSUPPORTED, "lap5: 'inp' and 'out' overlap in memory (see gt4mi_lap5_*)");
     View<const T> in_c{in_v.p, in_v.si, in_v.sj, in_v.sk};
     bool done = false;

@@ -219,12 +219,11 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
     {
         const View<T>* views[5] = {&a, &d, &s, &r, &o};
         const char* names[5] = {"inf", "diag", "sup", "rhs", "out"};
-        ByteSpan spans[5];
-        for (int f = 0; f < 5; ++f) spans[f] = span_of(*views[f], domain, h0, h0);
         for (int w = 2; w < 5; ++w)          // written fields: sup, rhs, out
             for (int x = 0; x < 5; ++x) {
                 if (x == w || (x > w && x >= 2)) continue;  // written/written pairs once
-                if (!spans_overlap(spans[w], spans[x])) continue;
+                // (element-disjoint views of one buffer -- interleaved slices, halves -- are not an overlap)
+                if (!views_overlap(*views[w], h0, h0, *views[x], h0, h0, domain)) continue;
                 if (w == 4 && same_view(*views[w], *views[x])) {
                     alias = true;
                     continue;

@@ -2,7 +2,7 @@
 frontend reads a definition's source."""
 import numpy as np
 
-from gt4py_amd.cartesian.gtscript import PARALLEL, Field, computation, interval  # noqa: F401
+from gt4py_amd.cartesian.gtscript import BACKWARD, FORWARD, PARALLEL, Field, computation, interval  # noqa: F401
 
 F64 = Field[np.float64]
 
@@ -50,3 +50,33 @@ def if_else_with_interference(a: F64, b: F64, out: F64):
         else:
             out = t + 1.0
             t = a
+
+
+def boundary_only_write_read_back(inp: F64, acc: F64, s: F64, out: F64):
+    """`acc` is assigned at the first level only and read back by the second sweep on ALL levels: above the first level
+    the second sweep must see the caller's `acc`, so it cannot live in the on-chip top-of-column cache (only `s`, which
+    every level of the first sweep assigns, can)."""
+    with computation(FORWARD):
+        with interval(0, 1):
+            acc = inp
+            s = inp
+        with interval(1, None):
+            s = s[0, 0, -1] + inp
+    with computation(BACKWARD):
+        with interval(-1, None):
+            out = acc + s
+        with interval(0, -1):
+            out = out[0, 0, 1] + acc * s
+
+
+def condition_input_rewritten_between_branches(a: F64, f: F64, t0: F64, out: F64):
+    """`not (f > 0)` is evaluated AFTER `f` changed sign: the two conditional assignments of `t` are not the branches of one
+    `if` / `else`, where neither holds `t` keeps the value of the first statement."""
+    with computation(PARALLEL), interval(...):
+        t = t0
+        if f > 0.0:
+            t = a
+        f = -f
+        if not (f > 0.0):
+            t = a * 2.0
+        out = t

@@ -301,3 +301,52 @@ def test_if_else_pairs_become_one_conditional_expression_unless_something_interf
     # the else branch of `out` reads the `t` the if branch assigned in between, and vice versa: nothing may be merged
     assert _statements(plan) == [("t", False), ("mask_0", False), ("out", True), ("t", True), ("out", True), ("t", True)]
     _rewrite_matches_the_original(P.if_else_with_interference)
+    # a statement between two conditional assignments rewrites what the condition reads
+    _rewrite_matches_the_original(P.condition_input_rewritten_between_branches)
+
+
+def test_top_of_column_cache_only_takes_fields_every_level_of_the_first_sweep_assigns():
+    """a field the FORWARD sweep assigns at the boundary level only and the BACKWARD sweep reads on
+    every level keeps the caller's values above that level -- the second sweep must read memory, not an on-chip cache that
+    nobody filled."""
+    from planner_cases import programs as P
+
+    _, plan = _planned(P.boundary_only_write_read_back)
+    assert [tc.names for tc in plan.top_cache.values()] == [("s",)]
+    _rewrite_matches_the_original(P.boundary_only_write_read_back, domain=(5, 4, 9))
+
+
+
+def test_elements_disjoint_never_claims_more_than_brute_force():
+    """hip_generic.elements_disjoint (and its C++ twin in csrc/common.hip.h) against the address sets of random slices of
+    one parent array: a claim of disjointness must always be true; the interleaved and the halves cases must be proven."""
+    from gt4py_amd.cartesian.backend.hip_generic import elements_disjoint
+
+    rng = np.random.default_rng(0)
+
+    def addresses(v):
+        idx = np.indices(v.shape).reshape(v.ndim, -1)
+        return set((v.__array_interface__["data"][0] + (idx * np.array(v.strides)[:, None]).sum(0)).tolist())
+
+    claims = 0
+    for _ in range(400):
+        shape = rng.integers(2, 6, size=4)
+        parent = np.zeros(shape, order=str(rng.choice(["C", "F"])))
+
+        def view():
+            sl = []
+            for n in shape[:3]:
+                a = int(rng.integers(0, n))
+                sl.append(slice(a, int(rng.integers(a + 1, n + 1))))
+            return parent[tuple(sl) + (int(rng.integers(0, shape[3])),)]
+
+        a, b = view(), view()
+        got = elements_disjoint(a.__array_interface__["data"][0], a.shape, b.__array_interface__["data"][0], b.shape, a.strides, 8)
+        if got:
+            claims += 1
+            assert not (addresses(a) & addresses(b))
+    assert claims > 100
+    vel = np.zeros((6, 5, 4, 2))
+    p0, p1 = (vel[..., n].__array_interface__["data"][0] for n in (0, 1))
+    assert elements_disjoint(p0, (6, 5, 4), p1, (6, 5, 4), vel[..., 0].strides, 8)
+    assert not elements_disjoint(p0, (6, 5, 4), p0 + vel.strides[1], (6, 5, 4), vel[..., 0].strides, 8)  # shifted by one row

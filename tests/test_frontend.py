@@ -414,7 +414,8 @@ def test_temporary_k_offsets_across_and_inside_loops():
 
     # not caught at build time by the reference; its numpy backend then fails on the slice (temporaries hold
     # exactly _dK_ levels).  Rejected here, so that no kernel reads outside its scratch buffer.
-    with pytest.raises(TypeError, match="Invalid access with offset in k to temporary field tmp."):
+    # (a distinct error, not the reference's TypeError: the reference's GTIR accepts the program)
+    with pytest.raises(analysis.TemporaryReadOutsideDomain, match="temporary field tmp is read beyond the K range"):
         analysis.compute_k_boundary(parse(beyond_the_domain_from_a_later_loop))
 
     def in_bounds_inside_the_declaring_loop(inp: Field[np.float64], out: Field[np.float64]):

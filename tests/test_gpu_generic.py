@@ -418,7 +418,8 @@ def test_conditionally_assigned_temporaries_across_a_stage_cut(inline_masked, mo
         np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["boundary_and_interior", "value_crosses_blocks", "if_else_pair", "if_else_with_interference"])
+@pytest.mark.parametrize("name", ["boundary_and_interior", "value_crosses_blocks", "if_else_pair", "if_else_with_interference",
+                                  "condition_input_rewritten_between_branches"])
 @pytest.mark.parametrize("domain", [(130, 11, 3), (5, 4, 2)])
 def test_planner_case_programs_on_the_device(name, domain):
     """The programs written for the planner's rewriting passes (tests/planner_cases/programs.py; their plans are pinned in
@@ -438,3 +439,25 @@ def test_planner_case_programs_on_the_device(name, domain):
     hip(**dev, origin=origins, domain=domain)
     for k in arrays:
         np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"{name} {domain}: field {k}")
+
+
+@pytest.mark.parametrize("domain", [(70, 5, 7), (66, 3, 58), (130, 4, 80), (64, 2, 161)])
+def test_boundary_only_write_is_not_served_from_the_top_of_column_cache(domain):
+    """`acc` is written at the first level only and read back on all levels by the second sweep; the
+    `_tc` variants (K >= 58) used to read it from registers / LDS that the first sweep never filled."""
+    import oracle.numpy_backend  # noqa: F401
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from planner_cases import programs as P
+
+    defn = P.boundary_only_write_read_back
+    ref = gtscript.stencil(backend="numpy", definition=defn)
+    hip = gtscript.stencil(backend="hip:mi300", definition=defn)
+    arrays, origins = zoo.make_inputs(ref, domain, 23)
+    expect = {k: v.copy() for k, v in arrays.items()}
+    ref(**expect, origin=origins, domain=domain)
+    dev = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=origins[k]) for k, v in arrays.items()}
+    hip(**dev, origin=origins, domain=domain)
+    for k in arrays:
+        np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"{domain}: field {k}")
+

@@ -211,3 +211,53 @@ def test_disjoint_halves_of_one_buffer_are_not_an_alias():
     want = host[1].copy()
     R.laplacian(host[0], want)
     assert np.array_equal(out.get(), want)
+
+
+def test_element_disjoint_views_of_one_buffer_run():
+    """interleaved slices (`vel[..., 0]` / `vel[..., 1]`) and the J halves of an I-contiguous
+    parent have overlapping BYTE ranges but share no element; the library proves that (common.hip.h:
+    elements_disjoint, hip_generic.elements_disjoint) and runs them -- kernel library and generic executor."""
+    import warnings
+
+    import torch
+
+    import oracle.numpy_backend  # noqa: F401
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.storage.device_array import DeviceArray
+
+    rng = np.random.default_rng(11)
+    lap = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64})
+    gen = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
+                           use_kernel_library=False)
+    hd = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64})
+    # 1. interleaved: the last axis of a (I, J, K, 2) array
+    host = rng.uniform(-1, 1, (34, 30, 6, 2))
+    for stencil in (lap, gen):
+        both = torch.from_numpy(host).cuda()
+        inp, out = DeviceArray(both[..., 0]), DeviceArray(both[..., 1])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            stencil(inp, out, origin=(1, 1, 0))
+        want = host[..., 1].copy()
+        R.laplacian(host[..., 0], want)
+        assert np.array_equal(out.get(), want)
+        assert np.array_equal(inp.get(), host[..., 0])
+    # 2. J halves of one I-contiguous parent (strides (1, pitch, pitch * 2 nj)): the halves' byte ranges interleave per level
+    ni, nj, nk = 40, 20, 5
+    parent = torch.zeros((nk, 2 * nj, ni), dtype=torch.float64, device="cuda").permute(2, 1, 0)  # I contiguous
+    u, c = rng.uniform(-10, 10, (ni, nj, nk)), rng.uniform(0, 0.5, (ni, nj, nk))
+    lower, upper = parent[:, :nj, :], parent[:, nj:, :]
+    lower.copy_(torch.from_numpy(u))
+    d_c = DeviceArray(torch.from_numpy(c).cuda())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hd(DeviceArray(lower), DeviceArray(upper), d_c, origin=(2, 2, 0), domain=(ni - 4, nj - 4, nk))
+    want = np.zeros_like(u)
+    R.hdiff(u, want, c)
+    assert np.array_equal(upper.cpu().numpy(), want)
+    # 3. ... but a view shifted by one row inside the same half still overlaps and is refused
+    with pytest.raises(Exception, match="overlap in memory"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lap(DeviceArray(parent[:, 0:10, :]), DeviceArray(parent[:, 1:11, :]), origin=(1, 1, 0), domain=(ni - 2, 8, nk))

@@ -481,144 +481,201 @@ def _committed_traffic(workload: str):
 
 
 # ---- N > 1: the Laplacian on a decomposed 512^3 grid ----------------------------------------------------
+def _agree(ctx, ok: int) -> int:
+    """Every rank learns whether ALL ranks succeeded."""
+    if ctx["distributed"]:
+        import torch
+
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctx.get("device", "cuda"))
+        ctx["dist"].all_reduce(flag, op=ctx["dist"].ReduceOp.MIN)
+        ok = int(flag.item())
+    return ok
+
+
+def _slowest_rank_ms(ctx, fn, calls: int, warm: int = 3) -> float:
+    """Milliseconds per call of ``fn`` over ``calls`` calls, the slowest rank's figure on every rank."""
+    import torch
+
+    device = ctx.get("device", "cuda")
+    sync = torch.cuda.synchronize if device == "cuda" else (lambda: None)
+    for _ in range(warm):
+        fn()
+    sync()
+    if ctx["distributed"]:
+        ctx["dist"].barrier()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        fn()
+    sync()
+    dt = torch.tensor([(time.perf_counter() - t0) / calls * 1e3], dtype=torch.float64, device=device)
+    if ctx["distributed"]:
+        ctx["dist"].all_reduce(dt, op=ctx["dist"].ReduceOp.MAX)
+    return float(dt.item())
+
+
+def gather_rank_proof(ctx, info) -> dict:
+    """What RCCL itself reports on every rank (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), gathered: the line's
+    evidence that the communicator really spans N ranks on N devices."""
+    mine = (int(info["rank"]), int(info["device"]), int(info["nranks"]))
+    if ctx["distributed"]:
+        everyone = [None] * ctx["world"]
+        ctx["dist"].all_gather_object(everyone, mine)
+    else:
+        everyone = [mine]
+    return {"rccl_nranks": int(info["nranks"]), "rccl_ranks_agree": len({e[2] for e in everyone}) == 1,
+            "rank_devices": [[e[0], e[1]] for e in sorted(everyone)]}
+
+
+def transport_fallback_banner(rank: int, why: str) -> None:
+    """A run that silently changed transport would put a Python-driven exchange (~250 us per step) into the scaling
+    curve without anyone noticing: say it loudly (and the JSON line carries "transport_fallback": true)."""
+    if rank == 0:
+        bar = "!" * 100
+        print(f"{bar}\nbench.py: NATIVE RCCL TRANSPORT UNAVAILABLE ({why}); FALLING BACK TO torch.distributed P2P DRIVEN FROM "
+              f"PYTHON.\nThe numbers of this run are NOT those of the product path (libgt4py_amd's native RCCL plan).\n{bar}",
+              file=sys.stderr, flush=True)
+
+
+def _native_comm(ctx, selfloop: bool):
+    """(NativeComm or None, proof) -- creating the communicator is collective; should it fail on any rank, every rank
+    falls back to the torch transport together.  proof = what RCCL itself reports (ncclCommCount) + the rank -> device map."""
+    import torch
+
+    from gt4py_amd.distributed import NativeComm
+
+    dog, rank = ctx["dog"], ctx["rank"]
+    dog.arm(180, "native RCCL communicator (ncclCommInitRank)")
+    ok, comm, info = 1, None, None
+    try:
+        comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
+        info = comm.info()
+    except Exception as ex:
+        ok = 0
+        print(f"rank {rank}: native RCCL communicator failed ({ex!r})", file=sys.stderr)
+    if not _agree(ctx, ok):
+        transport_fallback_banner(rank, "ncclCommInitRank failed on at least one rank")
+        return None, None
+    return comm, gather_rank_proof(ctx, info)
+
+
 def _setup_distributed_laplacian(args, ctx):
-    """Returns (step, kernel_step, local_domain, config, extras) for the decomposed headline workload."""
+    """Returns (step, kernel_step, local_domain, config, extras) for the decomposed headline workload.
+
+    Headline (like-for-like with N = 1 and with the north star): INDEPENDENT applies on fixed inputs, ghost depth 1, the
+    input's ghost cells exchanged on EVERY apply next to the interior kernel (gt4mi_dist_lap5_f64: pack, interior ||
+    send/recv/unpack, one ring kernel).  The communication-avoiding time steppers are a different workload (u <- lap(u),
+    one exchange per H steps) and are reported beside it (extras["timestep"] -> line["extra"])."""
     import numpy as np
     import torch
 
     from gt4py_amd.cartesian import gtscript
-    from gt4py_amd.distributed import (Decomposition, HaloExchanger, NativeComm, NativeHaloExchanger,
-                                       choose_process_grid, overlapped_apply, process_grid_candidates)
+    from gt4py_amd.distributed import (Decomposition, HaloExchanger, NativeHaloExchanger, choose_process_grid, overlapped_apply,
+                                       process_grid_candidates)
 
     world, rank, local_rank, distributed, dog = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["distributed"], ctx["dog"]
-    dist = ctx.get("dist")
     selfloop = args.dist_selfloop and world == 1
     total = (GRID[0], GRID[1] // max(args.selfloop_ranks, 1), GRID[2]) if selfloop else GRID
     lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64}, device_sync=False)
     transport = os.environ.get("GT4MI_BENCH_COMM", "native")
-    mode = os.environ.get("GT4MI_BENCH_MODE", "timestep")
-
-    def agree(ok: int) -> int:  # every rank learns whether ALL ranks succeeded
-        if distributed:
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        return ok
-
-    comm = None
+    mode = os.environ.get("GT4MI_BENCH_MODE", "apply")
+    fallback = False
+    comm, proof = None, None
     if transport == "native":
-        # RCCL communicator owned by libgt4py_amd.  Creating it is collective; should it fail on any
-        # rank, every rank falls back to the torch.distributed transport together.
-        dog.arm(180, "native RCCL communicator (ncclCommInitRank)")
-        ok = 1
-        try:
-            comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
-        except Exception as ex:
-            ok = 0
-            print(f"rank {rank}: native RCCL communicator failed ({ex!r})", file=sys.stderr)
-        if not agree(ok):
-            transport, comm = "torch", None
-            print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
+        comm, proof = _native_comm(ctx, selfloop)
+        if comm is None:
+            transport, fallback = "torch", True
 
     def grid_of(name):
         pi, pj = name.split("x")
         return int(pi), int(pj)
 
-    # What is measured before the warm-up (all ranks agreeing on the slowest rank's time), unless pinned through
-    # the environment: the process grid (xGMI is point-to-point, so the largest message of an exchange is what
-    # costs: 1x8 sends 2.1 MB faces, 4x2 and 2x4 at most 1.05 MB), the ghost depth = steps served by one exchange
-    # (communication-avoiding time stepping) and whether that exchange runs next to the last step's interior
-    # kernel or after a full-domain kernel.  In the 1-GPU rehearsal (on-device self-copy) "depth 4, not
-    # overlapped" is fastest (profiles/r1_dist_selfloop_seq_vs_overlap.log); on real links it is not known.
     periodic = (False, True) if selfloop else (False, False)
-    calibration = None
     grid = (1, 1) if selfloop else choose_process_grid(world, total)
-    if "GT4MI_BENCH_GRID" in os.environ:
+    pinned_grid = "GT4MI_BENCH_GRID" in os.environ
+    if pinned_grid:
         grid = grid_of(os.environ["GT4MI_BENCH_GRID"])
-    overlap = os.environ.get("GT4MI_BENCH_OVERLAP", "1") != "0"
-    halo = 1
-    if transport == "native" and mode == "timestep":
-        pinned = any(k in os.environ for k in ("GT4MI_BENCH_HALO", "GT4MI_BENCH_OVERLAP"))
-        halo = max(1, int(os.environ.get("GT4MI_BENCH_HALO", "2")))
-        if not pinned:
-            def calibrate():
-                table = {}
-                for cand_halo in (1, 2, 4):
-                    grids = [(1, 1)] if selfloop else ([grid] if "GT4MI_BENCH_GRID" in os.environ else
-                                                       process_grid_candidates(world, total, cand_halo))
-                    if selfloop and total[1] < 2 * cand_halo:
-                        continue
-                    for cand_grid in grids:
-                        cdec = Decomposition(total, cand_grid, rank, halo=cand_halo, periodic=periodic)
-                        cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
-                        for cand_overlap in (True, False):
-                            ca, cb = cpairs[0][0], cpairs[1][0]
-                            ca.tensor.mul_(1e-150)
-                            cex = NativeHaloExchanger(cdec, np.float64, comm)
-                            cstep = cex.make_time_stepper_lap5(ca, cb, cdec.origin, overlap=cand_overlap)
-                            for _ in range(2 * cand_halo):
-                                cstep()
-                            torch.cuda.synchronize()
-                            if distributed:
-                                dist.barrier()
-                            t0 = time.perf_counter()
-                            for _ in range(24):
-                                cstep()
-                            torch.cuda.synchronize()
-                            dt = torch.tensor([(time.perf_counter() - t0) / 24], dtype=torch.float64, device="cuda")
-                            if distributed:
-                                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                            key = f"{cand_grid[0]}x{cand_grid[1]}_halo{cand_halo}_{'overlap' if cand_overlap else 'sequential'}"
-                            table[key] = round(float(dt.item()) * 1e3, 5)
-                            cex.close()
-                        del cpairs
-                torch.cuda.empty_cache()
-                best = min(table, key=table.get)
-                g, h, o = best.split("_")
-                return table, grid_of(g), int(h[4:]), o == "overlap"
+    single_phase = os.environ.get("GT4MI_BENCH_SINGLE_PHASE", "0") == "1"
+    schedule, wg_per_cu = os.environ.get("GT4MI_BENCH_SCHEDULE", "join"), int(os.environ.get("GT4MI_BENCH_WG_PER_CU", "0"))
+    calibration = None
 
-            # A transport that creates its communicator but cannot move data must not take the run down:
-            # every rank reports whether its calibration went through, and all fall back together.
-            dog.arm(420, "calibration of process grid x ghost depth x overlap")
-            ok = 1
-            try:
-                calibration, grid, halo, overlap = calibrate()
-            except Exception as ex:
-                ok, calibration = 0, None
-                print(f"rank {rank}: native RCCL halo exchange failed during calibration ({ex!r})", file=sys.stderr)
-            if not agree(ok):
-                transport, comm, halo, overlap = "torch", None, 1, True
-                grid = (1, 1) if selfloop else choose_process_grid(world, total)
-                print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
+    def apply_candidate(cand_grid, cand_single, cand_schedule="join", cand_wg=0):
+        """(step(i), keepalive) of the headline form on one process grid / message table / schedule / throttle."""
+        cdec = Decomposition(total, cand_grid, rank, halo=1, periodic=periodic)
+        cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=1337 + rank, origin=cdec.origin)
+        cex = [NativeHaloExchanger(cdec, np.float64, comm, single_phase=cand_single).tune(cand_schedule, cand_wg) for _ in cpairs]
+        bound = [ex.make_dist_lap5(inp, out, cdec.origin, cdec.origin) for ex, (inp, out) in zip(cex, cpairs)]
+        state = {"i": 0}
+
+        def call():
+            bound[state["i"] % len(bound)]()
+            state["i"] += 1
+
+        return call, (cdec, cpairs, cex, bound)
+
+    if transport == "native" and mode == "apply" and not ("GT4MI_BENCH_SINGLE_PHASE" in os.environ and pinned_grid):
+        # Measured before the warm-up, all ranks agreeing on the slowest rank's time: the process grid (xGMI is
+        # point-to-point: what costs is the LARGEST message of a round, 1x8 sends 2.1 MB faces, 4x2 and 2x4 at most
+        # 1.05 MB) and the message table (two rounds with 4 neighbours, or one round with faces + corners to 8).
+        dog.arm(420, "calibration of process grid x message table")
+        ok, table = 1, {}
+        try:
+            grids = [grid] if (selfloop or pinned_grid) else process_grid_candidates(world, total, 1)
+            for cand_grid in grids:
+                for cand_single in ((single_phase,) if "GT4MI_BENCH_SINGLE_PHASE" in os.environ else (False, True)):
+                    for cand_schedule in ("join", "chain"):
+                        for cand_wg in (0, 4, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
+                            call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg)
+                            key = (f"{cand_grid[0]}x{cand_grid[1]}_{'single' if cand_single else 'two'}phase_{cand_schedule}"
+                                   f"_wg{cand_wg}")
+                            table[key] = round(_slowest_rank_ms(ctx, call, 24), 5)
+                            for ex in keep[2]:
+                                ex.close()
+                            del call, keep
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            ok = 0
+            print(f"rank {rank}: native RCCL halo exchange failed during calibration ({ex!r})", file=sys.stderr)
+        if not _agree(ctx, ok):
+            transport, comm, fallback = "torch", None, True
+            transport_fallback_banner(rank, "the native halo exchange failed during calibration")
+        else:
+            calibration = table
+            best = min(table, key=table.get)
+            g, ph, schedule, wg = best.split("_")
+            grid, single_phase, wg_per_cu = grid_of(g), ph == "singlephase", int(wg[2:])
     dog.arm(180, "set-up of the decomposed fields and exchangers")
-    dec = Decomposition(total, grid, rank, halo=halo, periodic=periodic)
+    dec = Decomposition(total, grid, rank, halo=1, periodic=periodic)
     origin = {"inp": dec.origin, "out": dec.origin}
-    pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank, origin=dec.origin)
     local_domain = dec.local_domain
     frozen = lap.freeze(origin=origin, domain=local_domain)
-    if transport == "native":
-        # whole step (pack, RCCL send/recv, unpack, interior, strips, 2 streams) = one C call
-        exchangers = [NativeHaloExchanger(dec, np.float64, comm) for _ in pairs]
-        if mode == "timestep":
-            # time stepping u <- lap(u) between two buffers.  Ghost regions are `halo` deep and one
-            # exchange serves `halo` steps (the steps in between grow their domain into the ghost
-            # region instead of communicating); the exchange of the freshly written field travels
-            # next to that step's interior kernel and is joined `halo` steps later.
-            # The amplitude starts at 1e-150 so that ~8x growth per step stays finite for 600 steps.
-            a, b = pairs[0][0], pairs[1][0]
-            a.tensor.mul_(1e-150)
-            stepper = exchangers[0].make_time_stepper_lap5(a, b, origin["inp"], overlap=overlap)
+    stepper_state = {}
+    if transport == "native" and mode == "apply":
+        call, keep = apply_candidate(grid, single_phase, schedule, wg_per_cu)
+        pairs, exchangers = keep[1], keep[2]
 
-            def step(i):
-                stepper()
-        else:  # independent applies on fixed inputs: exchange the input, then apply
-            steps_bound = [ex.make_dist_lap5(inp, out, origin["inp"], origin["out"]) for ex, (inp, out) in
-                           zip(exchangers, pairs)]
+        def step(i):
+            call()
+    elif transport == "native":  # GT4MI_BENCH_MODE=timestep: the communication-avoiding stepper as the timed workload
+        halo = max(1, int(os.environ.get("GT4MI_BENCH_HALO", "2")))
+        dec = Decomposition(total, grid, rank, halo=halo, periodic=periodic)
+        origin = {"inp": dec.origin, "out": dec.origin}
+        frozen = lap.freeze(origin=origin, domain=dec.local_domain)
+        pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank, origin=dec.origin)
+        exchangers = [NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase).tune(schedule, wg_per_cu)]
+        a, b = pairs[0][0], pairs[1][0]
+        a.tensor.mul_(1e-150)  # ~8x growth per step stays finite for 600 steps
+        b.tensor.copy_(a.tensor)
+        cycle = exchangers[0].make_time_skewed_lap5(a, b, dec.origin)
+        stepper_state["halo"] = halo
 
-            def step(i):
-                steps_bound[i % len(pairs)]()
+        def step(i):
+            if i % halo == 0:
+                cycle()
+        keep = (cycle,)
     else:  # torch.distributed point-to-point ops driven from Python
+        pairs = _device_fields(dec.local_shape, n_pairs=2, seed=1337 + rank, origin=dec.origin)
         exchangers = [HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank)) for _ in pairs]
+        keep = ()
 
         def step(i):
             inp, out = pairs[i % len(pairs)]
@@ -628,17 +685,61 @@ def _setup_distributed_laplacian(args, ctx):
         inp, out = pairs[i % len(pairs)]
         frozen(inp=inp, out=out)
 
-    config = {"workload": "fp64 5-point Laplacian 512x512x512 split over the ranks (strong scaling); "
-                          + ("time stepping u <- lap(u), ghost regions %d deep: one RCCL send/recv exchange per %d "
-                             "steps" % (halo, halo) if mode == "timestep"
-                             and transport == "native" else "independent applies, ghost cells exchanged every step"),
-              "grid": list(total), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(local_domain),
-              "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange,
-              "transport": transport, "mode": mode, "selfloop": bool(selfloop),
-              "exchange_overlapped_with_interior": bool(overlap) if mode == "timestep" and transport == "native" else None,
-              "calibration_ms_per_step": calibration}
-    extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen)}
-    return step, kernel_step, local_domain, config, extras
+    def timestep_extras():
+        """The communication-avoiding time steppers (u <- lap(u), ghost regions H deep, one exchange per H steps) on the
+        chosen grid: ms per STEP of every schedule x depth, slowest rank; collective, so every rank runs it."""
+        if transport != "native" or os.environ.get("GT4MI_BENCH_TIMESTEP", "1") == "0":
+            return None
+        table = {}
+        for cand_halo in (1, 2, 3, 4):
+            if cand_halo > 1 and ((grid[1] > 1 or selfloop) and total[1] // grid[1] < 2 * (2 * cand_halo - 1)
+                                  or grid[0] > 1 and total[0] // grid[0] < 2 * (2 * cand_halo - 1)):
+                continue
+            cdec = Decomposition(total, grid, rank, halo=cand_halo, periodic=periodic)
+            for stepper in ("skewed_join", "skewed_chain", "skewed_chain_wg4", "wide_overlap", "wide_sequential"):
+                if not stepper.startswith("skewed") and cand_halo == 3:
+                    continue
+                cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
+                ca, cb = cpairs[0][0], cpairs[1][0]
+                ca.tensor.mul_(1e-150)
+                cb.tensor.copy_(ca.tensor)
+                cex = NativeHaloExchanger(cdec, np.float64, comm, single_phase=single_phase)
+                if stepper.startswith("skewed"):
+                    cex.tune("chain" if "chain" in stepper else "join", 4 if stepper.endswith("wg4") else 0)
+                    fn, per_call = cex.make_time_skewed_lap5(ca, cb, cdec.origin), cand_halo
+                else:
+                    fn, per_call = cex.make_time_stepper_lap5(ca, cb, cdec.origin, overlap=stepper == "wide_overlap"), 1
+                calls = max(24 // per_call, 6) if per_call > 1 else 24
+                ms = _slowest_rank_ms(ctx, fn, calls, warm=2 * (cand_halo if per_call == 1 else 1)) / per_call
+                table[f"{stepper}_halo{cand_halo}"] = round(ms, 5)
+                cex.close()
+                del cpairs, ca, cb, fn
+        torch.cuda.empty_cache()
+        best = min(table, key=table.get)
+        lups = float(np.prod(dec.global_domain))
+        return {"timestep_glups": round(lups / table[best] / 1e6, 2), "timestep_best": best, "timestep_ms_per_step": table,
+                "timestep_workload": "time stepping u <- lap(u) on the same decomposed grid, ghost regions H deep, ONE exchange "
+                                     "per H steps (skewed: boundary bands first, the faces travel next to H interior kernels; "
+                                     "wide: grown launches, exchange next to one interior kernel / after a full-domain kernel) "
+                                     "-- a different workload from `value`, reported beside it"}
+
+    what = {"apply": "independent applies on fixed inputs (two rotating pairs), ghost depth 1, the input's ghost cells "
+                     "exchanged on EVERY apply next to the interior kernel (RCCL send/recv on a side stream)",
+            "timestep": "time stepping u <- lap(u), time-skewed schedule, ghost regions %d deep: one RCCL exchange per %d steps"
+                        % (stepper_state.get("halo", 1), stepper_state.get("halo", 1))}[mode if transport == "native" else "apply"]
+    config = {"workload": "fp64 5-point Laplacian 512x512x512 split over the ranks (strong scaling); " + what,
+              "grid": list(total), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(dec.local_domain),
+              "halo_depth": stepper_state.get("halo", 1),
+              "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange,
+              "message_table": ("single-phase (faces + corners, up to 8 neighbours)" if single_phase else
+                                "two-phase (I faces, then J faces with the fresh I-halo columns)") if transport == "native" else "two-phase",
+              "transport": transport, "mode": mode if transport == "native" else "apply", "selfloop": bool(selfloop),
+              "exchange_overlapped_with_interior": True,
+              "schedule": schedule if transport == "native" else "join", "interior_workgroups_per_cu": wg_per_cu,
+              "calibration_ms_per_apply": calibration}
+    extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
+              "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback}
+    return step, kernel_step, dec.local_domain, config, extras
 
 
 # ---- BASELINE.json configs[4]: horizontal diffusion, 512 x 1024 x 80 per rank, ghost depth 2 --------------
@@ -649,11 +750,10 @@ def _setup_hdiff2048(args, ctx):
     import gt4py_amd.storage as gt_storage
     from gt4py_amd.cartesian import gtscript
     from gt4py_amd.cartesian.backend import hip_templates
-    from gt4py_amd.distributed import (Decomposition, HaloExchanger, NativeComm, NativeHaloExchanger, TunedApply,
-                                       choose_process_grid)
+    from gt4py_amd.distributed import (Decomposition, HaloExchanger, NativeHaloExchanger, choose_process_grid, overlapped_apply,
+                                       sequential_apply)
 
     world, rank, local_rank, distributed, dog = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["distributed"], ctx["dog"]
-    dist = ctx.get("dist")
     selfloop = args.dist_selfloop and world == 1
     halo = 2
     grid = choose_process_grid(world, HDIFF_GLOBAL, halo)  # 8 ranks -> 4 x 2
@@ -677,37 +777,56 @@ def _setup_hdiff2048(args, ctx):
     origin = {k: dec.origin for k in fields}
     frozen = hd.freeze(origin=origin, domain=dec.local_domain)
     decomposed = distributed or selfloop
-    transport, comm, exchangers, tuned = "none", None, [], None
+    transport, comm, proof, exchangers, fallback = "none", None, None, [], False
+    timings, choice = None, "single launch"
     if decomposed:
         transport = os.environ.get("GT4MI_BENCH_COMM", "native")
         if transport == "native":
-            dog.arm(180, "native RCCL communicator (ncclCommInitRank)")
-            ok = 1
+            comm, proof = _native_comm(ctx, selfloop)
+            if comm is None:
+                transport, fallback = "torch", True
+        if transport == "native":
+            # one C call per apply (gt4mi_dist_hdiff_f64: pack, interior || exchange, ONE ring kernel) with either message
+            # table, and the plain sequence (exchange, then one full-domain launch): measured, slowest rank decides
+            flags = type(hd)._gt_binding_.flags
+            forms, exchangers, form_exchanger = {}, [], {}
+            for table, single in (("two_phase", False), ("single_phase", True)):
+                for cand_schedule in ("join", "chain"):
+                    for cand_wg in (0, 3, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
+                        ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(cand_schedule, cand_wg)
+                        exchangers.append(ex)
+                        name = f"fused_{table}_{cand_schedule}_wg{cand_wg}"
+                        forms[name] = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
+                        form_exchanger[name] = ex
+                forms[f"sequential_{table}"] = (lambda ex=ex: sequential_apply(hd, dec, origin, fields, {"in_field": ex}))
+                form_exchanger[f"sequential_{table}"] = ex
+            pinned = os.environ.get("GT4MI_BENCH_FORM")
+            dog.arm(300, "calibration of the apply forms")
+            ok, timings = 1, {}
             try:
-                comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
-                ex = NativeHaloExchanger(dec, np.float64, comm)
+                for name, fn in forms.items():
+                    if pinned is None or pinned == name:
+                        timings[name] = round(_slowest_rank_ms(ctx, fn, 16), 5)
             except Exception as exn:
                 ok = 0
-                print(f"rank {rank}: native RCCL set-up failed ({exn!r})", file=sys.stderr)
-            if distributed:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if not ok:
-                transport, comm = "torch", None
-                print("falling back to GT4MI_BENCH_COMM=torch", file=sys.stderr)
+                print(f"rank {rank}: native RCCL halo exchange failed during calibration ({exn!r})", file=sys.stderr)
+            if not _agree(ctx, ok):
+                transport, comm, fallback = "torch", None, True
+                transport_fallback_banner(rank, "the native halo exchange failed during calibration")
+            else:
+                choice = min(timings, key=timings.get)
+                chosen = forms[choice]
+                exchangers.remove(form_exchanger[choice])
+                exchangers.insert(0, form_exchanger[choice])  # the one the line describes
+
+                def step(i):
+                    chosen()
         if transport != "native":
             ex = HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank))
-        exchangers = [ex]
-        tuned = TunedApply(hd, dec, origin, {"in_field": ex})
-        if "GT4MI_BENCH_OVERLAP" in os.environ:
-            tuned.choice = "overlapped" if os.environ["GT4MI_BENCH_OVERLAP"] != "0" else "sequential"
-        else:
-            dog.arm(300, "calibration overlapped vs sequential apply")
-            tuned.calibrate(fields, iters=12)  # on a clone of out_field; all ranks adopt the slowest rank's verdict
+            exchangers, choice = [ex], "overlapped (torch transport)"
 
-        def step(i):
-            tuned(fields)
+            def step(i):
+                overlapped_apply(hd, dec, origin, fields, {"in_field": ex})
     else:
         def step(i):
             frozen(**fields)
@@ -720,11 +839,24 @@ def _setup_hdiff2048(args, ctx):
                           "4x2 grid), ghost depth 2, in_field's ghost cells exchanged every apply",
               "grid": list(total), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(dec.local_domain),
               "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange if exchangers else 0,
-              "transport": transport, "selfloop": bool(selfloop),
-              "apply_form": tuned.choice if tuned is not None else "single launch",
-              "calibration_ms_per_step": {k: round(v, 5) for k, v in tuned.timings_ms.items()} if tuned is not None else None}
-    extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen, tuned)}
+              "transport": transport, "selfloop": bool(selfloop), "apply_form": choice,
+              "calibration_ms_per_apply": timings}
+    extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen),
+              "proof": proof, "transport_fallback": fallback}
     return step, kernel_step, dec.local_domain, config, extras
+
+
+def decomposed_line_keys(proof, transport_fallback: bool, n_gpus: int, timestep) -> dict:
+    """Top-level keys every N > 1 (or self-loop) line carries: how many ranks RCCL itself reports and on which devices,
+    whether the run fell back from the native transport, and the communication-avoiding steppers beside the headline."""
+    proof = proof or {}
+    out = {"rccl_nranks": proof.get("rccl_nranks"), "rank_devices": proof.get("rank_devices"),
+           "rccl_matches_n_gpus": bool(proof) and proof.get("rccl_nranks") == n_gpus and bool(proof.get("rccl_ranks_agree"))
+           and len(proof.get("rank_devices") or []) == n_gpus,
+           "transport_fallback": bool(transport_fallback)}
+    if timestep is not None:
+        out["extra"] = timestep
+    return out
 
 
 def main() -> None:
@@ -849,6 +981,13 @@ def main() -> None:
     exchangers = extras.get("exchangers") or []
     if exchangers and isinstance(exchangers[0], NativeHaloExchanger):
         config["side_stream_concurrent"] = exchangers[0].concurrent
+    timestep = None
+    if callable(extras.get("timestep")):  # collective: every rank runs it
+        dog.arm(420, "communication-avoiding time steppers (informational)")
+        try:
+            timestep = extras["timestep"]()
+        except Exception as ex:
+            print(f"rank {rank}: time-stepper measurement failed ({ex!r})", file=sys.stderr)
     if rank == 0:
         dog.arm(900, "informational kernels and CPU baseline")
         headline = args.workload == "lap512" and not decomposed
@@ -885,6 +1024,8 @@ def main() -> None:
             },
             "device": _lib.device_info(),
         }
+        if decomposed:
+            line.update(decomposed_line_keys(extras.get("proof"), bool(extras.get("transport_fallback")), n_gpus, timestep))
         if headline:
             try:
                 line["host_cost_per_call"] = host_cost_per_call(lap)

@@ -29,6 +29,10 @@ EXPORTED_SYMBOLS = (
     "gt4mi_lap5_f32",
     "gt4mi_hdiff_f64",
     "gt4mi_hdiff_f32",
+    "gt4mi_hdiff_ring_f64",
+    "gt4mi_hdiff_ring_f32",
+    "gt4mi_lap5_ring_f64",
+    "gt4mi_lap5_ring_f32",
     "gt4mi_tridiag_f64",
     "gt4mi_tridiag_f32",
     "gt4mi_halo_pack",
@@ -36,8 +40,10 @@ EXPORTED_SYMBOLS = (
     "gt4mi_comm_unique_id",
     "gt4mi_comm_create",
     "gt4mi_comm_destroy",
+    "gt4mi_comm_info",
     "gt4mi_halo_plan_create",
     "gt4mi_halo_plan_destroy",
+    "gt4mi_halo_plan_set_option",
     "gt4mi_halo_plan_concurrent",
     "gt4mi_halo_exchange",
     "gt4mi_halo_exchange_begin",
@@ -46,6 +52,9 @@ EXPORTED_SYMBOLS = (
     "gt4mi_dist_lap5_f64",
     "gt4mi_dist_lap5_f64_pipelined",
     "gt4mi_dist_lap5_f64_wide",
+    "gt4mi_dist_lap5_f64_skewed",
+    "gt4mi_dist_hdiff_f64",
+    "gt4mi_dist_hdiff_f32",
     "gt4mi_rtc_compile",
     "gt4mi_rtc_free",
     "gt4mi_module_load",
@@ -57,7 +66,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_stream_copy",
 )
 
-GT4MI_ABI_VERSION = 2
+GT4MI_ABI_VERSION = 3
 
 # gt4mi_status
 OK = 0
@@ -69,6 +78,9 @@ ERR_HIP = -4
 # lap5 variants / flags
 LAP_NOTEBOOK, LAP_DOCS, LAP_SUITE, LAP_AVG = 0, 1, 2, 3
 LAP_LITERAL_F32 = 1
+# gt4mi_halo_plan_set_option
+PLAN_SCHEDULE, PLAN_INTERIOR_WG_PER_CU = 0, 1
+SCHEDULE_JOIN, SCHEDULE_CHAIN = 0, 1
 # hdiff flags
 HDIFF_LIMITER, HDIFF_INTERNAL_F32, HDIFF_COEFF_F32 = 1, 2, 4
 
@@ -144,6 +156,15 @@ def _declare(lib: ctypes.CDLL) -> None:
         f = getattr(lib, name)
         f.restype = I
         f.argtypes = [DOM, FP, FP, FP, D, I, P, EI]
+    W4 = ctypes.POINTER(ctypes.c_int)
+    for name in ("gt4mi_hdiff_ring_f64", "gt4mi_hdiff_ring_f32"):
+        f = getattr(lib, name)
+        f.restype = I
+        f.argtypes = [DOM, FP, FP, FP, D, I, W4, P, EI]
+    for name in ("gt4mi_lap5_ring_f64", "gt4mi_lap5_ring_f32"):
+        f = getattr(lib, name)
+        f.restype = I
+        f.argtypes = [DOM, FP, FP, I, I, W4, W4, P, EI]
     for name in ("gt4mi_tridiag_f64", "gt4mi_tridiag_f32"):
         f = getattr(lib, name)
         f.restype = I
@@ -162,10 +183,15 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_comm_create.argtypes = [P, I, I, PP]
     lib.gt4mi_comm_destroy.restype = I
     lib.gt4mi_comm_destroy.argtypes = [P]
+    IP = ctypes.POINTER(ctypes.c_int)
+    lib.gt4mi_comm_info.restype = I
+    lib.gt4mi_comm_info.argtypes = [P, IP, IP, IP]
     lib.gt4mi_halo_plan_create.restype = I
     lib.gt4mi_halo_plan_create.argtypes = [P, I, MP, I, MP, I, PP]
     lib.gt4mi_halo_plan_destroy.restype = I
     lib.gt4mi_halo_plan_destroy.argtypes = [P]
+    lib.gt4mi_halo_plan_set_option.restype = I
+    lib.gt4mi_halo_plan_set_option.argtypes = [P, I, I]
     lib.gt4mi_halo_plan_concurrent.restype = I
     lib.gt4mi_halo_plan_concurrent.argtypes = [P]
     lib.gt4mi_halo_exchange.restype = I
@@ -182,6 +208,12 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_dist_lap5_f64_pipelined.argtypes = [P, DOM, FP, FP, I, I, P]
     lib.gt4mi_dist_lap5_f64_wide.restype = I
     lib.gt4mi_dist_lap5_f64_wide.argtypes = [P, DOM, FP, FP, I, I, I, I, P]
+    lib.gt4mi_dist_lap5_f64_skewed.restype = I
+    lib.gt4mi_dist_lap5_f64_skewed.argtypes = [P, DOM, FP, FP, I, I, I, P]
+    for name in ("gt4mi_dist_hdiff_f64", "gt4mi_dist_hdiff_f32"):
+        f = getattr(lib, name)
+        f.restype = I
+        f.argtypes = [P, DOM, FP, FP, FP, D, I, I, P]
     SZ = ctypes.c_size_t
     lib.gt4mi_rtc_compile.restype = I
     lib.gt4mi_rtc_compile.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), I, PP,
@@ -239,6 +271,11 @@ def check(func: str, status: int) -> None:
 
 def domain3(domain: Sequence[int]):
     return _Int3(*map(int, domain))
+
+
+def int4(values: Sequence[int]):
+    """``const int[4]`` argument: ring widths towards {low I, high I, low J, high J}."""
+    return (ctypes.c_int * 4)(*map(int, values))
 
 
 def rtc_compile(source: str, name: str = "gt4mi_stencil.hip", options: Sequence[str] = ()) -> bytes:

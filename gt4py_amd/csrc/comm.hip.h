@@ -40,6 +40,9 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(RcclComm, int*) = nullptr;      // optional: what the communicator itself reports
+    int (*CommUserRank)(RcclComm, int*) = nullptr;
+    int (*CommCuDevice)(RcclComm, int*) = nullptr;
     bool ok = false;
 };
 
@@ -65,6 +68,9 @@ inline RcclApi& rccl() {
         a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
         a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
+        a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
+        a.CommCuDevice = reinterpret_cast<decltype(a.CommCuDevice)>(dlsym(h, "ncclCommCuDevice"));
         a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
         return a;
     }();
@@ -103,6 +109,9 @@ struct gt4mi_halo_plan {
     hipEvent_t ready = nullptr, done = nullptr;
     bool forked = false;                  // `ready` already recorded by gt4mi_halo_exchange_fork
     bool primed = false;                  // `done` has been recorded at least once (pipelined stepping)
+    // how the fused distributed steps are scheduled (gt4mi_halo_plan_set_option); -1 = the entry point's own default
+    int schedule = -1;            // GT4MI_SCHEDULE_JOIN / GT4MI_SCHEDULE_CHAIN
+    int interior_wg_per_cu = -1;  // occupancy limit of the interior kernel while the exchange runs next to it (0 = none)
     // concurrency probe (ensure_concurrent_stream)
     unsigned* probe = nullptr;            // two device words: flag, result
     hipStream_t probed_main = nullptr;
@@ -163,18 +172,55 @@ inline int ensure_concurrent_stream(gt4mi_halo_plan* plan, hipStream_t main_stre
 // All boxes of one phase are packed (or unpacked) by ONE launch: blockIdx.y selects the box.  The
 // exchange is latency-bound, so launches on its critical path are what matters.
 struct BoxBatch {
-    static constexpr int MAX = 4;
+    static constexpr int MAX = 8;  // a single-phase plan has up to 8 neighbours (4 faces + 4 corners)
     int n;
     int64_t offset[MAX];  // element offset of the box start inside the field
     int ext[MAX][3];
+    int vec[MAX];         // 1: rows along I are whole 16-byte vectors in the field and in the buffer
     void* buffer[MAX];
 };
 
+// One box per blockIdx.y.  Boxes whose rows along I start and end on 16-byte boundaries (in the field and in the dense
+// buffer) move as 16-byte vectors, UNROLL of them per thread with all loads issued first: next to an HBM-saturating
+// interior kernel a copy is bound by the bytes it keeps in flight -- the one-item-per-thread form took 29 us for the two
+// 2 MB faces of the 512 x 64 x 512 share where it takes 5 us alone (profiles/r3_dist_lap5_skewed_timeline.txt).  Other
+// boxes (one-column faces of 8-byte items, odd origins) go item by item.
 template <typename U, bool PACK>
 __global__ void __launch_bounds__(256)
 halo_batch_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b) {
+    constexpr int UNROLL = 4;
+    constexpr int PER_VEC = 16 / (int)sizeof(U);
     const int m = blockIdx.y;
-    const int ei = b.ext[m][0], ej = b.ext[m][1], ek = b.ext[m][2];
+    const int ej = b.ext[m][1], ek = b.ext[m][2];
+    if (b.vec[m]) {
+        const int ei = b.ext[m][0] / PER_VEC;  // vectors per row
+        const int64_t n = (int64_t)ei * ej * ek;
+        U* base = field + b.offset[m];
+        u32x4* buf = static_cast<u32x4*>(b.buffer[m]);
+        for (int64_t t0 = ((int64_t)blockIdx.x * UNROLL) * 256 + threadIdx.x; t0 < n; t0 += (int64_t)gridDim.x * 256 * UNROLL) {
+            u32x4 v[UNROLL];
+            u32x4* where[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t t = t0 + (int64_t)u * 256;
+                const int64_t tt = t < n ? t : n - 1;
+                const int i = (int)(tt % ei);
+                const int64_t r = tt / ei;
+                where[u] = reinterpret_cast<u32x4*>(base + (int64_t)i * PER_VEC + (r % ej) * sj + (r / ej) * sk);
+                v[u] = PACK ? *where[u] : buf[tt];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t t = t0 + (int64_t)u * 256;
+                if (t < n) {
+                    if constexpr (PACK) buf[t] = v[u];
+                    else *where[u] = v[u];
+                }
+            }
+        }
+        return;
+    }
+    const int ei = b.ext[m][0];
     const int64_t n = (int64_t)ei * ej * ek;
     U* base = field + b.offset[m];
     U* buf = static_cast<U*>(b.buffer[m]);
@@ -195,7 +241,10 @@ inline int plan_copy_batch(const gt4mi_field* f, const std::vector<gt4mi_halo_pl
     if ((int)msgs.size() > BoxBatch::MAX) return fail(GT4MI_ERR_UNSUPPORTED, "halo: more than %d boxes per phase", BoxBatch::MAX);
     BoxBatch b;
     b.n = (int)msgs.size();
-    int64_t nmax = 0;
+    constexpr int64_t PER_VEC = 16 / (int64_t)sizeof(U);
+    const bool field_vec = f->stride[0] == (int64_t)sizeof(U) && f->stride[1] % 16 == 0 && f->stride[2] % 16 == 0 &&
+                           reinterpret_cast<uintptr_t>(f->data) % 16 == 0;
+    int64_t blocks = 0;
     for (int m = 0; m < b.n; ++m) {
         int64_t off = 0, n = 1;
         for (int a = 0; a < 3; ++a) {
@@ -209,11 +258,13 @@ inline int plan_copy_batch(const gt4mi_field* f, const std::vector<gt4mi_halo_pl
         }
         b.offset[m] = off;
         b.buffer[m] = msgs[m].buffer;
-        nmax = n > nmax ? n : nmax;
+        b.vec[m] = field_vec && msgs[m].lo[0] % PER_VEC == 0 && msgs[m].ext[0] % PER_VEC == 0 &&
+                   reinterpret_cast<uintptr_t>(msgs[m].buffer) % 16 == 0;
+        const int64_t need = b.vec[m] ? cdiv(n / PER_VEC, 256 * 4) : cdiv(n, 256);
+        blocks = need > blocks ? need : blocks;
     }
-    if (nmax == 0) return GT4MI_OK;
-    int64_t blocks = cdiv(nmax, 256);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) return GT4MI_OK;
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((halo_batch_kernel<U, PACK>), dim3((unsigned)blocks, (unsigned)b.n), dim3(256), 0, s,
                        static_cast<U*>(f->data), f->stride[0] / (int64_t)sizeof(U), f->stride[1] / (int64_t)sizeof(U),
                        f->stride[2] / (int64_t)sizeof(U), b);

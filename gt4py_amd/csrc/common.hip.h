@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "gt4py_amd.h"
 
@@ -193,6 +194,34 @@ inline bool vec_ok(const V& v, int vec) {
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Dynamic LDS bytes the whole-domain kernels are launched with.  The kernels use no LDS; a workgroup that RESERVES some
+// limits how many workgroups a CU holds (160 KB per CU), i.e. the waves and with them the bytes the kernel keeps in flight.
+// An HBM-saturating stencil kernel at full occupancy has tens of MB outstanding, and every other kernel on the device then
+// waits ~10 us per memory access -- the send/recv kernels of a halo exchange crawl (13 -> 170 us next to horizontal
+// diffusion, profiles/r1_dist_hdiff_rehearsal.log).  The distributed steps throttle their INTERIOR kernel with this while
+// an exchange is in flight next to it (gt4mi_dist_*); everything else launches with 0.
+inline unsigned& launch_dynamic_lds() {
+    static thread_local unsigned bytes = 0;
+    return bytes;
+}
+
+struct ScopedLaunchLds {
+    unsigned saved;
+    explicit ScopedLaunchLds(unsigned bytes) : saved(launch_dynamic_lds()) { launch_dynamic_lds() = bytes; }
+    ~ScopedLaunchLds() { launch_dynamic_lds() = saved; }
+};
+
+// bytes to reserve per workgroup so that at most `workgroups_per_cu` of them share a CU (0 = no limit)
+inline unsigned lds_for_workgroups_per_cu(int workgroups_per_cu) {
+    if (workgroups_per_cu <= 0) return 0;
+    return (unsigned)((160 * 1024) / workgroups_per_cu) & ~255u;
+}
+
+inline int env_int(const char* name, int fallback) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : fallback;
+}
 
 // ---- device helpers ---------------------------------------------------------------------------
 template <typename T, int N>

@@ -11,9 +11,25 @@
 #include "common.hip.h"
 #include "halo.hip.h"
 #include "hdiff.hip.h"
+#include "hdiff_ring.hip.h"
 #include "lap5.hip.h"
+#include "lap5_ring.hip.h"
 #include "rtc.hip.h"
 #include "tridiag.hip.h"
+
+namespace gt4mi {
+// How a fused distributed step is laid out on the two streams, and how far the interior kernel is throttled while the
+// exchange runs next to it: the plan's options (gt4mi_halo_plan_set_option), else the environment (experiments), else the
+// entry point's default -- measured on the 1-GPU self-loop, profiles/r3_dist_*_timeline*.txt.
+inline int plan_schedule(const gt4mi_halo_plan* plan, int fallback) {
+    static const int env = env_int("GT4MI_DIST_SCHEDULE", -1);
+    return plan->schedule >= 0 ? plan->schedule : (env >= 0 ? env : fallback);
+}
+inline int plan_interior_wg_per_cu(const gt4mi_halo_plan* plan, int fallback) {
+    static const int env = env_int("GT4MI_DIST_INTERIOR_WG_PER_CU", -1);
+    return plan->interior_wg_per_cu >= 0 ? plan->interior_wg_per_cu : (env >= 0 ? env : fallback);
+}
+}  // namespace gt4mi
 
 namespace {
 
@@ -63,6 +79,71 @@ struct Timer {
     }
 };
 
+}  // namespace
+
+namespace {
+template <typename T>
+int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* in_field, const gt4mi_field* out_field,
+               const gt4mi_field* coeff, double coeff_scalar, int flags, int sides, void* main_stream) {
+    if (plan == nullptr || in_field == nullptr || out_field == nullptr || domain == nullptr)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_hdiff: null argument");
+    if (plan->elem_size != (int)sizeof(T))
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_hdiff: the plan moves %d-byte items, the fields hold %d-byte items",
+                           plan->elem_size, (int)sizeof(T));
+    hipStream_t ms = static_cast<hipStream_t>(main_stream);
+    if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
+    const int64_t di = domain[0], dj = domain[1], dk = domain[2];
+    constexpr int64_t H = 2;  // the stencil's reach
+    int64_t lo_i = (sides & 1) ? H : 0, hi_i = (sides & 2) ? H : 0, lo_j = (sides & 4) ? H : 0, hi_j = (sides & 8) ? H : 0;
+    lo_i = lo_i < di ? lo_i : di;
+    hi_i = hi_i < di - lo_i ? hi_i : di - lo_i;
+    lo_j = lo_j < dj ? lo_j : dj;
+    hi_j = hi_j < dj - lo_j ? hi_j : dj - lo_j;
+    // refuse what the ring would refuse BEFORE anything is enqueued (bounds, aliases): an empty ring validates only
+    const int none[4] = {0, 0, 0, 0};
+    if (int rc = gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, none, ms)) return rc;
+    const int widths[4] = {(int)lo_i, (int)hi_i, (int)lo_j, (int)hi_j};
+    auto interior = [&]() -> int {
+        if (!(di - lo_i - hi_i > 0 && dj - lo_j - hi_j > 0 && dk > 0)) return GT4MI_OK;
+        gt4mi_field a = *in_field, b = *out_field, c;
+        a.origin[0] += lo_i; a.origin[1] += lo_j;
+        b.origin[0] += lo_i; b.origin[1] += lo_j;
+        if (coeff) {
+            c = *coeff;
+            c.origin[0] += lo_i; c.origin[1] += lo_j;
+        }
+        const int64_t sub[3] = {di - lo_i - hi_i, dj - lo_j - hi_j, dk};
+        // 3 of 4 workgroups per CU: the send/recv kernel next to it takes 77 us instead of 190 (profiles/r3_dist_hdiff_timeline.txt)
+        gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 3)));
+        return gt4mi::hdiff_run<T>(sub, &a, &b, coeff ? &c : nullptr, coeff_scalar, flags, ms);
+    };
+    if (gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_CHAIN) == GT4MI_SCHEDULE_CHAIN) {
+        // Schedule "chain": the main stream carries NOTHING but the interior kernel; pack -> send/recv -> unpack -> ring run
+        // in order on the side stream (the ring writes out_field's ring, the interior its interior).  No cross-stream wait
+        // lies on the critical path: the join after the interior is already satisfied when the chain fits under it, and
+        // back-to-back applies run their interiors back to back (profiles/r3_dist_hdiff_timeline_*.txt).
+        GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+        GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+        if (int rc = interior()) return rc;
+        if (int rc = gt4mi::halo_exchange_on(plan, in_field, plan->stream)) return rc;
+        if (int rc = gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, plan->stream)) return rc;
+        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+        return GT4MI_OK;
+    }
+    // Schedule "join": 1. pack the first faces on the main stream, ahead of the interior kernel (alone: ~5 us; next to it: 20+)
+    if (int rc = gt4mi::halo_pack_first(plan, in_field, ms)) return rc;
+    GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+    GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+    // 2. main stream: the interior, which reads no ghost cell
+    if (int rc = interior()) return rc;
+    // 3. side stream: send / receive / unpack (and the second phase of a two-phase plan) next to the interior kernel
+    if (int rc = gt4mi::halo_exchange_on(plan, in_field, plan->stream, /*first_pack_done=*/true)) return rc;
+    GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+    // 4. main stream: join, then the ring that reads the ghost cells -- one launch for all four boxes
+    GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+    return gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, ms);
+}
 }  // namespace
 
 extern "C" {
@@ -117,6 +198,37 @@ int gt4mi_hdiff_f32(const int64_t domain[3], const gt4mi_field* in_field, const 
     Timer t(info, stream);
     return gt4mi::hdiff_run<float>(domain, in_field, out_field, coeff, coeff_scalar, flags,
                                    static_cast<hipStream_t>(stream));
+}
+
+int gt4mi_hdiff_ring_f64(const int64_t domain[3], const gt4mi_field* in_field, const gt4mi_field* out_field,
+                         const gt4mi_field* coeff, double coeff_scalar, int flags, const int widths[4], void* stream,
+                         gt4mi_exec_info* info) {
+    Timer t(info, stream);
+    return gt4mi::hdiff_ring_run<double>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths,
+                                         static_cast<hipStream_t>(stream));
+}
+
+int gt4mi_hdiff_ring_f32(const int64_t domain[3], const gt4mi_field* in_field, const gt4mi_field* out_field,
+                         const gt4mi_field* coeff, double coeff_scalar, int flags, const int widths[4], void* stream,
+                         gt4mi_exec_info* info) {
+    Timer t(info, stream);
+    return gt4mi::hdiff_ring_run<float>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths,
+                                        static_cast<hipStream_t>(stream));
+}
+
+int gt4mi_lap5_ring_f64(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int variant, int flags,
+                        const int outer[4], const int inner[4], void* stream, gt4mi_exec_info* info) {
+    (void)flags;
+    Timer t(info, stream);
+    return gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, static_cast<hipStream_t>(stream));
+}
+
+int gt4mi_lap5_ring_f32(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int variant, int flags,
+                        const int outer[4], const int inner[4], void* stream, gt4mi_exec_info* info) {
+    Timer t(info, stream);
+    if (flags & GT4MI_LAP_LITERAL_F32)
+        return gt4mi::lap5_ring_run<float, float>(domain, inp, out, variant, outer, inner, static_cast<hipStream_t>(stream));
+    return gt4mi::lap5_ring_run<float, double>(domain, inp, out, variant, outer, inner, static_cast<hipStream_t>(stream));
 }
 
 int gt4mi_tridiag_f64(const int64_t domain[3], const gt4mi_field* inf, const gt4mi_field* diag,
@@ -174,6 +286,26 @@ int gt4mi_comm_create(const void* id128, int nranks, int rank, gt4mi_comm** comm
                            gt4mi::rccl().GetErrorString ? gt4mi::rccl().GetErrorString(r) : "rccl error");
     }
     *comm = c;
+    return GT4MI_OK;
+}
+
+int gt4mi_comm_info(gt4mi_comm* comm, int* nranks, int* rank, int* device) {
+    if (comm == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "comm_info: null communicator");
+    gt4mi::RcclApi& api = gt4mi::rccl();
+    // what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), not what the
+    // caller passed to gt4mi_comm_create
+    if (nranks) {
+        if (!api.CommCount) return gt4mi::fail(GT4MI_ERR_UNSUPPORTED, "comm_info: ncclCommCount not available");
+        GT4MI_RCCL_CHECK(api.CommCount(comm->comm, nranks));
+    }
+    if (rank) {
+        if (!api.CommUserRank) return gt4mi::fail(GT4MI_ERR_UNSUPPORTED, "comm_info: ncclCommUserRank not available");
+        GT4MI_RCCL_CHECK(api.CommUserRank(comm->comm, rank));
+    }
+    if (device) {
+        if (!api.CommCuDevice) return gt4mi::fail(GT4MI_ERR_UNSUPPORTED, "comm_info: ncclCommCuDevice not available");
+        GT4MI_RCCL_CHECK(api.CommCuDevice(comm->comm, device));
+    }
     return GT4MI_OK;
 }
 
@@ -236,6 +368,21 @@ int gt4mi_halo_plan_create(gt4mi_comm* comm, int elem_size, const gt4mi_halo_msg
     }
     *plan = p;
     return GT4MI_OK;
+}
+
+int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
+    if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: null plan");
+    switch (option) {
+        case GT4MI_PLAN_SCHEDULE:
+            if (value < -1 || value > GT4MI_SCHEDULE_CHAIN) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
+            plan->schedule = value;
+            return GT4MI_OK;
+        case GT4MI_PLAN_INTERIOR_WG_PER_CU:
+            if (value < -1 || value > 16) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: %d workgroups per CU", value);
+            plan->interior_wg_per_cu = value;
+            return GT4MI_OK;
+    }
+    return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: unknown option %d", option);
 }
 
 int gt4mi_halo_plan_concurrent(gt4mi_halo_plan* plan) {
@@ -308,6 +455,24 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
         const int64_t d[3] = {ei, ej, dk};
         return gt4mi::lap5_run<double, double>(d, &a, &b, variant, ms);
     };
+    const int outer[4] = {0, 0, 0, 0};
+    const int inner[4] = {(int)lo_i, (int)(hi_i && di - 1 >= lo_i ? 1 : 0), (int)lo_j, (int)(hi_j && dj - 1 >= lo_j ? 1 : 0)};
+    auto interior = [&]() -> int {
+        gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 0)));
+        return run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j);
+    };
+    if (gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_JOIN) == GT4MI_SCHEDULE_CHAIN) {
+        // the main stream carries the interior kernel only; pack -> send/recv -> unpack -> ring in order on the side stream
+        // (see dist_hdiff)
+        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
+        GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+        GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+        if (int rc = interior()) return rc;
+        if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream)) return rc;
+        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, plan->stream)) return rc;
+        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        return gt4mi_halo_exchange_end(plan, main_stream);
+    }
     // 1. pack the first faces ON THE MAIN STREAM, ahead of the interior kernel: alone it takes ~5 us;
     //    launched next to the interior kernel's thousands of workgroups it took 22 us and delayed the
     //    whole exchange past the end of the interior kernel (profiles/r1_dist_step_timeline.txt).
@@ -316,23 +481,13 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
     GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
     GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
     // 2. main stream: interior, independent of the ghost cells in flight
-    if (int rc = run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j)) return rc;
+    if (int rc = interior()) return rc;
     // 3. side stream: RCCL send/recv + unpack (+ second phase), concurrent with the interior kernel
     if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/true)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-    // 4. main stream: join, then the boundary strips (both J rows in one launch)
+    // 4. main stream: join, then the ring of points that read ghost cells -- ONE launch (lap5_ring.hip.h)
     if (int rc = gt4mi_halo_exchange_end(plan, main_stream)) return rc;
-    {
-        int rows[2], n = 0;
-        if (lo_j) rows[n++] = 0;
-        if (hi_j && dj - 1 >= lo_j) rows[n++] = (int)(dj - 1);
-        if (n)
-            if (int rc = gt4mi::lap5_run_rows<double, double>(domain, inp, out, variant, rows[0], n > 1 ? rows[1] : rows[0], n, ms))
-                return rc;
-    }
-    if (lo_i) if (int rc = run(0, lo_j, 1, dj - lo_j - hi_j)) return rc;
-    if (hi_i && di - 1 >= lo_i) if (int rc = run(di - 1, lo_j, 1, dj - lo_j - hi_j)) return rc;
-    return GT4MI_OK;
+    return gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, ms);
 }
 
 int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
@@ -377,18 +532,10 @@ int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], con
     }
     // last step of the cycle: `out`'s faces (H deep) are what the neighbours need next
     const int64_t lo_i = w ? H : 0, hi_i = e ? H : 0, lo_j = s ? H : 0, hi_j = n ? H : 0;
-    if (H == 1 && !w && !e) {  // both single rows in one launch
-        int rows[2], nr = 0;
-        if (s) rows[nr++] = 0;
-        if (n) rows[nr++] = (int)(dj - 1);
-        if (nr)
-            if (int rc = gt4mi::lap5_run_rows<double, double>(domain, inp, out, variant, rows[0], nr > 1 ? rows[1] : rows[0], nr, ms))
-                return rc;
-    } else {
-        if (int rc = run(0, di, 0, lo_j)) return rc;
-        if (int rc = run(0, di, dj - hi_j, dj)) return rc;
-        if (int rc = run(0, lo_i, lo_j, dj - hi_j)) return rc;
-        if (int rc = run(di - hi_i, di, lo_j, dj - hi_j)) return rc;
+    {  // the H-deep ring of `out` in ONE launch (lap5_ring.hip.h)
+        const int outer[4] = {0, 0, 0, 0};
+        const int inner[4] = {(int)lo_i, (int)hi_i, (int)lo_j, (int)hi_j};
+        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, ms)) return rc;
     }
     // pack on the main stream (before the interior kernel floods the CUs), then fork
     if (int rc = gt4mi::halo_pack_first(plan, out, ms)) return rc;
@@ -402,11 +549,87 @@ int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], con
     return GT4MI_OK;
 }
 
+int gt4mi_dist_lap5_f64_skewed(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* field_a,
+                               const gt4mi_field* field_b, int variant, int sides, int halo, void* main_stream) {
+    if (plan == nullptr || field_a == nullptr || field_b == nullptr || domain == nullptr)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5_skewed: null argument");
+    if (halo < 1) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5_skewed: need halo >= 1");
+    if (!plan->primed)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT,
+                           "dist_lap5_skewed: the ghost cells of the first input were never exchanged "
+                           "(call gt4mi_halo_exchange_begin on it once before the first cycle)");
+    hipStream_t ms = static_cast<hipStream_t>(main_stream);
+    const int64_t di = domain[0], dj = domain[1], dk = domain[2];
+    const int H = halo;
+    const bool w = sides & 1, e = sides & 2, s = sides & 4, n = sides & 8;
+    // the band of step 1 reaches 2H - 1 points into the domain from every side that has a neighbour
+    if ((w || e) && di < (int64_t)(2 * H - 1) * ((w ? 1 : 0) + (e ? 1 : 0)))
+        return gt4mi::fail(GT4MI_ERR_UNSUPPORTED, "dist_lap5_skewed: local I extent too small for a ghost depth of %d", H);
+    if ((s || n) && dj < (int64_t)(2 * H - 1) * ((s ? 1 : 0) + (n ? 1 : 0)))
+        return gt4mi::fail(GT4MI_ERR_UNSUPPORTED, "dist_lap5_skewed: local J extent too small for a ghost depth of %d", H);
+    if (!(plan->probed && plan->probed_main == ms)) {
+        // the probe synchronises: keep the exchange in flight ordered before it
+        GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+        if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
+        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+    }
+    // join the exchange that delivered field_a's ghost cells (started by the previous cycle)
+    GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+    auto src_of = [&](int step) { return (step % 2 == 1) ? field_a : field_b; };  // step 1 reads a, writes b
+    auto dst_of = [&](int step) { return (step % 2 == 1) ? field_b : field_a; };
+    // 1. the bands, outermost first: step st on [-(H - st), 2H - st) points from every side with a neighbour
+    for (int st = 1; st <= H; ++st) {
+        const int g = H - st, d = 2 * H - st;
+        const int outer[4] = {w ? g : 0, e ? g : 0, s ? g : 0, n ? g : 0};
+        const int inner[4] = {w ? d : 0, e ? d : 0, s ? d : 0, n ? d : 0};
+        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, src_of(st), dst_of(st), variant, outer, inner, ms)) return rc;
+    }
+    // 2. the H-deep faces of the result are final: pack them on the main stream (before the interior kernels flood the
+    //    device), then the side stream sends / receives / unpacks next to ALL H interior kernels
+    const gt4mi_field* result = dst_of(H);
+    // (chain schedule: the pack runs on the side stream as well, next to the first interior kernel)
+    const bool pack_on_side = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_JOIN) == GT4MI_SCHEDULE_CHAIN;
+    if (!pack_on_side)
+        if (int rc = gt4mi::halo_pack_first(plan, result, ms)) return rc;
+    GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+    GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+    // 3. the interiors: step st on the domain shrunk by 2H - st
+    for (int st = 1; st <= H; ++st) {
+        const int64_t d = 2 * H - st;
+        const int64_t i0 = w ? d : 0, i1 = di - (e ? d : 0), j0 = s ? d : 0, j1 = dj - (n ? d : 0);
+        if (i1 > i0 && j1 > j0 && dk > 0) {
+            gt4mi_field a = *src_of(st), b = *dst_of(st);
+            a.origin[0] += i0; a.origin[1] += j0;
+            b.origin[0] += i0; b.origin[1] += j0;
+            const int64_t sub[3] = {i1 - i0, j1 - j0, dk};
+            gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 0)));
+            if (int rc = gt4mi::lap5_run<double, double>(sub, &a, &b, variant, ms)) return rc;
+        }
+        if (st == 1) {  // enqueued after the first interior launch so that the device has work while the host talks to RCCL
+            if (int rc = gt4mi::halo_exchange_on(plan, result, plan->stream, /*first_pack_done=*/!pack_on_side)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        }
+    }
+    return GT4MI_OK;
+}
+
 int gt4mi_dist_lap5_f64_pipelined(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                                   const gt4mi_field* out, int variant, int sides, void* main_stream) {
     return gt4mi_dist_lap5_f64_wide(plan, domain, inp, out, variant, sides, 1, 0, main_stream);
 }
 
+
+int gt4mi_dist_hdiff_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* in_field,
+                         const gt4mi_field* out_field, const gt4mi_field* coeff, double coeff_scalar, int flags, int sides,
+                         void* main_stream) {
+    return dist_hdiff<double>(plan, domain, in_field, out_field, coeff, coeff_scalar, flags, sides, main_stream);
+}
+
+int gt4mi_dist_hdiff_f32(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* in_field,
+                         const gt4mi_field* out_field, const gt4mi_field* coeff, double coeff_scalar, int flags, int sides,
+                         void* main_stream) {
+    return dist_hdiff<float>(plan, domain, in_field, out_field, coeff, coeff_scalar, flags, sides, main_stream);
+}
 
 int gt4mi_stream_copy(const void* src, void* dst, size_t nbytes, void* stream) {
     if (src == nullptr || dst == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "stream_copy: null pointer");

@@ -29,37 +29,14 @@ inline bool hdiff_jmarch_enabled() {
     return on;
 }
 
-template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ,
-          int PF, int XCDG = 0>
-__global__ void __launch_bounds__(256)
-hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scalar, int dI,
-                    int dJ, unsigned waves_i, unsigned tiles_j, unsigned groups_j) {
+// One strip: wave `wi` along I, rows [tj * LJ, tj * LJ + LJ) of level k, of a domain of dI x dJ points whose origin the
+// views point at.  Shared by the whole-domain kernel below and by the boundary-ring kernel (hdiff_ring.hip.h).
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ, int PF>
+__device__ __forceinline__ void hdiff_jmarch_strip(const View<const T>& in, const View<T>& out, const View<const T>& cf,
+                                                   PW coeff_scalar, int dI, int dJ, unsigned wi, unsigned tj, unsigned k) {
     constexpr int H = (VEC >= 2) ? 1 : 2;   // halo lanes per side
     constexpr int OUT_LANES = 64 - 2 * H;
     const unsigned lane = threadIdx.x & 63;
-    // A workgroup = 4 independent waves on 4 consecutive J strips of one I column, so 3 of the 4
-    // strip boundaries (4 shared rows each) are re-read inside one CU; workgroups are ordered along
-    // J, then I, then K, and runs of XCDG of them share an XCD (see lap5.hip.h).
-    unsigned wg = blockIdx.x;
-    unsigned jg, column;
-    if constexpr (XCDG < 0) {
-        // chunked: every (I column, K level) is dealt to the 8 XCDs as 8 contiguous chunks of workgroups along J
-        // (the launch pads groups_j to a multiple of 8; hardware deals workgroups to XCDs round-robin in linear order)
-        const unsigned padded = ((groups_j + 7u) / 8u) * 8u, per = padded / 8u;
-        column = wg / padded;
-        const unsigned r = wg % padded;
-        jg = (r % 8u) * per + r / 8u;
-        if (jg >= groups_j) return;
-    } else {
-        if constexpr (XCDG > 0) wg = xcd_remap_grouped<(unsigned)XCDG>(wg, gridDim.x);
-        jg = wg % groups_j;
-        column = wg / groups_j;
-    }
-    const unsigned tj = jg * 4 + (threadIdx.x >> 6);
-    if (tj >= tiles_j) return;
-    const unsigned wi = column % waves_i;
-    const unsigned k = column / waves_i;
-
     const int col = ((int)(wi * OUT_LANES) - H + (int)lane) * VEC;  // first column of this lane
     const int j0 = (int)tj * LJ;
     const int nrows = (dJ - j0 < LJ) ? (dJ - j0) : LJ;
@@ -206,6 +183,37 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
     }
 }
 
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ,
+          int PF, int XCDG = 0>
+__global__ void __launch_bounds__(256)
+hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scalar, int dI,
+                    int dJ, unsigned waves_i, unsigned tiles_j, unsigned groups_j) {
+    // A workgroup = 4 independent waves on 4 consecutive J strips of one I column, so 3 of the 4
+    // strip boundaries (4 shared rows each) are re-read inside one CU; workgroups are ordered along
+    // J, then I, then K, and runs of XCDG of them share an XCD (see lap5.hip.h).
+    unsigned wg = blockIdx.x;
+    unsigned jg, column;
+    if constexpr (XCDG < 0) {
+        // chunked: every (I column, K level) is dealt to the 8 XCDs as 8 contiguous chunks of workgroups along J
+        // (the launch pads groups_j to a multiple of 8; hardware deals workgroups to XCDs round-robin in linear order)
+        const unsigned padded = ((groups_j + 7u) / 8u) * 8u, per = padded / 8u;
+        column = wg / padded;
+        const unsigned r = wg % padded;
+        jg = (r % 8u) * per + r / 8u;
+        if (jg >= groups_j) return;
+    } else {
+        if constexpr (XCDG > 0) wg = xcd_remap_grouped<(unsigned)XCDG>(wg, gridDim.x);
+        jg = wg % groups_j;
+        column = wg / groups_j;
+    }
+    const unsigned tj = jg * 4 + (threadIdx.x >> 6);
+    if (tj >= tiles_j) return;
+    const unsigned wi = column % waves_i;
+    const unsigned k = column / waves_i;
+
+    hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF>(in, out, cf, coeff_scalar, dI, dJ, wi, tj, k);
+}
+
 // Rows per strip / rows prefetched ahead, from the sweep in profiles/r1_microbench_d_*.log
 // (MI355X, 1024x1024x80 f32 and 512x1024x80 f64): short strips with most of their rows in flight
 // win; the 4-row prologue is re-read from L2.
@@ -230,7 +238,7 @@ inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
     if (nblocks > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: domain too large for one launch");
     hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, HdiffTuning<T>::PF,
                                             HdiffTuning<T>::XCDG>),
-                       dim3((unsigned)nblocks), dim3(256), 0, stream, in, out, cf, coeff_scalar, (int)d[0],
+                       dim3((unsigned)nblocks), dim3(256), launch_dynamic_lds(), stream, in, out, cf, coeff_scalar, (int)d[0],
                        (int)d[1], waves_i, tiles_j, groups_j);
     return GT4MI_OK;
 }

@@ -175,7 +175,7 @@ inline int lap5_launch_strip(const View<const T>& in, const View<T>& out, const 
     const int64_t n = (int64_t)tx * ty * d[2];
     if (n > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "lap5: domain too large for one launch");
     hipLaunchKernelGGL((lap5_strip_kernel<T, W, VARIANT, VEC, LJ, BLOCK, Lap5Tuning::XCDG>), dim3((unsigned)n), dim3(BLOCK),
-                       0, stream, in, out, (int)d[0], (int)d[1], tx, ty);
+                       launch_dynamic_lds(), stream, in, out, (int)d[0], (int)d[1], tx, ty);
     return GT4MI_OK;
 }
 

@@ -7,21 +7,73 @@ from __future__ import annotations
 
 from typing import Any, Dict, Mapping, Sequence
 
-from .halo import (Decomposition, HaloExchanger, HipPacker, choose_process_grid, exchange_cost, halo_boxes,
-                   process_grid_candidates, scatter_global)
+from .halo import (Decomposition, HaloExchanger, HipPacker, choose_process_grid, exchange_cost, halo_boxes, halo_sides,
+                   process_grid_candidates, receive_order, scatter_global)
 from .native import NativeComm, NativeHaloExchanger
 
 __all__ = ["Decomposition", "HaloExchanger", "HipPacker", "NativeComm", "NativeHaloExchanger", "TunedApply",
-           "choose_process_grid", "exchange_cost", "halo_boxes", "overlapped_apply", "process_grid_candidates",
-           "scatter_global", "sequential_apply"]
+           "choose_process_grid", "exchange_cost", "fused_apply", "halo_boxes", "halo_sides", "overlapped_apply",
+           "process_grid_candidates", "receive_order", "scatter_global", "sequential_apply"]
 
 
 def _shifted(origin: Mapping[str, Sequence[int]], shift: Sequence[int]) -> Dict[str, tuple]:
     return {name: tuple(int(o) + int(s) for o, s in zip(org, shift)) for name, org in origin.items()}
 
 
+_FUSED_CACHE: Dict[Any, Any] = {}
+
+
+def fused_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequence[int]], arguments: Dict[str, Any],
+                exchange: Mapping[str, Any]) -> bool:
+    """The distributed apply as ONE native call, where the library has it: a stencil bound to the hand-written horizontal
+    diffusion (``gt4mi_dist_hdiff_*``, ghost depth 2) or 5-point (``gt4mi_dist_lap5_f64``, ghost depth 1) kernels whose
+    read field is exchanged through a ``NativeHaloExchanger``.  Pack, interior kernel next to the exchange, then one ring
+    kernel for the points that read ghost cells.  Returns False when the combination is not covered (the caller falls
+    back to the stencil-agnostic schedule of ``overlapped_apply``)."""
+    binding = getattr(type(stencil), "_gt_binding_", None)
+    if binding is None or len(exchange) != 1:
+        return False
+    (name, ex), = exchange.items()
+    if not isinstance(ex, NativeHaloExchanger):
+        return False
+    roles = binding.roles
+    read_role = {"hdiff": "in_field", "lap5": "inp"}.get(binding.family)
+    if read_role is None or roles.get(read_role) != name:
+        return False
+    if len({tuple(origin[roles[r]]) for r in roles if roles[r] in origin}) != 1:
+        return False  # the native step takes ONE origin for all fields
+    org = tuple(origin[name])
+    itemsize = binding.dtype.itemsize
+    if ex.itemsize != itemsize:
+        return False
+    field_names = [roles[r] for r in roles if roles[r] in arguments and hasattr(arguments[roles[r]], "ptr")]
+    scalars = tuple(float(arguments[roles[r]]) for r in roles if roles[r] in arguments and not hasattr(arguments[roles[r]], "ptr"))
+    key = (id(stencil), id(ex), org, tuple(id(arguments[n]) for n in field_names), scalars)
+    entry = _FUSED_CACHE.get(key)
+    if entry is None or any(r() is not arguments[n] for n, r in entry[1]):
+        import weakref
+
+        if binding.family == "hdiff":
+            if decomp.halo != 2:
+                return False
+            coeff_name = roles["coeff"]
+            coeff = arguments[coeff_name]
+            is_field = hasattr(coeff, "ptr")
+            call = ex.make_dist_hdiff(arguments[name], arguments[roles["out_field"]], coeff if is_field else None, org,
+                                      binding.flags, 0.0 if is_field else float(coeff))
+        else:
+            if decomp.halo != 1 or itemsize != 8 or binding.flags:
+                return False
+            call = ex.make_dist_lap5(arguments[name], arguments[roles["out"]], org, org, binding.variant)
+        if len(_FUSED_CACHE) >= 16:
+            _FUSED_CACHE.pop(next(iter(_FUSED_CACHE)))
+        entry = _FUSED_CACHE[key] = (call, [(n, weakref.ref(arguments[n])) for n in field_names])
+    entry[0]()
+    return True
+
+
 def overlapped_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequence[int]], arguments: Dict[str, Any],
-                     exchange: Mapping[str, HaloExchanger]) -> None:
+                     exchange: Mapping[str, HaloExchanger], fused: bool = True) -> None:
     """One distributed apply of ``stencil`` on this rank.
 
     ``exchange`` maps the names of the read fields whose ghost cells are refreshed this step to
@@ -30,10 +82,14 @@ def overlapped_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequen
         side stream : pack -> RCCL send/recv (I faces, then J faces) -> unpack
         main stream : interior kernel  ................  wait  -> boundary-strip kernels
 
+    Stencils bound to the kernel library's horizontal diffusion / 5-point kernels take the native fused step instead
+    (``fused_apply``: one C call, one ring kernel for all boundary strips) unless ``fused=False``.
     The stencil must have been built with ``device_sync=False`` so that launches stay asynchronous.
     ``arguments`` holds the device arrays / scalars by parameter name; ``origin`` the per-field origin
     of the LOCAL compute domain.
     """
+    if fused and fused_apply(stencil, decomp, origin, arguments, exchange):
+        return
     pending = []  # (exchanger, is_native, handle)
     native = [(name, ex) for name, ex in exchange.items() if isinstance(ex, NativeHaloExchanger)]
     for name, ex in exchange.items():

@@ -229,17 +229,83 @@ def halo_boxes(decomp: Decomposition) -> List[List[Box]]:
     return phases
 
 
+#: sides of a block in message order, and the side a message sent towards each of them arrives on
+SIDES = ("W", "E", "S", "N", "SW", "SE", "NW", "NE")
+OPPOSITE = {"W": "E", "E": "W", "S": "N", "N": "S", "SW": "NE", "NE": "SW", "SE": "NW", "NW": "SE"}
+_SIDE_STEP = {"W": (-1, 0), "E": (1, 0), "S": (0, -1), "N": (0, 1), "SW": (-1, -1), "SE": (1, -1), "NW": (-1, 1), "NE": (1, 1)}
+
+SideBox = Tuple[str, int, Tuple[int, int, int], Tuple[int, int, int], Tuple[int, int, int]]
+
+
+def halo_sides(decomp: Decomposition, single_phase: bool = False) -> List[List[SideBox]]:
+    """Per phase, the (side, peer, send_lo, recv_lo, extent) boxes of this rank in LOCAL array indices, in ``SIDES`` order.
+
+    Two-phase (default): ``halo_boxes`` with the side named.  Single-phase: ONE round with up to 8 neighbours -- the four
+    faces (owned cells only along the other axis, plus the ghost cells on a side WITHOUT a neighbour there: physical
+    boundary data the neighbour's corner reads need) and the four h x h corners to the diagonal neighbours.  Half the
+    dependent rounds of pack -> send/recv -> unpack; on a fully connected xGMI node every neighbour has a link of its own.
+    """
+    if not single_phase:
+        names = (("W", "E"), ("S", "N"))
+        out = []
+        for p, phase in enumerate(halo_boxes(decomp)):
+            nb = decomp.neighbours
+            sides = [sd for sd in names[p] if nb[sd] is not None]
+            out.append([(sd, *box) for sd, box in zip(sides, phase)])
+        return out
+    h = decomp.halo
+    di, dj, dk = decomp.local_domain
+    ci, cj = decomp.coords
+    nb = {sd: decomp.rank_of(ci + st[0], cj + st[1]) for sd, st in _SIDE_STEP.items()}
+    # along an axis: (send range, receive range) of the low / high side, and the range of a face along the OTHER axis
+    lo_send, lo_recv = (h, 2 * h), (0, h)
+
+    def hi(d):
+        return (d, d + h), (d + h, d + 2 * h)
+
+    def across(d, low_nb, high_nb):  # owned cells + ghost cells on sides without a neighbour
+        return (0 if low_nb is None else h), (d + 2 * h if high_nb is None else d + h)
+
+    boxes: List[SideBox] = []
+    for sd in SIDES:
+        peer = nb[sd]
+        if peer is None:
+            continue
+        si, sj = _SIDE_STEP[sd]
+        if si == 0:
+            i_send = i_recv = across(di, nb["W"], nb["E"])
+        else:
+            i_send, i_recv = (lo_send, lo_recv) if si < 0 else hi(di)
+        if sj == 0:
+            j_send = j_recv = across(dj, nb["S"], nb["N"])
+        else:
+            j_send, j_recv = (lo_send, lo_recv) if sj < 0 else hi(dj)
+        ext = (i_send[1] - i_send[0], j_send[1] - j_send[0], dk)
+        boxes.append((sd, peer, (i_send[0], j_send[0], 0), (i_recv[0], j_recv[0], 0), ext))
+    return [boxes, []]
+
+
+def receive_order(phase: Sequence[SideBox]) -> List[int]:
+    """Indices into ``phase`` in the order the receives must be posted.  RCCL / gloo pair the k-th send to a peer with the
+    k-th receive posted for that peer; sends go out in ``SIDES`` order, so the receive that matches the peer's send
+    towards side s is the one into my ghost zone on the OPPOSITE side: post receives in the order of the opposite sides.
+    (With a periodic axis of 1 or 2 ranks several messages of a phase go to the same peer -- the case that needs it.)"""
+    by_side = {box[0]: n for n, box in enumerate(phase)}
+    return [by_side[OPPOSITE[sd]] for sd in SIDES if OPPOSITE[sd] in by_side]
+
+
 class HaloExchanger:
     """Halo exchange of one field shape/dtype for one rank through ``torch.distributed`` point-to-point
     operations (RCCL on GPUs, gloo in the CPU tests), with persistent staging buffers."""
 
-    def __init__(self, decomp: Decomposition, dtype, device, packer=None, group=None):
+    def __init__(self, decomp: Decomposition, dtype, device, packer=None, group=None, single_phase: bool = False):
         self.decomp = decomp
         self.group = group
         self.device = torch.device(device)
         self.packer = packer if packer is not None else HipPacker()
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self.phases = halo_boxes(decomp)
+        self.sides = halo_sides(decomp, single_phase)
+        self.phases = [[box[1:] for box in phase] for phase in self.sides]
         self.buffers = {}
         for p, phase in enumerate(self.phases):
             for m, (_, _, _, ext) in enumerate(phase):
@@ -259,12 +325,13 @@ class HaloExchanger:
         for m, (_, send_lo, _, ext) in enumerate(phase):
             self.packer.pack(tensor, send_lo, ext, self.buffers[(p, m, "send")])
         # NCCL / gloo match the k-th send to a peer with the k-th receive posted for that peer, so the ORDER is
-        # part of the protocol: sends go low side first, receives HIGH side first.  On a periodic axis with 1
-        # or 2 ranks both faces of a phase go to the same peer, and my low-side face must land in the peer's
-        # high-side ghost zone (NativeHaloExchanger.message_tables does the same).
+        # part of the protocol: sends go out in SIDES order, receives in the order of the opposite sides
+        # (receive_order).  On a periodic axis with 1 or 2 ranks several faces of a phase go to the same peer, and
+        # my low-side face must land in the peer's high-side ghost zone (NativeHaloExchanger.message_tables does
+        # the same).
         for m, (peer, _, _, _) in enumerate(phase):
             ops.append(dist.P2POp(dist.isend, self.buffers[(p, m, "send")], peer, self.group))
-        for m in reversed(range(len(phase))):
+        for m in receive_order(self.sides[p]):
             ops.append(dist.P2POp(dist.irecv, self.buffers[(p, m, "recv")], phase[m][0], self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()

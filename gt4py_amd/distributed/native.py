@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from .. import _lib
-from .halo import Decomposition, halo_boxes
+from .halo import Decomposition, halo_sides, receive_order
 
 
 def _stream_ptr() -> int:
@@ -66,6 +66,13 @@ class NativeComm:
     def handle(self) -> ctypes.c_void_p:
         return self._handle
 
+    def info(self) -> dict:
+        """What RCCL itself reports for this communicator: {"nranks": ncclCommCount, "rank": ncclCommUserRank,
+        "device": ncclCommCuDevice} -- the proof a benchmark line can carry that RCCL joined N ranks."""
+        n, r, d = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.check("gt4mi_comm_info", self._lib.gt4mi_comm_info(self._handle, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)))
+        return {"nranks": n.value, "rank": r.value, "device": d.value}
+
     def close(self) -> None:
         if self._handle is not None and self._handle.value:
             self._lib.gt4mi_comm_destroy(self._handle)
@@ -90,30 +97,35 @@ class NativeHaloExchanger:
     """Two-phase ghost-cell exchange of one field shape through a native plan (see halo.halo_boxes)."""
 
     @staticmethod
-    def message_tables(decomp: Decomposition):
+    def message_tables(decomp: Decomposition, single_phase: bool = False):
         """(sends, recvs) of one rank as plain tuples (peer, phase, lo, extent), in the order RCCL sees them.
 
         RCCL matches the k-th send to a peer with the k-th receive posted for that peer inside one group, so
-        the ORDER is part of the protocol: sends go low side first, receives high side first -- with a
-        periodic axis of 1 or 2 ranks both messages of a phase go to the same peer, and my low-side face must
-        land in the peer's HIGH-side ghost zone.  Pure Python (checked for whole process grids on the CPU in
-        tests/test_distributed.py: every send has a receive of the same size waiting for it)."""
+        the ORDER is part of the protocol: sends go out in ``halo.SIDES`` order, receives in the order of the opposite
+        sides (``halo.receive_order``) -- with a periodic axis of 1 or 2 ranks several messages of a phase go to the same
+        peer, and my low-side face must land in the peer's HIGH-side ghost zone.  ``single_phase``: one round with
+        faces and corner boxes to up to 8 neighbours instead of two rounds with 4 (``halo.halo_sides``).  Pure Python
+        (checked for whole process grids on the CPU in tests/test_distributed.py: every send has a receive of the same
+        size waiting for it)."""
         sends, recvs = [], []
-        for p, phase in enumerate(halo_boxes(decomp)):
-            for peer, send_lo, _, ext in phase:
+        for p, phase in enumerate(halo_sides(decomp, single_phase)):
+            for _, peer, send_lo, _, ext in phase:
                 sends.append((int(peer), p, tuple(int(v) for v in send_lo), tuple(int(v) for v in ext)))
-            for peer, _, recv_lo, ext in reversed(phase):
+            for m in receive_order(phase):
+                _, peer, _, recv_lo, ext = phase[m]
                 recvs.append((int(peer), p, tuple(int(v) for v in recv_lo), tuple(int(v) for v in ext)))
         return sends, recvs
 
-    def __init__(self, decomp: Decomposition, dtype, comm: NativeComm):
+    def __init__(self, decomp: Decomposition, dtype, comm: NativeComm, single_phase: bool = False):
         self.decomp = decomp
         self.comm = comm
+        self.single_phase = bool(single_phase)
         self.itemsize = np.dtype(dtype).itemsize
-        send_table, recv_table = self.message_tables(decomp)
+        send_table, recv_table = self.message_tables(decomp, single_phase)
         sends = [_lib.HaloMsg.make(*m) for m in send_table]
         recvs = [_lib.HaloMsg.make(*m) for m in recv_table]
         self.bytes_per_exchange = sum(int(np.prod(tuple(m.extent))) for m in sends) * self.itemsize
+        self.largest_message_bytes = max([int(np.prod(tuple(m.extent))) for m in sends] or [0]) * self.itemsize
         SendArr, RecvArr = _lib.HaloMsg * max(len(sends), 1), _lib.HaloMsg * max(len(recvs), 1)
         plan = ctypes.c_void_p()
         lib = _lib.load()
@@ -125,6 +137,20 @@ class NativeHaloExchanger:
         nb = decomp.neighbours
         self.sides = ((1 if nb["W"] is not None else 0) | (2 if nb["E"] is not None else 0)
                       | (4 if nb["S"] is not None else 0) | (8 if nb["N"] is not None else 0))
+
+    def tune(self, schedule: Optional[str] = None, interior_wg_per_cu: Optional[int] = None) -> "NativeHaloExchanger":
+        """How the fused distributed steps built on this exchanger are scheduled (gt4mi_halo_plan_set_option):
+        ``schedule`` "join" (pack and interior on the caller's stream, send/recv/unpack beside it, join, ring) or "chain"
+        (the caller's stream carries the interior only; pack, send/recv, unpack and ring in order on the side stream);
+        ``interior_wg_per_cu`` limits the occupancy of the interior kernel while the exchange runs next to it (0 = no
+        limit).  ``None`` leaves an option at the entry point's default."""
+        if schedule is not None:
+            value = {"join": _lib.SCHEDULE_JOIN, "chain": _lib.SCHEDULE_CHAIN, "default": -1}[schedule]
+            _lib.check("gt4mi_halo_plan_set_option", self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_SCHEDULE, value))
+        if interior_wg_per_cu is not None:
+            _lib.check("gt4mi_halo_plan_set_option",
+                       self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_INTERIOR_WG_PER_CU, int(interior_wg_per_cu)))
+        return self
 
     def exchange(self, array) -> None:
         """Enqueue the exchange of ``array``'s ghost cells on the current stream."""
@@ -159,6 +185,61 @@ class NativeHaloExchanger:
 
         apply._keepalive = (fi, fo, dom, inp, out)  # type: ignore[attr-defined]
         return apply
+
+    def make_dist_hdiff(self, in_field, out_field, coeff, origin: Sequence[int], flags: int, coeff_scalar: float = 0.0):
+        """Pre-bind one distributed apply of horizontal diffusion (gt4mi_dist_hdiff_f64 / _f32: pack, interior next to the
+        exchange, one ring kernel) -> a zero-argument callable.  ``coeff`` is a device array or None (then
+        ``coeff_scalar``); ``flags`` as for gt4mi_hdiff_* (``KernelBinding.flags`` of a recognised stencil)."""
+        if self.decomp.halo != 2:
+            raise ValueError("gt4mi_dist_hdiff needs ghost regions exactly 2 deep")
+        fi, fo = _field_struct(in_field, origin), _field_struct(out_field, origin)
+        fc = _field_struct(coeff, origin) if coeff is not None else None
+        dom = _lib.domain3(self.decomp.local_domain)
+        name = "gt4mi_dist_hdiff_f64" if self.itemsize == 8 else "gt4mi_dist_hdiff_f32"
+        fn, plan, sides = getattr(self._lib, name), self._plan, self.sides
+        ri, ro, rc_ = ctypes.byref(fi), ctypes.byref(fo), (ctypes.byref(fc) if fc is not None else None)
+        cs, fl = float(coeff_scalar), int(flags)
+
+        def apply():
+            rc = fn(plan, dom, ri, ro, rc_, cs, fl, sides, _stream_ptr())
+            if rc:
+                _lib.check(name, rc)
+
+        apply._keepalive = (fi, fo, fc, dom, in_field, out_field, coeff)  # type: ignore[attr-defined]
+        return apply
+
+    def make_time_skewed_lap5(self, field_a, field_b, origin: Sequence[int], variant: int = 0):
+        """Pre-bind the time-skewed Laplacian stepper (gt4mi_dist_lap5_f64_skewed): ONE call advances a whole cycle of
+        H = ``decomp.halo`` steps, boundary bands first, then the faces travel next to all H interior kernels.  Bit-identical
+        to H undecomposed steps.  Primes the pipeline with one exchange of ``field_a``.  Returns a zero-argument callable;
+        ``callable.steps_per_call`` is H and ``callable.result()`` the field that holds the newest values."""
+        if self.itemsize != 8:
+            raise ValueError("the native Laplacian time stepper needs fp64 fields")
+        halo = int(self.decomp.halo)
+        fa, fb = _field_struct(field_a, origin), _field_struct(field_b, origin)
+        dom = _lib.domain3(self.decomp.local_domain)
+        fn, plan, sides = self._lib.gt4mi_dist_lap5_f64_skewed, self._plan, self.sides
+        ra, rb = ctypes.byref(fa), ctypes.byref(fb)
+        self.begin(field_a)
+        state = {"cycles": 0}
+        swaps = halo % 2 == 1  # an odd number of steps leaves the result in the other buffer
+
+        def cycle():
+            flipped = swaps and state["cycles"] % 2 == 1
+            src, dst = (rb, ra) if flipped else (ra, rb)
+            rc = fn(plan, dom, src, dst, variant, sides, halo, _stream_ptr())
+            if rc:
+                _lib.check("gt4mi_dist_lap5_f64_skewed", rc)
+            state["cycles"] += 1
+
+        def result():
+            steps = state["cycles"] * halo
+            return field_b if steps % 2 == 1 else field_a
+
+        cycle.steps_per_call = halo  # type: ignore[attr-defined]
+        cycle.result = result  # type: ignore[attr-defined]
+        cycle._keepalive = (fa, fb, dom, field_a, field_b)  # type: ignore[attr-defined]
+        return cycle
 
     @property
     def concurrent(self):

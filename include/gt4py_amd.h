@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GT4MI_ABI_VERSION 2
+#define GT4MI_ABI_VERSION 3
 
 typedef enum gt4mi_status {
     GT4MI_OK = 0,
@@ -120,6 +120,24 @@ int gt4mi_hdiff_f32(const int64_t domain[3], const gt4mi_field* in_field,
                     const gt4mi_field* out_field, const gt4mi_field* coeff, double coeff_scalar,
                     int flags, void* stream, gt4mi_exec_info* info);
 
+/* The same stencils on a RING of the compute domain only (NEW: the boundary part of an IJ-decomposed apply, SURVEY.md
+ * section 8e; one launch for up to four boxes).  widths / inner / outer are {low I, high I, low J, high J}.
+ *   gt4mi_hdiff_ring_*: the points less than widths[side] away from a side of the domain (0 = that side has no ring);
+ *                       same arguments, bounds and alias rules as gt4mi_hdiff_*.
+ *   gt4mi_lap5_ring_*:  (the domain grown by outer[side]) minus (the domain shrunk by inner[side]); `inp` must be readable
+ *                       one point beyond the grown domain.  outer > 0 is what communication-avoiding time stepping
+ *                       computes redundantly inside its ghost region (gt4mi_dist_lap5_f64_skewed). */
+int gt4mi_hdiff_ring_f64(const int64_t domain[3], const gt4mi_field* in_field, const gt4mi_field* out_field,
+                         const gt4mi_field* coeff, double coeff_scalar, int flags, const int widths[4], void* stream,
+                         gt4mi_exec_info* info);
+int gt4mi_hdiff_ring_f32(const int64_t domain[3], const gt4mi_field* in_field, const gt4mi_field* out_field,
+                         const gt4mi_field* coeff, double coeff_scalar, int flags, const int widths[4], void* stream,
+                         gt4mi_exec_info* info);
+int gt4mi_lap5_ring_f64(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int variant, int flags,
+                        const int outer[4], const int inner[4], void* stream, gt4mi_exec_info* info);
+int gt4mi_lap5_ring_f32(const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int variant, int flags,
+                        const int outer[4], const int inner[4], void* stream, gt4mi_exec_info* info);
+
 /* ---- vertical tridiagonal (Thomas) solve --------------------------------------------------------
  * Replaces run_computation of `tridiagonal_solver` (stencil_definitions.py:219-232):
  * FORWARD sweep rewrites sup and rhs IN PLACE (they are READ_WRITE API fields), BACKWARD sweep
@@ -142,10 +160,14 @@ int gt4mi_halo_unpack(const gt4mi_field* field, const int64_t lo[3], const int64
 /* ---- multi-GPU: RCCL halo exchange driven from native code (NEW, no reference counterpart) --------
  * One process per GPU.  gt4mi_comm wraps an RCCL communicator created from a 128-byte unique id
  * (gt4mi_comm_unique_id on one rank, distributed by the host program, e.g. torch.distributed).
- * A gt4mi_halo_plan holds, for one field shape, the boxes to send/receive in the two phases of the
- * exchange (phase 0: I faces, phase 1: J faces including the I-halo columns) and owns the dense
- * device staging buffers.  Within a phase the k-th send to a peer pairs with the k-th receive that
- * peer posts from this rank (RCCL point-to-point ordering). */
+ * A gt4mi_halo_plan holds, for one field shape, the boxes to send/receive in the (up to) two phases of the
+ * exchange and owns the dense device staging buffers.  Two message tables are in use (the host builds them):
+ *   two-phase     phase 0: I faces, phase 1: J faces including the I-halo columns (corners for free, 4 neighbours,
+ *                 two dependent rounds of pack -> send/recv -> unpack);
+ *   single-phase  everything in phase 0: 4 faces + 4 corner boxes to up to 8 neighbours, ONE round -- half the
+ *                 latency; on a fully connected xGMI node the diagonal neighbours have links of their own.
+ * Within a phase the k-th send to a peer pairs with the k-th receive that peer posts from this rank (RCCL
+ * point-to-point ordering); at most 8 boxes per phase and direction. */
 typedef struct gt4mi_comm gt4mi_comm;
 typedef struct gt4mi_halo_plan gt4mi_halo_plan;
 
@@ -159,9 +181,23 @@ typedef struct gt4mi_halo_msg {
 int gt4mi_comm_unique_id(void* id128);
 int gt4mi_comm_create(const void* id128, int nranks, int rank, gt4mi_comm** comm);
 int gt4mi_comm_destroy(gt4mi_comm* comm);
+/* What RCCL reports for the communicator (ncclCommCount, ncclCommUserRank, ncclCommCuDevice); any pointer may be NULL.
+ * Lets a benchmark line state how many ranks RCCL really joined. */
+int gt4mi_comm_info(gt4mi_comm* comm, int* nranks, int* rank, int* device);
 int gt4mi_halo_plan_create(gt4mi_comm* comm, int elem_size, const gt4mi_halo_msg* sends, int nsends,
                            const gt4mi_halo_msg* recvs, int nrecvs, gt4mi_halo_plan** plan);
 int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
+/* How the fused distributed steps (gt4mi_dist_*) built on this plan are scheduled; value -1 = the entry point's default.
+ *   GT4MI_PLAN_SCHEDULE             GT4MI_SCHEDULE_JOIN:  main: pack, interior, [join], ring;  side: send/recv, unpack
+ *                                   GT4MI_SCHEDULE_CHAIN: main: interior only;  side: pack, send/recv, unpack, ring -- no
+ *                                   cross-stream wait on the critical path as long as the chain fits under the interior
+ *   GT4MI_PLAN_INTERIOR_WG_PER_CU   at most this many workgroups of the INTERIOR kernel per CU while the exchange runs
+ *                                   next to it (0 = no limit): an HBM-saturating kernel at full occupancy keeps tens of MB
+ *                                   in flight and the send/recv kernel beside it waits ~10 us per memory access
+ * Which combination is fastest depends on the links; bench.py measures them (config.calibration_ms_per_apply). */
+enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1 };
+enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1 };
+int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value);
 /* 1 = the plan's side stream was verified to run concurrently with the caller's stream, 0 = no
  * concurrent stream could be found (the exchange still works, serialised), 2 = not probed yet.
  * HIP multiplexes streams onto a few hardware queues; the overlapped entry points probe on first use
@@ -184,6 +220,18 @@ int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream);
  * that have a neighbour: 1 = low I (W), 2 = high I (E), 4 = low J (S), 8 = high J (N). */
 int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int sides, void* main_stream);
+
+/* One distributed apply of horizontal diffusion (the stencil of gt4mi_hdiff_*; BASELINE configs[4]) in a single call:
+ *   main stream: pack of in_field's faces -> interior kernel (the domain minus a ring 2 points deep on every side
+ *                that has a neighbour) ................................. join -> ring kernel (one launch, four boxes)
+ *   side stream:                             RCCL send/recv -> unpack (-> second phase of a two-phase plan)
+ * The plan must exchange faces 2 deep and include the corner cells (either message table above).  `sides` as above. */
+int gt4mi_dist_hdiff_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* in_field,
+                         const gt4mi_field* out_field, const gt4mi_field* coeff, double coeff_scalar, int flags, int sides,
+                         void* main_stream);
+int gt4mi_dist_hdiff_f32(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* in_field,
+                         const gt4mi_field* out_field, const gt4mi_field* coeff, double coeff_scalar, int flags, int sides,
+                         void* main_stream);
 
 /* Time-stepping form (out of step n is inp of step n+1): each call
  *   1. joins the exchange that delivered `inp`'s ghost cells (started by the previous call, or once by
@@ -210,6 +258,19 @@ int gt4mi_dist_lap5_f64_pipelined(gt4mi_halo_plan* plan, const int64_t domain[3]
 int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                              const gt4mi_field* out, int variant, int sides, int halo, int phase,
                              void* main_stream);
+
+/* Time-skewed form of the same: ONE call runs a whole cycle of `halo` steps, field_a -> field_b -> field_a ... (the
+ * result is in field_b for odd `halo`, in field_a for even), boundary first:
+ *   1. joins the exchange that delivered field_a's ghost cells (previous cycle, or gt4mi_halo_exchange_begin once);
+ *   2. for step s = 1 .. halo: the band from halo - s points outside the domain to 2 halo - s points inside it
+ *      (one ring launch each) -- after the last band the halo-deep faces of the result are final;
+ *   3. packs them and starts their exchange on the side stream;
+ *   4. for step s = 1 .. halo: the interior (the domain shrunk by 2 halo - s), `halo` kernels that all run next to the
+ *      exchange.
+ * Same redundant rows as the _wide form, but the exchange has `halo` interior kernels to hide behind instead of one.
+ * Two buffers suffice: band s overwrites only what interior s - 1 no longer reads. */
+int gt4mi_dist_lap5_f64_skewed(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* field_a,
+                               const gt4mi_field* field_b, int variant, int sides, int halo, void* main_stream);
 
 /* ---- run-time compiled stencils (generic executor) --------------------------------------------
  * Replaces the reference's per-stencil JIT build: setuptools + nvcc building a pybind11 extension

@@ -104,3 +104,19 @@ def tridiag(inf, diag, sup, rhs, out, origins, domain):
     fs = [ctypes.byref(a.field(origins[n])) for n, a in
           zip(("inf", "diag", "sup", "rhs", "out"), (inf, diag, sup, rhs, out))]
     call(name, _lib.domain3(domain), *fs, stream_ptr(), None)
+
+
+def hdiff_ring(inp: DevArray, out: DevArray, coeff, origin_in, origin_out, origin_coeff, domain, flags, widths):
+    name = "gt4mi_hdiff_ring_f64" if inp.dtype == np.float64 else "gt4mi_hdiff_ring_f32"
+    if isinstance(coeff, DevArray):
+        cf, cs = ctypes.byref(coeff.field(origin_coeff)), 0.0
+    else:
+        cf, cs = None, float(coeff)
+    call(name, _lib.domain3(domain), ctypes.byref(inp.field(origin_in)), ctypes.byref(out.field(origin_out)),
+         cf, cs, flags, _lib.int4(widths), stream_ptr(), None)
+
+
+def lap5_ring(inp: DevArray, out: DevArray, origin_in, origin_out, domain, outer, inner, variant=0, flags=0):
+    name = "gt4mi_lap5_ring_f64" if inp.dtype == np.float64 else "gt4mi_lap5_ring_f32"
+    call(name, _lib.domain3(domain), ctypes.byref(inp.field(origin_in)), ctypes.byref(out.field(origin_out)),
+         variant, flags, _lib.int4(outer), _lib.int4(inner), stream_ptr(), None)

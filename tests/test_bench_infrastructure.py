@@ -81,3 +81,50 @@ def test_bench_module_has_no_gpu_side_effects_on_import():
     proc = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print('torch' in sys.modules)" % str(ROOT)],
                           capture_output=True, text=True, timeout=120)
     assert proc.returncode == 0 and proc.stdout.strip() == "False"
+
+
+def _proof_worker(rank: int, world: int, port: int, tmpdir: str):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = {"world": world, "rank": rank, "distributed": True, "dist": dist, "device": "cpu"}
+        # what NativeComm.info() returns on an N-rank communicator (RCCL itself cannot run here)
+        proof = bench.gather_rank_proof(ctx, {"rank": rank, "device": rank, "nranks": world})
+        everyone_ok = bench._agree(ctx, 1)
+        one_failed = bench._agree(ctx, 0 if rank == 1 else 1)
+        ms = bench._slowest_rank_ms(ctx, (lambda: time.sleep(0.002 * (rank + 1))), calls=3, warm=1)  # rank 1 is the slow one
+        keys = bench.decomposed_line_keys(proof, False, world, {"timestep_glups": 1.0})
+        fallen = bench.decomposed_line_keys(None, True, world, None)
+        with open(os.path.join(tmpdir, f"rank{rank}.json"), "w") as fh:
+            json.dump({"keys": keys, "fallen": fallen, "ok": [everyone_ok, one_failed], "ms": ms}, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_the_n_gpu_line_says_how_many_ranks_rccl_saw_and_whether_the_transport_fell_back(tmp_path, capfd):
+    """the first SCALE line must be interpretable -- `rccl_nranks` / `rank_devices` gathered from
+    every rank, `transport_fallback` as a top-level key (plus a banner on stderr), the time steppers under `extra`.  The
+    collective helpers run here on gloo, world_size 2."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_proof_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in (0, 1):
+        got = json.loads((tmp_path / f"rank{rank}.json").read_text())
+        keys = got["keys"]
+        assert keys["rccl_nranks"] == 2 and keys["rank_devices"] == [[0, 0], [1, 1]] and keys["rccl_matches_n_gpus"] is True
+        assert keys["transport_fallback"] is False and keys["extra"] == {"timestep_glups": 1.0}
+        assert got["fallen"] == {"rccl_nranks": None, "rank_devices": None, "rccl_matches_n_gpus": False, "transport_fallback": True}
+        assert got["ok"] == [1, 0]  # one failing rank makes every rank fall back together
+        assert got["ms"] >= 3.5  # the slowest rank's time on every rank
+    bench.transport_fallback_banner(0, "testing")
+    err = capfd.readouterr().err
+    assert "NATIVE RCCL TRANSPORT UNAVAILABLE (testing)" in err and "NOT those of the product path" in err
+    bench.transport_fallback_banner(1, "testing")  # only rank 0 shouts
+    assert capfd.readouterr().err == ""

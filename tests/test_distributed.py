@@ -134,7 +134,8 @@ def test_in_process_4x2_exchange_and_hdiff():
 @pytest.mark.parametrize("grid,periodic", [((1, 1), (True, True)), ((1, 2), (False, True)), ((2, 1), (True, False)),
                                            ((2, 2), (True, True)), ((1, 2), (True, True)), ((3, 2), (True, True))])
 @pytest.mark.parametrize("halo", [1, 2])
-def test_torch_transport_message_order_on_periodic_axes(grid, periodic, halo):
+@pytest.mark.parametrize("single_phase", [False, True])
+def test_torch_transport_message_order_on_periodic_axes(grid, periodic, halo, single_phase):
     """HaloExchanger posts sends low side first and receives HIGH side first.  With 1 or 2 ranks on a periodic
     axis both faces of a phase go to the same peer and the k-th send is matched with the k-th receive (NCCL and
     gloo alike): replay every rank's operation list with that rule -- no transport needed -- and compare the
@@ -182,7 +183,7 @@ def test_torch_transport_message_order_on_periodic_axes(grid, periodic, halo):
         def wait(self):
             return None
 
-    exchangers = [HaloExchanger(d, torch.float64, "cpu", packer=TorchSlicePacker()) for d in decs]
+    exchangers = [HaloExchanger(d, torch.float64, "cpu", packer=TorchSlicePacker(), single_phase=single_phase) for d in decs]
     try:
         dist.P2POp = FakeOp
         for phase in (0, 1):
@@ -230,7 +231,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank: int, world: int, port: int, grid, tmpdir: str):
+def _worker(rank: int, world: int, port: int, grid, tmpdir: str, single_phase: bool = False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -250,7 +251,7 @@ def _worker(rank: int, world: int, port: int, grid, tmpdir: str):
         if nb["N"] is not None:
             blk[:, -h:] = 0
         t = torch.from_numpy(blk)
-        ex = HaloExchanger(dec, torch.float64, "cpu", packer=TorchSlicePacker())
+        ex = HaloExchanger(dec, torch.float64, "cpu", packer=TorchSlicePacker(), single_phase=single_phase)
         ex.exchange(t)
         out = np.zeros_like(blk)
         (shift, sub), strips = dec.interior_and_strips()
@@ -270,10 +271,10 @@ def _worker(rank: int, world: int, port: int, grid, tmpdir: str):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("grid", [(1, 2), (2, 1)])
-def test_gloo_world_size_2_laplacian(grid, tmp_path):
+@pytest.mark.parametrize("grid,single_phase", [((1, 2), False), ((2, 1), False), ((2, 1), True)])
+def test_gloo_world_size_2_laplacian(grid, single_phase, tmp_path):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, grid, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, grid, str(tmp_path), single_phase), nprocs=2, join=True)
     ok, nbytes = np.load(tmp_path / "ok.npy")
     assert ok == 1
     assert nbytes > 0
@@ -283,7 +284,8 @@ def test_gloo_world_size_2_laplacian(grid, tmp_path):
                                            ((1, 2), (False, True)), ((1, 1), (True, True)), ((2, 4), (True, False)),
                                            ((1, 4), (False, True))])
 @pytest.mark.parametrize("halo", [1, 2])
-def test_native_message_tables_pair_up_across_ranks(grid, periodic, halo):
+@pytest.mark.parametrize("single_phase", [False, True])
+def test_native_message_tables_pair_up_across_ranks(grid, periodic, halo, single_phase):
     """The native (RCCL) exchanger cannot run on more than one rank here, but its protocol can be checked:
     simulate every rank's message table and deliver the k-th send of rank r to peer p into p's k-th receive
     from r (RCCL's matching rule inside one group).  Every message must find a receive of the same extent,
@@ -319,7 +321,10 @@ def test_native_message_tables_pair_up_across_ranks(grid, periodic, halo):
         if nb["N"] is not None:
             have[:, -halo:] = np.nan
         locals_.append((have, want))
-    tables = [NativeHaloExchanger.message_tables(d) for d in decs]
+    tables = [NativeHaloExchanger.message_tables(d, single_phase) for d in decs]
+    if single_phase:  # one round: faces and corners, at most 8 boxes per rank
+        assert all(ph == 0 for sends, recvs in tables for _, ph, _, _ in (*sends, *recvs))
+        assert max(len(sends) for sends, _ in tables) <= 8
     for phase in (0, 1):
         mailbox = {}
         for r, (sends, _) in enumerate(tables):
@@ -410,6 +415,129 @@ def test_wide_halo_scheme_model_on_bounded_grids(grid, halo, nsteps):
         li, lj, _ = d.local_domain
         np.testing.assert_array_equal(src[r][H:H + li, H:H + lj], want[H + i0:H + i0 + li, H + j0:H + j0 + lj],
                                       err_msg=f"rank {r}")
+
+
+def ring_boxes(domain, outer, inner):
+    """The boxes of csrc/lap5_ring.hip.h: (domain grown by outer[W, E, S, N]) minus (domain shrunk by inner[...]) as
+    [(i0, i1, j0, j1)] relative to the compute-domain origin."""
+    di, dj = domain[0], domain[1]
+    (ow, oe, os_, on), (iw, ie, is_, in_) = outer, inner
+    boxes = []
+    if os_ + is_ > 0:
+        boxes.append((-ow, di + oe, -os_, is_))
+    if on + in_ > 0:
+        boxes.append((-ow, di + oe, dj - in_, dj + on))
+    if ow + iw > 0 and dj - is_ - in_ > 0:
+        boxes.append((-ow, iw, is_, dj - in_))
+    if oe + ie > 0 and dj - is_ - in_ > 0:
+        boxes.append((di - ie, di + oe, is_, dj - in_))
+    return boxes
+
+
+@pytest.mark.parametrize("grid", [(1, 4), (2, 2), (4, 2), (1, 8)])
+@pytest.mark.parametrize("halo,ncycles", [(1, 3), (2, 3), (3, 2)])
+@pytest.mark.parametrize("single_phase", [False, True])
+@pytest.mark.parametrize("ghosts_arrive", ["at once", "at the end of the cycle"])
+def test_time_skewed_scheme_model_on_bounded_grids(grid, halo, ncycles, single_phase, ghosts_arrive):
+    """Numpy model of gt4mi_dist_lap5_f64_skewed over a whole non-periodic process grid, with exactly the two buffers and
+    the launch order of the C code: the bands of steps 1 .. H (from H - s points outside the domain to 2H - s inside it),
+    pack of the result's faces, then the interiors of steps 1 .. H.  The ghost cells may land anywhere between the pack and
+    the next cycle: both extremes are played.  After every cycle the assembled field must equal H more steps on the
+    undecomposed array."""
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from oracle import ref_numpy as R
+
+    H = halo
+    gd = (12 * grid[0], 10 * grid[1], 2)
+    n = grid[0] * grid[1]
+    decs = [Decomposition(gd, grid, r, H) for r in range(n)]
+    rng = np.random.default_rng(5)
+    full = rng.uniform(-1, 1, (gd[0] + 2 * H, gd[1] + 2 * H, gd[2])) * 1e-3
+    u, v = full.copy(), full.copy()
+    core = (slice(H - 1, -(H - 1)) if H > 1 else slice(None),) * 2 + (slice(None),)
+    tables = [NativeHaloExchanger.message_tables(d, single_phase) for d in decs]
+
+    def pack(fields):  # what the ranks send, copied at pack time
+        mail = [{}, {}]
+        for phase in (0, 1):
+            for r, (sends, _) in enumerate(tables):
+                for peer, ph, lo, ext in sends:
+                    if ph == phase:
+                        mail[phase].setdefault((r, peer), []).append((lo, ext))
+        return mail
+
+    def deliver(fields):  # a two-phase plan packs its second phase after the first has been unpacked
+        for phase in (0, 1):
+            mailbox = {}
+            for r, (sends, _) in enumerate(tables):
+                for peer, ph, lo, ext in sends:
+                    if ph == phase:
+                        mailbox.setdefault((r, peer), []).append(
+                            fields[r][lo[0]:lo[0] + ext[0], lo[1]:lo[1] + ext[1], lo[2]:lo[2] + ext[2]].copy())
+            for r, (_, recvs) in enumerate(tables):
+                for peer, ph, lo, ext in recvs:
+                    if ph == phase:
+                        fields[r][lo[0]:lo[0] + ext[0], lo[1]:lo[1] + ext[1], lo[2]:lo[2] + ext[2]] = mailbox[(peer, r)].pop(0)
+
+    def apply(src, dst, box):
+        i0, i1, j0, j1 = box
+        if i1 <= i0 or j1 <= j0:
+            return
+        view = (slice(H + i0 - 1, H + i1 + 1), slice(H + j0 - 1, H + j1 + 1), slice(None))
+        R.laplacian(src[view], dst[view])
+
+    a, b = [], []
+    for d in decs:
+        i0, j0 = d.offset[0], d.offset[1]
+        li, lj, _ = d.local_domain
+        a.append(full[i0:i0 + li + 2 * H, j0:j0 + lj + 2 * H].copy())
+        # both buffers carry the fixed physical-boundary ring -- also where it crosses a neighbour's ghost rows, which the
+        # grown bands read and no exchange of the OTHER buffer ever fills (same precondition as the _wide form)
+        b.append(a[-1].copy())
+    for cycle in range(ncycles):
+        def src_of(st):
+            return a if st % 2 == 1 else b
+
+        def dst_of(st):
+            return b if st % 2 == 1 else a
+
+        sides = []
+        for d in decs:
+            nb = d.neighbours
+            sides.append([nb[k] is not None for k in ("W", "E", "S", "N")])
+        for st in range(1, H + 1):  # bands
+            for r, d in enumerate(decs):
+                outer = [H - st if f else 0 for f in sides[r]]
+                inner = [2 * H - st if f else 0 for f in sides[r]]
+                for box in ring_boxes(d.local_domain, outer, inner):
+                    apply(src_of(st)[r], dst_of(st)[r], box)
+        result = dst_of(H)
+        snapshot = [f.copy() for f in result]  # the faces are final here: what travels is what is packed now
+        if ghosts_arrive == "at once":
+            deliver(result)
+        for st in range(1, H + 1):  # interiors
+            for r, d in enumerate(decs):
+                li, lj, _ = d.local_domain
+                w, e, s_, n_ = [2 * H - st if f else 0 for f in sides[r]]
+                apply(src_of(st)[r], dst_of(st)[r], (w, li - e, s_, lj - n_))
+        if ghosts_arrive != "at once":
+            for r in range(n):  # the faces must not have changed since they were packed
+                (sends, _) = tables[r]
+                for peer, ph, lo, ext in sends:
+                    if ph == 0:
+                        sl = (slice(lo[0], lo[0] + ext[0]), slice(lo[1], lo[1] + ext[1]), slice(lo[2], lo[2] + ext[2]))
+                        np.testing.assert_array_equal(result[r][sl], snapshot[r][sl])
+            deliver(result)
+        if H % 2 == 1:
+            a, b = b, a  # the caller swaps the roles for an odd number of steps per cycle
+        for _ in range(H):
+            R.laplacian(u[core], v[core])
+            u, v = v, u
+        for r, d in enumerate(decs):
+            i0, j0 = d.offset[0], d.offset[1]
+            li, lj, _ = d.local_domain
+            np.testing.assert_array_equal(a[r][H:H + li, H:H + lj], u[H + i0:H + i0 + li, H + j0:H + j0 + lj],
+                                          err_msg=f"cycle {cycle}, rank {r}")
 
 
 # ---- world_size-2 gloo runs of the two drivers an N > 1 GPU job uses ------------------------------------------

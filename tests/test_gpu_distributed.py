@@ -372,3 +372,175 @@ def test_baseline_config4_share_with_all_four_neighbours(comm, form):
     inner = (slice(h + 2, -(h + 2)), slice(h + 2, -(h + 2)), slice(None))
     assert torch.equal(out[inner], inp[inner])
     ex.close()
+
+
+# ---- round 3: fused distributed horizontal diffusion, single-phase plans, the time-skewed stepper ---------------------
+def test_communicator_reports_what_rccl_sees(comm):
+    info = comm.info()
+    assert info["nranks"] == 1 and info["rank"] == 0 and info["device"] >= 0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("periodic", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("halo", [1, 2])
+def test_single_phase_self_exchange(comm, dtype, periodic, halo):
+    """The 8-neighbour table (faces + corner boxes in ONE round) refreshes exactly the cells the two-phase table does."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+
+    dec = Decomposition((37, 22, 5), (1, 1), 0, halo, periodic=periodic)
+    rng = np.random.default_rng(3)
+    host = rng.uniform(-1, 1, dec.local_shape).astype(dtype)
+    dev = gt_storage.from_array(host, dtype, backend="hip:mi300", aligned_index=dec.origin)
+    ex = NativeHaloExchanger(dec, dtype, comm, single_phase=True)
+    ex.exchange(dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.get(), _wrap(host, halo, *periodic))
+    ex.close()
+
+
+@pytest.mark.parametrize("single_phase", [False, True])
+@pytest.mark.parametrize("periodic", [(True, True), (False, True), (True, False)])
+@pytest.mark.parametrize("dtype,coeff_kind", [(np.float64, "field"), (np.float32, "field"), (np.float64, "scalar")])
+@pytest.mark.parametrize("gd", [(40, 36, 3), (130, 70, 4)])
+def test_fused_distributed_hdiff_step(comm, gd, dtype, coeff_kind, periodic, single_phase):
+    """gt4mi_dist_hdiff_*: pack, interior next to the exchange, ONE ring kernel == oracle on the wrapped field; reached
+    through the stencil-agnostic driver (overlapped_apply picks the fused step for a kernel-library stencil)."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger, fused_apply, overlapped_apply
+    from oracle import ref_numpy as R
+
+    defn = hip_templates.hdiff_limiter_field if coeff_kind == "field" else hip_templates.hdiff_limiter_scalar
+    dtypes = {"T": dtype} if coeff_kind == "field" else {"T": dtype, "S": np.float64}
+    hd = gtscript.stencil(backend="hip:mi300", definition=defn, dtypes=dtypes, device_sync=False)
+    dec = Decomposition(gd, (1, 1), 0, 2, periodic=periodic)
+    rng = np.random.default_rng(5)
+    host = rng.uniform(-10, 10, dec.local_shape).astype(dtype)
+    coeff = rng.uniform(0, 0.5, dec.local_shape).astype(dtype)
+    d_in = gt_storage.from_array(host, dtype, backend="hip:mi300", aligned_index=dec.origin)
+    d_out = gt_storage.zeros(dec.local_shape, dtype, backend="hip:mi300", aligned_index=dec.origin)
+    ex = NativeHaloExchanger(dec, dtype, comm, single_phase=single_phase)
+    names = list(inspect_signature_names(hd))
+    args = {names[0]: d_in, names[1]: d_out}
+    if coeff_kind == "field":
+        args[names[2]] = gt_storage.from_array(coeff, dtype, backend="hip:mi300", aligned_index=dec.origin)
+        oracle_coeff = coeff
+    else:
+        args[names[2]] = 0.21
+        oracle_coeff = np.float64(0.21)
+    origin = {n: dec.origin for n in names[:3] if not isinstance(args[n], float)}
+    assert fused_apply(hd, dec, origin, args, {names[0]: ex})  # the combination IS covered by the native step
+    d_out.tensor.zero_()
+    for _ in range(2):
+        overlapped_apply(hd, dec, origin, args, {names[0]: ex})
+    torch.cuda.synchronize()
+    wrapped = _wrap(host, 2, *periodic)
+    want = np.zeros_like(host)
+    R.hdiff(wrapped, want, oracle_coeff, domain=gd)
+    assert np.array_equal(d_out.get(), want)
+    assert np.array_equal(d_in.get(), wrapped)
+    ex.close()
+
+
+def inspect_signature_names(stencil):
+    import inspect
+
+    return inspect.signature(stencil.definition_func).parameters
+
+
+@pytest.mark.parametrize("single_phase", [False, True])
+@pytest.mark.parametrize("halo", [1, 2, 3])
+@pytest.mark.parametrize("periodic", [(False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("gd", [(48, 40, 4), (130, 36, 3)])
+def test_time_skewed_stepping(comm, gd, periodic, halo, single_phase):
+    """gt4mi_dist_lap5_f64_skewed: per cycle the bands of steps 1 .. H, then the exchange next to the H interior kernels;
+    after n cycles the compute domain equals n * H oracle steps with a fresh periodic wrap every step."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from oracle import ref_numpy as R
+
+    dec = Decomposition(gd, (1, 1), 0, halo, periodic=periodic)
+    o = dec.origin
+    rng = np.random.default_rng(200 + halo)
+    host = rng.uniform(-1, 1, dec.local_shape) * 1e-3
+    a = gt_storage.from_array(host, backend="hip:mi300", aligned_index=o)
+    # Both buffers carry the fixed physical-boundary ring -- also where it crosses the ghost rows of a neighbour: from a ghost
+    # depth of 3 on, the grown bands read those cells of the buffer that is NOT exchanged in that cycle (a decomposed run has
+    # them from the initial scatter of the global array; on the periodic self-loop they are the wrapped images).
+    b = gt_storage.from_array(_wrap(host, halo, *periodic), backend="hip:mi300", aligned_index=o)
+    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase)
+    cycle = ex.make_time_skewed_lap5(a, b, o)
+    assert cycle.steps_per_call == halo
+    ncycles = 3
+    for _ in range(ncycles):
+        cycle()
+    ex.end()
+    torch.cuda.synchronize()
+    h = halo
+    core = (slice(h - 1, -(h - 1)) if h > 1 else slice(None),) * 2 + (slice(None),)
+    u, v = host[core].copy(), host[core].copy()
+    for _ in range(ncycles * halo):
+        u = _wrap(u, 1, *periodic)
+        R.laplacian(u, v)
+        u, v = v, u
+    got = cycle.result().get()[core]
+    assert np.array_equal(got[1:-1, 1:-1], u[1:-1, 1:-1])
+    ex.close()
+
+
+@pytest.mark.parametrize("single_phase", [False, True])
+def test_baseline_config4_share_through_the_fused_native_step(comm, single_phase):
+    """BASELINE.json configs[4]'s per-rank share (512 x 1024 x 80 fp64, ghost depth 2, all four neighbours and the corners
+    live on the periodic self-loop) through gt4mi_dist_hdiff_f64: slabs against the oracle, ghost cells refreshed, and the
+    size-independent linear-field property on all 80 levels -- the same checks as the driver-level test above."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger, fused_apply
+    from oracle import ref_numpy as R
+
+    hd = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field,
+                          dtypes={"T": np.float64}, device_sync=False)
+    gd, h = (512, 1024, 80), 2
+    dec = Decomposition(gd, (1, 1), 0, h, periodic=(True, True))
+    gen = torch.Generator(device="cuda").manual_seed(20263)
+    fields = {}
+    for name, lo, hi in (("in_field", -10.0, 10.0), ("coeff", 0.0, 0.5), ("out_field", 0.0, 0.0)):
+        f = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+        if hi > lo:
+            f.tensor.copy_(torch.rand(dec.local_shape, dtype=torch.float64, device="cuda", generator=gen) * (hi - lo) + lo)
+        fields[name] = f
+    levels = [0, 1, 39, 78, 79]
+    host_in = fields["in_field"].tensor[:, :, levels].cpu().numpy()
+    host_cf = fields["coeff"].tensor[:, :, levels].cpu().numpy()
+    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase)
+    if single_phase:  # 2 I faces + 2 J faces of owned cells + 4 corners of 2 x 2
+        assert ex.bytes_per_exchange == (2 * (2 * 1024) + 2 * (512 * 2) + 4 * 4) * 80 * 8
+    origin = {n: dec.origin for n in fields}
+    assert fused_apply(hd, dec, origin, fields, {"in_field": ex})
+    torch.cuda.synchronize()
+    want = np.zeros_like(host_in)
+    wrapped = _wrap(host_in, h)
+    R.hdiff(wrapped, want, host_cf, domain=(gd[0], gd[1], len(levels)))
+    got = fields["out_field"].tensor[:, :, levels].cpu().numpy()
+    assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h])
+    assert np.array_equal(fields["in_field"].tensor[:, :, levels].cpu().numpy(), wrapped)
+    ii = torch.arange(dec.local_shape[0], dtype=torch.float64, device="cuda")[:, None, None]
+    jj = torch.arange(dec.local_shape[1], dtype=torch.float64, device="cuda")[None, :, None]
+    fields["in_field"].tensor.copy_((3.0 * ii + 5.0 * jj + 7.0).expand(dec.local_shape))
+    assert fused_apply(hd, dec, origin, fields, {"in_field": ex})
+    torch.cuda.synchronize()
+    out, inp = fields["out_field"].tensor, fields["in_field"].tensor
+    inner = (slice(h + 2, -(h + 2)), slice(h + 2, -(h + 2)), slice(None))
+    assert torch.equal(out[inner], inp[inner])
+    ex.close()

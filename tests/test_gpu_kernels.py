@@ -339,3 +339,75 @@ def test_empty_domains_are_no_ops_at_the_boundary(domain):
         G.tridiag(*d, {n: (0, 0, 0) for n in ("inf", "diag", "sup", "rhs", "out")}, domain)
         for n, arr in enumerate(d):
             assert (arr.get() == float(n + 1)).all()
+
+
+# ---- boundary-ring kernels (csrc/hdiff_ring.hip.h, lap5_ring.hip.h): one launch for the four boxes of a ring ---------
+def _ring_mask(shape, origin, domain, outer, inner):
+    """Boolean mask of (domain grown by outer[W, E, S, N]) minus (domain shrunk by inner[...]) in array indices."""
+    m = np.zeros(shape[:2], dtype=bool)
+    oi, oj = origin[0], origin[1]
+    di, dj = domain[0], domain[1]
+    m[oi - outer[0]:oi + di + outer[1], oj - outer[2]:oj + dj + outer[3]] = True
+    m[oi + inner[0]:oi + di - inner[1], oj + inner[2]:oj + dj - inner[3]] = False
+    return m
+
+
+@pytest.mark.parametrize("layout", ["ifirst", "ifirst_unaligned", "kfirst"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("widths", [(2, 2, 2, 2), (0, 2, 2, 0), (2, 0, 0, 0), (0, 0, 0, 2), (2, 2, 0, 0), (1, 0, 2, 3)])
+@pytest.mark.parametrize("domain", [(130, 70, 3), (7, 9, 2), (64, 5, 4)])
+def test_hdiff_ring_equals_the_whole_domain_kernel_on_the_ring(domain, widths, dtype, layout):
+    """gt4mi_hdiff_ring_*: the points within widths[side] of a side get exactly the values of the oracle (and of the
+    whole-domain kernel); everything else keeps what the output array held.  (1, 0, 2, 3) is not the shape the ring kernel
+    takes (column boxes 2 wide): it runs box by box on the ordinary kernels."""
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    if widths[0] + widths[1] > domain[0] or widths[2] + widths[3] > domain[1]:
+        pytest.skip("ring wider than the domain")
+    rng = np.random.default_rng(hash((domain, widths)) % 2**32)
+    shape = (domain[0] + 4, domain[1] + 4, domain[2])
+    u = rng.uniform(-10, 10, shape).astype(dtype)
+    c = rng.uniform(0, 0.5, shape).astype(dtype)
+    want_full = np.zeros_like(u)
+    R.hdiff(u, want_full, c)
+    for flags, coeff in ((_lib.HDIFF_LIMITER, "field"), (0, 0.125)):
+        if coeff != "field":  # a scalar weight declared with the fields' dtype, no limiter
+            weight = np.float32(coeff) if dtype == np.float32 else np.float64(coeff)
+            want_full = np.zeros_like(u)
+            R.hdiff(u, want_full, weight, limiter=False)
+        sentinel = np.full(shape, -777.0, dtype=dtype)
+        d_u, d_o = G.DevArray(u, layout, (2, 2, 0)), G.DevArray(sentinel, layout, (2, 2, 0))
+        d_c = G.DevArray(c, layout, (2, 2, 0)) if coeff == "field" else coeff
+        G.hdiff_ring(d_u, d_o, d_c, (2, 2, 0), (2, 2, 0), (2, 2, 0), domain,
+                     flags | (_lib.HDIFF_COEFF_F32 if coeff != "field" and dtype == np.float32 else 0), widths)
+        mask = _ring_mask(shape, (2, 2, 0), domain, (0, 0, 0, 0), widths)
+        want = np.where(mask[:, :, None], want_full, sentinel)
+        got = d_o.get()
+        assert np.array_equal(got, want), (flags, np.argwhere(got != want)[:5])
+
+
+@pytest.mark.parametrize("layout", ["ifirst", "ifirst_unaligned", "jfirst"])
+@pytest.mark.parametrize("outer,inner", [((0, 0, 0, 0), (1, 1, 1, 1)), ((0, 0, 0, 0), (0, 0, 1, 1)), ((0, 0, 1, 1), (0, 0, 3, 3)),
+                                         ((1, 1, 1, 1), (3, 3, 3, 3)), ((2, 0, 0, 2), (4, 0, 0, 4)), ((0, 0, 0, 0), (2, 2, 2, 2)),
+                                         ((0, 3, 0, 0), (0, 7, 0, 0)), ((0, 0, 3, 0), (0, 0, 7, 0))])
+@pytest.mark.parametrize("domain", [(128, 40, 3), (70, 33, 2), (520, 18, 2)])
+@pytest.mark.parametrize("variant", [0, 3])
+def test_lap5_ring_equals_the_whole_domain_kernel_on_the_ring(domain, outer, inner, layout, variant):
+    """gt4mi_lap5_ring_f64: (domain grown by outer) minus (domain shrunk by inner) gets the oracle's values -- also in the
+    ghost region, where the time-skewed stepper computes redundantly -- and nothing else is written."""
+    import gpu_util as G
+
+    H = 4
+    rng = np.random.default_rng(hash((domain, outer, inner)) % 2**32)
+    shape = (domain[0] + 2 * H, domain[1] + 2 * H, domain[2])
+    u = rng.uniform(-1, 1, shape)
+    want_full = np.zeros_like(u)
+    R.laplacian(u, want_full, variant=["notebook", "docs", "suite", "avg"][variant])  # on [1, -1) of the whole array
+    sentinel = np.full(shape, -777.0)
+    d_u, d_o = G.DevArray(u, layout, (H, H, 0)), G.DevArray(sentinel, layout, (H, H, 0))
+    G.lap5_ring(d_u, d_o, (H, H, 0), (H, H, 0), domain, outer, inner, variant=variant)
+    mask = _ring_mask(shape, (H, H, 0), domain, outer, inner)
+    want = np.where(mask[:, :, None], want_full, sentinel)
+    got = d_o.get()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]

@@ -237,7 +237,10 @@ def other_kernels(steps: int = 20):
 
     def run(name, obj, fields, origin, domain, bytes_per_lup, scalars=None, note=None):
         frozen = obj.freeze(origin=origin, domain=domain)
-        call = lambda i: frozen(**fields, **(scalars or {}))  # noqa: E731
+        if isinstance(fields, (list, tuple)):  # several sets of fields, rotated launch by launch
+            call = lambda i: frozen(**fields[i % len(fields)], **(scalars or {}))  # noqa: E731
+        else:
+            call = lambda i: frozen(**fields, **(scalars or {}))  # noqa: E731
         # Warm up and time for a fixed amount of device time, not a fixed count: the clocks need a few milliseconds of
         # load to settle, and 10 + 20 launches of a 0.18 ms kernel measured it 7-12 % slow (scripts/hdiff_bench_context.py
         # next to scripts/hdiff_api_timing.py on one box: 0.206 vs 0.182 ms)
@@ -260,6 +263,21 @@ def other_kernels(steps: int = 20):
                      "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4)}
         if note:
             out[name]["note"] = note
+
+    # BASELINE.json configs[1] as named: 512 x 512 x 128 fp64.  One field is 285 MB with its halo -- about the size of the
+    # 256 MB Infinity Cache -- so the launches rotate over FOUR (inp, out) pairs (2.3 GB; SURVEY.md section 8d asks for >= 3):
+    # nothing a launch reads or writes can still be cache-resident from its previous turn.
+    dom = (512, 512, 128)
+    lap_obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
+                               device_sync=False)
+    shape = (dom[0] + 2, dom[1] + 2, dom[2])
+    sets = [{"inp": field(shape, np.float64, (1, 1, 0)), "out": field(shape, np.float64, (1, 1, 0))} for _ in range(4)]
+    run("laplacian_f64_512x512x128_config1", lap_obj, sets, {k: (1, 1, 0) for k in ("inp", "out")}, dom, 16.0,
+        note="BASELINE.json configs[1] at its own size, four rotating (inp, out) pairs = 2.3 GB so that the 256 MB Infinity "
+             "Cache cannot serve repeats; the headline `value` is the same kernel on 512^3")
+    out["laplacian_f64_512x512x128_config1"]["rotating_pairs"] = len(sets)
+    del sets
+    torch.cuda.empty_cache()
 
     for tag, dt, dom, lit, note in (
             ("hdiff_limiter_f32_1024x1024x80", np.float32, (1024, 1024, 80), 64,

@@ -148,3 +148,83 @@ def tridiag_debug_order(inf, diag, sup, rhs, out, *, origins=None, domain=None):
                 for k in range(dK - 2, -1, -1):
                     out[at(out, "out", i, j, k)] = rhs[at(rhs, "rhs", i, j, k)] - (
                         sup[at(sup, "sup", i, j, k)] * out[at(out, "out", i, j, k + 1)])
+
+
+def vadv_debug_order(utens_stage, u_stage, wcon, u_pos, utens, dtr_stage, *, origins=None, domain=None, bet_m=0.5, bet_p=0.5):
+    """``vertical_advection_dycore`` (stencil_definitions.py:235-313) in the debug backend's order.  That backend merges
+    the statements of an interval section into ONE horizontal execution when none reads another's result at a horizontal
+    offset (debug_backend.py:42-45: HorizontalExecutionMerging; here only the never-written ``wcon`` is read at an I
+    offset), so the generated loops are, per vertical loop and section,
+
+        for i: for j: for k in section (forward or backward): every statement of the section at the point (i, j, k)
+
+    -- a whole IJ sweep per interval section, columns innermost: neither the numpy backend's level-by-level slices
+    (``ref_numpy.vadv``) nor one column through all sections at a time.  Temporaries are domain-sized arrays between the
+    sections, numpy float64 scalars inside."""
+    names = ("utens_stage", "u_stage", "wcon", "u_pos", "utens")
+    arrs = dict(zip(names, (utens_stage, u_stage, wcon, u_pos, utens)))
+    origins = origins or {n: (0, 0, 0) for n in names}
+    dI, dJ, dK = domain if domain is not None else (wcon.shape[0] - 1, wcon.shape[1], wcon.shape[2] - 1)
+    f8 = np.float64
+    dtr, BET_M, BET_P = f8(dtr_stage), f8(bet_m), f8(bet_p)
+
+    def at(name, i, j, k):
+        o = origins[name]
+        return arrs[name][o[0] + i, o[1] + j, o[2] + k]
+
+    ccol = np.zeros((dI, dJ, dK))
+    dcol = np.zeros((dI, dJ, dK))
+    datacol = np.zeros((dI, dJ, dK))
+    with np.errstate(all="ignore"):
+        for i in range(dI):  # FORWARD, interval(0, 1)
+            for j in range(dJ):
+                k = 0
+                gcv = f8(0.25) * (at("wcon", i + 1, j, k + 1) + at("wcon", i, j, k + 1))
+                cs = gcv * BET_M
+                c = gcv * BET_P
+                bcol = dtr - c
+                correction_term = (-cs) * (at("u_stage", i, j, k + 1) - at("u_stage", i, j, k))
+                d = (((dtr * at("u_pos", i, j, k)) + at("utens", i, j, k)) + at("utens_stage", i, j, k)) + correction_term
+                divided = f8(1.0) / bcol
+                ccol[i, j, k] = c * divided
+                dcol[i, j, k] = d * divided
+        for i in range(dI):  # FORWARD, interval(1, -1)
+            for j in range(dJ):
+                for k in range(1, dK - 1):
+                    gav = (-f8(0.25)) * (at("wcon", i + 1, j, k) + at("wcon", i, j, k))
+                    gcv = f8(0.25) * (at("wcon", i + 1, j, k + 1) + at("wcon", i, j, k + 1))
+                    as_ = gav * BET_M
+                    cs = gcv * BET_M
+                    acol = gav * BET_P
+                    c = gcv * BET_P
+                    bcol = (dtr - acol) - c
+                    correction_term = ((-as_) * (at("u_stage", i, j, k - 1) - at("u_stage", i, j, k))) - (
+                        cs * (at("u_stage", i, j, k + 1) - at("u_stage", i, j, k)))
+                    d = (((dtr * at("u_pos", i, j, k)) + at("utens", i, j, k)) + at("utens_stage", i, j, k)) + correction_term
+                    divided = f8(1.0) / (bcol - (ccol[i, j, k - 1] * acol))
+                    ccol[i, j, k] = c * divided
+                    dcol[i, j, k] = (d - (dcol[i, j, k - 1] * acol)) * divided
+        for i in range(dI):  # FORWARD, interval(-1, None)
+            for j in range(dJ):
+                k = dK - 1
+                gav = (-f8(0.25)) * (at("wcon", i + 1, j, k) + at("wcon", i, j, k))
+                as_ = gav * BET_M
+                acol = gav * BET_P
+                bcol = dtr - acol
+                correction_term = (-as_) * (at("u_stage", i, j, k - 1) - at("u_stage", i, j, k))
+                d = (((dtr * at("u_pos", i, j, k)) + at("utens", i, j, k)) + at("utens_stage", i, j, k)) + correction_term
+                divided = f8(1.0) / (bcol - (ccol[i, j, k - 1] * acol))
+                dcol[i, j, k] = (d - (dcol[i, j, k - 1] * acol)) * divided
+        o = origins["utens_stage"]
+        for i in range(dI):  # BACKWARD, interval(-1, None)
+            for j in range(dJ):
+                k = dK - 1
+                datacol[i, j, k] = dcol[i, j, k]
+                utens_stage[o[0] + i, o[1] + j, o[2] + k] = dtr * (datacol[i, j, k] - at("u_pos", i, j, k))
+        for i in range(dI):  # BACKWARD, interval(0, -1)
+            for j in range(dJ):
+                for k in range(dK - 2, -1, -1):
+                    datacol[i, j, k] = dcol[i, j, k] - (ccol[i, j, k] * datacol[i, j, k + 1])
+                    utens_stage[o[0] + i, o[1] + j, o[2] + k] = dtr * (datacol[i, j, k] - at("u_pos", i, j, k))
+    return utens_stage
+

@@ -235,6 +235,88 @@ def tridiag(inf, diag, sup, rhs, out, *, origins=None, domain=None):
 
 
 # --------------------------------------------------------------------------------------
+# vertical_advection_dycore (stencil_definitions.py:235-313) -- SURVEY.md section 8f rank 1
+# --------------------------------------------------------------------------------------
+def vadv(utens_stage, u_stage, wcon, u_pos, utens, dtr_stage, *, origins=None, domain=None, bet_m=0.5, bet_p=0.5):
+    """``vertical_advection_dycore``: implicit vertical advection, a Thomas solve whose coefficients are assembled on the
+    fly.  Writes ``utens_stage`` in place; every other field is read only.
+
+    Written against the DEFINITION (stencil_definitions.py:235-313), statement by statement, in the numpy backend's
+    schedule: sequential K is a Python loop over single-level slices, within a level the statements run in program order
+    over the whole IJ domain (npir_codegen.py:64-71, 243-248); three FORWARD interval blocks (0, 1), (1, -1), (-1, None),
+    then two BACKWARD blocks (-1, None), (0, -1).  Expressions are evaluated exactly as Python parses them: ``-cs * x`` is
+    ``(-cs) * x``, ``a + b + c + d`` associates to the left, ``-0.25 * (...)`` is ``(-(0.25)) * (...)``
+    (frontend/gtscript_frontend.py:1477-1504).  All fields are float64 (``Field3D``), the externals BET_M = BET_P = 0.5
+    and the literals are float64 (definitions.py:40-42), ``dtr_stage`` is a float64 scalar.  Temporaries (gcv, cs, ccol,
+    bcol, correction_term, dcol, divided, gav, as_, acol, datacol) are domain-sized arrays as in npir_codegen.py:88-104.
+    ``wcon`` is read at [1, 0, 0], [1, 0, 1] and [0, 0, 1]: it needs one more column and one more level than the domain.
+    This function does NOT go through this repository's frontend or IR."""
+    names = ("utens_stage", "u_stage", "wcon", "u_pos", "utens")
+    arrs = dict(zip(names, (utens_stage, u_stage, wcon, u_pos, utens)))
+    if origins is None:
+        origins = {n: (0, 0, 0) for n in names}
+    if domain is None:
+        domain = (wcon.shape[0] - 1, wcon.shape[1], wcon.shape[2] - 1)
+    di, dj, dk = domain
+    f8 = np.float64
+    dtr, BET_M, BET_P = f8(dtr_stage), f8(bet_m), f8(bet_p)
+
+    def lvl(name, k, di_=0, dk_=0):
+        oi, oj, ok = origins[name]
+        return arrs[name][oi + di_: oi + di_ + di, oj: oj + dj, ok + k + dk_]
+
+    tmp = {n: np.zeros((di, dj, dk), dtype=f8) for n in
+           ("gcv", "cs", "ccol", "bcol", "correction_term", "dcol", "divided", "gav", "as_", "acol", "datacol")}
+    t = tmp.__getitem__
+    with np.errstate(divide="ignore", over="ignore", under="ignore", invalid="ignore"):
+        # FORWARD, interval(0, 1)
+        k = 0
+        t("gcv")[:, :, k] = f8(0.25) * (lvl("wcon", k, 1, 1) + lvl("wcon", k, 0, 1))
+        t("cs")[:, :, k] = t("gcv")[:, :, k] * BET_M
+        t("ccol")[:, :, k] = t("gcv")[:, :, k] * BET_P
+        t("bcol")[:, :, k] = dtr - t("ccol")[:, :, k]
+        t("correction_term")[:, :, k] = (-t("cs")[:, :, k]) * (lvl("u_stage", k, 0, 1) - lvl("u_stage", k))
+        t("dcol")[:, :, k] = (((dtr * lvl("u_pos", k)) + lvl("utens", k)) + lvl("utens_stage", k)) + t("correction_term")[:, :, k]
+        t("divided")[:, :, k] = f8(1.0) / t("bcol")[:, :, k]
+        t("ccol")[:, :, k] = t("ccol")[:, :, k] * t("divided")[:, :, k]
+        t("dcol")[:, :, k] = t("dcol")[:, :, k] * t("divided")[:, :, k]
+        # FORWARD, interval(1, -1)
+        for k in range(1, dk - 1):
+            t("gav")[:, :, k] = (-f8(0.25)) * (lvl("wcon", k, 1, 0) + lvl("wcon", k))
+            t("gcv")[:, :, k] = f8(0.25) * (lvl("wcon", k, 1, 1) + lvl("wcon", k, 0, 1))
+            t("as_")[:, :, k] = t("gav")[:, :, k] * BET_M
+            t("cs")[:, :, k] = t("gcv")[:, :, k] * BET_M
+            t("acol")[:, :, k] = t("gav")[:, :, k] * BET_P
+            t("ccol")[:, :, k] = t("gcv")[:, :, k] * BET_P
+            t("bcol")[:, :, k] = (dtr - t("acol")[:, :, k]) - t("ccol")[:, :, k]
+            t("correction_term")[:, :, k] = ((-t("as_")[:, :, k]) * (lvl("u_stage", k, 0, -1) - lvl("u_stage", k))) - (
+                t("cs")[:, :, k] * (lvl("u_stage", k, 0, 1) - lvl("u_stage", k)))
+            t("dcol")[:, :, k] = (((dtr * lvl("u_pos", k)) + lvl("utens", k)) + lvl("utens_stage", k)) + t("correction_term")[:, :, k]
+            t("divided")[:, :, k] = f8(1.0) / (t("bcol")[:, :, k] - (t("ccol")[:, :, k - 1] * t("acol")[:, :, k]))
+            t("ccol")[:, :, k] = t("ccol")[:, :, k] * t("divided")[:, :, k]
+            t("dcol")[:, :, k] = (t("dcol")[:, :, k] - (t("dcol")[:, :, k - 1] * t("acol")[:, :, k])) * t("divided")[:, :, k]
+        # FORWARD, interval(-1, None)
+        k = dk - 1
+        t("gav")[:, :, k] = (-f8(0.25)) * (lvl("wcon", k, 1, 0) + lvl("wcon", k))
+        t("as_")[:, :, k] = t("gav")[:, :, k] * BET_M
+        t("acol")[:, :, k] = t("gav")[:, :, k] * BET_P
+        t("bcol")[:, :, k] = dtr - t("acol")[:, :, k]
+        t("correction_term")[:, :, k] = (-t("as_")[:, :, k]) * (lvl("u_stage", k, 0, -1) - lvl("u_stage", k))
+        t("dcol")[:, :, k] = (((dtr * lvl("u_pos", k)) + lvl("utens", k)) + lvl("utens_stage", k)) + t("correction_term")[:, :, k]
+        t("divided")[:, :, k] = f8(1.0) / (t("bcol")[:, :, k] - (t("ccol")[:, :, k - 1] * t("acol")[:, :, k]))
+        t("dcol")[:, :, k] = (t("dcol")[:, :, k] - (t("dcol")[:, :, k - 1] * t("acol")[:, :, k])) * t("divided")[:, :, k]
+        # BACKWARD, interval(-1, None)
+        k = dk - 1
+        t("datacol")[:, :, k] = t("dcol")[:, :, k]
+        lvl("utens_stage", k)[...] = dtr * (t("datacol")[:, :, k] - lvl("u_pos", k))
+        # BACKWARD, interval(0, -1)
+        for k in range(dk - 2, -1, -1):
+            t("datacol")[:, :, k] = t("dcol")[:, :, k] - (t("ccol")[:, :, k] * t("datacol")[:, :, k + 1])
+            lvl("utens_stage", k)[...] = dtr * (t("datacol")[:, :, k] - lvl("u_pos", k))
+    return utens_stage
+
+
+# --------------------------------------------------------------------------------------
 # Point-by-point restatements (the "debug" backend's loop order, gtc/debug/debug_codegen.py:
 # 93-134).  Pure Python loops: small cases only.  Independent of the slicing code above.
 # --------------------------------------------------------------------------------------

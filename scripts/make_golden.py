@@ -143,10 +143,84 @@ def make_stencil_vectors() -> None:
     np.savez_compressed(OUT / "stencils_small.npz", **out)
 
 
+def make_vadv_vector() -> None:
+    """tests/golden/vadv_small.npz: ``vertical_advection_dycore`` (stencil_definitions.py:235-313) as the statement code
+    the numpy backend's rules give (sequential K = single-level slices k_:k_+1, statements in program order, temporaries as
+    domain-sized ``Field.empty`` arrays, npir_codegen.py:64-104, 205-212, 243-248) on the reference's real ``Field`` shim,
+    with a different origin per field.  A file of its own: stencils_small.npz stays byte for byte what it was."""
+    Field = _load(REF / "cartesian" / "utils" / "field.py", "_ref_field").Field
+    T3 = (True, True, True)
+    rng = np.random.default_rng(20261002)
+    dom = (5, 4, 11)
+    dI, dJ, dK = dom
+    f8 = np.float64
+    origins = {"utens_stage": (1, 0, 2), "u_stage": (0, 2, 1), "wcon": (2, 1, 0), "u_pos": (0, 0, 0), "utens": (1, 1, 1)}
+    shapes = {"utens_stage": (7, 5, 14), "u_stage": (6, 7, 13), "wcon": (8, 6, 12), "u_pos": (5, 4, 11), "utens": (6, 6, 13)}
+    arrays = {n: rng.uniform(-1, 1, shapes[n]) for n in origins}
+    result = arrays["utens_stage"].copy()
+    utens_stage, u_stage, wcon, u_pos, utens = (
+        Field(result if n == "utens_stage" else arrays[n], origins[n], T3) for n in ("utens_stage", "u_stage", "wcon", "u_pos", "utens"))
+    dtr_stage, BET_M, BET_P = f8(3.0 / 20.0), f8(0.5), f8(0.5)
+    tmp = {n: Field.empty((dI, dJ, dK), f8, (0, 0, 0), T3) for n in
+           ("gcv", "cs", "ccol", "bcol", "correction_term", "dcol", "divided", "gav", "as_", "acol", "datacol")}
+    gcv, cs, ccol, bcol, correction_term, dcol, divided, gav, as_, acol, datacol = (tmp[n] for n in (
+        "gcv", "cs", "ccol", "bcol", "correction_term", "dcol", "divided", "gav", "as_", "acol", "datacol"))
+    i, I, j, J = 0, dI, 0, dJ
+    for k_ in range(0, 1):  # FORWARD, interval(0, 1)
+        s, n1 = slice(k_, k_ + 1), slice(k_ + 1, k_ + 2)
+        gcv[i:I, j:J, s] = f8(0.25) * (wcon[i + 1:I + 1, j:J, n1] + wcon[i:I, j:J, n1])
+        cs[i:I, j:J, s] = gcv[i:I, j:J, s] * BET_M
+        ccol[i:I, j:J, s] = gcv[i:I, j:J, s] * BET_P
+        bcol[i:I, j:J, s] = dtr_stage - ccol[i:I, j:J, s]
+        correction_term[i:I, j:J, s] = (-cs[i:I, j:J, s]) * (u_stage[i:I, j:J, n1] - u_stage[i:I, j:J, s])
+        dcol[i:I, j:J, s] = (((dtr_stage * u_pos[i:I, j:J, s]) + utens[i:I, j:J, s]) + utens_stage[i:I, j:J, s]) + correction_term[i:I, j:J, s]
+        divided[i:I, j:J, s] = f8(1.0) / bcol[i:I, j:J, s]
+        ccol[i:I, j:J, s] = ccol[i:I, j:J, s] * divided[i:I, j:J, s]
+        dcol[i:I, j:J, s] = dcol[i:I, j:J, s] * divided[i:I, j:J, s]
+    for k_ in range(1, dK - 1):  # FORWARD, interval(1, -1)
+        s, n1, p1 = slice(k_, k_ + 1), slice(k_ + 1, k_ + 2), slice(k_ - 1, k_)
+        gav[i:I, j:J, s] = (-f8(0.25)) * (wcon[i + 1:I + 1, j:J, s] + wcon[i:I, j:J, s])
+        gcv[i:I, j:J, s] = f8(0.25) * (wcon[i + 1:I + 1, j:J, n1] + wcon[i:I, j:J, n1])
+        as_[i:I, j:J, s] = gav[i:I, j:J, s] * BET_M
+        cs[i:I, j:J, s] = gcv[i:I, j:J, s] * BET_M
+        acol[i:I, j:J, s] = gav[i:I, j:J, s] * BET_P
+        ccol[i:I, j:J, s] = gcv[i:I, j:J, s] * BET_P
+        bcol[i:I, j:J, s] = (dtr_stage - acol[i:I, j:J, s]) - ccol[i:I, j:J, s]
+        correction_term[i:I, j:J, s] = ((-as_[i:I, j:J, s]) * (u_stage[i:I, j:J, p1] - u_stage[i:I, j:J, s])) - (
+            cs[i:I, j:J, s] * (u_stage[i:I, j:J, n1] - u_stage[i:I, j:J, s]))
+        dcol[i:I, j:J, s] = (((dtr_stage * u_pos[i:I, j:J, s]) + utens[i:I, j:J, s]) + utens_stage[i:I, j:J, s]) + correction_term[i:I, j:J, s]
+        divided[i:I, j:J, s] = f8(1.0) / (bcol[i:I, j:J, s] - (ccol[i:I, j:J, p1] * acol[i:I, j:J, s]))
+        ccol[i:I, j:J, s] = ccol[i:I, j:J, s] * divided[i:I, j:J, s]
+        dcol[i:I, j:J, s] = (dcol[i:I, j:J, s] - (dcol[i:I, j:J, p1] * acol[i:I, j:J, s])) * divided[i:I, j:J, s]
+    for k_ in range(dK - 1, dK):  # FORWARD, interval(-1, None)
+        s, p1 = slice(k_, k_ + 1), slice(k_ - 1, k_)
+        gav[i:I, j:J, s] = (-f8(0.25)) * (wcon[i + 1:I + 1, j:J, s] + wcon[i:I, j:J, s])
+        as_[i:I, j:J, s] = gav[i:I, j:J, s] * BET_M
+        acol[i:I, j:J, s] = gav[i:I, j:J, s] * BET_P
+        bcol[i:I, j:J, s] = dtr_stage - acol[i:I, j:J, s]
+        correction_term[i:I, j:J, s] = (-as_[i:I, j:J, s]) * (u_stage[i:I, j:J, p1] - u_stage[i:I, j:J, s])
+        dcol[i:I, j:J, s] = (((dtr_stage * u_pos[i:I, j:J, s]) + utens[i:I, j:J, s]) + utens_stage[i:I, j:J, s]) + correction_term[i:I, j:J, s]
+        divided[i:I, j:J, s] = f8(1.0) / (bcol[i:I, j:J, s] - (ccol[i:I, j:J, p1] * acol[i:I, j:J, s]))
+        dcol[i:I, j:J, s] = (dcol[i:I, j:J, s] - (dcol[i:I, j:J, p1] * acol[i:I, j:J, s])) * divided[i:I, j:J, s]
+    for k_ in range(dK - 1, dK - 2, -1):  # BACKWARD, interval(-1, None)
+        s = slice(k_, k_ + 1)
+        datacol[i:I, j:J, s] = dcol[i:I, j:J, s]
+        utens_stage[i:I, j:J, s] = dtr_stage * (datacol[i:I, j:J, s] - u_pos[i:I, j:J, s])
+    for k_ in range(dK - 2, -1, -1):  # BACKWARD, interval(0, -1)
+        s, n1 = slice(k_, k_ + 1), slice(k_ + 1, k_ + 2)
+        datacol[i:I, j:J, s] = dcol[i:I, j:J, s] - (ccol[i:I, j:J, s] * datacol[i:I, j:J, n1])
+        utens_stage[i:I, j:J, s] = dtr_stage * (datacol[i:I, j:J, s] - u_pos[i:I, j:J, s])
+    out = {f"vadv_{n}": arrays[n] for n in arrays}
+    out.update(vadv_utens_stage_out=result, vadv_domain=dom, vadv_dtr_stage=float(dtr_stage),
+               vadv_origins=np.array([origins[n] for n in ("utens_stage", "u_stage", "wcon", "u_pos", "utens")]))
+    np.savez_compressed(OUT / "vadv_small.npz", **out)
+
+
 if __name__ == "__main__":
     if not REF.exists():
         sys.exit("the reference tree is not available here; fixtures are committed under tests/golden/")
     OUT.mkdir(parents=True, exist_ok=True)
     make_layout_tables()
     make_stencil_vectors()
+    make_vadv_vector()
     print("wrote", sorted(p.name for p in OUT.iterdir()))

@@ -271,6 +271,50 @@ def test_large_domain_properties_512cubed():
     assert np.array_equal(out[1:-1, 201:214, 100:103].get(), want[1:-1, 1:-1])
 
 
+def test_baseline_config1_512x512x128_with_rotating_buffer_pairs():
+    """BASELINE.json configs[1] at its own size (512 x 512 x 128 fp64; one field = 285 MB with its halo, about the size of
+    the 256 MB Infinity Cache), applied over FOUR rotating (inp, out) pairs the way bench.py times it (SURVEY.md section
+    8d: >= 3 pairs, so that a cache-resident previous pass cannot flatter the number -- or hide a stale read here).
+    Every pair: the known answer lap(x^2 + y^2) == 4 on the whole domain, the halo of `out` untouched, and a random
+    field's slab against the oracle; results of earlier pairs still intact after the later launches."""
+    from oracle import ref_numpy as R
+
+    gt_storage, gtscript = _imports()
+    import torch
+
+    lap = gtscript.stencil(backend=BACKEND, definition=lap_cartesian, device_sync=False)
+    dom = (512, 512, 128)
+    shape = (dom[0] + 2, dom[1] + 2, dom[2])
+    origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}
+    frozen = lap.freeze(origin=origin, domain=dom)
+    x = torch.arange(shape[0], dtype=torch.float64, device="cuda").reshape(-1, 1, 1)
+    y = torch.arange(shape[1], dtype=torch.float64, device="cuda").reshape(1, -1, 1)
+    g = torch.Generator(device="cuda").manual_seed(1337)
+    pairs = []
+    for n in range(4):
+        inp = gt_storage.empty(shape, backend=BACKEND, aligned_index=(1, 1, 0))
+        out = gt_storage.full(shape, -3.0, backend=BACKEND, aligned_index=(1, 1, 0))
+        if n % 2 == 0:
+            inp.tensor.copy_(((x * x + y * y) * float(n + 1)).expand(shape))
+        else:
+            inp.tensor.copy_(torch.rand(shape, dtype=torch.float64, device="cuda", generator=g) * 2 - 1)
+        pairs.append((inp, out))
+    for rounds in range(3):  # the rotation of the benchmark: pair 0, 1, 2, 3, 0, 1, ...
+        for inp, out in pairs:
+            frozen(inp=inp, out=out)
+    torch.cuda.synchronize()
+    for n, (inp, out) in enumerate(pairs):
+        t = out.tensor
+        assert bool((t[0] == -3.0).all()) and bool((t[-1] == -3.0).all()) and bool((t[:, 0] == -3.0).all()) and bool((t[:, -1] == -3.0).all())
+        if n % 2 == 0:
+            assert bool((t[1:-1, 1:-1, :] == 4.0 * (n + 1)).all())
+        else:
+            slab = inp[:, 300:318, 60:64].get()
+            want = np.zeros_like(slab)
+            R.laplacian(slab, want)
+            assert np.array_equal(out[1:-1, 301:317, 60:64].get(), want[1:-1, 1:-1])
+
+
 def test_large_domain_properties_hdiff_and_tridiagonal():
     """BASELINE sizes C3 (1024x1024x80 fp32 hdiff) and C4 (1024x1024x160 fp64 tridiagonal): properties
     that need no full-size CPU run.

@@ -278,3 +278,87 @@ def test_the_frontend_builds_exactly_the_hand_written_trees():
             # ... and the extent analysis finds the block extents written down by hand above
             found = analysis.compute_extents(parsed)
             assert found.blocks == ext.blocks and {k: found.fields[k] for k in ext.fields} == ext.fields
+
+
+# ---- 3. vertical_advection_dycore: out of common mode ------------------------------
+# Until round 3 the generated column kernel of this stencil was checked only against ``oracle.numpy_backend`` fed by the
+# PRODUCT's frontend / IR.  ``ref_numpy.vadv`` and ``ref_debug_order.vadv_debug_order`` are written against the reference's
+# definition (stencil_definitions.py:235-313) and touch neither; tests/golden/vadv_small.npz was produced on the
+# reference's own ``Field`` shim (scripts/make_golden.py).
+VADV_GOLD = np.load(pathlib.Path(__file__).parent / "golden" / "vadv_small.npz")
+VADV_FIELDS = ("utens_stage", "u_stage", "wcon", "u_pos", "utens")
+
+
+def _vadv_golden_case():
+    origins = {n: tuple(int(v) for v in VADV_GOLD["vadv_origins"][k]) for k, n in enumerate(VADV_FIELDS)}
+    fields = {n: VADV_GOLD["vadv_" + n].copy() for n in VADV_FIELDS}
+    return fields, origins, tuple(int(v) for v in VADV_GOLD["vadv_domain"]), float(VADV_GOLD["vadv_dtr_stage"])
+
+
+@pytest.mark.parametrize("which", ["slices", "debug order"])
+def test_vadv_restatements_reproduce_the_golden_vector(which):
+    fields, origins, domain, dtr = _vadv_golden_case()
+    fn = R.vadv if which == "slices" else DBG.vadv_debug_order
+    fn(*[fields[n] for n in VADV_FIELDS], dtr, origins=origins, domain=domain)
+    assert _same(fields["utens_stage"], VADV_GOLD["vadv_utens_stage_out"])
+    for n in VADV_FIELDS[1:]:
+        assert _same(fields[n], VADV_GOLD["vadv_" + n])  # read-only fields untouched
+
+
+def _vadv_definition():
+    import bench
+
+    return bench._vertical_advection_dycore
+
+
+@pytest.mark.parametrize("domain", [(6, 5, 3), (4, 3, 4), (9, 4, 17), (3, 2, 64)])  # K >= 3: the stencil's minimum (gtir_k_boundary.py:78-109)
+def test_vadv_three_ways_and_through_the_frontend(domain):
+    """Level-by-level slices == debug-backend order == the generic oracle interpreting the PRODUCT frontend's IR of the
+    same definition: the frontend / IR path is now pinned by two restatements that do not use it."""
+    from gt4py_amd.cartesian import gtscript
+
+    rng = np.random.default_rng(sum(domain))
+    shape = (domain[0] + 1, domain[1], domain[2] + 1)
+    fields = {n: rng.uniform(-1, 1, shape) for n in VADV_FIELDS}
+    runs = [{n: v.copy() for n, v in fields.items()} for _ in range(3)]
+    R.vadv(*[runs[0][n] for n in VADV_FIELDS], 0.15, domain=domain)
+    DBG.vadv_debug_order(*[runs[1][n] for n in VADV_FIELDS], 0.15, domain=domain)
+    ref = gtscript.stencil(backend="numpy", definition=_vadv_definition(), externals={"BET_M": 0.5, "BET_P": 0.5})
+    ref(**runs[2], dtr_stage=0.15, origin=(0, 0, 0), domain=domain)
+    for n in VADV_FIELDS:
+        assert _same(runs[0][n], runs[1][n]) and _same(runs[0][n], runs[2][n]), n
+    assert not _same(runs[0]["utens_stage"], fields["utens_stage"])
+
+
+def vadv_residual(fields_before, utens_stage_after, dtr, domain):
+    """Largest residual of the tridiagonal system the stencil solves, assembled independently of the sweeps:
+    a_k x_(k-1) + b_k x_k + c_k x_(k+1) = d_k with x = utens_stage / dtr + u_pos, relative to |d| + |b x|."""
+    di, dj, dk = domain
+    f = {n: v[:di + 1, :dj, :dk + 1] for n, v in fields_before.items()}
+    w = f["wcon"]
+    gav = -0.25 * (w[1:, :, :dk] + w[:-1, :, :dk])      # level k
+    gcv = 0.25 * (w[1:, :, 1:dk + 1] + w[:-1, :, 1:dk + 1])  # level k + 1
+    a, c = gav * 0.5, gcv * 0.5
+    a[:, :, 0], c[:, :, dk - 1] = 0.0, 0.0
+    b = dtr - a - c
+    us = f["u_stage"][:di, :, :]
+    corr = np.zeros((di, dj, dk))
+    corr[:, :, 1:] += -a[:, :, 1:] * (us[:, :, 0:dk - 1] - us[:, :, 1:dk])
+    corr[:, :, :dk - 1] += -c[:, :, :dk - 1] * (us[:, :, 1:dk] - us[:, :, 0:dk - 1])
+    d = dtr * f["u_pos"][:di, :, :dk] + f["utens"][:di, :, :dk] + f["utens_stage"][:di, :, :dk] + corr
+    x = utens_stage_after[:di, :dj, :dk] / dtr + f["u_pos"][:di, :, :dk]
+    lhs = b * x
+    lhs[:, :, 1:] += a[:, :, 1:] * x[:, :, :-1]
+    lhs[:, :, :-1] += c[:, :, :-1] * x[:, :, 1:]
+    return float(np.max(np.abs(lhs - d) / (np.abs(d) + np.abs(b * x) + 1e-300)))
+
+
+def test_vadv_solves_the_tridiagonal_system_it_assembles():
+    rng = np.random.default_rng(3)
+    domain = (7, 6, 40)
+    shape = (domain[0] + 1, domain[1], domain[2] + 1)
+    before = {n: rng.uniform(-1, 1, shape) for n in VADV_FIELDS}
+    after = {n: v.copy() for n, v in before.items()}
+    # dtr_stage = 3 makes the system diagonally dominant (|a| + |c| <= 0.5 for wcon in [-1, 1))
+    R.vadv(*[after[n] for n in VADV_FIELDS], 3.0, domain=domain)
+    assert vadv_residual(before, after["utens_stage"], 3.0, domain) < 1e-13

@@ -301,10 +301,12 @@ def other_kernels(steps: int = 20):
               "sup": field(dom, np.float64, (0, 0, 0)), "rhs": field(dom, np.float64, (0, 0, 0), -10.0, 10.0),
               "out": field(dom, np.float64, (0, 0, 0))}
     run("tridiagonal_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 56.0,
-        note="the backward sweep re-reads the part of sup', rhs' that does not fit on chip (120 of 160 levels stay in "
-             "registers + LDS): 60.2 B/LUP moved (PMC, profiles/r2_kernel_hbm_traffic_pmc.txt); inputs are whatever the previous launch left in sup/rhs "
-             "(timing only, values are checked in tests/); speed depends on the box by +-10 % (address translation, "
-             "profiles/r2_tridiag_translation_counters.txt)")
+        note="measured range over the boxes of rounds 1-3: 0.60-0.73 of the HBM peak (84-104 GLUPS; the K-strided column "
+             "kernels are the only ones whose speed depends on the box, +-10 %: address translation, "
+             "profiles/r2_tridiag_translation_counters.txt); a 4-read / 3-write streaming kernel reaches 0.71 "
+             "(profiles/r3_microbench_rw_mix.log).  The backward sweep re-reads the part of sup', rhs' that does not fit on chip (144 of 160 levels stay in "
+             "registers + LDS): 57.6 B/LUP moved (PMC, profiles/r2_kernel_hbm_traffic_pmc.txt); inputs are whatever the previous launch left "
+             "in sup/rhs (timing only, values are checked in tests/)")
     out["tridiagonal_f64_1024x1024x160"]["field_addresses_mod_4MiB"] = [int(f.ptr % (4 << 20)) for f in fields.values()]
     del fields
     torch.cuda.empty_cache()
@@ -465,7 +467,10 @@ def cpu_baseline_child(seconds_budget: float) -> None:
         "kind": "port",
         "sample": f"fp64 5-pt Laplacian on the full {dom[0]}x{dom[1]}x{dom[2]} grid, {len(rates)} batches of {batch} "
                   f"applies in {dt:.1f} s (median batch), C/OpenMP restatement of gt:cpu_ifirst semantics "
-                  f"(oracle/cpu_ifirst.c), I-contiguous, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores)",
+                  f"(oracle/cpu_ifirst.c), I-contiguous, threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores); "
+                  f"{lib.oracle_max_threads()} threads = what the container may keep busy (min of affinity mask and cgroup CPU "
+                  f"quota) of the host's {os.cpu_count()} logical CPUs",
+        "host_logical_cpus": os.cpu_count(),
         "gb_per_s": round(med * BYTES_PER_LUP, 2),
         "batch_glups_min_max": [round(min(rates), 3), round(max(rates), 3)],
         "spread_pct": round(100.0 * (max(rates) - min(rates)) / med, 1),

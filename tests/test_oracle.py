@@ -206,3 +206,23 @@ def test_c_restatement_matches_numpy_restatement():
     R.tridiag(inf, diag, s1, r1, o1)
     C.tridiag_f64(inf, diag, s2, r2, o2, shape, threads=2)
     assert np.array_equal(o2, o1) and np.array_equal(s2, s1) and np.array_equal(r2, r1)
+
+
+def test_c_restatement_is_clean_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """Sanitizers belong on the CPU build (GPU AddressSanitizer is not available on this pool): oracle/selftest_cpu_ifirst.c
+    runs every entry point of oracle/cpu_ifirst.c on heap arrays exactly as large as the stencils' reach requires, on both
+    layouts and on degenerate domains, under -fsanitize=address,undefined with recovery off."""
+    import pathlib
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    src = pathlib.Path(__file__).resolve().parent.parent / "oracle" / "selftest_cpu_ifirst.c"
+    exe = tmp_path / "selftest_cpu_ifirst"
+    build = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
+                            "-ffp-contract=off", "-Wall", "-o", str(exe), str(src), "-lm"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "clean under the sanitizers" in run.stdout, (run.stdout + run.stderr)[-2000:]
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr

@@ -708,11 +708,29 @@ def _setup_distributed_laplacian(args, ctx):
         inp, out = pairs[i % len(pairs)]
         frozen(inp=inp, out=out)
 
+    def pipelined_applies():
+        """The same independent applies WITHOUT the per-apply join (GT4MI_PLAN_DEFER_JOIN): each (inp, out) pair has its own
+        plan and side stream, so the interior of apply i + 1 runs next to the exchange and ring of apply i; every apply
+        still exchanges its own input's ghost cells.  ms per apply, slowest rank."""
+        table = {}
+        for cand_wg in (0, 4, 2):
+            call, keep = apply_candidate(grid, single_phase, "chain", cand_wg)
+            for ex in keep[2]:
+                ex.tune(defer_join=True)
+            table[f"chain_wg{cand_wg}"] = round(_slowest_rank_ms(ctx, call, 48), 5)
+            for ex in keep[2]:
+                ex.end()
+                ex.close()
+            del call, keep
+        torch.cuda.empty_cache()
+        return table
+
     def timestep_extras():
         """The communication-avoiding time steppers (u <- lap(u), ghost regions H deep, one exchange per H steps) on the
         chosen grid: ms per STEP of every schedule x depth, slowest rank; collective, so every rank runs it."""
         if transport != "native" or os.environ.get("GT4MI_BENCH_TIMESTEP", "1") == "0":
             return None
+        pipelined = pipelined_applies() if mode == "apply" else None
         table = {}
         for cand_halo in (1, 2, 3, 4):
             if cand_halo > 1 and ((grid[1] > 1 or selfloop) and total[1] // grid[1] < 2 * (2 * cand_halo - 1)
@@ -740,7 +758,15 @@ def _setup_distributed_laplacian(args, ctx):
         torch.cuda.empty_cache()
         best = min(table, key=table.get)
         lups = float(np.prod(dec.global_domain))
-        return {"timestep_glups": round(lups / table[best] / 1e6, 2), "timestep_best": best, "timestep_ms_per_step": table,
+        out = {}
+        if pipelined:
+            pbest = min(pipelined, key=pipelined.get)
+            out = {"pipelined_apply_glups": round(lups / pipelined[pbest] / 1e6, 2), "pipelined_apply_best": pbest,
+                   "pipelined_apply_ms": pipelined,
+                   "pipelined_apply_workload": "the applies of `value` without the join after each one: the applies are independent "
+                                               "(two rotating pairs, a plan and side stream each), so apply i + 1's interior kernel "
+                                               "runs next to apply i's exchange and ring; every apply still exchanges its own ghost cells"}
+        return {**out, "timestep_glups": round(lups / table[best] / 1e6, 2), "timestep_best": best, "timestep_ms_per_step": table,
                 "timestep_workload": "time stepping u <- lap(u) on the same decomposed grid, ghost regions H deep, ONE exchange "
                                      "per H steps (skewed: boundary bands first, the faces travel next to H interior kernels; "
                                      "wide: grown launches, exchange next to one interior kernel / after a full-domain kernel) "
@@ -857,6 +883,26 @@ def _setup_hdiff2048(args, ctx):
     def kernel_step(i):
         frozen(**fields)
 
+    def pipelined_applies():
+        """Back-to-back applies without the join after each one (GT4MI_PLAN_DEFER_JOIN; the bench's applies are independent):
+        the interior of apply i + 1 runs next to the exchange and ring of apply i."""
+        if transport != "native":
+            return None
+        table = {}
+        flags = type(hd)._gt_binding_.flags
+        for single in (False, True):
+            for cand_wg in (0, 3, 2):
+                ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune("chain", cand_wg, defer_join=True)
+                fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
+                table[f"{'single' if single else 'two'}_phase_chain_wg{cand_wg}"] = round(_slowest_rank_ms(ctx, fn, 32), 5)
+                ex.end()
+                ex.close()
+        best = min(table, key=table.get)
+        return {"pipelined_apply_glups": round(float(np.prod(total)) / table[best] / 1e6, 2), "pipelined_apply_best": best,
+                "pipelined_apply_ms": table,
+                "pipelined_apply_workload": "the applies of `value` without the join after each one (they are independent): apply "
+                                            "i + 1's interior kernel runs next to apply i's exchange and ring"}
+
     config = {"workload": "BASELINE.json configs[4]: fp64 horizontal diffusion (lap-of-lap + flux limiter), "
                           f"{HDIFF_SHARE[0]}x{HDIFF_SHARE[1]}x{HDIFF_SHARE[2]} per rank (weak scaling; 8 ranks = 2048x2048x80 on the "
                           "4x2 grid), ghost depth 2, in_field's ghost cells exchanged every apply",
@@ -865,7 +911,7 @@ def _setup_hdiff2048(args, ctx):
               "transport": transport, "selfloop": bool(selfloop), "apply_form": choice,
               "calibration_ms_per_apply": timings}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen),
-              "proof": proof, "transport_fallback": fallback}
+              "proof": proof, "transport_fallback": fallback, "timestep": pipelined_applies if decomposed else None}
     return step, kernel_step, dec.local_domain, config, extras
 
 

@@ -220,10 +220,31 @@ GT_DEV float gt_round_away_from_zero(float a) { return __builtin_copysignf(__bui
 // Workgroup -> tile.  The dispatcher deals workgroups round-robin to the 8 XCDs in linear order (x
 // fastest); give each XCD runs of `rows` consecutive tile rows instead of every 8th tile.
 GT_DEV void gt_tile(unsigned rows, unsigned& bx, unsigned& by, unsigned& bz) {
+    if (rows == 0u) {  // no grouping: the hardware's own order
+        bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+        return;
+    }
     const unsigned long long gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    if (n < 0x80000000ull) {
+        // 32-bit index arithmetic (every launch in practice): a 64-bit division is ~100 scalar instructions, and a strip
+        // kernel's workgroup lives for a few microseconds -- five of them in front of the first load cost the generated
+        // Laplacian 2-3 % (profiles/r3_codegen_strip_blocks.log)
+        const unsigned ux = gridDim.x, uy = gridDim.y, un = (unsigned)n;
+        unsigned l = blockIdx.x + ux * (blockIdx.y + uy * blockIdx.z);
+        const unsigned g = ux * rows, span = 8u * g;
+        if (l < (un / span) * span) {
+            const unsigned xcd = l & 7u, slot = l >> 3, run = slot / g;
+            l = (run * 8u + xcd) * g + (slot - run * g);
+        }
+        const unsigned row = l / ux;
+        bx = l - row * ux;
+        bz = row / uy;
+        by = row - bz * uy;
+        return;
+    }
     unsigned long long l = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
     const unsigned long long g = gx * rows, span = 8ull * g;
-    if (rows != 0u && l < (n / span) * span) {
+    if (l < (n / span) * span) {
         const unsigned long long xcd = l % 8ull, slot = l / 8ull;
         l = ((slot / g) * 8ull + xcd) * g + slot % g;
     }
@@ -314,6 +335,8 @@ class KernelSource:
     #: arithmetic is what binds the recomputing kernel); with 4-byte temporaries recomputing is cheaper than passing
     #: them around (all-float32 hdiff: 466 GLUPS recomputing, 441 sharing; fp64 internals: 418 and 434)
     shared_preferred: bool = False
+    #: workgroup shape of the `_vec` kernel when it differs from `block` (light stages: 256 x 1, see _strip_shape)
+    vec_block: Optional[Tuple[int, int, int]] = None
 
 
 @dataclass
@@ -1101,9 +1124,9 @@ class _Emitter:
             top_cache = tuple(variants) or None
         vec = _vector_width(self, stage) if j_per_thread == 1 and block[0] % 64 == 0 else 0
         vec_fields: Tuple[str, ...] = ()
-        vec_rows, xcd_rows = _strip_shape(self, stage) if vec else (max(1, TUNING["vector_rows"]), TUNING["xcd_rows"])
+        vec_rows, xcd_rows, vec_block = _strip_shape(self, stage, block) if vec else (max(1, TUNING["vector_rows"]), TUNING["xcd_rows"], block)
         if vec:
-            vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, block, k_per_thread, xcd_rows)
+            vec_fields = _emit_vector_kernel(self, si, stage, kname, vec, vec_rows, vec_block, k_per_thread, xcd_rows)
         shared_halo, shared_vec, shared_fields, shared_rows, shared_preferred = 0, 0, (), 0, False
         svec = vec or (_vector_width(self, stage, any_reach=True) if j_per_thread == 1 and block[0] % 64 == 0 else 0)
         if svec:
@@ -1116,7 +1139,7 @@ class _Emitter:
         plane = None if stage.plane is None else (stage.plane[0], stage.plane[1].value, stage.plane[2])
         return KernelSource(kname, stage.mapping, stage.extent, block, k_per_thread, j_per_thread, vec, vec_fields,
                             vec_rows if vec else 1, plane, top_cache, shared_halo, shared_rows if shared_halo else 0,
-                            shared_vec, shared_fields, shared_preferred)
+                            shared_vec, shared_fields, shared_preferred, vec_block if vec and vec_block != block else None)
 
 
 def _vector_width(em: "_Emitter", stage: Stage, any_reach: bool = False) -> int:
@@ -1164,24 +1187,29 @@ def _vector_width(em: "_Emitter", stage: Stage, any_reach: bool = False) -> int:
     return vec
 
 
-def _strip_shape(em: "_Emitter", stage: Stage) -> Tuple[int, int]:
-    """(J rows per lane, rows per XCD run) of a stage's strip kernel.  Measured in round 1
+def _strip_shape(em: "_Emitter", stage: Stage, block=(64, 4, 1)) -> Tuple[int, int, Tuple[int, int, int]]:
+    """(J rows per lane, rows per XCD run, workgroup shape) of a stage's strip kernel.  Measured in round 1
     (profiles/r1_codegen_sweep.log, r1_codegen_xcd_rows_strip_kernels.log): 8 rows per lane and XCD runs of 4 tile rows
     help the Laplacian (+2 % and +4 %) and hurt horizontal diffusion (-8 % registers, -5 %), so the tall, XCD-grouped shape
-    is for LIGHT stages only: one statement reading one 8-byte array within one row / column of the point.  Explicit
-    settings of GT4MI_CODEGEN_VECTOR_ROWS / _XCD_ROWS win."""
+    is for LIGHT stages only: one statement reading one 8-byte array within one row / column of the point.  Round 3: those
+    stages also get the hand-written kernel's workgroup, 256 lanes along I x 1 (a tile of 512 columns x 8 rows instead of
+    128 x 32: the wave edges' neighbour columns are then mostly inside the workgroup) -- 364 -> 368 GLUPS on the 512^3
+    Laplacian (profiles/r3_codegen_strip_blocks.log).  Explicit settings of GT4MI_CODEGEN_VECTOR_ROWS / _XCD_ROWS /
+    _BLOCK_IJK win."""
     import os
 
     rows, xcd = max(1, TUNING["vector_rows"]), TUNING["xcd_rows"]
     if "GT4MI_CODEGEN_VECTOR_ROWS" in os.environ or "GT4MI_CODEGEN_XCD_ROWS" in os.environ:
-        return rows, xcd
+        return rows, xcd, tuple(block)
     stmts = [s for nest in stage.nests for s in nest.stmts]
     reads = [e for s in stmts for e in _stmt_field_reads(s) if e.name not in em.plan.locals]
     arrays = {e.name for e in reads}
     light = (len(stmts) == 1 and len(stage.nests) == 1 and len(arrays) == 1
              and all(max(abs(e.offset[0]), abs(e.offset[1])) <= 1 and e.offset[2] == 0 for e in reads)
              and all(em.decl_dtype[n].itemsize == 8 for n in arrays | {stmts[0].target.name}))
-    return (8, 4) if light else (rows, xcd)
+    if not light:
+        return rows, xcd, tuple(block)
+    return 8, 4, (tuple(block) if "GT4MI_CODEGEN_BLOCK_IJK" in os.environ else (256, 1, 1))
 
 
 def _shared_form(em: "_Emitter", stage: Stage, vec: int, k_per_thread: int):
@@ -1546,6 +1574,11 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
                     for v in range(vec):
                         need.add(v + e.offset[0])
         names: Dict[Tuple[str, int, int], Dict[int, str]] = {}
+        # Every row's 16-byte load is issued BEFORE the first lane shift: a shift waits for its row, and the edge lanes'
+        # scalar loads sit in branches the scheduler does not move loads across -- interleaved row by row (as this was
+        # emitted until round 3) the later rows' loads queued up behind them (the hand-written lap5_strip_tile issues all
+        # LJ + 2 rows up front: +8 % there, profiles/r1_microbench_*.log).
+        after_loads: List[str] = []
         for rn, ((name, dj, dk), need) in enumerate(sorted(rows.items(), key=lambda kv: (kv[0][0], kv[0][2], kv[0][1]))):
             c = _c_ident(name)
             ct = _CTYPE[em.decl_dtype[name].name]
@@ -1556,15 +1589,16 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
             elems = {v: f"r{rn}[{v}]" for v in range(vec)}
             for e in sorted(x for x in need if x < 0):  # from the lane below: its component vec + e
                 var = f"r{rn}_m{-e}"
-                L.append(f"        {ct} {var} = gt_shift<{ct}, true>(r{rn}[{vec + e}]);")
-                L.append(f"        if (edge_lo) {var} = p{rn}[{e}];")
+                after_loads.append(f"        {ct} {var} = gt_shift<{ct}, true>(r{rn}[{vec + e}]);")
+                after_loads.append(f"        if (edge_lo) {var} = p{rn}[{e}];")
                 elems[e] = var
             for e in sorted(x for x in need if x >= vec):  # from the lane above: its component e - vec
                 var = f"r{rn}_p{e}"
-                L.append(f"        {ct} {var} = gt_shift<{ct}, false>(r{rn}[{e - vec}]);")
-                L.append(f"        if (edge_hi) {var} = p{rn}[{e}];")
+                after_loads.append(f"        {ct} {var} = gt_shift<{ct}, false>(r{rn}[{e - vec}]);")
+                after_loads.append(f"        if (edge_hi) {var} = p{rn}[{e}];")
                 elems[e] = var
             names[(name, dj, dk)] = elems
+        L.extend(after_loads)
         em.vec_rows = names
         for jv in range(JT):
             for v in range(vec):

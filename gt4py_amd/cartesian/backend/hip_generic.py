@@ -438,6 +438,8 @@ class HipGenericStencilObject(StencilObject):
                     geometry[n][0] % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0
                     and geometry[n][2] % kern.vec == 0 for n in kern.vec_fields):
                 fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned
+                block = kern.vec_block or kern.block
+                return fn, _U3(-(-ni // (block[0] * lanes)), -(-nj // (block[1] * rows)), nk), _U3(*block)
             grid = _U3(-(-ni // (kern.block[0] * lanes)), -(-nj // (kern.block[1] * kern.j_per_thread * rows)), nk)
             return fn, grid, _U3(*kern.block)
 

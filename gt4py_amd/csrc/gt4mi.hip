@@ -128,7 +128,8 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
         if (int rc = gt4mi::halo_exchange_on(plan, in_field, plan->stream)) return rc;
         if (int rc = gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, plan->stream)) return rc;
         GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-        GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+        plan->primed = true;
+        if (!plan->defer_join) GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
         return GT4MI_OK;
     }
     // Schedule "join": 1. pack the first faces on the main stream, ahead of the interior kernel (alone: ~5 us; next to it: 20+)
@@ -377,6 +378,10 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
             if (value < -1 || value > GT4MI_SCHEDULE_CHAIN) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
             plan->schedule = value;
             return GT4MI_OK;
+        case GT4MI_PLAN_DEFER_JOIN:
+            if (value != 0 && value != 1) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: defer_join %d", value);
+            plan->defer_join = value;
+            return GT4MI_OK;
         case GT4MI_PLAN_INTERIOR_WG_PER_CU:
             if (value < -1 || value > 16) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: %d workgroups per CU", value);
             plan->interior_wg_per_cu = value;
@@ -434,6 +439,7 @@ int gt4mi_halo_exchange_begin(gt4mi_halo_plan* plan, const gt4mi_field* field, v
 
 int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream) {
     if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_exchange_end: null plan");
+    if (!plan->primed) return GT4MI_OK;  // nothing in flight: `done` was never recorded
     GT4MI_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(main_stream), plan->done, 0));
     return GT4MI_OK;
 }
@@ -471,7 +477,8 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
         if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream)) return rc;
         if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, plan->stream)) return rc;
         GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-        return gt4mi_halo_exchange_end(plan, main_stream);
+        plan->primed = true;
+        return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
     }
     // 1. pack the first faces ON THE MAIN STREAM, ahead of the interior kernel: alone it takes ~5 us;
     //    launched next to the interior kernel's thousands of workgroups it took 22 us and delayed the

@@ -138,18 +138,23 @@ class NativeHaloExchanger:
         self.sides = ((1 if nb["W"] is not None else 0) | (2 if nb["E"] is not None else 0)
                       | (4 if nb["S"] is not None else 0) | (8 if nb["N"] is not None else 0))
 
-    def tune(self, schedule: Optional[str] = None, interior_wg_per_cu: Optional[int] = None) -> "NativeHaloExchanger":
+    def tune(self, schedule: Optional[str] = None, interior_wg_per_cu: Optional[int] = None,
+             defer_join: Optional[bool] = None) -> "NativeHaloExchanger":
         """How the fused distributed steps built on this exchanger are scheduled (gt4mi_halo_plan_set_option):
         ``schedule`` "join" (pack and interior on the caller's stream, send/recv/unpack beside it, join, ring) or "chain"
         (the caller's stream carries the interior only; pack, send/recv, unpack and ring in order on the side stream);
         ``interior_wg_per_cu`` limits the occupancy of the interior kernel while the exchange runs next to it (0 = no
-        limit).  ``None`` leaves an option at the entry point's default."""
+        limit); ``defer_join`` (chain schedule) lets a fused step return without joining the side stream -- for INDEPENDENT
+        applies, whose results the caller consumes only after ``end()``.  ``None`` leaves an option as it is."""
         if schedule is not None:
             value = {"join": _lib.SCHEDULE_JOIN, "chain": _lib.SCHEDULE_CHAIN, "default": -1}[schedule]
             _lib.check("gt4mi_halo_plan_set_option", self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_SCHEDULE, value))
         if interior_wg_per_cu is not None:
             _lib.check("gt4mi_halo_plan_set_option",
                        self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_INTERIOR_WG_PER_CU, int(interior_wg_per_cu)))
+        if defer_join is not None:  # independent applies: the caller joins with end() before consuming results
+            _lib.check("gt4mi_halo_plan_set_option",
+                       self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_DEFER_JOIN, int(bool(defer_join))))
         return self
 
     def exchange(self, array) -> None:

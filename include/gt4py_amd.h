@@ -194,8 +194,12 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *   GT4MI_PLAN_INTERIOR_WG_PER_CU   at most this many workgroups of the INTERIOR kernel per CU while the exchange runs
  *                                   next to it (0 = no limit): an HBM-saturating kernel at full occupancy keeps tens of MB
  *                                   in flight and the send/recv kernel beside it waits ~10 us per memory access
+ *   GT4MI_PLAN_DEFER_JOIN           1 (chain schedule only): gt4mi_dist_hdiff_* / gt4mi_dist_lap5_f64 return WITHOUT making
+ *                                   the caller's stream wait for the side stream's chain; the caller joins with
+ *                                   gt4mi_halo_exchange_end before anything consumes the result.  For INDEPENDENT applies:
+ *                                   the interior of the next apply runs next to the exchange and ring of this one.
  * Which combination is fastest depends on the links; bench.py measures them (config.calibration_ms_per_apply). */
-enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1 };
+enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1, GT4MI_PLAN_DEFER_JOIN = 2 };
 enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1 };
 int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value);
 /* 1 = the plan's side stream was verified to run concurrently with the caller's stream, 0 = no

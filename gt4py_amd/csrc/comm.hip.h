@@ -108,7 +108,8 @@ struct gt4mi_halo_plan {
     hipStream_t stream = nullptr;         // side stream the exchange runs on in the overlapped form
     hipEvent_t ready = nullptr, done = nullptr;
     bool forked = false;                  // `ready` already recorded by gt4mi_halo_exchange_fork
-    bool primed = false;                  // `done` has been recorded at least once (pipelined stepping)
+    bool primed = false;                  // the exchange of a stepper's first input was started (gt4mi_halo_exchange_begin)
+    bool done_recorded = false;           // `done` has been recorded at least once: gt4mi_halo_exchange_end has something to wait for
     // how the fused distributed steps are scheduled (gt4mi_halo_plan_set_option); -1 = the entry point's own default
     int schedule = -1;            // GT4MI_SCHEDULE_JOIN / GT4MI_SCHEDULE_CHAIN
     int interior_wg_per_cu = -1;  // occupancy limit of the interior kernel while the exchange runs next to it (0 = none)

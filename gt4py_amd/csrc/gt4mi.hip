@@ -128,7 +128,7 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
         if (int rc = gt4mi::halo_exchange_on(plan, in_field, plan->stream)) return rc;
         if (int rc = gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, plan->stream)) return rc;
         GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-        plan->primed = true;
+        plan->done_recorded = true;
         if (!plan->defer_join) GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
         return GT4MI_OK;
     }
@@ -141,6 +141,7 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
     // 3. side stream: send / receive / unpack (and the second phase of a two-phase plan) next to the interior kernel
     if (int rc = gt4mi::halo_exchange_on(plan, in_field, plan->stream, /*first_pack_done=*/true)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
     // 4. main stream: join, then the ring that reads the ghost cells -- one launch for all four boxes
     GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
     return gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, ms);
@@ -433,13 +434,14 @@ int gt4mi_halo_exchange_begin(gt4mi_halo_plan* plan, const gt4mi_field* field, v
     GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
     if (int rc = gt4mi::halo_exchange_on(plan, field, plan->stream)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
     plan->primed = true;
     return GT4MI_OK;
 }
 
 int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream) {
     if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_exchange_end: null plan");
-    if (!plan->primed) return GT4MI_OK;  // nothing in flight: `done` was never recorded
+    if (!plan->done_recorded) return GT4MI_OK;  // nothing was ever put in flight on the side stream
     GT4MI_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(main_stream), plan->done, 0));
     return GT4MI_OK;
 }
@@ -477,7 +479,7 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
         if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream)) return rc;
         if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, plan->stream)) return rc;
         GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-        plan->primed = true;
+        plan->done_recorded = true;
         return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
     }
     // 1. pack the first faces ON THE MAIN STREAM, ahead of the interior kernel: alone it takes ~5 us;
@@ -492,6 +494,7 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
     // 3. side stream: RCCL send/recv + unpack (+ second phase), concurrent with the interior kernel
     if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/true)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
     // 4. main stream: join, then the ring of points that read ghost cells -- ONE launch (lap5_ring.hip.h)
     if (int rc = gt4mi_halo_exchange_end(plan, main_stream)) return rc;
     return gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, ms);
@@ -527,6 +530,7 @@ int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], con
             GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
             if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
             GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
         }
         // join the exchange that delivered `inp`'s ghost cells (started `halo` steps ago)
         GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
@@ -553,6 +557,7 @@ int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], con
     if (int rc = run(lo_i, di - hi_i, lo_j, dj - hi_j)) return rc;
     if (int rc = gt4mi::halo_exchange_on(plan, out, plan->stream, /*first_pack_done=*/true)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
     return GT4MI_OK;
 }
 
@@ -579,6 +584,7 @@ int gt4mi_dist_lap5_f64_skewed(gt4mi_halo_plan* plan, const int64_t domain[3], c
         GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
         if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
         GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
     }
     // join the exchange that delivered field_a's ghost cells (started by the previous cycle)
     GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
@@ -615,6 +621,7 @@ int gt4mi_dist_lap5_f64_skewed(gt4mi_halo_plan* plan, const int64_t domain[3], c
         if (st == 1) {  // enqueued after the first interior launch so that the device has work while the host talks to RCCL
             if (int rc = gt4mi::halo_exchange_on(plan, result, plan->stream, /*first_pack_done=*/!pack_on_side)) return rc;
             GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
         }
     }
     return GT4MI_OK;

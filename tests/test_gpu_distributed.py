@@ -544,3 +544,40 @@ def test_baseline_config4_share_through_the_fused_native_step(comm, single_phase
     inner = (slice(h + 2, -(h + 2)), slice(h + 2, -(h + 2)), slice(None))
     assert torch.equal(out[inner], inp[inner])
     ex.close()
+
+
+@pytest.mark.parametrize("schedule", ["join", "chain"])
+@pytest.mark.parametrize("stencil", ["lap5", "hdiff"])
+def test_fused_steps_wait_for_the_exchange_when_the_interior_is_shorter(comm, stencil, schedule):
+    """A flat, wide local domain: the interior kernel (a few rows) finishes long before the 1-2 MB faces have travelled, so a
+    ring kernel that did not wait for the unpack would read the stale ghost rows.  (Round 3 briefly had exactly that: the
+    join was skipped in the join schedule of gt4mi_dist_lap5_f64; the small domains of the other tests never showed it.)"""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from oracle import ref_numpy as R
+
+    h = 1 if stencil == "lap5" else 2
+    gd = (2048, 8, 96)
+    dec = Decomposition(gd, (1, 1), 0, h, periodic=(False, True))
+    rng = np.random.default_rng(31)
+    host = rng.uniform(-1, 1, dec.local_shape)
+    for attempt in range(3):
+        inp = gt_storage.from_array(host, backend="hip:mi300", aligned_index=dec.origin)
+        out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+        ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=bool(attempt % 2)).tune(schedule, 0)
+        wrapped = _wrap(host, h, False, True)
+        want = np.zeros_like(host)
+        if stencil == "lap5":
+            step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin)
+            R.laplacian(wrapped[h - 1:wrapped.shape[0] - h + 1, h - 1:wrapped.shape[1] - h + 1] if h > 1 else wrapped, want)
+        else:
+            coeff = gt_storage.from_array(np.full(dec.local_shape, 0.1), backend="hip:mi300", aligned_index=dec.origin)
+            step = ex.make_dist_hdiff(inp, out, coeff, dec.origin, _lib.HDIFF_LIMITER)
+            R.hdiff(wrapped, want, np.full(dec.local_shape, 0.1), domain=gd)
+        step()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.get(), want), (stencil, schedule, attempt)
+        ex.close()

@@ -50,6 +50,8 @@ def fused_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequence[in
     scalars = tuple(float(arguments[roles[r]]) for r in roles if roles[r] in arguments and not hasattr(arguments[roles[r]], "ptr"))
     key = (id(stencil), id(ex), org, tuple(id(arguments[n]) for n in field_names), scalars)
     entry = _FUSED_CACHE.get(key)
+    # (the cached call holds raw pointers, not the arrays: it is only used while every array it was bound to is alive and IS
+    # the one passed now -- a recycled id() of a dead array fails the identity check and the call is rebuilt)
     if entry is None or any(r() is not arguments[n] for n, r in entry[1]):
         import weakref
 
@@ -60,11 +62,11 @@ def fused_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequence[in
             coeff = arguments[coeff_name]
             is_field = hasattr(coeff, "ptr")
             call = ex.make_dist_hdiff(arguments[name], arguments[roles["out_field"]], coeff if is_field else None, org,
-                                      binding.flags, 0.0 if is_field else float(coeff))
+                                      binding.flags, 0.0 if is_field else float(coeff), hold_arrays=False)
         else:
             if decomp.halo != 1 or itemsize != 8 or binding.flags:
                 return False
-            call = ex.make_dist_lap5(arguments[name], arguments[roles["out"]], org, org, binding.variant)
+            call = ex.make_dist_lap5(arguments[name], arguments[roles["out"]], org, org, binding.variant, hold_arrays=False)
         if len(_FUSED_CACHE) >= 16:
             _FUSED_CACHE.pop(next(iter(_FUSED_CACHE)))
         entry = _FUSED_CACHE[key] = (call, [(n, weakref.ref(arguments[n])) for n in field_names])

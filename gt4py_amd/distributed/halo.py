@@ -298,10 +298,15 @@ class HaloExchanger:
     """Halo exchange of one field shape/dtype for one rank through ``torch.distributed`` point-to-point
     operations (RCCL on GPUs, gloo in the CPU tests), with persistent staging buffers."""
 
-    def __init__(self, decomp: Decomposition, dtype, device, packer=None, group=None, single_phase: bool = False):
+    def __init__(self, decomp: Decomposition, dtype, device, packer=None, group=None, single_phase: bool = False,
+                 stage_on_host: bool = False):
         self.decomp = decomp
         self.group = group
         self.device = torch.device(device)
+        #: device buffers are copied to pinned host twins for the transfer (a process group whose backend cannot move device
+        #: memory, e.g. gloo between two processes that share ONE GPU -- how the decomposed GPU path runs with two real
+        #: ranks on a 1-GPU box, tests/test_gpu_distributed.py)
+        self.stage_on_host = bool(stage_on_host) and self.device.type == "cuda"
         self.packer = packer if packer is not None else HipPacker()
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.sides = halo_sides(decomp, single_phase)
@@ -312,10 +317,13 @@ class HaloExchanger:
                 n = int(np.prod(ext))
                 self.buffers[(p, m, "send")] = torch.empty(n, dtype=dtype, device=self.device)
                 self.buffers[(p, m, "recv")] = torch.empty(n, dtype=dtype, device=self.device)
+                if self.stage_on_host:
+                    self.buffers[(p, m, "send", "host")] = torch.empty(n, dtype=dtype, pin_memory=True)
+                    self.buffers[(p, m, "recv", "host")] = torch.empty(n, dtype=dtype, pin_memory=True)
 
     @property
     def bytes_per_exchange(self) -> int:
-        return sum(b.numel() * b.element_size() for key, b in self.buffers.items() if key[2] == "send")
+        return sum(b.numel() * b.element_size() for key, b in self.buffers.items() if key[2] == "send" and len(key) == 3)
 
     def _run_phase(self, tensor, p: int) -> None:
         phase = self.phases[p]
@@ -329,12 +337,20 @@ class HaloExchanger:
         # (receive_order).  On a periodic axis with 1 or 2 ranks several faces of a phase go to the same peer, and
         # my low-side face must land in the peer's high-side ghost zone (NativeHaloExchanger.message_tables does
         # the same).
+        wire = ("host",) if self.stage_on_host else ()
+        if self.stage_on_host:
+            for m in range(len(phase)):
+                self.buffers[(p, m, "send", "host")].copy_(self.buffers[(p, m, "send")], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
         for m, (peer, _, _, _) in enumerate(phase):
-            ops.append(dist.P2POp(dist.isend, self.buffers[(p, m, "send")], peer, self.group))
+            ops.append(dist.P2POp(dist.isend, self.buffers[(p, m, "send") + wire], peer, self.group))
         for m in receive_order(self.sides[p]):
-            ops.append(dist.P2POp(dist.irecv, self.buffers[(p, m, "recv")], phase[m][0], self.group))
+            ops.append(dist.P2POp(dist.irecv, self.buffers[(p, m, "recv") + wire], phase[m][0], self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if self.stage_on_host:
+            for m in range(len(phase)):
+                self.buffers[(p, m, "recv")].copy_(self.buffers[(p, m, "recv", "host")], non_blocking=True)
         for m, (_, _, recv_lo, ext) in enumerate(phase):
             self.packer.unpack(tensor, recv_lo, ext, self.buffers[(p, m, "recv")])
 

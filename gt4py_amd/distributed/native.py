@@ -174,43 +174,47 @@ class NativeHaloExchanger:
     def end(self) -> None:
         _lib.check("gt4mi_halo_exchange_end", self._lib.gt4mi_halo_exchange_end(self._plan, _stream_ptr()))
 
-    def make_dist_lap5(self, inp, out, origin_inp: Sequence[int], origin_out: Sequence[int], variant: int = 0):
-        """Pre-bind one distributed Laplacian apply (halo 1) -> a zero-argument callable."""
+    def make_dist_lap5(self, inp, out, origin_inp: Sequence[int], origin_out: Sequence[int], variant: int = 0,
+                       hold_arrays: bool = True):
+        """Pre-bind one distributed Laplacian apply (halo 1) -> a zero-argument callable.  ``hold_arrays=False``: the
+        callable does not keep the arrays alive (a caller that checks their identity itself, ``distributed.fused_apply``)."""
         if self.decomp.halo != 1 or self.itemsize != 8:
             raise ValueError("gt4mi_dist_lap5_f64 needs fp64 fields and a halo of 1")
         fi, fo = _field_struct(inp, origin_inp), _field_struct(out, origin_out)
         dom = _lib.domain3(self.decomp.local_domain)
-        fn, plan, sides = self._lib.gt4mi_dist_lap5_f64, self._plan, self.sides
+        fn, sides = self._lib.gt4mi_dist_lap5_f64, self.sides
         ri, ro = ctypes.byref(fi), ctypes.byref(fo)
 
         def apply():
-            rc = fn(plan, dom, ri, ro, variant, sides, _stream_ptr())
+            rc = fn(self._plan, dom, ri, ro, variant, sides, _stream_ptr())  # (a closed exchanger's plan is NULL: an error, not a crash)
             if rc:
                 _lib.check("gt4mi_dist_lap5_f64", rc)
 
-        apply._keepalive = (fi, fo, dom, inp, out)  # type: ignore[attr-defined]
+        apply._keepalive = (fi, fo, dom) + ((inp, out) if hold_arrays else ())  # type: ignore[attr-defined]
         return apply
 
-    def make_dist_hdiff(self, in_field, out_field, coeff, origin: Sequence[int], flags: int, coeff_scalar: float = 0.0):
+    def make_dist_hdiff(self, in_field, out_field, coeff, origin: Sequence[int], flags: int, coeff_scalar: float = 0.0,
+                        hold_arrays: bool = True):
         """Pre-bind one distributed apply of horizontal diffusion (gt4mi_dist_hdiff_f64 / _f32: pack, interior next to the
         exchange, one ring kernel) -> a zero-argument callable.  ``coeff`` is a device array or None (then
-        ``coeff_scalar``); ``flags`` as for gt4mi_hdiff_* (``KernelBinding.flags`` of a recognised stencil)."""
+        ``coeff_scalar``); ``flags`` as for gt4mi_hdiff_* (``KernelBinding.flags`` of a recognised stencil);
+        ``hold_arrays`` as for ``make_dist_lap5``."""
         if self.decomp.halo != 2:
             raise ValueError("gt4mi_dist_hdiff needs ghost regions exactly 2 deep")
         fi, fo = _field_struct(in_field, origin), _field_struct(out_field, origin)
         fc = _field_struct(coeff, origin) if coeff is not None else None
         dom = _lib.domain3(self.decomp.local_domain)
         name = "gt4mi_dist_hdiff_f64" if self.itemsize == 8 else "gt4mi_dist_hdiff_f32"
-        fn, plan, sides = getattr(self._lib, name), self._plan, self.sides
+        fn, sides = getattr(self._lib, name), self.sides
         ri, ro, rc_ = ctypes.byref(fi), ctypes.byref(fo), (ctypes.byref(fc) if fc is not None else None)
         cs, fl = float(coeff_scalar), int(flags)
 
         def apply():
-            rc = fn(plan, dom, ri, ro, rc_, cs, fl, sides, _stream_ptr())
+            rc = fn(self._plan, dom, ri, ro, rc_, cs, fl, sides, _stream_ptr())
             if rc:
                 _lib.check(name, rc)
 
-        apply._keepalive = (fi, fo, fc, dom, in_field, out_field, coeff)  # type: ignore[attr-defined]
+        apply._keepalive = (fi, fo, fc, dom) + ((in_field, out_field, coeff) if hold_arrays else ())  # type: ignore[attr-defined]
         return apply
 
     def make_time_skewed_lap5(self, field_a, field_b, origin: Sequence[int], variant: int = 0):

@@ -581,3 +581,95 @@ def test_fused_steps_wait_for_the_exchange_when_the_interior_is_shorter(comm, st
         torch.cuda.synchronize()
         assert np.array_equal(out.get(), want), (stencil, schedule, attempt)
         ex.close()
+
+
+# ---- two REAL ranks on the one GPU of the box -------------------------------------------------------------------------
+# RCCL refuses two ranks on one device, so the native plan cannot run here with a peer that is not the rank itself.  The
+# torch transport can: two processes share GPU 0, the process group is gloo, the dense face buffers are staged through
+# pinned host memory (HaloExchanger(stage_on_host=True)).  Everything else is the decomposed GPU path as an N-GPU job runs
+# it -- scatter of a global field, HIP pack / unpack kernels, the kernel-library stencils on the interior and on the
+# boundary strips, per-rank origins -- with neighbours that are OTHER processes.
+def _two_rank_worker(rank: int, world: int, port: int, grid, tmpdir: str):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import gt4py_amd.storage as gt_storage
+        from gt4py_amd.cartesian import gtscript
+        from gt4py_amd.cartesian.backend import hip_templates
+        from gt4py_amd.distributed import (Decomposition, HaloExchanger, overlapped_apply, scatter_global, sequential_apply)
+        from oracle import ref_numpy as R
+
+        rng = np.random.default_rng(4096)  # the same stream on every rank: the same global fields
+        results = {}
+        for name, h, gd in (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5))):
+            glob = rng.uniform(-10, 10, (gd[0] + 2 * h, gd[1] + 2 * h, gd[2]))
+            coeff = rng.uniform(0, 0.5, glob.shape)
+            want = np.zeros_like(glob)
+            if name == "hdiff":
+                R.hdiff(glob, want, coeff, domain=gd)
+                stencil = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field,
+                                           dtypes={"T": np.float64}, device_sync=False)
+                read, write = "in_field", "out_field"
+            else:
+                R.laplacian(glob, want)
+                stencil = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
+                                           device_sync=False)
+                read, write = "inp", "out"
+            dec = Decomposition(gd, grid, rank, h)
+            for form, apply in (("overlapped", overlapped_apply), ("sequential", sequential_apply)):
+                for single_phase in (False, True):
+                    blk = scatter_global(glob, dec).copy()
+                    nb = dec.neighbours  # ghost cells that belong to the neighbour must come from the exchange
+                    if nb["W"] is not None:
+                        blk[:h] = np.nan
+                    if nb["E"] is not None:
+                        blk[-h:] = np.nan
+                    if nb["S"] is not None:
+                        blk[:, :h] = np.nan
+                    if nb["N"] is not None:
+                        blk[:, -h:] = np.nan
+                    args = {read: gt_storage.from_array(blk, backend="hip:mi300", aligned_index=dec.origin),
+                            write: gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)}
+                    if name == "hdiff":
+                        args["coeff"] = gt_storage.from_array(scatter_global(coeff, dec), backend="hip:mi300", aligned_index=dec.origin)
+                    origin = {n: dec.origin for n in args}
+                    ex = HaloExchanger(dec, torch.float64, torch.device("cuda", 0), single_phase=single_phase, stage_on_host=True)
+                    apply(stencil, dec, origin, args, {read: ex})
+                    torch.cuda.synchronize()
+                    assert np.array_equal(args[read].get(), scatter_global(glob, dec)), (name, form, "ghost cells")
+                    results[(name, form, single_phase)] = args[write].get()[h:-h, h:-h].copy()
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (dec.global_slices(with_halo=False), {k: v for k, v in results.items() if k[0] == name}))
+            if rank == 0:
+                for key in gathered[0][1]:
+                    got = np.zeros_like(glob)
+                    for sl, res in gathered:
+                        got[sl] = res[key]
+                    assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h]), key
+        if rank == 0:
+            np.save(os.path.join(tmpdir, "ok.npy"), np.array([len(results)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid", [(1, 2), (2, 1)])
+def test_two_processes_share_the_gpu_and_exchange_real_faces(grid, tmp_path):
+    """World size 2 on the GPU: each rank owns half of a global field, its neighbour is ANOTHER process.  Horizontal diffusion
+    (ghost depth 2, corners through either message table) and the Laplacian through the stencil-agnostic drivers; the
+    assembled result equals the oracle on the undecomposed field bit for bit, and every rank's ghost cells equal the global
+    field's values."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_two_rank_worker, args=(2, port, grid, str(tmp_path)), nprocs=2, join=True)
+    assert int(np.load(tmp_path / "ok.npy")[0]) == 8

@@ -964,7 +964,10 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # GT4MI_BENCH_FORCE_DISTRIBUTED=1: take the N > 1 code path with a world of ONE rank (process group, collectives,
+    # communicator through the broadcast, calibration, line keys) -- the rehearsal a 1-GPU box allows of everything in that
+    # path except a message to another device (scripts / tests only; never the headline)
+    distributed = world > 1 or os.environ.get("GT4MI_BENCH_FORCE_DISTRIBUTED", "0") == "1"
     ctx = {"world": world, "rank": rank, "local_rank": local_rank, "distributed": distributed, "dog": dog}
     if distributed:
         import torch.distributed as dist

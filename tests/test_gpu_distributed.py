@@ -673,3 +673,39 @@ def test_two_processes_share_the_gpu_and_exchange_real_faces(grid, tmp_path):
         port = sock.getsockname()[1]
     mp.spawn(_two_rank_worker, args=(2, port, grid, str(tmp_path)), nprocs=2, join=True)
     assert int(np.load(tmp_path / "ok.npy")[0]) == 8
+
+
+@pytest.mark.parametrize("workload", ["lap512", "hdiff2048"])
+def test_bench_n_gpu_code_path_with_a_world_of_one(workload, tmp_path):
+    """`bench.py` the way the driver launches it for N > 1 (torch.distributed.run, nccl process group), with a world of ONE rank
+    forced onto the distributed code path (GT4MI_BENCH_FORCE_DISTRIBUTED=1): rendezvous, barriers and all-reduces on the
+    device, the native communicator created through the broadcast of its id, the calibration of grid x message table x
+    schedule x throttle, the informational steppers, and the keys the N > 1 line must carry.  Everything of that path
+    except a message to another device."""
+    import json
+    import os
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, GT4MI_BENCH_FORCE_DISTRIBUTED="1")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(root / "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2",
+                           "--workload", workload], env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]  # ONE JSON line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["unit"] == "GLUPS"
+    assert line["rccl_nranks"] == 1 and line["rank_devices"] == [[0, 0]] and line["rccl_matches_n_gpus"] is True
+    assert line["transport_fallback"] is False and line["config"]["transport"] == "native"
+    assert line["config"]["calibration_ms_per_apply"] and "extra" in line
+    if workload == "lap512":
+        assert {"timestep_glups", "timestep_ms_per_step", "pipelined_apply_glups"} <= set(line["extra"])
+        assert line["config"]["mode"] == "apply" and line["config"]["halo_depth"] == 1
+    assert "NATIVE RCCL TRANSPORT UNAVAILABLE" not in proc.stderr

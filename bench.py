@@ -838,24 +838,36 @@ def _setup_hdiff2048(args, ctx):
             # one C call per apply (gt4mi_dist_hdiff_f64: pack, interior || exchange, ONE ring kernel) with either message
             # table, and the plain sequence (exchange, then one full-domain launch): measured, slowest rank decides
             flags = type(hd)._gt_binding_.flags
-            forms, exchangers, form_exchanger = {}, [], {}
-            for table, single in (("two_phase", False), ("single_phase", True)):
-                for cand_schedule in ("join", "chain"):
-                    for cand_wg in (0, 3, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
-                        ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(cand_schedule, cand_wg)
-                        exchangers.append(ex)
-                        name = f"fused_{table}_{cand_schedule}_wg{cand_wg}"
-                        forms[name] = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
-                        form_exchanger[name] = ex
-                forms[f"sequential_{table}"] = (lambda ex=ex: sequential_apply(hd, dec, origin, fields, {"in_field": ex}))
-                form_exchanger[f"sequential_{table}"] = ex
+            edge_candidates = tuple(int(v) for v in os.environ.get("GT4MI_BENCH_EDGE_CANDIDATES", "2,16,32").split(","))
+
+            def make_form(name):
+                """(callable, exchanger) of one apply form.  One plan (side stream, staging buffers) per form, created when
+                it is measured and closed right after: with dozens of plans alive the runtime maps some side streams onto
+                the caller's hardware queue and those forms run serialised (0.27 ms instead of 0.21, seen with 72 plans)."""
+                parts = name.split("_")
+                single = parts[1] == "single"
+                if parts[0] == "sequential":
+                    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single)
+                    return (lambda: sequential_apply(hd, dec, origin, fields, {"in_field": ex})), ex
+                ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(parts[3], int(parts[4][2:]),
+                                                                                          edge_columns=int(parts[5][4:]))
+                return ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags), ex
+
+            names = []
+            for table in ("two_phase", "single_phase"):
+                names += [f"fused_{table}_{sched}_wg{wg}_edge{edge}" for sched in ("join", "chain") for wg in (0, 3, 2)
+                          for edge in edge_candidates]
+                names.append(f"sequential_{table}")
             pinned = os.environ.get("GT4MI_BENCH_FORM")
             dog.arm(300, "calibration of the apply forms")
             ok, timings = 1, {}
             try:
-                for name, fn in forms.items():
+                for name in names:
                     if pinned is None or pinned == name:
+                        fn, ex = make_form(name)
                         timings[name] = round(_slowest_rank_ms(ctx, fn, 16), 5)
+                        ex.close()
+                        del fn, ex
             except Exception as exn:
                 ok = 0
                 print(f"rank {rank}: native RCCL halo exchange failed during calibration ({exn!r})", file=sys.stderr)
@@ -864,9 +876,8 @@ def _setup_hdiff2048(args, ctx):
                 transport_fallback_banner(rank, "the native halo exchange failed during calibration")
             else:
                 choice = min(timings, key=timings.get)
-                chosen = forms[choice]
-                exchangers.remove(form_exchanger[choice])
-                exchangers.insert(0, form_exchanger[choice])  # the one the line describes
+                chosen, ex = make_form(choice)
+                exchangers = [ex]  # the one the line describes
 
                 def step(i):
                     chosen()
@@ -892,11 +903,13 @@ def _setup_hdiff2048(args, ctx):
         flags = type(hd)._gt_binding_.flags
         for single in (False, True):
             for cand_wg in (0, 3, 2):
-                ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune("chain", cand_wg, defer_join=True)
-                fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
-                table[f"{'single' if single else 'two'}_phase_chain_wg{cand_wg}"] = round(_slowest_rank_ms(ctx, fn, 32), 5)
-                ex.end()
-                ex.close()
+                for cand_edge in (2, 32):
+                    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune("chain", cand_wg, defer_join=True,
+                                                                                              edge_columns=cand_edge)
+                    fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
+                    table[f"{'single' if single else 'two'}_phase_chain_wg{cand_wg}_edge{cand_edge}"] = round(_slowest_rank_ms(ctx, fn, 32), 5)
+                    ex.end()
+                    ex.close()
         best = min(table, key=table.get)
         return {"pipelined_apply_glups": round(float(np.prod(total)) / table[best] / 1e6, 2), "pipelined_apply_best": best,
                 "pipelined_apply_ms": table,

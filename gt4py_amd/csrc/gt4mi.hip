@@ -25,6 +25,10 @@ inline int plan_schedule(const gt4mi_halo_plan* plan, int fallback) {
     static const int env = env_int("GT4MI_DIST_SCHEDULE", -1);
     return plan->schedule >= 0 ? plan->schedule : (env >= 0 ? env : fallback);
 }
+inline int plan_edge_columns(const gt4mi_halo_plan* plan, int fallback) {
+    static const int env = env_int("GT4MI_DIST_EDGE_COLUMNS", -1);
+    return plan->edge_columns >= 0 ? plan->edge_columns : (env >= 0 ? env : fallback);
+}
 inline int plan_interior_wg_per_cu(const gt4mi_halo_plan* plan, int fallback) {
     static const int env = env_int("GT4MI_DIST_INTERIOR_WG_PER_CU", -1);
     return plan->interior_wg_per_cu >= 0 ? plan->interior_wg_per_cu : (env >= 0 ? env : fallback);
@@ -94,7 +98,12 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
     if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
     const int64_t di = domain[0], dj = domain[1], dk = domain[2];
     constexpr int64_t H = 2;  // the stencil's reach
-    int64_t lo_i = (sides & 1) ? H : 0, hi_i = (sides & 2) ? H : 0, lo_j = (sides & 4) ? H : 0, hi_j = (sides & 8) ? H : 0;
+    // W / E: the ring takes a box EW >= 2 columns wide (whole cache lines, J-march strips; hdiff_ring.hip.h) off the interior
+    // kernel -- even, so that both parts keep their 16-byte alignment; only where the interior keeps at least as much
+    int64_t EW = gt4mi::plan_edge_columns(plan, 16);
+    EW = EW < H ? H : EW - EW % 2;
+    if (di < 4 * EW) EW = H;
+    int64_t lo_i = (sides & 1) ? EW : 0, hi_i = (sides & 2) ? EW : 0, lo_j = (sides & 4) ? H : 0, hi_j = (sides & 8) ? H : 0;
     lo_i = lo_i < di ? lo_i : di;
     hi_i = hi_i < di - lo_i ? hi_i : di - lo_i;
     lo_j = lo_j < dj ? lo_j : dj;
@@ -113,8 +122,9 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
             c.origin[0] += lo_i; c.origin[1] += lo_j;
         }
         const int64_t sub[3] = {di - lo_i - hi_i, dj - lo_j - hi_j, dk};
-        // 3 of 4 workgroups per CU: the send/recv kernel next to it takes 77 us instead of 190 (profiles/r3_dist_hdiff_timeline.txt)
-        gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 3)));
+        // 2 of 4 workgroups per CU: the send/recv kernel next to it takes 59 us instead of 190 (3 of 4: 77;
+        // profiles/r3_dist_hdiff_timeline_by_schedule_and_throttle.txt, r3_dist_hdiff_edge_width_sweep.txt)
+        gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 2)));
         return gt4mi::hdiff_run<T>(sub, &a, &b, coeff ? &c : nullptr, coeff_scalar, flags, ms);
     };
     if (gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_CHAIN) == GT4MI_SCHEDULE_CHAIN) {
@@ -378,6 +388,10 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
         case GT4MI_PLAN_SCHEDULE:
             if (value < -1 || value > GT4MI_SCHEDULE_CHAIN) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
             plan->schedule = value;
+            return GT4MI_OK;
+        case GT4MI_PLAN_EDGE_COLUMNS:
+            if (value < -1 || value > 4096) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: %d edge columns", value);
+            plan->edge_columns = value;
             return GT4MI_OK;
         case GT4MI_PLAN_DEFER_JOIN:
             if (value != 0 && value != 1) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: defer_join %d", value);

@@ -32,7 +32,7 @@ namespace gt4mi {
 struct RingBoxes {
     static constexpr int MAX = 4;
     int n;                      // boxes in use
-    int kind[MAX];              // 0 = row box, 1 = column box
+    int kind[MAX];              // 0 = row box (strips of 2 rows), 1 = 2-column box (lanes along J), 2 = tall box (J-march strips)
     int i0[MAX], j0[MAX];       // first point, relative to the compute-domain origin
     int ei[MAX], ej[MAX];       // extent
     unsigned per_level[MAX];    // tiles per K level
@@ -106,13 +106,20 @@ hdiff_ring_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scal
     if (b.kind[m] == 0) {
         hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, 2, 2>(in_b, out_b, cf_b, coeff_scalar, b.ei[m], b.ej[m],
                                                                       r % b.tiles_i[m], r / b.tiles_i[m], k);
+    } else if (b.kind[m] == 2) {
+        // a W / E box several columns wide: the whole-domain kernel's strips (full cache lines, nothing strided)
+        hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, HdiffTuning<T>::LJ, HdiffTuning<T>::PF>(
+            in_b, out_b, cf_b, coeff_scalar, b.ei[m], b.ej[m], r % b.tiles_i[m], r / b.tiles_i[m], k);
     } else {
         hdiff_column_strip<T, W, PW, LIMITER, COEFF_FIELD, 2>(in_b, out_b, cf_b, coeff_scalar, b.ej[m], r, k);
     }
 }
 
 // Widths of the ring towards low I, high I, low J, high J (0 where the domain has no neighbour).  The ring kernel takes
-// I-contiguous fields and widths of 0 or 2 (the stencil's halo); everything else runs box by box on the ordinary kernels.
+// I-contiguous fields; a W / E box exactly 2 columns wide runs the transposed tile, any other width J-march strips --
+// the distributed step asks for W / E boxes a few cache lines wide (GT4MI_PLAN_EDGE_COLUMNS): what they compute is taken out
+// of the interior kernel, and a box of 32 columns moves whole 256-byte row segments where the 2-column box touched four
+// sectors per row for 16 bytes of output.  Other layouts run box by box on the ordinary kernels.
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD>
 inline int hdiff_launch_ring(const View<const T>& in, const View<T>& out, const View<const T>& cf, PW coeff_scalar,
                              const int64_t d[3], const int widths[4], hipStream_t stream, bool point_per_thread = false) {
@@ -126,9 +133,9 @@ inline int hdiff_launch_ring(const View<const T>& in, const View<T>& out, const 
     if (hi_i > 0 && dj - lo_j - hi_j > 0) boxes[n++] = {1, di - hi_i, lo_j, hi_i, dj - lo_j - hi_j};
     if (n == 0 || dk == 0) return GT4MI_OK;
     const bool contiguous = in.si == 1 && out.si == 1 && (!COEFF_FIELD || cf.si == 1);
-    bool fits = contiguous && !point_per_thread && hdiff_jmarch_enabled();  // point_per_thread: `coeff` IS `out_field` (hdiff.hip.h)
+    const bool fits = contiguous && !point_per_thread && hdiff_jmarch_enabled();  // point_per_thread: `coeff` IS `out_field` (hdiff.hip.h)
     for (int m = 0; m < n; ++m)
-        if (boxes[m].kind == 1 && boxes[m].ei != 2) fits = false;
+        if (boxes[m].kind == 1 && boxes[m].ei != 2) boxes[m].kind = 2;  // not the 2-column shape: J-march strips
     if (!fits) {
         for (int m = 0; m < n; ++m) {
             const Box& x = boxes[m];
@@ -155,10 +162,10 @@ inline int hdiff_launch_ring(const View<const T>& in, const View<T>& out, const 
         }
         const Box& x = boxes[m];
         b.kind[m] = x.kind; b.i0[m] = (int)x.i0; b.j0[m] = (int)x.j0; b.ei[m] = (int)x.ei; b.ej[m] = (int)x.ej;
-        if (x.kind == 0) {
+        if (x.kind != 1) {
             const int out_lanes = vec ? 62 * VMAX : 60;  // columns per wave (hdiff_jmarch_strip: H = 1 for vectors, 2 for scalars)
             b.tiles_i[m] = (unsigned)cdiv(x.ei, out_lanes);
-            b.per_level[m] = b.tiles_i[m] * (unsigned)cdiv(x.ej, 2);
+            b.per_level[m] = b.tiles_i[m] * (unsigned)cdiv(x.ej, x.kind == 0 ? 2 : HdiffTuning<T>::LJ);
         } else {
             b.tiles_i[m] = 1;
             b.per_level[m] = (unsigned)cdiv(x.ej, 60);

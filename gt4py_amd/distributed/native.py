@@ -139,7 +139,7 @@ class NativeHaloExchanger:
                       | (4 if nb["S"] is not None else 0) | (8 if nb["N"] is not None else 0))
 
     def tune(self, schedule: Optional[str] = None, interior_wg_per_cu: Optional[int] = None,
-             defer_join: Optional[bool] = None) -> "NativeHaloExchanger":
+             defer_join: Optional[bool] = None, edge_columns: Optional[int] = None) -> "NativeHaloExchanger":
         """How the fused distributed steps built on this exchanger are scheduled (gt4mi_halo_plan_set_option):
         ``schedule`` "join" (pack and interior on the caller's stream, send/recv/unpack beside it, join, ring) or "chain"
         (the caller's stream carries the interior only; pack, send/recv, unpack and ring in order on the side stream);
@@ -152,6 +152,9 @@ class NativeHaloExchanger:
         if interior_wg_per_cu is not None:
             _lib.check("gt4mi_halo_plan_set_option",
                        self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_INTERIOR_WG_PER_CU, int(interior_wg_per_cu)))
+        if edge_columns is not None:  # fused hdiff: width of the W / E boxes the ring kernel takes off the interior
+            _lib.check("gt4mi_halo_plan_set_option",
+                       self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_EDGE_COLUMNS, int(edge_columns)))
         if defer_join is not None:  # independent applies: the caller joins with end() before consuming results
             _lib.check("gt4mi_halo_plan_set_option",
                        self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_DEFER_JOIN, int(bool(defer_join))))

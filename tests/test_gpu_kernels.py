@@ -354,12 +354,13 @@ def _ring_mask(shape, origin, domain, outer, inner):
 
 @pytest.mark.parametrize("layout", ["ifirst", "ifirst_unaligned", "kfirst"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("widths", [(2, 2, 2, 2), (0, 2, 2, 0), (2, 0, 0, 0), (0, 0, 0, 2), (2, 2, 0, 0), (1, 0, 2, 3)])
+@pytest.mark.parametrize("widths", [(2, 2, 2, 2), (0, 2, 2, 0), (2, 0, 0, 0), (0, 0, 0, 2), (2, 2, 0, 0), (1, 0, 2, 3), (32, 32, 2, 2),
+                                    (16, 0, 2, 0), (6, 3, 2, 2)])
 @pytest.mark.parametrize("domain", [(130, 70, 3), (7, 9, 2), (64, 5, 4)])
 def test_hdiff_ring_equals_the_whole_domain_kernel_on_the_ring(domain, widths, dtype, layout):
     """gt4mi_hdiff_ring_*: the points within widths[side] of a side get exactly the values of the oracle (and of the
-    whole-domain kernel); everything else keeps what the output array held.  (1, 0, 2, 3) is not the shape the ring kernel
-    takes (column boxes 2 wide): it runs box by box on the ordinary kernels."""
+    whole-domain kernel); everything else keeps what the output array held.  W / E boxes exactly 2 columns wide run the
+    transposed tile, other widths (1, 3, 6, 16, 32: the fused distributed step asks for 32) J-march strips."""
     import gpu_util as G
     from gt4py_amd import _lib
 

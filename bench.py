@@ -598,6 +598,10 @@ def _setup_distributed_laplacian(args, ctx):
     world, rank, local_rank, distributed, dog = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["distributed"], ctx["dog"]
     selfloop = args.dist_selfloop and world == 1
     total = (GRID[0], GRID[1] // max(args.selfloop_ranks, 1), GRID[2]) if selfloop else GRID
+    selfloop_grid = None
+    if selfloop and args.selfloop_grid:  # the share of ONE rank of a PI x PJ grid, every neighbour the rank itself
+        pi, pj = (int(v) for v in args.selfloop_grid.split("x"))
+        total, selfloop_grid = (GRID[0] // pi, GRID[1] // pj, GRID[2]), (pi, pj)
     lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64}, device_sync=False)
     transport = os.environ.get("GT4MI_BENCH_COMM", "native")
     mode = os.environ.get("GT4MI_BENCH_MODE", "apply")
@@ -613,6 +617,8 @@ def _setup_distributed_laplacian(args, ctx):
         return int(pi), int(pj)
 
     periodic = (False, True) if selfloop else (False, False)
+    if selfloop_grid is not None:
+        periodic = (selfloop_grid[0] > 1, selfloop_grid[1] > 1)
     grid = (1, 1) if selfloop else choose_process_grid(world, total)
     pinned_grid = "GT4MI_BENCH_GRID" in os.environ
     if pinned_grid:
@@ -957,6 +963,9 @@ def main() -> None:
     ap.add_argument("--dist-selfloop", action="store_true",
                     help="1-GPU rehearsal of the N>1 step: periodic domain whose halo messages go to the "
                          "rank itself through RCCL (not the headline metric)")
+    ap.add_argument("--selfloop-grid", default="",
+                    help="with --dist-selfloop and lap512: PIxPJ, e.g. 4x2 -- the share of one rank of that process grid "
+                         "(512/PI x 512/PJ x 512), periodic along every cut axis (W / E neighbours too)")
     ap.add_argument("--selfloop-ranks", type=int, default=1,
                     help="with --dist-selfloop and lap512: shrink J to 512/N, the per-rank share of an N-GPU run")
     args = ap.parse_args()

@@ -51,20 +51,11 @@ __device__ __forceinline__ T lap5_expr(T c, T w, T e, T s, T n) {
     }
 }
 
-// One strip: columns [bx*BLOCK*VEC, ...) x rows [j0, min(j0+LJ, dJ)) of level k.
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int NTL = 0>
-__device__ __forceinline__ void lap5_strip_tile(const View<const T>& in, const View<T>& out, int dI, int dJ,
-                                                unsigned bx, int j0, unsigned k) {
-    const unsigned lane = threadIdx.x & 63;
-
-    // Lanes past the end of the row stay active (DPP needs their neighbours' exec bits) but are
-    // clamped onto the last valid vector and never store.
-    int i0 = (int)(bx * BLOCK + threadIdx.x) * VEC;
-    const bool active = i0 < dI;
-    if (!active) i0 = dI - VEC;
-    const bool edge_w = lane == 0;
-    const bool edge_e = (lane == 63) || (i0 + VEC >= dI);
-
+// The strip of ONE lane: VEC columns from i0 x rows [j0, min(j0+LJ, dJ)) of level k.  edge_w / edge_e: the lane's west / east
+// neighbour column is not in the adjacent lane's registers (first / last lane of a row of lanes) and is loaded instead.
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int NTL = 0>
+__device__ __forceinline__ void lap5_strip_lane(const View<const T>& in, const View<T>& out, int dJ, int i0, bool active,
+                                                bool edge_w, bool edge_e, int j0, unsigned k) {
     const T* __restrict__ col = in.p + (int64_t)k * in.sk + i0;
     T* __restrict__ ocol = out.p + (int64_t)k * out.sk + i0;
 
@@ -113,6 +104,35 @@ __device__ __forceinline__ void lap5_strip_tile(const View<const T>& in, const V
         }
         if (active && (j0 + t - 1 < dJ)) vstore<T, VEC, true>(ocol + (int64_t)(j0 + t - 1) * out.sj, res);
     }
+}
+
+// One strip: columns [bx*BLOCK*VEC, ...) x rows [j0, min(j0+LJ, dJ)) of level k; the lanes of a wave lie along I.
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int NTL = 0>
+__device__ __forceinline__ void lap5_strip_tile(const View<const T>& in, const View<T>& out, int dI, int dJ,
+                                                unsigned bx, int j0, unsigned k) {
+    const unsigned lane = threadIdx.x & 63;
+    // Lanes past the end of the row stay active (DPP needs their neighbours' exec bits) but are
+    // clamped onto the last valid vector and never store.
+    int i0 = (int)(bx * BLOCK + threadIdx.x) * VEC;
+    const bool active = i0 < dI;
+    if (!active) i0 = dI - VEC;
+    lap5_strip_lane<T, W, VARIANT, VEC, LJ, NTL>(in, out, dJ, i0, active, lane == 0, (lane == 63) || (i0 + VEC >= dI), j0, k);
+}
+
+// A box only LPR * VEC columns wide (the W / E boxes of a decomposed apply): a wave is 64 / LPR rows of LPR lanes, each row of
+// lanes a strip of LJ rows of its own -- the lane shifts of lap5_strip_lane still fetch the neighbour column inside a row of
+// lanes, the first and last lane of each row load theirs.  A wave covers (64 / LPR) * LJ rows of the box.
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int LPR>
+__device__ __forceinline__ void lap5_narrow_tile(const View<const T>& in, const View<T>& out, int dI, int dJ, unsigned tile,
+                                                 unsigned k) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int li = lane % LPR, sub = lane / LPR;
+    int i0 = li * VEC;
+    const bool active = i0 < dI;
+    if (!active) i0 = dI - VEC;
+    const int j0 = ((int)tile * (64 / LPR) + sub) * LJ;
+    lap5_strip_lane<T, W, VARIANT, VEC, LJ>(in, out, dJ, i0, active && j0 < dJ, li == 0, (li == LPR - 1) || (i0 + VEC >= dI),
+                                            j0 < dJ ? j0 : dJ, k);
 }
 
 template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG = 0, int NTL = 0>

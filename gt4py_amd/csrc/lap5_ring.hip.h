@@ -7,7 +7,8 @@
 //     faces can travel while H interior kernels run.
 // Both are "the domain grown by outer[side], minus the domain shrunk by inner[side]": up to four boxes -- two row boxes
 // over the full width (S, N) and two column boxes between them (W, E).  Row boxes run the register-strip tile of
-// lap5.hip.h (lanes along I); column boxes are a few columns wide, so there a thread owns a ROW (lanes along J).
+// lap5.hip.h (lanes along I); column boxes of 2 .. 16 columns run rows of 16 / VEC lanes (lap5_narrow_tile: the distributed apply
+// asks for W / E boxes 16 columns wide, which keeps its interior kernel on 16-byte lanes), other widths a thread per row.
 // One launch instead of four; same per-point expression (lap5_expr): bit-identical to the whole-domain kernel.
 #pragma once
 
@@ -31,6 +32,10 @@ lap5_ring_kernel(View<const T> in, View<T> out, RingBoxes b) {
     const View<T> out_b{out.p + oi + oj * out.sj, 1, out.sj, out.sk};
     if (b.kind[m] == 0) {
         lap5_strip_tile<T, W, VARIANT, VEC, LJ, 256>(in_b, out_b, b.ei[m], b.ej[m], r % b.tiles_i[m], (int)(r / b.tiles_i[m]) * LJ, k);
+    } else if (b.kind[m] == 2) {
+        // a W / E box up to 16 columns wide: every wave takes (64 / LPR) strips of 8 rows (lap5_narrow_tile)
+        constexpr int LPR = 16 / VEC;
+        lap5_narrow_tile<T, W, VARIANT, VEC, 8, LPR>(in_b, out_b, b.ei[m], b.ej[m], r * 4 + (threadIdx.x >> 6), k);
     } else {
         const int j = (int)(r * 256 + threadIdx.x);
         if (j >= b.ej[m]) return;
@@ -73,13 +78,15 @@ inline int lap5_launch_ring(const View<const T>& in, const View<T>& out, const i
     constexpr int VMAX = 16 / sizeof(T);
     bool vec = true;
     int64_t deepest = 1;
+    for (int m = 0; m < n; ++m)  // column boxes of 2 .. 16 columns: rows of lanes instead of a thread per row (lap5_narrow_tile)
+        if (boxes[m].kind == 1 && boxes[m].ei >= 2 && boxes[m].ei <= 16) boxes[m].kind = 2;
     for (int m = 0; m < n; ++m) {
         const Box& x = boxes[m];
-        if (x.kind != 0) continue;
+        if (x.kind == 1) continue;
         const View<const T> in_b{in.p + x.i0 + x.j0 * in.sj, 1, in.sj, in.sk};
         const View<T> out_b{out.p + x.i0 + x.j0 * out.sj, 1, out.sj, out.sk};
         vec = vec && vec_ok(in_b, VMAX) && vec_ok(out_b, VMAX) && x.ei % VMAX == 0;
-        deepest = x.ej > deepest ? x.ej : deepest;
+        if (x.kind == 0) deepest = x.ej > deepest ? x.ej : deepest;
     }
     const int lj = deepest <= 1 ? 1 : (deepest <= 2 ? 2 : 4);
     const int vecw = vec ? VMAX : 1;
@@ -98,6 +105,10 @@ inline int lap5_launch_ring(const View<const T>& in, const View<T>& out, const i
         if (x.kind == 0) {
             b.tiles_i[m] = (unsigned)cdiv(x.ei, (int64_t)256 * vecw);
             b.per_level[m] = b.tiles_i[m] * (unsigned)cdiv(x.ej, lj);
+        } else if (x.kind == 2) {
+            const int64_t rows_per_wave = (64 / (16 / vecw)) * 8;  // (64 / LPR) strips of 8 rows
+            b.tiles_i[m] = 1;
+            b.per_level[m] = (unsigned)cdiv(cdiv(x.ej, rows_per_wave), 4);  // four waves per workgroup
         } else {
             b.tiles_i[m] = 1;
             b.per_level[m] = (unsigned)cdiv(x.ej, 256);

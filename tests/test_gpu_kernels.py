@@ -391,7 +391,8 @@ def test_hdiff_ring_equals_the_whole_domain_kernel_on_the_ring(domain, widths, d
 @pytest.mark.parametrize("layout", ["ifirst", "ifirst_unaligned", "jfirst"])
 @pytest.mark.parametrize("outer,inner", [((0, 0, 0, 0), (1, 1, 1, 1)), ((0, 0, 0, 0), (0, 0, 1, 1)), ((0, 0, 1, 1), (0, 0, 3, 3)),
                                          ((1, 1, 1, 1), (3, 3, 3, 3)), ((2, 0, 0, 2), (4, 0, 0, 4)), ((0, 0, 0, 0), (2, 2, 2, 2)),
-                                         ((0, 3, 0, 0), (0, 7, 0, 0)), ((0, 0, 3, 0), (0, 0, 7, 0))])
+                                         ((0, 3, 0, 0), (0, 7, 0, 0)), ((0, 0, 3, 0), (0, 0, 7, 0)), ((0, 0, 0, 0), (16, 16, 1, 1)),
+                                         ((0, 0, 0, 0), (8, 0, 1, 0)), ((0, 0, 0, 0), (0, 16, 0, 0)), ((0, 0, 0, 0), (20, 0, 0, 0))])
 @pytest.mark.parametrize("domain", [(128, 40, 3), (70, 33, 2), (520, 18, 2)])
 @pytest.mark.parametrize("variant", [0, 3])
 def test_lap5_ring_equals_the_whole_domain_kernel_on_the_ring(domain, outer, inner, layout, variant):

@@ -536,6 +536,37 @@ def _slowest_rank_ms(ctx, fn, calls: int, warm: int = 3) -> float:
     return float(dt.item())
 
 
+def measure_candidate(ctx, make, calls: int, warm: int = 3):
+    """ms per call of one calibration candidate (slowest rank), or None when it cannot run on SOME rank -- then on no rank.
+
+    ``make()`` returns (callable, cleanup).  Building the candidate and its first calls happen without any collective, so a
+    rank on which they fail (an option this device / runtime refuses, a launch error) does not leave the others waiting in
+    a barrier: every rank reports, all agree, and only candidates that work everywhere are timed.  One exotic candidate that
+    fails must cost that candidate, not the native transport."""
+    import torch
+
+    fn = cleanup = None
+    ok = 1
+    try:
+        fn, cleanup = make()
+        for _ in range(warm):
+            fn()
+        if ctx.get("device", "cuda") == "cuda":
+            torch.cuda.synchronize()
+    except Exception as ex:
+        ok = 0
+        print(f"rank {ctx['rank']}: calibration candidate failed ({ex!r})", file=sys.stderr)
+    ms = None
+    if _agree(ctx, ok):
+        ms = round(_slowest_rank_ms(ctx, fn, calls, warm=0), 5)
+    if cleanup is not None:
+        try:
+            cleanup()
+        except Exception:
+            pass
+    return ms
+
+
 def gather_rank_proof(ctx, info) -> dict:
     """What RCCL itself reports on every rank (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), gathered: the line's
     evidence that the communicator really spans N ranks on N devices."""
@@ -653,20 +684,22 @@ def _setup_distributed_laplacian(args, ctx):
                 for cand_single in ((single_phase,) if "GT4MI_BENCH_SINGLE_PHASE" in os.environ else (False, True)):
                     for cand_schedule in ("join", "chain"):
                         for cand_wg in (0, 4, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
-                            call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg)
+                            def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg):
+                                call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg)
+                                return call, (lambda: [ex.close() for ex in keep[2]])
+
                             key = (f"{cand_grid[0]}x{cand_grid[1]}_{'single' if cand_single else 'two'}phase_{cand_schedule}"
                                    f"_wg{cand_wg}")
-                            table[key] = round(_slowest_rank_ms(ctx, call, 24), 5)
-                            for ex in keep[2]:
-                                ex.close()
-                            del call, keep
+                            ms = measure_candidate(ctx, make, 24)
+                            if ms is not None:
+                                table[key] = ms
             torch.cuda.empty_cache()
         except Exception as ex:
             ok = 0
             print(f"rank {rank}: native RCCL halo exchange failed during calibration ({ex!r})", file=sys.stderr)
-        if not _agree(ctx, ok):
+        if not _agree(ctx, ok and bool(table)):
             transport, comm, fallback = "torch", None, True
-            transport_fallback_banner(rank, "the native halo exchange failed during calibration")
+            transport_fallback_banner(rank, "the native halo exchange failed during calibration (no candidate ran on every rank)")
         else:
             calibration = table
             best = min(table, key=table.get)
@@ -720,14 +753,15 @@ def _setup_distributed_laplacian(args, ctx):
         still exchanges its own input's ghost cells.  ms per apply, slowest rank."""
         table = {}
         for cand_wg in (0, 4, 2):
-            call, keep = apply_candidate(grid, single_phase, "chain", cand_wg)
-            for ex in keep[2]:
-                ex.tune(defer_join=True)
-            table[f"chain_wg{cand_wg}"] = round(_slowest_rank_ms(ctx, call, 48), 5)
-            for ex in keep[2]:
-                ex.end()
-                ex.close()
-            del call, keep
+            def make(cand_wg=cand_wg):
+                call, keep = apply_candidate(grid, single_phase, "chain", cand_wg)
+                for ex in keep[2]:
+                    ex.tune(defer_join=True)
+                return call, (lambda: [(ex.end(), ex.close()) for ex in keep[2]])
+
+            ms = measure_candidate(ctx, make, 48)
+            if ms is not None:
+                table[f"chain_wg{cand_wg}"] = ms
         torch.cuda.empty_cache()
         return table
 
@@ -746,23 +780,26 @@ def _setup_distributed_laplacian(args, ctx):
             for stepper in ("skewed_join", "skewed_chain", "skewed_chain_wg4", "wide_overlap", "wide_sequential"):
                 if not stepper.startswith("skewed") and cand_halo == 3:
                     continue
-                cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
-                ca, cb = cpairs[0][0], cpairs[1][0]
-                ca.tensor.mul_(1e-150)
-                cb.tensor.copy_(ca.tensor)
-                cex = NativeHaloExchanger(cdec, np.float64, comm, single_phase=single_phase)
-                if stepper.startswith("skewed"):
-                    cex.tune("chain" if "chain" in stepper else "join", 4 if stepper.endswith("wg4") else 0)
-                    fn, per_call = cex.make_time_skewed_lap5(ca, cb, cdec.origin), cand_halo
-                else:
-                    fn, per_call = cex.make_time_stepper_lap5(ca, cb, cdec.origin, overlap=stepper == "wide_overlap"), 1
+                per_call = cand_halo if stepper.startswith("skewed") else 1
+
+                def make(stepper=stepper, cdec=cdec):
+                    cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
+                    ca, cb = cpairs[0][0], cpairs[1][0]
+                    ca.tensor.mul_(1e-150)
+                    cb.tensor.copy_(ca.tensor)
+                    cex = NativeHaloExchanger(cdec, np.float64, comm, single_phase=single_phase)
+                    if stepper.startswith("skewed"):
+                        cex.tune("chain" if "chain" in stepper else "join", 4 if stepper.endswith("wg4") else 0)
+                        fn = cex.make_time_skewed_lap5(ca, cb, cdec.origin)
+                    else:
+                        fn = cex.make_time_stepper_lap5(ca, cb, cdec.origin, overlap=stepper == "wide_overlap")
+                    return fn, cex.close
+
                 calls = max(24 // per_call, 6) if per_call > 1 else 24
-                ms = _slowest_rank_ms(ctx, fn, calls, warm=2 * (cand_halo if per_call == 1 else 1)) / per_call
-                table[f"{stepper}_halo{cand_halo}"] = round(ms, 5)
-                cex.close()
-                del cpairs, ca, cb, fn
+                ms = measure_candidate(ctx, make, calls, warm=2 * (cand_halo if per_call == 1 else 1))
+                if ms is not None:
+                    table[f"{stepper}_halo{cand_halo}"] = round(ms / per_call, 5)
         torch.cuda.empty_cache()
-        best = min(table, key=table.get)
         lups = float(np.prod(dec.global_domain))
         out = {}
         if pipelined:
@@ -772,6 +809,9 @@ def _setup_distributed_laplacian(args, ctx):
                    "pipelined_apply_workload": "the applies of `value` without the join after each one: the applies are independent "
                                                "(two rotating pairs, a plan and side stream each), so apply i + 1's interior kernel "
                                                "runs next to apply i's exchange and ring; every apply still exchanges its own ghost cells"}
+        if not table:
+            return out or None
+        best = min(table, key=table.get)
         return {**out, "timestep_glups": round(lups / table[best] / 1e6, 2), "timestep_best": best, "timestep_ms_per_step": table,
                 "timestep_workload": "time stepping u <- lap(u) on the same decomposed grid, ghost regions H deep, ONE exchange "
                                      "per H steps (skewed: boundary bands first, the faces travel next to H interior kernels; "
@@ -870,14 +910,17 @@ def _setup_hdiff2048(args, ctx):
             try:
                 for name in names:
                     if pinned is None or pinned == name:
-                        fn, ex = make_form(name)
-                        timings[name] = round(_slowest_rank_ms(ctx, fn, 16), 5)
-                        ex.close()
-                        del fn, ex
+                        def make(name=name):
+                            fn, ex = make_form(name)
+                            return fn, ex.close
+
+                        ms = measure_candidate(ctx, make, 16)
+                        if ms is not None:
+                            timings[name] = ms
             except Exception as exn:
                 ok = 0
                 print(f"rank {rank}: native RCCL halo exchange failed during calibration ({exn!r})", file=sys.stderr)
-            if not _agree(ctx, ok):
+            if not _agree(ctx, ok and bool(timings)):
                 transport, comm, fallback = "torch", None, True
                 transport_fallback_banner(rank, "the native halo exchange failed during calibration")
             else:
@@ -909,13 +952,18 @@ def _setup_hdiff2048(args, ctx):
         flags = type(hd)._gt_binding_.flags
         for single in (False, True):
             for cand_wg in (0, 3, 2):
-                for cand_edge in (2, 32):
-                    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune("chain", cand_wg, defer_join=True,
-                                                                                              edge_columns=cand_edge)
-                    fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
-                    table[f"{'single' if single else 'two'}_phase_chain_wg{cand_wg}_edge{cand_edge}"] = round(_slowest_rank_ms(ctx, fn, 32), 5)
-                    ex.end()
-                    ex.close()
+                for cand_edge in (2, 16, 32):
+                    def make(single=single, cand_wg=cand_wg, cand_edge=cand_edge):
+                        ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune("chain", cand_wg, defer_join=True,
+                                                                                                  edge_columns=cand_edge)
+                        fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
+                        return fn, (lambda: (ex.end(), ex.close()))
+
+                    ms = measure_candidate(ctx, make, 32)
+                    if ms is not None:
+                        table[f"{'single' if single else 'two'}_phase_chain_wg{cand_wg}_edge{cand_edge}"] = ms
+        if not table:
+            return None
         best = min(table, key=table.get)
         return {"pipelined_apply_glups": round(float(np.prod(total)) / table[best] / 1e6, 2), "pipelined_apply_best": best,
                 "pipelined_apply_ms": table,

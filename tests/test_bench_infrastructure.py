@@ -95,10 +95,21 @@ def _proof_worker(rank: int, world: int, port: int, tmpdir: str):
         everyone_ok = bench._agree(ctx, 1)
         one_failed = bench._agree(ctx, 0 if rank == 1 else 1)
         ms = bench._slowest_rank_ms(ctx, (lambda: time.sleep(0.002 * (rank + 1))), calls=3, warm=1)  # rank 1 is the slow one
+        # a calibration candidate that fails on ONE rank is dropped on every rank without anyone waiting in a barrier
+        def good():
+            return (lambda: time.sleep(0.001)), (lambda: None)
+
+        def bad_on_rank_1():
+            if rank == 1:
+                raise RuntimeError("this device refuses the option")
+            return (lambda: None), (lambda: None)
+
+        candidates = [bench.measure_candidate(ctx, good, 3, warm=1), bench.measure_candidate(ctx, bad_on_rank_1, 3, warm=1),
+                      bench.measure_candidate(ctx, good, 3, warm=1)]
         keys = bench.decomposed_line_keys(proof, False, world, {"timestep_glups": 1.0})
         fallen = bench.decomposed_line_keys(None, True, world, None)
         with open(os.path.join(tmpdir, f"rank{rank}.json"), "w") as fh:
-            json.dump({"keys": keys, "fallen": fallen, "ok": [everyone_ok, one_failed], "ms": ms}, fh)
+            json.dump({"keys": keys, "fallen": fallen, "ok": [everyone_ok, one_failed], "ms": ms, "candidates": candidates}, fh)
     finally:
         dist.destroy_process_group()
 
@@ -123,6 +134,8 @@ def test_the_n_gpu_line_says_how_many_ranks_rccl_saw_and_whether_the_transport_f
         assert got["fallen"] == {"rccl_nranks": None, "rank_devices": None, "rccl_matches_n_gpus": False, "transport_fallback": True}
         assert got["ok"] == [1, 0]  # one failing rank makes every rank fall back together
         assert got["ms"] >= 3.5  # the slowest rank's time on every rank
+        c = got["candidates"]
+        assert c[0] is not None and c[0] >= 1.0 and c[1] is None and c[2] is not None
     bench.transport_fallback_banner(0, "testing")
     err = capfd.readouterr().err
     assert "NATIVE RCCL TRANSPORT UNAVAILABLE (testing)" in err and "NOT those of the product path" in err

@@ -256,6 +256,39 @@ static void section_mix() {
         mix_variant<1, 2>(buf, nbytes);
     }
     for (int n = 0; n < 7; ++n) hipFree(buf[n]);
+    // the same 2 : 1 and 4 : 3 mixes with the arrays placed at different relative offsets inside ONE allocation: does the
+    // ceiling depend on where the streams sit relative to each other (as the tridiagonal solve's five fields do)?
+    {
+        const size_t span = nbytes + (8ull << 20);
+        char* big;
+        CK(hipMalloc(&big, 7 * span + (8ull << 20)));
+        CK(hipMemset(big, 1, 7 * span));
+        char* base = (char*)(((uintptr_t)big + (4ull << 20) - 1) / (4ull << 20) * (4ull << 20));
+        for (size_t step_kib : {0ull, 4ull, 64ull, 256ull, 1024ull, 1536ull, 2048ull, 3072ull}) {
+            char* at[7];
+            for (int n = 0; n < 7; ++n) at[n] = base + n * span + n * (step_kib << 10);
+            // read arrays = slots 0..3, written = 4..6 (mix_variant's convention)
+            for (int rep = 0; rep < 2; ++rep) {
+                const size_t nvec = nbytes / 16;
+                auto R = [&](int n) { return reinterpret_cast<const u32x4*>(at[n]); };
+                auto Wr = [&](int n) { return reinterpret_cast<u32x4*>(at[4 + n]); };
+                char cfg[96];
+                double ms = time_ms([&](int) {
+                    hipLaunchKernelGGL((mix_kernel<2, 1>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, R(0), R(1), R(2), R(3), Wr(0),
+                                       Wr(1), Wr(2), nvec);
+                }, 10);
+                snprintf(cfg, sizeof cfg, "2 read : 1 written, arrays %zu KiB apart (mod 4 MiB)", step_kib);
+                report("rw_place", cfg, ms, (double)nvec, 48.0);
+                ms = time_ms([&](int) {
+                    hipLaunchKernelGGL((mix_kernel<4, 3>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, R(0), R(1), R(2), R(3), Wr(0),
+                                       Wr(1), Wr(2), nvec);
+                }, 10);
+                snprintf(cfg, sizeof cfg, "4 read : 3 written, arrays %zu KiB apart (mod 4 MiB)", step_kib);
+                report("rw_place", cfg, ms, (double)nvec, 112.0);
+            }
+        }
+        hipFree(big);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

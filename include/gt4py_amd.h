@@ -198,9 +198,11 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *                                   the caller's stream wait for the side stream's chain; the caller joins with
  *                                   gt4mi_halo_exchange_end before anything consumes the result.  For INDEPENDENT applies:
  *                                   the interior of the next apply runs next to the exchange and ring of this one.
- *   GT4MI_PLAN_EDGE_COLUMNS         gt4mi_dist_hdiff_*: width of the W / E boxes left to the ring kernel (>= 2, even; default
- *                                   16): what the ring computes is taken off the interior kernel, and a box of whole cache
- *                                   lines costs the memory system less than the 2-column box the stencil's reach requires
+ *   GT4MI_PLAN_EDGE_COLUMNS         gt4mi_dist_hdiff_* / gt4mi_dist_lap5_f64: width of the W / E boxes left to the ring kernel
+ *                                   (even; default 16, 8 for local domains narrower than 256 columns; the Laplacian's at most
+ *                                   16): what the ring computes is taken off the interior kernel, a box of whole cache lines
+ *                                   costs the memory system less than the 1 - 2 columns the stencil's reach requires, and the
+ *                                   interior kernel keeps its 16-byte alignment
  * Which combination is fastest depends on the links; bench.py measures them (config.calibration_ms_per_apply). */
 enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1, GT4MI_PLAN_DEFER_JOIN = 2, GT4MI_PLAN_EDGE_COLUMNS = 3 };
 enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1 };

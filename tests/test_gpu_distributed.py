@@ -62,22 +62,26 @@ def test_periodic_self_exchange(comm, dtype, periodic, halo):
     ex.close()
 
 
+@pytest.mark.parametrize("edge_columns,schedule", [(None, None), (1, "join"), (8, "chain"), (16, "chain"), (6, "join")])
 @pytest.mark.parametrize("periodic", [(True, True), (False, True), (True, False)])
-def test_fused_distributed_laplacian_step(comm, periodic):
-    """gt4mi_dist_lap5_f64 (exchange || interior, then strips) == oracle Laplacian on the wrapped field."""
+def test_fused_distributed_laplacian_step(comm, periodic, edge_columns, schedule):
+    """gt4mi_dist_lap5_f64 (exchange || interior, then the ring) == oracle Laplacian on the wrapped field, for every width
+    of the W / E boxes the ring takes off the interior and both schedules."""
     import torch
 
     import gt4py_amd.storage as gt_storage
     from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
     from oracle import ref_numpy as R
 
-    gd = (64, 48, 6)
+    gd = (64, 48, 6) if edge_columns != 16 else (300, 40, 4)  # 16 columns need a local domain at least 256 wide
     dec = Decomposition(gd, (1, 1), 0, 1, periodic=periodic)
     rng = np.random.default_rng(11)
     host = rng.uniform(-1, 1, dec.local_shape)
     inp = gt_storage.from_array(host, backend="hip:mi300", aligned_index=(1, 1, 0))
     out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=(1, 1, 0))
     ex = NativeHaloExchanger(dec, np.float64, comm)
+    if edge_columns is not None:
+        ex.tune(schedule, 0, edge_columns=edge_columns)
     step = ex.make_dist_lap5(inp, out, (1, 1, 0), (1, 1, 0))
     for _ in range(3):
         step()
@@ -426,6 +430,8 @@ def test_fused_distributed_hdiff_step(comm, gd, dtype, coeff_kind, periodic, sin
     d_in = gt_storage.from_array(host, dtype, backend="hip:mi300", aligned_index=dec.origin)
     d_out = gt_storage.zeros(dec.local_shape, dtype, backend="hip:mi300", aligned_index=dec.origin)
     ex = NativeHaloExchanger(dec, dtype, comm, single_phase=single_phase)
+    if gd[0] > 100:  # the wide domain: other widths of the W / E boxes than the default, and the other schedule
+        ex.tune("join" if single_phase else "chain", 3, edge_columns=8 if periodic[1] else 32)
     names = list(inspect_signature_names(hd))
     args = {names[0]: d_in, names[1]: d_out}
     if coeff_kind == "field":

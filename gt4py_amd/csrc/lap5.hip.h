@@ -53,9 +53,13 @@ __device__ __forceinline__ T lap5_expr(T c, T w, T e, T s, T n) {
 
 // The strip of ONE lane: VEC columns from i0 x rows [j0, min(j0+LJ, dJ)) of level k.  edge_w / edge_e: the lane's west / east
 // neighbour column is not in the adjacent lane's registers (first / last lane of a row of lanes) and is loaded instead.
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int NTL = 0>
+// MASKED: only the columns [c_lo, c_hi) of the (16-byte aligned) view are the compute domain -- a domain whose first column
+// is not on a 16-byte boundary, or whose width is odd, shifted onto the boundary (lap5_launch_variant): vectors are loaded
+// whole (they reach at most one column into the halo on either side), stored element by element where they straddle the
+// domain's edge, and a neighbour column outside the halo is never loaded (its consumer is not a domain point).
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int NTL = 0, bool MASKED = false>
 __device__ __forceinline__ void lap5_strip_lane(const View<const T>& in, const View<T>& out, int dJ, int i0, bool active,
-                                                bool edge_w, bool edge_e, int j0, unsigned k) {
+                                                bool edge_w, bool edge_e, int j0, unsigned k, int c_lo = 0, int c_hi = 0) {
     const T* __restrict__ col = in.p + (int64_t)k * in.sk + i0;
     T* __restrict__ ocol = out.p + (int64_t)k * out.sk + i0;
 
@@ -83,13 +87,18 @@ __device__ __forceinline__ void lap5_strip_lane(const View<const T>& in, const V
             vload<T, VEC>(col + roff[t], r[t]);
         }
     }
+    bool first_in = true, last_in = true;  // the lane's first / last column is a domain point
+    if constexpr (MASKED) {
+        first_in = i0 >= c_lo && i0 < c_hi;
+        last_in = i0 + VEC - 1 >= c_lo && i0 + VEC - 1 < c_hi;
+    }
     T w[LJ + 2], e[LJ + 2];
 #pragma unroll
     for (int t = 1; t <= LJ; ++t) {
         T wl = lane_shift<T, true>(r[t][VEC - 1]);
         T el = lane_shift<T, false>(r[t][0]);
-        if (edge_w) wl = col[roff[t] - 1];
-        if (edge_e) el = col[roff[t] + VEC];
+        if (edge_w && first_in) wl = col[roff[t] - 1];
+        if (edge_e && last_in) el = col[roff[t] + VEC];
         w[t] = wl;
         e[t] = el;
     }
@@ -102,21 +111,32 @@ __device__ __forceinline__ void lap5_strip_lane(const View<const T>& in, const V
             const T ev = (v == VEC - 1) ? e[t] : r[t][v + 1];
             res[v] = lap5_expr<T, W, VARIANT>(r[t][v], wv, ev, r[t - 1][v], r[t + 1][v]);
         }
-        if (active && (j0 + t - 1 < dJ)) vstore<T, VEC, true>(ocol + (int64_t)(j0 + t - 1) * out.sj, res);
+        if (active && (j0 + t - 1 < dJ)) {
+            T* o = ocol + (int64_t)(j0 + t - 1) * out.sj;
+            if (!MASKED || (first_in && last_in)) {
+                vstore<T, VEC, true>(o, res);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (i0 + v >= c_lo && i0 + v < c_hi) __builtin_nontemporal_store(res[v], o + v);
+            }
+        }
     }
 }
 
 // One strip: columns [bx*BLOCK*VEC, ...) x rows [j0, min(j0+LJ, dJ)) of level k; the lanes of a wave lie along I.
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int NTL = 0>
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int NTL = 0, bool MASKED = false>
 __device__ __forceinline__ void lap5_strip_tile(const View<const T>& in, const View<T>& out, int dI, int dJ,
-                                                unsigned bx, int j0, unsigned k) {
+                                                unsigned bx, int j0, unsigned k, int c_lo = 0) {
     const unsigned lane = threadIdx.x & 63;
     // Lanes past the end of the row stay active (DPP needs their neighbours' exec bits) but are
-    // clamped onto the last valid vector and never store.
+    // clamped onto the last valid vector and never store.  (MASKED: dI counts from the aligned column, the domain is
+    // [c_lo, dI); the last vector may hold one column of halo.)
     int i0 = (int)(bx * BLOCK + threadIdx.x) * VEC;
     const bool active = i0 < dI;
-    if (!active) i0 = dI - VEC;
-    lap5_strip_lane<T, W, VARIANT, VEC, LJ, NTL>(in, out, dJ, i0, active, lane == 0, (lane == 63) || (i0 + VEC >= dI), j0, k);
+    if (!active) i0 = MASKED ? ((dI + VEC - 1) / VEC - 1) * VEC : dI - VEC;
+    lap5_strip_lane<T, W, VARIANT, VEC, LJ, NTL, MASKED>(in, out, dJ, i0, active, lane == 0, (lane == 63) || (i0 + VEC >= dI), j0, k,
+                                                        c_lo, dI);
 }
 
 // A box only LPR * VEC columns wide (the W / E boxes of a decomposed apply): a wave is 64 / LPR rows of LPR lanes, each row of
@@ -135,9 +155,9 @@ __device__ __forceinline__ void lap5_narrow_tile(const View<const T>& in, const 
                                             j0 < dJ ? j0 : dJ, k);
 }
 
-template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG = 0, int NTL = 0>
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG = 0, int NTL = 0, bool MASKED = false>
 __global__ void __launch_bounds__(BLOCK)
-lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x, unsigned tiles_y) {
+lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x, unsigned tiles_y, int c_lo = 0) {
     // XCDG > 0: runs of XCDG consecutive strips share an XCD (private L2), so the halo rows they
     // share are L2 hits instead of a second fabric fetch.  XCDG = -1: one contiguous range per XCD.
     unsigned b = blockIdx.x;
@@ -146,7 +166,7 @@ lap5_strip_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_
     const unsigned bx = b % tiles_x;
     const unsigned by = (b / tiles_x) % tiles_y;
     const unsigned k = b / (tiles_x * tiles_y);
-    lap5_strip_tile<T, W, VARIANT, VEC, LJ, BLOCK, NTL>(in, out, dI, dJ, bx, (int)by * LJ, k);
+    lap5_strip_tile<T, W, VARIANT, VEC, LJ, BLOCK, NTL, MASKED>(in, out, dI, dJ, bx, (int)by * LJ, k, c_lo);
 }
 
 // Up to two single J rows (row_a, row_b) of every level in ONE launch: the boundary strips of a
@@ -195,7 +215,24 @@ inline int lap5_launch_strip(const View<const T>& in, const View<T>& out, const 
     const int64_t n = (int64_t)tx * ty * d[2];
     if (n > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "lap5: domain too large for one launch");
     hipLaunchKernelGGL((lap5_strip_kernel<T, W, VARIANT, VEC, LJ, BLOCK, Lap5Tuning::XCDG>), dim3((unsigned)n), dim3(BLOCK),
-                       launch_dynamic_lds(), stream, in, out, (int)d[0], (int)d[1], tx, ty);
+                       launch_dynamic_lds(), stream, in, out, (int)d[0], (int)d[1], tx, ty, 0);
+    return GT4MI_OK;
+}
+
+// The same strips for a domain that starts `lead` columns past a 16-byte boundary and / or has an odd width: the views are
+// moved onto the boundary and the kernel masks the columns outside [lead, lead + dI) (lap5_strip_lane<..., MASKED>).
+template <typename T, typename W, int VARIANT, int VEC, int BLOCK>
+inline int lap5_launch_strip_masked(const View<const T>& in, const View<T>& out, const int64_t d[3], int lead, hipStream_t stream) {
+    constexpr int LJ = Lap5Tuning::LJ;
+    const View<const T> in_a{in.p - lead, in.si, in.sj, in.sk};
+    const View<T> out_a{out.p - lead, out.si, out.sj, out.sk};
+    const int64_t width = d[0] + lead;
+    const unsigned tx = (unsigned)cdiv(width, (int64_t)BLOCK * VEC);
+    const unsigned ty = (unsigned)cdiv(d[1], LJ);
+    const int64_t n = (int64_t)tx * ty * d[2];
+    if (n > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "lap5: domain too large for one launch");
+    hipLaunchKernelGGL((lap5_strip_kernel<T, W, VARIANT, VEC, LJ, BLOCK, Lap5Tuning::XCDG, 0, true>), dim3((unsigned)n), dim3(BLOCK),
+                       launch_dynamic_lds(), stream, in_a, out_a, (int)width, (int)d[1], tx, ty, lead);
     return GT4MI_OK;
 }
 
@@ -211,6 +248,23 @@ inline int lap5_launch_variant(const View<const T>& in, const View<T>& out, cons
             if (lanes <= 64) return lap5_launch_strip<T, W, VARIANT, VMAX, 64>(in, out, d, stream);
             if (lanes <= 128) return lap5_launch_strip<T, W, VARIANT, VMAX, 128>(in, out, d, stream);
             return lap5_launch_strip<T, W, VARIANT, VMAX, 256>(in, out, d, stream);
+        }
+        if constexpr (sizeof(T) == 8) {
+            // 8-byte items whose rows are 16-byte aligned among themselves, `inp` and `out` equally far (0 or 1 column) from a
+            // 16-byte boundary: the 16-byte-lane strips with masked edges instead of 8-byte lanes (a domain origin that is not
+            // the storage's aligned column, or an odd width, cost 14-19 % on 8-byte lanes: profiles/r3_misaligned_origin.log)
+            const int lead = (int)((reinterpret_cast<uintptr_t>(in.p) % 16) / sizeof(T));
+            const bool same = lead == (int)((reinterpret_cast<uintptr_t>(out.p) % 16) / sizeof(T));
+            if (same && in.sj % VMAX == 0 && in.sk % VMAX == 0 && out.sj % VMAX == 0 && out.sk % VMAX == 0) {
+                const int64_t lanes = cdiv(d[0] + lead, VMAX);
+                if (lanes <= 64) return lap5_launch_strip_masked<T, W, VARIANT, VMAX, 64>(in, out, d, lead, stream);
+                if (lanes <= 128) return lap5_launch_strip_masked<T, W, VARIANT, VMAX, 128>(in, out, d, lead, stream);
+                // one lane more than the aligned domain needs (512 columns from an odd origin: 257 lanes) must not cost a
+                // second, almost empty workgroup per row: five waves instead of four where that wastes fewer lanes
+                if (cdiv(lanes, 320) * 320 < cdiv(lanes, 256) * 256)
+                    return lap5_launch_strip_masked<T, W, VARIANT, VMAX, 320>(in, out, d, lead, stream);
+                return lap5_launch_strip_masked<T, W, VARIANT, VMAX, 256>(in, out, d, lead, stream);
+            }
         }
         if (d[0] <= 64) return lap5_launch_strip<T, W, VARIANT, 1, 64>(in, out, d, stream);
         return lap5_launch_strip<T, W, VARIANT, 1, 256>(in, out, d, stream);

@@ -413,3 +413,23 @@ def test_lap5_ring_equals_the_whole_domain_kernel_on_the_ring(domain, outer, inn
     want = np.where(mask[:, :, None], want_full, sentinel)
     got = d_o.get()
     assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+
+
+@pytest.mark.parametrize("domain", [(512, 9, 3), (511, 6, 2), (513, 5, 2), (1030, 5, 2), (126, 20, 4), (640, 4, 2)])
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("align", [(0, 0, 0), (1, 1, 0)])
+def test_lap5_origin_off_the_aligned_column_and_odd_widths(domain, variant, align):
+    """A compute-domain origin one column past a 16-byte boundary (storage allocated with the default aligned_index, origin
+    (1, 1, 0)) and odd widths run the 16-byte-lane strips with masked edges (lap5_strip_lane<..., MASKED>; five-wave
+    workgroups where the extra lane would otherwise need a second one) -- same values as the oracle, halo of `out` untouched."""
+    import gpu_util as G
+
+    rng = np.random.default_rng(sum(domain) + variant)
+    shape = (domain[0] + 2, domain[1] + 2, domain[2])
+    inp = rng.uniform(-1, 1, shape)
+    out0 = rng.uniform(-1, 1, shape)
+    want = out0.copy()
+    R.laplacian(inp, want, domain=domain, variant=["notebook", "docs", "suite", "avg"][variant])
+    d_in, d_out = G.DevArray(inp, "ifirst", align_index=align), G.DevArray(out0, "ifirst", align_index=align)
+    G.lap5(d_in, d_out, (1, 1, 0), (1, 1, 0), domain, variant)
+    _eq(d_out.get(), want, f"lap5 f64 {domain} aligned_index {align} v{variant}")

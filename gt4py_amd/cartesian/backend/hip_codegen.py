@@ -1537,13 +1537,18 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
     def has(n: str, axis: str) -> bool:
         return axis in em.axes.get(n, ("I", "J", "K"))
 
-    L.append(f'extern "C" __global__ void __launch_bounds__({block[0] * block[1]}) {kname}_vec(const gt_args a) {{')
+    # the workgroup shape is the LAUNCH's (blockDim): the host may add a fifth wave along I where one extra lane -- a domain
+    # of 512 columns from an odd origin needs 257 -- would otherwise cost a second, almost empty workgroup per row
+    L.append(f'extern "C" __global__ void __launch_bounds__({max(block[0] * block[1], 320)}) {kname}_vec(const gt_args a) {{')
     L.append("    unsigned gt_bx, gt_by, gt_bz;")
     L.append(f"    gt_tile({xcd_rows}u, gt_bx, gt_by, gt_bz);")
     L.append("    const int lane = threadIdx.x & 63;  // waves lie along I: blockDim.x is a multiple of 64")
-    L.append(f"    const gt_i64 i0 = ((gt_i64)gt_bx * {block[0]} + threadIdx.x) * {vec};")
+    # a.lead: the origins lie `lead` items past a 16-byte boundary (all arrays alike; the host checks): lanes start that far
+    # BEFORE the domain, so that every lane's vector is naturally aligned; the first lane of a row then holds a partial
+    # vector (handled point by point, like the last one) and its right-hand neighbour loads its west column itself
+    L.append(f"    const gt_i64 i0 = ((gt_i64)gt_bx * blockDim.x + threadIdx.x) * {vec} - a.lead;")
     L.append(f"    const gt_i64 iend = a.dI + ({ihi}), jend = a.dJ + ({jhi});")
-    L.append(f"    const gt_i64 j0 = ((gt_i64)gt_by * {block[1]} + threadIdx.y) * {JT} + ({jlo});")
+    L.append(f"    const gt_i64 j0 = ((gt_i64)gt_by * blockDim.y + threadIdx.y) * {JT} + ({jlo});")
     L.append("    if (i0 >= iend || j0 >= jend) return;")
     for n in globals_:
         c = _c_ident(n)
@@ -1552,8 +1557,8 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
         qual = " __restrict__" if n in plan.scratch else " GT_RESTRICT"
         off = " + ".join(t for t in ("i0" if has(n, "I") else "", f"j0 * a.{c}_sj" if has(n, "J") else "") if t) or "0"
         L.append(f"    {const}{ct}* const{qual} b_{c} = a.{c} + {off};")
-    L.append(f"    const bool whole = i0 + {vec} <= iend && j0 + {JT} <= jend;  // else: a partial vector / strip")
-    L.append(f"    const bool edge_lo = lane == 0, edge_hi = lane == 63 || i0 + {2 * vec} > iend;")
+    L.append(f"    const bool whole = i0 >= 0 && i0 + {vec} <= iend && j0 + {JT} <= jend;  // else: a partial vector / strip")
+    L.append(f"    const bool edge_lo = lane == 0 || i0 < {vec}, edge_hi = lane == 63 || i0 + {2 * vec} > iend;")
     if k_per_thread > 1:
         L.append("    #pragma unroll")
         L.append(f"    for (int kk = 0; kk < {k_per_thread}; ++kk) {{")
@@ -1648,6 +1653,7 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
         L.append("          if (j >= jend) break;")
         L.append(f"          for (int v = 0; v < {vec}; ++v) {{")
         L.append("            const gt_i64 i = i0 + v;")
+        L.append("            if (i < 0) continue;")
         L.append("            if (i >= iend) break;")
         for n in globals_:
             c = _c_ident(n)
@@ -1691,9 +1697,10 @@ def generate(stencil: ir.Stencil) -> GeneratedProgram:
         fields_c.append((f"p_{_c_ident(p.name)}", _CTYPES_TYPE[dt.name]))
     struct_lines.append("    gt_i64 dI, dJ, dK;")
     struct_lines.append("    gt_i64 k_lo, k_hi;  // thread-per-point kernels cover the levels [k_lo, k_hi) of this launch")
+    struct_lines.append("    gt_i64 lead;  // `_vec` kernels: the arrays' origins lie this many items past a 16-byte boundary (0 .. vec - 1)")
     struct_lines.append("};")
     fields_c += [("dI", ctypes.c_int64), ("dJ", ctypes.c_int64), ("dK", ctypes.c_int64), ("k_lo", ctypes.c_int64),
-                 ("k_hi", ctypes.c_int64)]
+                 ("k_hi", ctypes.c_int64), ("lead", ctypes.c_int64)]
     args_struct = type("gt_args", (ctypes.Structure,), {"_fields_": fields_c})
 
     kernels = []

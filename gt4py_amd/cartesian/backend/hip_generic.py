@@ -396,6 +396,13 @@ class HipGenericStencilObject(StencilObject):
             setattr(args, f"p_{hip_codegen._c_ident(p.name)}", np.dtype(p.dtype).type(arguments[p.name]).item())
         args.dI, args.dJ, args.dK = dI, dJ, dK
         args.k_lo, args.k_hi = 0, dK
+        # How many items the origins of the API fields lie past a 16-byte boundary -- the same for all of them (the usual
+        # case: storages allocated alike, one origin), else 0: the `_vec` strip kernels then start their lanes that far
+        # before the domain (hip_codegen._emit_vector_kernel) instead of leaving such calls to the one-point-per-thread twin
+        leads = {(geometry[d.name][0] % 16) // geometry[d.name][3] if geometry[d.name][3] in (4, 8) else -1
+                 for d in plan.api_fields if "I" in d.axes}
+        lead = leads.pop() if len(leads) == 1 else 0
+        args.lead = lead if lead > 0 else 0
 
         no_alias = _ranges_disjoint(spans) or _check_aliases(plan, [d.name for d in plan.api_fields], spans, views, boxes)
         vkey = (unit_i, no_alias)
@@ -434,12 +441,15 @@ class HipGenericStencilObject(StencilObject):
                 per_wave = (64 - 2 * kern.shared_halo) * kern.shared_vec
                 grid = _U3(-(-ni // (per_wave * (kern.block[0] // 64))), -(-nj // (kern.block[1] * kern.shared_rows)), nk)
                 return sfn, grid, _U3(*kern.block)
-            if vfn is not None and no_alias and all(
-                    geometry[n][0] % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0
+            if vfn is not None and no_alias and args.lead < kern.vec and all(
+                    (geometry[n][0] - args.lead * geometry[n][3]) % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0
                     and geometry[n][2] % kern.vec == 0 for n in kern.vec_fields):
-                fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned
+                fn, lanes, rows = vfn, kern.vec, kern.vec_rows  # every lane's vector is naturally aligned (after the lead)
                 block = kern.vec_block or kern.block
-                return fn, _U3(-(-ni // (block[0] * lanes)), -(-nj // (block[1] * rows)), nk), _U3(*block)
+                need = -(-(ni + args.lead) // lanes)  # lanes along I
+                if block[1] == 1 and block[0] == 256 and -(-need // 320) * 320 < -(-need // 256) * 256:
+                    block = (320, 1, 1)  # five waves: fewer idle lanes than a second workgroup per row
+                return fn, _U3(-(-need // block[0]), -(-nj // (block[1] * rows)), nk), _U3(*block)
             grid = _U3(-(-ni // (kern.block[0] * lanes)), -(-nj // (kern.block[1] * kern.j_per_thread * rows)), nk)
             return fn, grid, _U3(*kern.block)
 

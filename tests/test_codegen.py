@@ -143,7 +143,7 @@ def test_generated_source_compiles_for_gfx950(programs, name):
     n_arrays = len(prog.plan.api_fields) + len(prog.plan.scratch)
     n_data = sum(len(d.data_dims) for d in (*prog.plan.api_fields, *prog.plan.stencil.temporaries)
                  if d.name in prog.plan.scratch or d in prog.plan.api_fields)
-    assert len(prog.args_struct._fields_) == 4 * n_arrays + n_data + len(prog.plan.params) + 5
+    assert len(prog.args_struct._fields_) == 4 * n_arrays + n_data + len(prog.plan.params) + 6  # dI, dJ, dK, k_lo, k_hi, lead
 
 
 def test_horizontal_stages_get_a_16_byte_lane_twin(programs):

@@ -76,8 +76,10 @@ def test_strided_layout_variant(name):
 
 @pytest.mark.parametrize("name", ["laplacian", "horizontal_diffusion", "horizontal_diffusion_f32", "if_with_offsets"])
 def test_misaligned_origin_falls_back_to_one_point_per_thread(name):
-    """The 16-byte-lane kernels need every lane's vector naturally aligned.  An origin on an odd column (the
-    array is aligned on column 0 instead) must select the scalar twin -- and both must agree with the oracle."""
+    """The 16-byte-lane kernels need every lane's vector naturally aligned.  An origin on an odd column (the array is
+    aligned on column 0 instead) either starts the lanes of the `_vec` strip kernel that far before the domain (round 3:
+    `a.lead`; single-stage stencils whose arrays are all equally misaligned) or selects the scalar twin -- and all of
+    them must agree with the oracle."""
     import oracle.numpy_backend  # noqa: F401
     import gt4py_amd.storage as gt_storage
     from gt4py_amd.cartesian import gtscript

@@ -32,12 +32,16 @@ inline bool hdiff_jmarch_enabled() {
 // One strip: wave `wi` along I, rows [tj * LJ, tj * LJ + LJ) of level k, of a domain of dI x dJ points whose origin the
 // views point at.  Shared by the whole-domain kernel below and by the boundary-ring kernel (hdiff_ring.hip.h).
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ, int PF>
+// `lead`: the views' origins lie that many items past a 16-byte boundary (all three alike): the lanes then start `lead`
+// columns further left, which makes every lane's vector naturally aligned again; the lanes that straddle the edge of the
+// readable / writable columns take the element-wise paths that partial vectors at the domain's edges take anyway.
 __device__ __forceinline__ void hdiff_jmarch_strip(const View<const T>& in, const View<T>& out, const View<const T>& cf,
-                                                   PW coeff_scalar, int dI, int dJ, unsigned wi, unsigned tj, unsigned k) {
+                                                   PW coeff_scalar, int dI, int dJ, unsigned wi, unsigned tj, unsigned k,
+                                                   int lead = 0) {
     constexpr int H = (VEC >= 2) ? 1 : 2;   // halo lanes per side
     constexpr int OUT_LANES = 64 - 2 * H;
     const unsigned lane = threadIdx.x & 63;
-    const int col = ((int)(wi * OUT_LANES) - H + (int)lane) * VEC;  // first column of this lane
+    const int col = ((int)(wi * OUT_LANES) - H + (int)lane) * VEC - lead;  // first column of this lane
     const int j0 = (int)tj * LJ;
     const int nrows = (dJ - j0 < LJ) ? (dJ - j0) : LJ;
 
@@ -187,7 +191,7 @@ template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, i
           int PF, int XCDG = 0>
 __global__ void __launch_bounds__(256)
 hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scalar, int dI,
-                    int dJ, unsigned waves_i, unsigned tiles_j, unsigned groups_j) {
+                    int dJ, unsigned waves_i, unsigned tiles_j, unsigned groups_j, int lead) {
     // A workgroup = 4 independent waves on 4 consecutive J strips of one I column, so 3 of the 4
     // strip boundaries (4 shared rows each) are re-read inside one CU; workgroups are ordered along
     // J, then I, then K, and runs of XCDG of them share an XCD (see lap5.hip.h).
@@ -211,7 +215,7 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
     const unsigned wi = column % waves_i;
     const unsigned k = column / waves_i;
 
-    hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF>(in, out, cf, coeff_scalar, dI, dJ, wi, tj, k);
+    hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF>(in, out, cf, coeff_scalar, dI, dJ, wi, tj, k, lead);
 }
 
 // Rows per strip / rows prefetched ahead, from the sweep in profiles/r1_microbench_d_*.log
@@ -228,10 +232,10 @@ struct HdiffTuning {
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC>
 inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
                                    const View<const T>& cf, PW coeff_scalar, const int64_t d[3],
-                                   hipStream_t stream) {
+                                   hipStream_t stream, int lead = 0) {
     constexpr int H = (VEC >= 2) ? 1 : 2;
     constexpr int LJ = HdiffTuning<T>::LJ;
-    const unsigned waves_i = (unsigned)cdiv(d[0], (int64_t)(64 - 2 * H) * VEC);
+    const unsigned waves_i = (unsigned)cdiv(d[0] + lead, (int64_t)(64 - 2 * H) * VEC);
     const unsigned tiles_j = (unsigned)cdiv(d[1], LJ);
     const unsigned groups_j = (unsigned)cdiv(tiles_j, 4);
     const int64_t nblocks = (int64_t)waves_i * groups_j * d[2];
@@ -239,17 +243,40 @@ inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
     hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, HdiffTuning<T>::PF,
                                             HdiffTuning<T>::XCDG>),
                        dim3((unsigned)nblocks), dim3(256), launch_dynamic_lds(), stream, in, out, cf, coeff_scalar, (int)d[0],
-                       (int)d[1], waves_i, tiles_j, groups_j);
+                       (int)d[1], waves_i, tiles_j, groups_j, lead);
     return GT4MI_OK;
+}
+
+// 16-byte lanes are possible when the rows of all fields are 16-byte aligned among themselves and the origins lie equally
+// far (`*lead` items, 0 .. vec - 1) past a 16-byte boundary -- not only when they lie ON one: a storage allocated with the
+// default aligned_index and used from origin (2, 2, 0) puts float32 fields 8 bytes off, which used to mean 4-byte lanes
+// (278 instead of 410 GLUPS on 1024 x 1024 x 80, profiles/r3_misaligned_origin.log).
+template <typename V>
+inline bool vec_rows_ok(const V& v, int vec, int* lead) {
+    if (v.si != 1 || v.sj % vec != 0 || v.sk % vec != 0) return false;
+    const uintptr_t bytes = reinterpret_cast<uintptr_t>(v.p) % (vec * sizeof(*v.p));
+    if (bytes % sizeof(*v.p) != 0) return false;
+    *lead = (int)(bytes / sizeof(*v.p));
+    return true;
+}
+
+template <typename T, bool COEFF_FIELD>
+inline bool hdiff_common_lead(const View<const T>& in, const View<T>& out, const View<const T>& cf, int vec, int* lead) {
+    int li = 0, lo = 0, lc = 0;
+    if (!vec_rows_ok(in, vec, &li) || !vec_rows_ok(out, vec, &lo)) return false;
+    if (COEFF_FIELD && !vec_rows_ok(cf, vec, &lc)) return false;
+    if (li != lo || (COEFF_FIELD && lc != li)) return false;
+    *lead = li;
+    return true;
 }
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD>
 inline int hdiff_launch_jmarch(const View<const T>& in, const View<T>& out, const View<const T>& cf,
                                PW coeff_scalar, const int64_t d[3], hipStream_t stream) {
     constexpr int VMAX = 16 / sizeof(T);
-    const bool vec = vec_ok(in, VMAX) && vec_ok(out, VMAX) && (!COEFF_FIELD || vec_ok(cf, VMAX));
-    if (vec)
-        return hdiff_launch_jmarch_vec<T, W, PW, LIMITER, COEFF_FIELD, VMAX>(in, out, cf, coeff_scalar, d, stream);
+    int lead = 0;
+    if (hdiff_common_lead<T, COEFF_FIELD>(in, out, cf, VMAX, &lead))
+        return hdiff_launch_jmarch_vec<T, W, PW, LIMITER, COEFF_FIELD, VMAX>(in, out, cf, coeff_scalar, d, stream, lead);
     return hdiff_launch_jmarch_vec<T, W, PW, LIMITER, COEFF_FIELD, 1>(in, out, cf, coeff_scalar, d, stream);
 }
 

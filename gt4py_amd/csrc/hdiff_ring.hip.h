@@ -37,6 +37,7 @@ struct RingBoxes {
     int ei[MAX], ej[MAX];       // extent
     unsigned per_level[MAX];    // tiles per K level
     unsigned tiles_i[MAX];      // row boxes: tiles along I
+    int lead[MAX];              // J-march boxes: items the box's first column lies past a 16-byte boundary (hdiff_jmarch_strip)
     unsigned first[MAX + 1];    // prefix sums of tiles (per_level * dK)
 };
 
@@ -105,11 +106,11 @@ hdiff_ring_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scal
     const View<const T> cf_b{COEFF_FIELD ? cf.p + oi + oj * cf.sj : nullptr, 1, cf.sj, cf.sk};
     if (b.kind[m] == 0) {
         hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, 2, 2>(in_b, out_b, cf_b, coeff_scalar, b.ei[m], b.ej[m],
-                                                                      r % b.tiles_i[m], r / b.tiles_i[m], k);
+                                                                      r % b.tiles_i[m], r / b.tiles_i[m], k, b.lead[m]);
     } else if (b.kind[m] == 2) {
         // a W / E box several columns wide: the whole-domain kernel's strips (full cache lines, nothing strided)
         hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, HdiffTuning<T>::LJ, HdiffTuning<T>::PF>(
-            in_b, out_b, cf_b, coeff_scalar, b.ei[m], b.ej[m], r % b.tiles_i[m], r / b.tiles_i[m], k);
+            in_b, out_b, cf_b, coeff_scalar, b.ei[m], b.ej[m], r % b.tiles_i[m], r / b.tiles_i[m], k, b.lead[m]);
     } else {
         hdiff_column_strip<T, W, PW, LIMITER, COEFF_FIELD, 2>(in_b, out_b, cf_b, coeff_scalar, b.ej[m], r, k);
     }
@@ -149,22 +150,24 @@ inline int hdiff_launch_ring(const View<const T>& in, const View<T>& out, const 
         return GT4MI_OK;
     }
     constexpr int VMAX = 16 / sizeof(T);
-    const bool vec = vec_ok(in, VMAX) && vec_ok(out, VMAX) && (!COEFF_FIELD || vec_ok(cf, VMAX));
+    int base_lead = 0;
+    const bool vec = hdiff_common_lead<T, COEFF_FIELD>(in, out, cf, VMAX, &base_lead);
     RingBoxes b;
     b.n = n;
     b.first[0] = 0;
     for (int m = 0; m < RingBoxes::MAX; ++m) {
         if (m >= n) {
-            b.kind[m] = b.i0[m] = b.j0[m] = b.ei[m] = b.ej[m] = 0;
+            b.kind[m] = b.i0[m] = b.j0[m] = b.ei[m] = b.ej[m] = b.lead[m] = 0;
             b.per_level[m] = b.tiles_i[m] = 1;
             b.first[m + 1] = b.first[n];
             continue;
         }
         const Box& x = boxes[m];
         b.kind[m] = x.kind; b.i0[m] = (int)x.i0; b.j0[m] = (int)x.j0; b.ei[m] = (int)x.ei; b.ej[m] = (int)x.ej;
+        b.lead[m] = vec ? (int)(((base_lead + x.i0) % VMAX + VMAX) % VMAX) : 0;  // of the box's own first column
         if (x.kind != 1) {
             const int out_lanes = vec ? 62 * VMAX : 60;  // columns per wave (hdiff_jmarch_strip: H = 1 for vectors, 2 for scalars)
-            b.tiles_i[m] = (unsigned)cdiv(x.ei, out_lanes);
+            b.tiles_i[m] = (unsigned)cdiv(x.ei + b.lead[m], out_lanes);
             b.per_level[m] = b.tiles_i[m] * (unsigned)cdiv(x.ej, x.kind == 0 ? 2 : HdiffTuning<T>::LJ);
         } else {
             b.tiles_i[m] = 1;

@@ -386,7 +386,7 @@ static void hdiff_variant(const DevField<T>& in, DevField<T>& out, const DevFiel
     snprintf(cfg, sizeof cfg, "%s jmarch VEC=%d LJ=%d PF=%d xcd=%d", tag, VEC, LJ, PF, XCDG);
     const double ms = time_ms([&](int) {
         hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, W, true, true, VEC, LJ, PF, XCDG>), dim3(nb), dim3(256), 0, 0,
-                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, groups_j);
+                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, groups_j, 0);
     }, 20);
     report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, bpl);
 }
@@ -450,7 +450,7 @@ static void hdiff_variant_w(const DevField<T>& in, DevField<T>& out, const DevFi
     snprintf(cfg, sizeof cfg, "%s %s-internal VEC=%d LJ=%d PF=%d xcd=%d", tag, sizeof(W) == 4 ? "f32" : "f64", VEC, LJ, PF, XCDG);
     const double ms = time_ms([&](int) {
         hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, W, true, true, VEC, LJ, PF, XCDG>), dim3(nb), dim3(256), 0, 0,
-                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, groups_j);
+                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, groups_j, 0);
     }, 20);
     report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, 3.0 * sizeof(T));
 }

@@ -433,3 +433,31 @@ def test_lap5_origin_off_the_aligned_column_and_odd_widths(domain, variant, alig
     d_in, d_out = G.DevArray(inp, "ifirst", align_index=align), G.DevArray(out0, "ifirst", align_index=align)
     G.lap5(d_in, d_out, (1, 1, 0), (1, 1, 0), domain, variant)
     _eq(d_out.get(), want, f"lap5 f64 {domain} aligned_index {align} v{variant}")
+
+
+@pytest.mark.parametrize("align", [(0, 0, 0), (1, 1, 0), (3, 0, 0), (2, 2, 0)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("domain", [(130, 20, 3), (257, 9, 2), (61, 33, 2), (4, 4, 1)])
+def test_hdiff_origin_off_the_aligned_column(domain, dtype, align):
+    """Horizontal diffusion from an origin that lies 1 - 3 items past a 16-byte boundary (default aligned_index with origin
+    (2, 2, 0) puts float32 fields 8 bytes off): the J-march strips keep their 16-byte lanes, started `lead` columns further
+    left (hdiff_jmarch_strip), whole domain and boundary ring alike; same values as the oracle, nothing else written."""
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    rng = np.random.default_rng(sum(domain))
+    shape = (domain[0] + 4, domain[1] + 4, domain[2])
+    u = rng.uniform(-10, 10, shape).astype(dtype)
+    c = rng.uniform(0, 0.5, shape).astype(dtype)
+    want = np.full(shape, -5.0, dtype=dtype)
+    R.hdiff(u, want, c)
+    d_u, d_c = G.DevArray(u, "ifirst", align), G.DevArray(c, "ifirst", align)
+    d_o = G.DevArray(np.full(shape, -5.0, dtype=dtype), "ifirst", align)
+    G.hdiff(d_u, d_o, d_c, (2, 2, 0), (2, 2, 0), (2, 2, 0), domain, _lib.HDIFF_LIMITER)
+    _eq(d_o.get(), want, f"hdiff {np.dtype(dtype).name} {domain} aligned_index {align}")
+    if domain[0] >= 40 and domain[1] >= 8:  # the ring with the widths the fused distributed step uses
+        widths = (16, 16, 2, 2)
+        d_r = G.DevArray(np.full(shape, -5.0, dtype=dtype), "ifirst", align)
+        G.hdiff_ring(d_u, d_r, d_c, (2, 2, 0), (2, 2, 0), (2, 2, 0), domain, _lib.HDIFF_LIMITER, widths)
+        mask = _ring_mask(shape, (2, 2, 0), domain, (0, 0, 0, 0), widths)
+        _eq(d_r.get(), np.where(mask[:, :, None], want, dtype(-5.0)), f"hdiff ring {np.dtype(dtype).name} {domain} aligned_index {align}")

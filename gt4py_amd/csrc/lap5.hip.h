@@ -249,21 +249,25 @@ inline int lap5_launch_variant(const View<const T>& in, const View<T>& out, cons
             if (lanes <= 128) return lap5_launch_strip<T, W, VARIANT, VMAX, 128>(in, out, d, stream);
             return lap5_launch_strip<T, W, VARIANT, VMAX, 256>(in, out, d, stream);
         }
-        if constexpr (sizeof(T) == 8) {
-            // 8-byte items whose rows are 16-byte aligned among themselves, `inp` and `out` equally far (0 or 1 column) from a
-            // 16-byte boundary: the 16-byte-lane strips with masked edges instead of 8-byte lanes (a domain origin that is not
-            // the storage's aligned column, or an odd width, cost 14-19 % on 8-byte lanes: profiles/r3_misaligned_origin.log)
-            const int lead = (int)((reinterpret_cast<uintptr_t>(in.p) % 16) / sizeof(T));
-            const bool same = lead == (int)((reinterpret_cast<uintptr_t>(out.p) % 16) / sizeof(T));
-            if (same && in.sj % VMAX == 0 && in.sk % VMAX == 0 && out.sj % VMAX == 0 && out.sk % VMAX == 0) {
-                const int64_t lanes = cdiv(d[0] + lead, VMAX);
-                if (lanes <= 64) return lap5_launch_strip_masked<T, W, VARIANT, VMAX, 64>(in, out, d, lead, stream);
-                if (lanes <= 128) return lap5_launch_strip_masked<T, W, VARIANT, VMAX, 128>(in, out, d, lead, stream);
+        {
+            // Rows that are aligned among themselves to a lane of TWO items (16 bytes for 8-byte items, 8 bytes for 4-byte
+            // ones: a whole vector then reaches at most one column into the halo on either side), `inp` and `out` equally far
+            // (0 or 1 column) from such a boundary: two-item lanes with masked edges instead of one-item lanes (a domain origin
+            // that is not the storage's aligned column, or an odd width, cost 14-19 % on 8-byte lanes:
+            // profiles/r3_misaligned_origin.log)
+            constexpr int VM = 2;
+            constexpr uintptr_t unit = VM * sizeof(T);
+            const int lead = (int)((reinterpret_cast<uintptr_t>(in.p) % unit) / sizeof(T));
+            const bool same = lead == (int)((reinterpret_cast<uintptr_t>(out.p) % unit) / sizeof(T));
+            if (same && in.sj % VM == 0 && in.sk % VM == 0 && out.sj % VM == 0 && out.sk % VM == 0) {
+                const int64_t lanes = cdiv(d[0] + lead, VM);
+                if (lanes <= 64) return lap5_launch_strip_masked<T, W, VARIANT, VM, 64>(in, out, d, lead, stream);
+                if (lanes <= 128) return lap5_launch_strip_masked<T, W, VARIANT, VM, 128>(in, out, d, lead, stream);
                 // one lane more than the aligned domain needs (512 columns from an odd origin: 257 lanes) must not cost a
                 // second, almost empty workgroup per row: five waves instead of four where that wastes fewer lanes
                 if (cdiv(lanes, 320) * 320 < cdiv(lanes, 256) * 256)
-                    return lap5_launch_strip_masked<T, W, VARIANT, VMAX, 320>(in, out, d, lead, stream);
-                return lap5_launch_strip_masked<T, W, VARIANT, VMAX, 256>(in, out, d, lead, stream);
+                    return lap5_launch_strip_masked<T, W, VARIANT, VM, 320>(in, out, d, lead, stream);
+                return lap5_launch_strip_masked<T, W, VARIANT, VM, 256>(in, out, d, lead, stream);
             }
         }
         if (d[0] <= 64) return lap5_launch_strip<T, W, VARIANT, 1, 64>(in, out, d, stream);

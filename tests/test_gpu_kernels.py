@@ -44,9 +44,10 @@ def test_lap5_f64_parity(domain, layout, variant):
 
 
 @pytest.mark.parametrize("literal32", [False, True])
-@pytest.mark.parametrize("domain", [(17, 33, 5), (64, 64, 8), (300, 37, 2)])
+@pytest.mark.parametrize("domain", [(17, 33, 5), (64, 64, 8), (300, 37, 2), (513, 6, 2)])
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
-def test_lap5_f32_parity(domain, variant, literal32):
+@pytest.mark.parametrize("align", [(1, 1, 0), (0, 0, 0), (2, 0, 0)])
+def test_lap5_f32_parity(domain, variant, literal32, align):
     import gpu_util as G
     from gt4py_amd import _lib
 
@@ -68,10 +69,11 @@ def test_lap5_f32_parity(domain, variant, literal32):
         r = W(0.25) * (((n + s) + e) + w).astype(W)
     want = np.zeros(shape, np.float32)
     want[1:-1, 1:-1] = r.astype(np.float32)
-    d_in = G.DevArray(inp, "ifirst", align_index=(1, 1, 0))
-    d_out = G.DevArray(np.zeros(shape, np.float32), "ifirst", align_index=(1, 1, 0))
+    # (origins 4 or 8 bytes off a 16-byte boundary and widths that are no multiple of 4 run 8-byte lanes with masked edges)
+    d_in = G.DevArray(inp, "ifirst", align_index=align)
+    d_out = G.DevArray(np.zeros(shape, np.float32), "ifirst", align_index=align)
     G.lap5(d_in, d_out, (1, 1, 0), (1, 1, 0), domain, variant, _lib.LAP_LITERAL_F32 if literal32 else 0)
-    _eq(d_out.get(), want, f"lap5 f32 {domain} v{variant} lit32={literal32}")
+    _eq(d_out.get(), want, f"lap5 f32 {domain} v{variant} lit32={literal32} aligned_index {align}")
 
 
 def test_lap5_known_answers():

@@ -1358,10 +1358,11 @@ def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
     L.append(f"    gt_tile({int(TUNING['shared_xcd_rows'])}u, gt_bx, gt_by, gt_bz);")
     L.append("    const int lane = threadIdx.x & 63;  // waves lie along I and overlap by the halo lanes")
     L.append(f"    const gt_i64 wave_x = (gt_i64)gt_bx * {block[0] // 64} + (threadIdx.x >> 6);")
-    L.append(f"    const gt_i64 i0 = (wave_x * {out_lanes} - {halo} + lane) * {vec};")
+    # a.lead: the origins lie `lead` items past a 16-byte boundary (see _emit_vector_kernel): the lanes start that far west
+    L.append(f"    const gt_i64 i0 = (wave_x * {out_lanes} - {halo} + lane) * {vec} - a.lead;")
     L.append("    const gt_i64 iend = a.dI, jend = a.dJ;")
     L.append(f"    const gt_i64 j0 = ((gt_i64)gt_by * {block[1]} + threadIdx.y) * {JT};")
-    L.append(f"    if (wave_x * {out_lanes * vec} >= iend || j0 >= jend) return;  // whole waves only: DPP needs every lane")
+    L.append(f"    if (wave_x * {out_lanes * vec} - a.lead >= iend || j0 >= jend) return;  // whole waves only: DPP needs every lane")
     L.append(f"    const bool out_lane = lane >= {halo} && lane < {64 - halo};")
     for n in globals_:
         c = _c_ident(n)
@@ -1487,17 +1488,17 @@ def _emit_shared_nest(em: "_Emitter", si: int, stage: Stage, nest: Nest, order, 
                 if obj.mask is not None:  # under a run-time `if`: point by point where the condition holds
                     L.append("        if (out_lane) {")
                     for v in range(vec):
-                        L.append(f"          if (i0 + {v} < iend && ({conds[v]})) ({ptr})[{v}] = {names[v]};")
+                        L.append(f"          if (i0 + {v} >= 0 && i0 + {v} < iend && ({conds[v]})) ({ptr})[{v}] = {names[v]};")
                     L.append("        }")
                     continue
                 store = (f"__builtin_nontemporal_store(gt_vec<{ct}, {vec}>{{{', '.join(names)}}}, reinterpret_cast<gt_vec<{ct}, {vec}>*>({ptr}))"
                          if tname in em.streaming else
                          f"*reinterpret_cast<gt_vec<{ct}, {vec}>*>({ptr}) = gt_vec<{ct}, {vec}>{{{', '.join(names)}}}")
                 L.append("        if (out_lane) {")
-                L.append(f"          if (i0 + {vec} <= iend) {store};")
+                L.append(f"          if (i0 >= 0 && i0 + {vec} <= iend) {store};")
                 L.append("          else {")
                 for v in range(vec):
-                    L.append(f"            if (i0 + {v} < iend) ({ptr})[{v}] = {names[v]};")
+                    L.append(f"            if (i0 + {v} >= 0 && i0 + {v} < iend) ({ptr})[{v}] = {names[v]};")
                 L.append("          }")
                 L.append("        }")
     finally:
@@ -1508,6 +1509,7 @@ def _emit_shared_nest(em: "_Emitter", si: int, stage: Stage, nest: Nest, order, 
     L.append("          if (j >= jend) break;")
     L.append(f"          for (int v = 0; v < {vec}; ++v) {{")
     L.append("            const gt_i64 i = i0 + v;")
+    L.append("            if (i < 0) continue;")
     L.append("            if (i >= iend) break;")
     for n in globals_:
         c = _c_ident(n)

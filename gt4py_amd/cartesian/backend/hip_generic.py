@@ -434,12 +434,12 @@ class HipGenericStencilObject(StencilObject):
                 return None
             nk = -(-levels // kern.k_per_thread) if kern.mapping == "ijk" else 1
             lanes = rows = 1
-            if sfn is not None and no_alias and (kern.shared_preferred or vfn is None) and all(
-                    geometry[n][0] % (kern.shared_vec * geometry[n][3]) == 0 and geometry[n][1] % kern.shared_vec == 0
-                    and geometry[n][2] % kern.shared_vec == 0 for n in kern.shared_fields):
+            if sfn is not None and no_alias and (kern.shared_preferred or vfn is None) and args.lead < kern.shared_vec and all(
+                    (geometry[n][0] - args.lead * geometry[n][3]) % (kern.shared_vec * geometry[n][3]) == 0
+                    and geometry[n][1] % kern.shared_vec == 0 and geometry[n][2] % kern.shared_vec == 0 for n in kern.shared_fields):
                 # temporaries shared between lanes: waves overlap by the halo lanes
                 per_wave = (64 - 2 * kern.shared_halo) * kern.shared_vec
-                grid = _U3(-(-ni // (per_wave * (kern.block[0] // 64))), -(-nj // (kern.block[1] * kern.shared_rows)), nk)
+                grid = _U3(-(-(ni + args.lead) // (per_wave * (kern.block[0] // 64))), -(-nj // (kern.block[1] * kern.shared_rows)), nk)
                 return sfn, grid, _U3(*kern.block)
             if vfn is not None and no_alias and args.lead < kern.vec and all(
                     (geometry[n][0] - args.lead * geometry[n][3]) % (kern.vec * geometry[n][3]) == 0 and geometry[n][1] % kern.vec == 0

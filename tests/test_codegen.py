@@ -177,7 +177,7 @@ def test_stages_with_inlined_temporaries_get_a_strip_kernel_that_shares_them(pro
         rows = 8 if vec == 4 else 4
         assert (kern.vec, kern.shared_halo, kern.shared_rows) == (vec, 1, rows), name  # inputs reach 2 columns: one halo lane
         src = prog.source[prog.source.index(f"gt4mi_{name}_stage0_vecs("):]
-        assert f"const gt_i64 i0 = (wave_x * 62 - 1 + lane) * {vec};" in src and "const bool out_lane = lane >= 1 && lane < 63;" in src
+        assert f"const gt_i64 i0 = (wave_x * 62 - 1 + lane) * {vec} - a.lead;" in src and "const bool out_lane = lane >= 1 && lane < 63;" in src
         # lap on rows -1 .. rows (rows + 2 of them, x vec components), each exactly once; the recomputing kernel derives
         # it per consumer
         laps = re.findall(r"const double (t_lap\w*?__v0_[mp]\d_\d) = ", src)
@@ -188,7 +188,7 @@ def test_stages_with_inlined_temporaries_get_a_strip_kernel_that_shares_them(pro
     hyper = programs["hyperdiffusion_6th"]
     assert [(k.vec, k.shared_vec, k.shared_halo) for k in hyper.kernels] == [(0, 2, 2)] and not hyper.plan.scratch
     assert len(hyper.plan.stages) == 1 and len(hyper.plan.stages[0].nests) == 2
-    assert "const gt_i64 i0 = (wave_x * 60 - 2 + lane) * 2;" in hyper.source
+    assert "const gt_i64 i0 = (wave_x * 60 - 2 + lane) * 2 - a.lead;" in hyper.source
     # the limiter written as if / else blocks: the conditionally assigned fluxes are selects, one stage, no scratch
     hd_if = programs["horizontal_diffusion_if"]
     assert len(hd_if.plan.stages) == 1 and not hd_if.plan.scratch and [(k.vec, k.shared_halo) for k in hd_if.kernels] == [(2, 1)]

@@ -74,12 +74,13 @@ def test_strided_layout_variant(name):
     assert (False, True) in type(hip)._gt_variants_
 
 
-@pytest.mark.parametrize("name", ["laplacian", "horizontal_diffusion", "horizontal_diffusion_f32", "if_with_offsets"])
+@pytest.mark.parametrize("name", ["laplacian", "horizontal_diffusion", "horizontal_diffusion_f32", "if_with_offsets",
+                                  "hyperdiffusion_6th", "horizontal_diffusion_if"])
 def test_misaligned_origin_falls_back_to_one_point_per_thread(name):
     """The 16-byte-lane kernels need every lane's vector naturally aligned.  An origin on an odd column (the array is
     aligned on column 0 instead) either starts the lanes of the `_vec` strip kernel that far before the domain (round 3:
-    `a.lead`; single-stage stencils whose arrays are all equally misaligned) or selects the scalar twin -- and all of
-    them must agree with the oracle."""
+    `a.lead`; single-stage stencils whose arrays are all equally misaligned; the `_vecs` kernels with temporaries shared
+    between lanes do the same) or selects the scalar twin -- and all of them must agree with the oracle."""
     import oracle.numpy_backend  # noqa: F401
     import gt4py_amd.storage as gt_storage
     from gt4py_amd.cartesian import gtscript
@@ -87,8 +88,7 @@ def test_misaligned_origin_falls_back_to_one_point_per_thread(name):
     defn, externals, scalars, opts = zoo.ZOO[name]
     ref = gtscript.stencil(backend="numpy", definition=defn, externals=externals)
     hip = gtscript.stencil(backend="hip:mi300", definition=defn, externals=externals, **opts)
-    domain = (37, 11, 5)
-    for shift in (1, 3):
+    for shift, domain in ((1, (37, 11, 5)), (3, (37, 11, 5)), (1, (130, 9, 3)), (2, (251, 10, 2))):  # one wave and several
         arrays, origins = zoo.make_inputs(ref, domain, seed=5)
         arrays = {k: np.pad(v, ((shift, 0), (0, 0), (0, 0))) for k, v in arrays.items()}
         origins = {k: (o[0] + shift, o[1], o[2]) for k, o in origins.items()}

@@ -280,6 +280,16 @@ def test_gloo_world_size_2_laplacian(grid, single_phase, tmp_path):
     assert nbytes > 0
 
 
+def test_gloo_world_size_8_laplacian_on_the_4x2_process_grid_single_phase(tmp_path):
+    """The north star's 512^3 decomposition (4 x 2) with eight real processes and the one-round message table (faces and
+    corners to every neighbour at once)."""
+    assert choose_process_grid(8, (512, 512, 512)) == (4, 2)
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, (4, 2), str(tmp_path), True), nprocs=8, join=True)
+    ok, nbytes = np.load(tmp_path / "ok.npy")
+    assert ok == 1 and nbytes > 0
+
+
 @pytest.mark.parametrize("grid,periodic", [((1, 8), (False, False)), ((4, 2), (False, False)), ((2, 2), (True, True)),
                                            ((1, 2), (False, True)), ((1, 1), (True, True)), ((2, 4), (True, False)),
                                            ((1, 4), (False, True))])
@@ -614,6 +624,16 @@ def _worker_hdiff_driver(rank: int, world: int, port: int, grid, tmpdir: str):
 def test_gloo_world_size_2_hdiff_drivers(grid, tmp_path):
     port = _free_port()
     mp.spawn(_worker_hdiff_driver, args=(2, port, grid, str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "ok.npy")[0] == 1
+
+
+def test_gloo_world_size_8_hdiff_on_the_4x2_process_grid(tmp_path):
+    """BASELINE.json configs[4]'s process grid with EIGHT real processes (gloo, CPU): every rank scatters its share of one
+    global field, exchanges faces and corners with its neighbours (interior ranks of the 4 x 2 grid have five of them), runs
+    the drivers, and the assembled result equals the oracle on the undecomposed field."""
+    assert choose_process_grid(8, (2048, 2048, 80)) == (4, 2)
+    port = _free_port()
+    mp.spawn(_worker_hdiff_driver, args=(8, port, (4, 2), str(tmp_path)), nprocs=8, join=True)
     assert np.load(tmp_path / "ok.npy")[0] == 1
 
 

@@ -36,6 +36,25 @@ def test_watchdog_rearm_and_disarm():
     assert proc.returncode == 0 and "alive" in proc.stdout
 
 
+def test_watchdog_prints_the_safe_line_and_exits_0_once_a_measurement_exists():
+    code = ("import os, sys, time; sys.path.insert(0, %r); import bench\n"
+            "dog = bench.Watchdog(0)\n"
+            "dog.safe = lambda reason: os.write(1, ('SAFE ' + reason + chr(10)).encode())\n"
+            "dog.arm(0.5, 'calibration of the overlapped forms')\n"
+            "time.sleep(60)\n") % str(ROOT)
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=50)
+    assert proc.returncode == 0
+    assert proc.stdout.startswith("SAFE phase 'calibration of the overlapped forms' ran past its")
+    assert "printed instead" in proc.stderr and "status 3" not in proc.stderr
+    # GT4MI_BENCH_DEADLINE_SCALE (tests only) shortens every deadline
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "dog = bench.Watchdog(0); dog.arm(50, 'x'); time.sleep(60)\n") % str(ROOT)
+    t0 = time.perf_counter()
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=50,
+                          env=dict(os.environ, GT4MI_BENCH_DEADLINE_SCALE="0.01"))
+    assert proc.returncode == 3 and time.perf_counter() - t0 < 30
+
+
 def test_committed_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     real = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())["lap5_f64_512"]
     assert set(real) >= {"bytes_per_launch", "kernel", "git_sha", "kernel_source_sha", "source"}

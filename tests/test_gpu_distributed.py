@@ -715,3 +715,38 @@ def test_bench_n_gpu_code_path_with_a_world_of_one(workload, tmp_path):
         assert {"timestep_glups", "timestep_ms_per_step", "pipelined_apply_glups"} <= set(line["extra"])
         assert line["config"]["mode"] == "apply" and line["config"]["halo_depth"] == 1
     assert "NATIVE RCCL TRANSPORT UNAVAILABLE" not in proc.stderr
+
+
+@pytest.mark.parametrize("workload,phase", [("lap512", "calibration"), ("hdiff2048", "calibration"), ("lap512", "informational")])
+def test_bench_prints_what_it_measured_when_a_later_phase_hangs(workload, phase, tmp_path):
+    """The first run on N > 1 devices tries forms that never ran between two devices.  Before it does, `bench.py` measures the
+    plainest form (exchange, then one launch) by the contract; a phase that then overruns its deadline -- simulated here:
+    GT4MI_BENCH_TEST_HANG -- ends the run with THAT line ("provisional", "deadline_exceeded"), status 0, instead of status 3
+    and no line.  After the headline is measured, a hanging informational section costs only itself."""
+    import json
+    import os
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, GT4MI_BENCH_FORCE_DISTRIBUTED="1", GT4MI_BENCH_TEST_HANG=phase, GT4MI_BENCH_DEADLINE_SCALE="0.1")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(root / "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2",
+                           "--workload", workload], env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["steps"] == 10 and line["warmup"] == 2 and line["roofline"]["frac"] > 0.3
+    assert "a hang simulated for the tests" in line["deadline_exceeded"] and "deadline of phase" in proc.stderr
+    assert line["rccl_nranks"] == 1 and line["transport_fallback"] is False
+    if phase == "calibration":
+        assert "sequential form" in line["provisional"] and line["config"]["transport"] == "native"
+        assert "sequential form" in line["config"]["workload"]
+    else:
+        assert "provisional" not in line and line["config"]["calibration_ms_per_apply"]

@@ -552,7 +552,7 @@ def _slowest_rank_ms(ctx, fn, calls: int, warm: int = 3) -> float:
 def measure_candidate(ctx, make, calls: int, warm: int = 3):
     """ms per call of one calibration candidate (slowest rank), or None when it cannot run on SOME rank -- then on no rank.
 
-    ``make()`` returns (callable, cleanup).  Building the candidate and its first calls happen without any collective, so a
+    ``make()`` returns (callable, cleanup) or (callable, cleanup, check).  Building the candidate and its first calls happen without any collective, so a
     rank on which they fail (an option this device / runtime refuses, a launch error) does not leave the others waiting in
     a barrier: every rank reports, all agree, and only candidates that work everywhere are timed.  One exotic candidate that
     fails must cost that candidate, not the native transport."""
@@ -561,11 +561,21 @@ def measure_candidate(ctx, make, calls: int, warm: int = 3):
     fn = cleanup = None
     ok = 1
     try:
-        fn, cleanup = make()
+        made = make()
+        fn, cleanup = made[0], made[1]
         for _ in range(warm):
             fn()
         if ctx.get("device", "cuda") == "cuda":
             torch.cuda.synchronize()
+        if len(made) > 2 and made[2] is not None:
+            # (fn, cleanup, check): check() -> (ok, what it found) runs the form once on fields whose correct outcome is known
+            # exactly (distributed.FormCheck); a form that is fast and wrong on some rank is dropped on every rank
+            good, found = made[2]()
+            ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
+            if not good:
+                ok = 0
+                ctx["forms_rejected"] = ctx.get("forms_rejected", 0) + 1
+                print(f"rank {ctx['rank']}: calibration candidate REJECTED, its results are wrong: {found}", file=sys.stderr)
     except Exception as ex:
         ok = 0
         print(f"rank {ctx['rank']}: calibration candidate failed ({ex!r})", file=sys.stderr)
@@ -690,7 +700,31 @@ def _setup_distributed_laplacian(args, ctx):
             bound[state["i"] % len(bound)]()
             state["i"] += 1
 
-        return call, (cdec, cpairs, cex, bound)
+        chk = form_check(cdec)
+        probe_apply = cex[0].make_dist_lap5(chk.probe, chk.out, cdec.origin, cdec.origin)
+
+        def check():
+            chk.reset()
+            probe_apply()
+            cex[0].end()
+            return chk.verdict()
+
+        return call, (cdec, cpairs, cex, bound, check)
+
+    checks = {}
+
+    def form_check(cdec):
+        """distributed.FormCheck of one process grid: fields whose correct outcome every rank knows exactly."""
+        key = cdec.grid
+        if key not in checks:
+            import gt4py_amd.storage as gt_storage
+            from gt4py_amd.distributed import FormCheck
+
+            cfrozen = lap.freeze(origin={"inp": cdec.origin, "out": cdec.origin}, domain=cdec.local_domain)
+            checks[key] = FormCheck(cdec, (lambda: gt_storage.zeros(cdec.local_shape, np.float64, backend="hip:mi300",
+                                                                    aligned_index=cdec.origin)),
+                                    (lambda a, b: cfrozen(inp=a, out=b)))
+        return checks[key]
 
     if transport == "native" and callable(ctx.get("provisional")):
         # Before anything that has never run between two devices is tried (the fused applies, their schedules, the other
@@ -720,6 +754,14 @@ def _setup_distributed_laplacian(args, ctx):
                        "halo_depth": 1, "halo_bytes_per_rank_per_exchange": pex[0].bytes_per_exchange,
                        "message_table": "two-phase (I faces, then J faces with the fresh I-halo columns)", "transport": "native",
                        "mode": "apply", "selfloop": bool(selfloop), "exchange_overlapped_with_interior": False}
+            chk = form_check(pdec)  # first of all: is what it computes right?  (fields whose correct outcome is known exactly)
+            chk.reset()
+            pex[0].exchange(chk.probe)
+            pfrozen(inp=chk.probe, out=chk.out)
+            good, found = chk.verdict()
+            ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
+            if not good:
+                raise RuntimeError("wrong results: " + found)
             ctx["provisional"](pstep, pkernel, pdec.local_domain, float(np.prod(pdec.global_domain)), pconfig, proof)
             for ex in pex:
                 ex.close()
@@ -746,7 +788,7 @@ def _setup_distributed_laplacian(args, ctx):
                         for cand_wg in (0, 4, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
                             def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg):
                                 call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg)
-                                return call, (lambda: [ex.close() for ex in keep[2]])
+                                return call, (lambda: [ex.close() for ex in keep[2]]), keep[4]
 
                             key = (f"{cand_grid[0]}x{cand_grid[1]}_{'single' if cand_single else 'two'}phase_{cand_schedule}"
                                    f"_wg{cand_wg}")
@@ -771,9 +813,12 @@ def _setup_distributed_laplacian(args, ctx):
     local_domain = dec.local_domain
     frozen = lap.freeze(origin=origin, domain=local_domain)
     stepper_state = {}
+    headline_verdict = None
     if transport == "native" and mode == "apply":
         call, keep = apply_candidate(grid, single_phase, schedule, wg_per_cu)
         pairs, exchangers = keep[1], keep[2]
+        headline_verdict = keep[4]()  # the form that is about to be timed, checked once more
+        ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
 
         def step(i):
             call()
@@ -802,6 +847,24 @@ def _setup_distributed_laplacian(args, ctx):
         def step(i):
             inp, out = pairs[i % len(pairs)]
             overlapped_apply(lap, dec, origin, {"inp": inp, "out": out}, {"inp": exchangers[i % len(pairs)]})
+
+        chk = form_check(dec)
+        chk.reset()
+        overlapped_apply(lap, dec, origin, {"inp": chk.probe, "out": chk.out}, {"inp": exchangers[0]})
+        headline_verdict = chk.verdict()
+        ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
+
+    verified = None
+    if headline_verdict is not None:
+        everywhere = bool(_agree(ctx, 1 if headline_verdict[0] else 0))
+        if not everywhere:
+            print(f"rank {rank}: THE TIMED FORM GIVES WRONG RESULTS on at least one rank (here: {headline_verdict[1]})", file=sys.stderr)
+        verified = {"headline_form_correct_on_every_rank": everywhere, "forms_checked": ctx.get("forms_checked", 0),
+                    "forms_rejected": ctx.get("forms_rejected", 0), "ghost_cells_checked_on_rank_0": form_check(dec).ghost_cells_to_fill,
+                    "how": "every form is run once on a field whose own points hold an exact function of the GLOBAL coordinates and "
+                           "whose ghost cells hold a sentinel: afterwards every cell must equal that function (or still the sentinel "
+                           "beyond a physical boundary) and the result must equal the local kernel applied to the exactly known input, "
+                           "bit for bit, on every rank (gt4py_amd/distributed/selfcheck.py); wrong forms are dropped from the calibration"}
 
     def kernel_step(i):  # the local kernel alone, for the per-GPU roofline figure
         inp, out = pairs[i % len(pairs)]
@@ -891,7 +954,7 @@ def _setup_distributed_laplacian(args, ctx):
               "transport": transport, "mode": mode if transport == "native" else "apply", "selfloop": bool(selfloop),
               "exchange_overlapped_with_interior": True,
               "schedule": schedule if transport == "native" else "join", "interior_workgroups_per_cu": wg_per_cu,
-              "calibration_ms_per_apply": calibration}
+              "calibration_ms_per_apply": calibration, "verified": verified}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
               "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback}
     return step, kernel_step, dec.local_domain, config, extras
@@ -934,6 +997,7 @@ def _setup_hdiff2048(args, ctx):
     decomposed = distributed or selfloop
     transport, comm, proof, exchangers, fallback = "none", None, None, [], False
     timings, choice = None, "single launch"
+    headline_verdict, verified, ghost_cells = None, None, 0
     if decomposed:
         transport = os.environ.get("GT4MI_BENCH_COMM", "native")
         if transport == "native":
@@ -952,19 +1016,48 @@ def _setup_hdiff2048(args, ctx):
                 the caller's hardware queue and those forms run serialised (0.27 ms instead of 0.21, seen with 72 plans)."""
                 parts = name.split("_")
                 single = parts[1] == "single"
+                chk = form_check()
                 if parts[0] == "sequential":
                     ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single)
-                    return (lambda: sequential_apply(hd, dec, origin, fields, {"in_field": ex})), ex
-                ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(parts[3], int(parts[4][2:]),
-                                                                                          edge_columns=int(parts[5][4:]))
-                return ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags), ex
+                    probe_fields = {"in_field": chk.probe, "out_field": chk.out, "coeff": fields["coeff"]}
+                    probe_apply = lambda: sequential_apply(hd, dec, origin, probe_fields, {"in_field": ex})  # noqa: E731
+                    fn = lambda: sequential_apply(hd, dec, origin, fields, {"in_field": ex})  # noqa: E731
+                else:
+                    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(parts[3], int(parts[4][2:]),
+                                                                                              edge_columns=int(parts[5][4:]))
+                    probe_apply = ex.make_dist_hdiff(chk.probe, chk.out, fields["coeff"], dec.origin, flags)
+                    fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
+
+                def check():
+                    chk.reset()
+                    probe_apply()
+                    ex.end()
+                    return chk.verdict()
+
+                return fn, ex, check
+
+            checks = []
+
+            def form_check():
+                """distributed.FormCheck on this rank's share: fields whose correct outcome every rank knows exactly."""
+                if not checks:
+                    from gt4py_amd.distributed import FormCheck
+
+                    checks.append(FormCheck(dec, (lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300",
+                                                                           aligned_index=dec.origin)),
+                                            (lambda a, b: frozen(in_field=a, out_field=b, coeff=fields["coeff"]))))
+                return checks[0]
 
             if callable(ctx.get("provisional")):
                 # the plainest form first, measured by the contract and kept as the line to print should a later phase hang
                 # (see _setup_distributed_laplacian)
                 ok = 1
                 try:
-                    pfn, pex = make_form("sequential_two_phase")
+                    pfn, pex, pcheck = make_form("sequential_two_phase")
+                    good, found = pcheck()  # first of all: is what it computes right?
+                    ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
+                    if not good:
+                        raise RuntimeError("wrong results: " + found)
                     pconfig = {"workload": "BASELINE.json configs[4]: fp64 horizontal diffusion (lap-of-lap + flux limiter), "
                                            f"{HDIFF_SHARE[0]}x{HDIFF_SHARE[1]}x{HDIFF_SHARE[2]} per rank (weak scaling; 8 ranks = "
                                            "2048x2048x80 on the 4x2 grid), ghost depth 2, in_field's ghost cells exchanged before "
@@ -995,8 +1088,8 @@ def _setup_hdiff2048(args, ctx):
                     for name in names:
                         if pinned is None or pinned == name:
                             def make(name=name):
-                                fn, ex = make_form(name)
-                                return fn, ex.close
+                                fn, ex, check = make_form(name)
+                                return fn, ex.close, check
 
                             ms = measure_candidate(ctx, make, 16)
                             if ms is not None:
@@ -1009,7 +1102,9 @@ def _setup_hdiff2048(args, ctx):
                     transport_fallback_banner(rank, "the native halo exchange failed during calibration")
                 else:
                     choice = min(timings, key=timings.get)
-                    chosen, ex = make_form(choice)
+                    chosen, ex, check = make_form(choice)
+                    headline_verdict = check()  # the form that is about to be timed, checked once more
+                    ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
                     exchangers = [ex]  # the one the line describes
 
                     def step(i):
@@ -1020,6 +1115,28 @@ def _setup_hdiff2048(args, ctx):
 
             def step(i):
                 overlapped_apply(hd, dec, origin, fields, {"in_field": ex})
+
+            from gt4py_amd.distributed import FormCheck
+
+            chk = FormCheck(dec, (lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin)),
+                            (lambda a, b: frozen(in_field=a, out_field=b, coeff=fields["coeff"])))
+            chk.reset()
+            overlapped_apply(hd, dec, origin, {"in_field": chk.probe, "out_field": chk.out, "coeff": fields["coeff"]}, {"in_field": ex})
+            headline_verdict = chk.verdict()
+            ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
+            ghost_cells = chk.ghost_cells_to_fill
+            del chk
+        elif checks:
+            ghost_cells = checks[0].ghost_cells_to_fill
+        if headline_verdict is not None:
+            everywhere = bool(_agree(ctx, 1 if headline_verdict[0] else 0))
+            if not everywhere:
+                print(f"rank {rank}: THE TIMED FORM GIVES WRONG RESULTS on at least one rank (here: {headline_verdict[1]})", file=sys.stderr)
+            verified = {"headline_form_correct_on_every_rank": everywhere, "forms_checked": ctx.get("forms_checked", 0),
+                        "forms_rejected": ctx.get("forms_rejected", 0), "ghost_cells_checked_on_rank_0": ghost_cells,
+                        "how": "see gt4py_amd/distributed/selfcheck.py: every form is run once on a field that holds an exact function "
+                               "of the GLOBAL coordinates (ghost cells: a sentinel); every cell and every point of the result must then "
+                               "be the known one, bit for bit, on every rank; wrong forms are dropped from the calibration"}
     else:
         def step(i):
             frozen(**fields)
@@ -1060,7 +1177,7 @@ def _setup_hdiff2048(args, ctx):
               "grid": list(total), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(dec.local_domain),
               "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange if exchangers else 0,
               "transport": transport, "selfloop": bool(selfloop), "apply_form": choice,
-              "calibration_ms_per_apply": timings}
+              "calibration_ms_per_apply": timings, "verified": verified}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen),
               "proof": proof, "transport_fallback": fallback, "timestep": pipelined_applies if decomposed else None}
     return step, kernel_step, dec.local_domain, config, extras

@@ -10,9 +10,10 @@ from typing import Any, Dict, Mapping, Sequence
 from .halo import (Decomposition, HaloExchanger, HipPacker, choose_process_grid, exchange_cost, halo_boxes, halo_sides,
                    process_grid_candidates, receive_order, scatter_global)
 from .native import NativeComm, NativeHaloExchanger
+from .selfcheck import FormCheck, coordinate_values, count_wrong_cells
 
-__all__ = ["Decomposition", "HaloExchanger", "HipPacker", "NativeComm", "NativeHaloExchanger", "TunedApply",
-           "choose_process_grid", "exchange_cost", "fused_apply", "halo_boxes", "halo_sides", "overlapped_apply",
+__all__ = ["Decomposition", "FormCheck", "HaloExchanger", "HipPacker", "NativeComm", "NativeHaloExchanger", "TunedApply",
+           "choose_process_grid", "coordinate_values", "count_wrong_cells", "exchange_cost", "fused_apply", "halo_boxes", "halo_sides", "overlapped_apply",
            "process_grid_candidates", "receive_order", "scatter_global", "sequential_apply"]
 
 

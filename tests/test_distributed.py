@@ -258,6 +258,18 @@ def _worker(rank: int, world: int, port: int, grid, tmpdir: str, single_phase: b
         for sh, dom in [(shift, sub)] + strips:
             org = tuple(o + s for o, s in zip(dec.origin, sh))
             R.laplacian(blk, out, origin_inp=org, origin_out=org, domain=dom)
+        # the gather-free self-check bench.py runs before it reports an N > 1 number (distributed/selfcheck.py)
+        from gt4py_amd.distributed.selfcheck import coordinate_values, count_wrong_cells
+
+        cut = (grid[0] > 1, grid[1] > 1)  # (gloo cannot send to the rank itself: periodic along the cut axes only)
+        for pdec in (dec, Decomposition(gd, grid, rank, 2, periodic=cut), Decomposition(gd, grid, rank, 1, periodic=cut)):
+            own, _ = coordinate_values(pdec)
+            before = count_wrong_cells(pdec, own)
+            HaloExchanger(pdec, torch.float64, "cpu", packer=TorchSlicePacker(), single_phase=single_phase).exchange(own)
+            after = count_wrong_cells(pdec, own)
+            assert before[0] == before[1] > 0 and after == (0, before[1]), (rank, pdec.periodic, before, after)
+            own[0, 0, 0] += 1.0  # a single wrong ghost cell is seen
+            assert count_wrong_cells(pdec, own)[0] == 1
         gathered = [None] * world
         dist.all_gather_object(gathered, (dec.global_slices(with_halo=False), out[h:-h, h:-h], ex.bytes_per_exchange))
         if rank == 0:

@@ -711,6 +711,9 @@ def test_bench_n_gpu_code_path_with_a_world_of_one(workload, tmp_path):
     assert line["rccl_nranks"] == 1 and line["rank_devices"] == [[0, 0]] and line["rccl_matches_n_gpus"] is True
     assert line["transport_fallback"] is False and line["config"]["transport"] == "native"
     assert line["config"]["calibration_ms_per_apply"] and "extra" in line
+    verified = line["config"]["verified"]  # every calibrated form reproduced the exactly known outcome (distributed/selfcheck.py)
+    assert verified["headline_form_correct_on_every_rank"] is True and verified["forms_rejected"] == 0
+    assert verified["forms_checked"] >= len(line["config"]["calibration_ms_per_apply"]) + 2 and verified["ghost_cells_checked_on_rank_0"] == 0
     if workload == "lap512":
         assert {"timestep_glups", "timestep_ms_per_step", "pipelined_apply_glups"} <= set(line["extra"])
         assert line["config"]["mode"] == "apply" and line["config"]["halo_depth"] == 1
@@ -750,3 +753,49 @@ def test_bench_prints_what_it_measured_when_a_later_phase_hangs(workload, phase,
         assert "sequential form" in line["config"]["workload"]
     else:
         assert "provisional" not in line and line["config"]["calibration_ms_per_apply"]
+
+
+@pytest.mark.parametrize("periodic,halo", [((True, True), 1), ((False, True), 1), ((True, True), 2)])
+def test_form_check_accepts_the_fused_applies_and_sees_a_form_that_reads_ghost_cells_too_early(periodic, halo):
+    """distributed.FormCheck (what bench.py runs on every rank before it trusts a form of the distributed apply): the fused
+    applies pass on the self-loop; a form that skips the exchange, and one that computes the ring BEFORE the exchange has
+    delivered (every ghost cell correct by the time anybody looks, the result not), are both seen."""
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.distributed import Decomposition, FormCheck, NativeComm, NativeHaloExchanger
+
+    dec = Decomposition((96, 40, 6), (1, 1), 0, halo=halo, periodic=periodic)
+    new = lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin)  # noqa: E731
+    comm = NativeComm(rank=0, world_size=1)
+    ex = NativeHaloExchanger(dec, np.float64, comm)
+    if halo == 1:
+        st = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64})
+        fr = st.freeze(origin={"inp": dec.origin, "out": dec.origin}, domain=dec.local_domain)
+        local = lambda a, b: fr(inp=a, out=b)  # noqa: E731
+    else:
+        st = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64})
+        coeff = new()
+        coeff.tensor.fill_(0.025)
+        fr = st.freeze(origin={n: dec.origin for n in ("in_field", "out_field", "coeff")}, domain=dec.local_domain)
+        local = lambda a, b: fr(in_field=a, out_field=b, coeff=coeff)  # noqa: E731
+    chk = FormCheck(dec, new, local)
+    assert chk.ghost_cells_to_fill > 0
+    for schedule in ("join", "chain"):
+        ex.tune(schedule, 0)
+        fused = (ex.make_dist_lap5(chk.probe, chk.out, dec.origin, dec.origin) if halo == 1 else
+                 ex.make_dist_hdiff(chk.probe, chk.out, coeff, dec.origin, type(st)._gt_binding_.flags))
+        chk.reset()
+        fused()
+        ex.end()
+        assert chk.verdict()[0], (schedule, chk.verdict()[1])
+    chk.reset()  # no exchange at all
+    local(chk.probe, chk.out)
+    ok, found = chk.verdict()
+    assert not ok and f"{chk.ghost_cells_to_fill} cells of the exchanged field differ" in found
+    chk.reset()  # the kernel first, the exchange afterwards: every cell is right in the end, the ring of the result is not
+    local(chk.probe, chk.out)
+    ex.exchange(chk.probe)
+    ok, found = chk.verdict()
+    assert not ok and found.startswith("0 cells of the exchanged field differ") and ", 0 points of the result" not in found
+    ex.close()

@@ -127,7 +127,8 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
         gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 2)));
         return gt4mi::hdiff_run<T>(sub, &a, &b, coeff ? &c : nullptr, coeff_scalar, flags, ms);
     };
-    if (gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_CHAIN) == GT4MI_SCHEDULE_CHAIN) {
+    if (gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_CHAIN) != GT4MI_SCHEDULE_JOIN) {  // (GT4MI_SCHEDULE_SWAP: as chain -- here the
+        // interior kernel is the critical path and stays on the caller's stream)
         // Schedule "chain": the main stream carries NOTHING but the interior kernel; pack -> send/recv -> unpack -> ring run
         // in order on the side stream (the ring writes out_field's ring, the interior its interior).  No cross-stream wait
         // lies on the critical path: the join after the interior is already satisfied when the chain fits under it, and
@@ -386,7 +387,7 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
     if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: null plan");
     switch (option) {
         case GT4MI_PLAN_SCHEDULE:
-            if (value < -1 || value > GT4MI_SCHEDULE_CHAIN) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
+            if (value < -1 || value > GT4MI_SCHEDULE_SWAP) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
             plan->schedule = value;
             return GT4MI_OK;
         case GT4MI_PLAN_EDGE_COLUMNS:
@@ -475,28 +476,42 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
     if (di < 16 * EW) EW = di >= 64 ? (EW < 8 ? EW : 8) : 1;  // narrow local domains keep most of their columns in the interior
     const int64_t lo_i = (sides & 1) ? EW : 0, hi_i = (sides & 2) ? EW : 0;
     const int64_t lo_j = (sides & 4) ? 1 : 0, hi_j = (sides & 8) ? 1 : 0;
-    auto run = [&](int64_t si, int64_t sj, int64_t ei, int64_t ej) -> int {
+    auto run = [&](int64_t si, int64_t sj, int64_t ei, int64_t ej, hipStream_t st) -> int {
         if (ei <= 0 || ej <= 0 || dk <= 0) return GT4MI_OK;
         gt4mi_field a = *inp, b = *out;
         a.origin[0] += si; a.origin[1] += sj;
         b.origin[0] += si; b.origin[1] += sj;
         const int64_t d[3] = {ei, ej, dk};
-        return gt4mi::lap5_run<double, double>(d, &a, &b, variant, ms);
+        return gt4mi::lap5_run<double, double>(d, &a, &b, variant, st);
     };
     const int outer[4] = {0, 0, 0, 0};
     const int inner[4] = {(int)(lo_i <= di ? lo_i : di), (int)(hi_i && di - hi_i >= lo_i ? hi_i : 0), (int)lo_j,
                           (int)(hi_j && dj - 1 >= lo_j ? 1 : 0)};
-    auto interior = [&]() -> int {
+    auto interior = [&](hipStream_t st) -> int {
         gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 0)));
-        return run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j);
+        return run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j, st);
     };
-    if (gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_JOIN) == GT4MI_SCHEDULE_CHAIN) {
+    const int schedule = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_JOIN);
+    if (schedule == GT4MI_SCHEDULE_SWAP) {
+        // the CALLER's stream carries the chain pack -> send/recv -> unpack -> ring (no cross-stream wait inside it, and it
+        // starts at once); the interior kernel runs beside it on the side stream; the caller joins the interior at the end
+        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
+        GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+        GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+        if (int rc = interior(plan->stream)) return rc;
+        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
+        if (int rc = gt4mi::halo_exchange_on(plan, inp, ms)) return rc;
+        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, ms)) return rc;
+        return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
+    }
+    if (schedule == GT4MI_SCHEDULE_CHAIN) {
         // the main stream carries the interior kernel only; pack -> send/recv -> unpack -> ring in order on the side stream
         // (see dist_hdiff)
         if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
         GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
         GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-        if (int rc = interior()) return rc;
+        if (int rc = interior(ms)) return rc;
         if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream)) return rc;
         if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, plan->stream)) return rc;
         GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
@@ -511,7 +526,7 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
     GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
     GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
     // 2. main stream: interior, independent of the ghost cells in flight
-    if (int rc = interior()) return rc;
+    if (int rc = interior(ms)) return rc;
     // 3. side stream: RCCL send/recv + unpack (+ second phase), concurrent with the interior kernel
     if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/true)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));

@@ -784,7 +784,7 @@ def _setup_distributed_laplacian(args, ctx):
             grids = [grid] if (selfloop or pinned_grid) else process_grid_candidates(world, total, 1)
             for cand_grid in grids:
                 for cand_single in ((single_phase,) if "GT4MI_BENCH_SINGLE_PHASE" in os.environ else (False, True)):
-                    for cand_schedule in ("join", "chain", "swap"):
+                    for cand_schedule in ("join", "chain", "swap", "swap-packed"):
                         for cand_wg in (0, 4, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
                             def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg):
                                 call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg)

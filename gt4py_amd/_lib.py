@@ -80,7 +80,7 @@ LAP_NOTEBOOK, LAP_DOCS, LAP_SUITE, LAP_AVG = 0, 1, 2, 3
 LAP_LITERAL_F32 = 1
 # gt4mi_halo_plan_set_option
 PLAN_SCHEDULE, PLAN_INTERIOR_WG_PER_CU, PLAN_DEFER_JOIN, PLAN_EDGE_COLUMNS = 0, 1, 2, 3
-SCHEDULE_JOIN, SCHEDULE_CHAIN, SCHEDULE_SWAP = 0, 1, 2
+SCHEDULE_JOIN, SCHEDULE_CHAIN, SCHEDULE_SWAP, SCHEDULE_SWAP_PACKED = 0, 1, 2, 3
 # hdiff flags
 HDIFF_LIMITER, HDIFF_INTERNAL_F32, HDIFF_COEFF_F32 = 1, 2, 4
 

@@ -387,7 +387,7 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
     if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: null plan");
     switch (option) {
         case GT4MI_PLAN_SCHEDULE:
-            if (value < -1 || value > GT4MI_SCHEDULE_SWAP) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
+            if (value < -1 || value > GT4MI_SCHEDULE_SWAP_PACKED) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
             plan->schedule = value;
             return GT4MI_OK;
         case GT4MI_PLAN_EDGE_COLUMNS:
@@ -492,16 +492,28 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
         return run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j, st);
     };
     const int schedule = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_JOIN);
-    if (schedule == GT4MI_SCHEDULE_SWAP) {
+    if (schedule == GT4MI_SCHEDULE_SWAP || schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
         // the CALLER's stream carries the chain pack -> send/recv -> unpack -> ring (no cross-stream wait inside it, and it
         // starts at once); the interior kernel runs beside it on the side stream; the caller joins the interior at the end
         if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
-        GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
-        GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-        if (int rc = interior(plan->stream)) return rc;
-        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-        plan->done_recorded = true;
-        if (int rc = gt4mi::halo_exchange_on(plan, inp, ms)) return rc;
+        if (schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
+            // ... and the interior kernel forks off AFTER the pack: the send/recv kernel gets a head start on the interior's
+            // ramp-up and the pack of strided I faces (8-10 us next to the interior) runs alone
+            if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+            GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+            if (int rc = gt4mi::halo_exchange_on(plan, inp, ms, /*first_pack_done=*/true)) return rc;
+            if (int rc = interior(plan->stream)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+            plan->done_recorded = true;
+        } else {
+            GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+            GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+            if (int rc = interior(plan->stream)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+            plan->done_recorded = true;
+            if (int rc = gt4mi::halo_exchange_on(plan, inp, ms)) return rc;
+        }
         if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, ms)) return rc;
         return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
     }

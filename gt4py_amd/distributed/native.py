@@ -143,12 +143,14 @@ class NativeHaloExchanger:
         """How the fused distributed steps built on this exchanger are scheduled (gt4mi_halo_plan_set_option):
         ``schedule`` "join" (pack and interior on the caller's stream, send/recv/unpack beside it, join, ring), "chain"
         (the caller's stream carries the interior only; pack, send/recv, unpack and ring in order on the side stream) or
-        "swap" (the Laplacian step: that chain on the caller's stream, the interior kernel on the side stream);
+        "swap" (the Laplacian step: that chain on the caller's stream, the interior kernel on the side stream; "swap-packed":
+        the interior forks off after the pack);
         ``interior_wg_per_cu`` limits the occupancy of the interior kernel while the exchange runs next to it (0 = no
         limit); ``defer_join`` (chain schedule) lets a fused step return without joining the side stream -- for INDEPENDENT
         applies, whose results the caller consumes only after ``end()``.  ``None`` leaves an option as it is."""
         if schedule is not None:
-            value = {"join": _lib.SCHEDULE_JOIN, "chain": _lib.SCHEDULE_CHAIN, "swap": _lib.SCHEDULE_SWAP, "default": -1}[schedule]
+            value = {"join": _lib.SCHEDULE_JOIN, "chain": _lib.SCHEDULE_CHAIN, "swap": _lib.SCHEDULE_SWAP, "swap-packed": _lib.SCHEDULE_SWAP_PACKED,
+                     "default": -1}[schedule]
             _lib.check("gt4mi_halo_plan_set_option", self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_SCHEDULE, value))
         if interior_wg_per_cu is not None:
             _lib.check("gt4mi_halo_plan_set_option",

@@ -194,6 +194,8 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *                                   GT4MI_SCHEDULE_SWAP (gt4mi_dist_lap5_f64; elsewhere = chain): main: pack, send/recv, unpack,
  *                                   ring back to back;  side: the interior kernel; the caller's stream joins the interior at
  *                                   the end -- for shares so small that the chain, not the interior, is the critical path
+ *                                   GT4MI_SCHEDULE_SWAP_PACKED: the same, the interior kernel forking off AFTER the pack (the
+ *                                   pack of strided I faces runs alone, the send/recv kernel starts ahead of the interior)
  *   GT4MI_PLAN_INTERIOR_WG_PER_CU   at most this many workgroups of the INTERIOR kernel per CU while the exchange runs
  *                                   next to it (0 = no limit): an HBM-saturating kernel at full occupancy keeps tens of MB
  *                                   in flight and the send/recv kernel beside it waits ~10 us per memory access
@@ -208,7 +210,7 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *                                   interior kernel keeps its 16-byte alignment
  * Which combination is fastest depends on the links; bench.py measures them (config.calibration_ms_per_apply). */
 enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1, GT4MI_PLAN_DEFER_JOIN = 2, GT4MI_PLAN_EDGE_COLUMNS = 3 };
-enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1, GT4MI_SCHEDULE_SWAP = 2 };
+enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1, GT4MI_SCHEDULE_SWAP = 2, GT4MI_SCHEDULE_SWAP_PACKED = 3 };
 int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value);
 /* 1 = the plan's side stream was verified to run concurrently with the caller's stream, 0 = no
  * concurrent stream could be found (the exchange still works, serialised), 2 = not probed yet.

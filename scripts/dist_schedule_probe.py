@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Exchange-per-apply Laplacian step on the 1-GPU self-loop, shares of 8 ranks (1x8, 2x4, 4x2): us per apply for every message table x
+schedule (join / chain / swap) x interior throttle -- the sweep behind DESIGN.md section 6's "swap" paragraph."""
 import sys, time, pathlib
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))

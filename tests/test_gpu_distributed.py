@@ -63,7 +63,7 @@ def test_periodic_self_exchange(comm, dtype, periodic, halo):
 
 
 @pytest.mark.parametrize("edge_columns,schedule", [(None, None), (1, "join"), (8, "chain"), (16, "chain"), (6, "join"), (8, "swap"),
-                                                   (16, "swap"), (1, "swap")])
+                                                   (16, "swap"), (1, "swap"), (8, "swap-packed"), (16, "swap-packed")])
 @pytest.mark.parametrize("periodic", [(True, True), (False, True), (True, False)])
 def test_fused_distributed_laplacian_step(comm, periodic, edge_columns, schedule):
     """gt4mi_dist_lap5_f64 (exchange || interior, then the ring) == oracle Laplacian on the wrapped field, for every width
@@ -553,7 +553,7 @@ def test_baseline_config4_share_through_the_fused_native_step(comm, single_phase
     ex.close()
 
 
-@pytest.mark.parametrize("schedule", ["join", "chain", "swap"])
+@pytest.mark.parametrize("schedule", ["join", "chain", "swap", "swap-packed"])
 def test_fused_laplacian_step_is_complete_in_stream_order_when_the_interior_is_longer(comm, schedule):
     """The other way round: a big interior next to small faces.  Whatever stream a schedule puts the interior kernel on (the
     side stream in "swap"), work the caller enqueues after the step on ITS stream -- here a copy of the result, no device
@@ -603,7 +603,7 @@ def test_fused_laplacian_step_is_complete_in_stream_order_when_the_interior_is_l
     ex.close()
 
 
-@pytest.mark.parametrize("schedule", ["join", "chain", "swap"])
+@pytest.mark.parametrize("schedule", ["join", "chain", "swap", "swap-packed"])
 @pytest.mark.parametrize("stencil", ["lap5", "hdiff"])
 def test_fused_steps_wait_for_the_exchange_when_the_interior_is_shorter(comm, stencil, schedule):
     """A flat, wide local domain: the interior kernel (a few rows) finishes long before the 1-2 MB faces have travelled, so a
@@ -832,7 +832,7 @@ def test_form_check_accepts_the_fused_applies_and_sees_a_form_that_reads_ghost_c
         local = lambda a, b: fr(in_field=a, out_field=b, coeff=coeff)  # noqa: E731
     chk = FormCheck(dec, new, local)
     assert chk.ghost_cells_to_fill > 0
-    for schedule in ("join", "chain", "swap"):
+    for schedule in ("join", "chain", "swap", "swap-packed"):
         ex.tune(schedule, 0)
         fused = (ex.make_dist_lap5(chk.probe, chk.out, dec.origin, dec.origin) if halo == 1 else
                  ex.make_dist_hdiff(chk.probe, chk.out, coeff, dec.origin, type(st)._gt_binding_.flags))

@@ -111,7 +111,7 @@ struct gt4mi_halo_plan {
     bool primed = false;                  // the exchange of a stepper's first input was started (gt4mi_halo_exchange_begin)
     bool done_recorded = false;           // `done` has been recorded at least once: gt4mi_halo_exchange_end has something to wait for
     // how the fused distributed steps are scheduled (gt4mi_halo_plan_set_option); -1 = the entry point's own default
-    int schedule = -1;            // GT4MI_SCHEDULE_JOIN / GT4MI_SCHEDULE_CHAIN
+    int schedule = -1;            // GT4MI_SCHEDULE_JOIN / _CHAIN / _SWAP / _SWAP_PACKED
     int interior_wg_per_cu = -1;  // occupancy limit of the interior kernel while the exchange runs next to it (0 = none)
     int edge_columns = -1;        // width of the W / E boxes a fused hdiff step leaves to the ring kernel (-1: default)
     int defer_join = 0;           // chain schedule: leave the final join to gt4mi_halo_exchange_end (independent applies)

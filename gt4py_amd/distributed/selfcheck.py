@@ -95,3 +95,122 @@ class FormCheck:
         return ok, (f"{wrong_cells} cells of the exchanged field differ from F(global coordinates) "
                     f"({self.ghost_cells_to_fill} ghost cells to fill), {wrong_out} points of the result differ from the "
                     f"local kernel on the exactly known input")
+
+
+def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("native", "torch"), out=None) -> int:
+    """The exchange and every fused distributed apply, checked on exactly known fields on every rank of the job (or, with
+    ``periodic``, of a world of one rank whose neighbours are the rank itself).  Launch one process per GPU
+    (``python -m torch.distributed.run --nproc-per-node N -m gt4py_amd.distributed``); returns the number of failed
+    checks over all ranks, rank 0 prints the table."""
+    import os
+    import sys
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+
+    from . import HaloExchanger, NativeComm, NativeHaloExchanger, choose_process_grid, overlapped_apply, sequential_apply
+
+    out = out or sys.stdout
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    started_group = False
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():  # (launched by torch.distributed.run, any world size)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        started_group = True
+    results = []  # (name, ok, detail)
+    if "torch" in transports and not dist.is_initialized():  # (the torch transport needs a process group, also to talk to itself)
+        transports = tuple(t for t in transports if t != "torch")
+    comm = NativeComm() if "native" in transports else None
+    lap = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64})
+    hd = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64})
+    try:
+        for halo in (1, 2):
+            grid = choose_process_grid(world, domain, halo)
+            wrap = (periodic or False, periodic or False)
+            dec = Decomposition(tuple(domain), grid, rank, halo, periodic=wrap)
+            new = lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin)  # noqa: E731
+            if halo == 1:
+                fr = lap.freeze(origin={"inp": dec.origin, "out": dec.origin}, domain=dec.local_domain)
+                local = lambda a, b: fr(inp=a, out=b)  # noqa: E731
+                names, stencil = ("inp", "out"), lap
+                extra = {}
+            else:
+                coeff = new()
+                coeff.tensor.fill_(0.025)
+                fr = hd.freeze(origin={n: dec.origin for n in ("in_field", "out_field", "coeff")}, domain=dec.local_domain)
+                local = lambda a, b: fr(in_field=a, out_field=b, coeff=coeff)  # noqa: E731
+                names, stencil = ("in_field", "out_field"), hd
+                extra = {"coeff": coeff}
+            chk = FormCheck(dec, new, local)
+            origin = {n: dec.origin for n in names + tuple(extra)}
+
+            def record(name, run):
+                chk.reset()
+                try:
+                    run()
+                    ok, detail = chk.verdict()
+                except Exception as ex:  # noqa: BLE001 - a failing form is a result, not the end of the check
+                    ok, detail = False, repr(ex)
+                results.append((f"halo {halo} grid {grid[0]}x{grid[1]} {name}", ok, detail))
+
+            for single in (False, True):
+                table = "single-phase" if single else "two-phase"
+                fields = {names[0]: chk.probe, names[1]: chk.out, **extra}
+                if "torch" in transports:
+                    ex = HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank), single_phase=single)
+                    record(f"torch {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: ex}))
+                    record(f"torch {table} overlapped", lambda: overlapped_apply(stencil, dec, origin, fields, {names[0]: ex}))
+                if comm is not None:
+                    nex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single)
+                    record(f"native {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: nex}))
+                    for schedule in ("join", "chain") + (("swap", "swap-packed") if halo == 1 else ()):
+                        for wg in (0, 2):
+                            nex.tune(schedule, wg)
+                            fused = (nex.make_dist_lap5(chk.probe, chk.out, dec.origin, dec.origin) if halo == 1 else
+                                     nex.make_dist_hdiff(chk.probe, chk.out, coeff, dec.origin, type(hd)._gt_binding_.flags))
+
+                            def run(fused=fused):
+                                fused()
+                                nex.end()
+
+                            record(f"native {table} fused {schedule} wg{wg}", run)
+                    nex.close()
+            del chk
+    finally:
+        if comm is not None:
+            comm.close()
+    mine = [(n, bool(ok), d) for n, ok, d in results]
+    everyone = [mine]
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+    failed = sum(1 for per_rank in everyone for _, ok, _ in per_rank if not ok)
+    if rank == 0:
+        for i, (name, _, _) in enumerate(mine):
+            verdicts = [per_rank[i] for per_rank in everyone]
+            bad = [(r, v[2]) for r, v in enumerate(verdicts) if not v[1]]
+            print(f"{name:60s} {'ok on every rank' if not bad else 'WRONG on ' + ', '.join(f'rank {r}: {d}' for r, d in bad)}", file=out)
+        print(f"{len(mine)} checks x {world} rank(s): {'all correct' if failed == 0 else str(failed) + ' FAILED'}", file=out)
+    if started_group:
+        dist.barrier()
+        dist.destroy_process_group()
+    return failed
+
+
+def main(argv=None) -> int:
+    """``python -m gt4py_amd.distributed [--domain I J K] [--periodic] [--transport native|torch|both]``"""
+    import argparse
+
+    ap = argparse.ArgumentParser(prog="python -m gt4py_amd.distributed", description=run_selfcheck.__doc__)
+    ap.add_argument("--domain", type=int, nargs=3, default=(256, 192, 16), metavar=("I", "J", "K"), help="GLOBAL compute domain")
+    ap.add_argument("--periodic", action="store_true", help="wrap both axes (with one rank: every neighbour is the rank itself)")
+    ap.add_argument("--transport", choices=("native", "torch", "both"), default="both")
+    a = ap.parse_args(argv)
+    return 1 if run_selfcheck(tuple(a.domain), a.periodic, ("native", "torch") if a.transport == "both" else (a.transport,)) else 0

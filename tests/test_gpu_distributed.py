@@ -790,7 +790,7 @@ def test_bench_prints_what_it_measured_when_a_later_phase_hangs(workload, phase,
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    env = dict(os.environ, GT4MI_BENCH_FORCE_DISTRIBUTED="1", GT4MI_BENCH_TEST_HANG=phase, GT4MI_BENCH_DEADLINE_SCALE="0.1")
+    env = dict(os.environ, GT4MI_BENCH_FORCE_DISTRIBUTED="1", GT4MI_BENCH_TEST_HANG=phase, GT4MI_BENCH_DEADLINE_SCALE="0.5")
     proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                            "--master-port", str(port), str(root / "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2",
                            "--workload", workload], env=env, capture_output=True, text=True, timeout=900, cwd=str(root))

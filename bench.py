@@ -1078,8 +1078,11 @@ def _setup_hdiff2048(args, ctx):
             if transport == "native":  # (still: the plainest form ran on every rank)
                 names = []
                 for table in ("two_phase", "single_phase"):
-                    names += [f"fused_{table}_{sched}_wg{wg}_edge{edge}" for sched in ("join", "chain") for wg in (0, 3, 2)
-                              for edge in edge_candidates]
+                    # (the "swap" schedules exist for this step too and are 4-6 % slower than "chain" on the self-loop: here the
+                    # interior kernel, not the chain, is the critical path -- GT4MI_BENCH_HDIFF_SCHEDULES adds them)
+                    schedules = tuple(os.environ.get("GT4MI_BENCH_HDIFF_SCHEDULES", "join,chain").split(","))
+                    names += [f"fused_{table}_{sched}_wg{wg}_edge{edge}" for sched in schedules
+                              for wg in (0, 3, 2) for edge in edge_candidates]
                     names.append(f"sequential_{table}")
                 pinned = os.environ.get("GT4MI_BENCH_FORM")
                 dog.arm(300, "calibration of the apply forms")

@@ -112,7 +112,7 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
     const int none[4] = {0, 0, 0, 0};
     if (int rc = gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, none, ms)) return rc;
     const int widths[4] = {(int)lo_i, (int)hi_i, (int)lo_j, (int)hi_j};
-    auto interior = [&]() -> int {
+    auto interior = [&](hipStream_t st) -> int {
         if (!(di - lo_i - hi_i > 0 && dj - lo_j - hi_j > 0 && dk > 0)) return GT4MI_OK;
         gt4mi_field a = *in_field, b = *out_field, c;
         a.origin[0] += lo_i; a.origin[1] += lo_j;
@@ -125,17 +125,39 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
         // 2 of 4 workgroups per CU: the send/recv kernel next to it takes 59 us instead of 190 (3 of 4: 77;
         // profiles/r3_dist_hdiff_timeline_by_schedule_and_throttle.txt, r3_dist_hdiff_edge_width_sweep.txt)
         gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 2)));
-        return gt4mi::hdiff_run<T>(sub, &a, &b, coeff ? &c : nullptr, coeff_scalar, flags, ms);
+        return gt4mi::hdiff_run<T>(sub, &a, &b, coeff ? &c : nullptr, coeff_scalar, flags, st);
     };
-    if (gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_CHAIN) != GT4MI_SCHEDULE_JOIN) {  // (GT4MI_SCHEDULE_SWAP: as chain -- here the
-        // interior kernel is the critical path and stays on the caller's stream)
+    const int schedule = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_CHAIN);
+    if (schedule == GT4MI_SCHEDULE_SWAP || schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
+        // Schedules "swap" / "swap-packed" (see gt4mi_dist_lap5_f64): the chain pack -> send/recv -> unpack -> ring back to back
+        // on the CALLER's stream, the interior kernel on the side stream -- forked off before the pack, or after it so that the
+        // send/recv kernel starts ahead of the interior's ramp-up; the caller's stream joins the interior at the end.
+        if (schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
+            if (int rc = gt4mi::halo_pack_first(plan, in_field, ms)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+            GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+            if (int rc = gt4mi::halo_exchange_on(plan, in_field, ms, /*first_pack_done=*/true)) return rc;
+            if (int rc = interior(plan->stream)) return rc;
+        } else {
+            GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+            GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+            if (int rc = interior(plan->stream)) return rc;
+            if (int rc = gt4mi::halo_exchange_on(plan, in_field, ms)) return rc;
+        }
+        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
+        if (int rc = gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, ms)) return rc;
+        if (!plan->defer_join) GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
+        return GT4MI_OK;
+    }
+    if (schedule == GT4MI_SCHEDULE_CHAIN) {
         // Schedule "chain": the main stream carries NOTHING but the interior kernel; pack -> send/recv -> unpack -> ring run
         // in order on the side stream (the ring writes out_field's ring, the interior its interior).  No cross-stream wait
         // lies on the critical path: the join after the interior is already satisfied when the chain fits under it, and
         // back-to-back applies run their interiors back to back (profiles/r3_dist_hdiff_timeline_*.txt).
         GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
         GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-        if (int rc = interior()) return rc;
+        if (int rc = interior(ms)) return rc;
         if (int rc = gt4mi::halo_exchange_on(plan, in_field, plan->stream)) return rc;
         if (int rc = gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, plan->stream)) return rc;
         GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
@@ -148,7 +170,7 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
     GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
     GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
     // 2. main stream: the interior, which reads no ghost cell
-    if (int rc = interior()) return rc;
+    if (int rc = interior(ms)) return rc;
     // 3. side stream: send / receive / unpack (and the second phase of a two-phase plan) next to the interior kernel
     if (int rc = gt4mi::halo_exchange_on(plan, in_field, plan->stream, /*first_pack_done=*/true)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));

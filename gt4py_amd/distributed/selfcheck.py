@@ -170,7 +170,7 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
                 if comm is not None:
                     nex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single)
                     record(f"native {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: nex}))
-                    for schedule in ("join", "chain") + (("swap", "swap-packed") if halo == 1 else ()):
+                    for schedule in ("join", "chain", "swap", "swap-packed"):
                         for wg in (0, 2):
                             nex.tune(schedule, wg)
                             fused = (nex.make_dist_lap5(chk.probe, chk.out, dec.origin, dec.origin) if halo == 1 else

@@ -191,7 +191,7 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *   GT4MI_PLAN_SCHEDULE             GT4MI_SCHEDULE_JOIN:  main: pack, interior, [join], ring;  side: send/recv, unpack
  *                                   GT4MI_SCHEDULE_CHAIN: main: interior only;  side: pack, send/recv, unpack, ring -- no
  *                                   cross-stream wait on the critical path as long as the chain fits under the interior
- *                                   GT4MI_SCHEDULE_SWAP (gt4mi_dist_lap5_f64; elsewhere = chain): main: pack, send/recv, unpack,
+ *                                   GT4MI_SCHEDULE_SWAP (gt4mi_dist_lap5_f64 and gt4mi_dist_hdiff_*): main: pack, send/recv, unpack,
  *                                   ring back to back;  side: the interior kernel; the caller's stream joins the interior at
  *                                   the end -- for shares so small that the chain, not the interior, is the critical path
  *                                   GT4MI_SCHEDULE_SWAP_PACKED: the same, the interior kernel forking off AFTER the pack (the

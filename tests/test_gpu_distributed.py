@@ -431,8 +431,9 @@ def test_fused_distributed_hdiff_step(comm, gd, dtype, coeff_kind, periodic, sin
     d_in = gt_storage.from_array(host, dtype, backend="hip:mi300", aligned_index=dec.origin)
     d_out = gt_storage.zeros(dec.local_shape, dtype, backend="hip:mi300", aligned_index=dec.origin)
     ex = NativeHaloExchanger(dec, dtype, comm, single_phase=single_phase)
-    if gd[0] > 100:  # the wide domain: other widths of the W / E boxes than the default, and the other schedule
-        ex.tune("join" if single_phase else "chain", 3, edge_columns=8 if periodic[1] else 32)
+    if gd[0] > 100:  # the wide domain: other widths of the W / E boxes than the default, and every schedule
+        case = (1 if single_phase else 0) + 2 * (0 if all(periodic) else (1 if periodic[1] else 2))
+        ex.tune(("join", "chain", "swap", "swap-packed")[case % 4], 3, edge_columns=8 if periodic[1] else 32)
     names = list(inspect_signature_names(hd))
     args = {names[0]: d_in, names[1]: d_out}
     if coeff_kind == "field":
@@ -866,7 +867,7 @@ def test_selfcheck_command_line_under_torchrun(tmp_path):
     import sys
 
     root = pathlib.Path(__file__).resolve().parent.parent
-    for extra, checks in ((["--periodic", "--transport", "native"], 28), ([], 36)):
+    for extra, checks in ((["--periodic", "--transport", "native"], 36), ([], 44)):
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]

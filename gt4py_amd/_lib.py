@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_halo_exchange_fork",
     "gt4mi_halo_exchange_end",
     "gt4mi_dist_lap5_f64",
+    "gt4mi_dist_lap5_f32",
     "gt4mi_dist_lap5_f64_pipelined",
     "gt4mi_dist_lap5_f64_wide",
     "gt4mi_dist_lap5_f64_skewed",
@@ -204,6 +205,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_halo_exchange_fork.argtypes = [P, P]
     lib.gt4mi_dist_lap5_f64.restype = I
     lib.gt4mi_dist_lap5_f64.argtypes = [P, DOM, FP, FP, I, I, P]
+    lib.gt4mi_dist_lap5_f32.restype = I
+    lib.gt4mi_dist_lap5_f32.argtypes = [P, DOM, FP, FP, I, I, I, P]
     lib.gt4mi_dist_lap5_f64_pipelined.restype = I
     lib.gt4mi_dist_lap5_f64_pipelined.argtypes = [P, DOM, FP, FP, I, I, P]
     lib.gt4mi_dist_lap5_f64_wide.restype = I

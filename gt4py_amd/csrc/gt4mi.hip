@@ -179,6 +179,100 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
     GT4MI_HIP_CHECK(hipStreamWaitEvent(ms, plan->done, 0));
     return gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, ms);
 }
+// One distributed apply of a 5-point stencil (gt4mi_dist_lap5_f64 / _f32): T the fields' type, W the type its literals have.
+template <typename T, typename W>
+int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int variant,
+              int sides, void* main_stream) {
+    if (plan == nullptr || inp == nullptr || out == nullptr || domain == nullptr)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5: null argument");
+    if (plan->elem_size != (int)sizeof(T))
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5: the plan moves %d-byte items, the fields hold %d-byte items",
+                           plan->elem_size, (int)sizeof(T));
+    hipStream_t ms = static_cast<hipStream_t>(main_stream);
+    if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
+    const int64_t di = domain[0], dj = domain[1], dk = domain[2];
+    // W / E: the ring takes a box EW columns wide off the interior kernel (whole cache lines; and the interior then starts
+    // on a 16-byte boundary -- one column in, it ran on 8-byte lanes at 85 us instead of 51 for the 128 x 256 x 512 share)
+    int64_t EW = gt4mi::plan_edge_columns(plan, 16);
+    EW = EW < 1 ? 1 : (EW > 16 ? 16 : EW);
+    if (EW > 1) EW -= EW % (int64_t)(16 / sizeof(T));  // whole 16-byte lanes: the interior kernel keeps its alignment
+    if (EW < 1) EW = 1;
+    if (di < 16 * EW) EW = di >= 64 ? (EW < 8 ? EW : 8) : 1;  // narrow local domains keep most of their columns in the interior
+    const int64_t lo_i = (sides & 1) ? EW : 0, hi_i = (sides & 2) ? EW : 0;
+    const int64_t lo_j = (sides & 4) ? 1 : 0, hi_j = (sides & 8) ? 1 : 0;
+    auto run = [&](int64_t si, int64_t sj, int64_t ei, int64_t ej, hipStream_t st) -> int {
+        if (ei <= 0 || ej <= 0 || dk <= 0) return GT4MI_OK;
+        gt4mi_field a = *inp, b = *out;
+        a.origin[0] += si; a.origin[1] += sj;
+        b.origin[0] += si; b.origin[1] += sj;
+        const int64_t d[3] = {ei, ej, dk};
+        return gt4mi::lap5_run<T, W>(d, &a, &b, variant, st);
+    };
+    const int outer[4] = {0, 0, 0, 0};
+    const int inner[4] = {(int)(lo_i <= di ? lo_i : di), (int)(hi_i && di - hi_i >= lo_i ? hi_i : 0), (int)lo_j,
+                          (int)(hi_j && dj - 1 >= lo_j ? 1 : 0)};
+    auto interior = [&](hipStream_t st) -> int {
+        gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 0)));
+        return run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j, st);
+    };
+    // default: swap -- the fastest of the four on every share of 8 ranks measured (1 x 8, 2 x 4, 4 x 2; DESIGN.md section 6)
+    const int schedule = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_SWAP);
+    if (schedule == GT4MI_SCHEDULE_SWAP || schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
+        // the CALLER's stream carries the chain pack -> send/recv -> unpack -> ring (no cross-stream wait inside it, and it
+        // starts at once); the interior kernel runs beside it on the side stream; the caller joins the interior at the end
+        if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
+        if (schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
+            // ... and the interior kernel forks off AFTER the pack: the send/recv kernel gets a head start on the interior's
+            // ramp-up and the pack of strided I faces (8-10 us next to the interior) runs alone
+            if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+            GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+            if (int rc = gt4mi::halo_exchange_on(plan, inp, ms, /*first_pack_done=*/true)) return rc;
+            if (int rc = interior(plan->stream)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+            plan->done_recorded = true;
+        } else {
+            GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+            GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+            if (int rc = interior(plan->stream)) return rc;
+            GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+            plan->done_recorded = true;
+            if (int rc = gt4mi::halo_exchange_on(plan, inp, ms)) return rc;
+        }
+        if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, ms)) return rc;
+        return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
+    }
+    if (schedule == GT4MI_SCHEDULE_CHAIN) {
+        // the main stream carries the interior kernel only; pack -> send/recv -> unpack -> ring in order on the side stream
+        // (see dist_hdiff)
+        if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
+        GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+        GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+        if (int rc = interior(ms)) return rc;
+        if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream)) return rc;
+        if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, plan->stream)) return rc;
+        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
+        return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
+    }
+    // 1. pack the first faces ON THE MAIN STREAM, ahead of the interior kernel: alone it takes ~5 us;
+    //    launched next to the interior kernel's thousands of workgroups it took 22 us and delayed the
+    //    whole exchange past the end of the interior kernel (profiles/r1_dist_step_timeline.txt).
+    //    The side stream then only waits for this pack (and whatever preceded it).
+    if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
+    GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
+    GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
+    // 2. main stream: interior, independent of the ghost cells in flight
+    if (int rc = interior(ms)) return rc;
+    // 3. side stream: RCCL send/recv + unpack (+ second phase), concurrent with the interior kernel
+    if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/true)) return rc;
+    GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
+        plan->done_recorded = true;
+    // 4. main stream: join, then the ring of points that read ghost cells -- ONE launch (lap5_ring.hip.h)
+    if (int rc = gt4mi_halo_exchange_end(plan, main_stream)) return rc;
+    return gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, ms);
+}
+
 }  // namespace
 
 extern "C" {
@@ -485,90 +579,13 @@ int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream) {
 
 int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int sides, void* main_stream) {
-    if (plan == nullptr || inp == nullptr || out == nullptr || domain == nullptr)
-        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5: null argument");
-    hipStream_t ms = static_cast<hipStream_t>(main_stream);
-    if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
-    const int64_t di = domain[0], dj = domain[1], dk = domain[2];
-    // W / E: the ring takes a box EW columns wide off the interior kernel (whole cache lines; and the interior then starts
-    // on a 16-byte boundary -- one column in, it ran on 8-byte lanes at 85 us instead of 51 for the 128 x 256 x 512 share)
-    int64_t EW = gt4mi::plan_edge_columns(plan, 16);
-    EW = EW < 1 ? 1 : (EW > 16 ? 16 : EW);
-    if (EW > 1) EW -= EW % 2;
-    if (di < 16 * EW) EW = di >= 64 ? (EW < 8 ? EW : 8) : 1;  // narrow local domains keep most of their columns in the interior
-    const int64_t lo_i = (sides & 1) ? EW : 0, hi_i = (sides & 2) ? EW : 0;
-    const int64_t lo_j = (sides & 4) ? 1 : 0, hi_j = (sides & 8) ? 1 : 0;
-    auto run = [&](int64_t si, int64_t sj, int64_t ei, int64_t ej, hipStream_t st) -> int {
-        if (ei <= 0 || ej <= 0 || dk <= 0) return GT4MI_OK;
-        gt4mi_field a = *inp, b = *out;
-        a.origin[0] += si; a.origin[1] += sj;
-        b.origin[0] += si; b.origin[1] += sj;
-        const int64_t d[3] = {ei, ej, dk};
-        return gt4mi::lap5_run<double, double>(d, &a, &b, variant, st);
-    };
-    const int outer[4] = {0, 0, 0, 0};
-    const int inner[4] = {(int)(lo_i <= di ? lo_i : di), (int)(hi_i && di - hi_i >= lo_i ? hi_i : 0), (int)lo_j,
-                          (int)(hi_j && dj - 1 >= lo_j ? 1 : 0)};
-    auto interior = [&](hipStream_t st) -> int {
-        gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 0)));
-        return run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j, st);
-    };
-    // default: swap -- the fastest of the four on every share of 8 ranks measured (1 x 8, 2 x 4, 4 x 2; DESIGN.md section 6)
-    const int schedule = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_SWAP);
-    if (schedule == GT4MI_SCHEDULE_SWAP || schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
-        // the CALLER's stream carries the chain pack -> send/recv -> unpack -> ring (no cross-stream wait inside it, and it
-        // starts at once); the interior kernel runs beside it on the side stream; the caller joins the interior at the end
-        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
-        if (schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
-            // ... and the interior kernel forks off AFTER the pack: the send/recv kernel gets a head start on the interior's
-            // ramp-up and the pack of strided I faces (8-10 us next to the interior) runs alone
-            if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
-            GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
-            GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-            if (int rc = gt4mi::halo_exchange_on(plan, inp, ms, /*first_pack_done=*/true)) return rc;
-            if (int rc = interior(plan->stream)) return rc;
-            GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-            plan->done_recorded = true;
-        } else {
-            GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
-            GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-            if (int rc = interior(plan->stream)) return rc;
-            GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-            plan->done_recorded = true;
-            if (int rc = gt4mi::halo_exchange_on(plan, inp, ms)) return rc;
-        }
-        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, ms)) return rc;
-        return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
-    }
-    if (schedule == GT4MI_SCHEDULE_CHAIN) {
-        // the main stream carries the interior kernel only; pack -> send/recv -> unpack -> ring in order on the side stream
-        // (see dist_hdiff)
-        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
-        GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
-        GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-        if (int rc = interior(ms)) return rc;
-        if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream)) return rc;
-        if (int rc = gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, plan->stream)) return rc;
-        GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-        plan->done_recorded = true;
-        return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
-    }
-    // 1. pack the first faces ON THE MAIN STREAM, ahead of the interior kernel: alone it takes ~5 us;
-    //    launched next to the interior kernel's thousands of workgroups it took 22 us and delayed the
-    //    whole exchange past the end of the interior kernel (profiles/r1_dist_step_timeline.txt).
-    //    The side stream then only waits for this pack (and whatever preceded it).
-    if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
-    GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
-    GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-    // 2. main stream: interior, independent of the ghost cells in flight
-    if (int rc = interior(ms)) return rc;
-    // 3. side stream: RCCL send/recv + unpack (+ second phase), concurrent with the interior kernel
-    if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/true)) return rc;
-    GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-        plan->done_recorded = true;
-    // 4. main stream: join, then the ring of points that read ghost cells -- ONE launch (lap5_ring.hip.h)
-    if (int rc = gt4mi_halo_exchange_end(plan, main_stream)) return rc;
-    return gt4mi::lap5_ring_run<double, double>(domain, inp, out, variant, outer, inner, ms);
+    return dist_lap5<double, double>(plan, domain, inp, out, variant, sides, main_stream);
+}
+
+int gt4mi_dist_lap5_f32(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
+                        const gt4mi_field* out, int variant, int flags, int sides, void* main_stream) {
+    if (flags & GT4MI_LAP_LITERAL_F32) return dist_lap5<float, float>(plan, domain, inp, out, variant, sides, main_stream);
+    return dist_lap5<float, double>(plan, domain, inp, out, variant, sides, main_stream);
 }
 
 int gt4mi_dist_lap5_f64_wide(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,

@@ -27,7 +27,7 @@ _FUSED_CACHE: Dict[Any, Any] = {}
 def fused_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequence[int]], arguments: Dict[str, Any],
                 exchange: Mapping[str, Any]) -> bool:
     """The distributed apply as ONE native call, where the library has it: a stencil bound to the hand-written horizontal
-    diffusion (``gt4mi_dist_hdiff_*``, ghost depth 2) or 5-point (``gt4mi_dist_lap5_f64``, ghost depth 1) kernels whose
+    diffusion (``gt4mi_dist_hdiff_*``, ghost depth 2) or 5-point (``gt4mi_dist_lap5_f64 / _f32``, ghost depth 1) kernels whose
     read field is exchanged through a ``NativeHaloExchanger``.  Pack, interior kernel next to the exchange, then one ring
     kernel for the points that read ghost cells.  Returns False when the combination is not covered (the caller falls
     back to the stencil-agnostic schedule of ``overlapped_apply``)."""
@@ -65,9 +65,10 @@ def fused_apply(stencil, decomp: Decomposition, origin: Mapping[str, Sequence[in
             call = ex.make_dist_hdiff(arguments[name], arguments[roles["out_field"]], coeff if is_field else None, org,
                                       binding.flags, 0.0 if is_field else float(coeff), hold_arrays=False)
         else:
-            if decomp.halo != 1 or itemsize != 8 or binding.flags:
+            if decomp.halo != 1 or itemsize not in (4, 8) or (binding.flags and itemsize == 8):
                 return False
-            call = ex.make_dist_lap5(arguments[name], arguments[roles["out"]], org, org, binding.variant, hold_arrays=False)
+            call = ex.make_dist_lap5(arguments[name], arguments[roles["out"]], org, org, binding.variant, hold_arrays=False,
+                                     flags=binding.flags)
         if len(_FUSED_CACHE) >= 16:
             _FUSED_CACHE.pop(next(iter(_FUSED_CACHE)))
         entry = _FUSED_CACHE[key] = (call, [(n, weakref.ref(arguments[n])) for n in field_names])

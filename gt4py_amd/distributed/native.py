@@ -181,20 +181,25 @@ class NativeHaloExchanger:
         _lib.check("gt4mi_halo_exchange_end", self._lib.gt4mi_halo_exchange_end(self._plan, _stream_ptr()))
 
     def make_dist_lap5(self, inp, out, origin_inp: Sequence[int], origin_out: Sequence[int], variant: int = 0,
-                       hold_arrays: bool = True):
-        """Pre-bind one distributed Laplacian apply (halo 1) -> a zero-argument callable.  ``hold_arrays=False``: the
-        callable does not keep the arrays alive (a caller that checks their identity itself, ``distributed.fused_apply``)."""
-        if self.decomp.halo != 1 or self.itemsize != 8:
-            raise ValueError("gt4mi_dist_lap5_f64 needs fp64 fields and a halo of 1")
+                       hold_arrays: bool = True, flags: int = 0):
+        """Pre-bind one distributed apply of a 5-point stencil (halo 1; gt4mi_dist_lap5_f64 / _f32 by the exchanger's item
+        size, ``flags`` as for gt4mi_lap5_f32) -> a zero-argument callable.  ``hold_arrays=False``: the callable does not
+        keep the arrays alive (a caller that checks their identity itself, ``distributed.fused_apply``)."""
+        if self.decomp.halo != 1 or self.itemsize not in (4, 8):
+            raise ValueError("gt4mi_dist_lap5_* needs fp64 / fp32 fields and a halo of 1")
         fi, fo = _field_struct(inp, origin_inp), _field_struct(out, origin_out)
         dom = _lib.domain3(self.decomp.local_domain)
-        fn, sides = self._lib.gt4mi_dist_lap5_f64, self.sides
+        sides = self.sides
         ri, ro = ctypes.byref(fi), ctypes.byref(fo)
+        if self.itemsize == 8:
+            name, fn, head = "gt4mi_dist_lap5_f64", self._lib.gt4mi_dist_lap5_f64, (variant,)
+        else:
+            name, fn, head = "gt4mi_dist_lap5_f32", self._lib.gt4mi_dist_lap5_f32, (variant, int(flags))
 
         def apply():
-            rc = fn(self._plan, dom, ri, ro, variant, sides, _stream_ptr())  # (a closed exchanger's plan is NULL: an error, not a crash)
+            rc = fn(self._plan, dom, ri, ro, *head, sides, _stream_ptr())  # (a closed exchanger's plan is NULL: an error, not a crash)
             if rc:
-                _lib.check("gt4mi_dist_lap5_f64", rc)
+                _lib.check(name, rc)
 
         apply._keepalive = (fi, fo, dom) + ((inp, out) if hold_arrays else ())  # type: ignore[attr-defined]
         return apply

@@ -236,6 +236,9 @@ int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream);
  * (unless GT4MI_PLAN_DEFER_JOIN says otherwise). */
 int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int sides, void* main_stream);
+/* The same for float32 fields (a plan created for 4-byte items); `flags` as for gt4mi_lap5_f32 (GT4MI_LAP_LITERAL_F32). */
+int gt4mi_dist_lap5_f32(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
+                        const gt4mi_field* out, int variant, int flags, int sides, void* main_stream);
 
 /* One distributed apply of horizontal diffusion (the stencil of gt4mi_hdiff_*; BASELINE configs[4]) in a single call:
  *   main stream: pack of in_field's faces -> interior kernel (the domain minus a ring 2 points deep on every side

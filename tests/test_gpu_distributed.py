@@ -95,6 +95,53 @@ def test_fused_distributed_laplacian_step(comm, periodic, edge_columns, schedule
     ex.close()
 
 
+@pytest.mark.parametrize("literal32", [False, True])
+@pytest.mark.parametrize("schedule", ["join", "chain", "swap", "swap-packed"])
+def test_fused_distributed_laplacian_step_float32(comm, schedule, literal32):
+    """gt4mi_dist_lap5_f32: the same step on float32 fields (a plan of 4-byte items), both literal precisions -- equal to the
+    whole-domain kernel on the exchanged field, and for float32 literals to the oracle's all-float32 Laplacian."""
+    import ctypes
+
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from gt4py_amd.distributed.native import _field_struct
+    from oracle import ref_numpy as R
+
+    flags = _lib.LAP_LITERAL_F32 if literal32 else 0
+    dec = Decomposition((300, 40, 4), (1, 1), 0, 1, periodic=(True, True))
+    host = np.random.default_rng(13).uniform(-1, 1, dec.local_shape).astype(np.float32)
+    inp = gt_storage.from_array(host, np.float32, backend="hip:mi300", aligned_index=dec.origin)
+    out = gt_storage.zeros(dec.local_shape, np.float32, backend="hip:mi300", aligned_index=dec.origin)
+    ref = gt_storage.zeros(dec.local_shape, np.float32, backend="hip:mi300", aligned_index=dec.origin)
+    ex = NativeHaloExchanger(dec, np.float32, comm).tune(schedule, 0)
+    step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin, flags=flags)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    wrapped = _wrap(host, 1, True, True)
+    assert np.array_equal(inp.get(), wrapped)
+    lib = _lib.load()
+    fi, fo = _field_struct(inp, dec.origin), _field_struct(ref, dec.origin)
+    _lib.check("gt4mi_lap5_f32", lib.gt4mi_lap5_f32(_lib.domain3(dec.local_domain), ctypes.byref(fi), ctypes.byref(fo), 0, flags,
+                                                    torch.cuda.current_stream().cuda_stream, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.get(), ref.get())
+    if literal32:
+        want = np.zeros_like(host)
+        R.laplacian(wrapped, want)
+        assert np.array_equal(out.get(), want)
+    # a plan of 8-byte items refuses float32 fields instead of moving half of every face
+    ex8 = NativeHaloExchanger(dec, np.float64, comm)
+    ex8.itemsize = 4  # (get past the Python-side choice of the entry point)
+    with pytest.raises(RuntimeError, match="8-byte items"):
+        ex8.make_dist_lap5(inp, out, dec.origin, dec.origin)()
+    ex8.close()
+    ex.close()
+
+
 def test_overlapped_apply_with_native_exchanger(comm):
     """The generic Python driver (any stencil family) on top of the native exchanger: hdiff, halo 2."""
     import torch

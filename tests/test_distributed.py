@@ -707,3 +707,35 @@ def test_gloo_world_size_2_wide_halo_time_stepping(grid, periodic, halo, tmp_pat
     port = _free_port()
     mp.spawn(_worker_wide_halo, args=(2, port, grid, halo, periodic, str(tmp_path)), nprocs=2, join=True)
     assert np.load(tmp_path / "ok.npy")[0] == 1
+
+
+@pytest.mark.parametrize("grid", [(4, 2), (1, 8), (3, 2)])
+def test_tridiagonal_solve_decomposes_without_any_exchange(grid):
+    """K is never split and the vertical solve reads no horizontal neighbour, so an IJ-decomposed
+    tridiagonal solve is the local solve on every rank's share -- ghost depth 0, no message.  The drivers with an empty
+    exchange table on every rank of the grid == the oracle on the undecomposed fields (``sup`` / ``rhs`` are updated in
+    place on every share exactly as on the whole)."""
+    import oracle.numpy_backend  # noqa: F401 - registers backend "numpy"
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.distributed import overlapped_apply, sequential_apply
+
+    tri = gtscript.stencil(backend="numpy", definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64})
+    rng = np.random.default_rng(7)
+    gd = (13, 10, 9)
+    glob = {"inf": rng.uniform(-1, 1, gd), "diag": rng.uniform(4, 5, gd), "sup": rng.uniform(-1, 1, gd), "rhs": rng.uniform(-10, 10, gd),
+            "out": np.zeros(gd)}
+    want = {k: v.copy() for k, v in glob.items()}
+    R.tridiag(want["inf"], want["diag"], want["sup"], want["rhs"], want["out"])
+    for apply in (overlapped_apply, sequential_apply):
+        got = {k: np.full(gd, np.nan) for k in ("sup", "rhs", "out")}
+        for rank in range(grid[0] * grid[1]):
+            dec = Decomposition(gd, grid, rank, 0)
+            assert dec.local_shape == dec.local_domain and dec.interior_and_strips()[1] == []
+            sl = dec.global_slices(with_halo=False)
+            args = {k: np.ascontiguousarray(v[sl]).view(HostField) for k, v in glob.items()}
+            apply(tri, dec, {k: (0, 0, 0) for k in args}, args, {})
+            for k in got:
+                got[k][sl] = np.asarray(args[k])
+        for k in got:
+            assert np.array_equal(got[k], want[k]), (apply.__name__, k)

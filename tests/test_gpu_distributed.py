@@ -927,3 +927,38 @@ def test_selfcheck_command_line_under_torchrun(tmp_path):
         assert len(lines) == checks and not any("WRONG" in ln for ln in lines), proc.stdout[-3000:]
         assert "all correct" in proc.stdout
         assert any("fused swap-packed wg2" in ln for ln in lines) and any("halo 2" in ln and "fused chain" in ln for ln in lines)
+
+
+@pytest.mark.parametrize("grid", [(4, 2), (1, 8)])
+def test_tridiagonal_solve_decomposes_without_any_exchange_on_the_device(grid):
+    """BASELINE configs[3] decomposed (ghost depth 0, no message): every rank's share through the
+    drivers with an empty exchange table, the kernel-library solve underneath, == the oracle on the undecomposed fields,
+    the in-place updates of ``sup`` / ``rhs`` included."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.distributed import Decomposition, overlapped_apply, sequential_apply
+    from oracle import ref_numpy as R
+
+    tri = gtscript.stencil(backend="hip:mi300", definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64}, device_sync=False)
+    assert type(tri)._gt_binding_.family == "tridiag"
+    rng = np.random.default_rng(7)
+    gd = (70, 44, 61)
+    glob = {"inf": rng.uniform(-1, 1, gd), "diag": rng.uniform(4, 5, gd), "sup": rng.uniform(-1, 1, gd), "rhs": rng.uniform(-10, 10, gd),
+            "out": np.zeros(gd)}
+    want = {k: v.copy() for k, v in glob.items()}
+    R.tridiag(want["inf"], want["diag"], want["sup"], want["rhs"], want["out"])
+    for apply in (overlapped_apply, sequential_apply):
+        got = {k: np.full(gd, np.nan) for k in ("sup", "rhs", "out")}
+        for rank in range(grid[0] * grid[1]):
+            dec = Decomposition(gd, grid, rank, 0)
+            sl = dec.global_slices(with_halo=False)
+            args = {k: gt_storage.from_array(np.ascontiguousarray(v[sl]), backend="hip:mi300") for k, v in glob.items()}
+            apply(tri, dec, {k: (0, 0, 0) for k in args}, args, {})
+            torch.cuda.synchronize()
+            for k in got:
+                got[k][sl] = args[k].get()
+        for k in got:
+            assert np.array_equal(got[k], want[k]), (apply.__name__, k)

@@ -473,6 +473,28 @@ def cpu_baseline_child(seconds_budget: float) -> None:
             break
     dt = time.perf_counter() - t_start
     med = statistics.median(rates)
+    # SURVEY.md section 8d also asks for the numpy restatement, single thread: what the reference's `numpy` backend does for
+    # this stencil (five ufunc passes with full-size temporaries), on the same grid in numpy's own (K-contiguous) layout
+    numpy_line = None
+    try:
+        from oracle import ref_numpy
+
+        nk = min(128, dom[2])  # a 512 x 512 x 128 slab (BASELINE configs[1]: 268 MB per array, far beyond one core's L3 share)
+        a = np.ascontiguousarray(inp[:, :, :nk])
+        b = np.zeros_like(a)
+        ref_numpy.laplacian(a, b)  # page touch + warm-up
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ref_numpy.laplacian(a, b)
+            times.append(time.perf_counter() - t0)
+        numpy_line = {"value": round(dom[0] * dom[1] * nk / min(times) / 1e9, 4), "unit": "GLUPS", "cores": 1,
+                      "sample": f"oracle/ref_numpy.laplacian (the numpy backend's statement-by-statement evaluation: five ufunc passes "
+                                f"with full-size temporaries) on a {dom[0]}x{dom[1]}x{nk} slab, K-contiguous, best of 3 applies "
+                                f"({min(times):.2f} s each)"}
+        del a, b
+    except Exception as ex:  # the second baseline must not take the first one down
+        numpy_line = {"error": repr(ex)}
     print(json.dumps({
         "value": round(med, 4),
         "unit": "GLUPS",
@@ -488,6 +510,7 @@ def cpu_baseline_child(seconds_budget: float) -> None:
         "batch_glups_min_max": [round(min(rates), 3), round(max(rates), 3)],
         "spread_pct": round(100.0 * (max(rates) - min(rates)) / med, 1),
         "host": host_model(),
+        "numpy_single_thread": numpy_line,
     }))
 
 

@@ -92,6 +92,8 @@ def test_cpu_baseline_child_reports_pinned_threads_and_spread():
     assert line["kind"] == "port" and line["unit"] == "GLUPS" and line["cores"] == 2 and line["value"] > 0
     assert {"sample", "spread_pct", "batch_glups_min_max", "host", "gb_per_s"} <= set(line)
     assert "512x512x512" in line["sample"] and "pinned" in line["sample"]
+    numpy_line = line["numpy_single_thread"]  # the numpy restatement, single thread, beside it
+    assert numpy_line["cores"] == 1 and 0 < numpy_line["value"] < line["value"] * 4 and "512x512x128" in numpy_line["sample"]
     assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
 
 

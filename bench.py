@@ -709,13 +709,19 @@ def _setup_distributed_laplacian(args, ctx):
         grid = grid_of(os.environ["GT4MI_BENCH_GRID"])
     single_phase = os.environ.get("GT4MI_BENCH_SINGLE_PHASE", "0") == "1"
     schedule, wg_per_cu = os.environ.get("GT4MI_BENCH_SCHEDULE", "join"), int(os.environ.get("GT4MI_BENCH_WG_PER_CU", "0"))
+    # how the faces travel: RCCL send/recv, or peer stores from the pack kernel (csrc/direct.hip.h); both are calibrated
+    transports = tuple(os.environ.get("GT4MI_BENCH_TRANSPORTS", "rccl,direct").split(","))
+    halo_transport = transports[0]
     calibration = None
 
-    def apply_candidate(cand_grid, cand_single, cand_schedule="join", cand_wg=0):
-        """(step(i), keepalive) of the headline form on one process grid / message table / schedule / throttle."""
+    def apply_candidate(cand_grid, cand_single, cand_schedule="join", cand_wg=0, cand_transport="rccl"):
+        """(step(i), keepalive) of the headline form on one process grid / message table / schedule / throttle / transport."""
         cdec = Decomposition(total, cand_grid, rank, halo=1, periodic=periodic)
         cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=1337 + rank, origin=cdec.origin)
         cex = [NativeHaloExchanger(cdec, np.float64, comm, single_phase=cand_single).tune(cand_schedule, cand_wg) for _ in cpairs]
+        if cand_transport == "direct":  # peer stores from the pack kernel instead of RCCL send/recv (collective; raises on EVERY rank
+            for ex in cex:              # when it is not available on some rank: measure_candidate then drops the candidate)
+                ex.use_direct_transport()
         bound = [ex.make_dist_lap5(inp, out, cdec.origin, cdec.origin) for ex, (inp, out) in zip(cex, cpairs)]
         state = {"i": 0}
 
@@ -809,15 +815,17 @@ def _setup_distributed_laplacian(args, ctx):
                 for cand_single in ((single_phase,) if "GT4MI_BENCH_SINGLE_PHASE" in os.environ else (False, True)):
                     for cand_schedule in ("join", "chain", "swap", "swap-packed"):
                         for cand_wg in (0, 4, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
-                            def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg):
-                                call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg)
-                                return call, (lambda: [ex.close() for ex in keep[2]]), keep[4]
+                            for cand_transport in transports:
+                                def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg,
+                                         cand_transport=cand_transport):
+                                    call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg, cand_transport)
+                                    return call, (lambda: [ex.close() for ex in keep[2]]), keep[4]
 
-                            key = (f"{cand_grid[0]}x{cand_grid[1]}_{'single' if cand_single else 'two'}phase_{cand_schedule}"
-                                   f"_wg{cand_wg}")
-                            ms = measure_candidate(ctx, make, 24)
-                            if ms is not None:
-                                table[key] = ms
+                                key = (f"{cand_grid[0]}x{cand_grid[1]}_{'single' if cand_single else 'two'}phase_{cand_schedule}"
+                                       f"_wg{cand_wg}_{cand_transport}")
+                                ms = measure_candidate(ctx, make, 24)
+                                if ms is not None:
+                                    table[key] = ms
             torch.cuda.empty_cache()
         except Exception as ex:
             ok = 0
@@ -828,7 +836,7 @@ def _setup_distributed_laplacian(args, ctx):
         else:
             calibration = table
             best = min(table, key=table.get)
-            g, ph, schedule, wg = best.split("_")
+            g, ph, schedule, wg, halo_transport = best.split("_")
             grid, single_phase, wg_per_cu = grid_of(g), ph == "singlephase", int(wg[2:])
     dog.arm(180, "set-up of the decomposed fields and exchangers")
     dec = Decomposition(total, grid, rank, halo=1, periodic=periodic)
@@ -838,7 +846,7 @@ def _setup_distributed_laplacian(args, ctx):
     stepper_state = {}
     headline_verdict = None
     if transport == "native" and mode == "apply":
-        call, keep = apply_candidate(grid, single_phase, schedule, wg_per_cu)
+        call, keep = apply_candidate(grid, single_phase, schedule, wg_per_cu, halo_transport)
         pairs, exchangers = keep[1], keep[2]
         headline_verdict = keep[4]()  # the form that is about to be timed, checked once more
         ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
@@ -977,6 +985,8 @@ def _setup_distributed_laplacian(args, ctx):
               "transport": transport, "mode": mode if transport == "native" else "apply", "selfloop": bool(selfloop),
               "exchange_overlapped_with_interior": True,
               "schedule": schedule if transport == "native" else "join", "interior_workgroups_per_cu": wg_per_cu,
+              "halo_transport": (halo_transport + (" (peer stores from the pack kernel, flags in the receiver's memory; no send/recv kernel)"
+                                                   if halo_transport == "direct" else " (send/recv)")) if transport == "native" else "torch",
               "calibration_ms_per_apply": calibration, "verified": verified}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
               "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback}

@@ -39,11 +39,16 @@ EXPORTED_SYMBOLS = (
     "gt4mi_halo_unpack",
     "gt4mi_comm_unique_id",
     "gt4mi_comm_create",
+    "gt4mi_comm_create_local",
     "gt4mi_comm_destroy",
     "gt4mi_comm_info",
     "gt4mi_halo_plan_create",
     "gt4mi_halo_plan_destroy",
     "gt4mi_halo_plan_set_option",
+    "gt4mi_halo_plan_direct_prepare",
+    "gt4mi_halo_plan_direct_layout",
+    "gt4mi_halo_plan_direct_connect",
+    "gt4mi_halo_plan_direct_status",
     "gt4mi_halo_plan_concurrent",
     "gt4mi_halo_exchange",
     "gt4mi_halo_exchange_begin",
@@ -80,8 +85,9 @@ ERR_HIP = -4
 LAP_NOTEBOOK, LAP_DOCS, LAP_SUITE, LAP_AVG = 0, 1, 2, 3
 LAP_LITERAL_F32 = 1
 # gt4mi_halo_plan_set_option
-PLAN_SCHEDULE, PLAN_INTERIOR_WG_PER_CU, PLAN_DEFER_JOIN, PLAN_EDGE_COLUMNS = 0, 1, 2, 3
-SCHEDULE_JOIN, SCHEDULE_CHAIN, SCHEDULE_SWAP, SCHEDULE_SWAP_PACKED = 0, 1, 2, 3
+PLAN_SCHEDULE, PLAN_INTERIOR_WG_PER_CU, PLAN_DEFER_JOIN, PLAN_EDGE_COLUMNS, PLAN_TRANSPORT = 0, 1, 2, 3, 4
+TRANSPORT_RCCL, TRANSPORT_DIRECT = 0, 1
+SCHEDULE_JOIN, SCHEDULE_CHAIN, SCHEDULE_SWAP, SCHEDULE_SWAP_PACKED, SCHEDULE_INLINE = 0, 1, 2, 3, 4
 # hdiff flags
 HDIFF_LIMITER, HDIFF_INTERNAL_F32, HDIFF_COEFF_F32 = 1, 2, 4
 
@@ -114,6 +120,13 @@ class HaloMsg(ctypes.Structure):
     @classmethod
     def make(cls, peer: int, phase: int, lo: Sequence[int], extent: Sequence[int]) -> "HaloMsg":
         return cls(int(peer), int(phase), _Int3(*map(int, lo)), _Int3(*map(int, extent)))
+
+
+class DirectInfo(ctypes.Structure):
+    """``gt4mi_direct_info``: what a rank's peers need to reach the receive buffers and flag words of its plan (plain bytes)."""
+
+    _fields_ = [("pool_handle", ctypes.c_char * 64), ("pool_bytes", ctypes.c_int64), ("flag_words", ctypes.c_int64),
+                ("pid", ctypes.c_int32), ("device", ctypes.c_int32)]
 
 
 class ExecInfo(ctypes.Structure):
@@ -180,6 +193,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     PP = ctypes.POINTER(ctypes.c_void_p)
     lib.gt4mi_comm_unique_id.restype = I
     lib.gt4mi_comm_unique_id.argtypes = [P]
+    lib.gt4mi_comm_create_local.restype = I
+    lib.gt4mi_comm_create_local.argtypes = [I, I, ctypes.POINTER(P)]
     lib.gt4mi_comm_create.restype = I
     lib.gt4mi_comm_create.argtypes = [P, I, I, PP]
     lib.gt4mi_comm_destroy.restype = I
@@ -193,6 +208,14 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_halo_plan_destroy.argtypes = [P]
     lib.gt4mi_halo_plan_set_option.restype = I
     lib.gt4mi_halo_plan_set_option.argtypes = [P, I, I]
+    lib.gt4mi_halo_plan_direct_prepare.restype = I
+    lib.gt4mi_halo_plan_direct_prepare.argtypes = [P, ctypes.POINTER(DirectInfo)]
+    lib.gt4mi_halo_plan_direct_layout.restype = I
+    lib.gt4mi_halo_plan_direct_layout.argtypes = [P, I, I, I, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
+    lib.gt4mi_halo_plan_direct_connect.restype = I
+    lib.gt4mi_halo_plan_direct_connect.argtypes = [P, I, I, I, ctypes.POINTER(DirectInfo), ctypes.c_int64, I]
+    lib.gt4mi_halo_plan_direct_status.restype = I
+    lib.gt4mi_halo_plan_direct_status.argtypes = [P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)]
     lib.gt4mi_halo_plan_concurrent.restype = I
     lib.gt4mi_halo_plan_concurrent.argtypes = [P]
     lib.gt4mi_halo_exchange.restype = I

@@ -19,6 +19,7 @@
 
 #include <dlfcn.h>
 
+#include <string>
 #include <vector>
 
 #include "common.hip.h"
@@ -119,6 +120,28 @@ struct gt4mi_halo_plan {
     unsigned* probe = nullptr;            // two device words: flag, result
     hipStream_t probed_main = nullptr;
     bool probed = false, concurrent = false;
+    // ---- the direct transport (direct.hip.h): peer stores from the pack kernel instead of RCCL send/recv ----
+    int transport = 0;  // GT4MI_TRANSPORT_RCCL / GT4MI_TRANSPORT_DIRECT
+    struct Direct {
+        bool prepared = false;
+        char* pool = nullptr;               // ALL receive buffers of the plan, one allocation other processes can map (hipIpc)
+        size_t pool_bytes = 0;
+        std::vector<size_t> recv_offset[2];
+        uint32_t* flags = nullptr;          // my flag words = the first page of the pool: [arrived: one per receive][consumed: one per send]
+        unsigned* counters = nullptr;       // device: finished blocks per message (push: per send, unpack: per receive)
+        uint32_t* error = nullptr;          // device: a wait ran out of time
+        uint32_t step = 0;                  // exchanges started
+        bool first_pushed = false;          // halo_pack_first already pushed the first phase of exchange `step`
+        struct Peer {
+            std::string pool_key;
+            char* pool = nullptr;
+            bool opened_pool = false;
+        };
+        std::vector<Peer> peers;
+        std::vector<char*> send_to[2];              // per send: where the message lands (in the peer's pool)
+        std::vector<uint32_t*> signal_arrived[2];   // per send: the peer's flag that says "it is there"
+        std::vector<uint32_t*> signal_consumed[2];  // per receive: the SENDER's flag that says "unpacked, the buffer is free again"
+    } direct;
 };
 
 namespace gt4mi {
@@ -290,17 +313,41 @@ inline int first_phase(const gt4mi_halo_plan* plan) {
 
 // Pack the faces of the first non-empty phase only (they depend on nothing but the field itself,
 // so a caller can enqueue this ahead of its interior kernel).
+inline int direct_push(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s);    // direct.hip.h
+inline int direct_unpack(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s);
+
 inline int halo_pack_first(gt4mi_halo_plan* plan, const gt4mi_field* field, hipStream_t s) {
     const int p = first_phase(plan);
     if (p > 1) return GT4MI_OK;
+    if (plan->transport == GT4MI_TRANSPORT_DIRECT) {  // the pack IS the transfer
+        ++plan->direct.step;
+        plan->direct.first_pushed = true;
+        return direct_push(plan, field, p, s);
+    }
     return plan_copy<true>(plan, field, plan->sends[p], s);
 }
 
 // Enqueue the two-phase exchange of `field`'s ghost cells on stream `s`.
 inline int halo_exchange_on(gt4mi_halo_plan* plan, const gt4mi_field* field, hipStream_t s,
                             bool first_pack_done = false) {
-    RcclApi& api = rccl();
     const int p0 = first_phase(plan);
+    if (plan->transport == GT4MI_TRANSPORT_DIRECT) {
+        // every face is stored straight into its neighbour's receive buffer by the pack kernel, whose last workgroup raises the
+        // neighbour's flag; the unpack kernel waits for its own flags, copies, and tells the senders that their buffers are free
+        if (!(first_pack_done && plan->direct.first_pushed)) ++plan->direct.step;
+        for (int phase = 0; phase < 2; ++phase) {
+            if (plan->sends[phase].empty() && plan->recvs[phase].empty()) continue;
+            if (!(first_pack_done && plan->direct.first_pushed && phase == p0))
+                if (int rc = direct_push(plan, field, phase, s)) return rc;
+            if (int rc = direct_unpack(plan, field, phase, s)) return rc;
+        }
+        plan->direct.first_pushed = false;
+        return GT4MI_OK;
+    }
+    if (plan->comm->comm == nullptr)
+        return fail(GT4MI_ERR_UNSUPPORTED, "halo: this communicator has no RCCL behind it (gt4mi_comm_create_local): switch the plan to the "
+                                          "direct transport first");
+    RcclApi& api = rccl();
     for (int phase = 0; phase < 2; ++phase) {
         auto& sends = plan->sends[phase];
         auto& recvs = plan->recvs[phase];
@@ -317,3 +364,5 @@ inline int halo_exchange_on(gt4mi_halo_plan* plan, const gt4mi_field* field, hip
 }
 
 }  // namespace gt4mi
+
+#include "direct.hip.h"

@@ -1,0 +1,353 @@
+// The direct halo transport: peer stores from the pack kernel -- NEW (the reference is single-device; SURVEY.md section 5 names
+// "direct peer stores from the pack kernel" as the alternative to RCCL point-to-point).
+//
+// Why: a halo message is <= 2 MB and an exchange per apply is latency bound.  With RCCL a face goes field -> send buffer (pack
+// kernel) -> peer's receive buffer (the send/recv kernel: 13 us alone, 30-190 us next to an HBM-saturating interior kernel) ->
+// ghost cells (unpack kernel).  Here the pack kernel stores every face straight into the NEIGHBOUR's receive buffer -- mapped
+// into this process with hipIpcOpenMemHandle; over xGMI when the neighbour is another device -- and its last workgroup raises a
+// flag at the neighbour; the neighbour's unpack kernel waits for its flags, copies, and raises the sender's "consumed" flag so
+// that the buffer may be overwritten by the next exchange.  Two kernels per phase, no third party, everything stream ordered.
+//
+//   * ONE pool of fine-grained device memory per plan -- a page of flag words, then all receive buffers --, exported with
+//     hipIpcGetMemHandle; a neighbour that is the rank itself (periodic axis of one rank) uses the pointer as it is;
+//   * flags: 32-bit counters; "arrived" flags (one per receive) live in the RECEIVER's pool, "consumed" flags (one per send) in
+//     the SENDER's: whoever waits polls its own memory, whoever signals stores over the link; both carry the number of the
+//     exchange, so nothing is ever reset.  (Flags in registered host memory worked too and cost 300-700 us per exchange: every
+//     polling workgroup is a PCIe read);
+//   * ordering without fences: the writer's stores to the peer are write-through (sc0 sc1: system scope), every wave waits for
+//     their acknowledgement (s_waitcnt vmcnt(0)), barrier, then one lane ADDS 1 to the flag (the flags count workgroups:
+//     16 KB of a message each, on both sides); the reader loads its receive buffer past the caches (sc0 sc1 loads) while one
+//     lane looks at the flag, and loads once more if the count was not there yet (bounded wait: 2 s, then the plan's error word
+//     is set and the data is garbage, which the callers' checks see).  Neither side ever writes back or invalidates a cache
+//     (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 stores AND sc1 loads");
+//   * who talks to whom is set up by the host side (gt4py_amd/distributed/native.py: the k-th send to a peer lands in the buffer
+//     of the k-th receive that peer posted for this rank, exactly RCCL's matching rule).
+//
+// Rehearsed on ONE device: every neighbour the rank itself, and TWO PROCESSES sharing the device (tests/test_gpu_distributed.py)
+// -- real IPC mappings, real cross-process flags; what a 1-GPU box cannot show is the same stores crossing xGMI.
+#pragma once
+
+#include <unistd.h>
+
+#include <cstring>
+
+namespace gt4mi {
+
+struct DirectBatch {
+    uint32_t* wait_flag[BoxBatch::MAX];    // the copies of box m may be stored when *wait_flag[m] >= wait_value[m]
+    uint32_t* signal_flag[BoxBatch::MAX];  // ... and every workgroup of box m adds 1 there when its part is done
+    uint32_t wait_value[BoxBatch::MAX];
+    unsigned blocks[BoxBatch::MAX];        // workgroups that work on box m (the others of the launch leave at once)
+    uint32_t* error;
+};
+
+constexpr int DIRECT_UNROLL = 4;                                   // 16-byte vectors per thread
+constexpr int64_t DIRECT_VECTORS_PER_BLOCK = 256 * DIRECT_UNROLL;  // 16 KB of every message per workgroup -- on BOTH sides: the
+// flags count workgroups, and the receiver must know how many the sender's launch had without being told
+
+inline unsigned direct_blocks(size_t message_bytes) { return (unsigned)((message_bytes / 16 + DIRECT_VECTORS_PER_BLOCK) / DIRECT_VECTORS_PER_BLOCK); }
+
+// 16 bytes to the peer's receive buffer, written THROUGH the caches (sc0 sc1 = system scope): once the wave's vmcnt is 0 the data
+// is where the peer will read it, and no cache holds a dirty copy that a fence would have to write back.
+__device__ __forceinline__ void direct_store(u32x4* where, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(where), "v"(v) : "memory");
+}
+// 16 bytes from my receive buffer, past the caches (another agent wrote them; a cached copy would be the previous exchange's).
+// The caller waits (s_waitcnt vmcnt(0)) before it uses the value: the compiler does not see this load.
+__device__ __forceinline__ u32x4 direct_load(const u32x4* where) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(where) : "memory");
+    return v;
+}
+
+// The copy of halo_batch_kernel (comm.hip.h) with a wait in front and a signal behind.  PACK: field box -> `buffer` (the peer's
+// receive buffer; wait: the peer has unpacked the previous exchange); else `buffer` (my receive buffer) -> field box (wait: the
+// data has arrived).  Next to an HBM-saturating interior kernel every DEPENDENT memory round trip costs ~10 us, so the kernel
+// has two of them: (flag poll || loads), then the stores; the signal is a posted add.
+template <typename U, bool PACK>
+__global__ void __launch_bounds__(256)
+halo_direct_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b, DirectBatch d) {
+    constexpr int UNROLL = DIRECT_UNROLL;
+    constexpr int PER_VEC = 16 / (int)sizeof(U);
+    const int m = blockIdx.y;
+    if (blockIdx.x >= d.blocks[m]) return;
+    __shared__ int ready;
+    const int ei_items = b.ext[m][0], ej = b.ext[m][1], ek = b.ext[m][2];
+    const int64_t n = (int64_t)ei_items * ej * ek, nv = n / PER_VEC;  // items, whole 16-byte vectors of the dense buffer
+    U* base = field + b.offset[m];
+    u32x4* vbuf = static_cast<u32x4*>(b.buffer[m]);
+    const bool rows_are_vectors = b.vec[m] != 0;
+    const int ei_vec = ei_items / PER_VEC;
+    auto item_at = [&](int64_t t) -> U* {  // item t of the dense buffer, in the field
+        const int i = (int)(t % ei_items);
+        const int64_t r = t / ei_items;
+        return base + i * si + (r % ej) * sj + (r / ej) * sk;
+    };
+    auto vector_at = [&](int64_t tv) -> u32x4* {  // (rows_are_vectors) vector tv of the dense buffer, in the field
+        const int i = (int)(tv % ei_vec);
+        const int64_t r = tv / ei_vec;
+        return reinterpret_cast<u32x4*>(base + (int64_t)i * PER_VEC + (r % ej) * sj + (r / ej) * sk);
+    };
+    union Vec { u32x4 v; U item[PER_VEC]; };
+    Vec x[UNROLL];
+    const int64_t tv0 = (int64_t)blockIdx.x * DIRECT_VECTORS_PER_BLOCK + threadIdx.x;
+    auto load_all = [&]() {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t tv = tv0 + (int64_t)u * 256;
+            if (tv >= nv) continue;
+            if constexpr (PACK) {
+                if (rows_are_vectors) x[u].v = *vector_at(tv);
+                else {
+#pragma unroll
+                    for (int e = 0; e < PER_VEC; ++e) x[u].item[e] = *item_at(tv * PER_VEC + e);
+                }
+            } else {
+                x[u].v = direct_load(vbuf + tv);
+            }
+        }
+    };
+    load_all();  // in flight while lane 0 looks at the flag
+    if (threadIdx.x == 0) {
+        // (counters wrap: "has reached" = the signed difference is not negative)
+        int ok = (int)(__hip_atomic_load(d.wait_flag[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.wait_value[m]) >= 0;
+        ready = ok;
+        if (!ok) {
+            const long long t0 = wall_clock64();  // 100 MHz
+            while ((int)(__hip_atomic_load(d.wait_flag[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.wait_value[m]) < 0) {
+                if (wall_clock64() - t0 > 200000000LL) {  // 2 s: the peer is not coming
+                    __hip_atomic_store(d.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the asm loads of the unpack side are invisible to the compiler)
+    __syncthreads();
+    if constexpr (!PACK) {
+        if (!ready) {  // what was loaded before the data had arrived is the previous exchange's: once more
+            load_all();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const int64_t tv = tv0 + (int64_t)u * 256;
+        if (tv >= nv) continue;
+        if constexpr (PACK) {
+            direct_store(vbuf + tv, x[u].v);
+        } else if (rows_are_vectors) {
+            *vector_at(tv) = x[u].v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < PER_VEC; ++e) *item_at(tv * PER_VEC + e) = x[u].item[e];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nv * PER_VEC) {  // the few items behind the last whole vector
+        U* buf = static_cast<U*>(b.buffer[m]);
+        const int64_t t = nv * PER_VEC + threadIdx.x;
+        if constexpr (PACK) __hip_atomic_store(buf + t, *item_at(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else *item_at(t) = __hip_atomic_load(buf + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // PACK: every wave waits until what it stored to the peer has been acknowledged (write-through stores: then it IS there);
+    // unpack: its loads from the receive buffer completed above.  No fence: a system-scope `buffer_wbl2` next to an interior
+    // kernel that keeps the L2 full of dirty lines cost 300-800 us per exchange in the first version of this kernel.
+    if constexpr (PACK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(d.signal_flag[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // posted
+}
+
+inline int direct_index(const gt4mi_halo_plan* plan, bool is_send, int phase, int m) {
+    const size_t nr0 = plan->recvs[0].size(), nr = nr0 + plan->recvs[1].size(), ns0 = plan->sends[0].size();
+    return is_send ? (int)(nr + (phase ? ns0 : 0) + m) : (int)((phase ? nr0 : 0) + m);
+}
+
+template <typename U, bool PACK>
+inline int direct_copy(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase, hipStream_t s) {
+    const auto& msgs = PACK ? plan->sends[phase] : plan->recvs[phase];
+    if (msgs.empty()) return GT4MI_OK;
+    if ((int)msgs.size() > BoxBatch::MAX) return fail(GT4MI_ERR_UNSUPPORTED, "halo: more than %d boxes per phase", BoxBatch::MAX);
+    auto& dx = plan->direct;
+    BoxBatch b;
+    DirectBatch d;
+    b.n = (int)msgs.size();
+    constexpr int64_t PER_VEC = 16 / (int64_t)sizeof(U);
+    const bool field_vec = f->stride[0] == (int64_t)sizeof(U) && f->stride[1] % 16 == 0 && f->stride[2] % 16 == 0 &&
+                           reinterpret_cast<uintptr_t>(f->data) % 16 == 0;
+    int64_t blocks = 0;
+    for (int m = 0; m < b.n; ++m) {
+        int64_t off = 0, n = 1;
+        for (int a = 0; a < 3; ++a) {
+            if (msgs[m].lo[a] + msgs[m].ext[a] > f->shape[a])
+                return fail(GT4MI_ERR_OUT_OF_BOUNDS, "halo: box [%lld, %lld) outside of axis %d (size %lld)",
+                            (long long)msgs[m].lo[a], (long long)(msgs[m].lo[a] + msgs[m].ext[a]), a, (long long)f->shape[a]);
+            if (f->stride[a] % (int64_t)sizeof(U) != 0) return fail(GT4MI_ERR_UNSUPPORTED, "halo: stride not a multiple of the item size");
+            off += msgs[m].lo[a] * (f->stride[a] / (int64_t)sizeof(U));
+            b.ext[m][a] = (int)msgs[m].ext[a];
+            n *= msgs[m].ext[a];
+        }
+        b.offset[m] = off;
+        void* buffer = PACK ? static_cast<void*>(dx.send_to[phase][m]) : msgs[m].buffer;
+        uint32_t* signal = PACK ? dx.signal_arrived[phase][m] : dx.signal_consumed[phase][m];
+        if (buffer == nullptr || signal == nullptr)
+            return fail(GT4MI_ERR_INVALID_ARGUMENT, "halo (direct transport): message %d of phase %d was never connected to its peer", m, phase);
+        b.buffer[m] = buffer;
+        b.vec[m] = field_vec && msgs[m].lo[0] % PER_VEC == 0 && msgs[m].ext[0] % PER_VEC == 0 && reinterpret_cast<uintptr_t>(buffer) % 16 == 0;
+        // PACK: wait until the peer has unpacked what the previous exchange put into this buffer; else: wait for the data.  The
+        // flags count workgroups (every exchange adds direct_blocks(bytes) to both): nothing is ever reset.
+        const unsigned nb = direct_blocks(msgs[m].bytes);
+        d.wait_flag[m] = dx.flags + direct_index(plan, PACK, phase, m);
+        d.wait_value[m] = (PACK ? dx.step - 1 : dx.step) * nb;
+        d.signal_flag[m] = signal;
+        d.blocks[m] = nb;
+        blocks = nb > blocks ? nb : blocks;
+    }
+    d.error = dx.error;
+    hipLaunchKernelGGL((halo_direct_kernel<U, PACK>), dim3((unsigned)blocks, (unsigned)b.n), dim3(256), 0, s,
+                       static_cast<U*>(f->data), f->stride[0] / (int64_t)sizeof(U), f->stride[1] / (int64_t)sizeof(U),
+                       f->stride[2] / (int64_t)sizeof(U), b, d);
+    GT4MI_HIP_CHECK(hipGetLastError());
+    return GT4MI_OK;
+}
+
+inline int direct_push(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s) {
+    if (!plan->direct.prepared) return fail(GT4MI_ERR_INVALID_ARGUMENT, "halo: the direct transport was never prepared");
+    return plan->elem_size == 8 ? direct_copy<uint64_t, true>(plan, field, phase, s) : direct_copy<uint32_t, true>(plan, field, phase, s);
+}
+
+inline int direct_unpack(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s) {
+    return plan->elem_size == 8 ? direct_copy<uint64_t, false>(plan, field, phase, s) : direct_copy<uint32_t, false>(plan, field, phase, s);
+}
+
+// ---- set-up ---------------------------------------------------------------------------------------------------------------
+constexpr size_t DIRECT_FLAG_BYTES = 4096;  // the first page of the pool: the flag words (up to 1024 messages)
+
+inline int direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* out) {
+    auto& dx = plan->direct;
+    if (!dx.prepared) {
+        // ONE allocation other processes can map: the flag words, then all receive buffers (256-byte aligned slots) -- replacing
+        // the per-message allocations of the plan.  Fine-grained device memory: flags and payload are written by another agent
+        // while kernels of this one read them, so no cache may keep a copy.
+        const size_t nflags = plan->recvs[0].size() + plan->recvs[1].size() + plan->sends[0].size() + plan->sends[1].size();
+        if (nflags * sizeof(uint32_t) > DIRECT_FLAG_BYTES) return fail(GT4MI_ERR_UNSUPPORTED, "direct transport: %d messages", (int)nflags);
+        size_t bytes = DIRECT_FLAG_BYTES;
+        for (int p = 0; p < 2; ++p)
+            for (auto& m : plan->recvs[p]) {
+                dx.recv_offset[p].push_back(bytes);
+                bytes += (m.bytes + 255) / 256 * 256;
+            }
+        dx.pool_bytes = bytes;
+        void* pool = nullptr;
+        if (hipExtMallocWithFlags(&pool, dx.pool_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(GT4MI_ERR_UNSUPPORTED, "direct transport: this runtime offers no fine-grained device memory (hipDeviceMallocFinegrained)");
+        }
+        GT4MI_HIP_CHECK(hipMemset(pool, 0, DIRECT_FLAG_BYTES));
+        dx.pool = static_cast<char*>(pool);
+        dx.flags = reinterpret_cast<uint32_t*>(pool);
+        for (int p = 0; p < 2; ++p)
+            for (size_t m = 0; m < plan->recvs[p].size(); ++m) {
+                if (plan->recvs[p][m].buffer) (void)hipFree(plan->recvs[p][m].buffer);
+                plan->recvs[p][m].buffer = dx.pool + dx.recv_offset[p][m];
+            }
+        void* words = nullptr;
+        GT4MI_HIP_CHECK(hipMalloc(&words, (nflags + 1) * sizeof(unsigned)));
+        GT4MI_HIP_CHECK(hipMemset(words, 0, (nflags + 1) * sizeof(unsigned)));
+        dx.counters = static_cast<unsigned*>(words);
+        dx.error = reinterpret_cast<uint32_t*>(dx.counters + nflags);
+        for (int p = 0; p < 2; ++p) {
+            dx.send_to[p].assign(plan->sends[p].size(), nullptr);
+            dx.signal_arrived[p].assign(plan->sends[p].size(), nullptr);
+            dx.signal_consumed[p].assign(plan->recvs[p].size(), nullptr);
+        }
+        GT4MI_HIP_CHECK(hipDeviceSynchronize());
+        dx.prepared = true;
+    }
+    if (out) {
+        memset(out, 0, sizeof *out);
+        hipIpcMemHandle_t h;
+        GT4MI_HIP_CHECK(hipIpcGetMemHandle(&h, dx.pool));
+        static_assert(sizeof h <= sizeof out->pool_handle, "hipIpcMemHandle_t grew");
+        memcpy(out->pool_handle, &h, sizeof h);
+        out->pool_bytes = (int64_t)dx.pool_bytes;
+        out->flag_words = (int64_t)(DIRECT_FLAG_BYTES / sizeof(uint32_t));
+        out->pid = (int32_t)getpid();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        out->device = dev;
+    }
+    return GT4MI_OK;
+}
+
+// The peer's pool in this process: this plan's own (peer == nullptr), or mapped once per distinct peer.
+inline int direct_peer(gt4mi_halo_plan* plan, const gt4mi_direct_info* peer, char** pool) {
+    auto& dx = plan->direct;
+    if (peer == nullptr) {
+        *pool = dx.pool;
+        return GT4MI_OK;
+    }
+    const std::string key(peer->pool_handle, sizeof peer->pool_handle);
+    for (auto& p : dx.peers)
+        if (p.pool_key == key) {
+            *pool = p.pool;
+            return GT4MI_OK;
+        }
+    if (peer->pid == (int32_t)getpid())  // (two ranks in one process do not exist: hipIpcOpenMemHandle refuses the exporter's own handle)
+        return fail(GT4MI_ERR_UNSUPPORTED, "direct transport: the peer is another plan of this process");
+    gt4mi_halo_plan::Direct::Peer p;
+    p.pool_key = key;
+    hipIpcMemHandle_t h;
+    memcpy(&h, peer->pool_handle, sizeof h);
+    void* mapped = nullptr;
+    if (hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(GT4MI_ERR_HIP, "direct transport: hipIpcOpenMemHandle failed for the receive buffers of pid %d (device %d)",
+                    (int)peer->pid, (int)peer->device);
+    }
+    p.pool = static_cast<char*>(mapped);
+    p.opened_pool = true;
+    dx.peers.push_back(p);
+    *pool = p.pool;
+    return GT4MI_OK;
+}
+
+inline int direct_connect(gt4mi_halo_plan* plan, int phase, int is_send, int index, const gt4mi_direct_info* peer,
+                          int64_t peer_pool_offset, int peer_flag_index) {
+    auto& dx = plan->direct;
+    if (!dx.prepared) return fail(GT4MI_ERR_INVALID_ARGUMENT, "direct transport: prepare the plan first");
+    if (phase < 0 || phase > 1) return fail(GT4MI_ERR_INVALID_ARGUMENT, "direct transport: phase %d", phase);
+    const size_t n = is_send ? plan->sends[phase].size() : plan->recvs[phase].size();
+    if (index < 0 || (size_t)index >= n) return fail(GT4MI_ERR_INVALID_ARGUMENT, "direct transport: message %d of %d", index, (int)n);
+    char* pool = nullptr;
+    if (int rc = direct_peer(plan, peer, &pool)) return rc;
+    uint32_t* flags = reinterpret_cast<uint32_t*>(pool);
+    if (peer_flag_index < 0 || (size_t)peer_flag_index >= DIRECT_FLAG_BYTES / sizeof(uint32_t))
+        return fail(GT4MI_ERR_INVALID_ARGUMENT, "direct transport: flag %d", peer_flag_index);
+    if (is_send) {
+        const int64_t pool_bytes = peer ? peer->pool_bytes : (int64_t)dx.pool_bytes;
+        if (peer_pool_offset < (int64_t)DIRECT_FLAG_BYTES || peer_pool_offset + (int64_t)plan->sends[phase][index].bytes > pool_bytes)
+            return fail(GT4MI_ERR_OUT_OF_BOUNDS, "direct transport: a message of %lld bytes at offset %lld of a pool of %lld",
+                        (long long)plan->sends[phase][index].bytes, (long long)peer_pool_offset, (long long)pool_bytes);
+        dx.send_to[phase][index] = pool + peer_pool_offset;
+        dx.signal_arrived[phase][index] = flags + peer_flag_index;
+    } else {
+        dx.signal_consumed[phase][index] = flags + peer_flag_index;
+    }
+    return GT4MI_OK;
+}
+
+inline void direct_release(gt4mi_halo_plan* plan) {
+    auto& dx = plan->direct;
+    if (!dx.prepared) return;
+    for (auto& p : dx.peers)
+        if (p.opened_pool) (void)hipIpcCloseMemHandle(p.pool);
+    dx.peers.clear();
+    if (dx.counters) (void)hipFree(dx.counters);
+    for (int p = 0; p < 2; ++p)
+        for (auto& m : plan->recvs[p]) m.buffer = nullptr;  // they lived in the pool
+    if (dx.pool) (void)hipFree(dx.pool);
+    dx = gt4mi_halo_plan::Direct();
+}
+
+}  // namespace gt4mi

@@ -128,6 +128,12 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
         return gt4mi::hdiff_run<T>(sub, &a, &b, coeff ? &c : nullptr, coeff_scalar, flags, st);
     };
     const int schedule = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_CHAIN);
+    if (schedule == GT4MI_SCHEDULE_INLINE) {  // one stream, no event (see dist_lap5)
+        if (int rc = gt4mi::halo_pack_first(plan, in_field, ms)) return rc;
+        if (int rc = interior(ms)) return rc;
+        if (int rc = gt4mi::halo_exchange_on(plan, in_field, ms, /*first_pack_done=*/true)) return rc;
+        return gt4mi::hdiff_ring_run<T>(domain, in_field, out_field, coeff, coeff_scalar, flags, widths, ms);
+    }
     if (schedule == GT4MI_SCHEDULE_SWAP || schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
         // Schedules "swap" / "swap-packed" (see gt4mi_dist_lap5_f64): the chain pack -> send/recv -> unpack -> ring back to back
         // on the CALLER's stream, the interior kernel on the side stream -- forked off before the pack, or after it so that the
@@ -217,6 +223,15 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
     };
     // default: swap -- the fastest of the four on every share of 8 ranks measured (1 x 8, 2 x 4, 4 x 2)
     const int schedule = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_SWAP);
+    if (schedule == GT4MI_SCHEDULE_INLINE) {
+        // ONE stream, no event: pack (with the direct transport: the faces are on their way when it ends), the interior kernel,
+        // then whatever is left of the exchange (direct: the unpack, whose data arrived long ago) and the ring
+        if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
+        if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
+        if (int rc = interior(ms)) return rc;
+        if (int rc = gt4mi::halo_exchange_on(plan, inp, ms, /*first_pack_done=*/true)) return rc;
+        return gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, ms);
+    }
     if (schedule == GT4MI_SCHEDULE_SWAP || schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
         // the CALLER's stream carries the chain pack -> send/recv -> unpack -> ring (no cross-stream wait inside it, and it
         // starts at once); the interior kernel runs beside it on the side stream; the caller joins the interior at the end
@@ -418,8 +433,24 @@ int gt4mi_comm_create(const void* id128, int nranks, int rank, gt4mi_comm** comm
     return GT4MI_OK;
 }
 
+int gt4mi_comm_create_local(int nranks, int rank, gt4mi_comm** comm) {
+    if (comm == nullptr || nranks < 1 || rank < 0 || rank >= nranks)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "comm_create_local: invalid argument");
+    gt4mi_comm* c = new gt4mi_comm;  // no RCCL communicator behind it: plans on it exchange through the direct transport only
+    c->nranks = nranks;
+    c->rank = rank;
+    *comm = c;
+    return GT4MI_OK;
+}
+
 int gt4mi_comm_info(gt4mi_comm* comm, int* nranks, int* rank, int* device) {
     if (comm == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "comm_info: null communicator");
+    if (comm->comm == nullptr) {  // gt4mi_comm_create_local: what the caller said, and the current device
+        if (nranks) *nranks = comm->nranks;
+        if (rank) *rank = comm->rank;
+        if (device) GT4MI_HIP_CHECK(hipGetDevice(device));
+        return GT4MI_OK;
+    }
     gt4mi::RcclApi& api = gt4mi::rccl();
     // what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), not what the
     // caller passed to gt4mi_comm_create
@@ -503,7 +534,7 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
     if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: null plan");
     switch (option) {
         case GT4MI_PLAN_SCHEDULE:
-            if (value < -1 || value > GT4MI_SCHEDULE_SWAP_PACKED) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
+            if (value < -1 || value > GT4MI_SCHEDULE_INLINE) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: schedule %d", value);
             plan->schedule = value;
             return GT4MI_OK;
         case GT4MI_PLAN_EDGE_COLUMNS:
@@ -518,6 +549,24 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
             if (value < -1 || value > 16) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: %d workgroups per CU", value);
             plan->interior_wg_per_cu = value;
             return GT4MI_OK;
+        case GT4MI_PLAN_TRANSPORT:
+            if (value != GT4MI_TRANSPORT_RCCL && value != GT4MI_TRANSPORT_DIRECT)
+                return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: transport %d", value);
+            if (value == GT4MI_TRANSPORT_DIRECT) {
+                if (!plan->direct.prepared)
+                    return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: prepare and connect the direct transport first "
+                                                                   "(gt4mi_halo_plan_direct_prepare / _connect)");
+                for (int ph = 0; ph < 2; ++ph) {
+                    for (size_t m = 0; m < plan->sends[ph].size(); ++m)
+                        if (!plan->direct.send_to[ph][m] || !plan->direct.signal_arrived[ph][m])
+                            return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: send %d of phase %d is not connected", (int)m, ph);
+                    for (size_t m = 0; m < plan->recvs[ph].size(); ++m)
+                        if (!plan->direct.signal_consumed[ph][m])
+                            return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: receive %d of phase %d is not connected", (int)m, ph);
+                }
+            }
+            plan->transport = value;
+            return GT4MI_OK;
     }
     return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: unknown option %d", option);
 }
@@ -527,8 +576,39 @@ int gt4mi_halo_plan_concurrent(gt4mi_halo_plan* plan) {
     return plan->probed ? (plan->concurrent ? 1 : 0) : 2;
 }
 
+int gt4mi_halo_plan_direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* info) {
+    if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_direct_prepare: null plan");
+    return gt4mi::direct_prepare(plan, info);
+}
+
+int gt4mi_halo_plan_direct_layout(gt4mi_halo_plan* plan, int phase, int is_send, int index, int64_t* pool_offset, int* flag_index) {
+    if (plan == nullptr || !plan->direct.prepared) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_direct_layout: not prepared");
+    if (phase < 0 || phase > 1) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_direct_layout: phase %d", phase);
+    const size_t n = is_send ? plan->sends[phase].size() : plan->recvs[phase].size();
+    if (index < 0 || (size_t)index >= n) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_direct_layout: message %d of %d", index, (int)n);
+    if (pool_offset) *pool_offset = is_send ? -1 : (int64_t)plan->direct.recv_offset[phase][index];
+    if (flag_index) *flag_index = gt4mi::direct_index(plan, is_send != 0, phase, index);
+    return GT4MI_OK;
+}
+
+int gt4mi_halo_plan_direct_connect(gt4mi_halo_plan* plan, int phase, int is_send, int index, const gt4mi_direct_info* peer,
+                                   int64_t peer_pool_offset, int peer_flag_index) {
+    if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_direct_connect: null plan");
+    return gt4mi::direct_connect(plan, phase, is_send, index, peer, peer_pool_offset, peer_flag_index);
+}
+
+int gt4mi_halo_plan_direct_status(gt4mi_halo_plan* plan, int* timed_out, unsigned* exchanges) {
+    if (plan == nullptr || !plan->direct.prepared) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_direct_status: not prepared");
+    uint32_t word = 0;
+    GT4MI_HIP_CHECK(hipMemcpy(&word, plan->direct.error, sizeof word, hipMemcpyDeviceToHost));  // (synchronises)
+    if (timed_out) *timed_out = (int)word;
+    if (exchanges) *exchanges = plan->direct.step;
+    return GT4MI_OK;
+}
+
 int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan) {
     if (plan == nullptr) return GT4MI_OK;
+    gt4mi::direct_release(plan);  // (the receive buffers of a prepared plan live in its pool)
     for (int ph = 0; ph < 2; ++ph) {
         for (auto& m : plan->sends[ph]) if (m.buffer) (void)hipFree(m.buffer);
         for (auto& m : plan->recvs[ph]) if (m.buffer) (void)hipFree(m.buffer);

@@ -31,8 +31,15 @@ class NativeComm:
     process group is initialised (any launcher would do); a single-process run needs no group.
     """
 
-    def __init__(self, rank: Optional[int] = None, world_size: Optional[int] = None, group=None):
+    def __init__(self, rank: Optional[int] = None, world_size: Optional[int] = None, group=None, rccl: bool = True):
         lib = _lib.load()
+        if not rccl:
+            # no RCCL communicator behind it (gt4mi_comm_create_local): for ranks RCCL cannot join -- two processes on ONE device,
+            # the rehearsal a 1-GPU box allows -- whose exchangers then use the direct transport only
+            handle = ctypes.c_void_p()
+            _lib.check("gt4mi_comm_create_local", lib.gt4mi_comm_create_local(int(world_size), int(rank), ctypes.byref(handle)))
+            self.rank, self.world_size, self._handle, self._lib = int(rank), int(world_size), handle, lib
+            return
         if rank is None or world_size is None:
             import torch.distributed as dist
 
@@ -134,6 +141,7 @@ class NativeHaloExchanger:
                                               RecvArr(*recvs), len(recvs), ctypes.byref(plan)))
         self._plan = plan
         self._lib = lib
+        self.transport = "rccl"
         nb = decomp.neighbours
         self.sides = ((1 if nb["W"] is not None else 0) | (2 if nb["E"] is not None else 0)
                       | (4 if nb["S"] is not None else 0) | (8 if nb["N"] is not None else 0))
@@ -149,7 +157,7 @@ class NativeHaloExchanger:
         limit); ``defer_join`` (chain schedule) lets a fused step return without joining the side stream -- for INDEPENDENT
         applies, whose results the caller consumes only after ``end()``.  ``None`` leaves an option as it is."""
         if schedule is not None:
-            value = {"join": _lib.SCHEDULE_JOIN, "chain": _lib.SCHEDULE_CHAIN, "swap": _lib.SCHEDULE_SWAP, "swap-packed": _lib.SCHEDULE_SWAP_PACKED,
+            value = {"join": _lib.SCHEDULE_JOIN, "chain": _lib.SCHEDULE_CHAIN, "swap": _lib.SCHEDULE_SWAP, "swap-packed": _lib.SCHEDULE_SWAP_PACKED, "inline": _lib.SCHEDULE_INLINE,
                      "default": -1}[schedule]
             _lib.check("gt4mi_halo_plan_set_option", self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_SCHEDULE, value))
         if interior_wg_per_cu is not None:
@@ -162,6 +170,104 @@ class NativeHaloExchanger:
             _lib.check("gt4mi_halo_plan_set_option",
                        self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_DEFER_JOIN, int(bool(defer_join))))
         return self
+
+    # ---- the direct transport: peer stores from the pack kernel instead of RCCL send/recv (csrc/direct.hip.h) ----
+    def use_direct_transport(self, group=None, all_gather=None) -> "NativeHaloExchanger":
+        """Switch this exchanger -- and every fused step built on it -- to the direct transport.  COLLECTIVE over the ranks of
+        the decomposition: every rank exports its pool of flag words and receive buffers (hipIpc), the descriptions travel
+        through ``torch.distributed.all_gather_object`` (``all_gather(obj) -> list``: any other channel; not needed when every
+        neighbour is the rank itself), and every message is connected to its counterpart by RCCL's matching rule: the k-th
+        send to a peer lands in the buffer of the k-th receive that peer posted for this rank.
+
+        A rank on which a step fails (no fine-grained device memory, a handle that cannot be opened) still takes part in
+        both rounds of the gather, so that EVERY rank raises ``RuntimeError`` together and stays on RCCL."""
+        lib, plan = self._lib, self._plan
+        sends, recvs = self.message_tables(self.decomp, self.single_phase)
+        rank = self.decomp.rank
+
+        def per_phase(table):
+            return [[m[0] for m in table if m[1] == p] for p in (0, 1)]  # peers, in plan order
+
+        def layout(is_send, phase, index):
+            off, flag = ctypes.c_int64(), ctypes.c_int()
+            _lib.check("gt4mi_halo_plan_direct_layout",
+                       lib.gt4mi_halo_plan_direct_layout(plan, phase, int(is_send), index, ctypes.byref(off), ctypes.byref(flag)))
+            return int(off.value), int(flag.value)
+
+        mine = {"rank": rank, "send_peers": per_phase(sends), "recv_peers": per_phase(recvs), "failure": None}
+        peers = {q for ph in mine["send_peers"] + mine["recv_peers"] for q in ph}
+        alone = peers <= {rank}
+        if not alone and all_gather is None:
+            import torch.distributed as dist
+
+            def all_gather(obj):
+                out = [None] * dist.get_world_size(group)
+                dist.all_gather_object(out, obj, group=group)
+                return out
+
+        try:
+            info = _lib.DirectInfo()
+            _lib.check("gt4mi_halo_plan_direct_prepare", lib.gt4mi_halo_plan_direct_prepare(plan, ctypes.byref(info)))
+            mine["info"] = bytes(info)
+            mine["recv_layout"] = [[layout(False, p, m) for m in range(len(mine["recv_peers"][p]))] for p in (0, 1)]
+            mine["send_flags"] = [[layout(True, p, m)[1] for m in range(len(mine["send_peers"][p]))] for p in (0, 1)]
+        except Exception as ex:  # noqa: BLE001 - reported to every rank below
+            mine["failure"] = f"rank {rank}: {ex}"
+        everyone = {rank: mine} if alone else {e["rank"]: e for e in all_gather(mine)}
+        failures = [e["failure"] for e in everyone.values() if e["failure"]]
+        keep = []  # the DirectInfo structures must outlive the connect calls only
+
+        def info_of(q):
+            if q == rank:
+                return None
+            peer = _lib.DirectInfo.from_buffer_copy(everyone[q]["info"])
+            keep.append(peer)
+            return ctypes.byref(peer)
+
+        def kth(peers_list, who, k):
+            """Index of the k-th entry equal to ``who``."""
+            seen = -1
+            for i, q in enumerate(peers_list):
+                seen += q == who
+                if q == who and seen == k:
+                    return i
+            raise RuntimeError(f"rank {who} has no message number {k} for rank {rank}: the message tables do not pair up")
+
+        mine_failure = None
+        if not failures:
+            try:
+                for p in (0, 1):
+                    for m, q in enumerate(mine["send_peers"][p]):
+                        k = mine["send_peers"][p][:m].count(q)
+                        j = kth(everyone[q]["recv_peers"][p], rank, k)
+                        off, flag = everyone[q]["recv_layout"][p][j]
+                        _lib.check("gt4mi_halo_plan_direct_connect",
+                                   lib.gt4mi_halo_plan_direct_connect(plan, p, 1, m, info_of(q), off, flag))
+                    for m, q in enumerate(mine["recv_peers"][p]):
+                        k = mine["recv_peers"][p][:m].count(q)
+                        j = kth(everyone[q]["send_peers"][p], rank, k)
+                        _lib.check("gt4mi_halo_plan_direct_connect",
+                                   lib.gt4mi_halo_plan_direct_connect(plan, p, 0, m, info_of(q), 0, everyone[q]["send_flags"][p][j]))
+            except Exception as ex:  # noqa: BLE001
+                mine_failure = f"rank {rank}: {ex}"
+        # (second round: nobody starts pushing before every rank has mapped its peers -- or everybody gives up together)
+        failures += [f for f in ([mine_failure] if alone else all_gather(mine_failure)) if f]
+        if failures:
+            raise RuntimeError("the direct halo transport is not available on every rank: " + "; ".join(sorted(set(failures))))
+        _lib.check("gt4mi_halo_plan_set_option", lib.gt4mi_halo_plan_set_option(plan, _lib.PLAN_TRANSPORT, _lib.TRANSPORT_DIRECT))
+        self.transport = "direct"
+        return self
+
+    def use_rccl_transport(self) -> "NativeHaloExchanger":
+        _lib.check("gt4mi_halo_plan_set_option", self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_TRANSPORT, _lib.TRANSPORT_RCCL))
+        self.transport = "rccl"
+        return self
+
+    def direct_status(self) -> dict:
+        """{"timed_out": a wait of the direct transport ever ran out of time (synchronises), "exchanges": started so far}."""
+        t, n = ctypes.c_int(), ctypes.c_uint()
+        _lib.check("gt4mi_halo_plan_direct_status", self._lib.gt4mi_halo_plan_direct_status(self._plan, ctypes.byref(t), ctypes.byref(n)))
+        return {"timed_out": bool(t.value), "exchanges": int(n.value)}
 
     def exchange(self, array) -> None:
         """Enqueue the exchange of ``array``'s ghost cells on the current stream."""

@@ -180,6 +180,9 @@ typedef struct gt4mi_halo_msg {
 
 int gt4mi_comm_unique_id(void* id128);
 int gt4mi_comm_create(const void* id128, int nranks, int rank, gt4mi_comm** comm);
+/* A communicator WITHOUT RCCL behind it (ranks that RCCL cannot join: two processes on one device; or no librccl at all):
+ * plans created on it move their messages through the direct transport only (gt4mi_halo_plan_direct_*). */
+int gt4mi_comm_create_local(int nranks, int rank, gt4mi_comm** comm);
 int gt4mi_comm_destroy(gt4mi_comm* comm);
 /* What RCCL reports for the communicator (ncclCommCount, ncclCommUserRank, ncclCommCuDevice); any pointer may be NULL.
  * Lets a benchmark line state how many ranks RCCL really joined. */
@@ -196,6 +199,9 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *                                   the end -- for shares so small that the chain, not the interior, is the critical path
  *                                   GT4MI_SCHEDULE_SWAP_PACKED: the same, the interior kernel forking off AFTER the pack (the
  *                                   pack of strided I faces runs alone, the send/recv kernel starts ahead of the interior)
+ *                                   GT4MI_SCHEDULE_INLINE: everything on the caller's stream, no event: pack, interior, the rest
+ *                                   of the exchange, ring -- made for the direct transport, whose pack kernel IS the transfer:
+ *                                   the faces travel while the interior kernel runs and the unpack finds them there
  *   GT4MI_PLAN_INTERIOR_WG_PER_CU   at most this many workgroups of the INTERIOR kernel per CU while the exchange runs
  *                                   next to it (0 = no limit): an HBM-saturating kernel at full occupancy keeps tens of MB
  *                                   in flight and the send/recv kernel beside it waits ~10 us per memory access
@@ -209,9 +215,35 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *                                   costs the memory system less than the 1 - 2 columns the stencil's reach requires, and the
  *                                   interior kernel keeps its 16-byte alignment
  * Which combination is fastest depends on the links; bench.py measures them (config.calibration_ms_per_apply). */
-enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1, GT4MI_PLAN_DEFER_JOIN = 2, GT4MI_PLAN_EDGE_COLUMNS = 3 };
-enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1, GT4MI_SCHEDULE_SWAP = 2, GT4MI_SCHEDULE_SWAP_PACKED = 3 };
+enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1, GT4MI_PLAN_DEFER_JOIN = 2, GT4MI_PLAN_EDGE_COLUMNS = 3,
+       GT4MI_PLAN_TRANSPORT = 4 };
+enum { GT4MI_TRANSPORT_RCCL = 0, GT4MI_TRANSPORT_DIRECT = 1 };
+enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1, GT4MI_SCHEDULE_SWAP = 2, GT4MI_SCHEDULE_SWAP_PACKED = 3,
+       GT4MI_SCHEDULE_INLINE = 4 };
 int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value);
+/* The DIRECT transport (GT4MI_PLAN_TRANSPORT = GT4MI_TRANSPORT_DIRECT; csrc/direct.hip.h): the pack kernel stores every face
+ * straight into the neighbour's receive buffer (mapped with hipIpcOpenMemHandle; the neighbour may be this rank itself, another
+ * process on this device, or another device of the node) and raises a flag there; the neighbour's unpack kernel waits for its
+ * flags.  No send/recv kernel, two launches per phase.  Set-up, once per plan, by the host side that knows who the peers are:
+ *   1. _direct_prepare on every rank: moves the plan's receive buffers into one exportable pool of fine-grained device memory
+ *      (its first page holds the flag words) and fills `info` -- plain bytes to hand to the peers over any channel;
+ *   2. _direct_layout: where receive (phase, index) sits in this rank's pool and which flag belongs to a message -- for the peers;
+ *   3. _direct_connect for every message: sends[phase][index] lands at `peer_pool_offset` of the peer's pool and raises the peer's
+ *      flag `peer_flag_index` (is_send = 1); after unpacking recvs[phase][index] this rank raises the SENDER's flag
+ *      `peer_flag_index` (is_send = 0).  The k-th send to a peer pairs with the k-th receive that peer posted for this rank (RCCL's
+ *      matching rule); `peer` = NULL: this rank itself;
+ *   4. gt4mi_halo_plan_set_option(plan, GT4MI_PLAN_TRANSPORT, GT4MI_TRANSPORT_DIRECT) after every rank has connected.
+ * _direct_status (synchronises): whether a wait ever ran out of time (2 s; the data of that exchange is then garbage). */
+typedef struct gt4mi_direct_info {
+    char pool_handle[64];  /* hipIpcMemHandle_t of the pool: a page of flag words, then the receive buffers */
+    int64_t pool_bytes, flag_words;
+    int32_t pid, device;
+} gt4mi_direct_info;
+int gt4mi_halo_plan_direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* info);
+int gt4mi_halo_plan_direct_layout(gt4mi_halo_plan* plan, int phase, int is_send, int index, int64_t* pool_offset, int* flag_index);
+int gt4mi_halo_plan_direct_connect(gt4mi_halo_plan* plan, int phase, int is_send, int index, const gt4mi_direct_info* peer,
+                                   int64_t peer_pool_offset, int peer_flag_index);
+int gt4mi_halo_plan_direct_status(gt4mi_halo_plan* plan, int* timed_out, unsigned* exchanges);
 /* 1 = the plan's side stream was verified to run concurrently with the caller's stream, 0 = no
  * concurrent stream could be found (the exchange still works, serialised), 2 = not probed yet.
  * HIP multiplexes streams onto a few hardware queues; the overlapped entry points probe on first use

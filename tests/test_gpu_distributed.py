@@ -962,3 +962,194 @@ def test_tridiagonal_solve_decomposes_without_any_exchange_on_the_device(grid):
                 got[k][sl] = args[k].get()
         for k in got:
             assert np.array_equal(got[k], want[k]), (apply.__name__, k)
+
+
+# ---- the direct transport: peer stores from the pack kernel (csrc/direct.hip.h) -----------------------------------------------
+@pytest.mark.parametrize("single_phase", [False, True])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("halo", [1, 2, 3])
+@pytest.mark.parametrize("periodic", [(True, True), (False, True), (True, False)])
+def test_direct_transport_exchange_on_the_self_loop(comm, periodic, halo, dtype, single_phase):
+    """Every neighbour the rank itself: after the exchange (pack kernel -> my own receive buffers, flags, unpack kernel) the
+    ghost cells hold the periodic wrap, for odd sizes (faces that are no whole 16-byte vectors) too, exchange after exchange
+    (the flags count up, the buffers are reused), and RCCL can be switched back on."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+
+    for gd in ((40, 36, 3), (131, 67, 5)):
+        dec = Decomposition(gd, (1, 1), 0, halo, periodic=periodic)
+        ex = NativeHaloExchanger(dec, dtype, comm, single_phase=single_phase).use_direct_transport()
+        assert ex.transport == "direct"
+        rng = np.random.default_rng(3)
+        for repeat in range(4):
+            host = rng.uniform(-1, 1, dec.local_shape).astype(dtype)
+            dev = gt_storage.from_array(host, dtype, backend="hip:mi300", aligned_index=dec.origin)
+            ex.exchange(dev)
+            torch.cuda.synchronize()
+            assert np.array_equal(dev.get(), _wrap(host, halo, *periodic)), (gd, repeat)
+        status = ex.direct_status()
+        assert status == {"timed_out": False, "exchanges": 4}
+        ex.use_rccl_transport()
+        dev = gt_storage.from_array(host, dtype, backend="hip:mi300", aligned_index=dec.origin)
+        ex.exchange(dev)
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.get(), _wrap(host, halo, *periodic))
+        ex.close()
+
+
+@pytest.mark.parametrize("schedule", ["join", "chain", "swap", "swap-packed", "inline"])
+@pytest.mark.parametrize("stencil", ["lap5", "hdiff"])
+def test_fused_steps_on_the_direct_transport(comm, stencil, schedule):
+    """The fused distributed steps with the faces pushed by the pack kernel: every schedule (also "inline": one stream, no
+    event), both message tables, bit-identical to the oracle on the wrapped field and to the RCCL transport; and the flat wide
+    domain whose interior is shorter than the exchange (a ring that did not wait for the unpack would read stale rows)."""
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from oracle import ref_numpy as R
+
+    h = 1 if stencil == "lap5" else 2
+    for gd, periodic in (((130, 70, 4), (True, True)), ((300, 40, 4), (False, True)), ((2048, 8, 96), (False, True))):
+        dec = Decomposition(gd, (1, 1), 0, h, periodic=periodic)
+        rng = np.random.default_rng(31)
+        host = rng.uniform(-1, 1, dec.local_shape)
+        wrapped = _wrap(host, h, *periodic)
+        want = np.zeros_like(host)
+        coeff_host = np.full(dec.local_shape, 0.1)
+        if stencil == "lap5":
+            R.laplacian(wrapped, want)
+        else:
+            R.hdiff(wrapped, want, coeff_host, domain=gd)
+        for single_phase in (False, True):
+            inp = gt_storage.from_array(host, backend="hip:mi300", aligned_index=dec.origin)
+            out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+            ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase).tune(schedule, 0).use_direct_transport()
+            if stencil == "lap5":
+                step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin)
+            else:
+                coeff = gt_storage.from_array(coeff_host, backend="hip:mi300", aligned_index=dec.origin)
+                step = ex.make_dist_hdiff(inp, out, coeff, dec.origin, _lib.HDIFF_LIMITER)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            assert np.array_equal(out.get(), want), (gd, single_phase)
+            assert np.array_equal(inp.get(), wrapped), (gd, single_phase)
+            assert ex.direct_status()["timed_out"] is False
+            ex.close()
+
+
+def _two_rank_direct_worker(rank: int, world: int, port: int, grid, periodic, tmpdir: str):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # (only carries the descriptions of the pools, and the results)
+    try:
+        torch.cuda.set_device(0)
+        import gt4py_amd.storage as gt_storage
+        from gt4py_amd import _lib
+        from gt4py_amd.distributed import Decomposition, FormCheck, NativeComm, NativeHaloExchanger, scatter_global
+        from gt4py_amd.cartesian import gtscript
+        from gt4py_amd.cartesian.backend import hip_templates
+        from oracle import ref_numpy as R
+
+        comm = NativeComm(rank=rank, world_size=world, rccl=False)  # RCCL cannot join two ranks on one device; no need to
+        assert comm.info() == {"nranks": world, "rank": rank, "device": 0}
+        rng = np.random.default_rng(4096)  # the same stream on every rank: the same global fields
+        checked = 0
+        for name, h, gd in (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5)), ("lap5", 1, (131, 67, 3))):
+            shape = (gd[0] + 2 * h, gd[1] + 2 * h, gd[2])
+            glob = rng.uniform(-10, 10, shape)
+            coeff = rng.uniform(0, 0.5, shape)
+            wrapped = glob.copy()  # the global field with its periodic wrap: what every rank's ghost cells must show
+            if periodic[0]:
+                wrapped[:h], wrapped[-h:] = wrapped[-2 * h:-h].copy(), wrapped[h:2 * h].copy()
+            if periodic[1]:
+                wrapped[:, :h], wrapped[:, -h:] = wrapped[:, -2 * h:-h].copy(), wrapped[:, h:2 * h].copy()
+            want = np.zeros_like(glob)
+            if name == "hdiff":
+                R.hdiff(wrapped, want, coeff, domain=gd)
+            else:
+                R.laplacian(wrapped, want)
+            dec = Decomposition(gd, grid, rank, h, periodic=periodic)
+            results = {}
+            for single_phase in (False, True):
+                for schedule in ("join", "chain", "swap", "swap-packed", "inline"):
+                    blk = scatter_global(wrapped, dec).copy()
+                    mine = blk.copy()
+                    nb = dec.neighbours  # ghost cells that belong to a neighbour must come from the exchange
+                    for side, sl in (("W", np.s_[:h]), ("E", np.s_[-h:]), ("S", np.s_[:, :h]), ("N", np.s_[:, -h:])):
+                        if nb[side] is not None:
+                            mine[sl] = np.nan
+                    inp = gt_storage.from_array(mine, backend="hip:mi300", aligned_index=dec.origin)
+                    out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+                    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase).tune(schedule, 0)
+                    with pytest.raises(RuntimeError, match="no RCCL behind it"):
+                        ex.exchange(inp)  # this communicator cannot fall back to send/recv
+                    ex.use_direct_transport()  # collective: the pools' descriptions travel over gloo, the faces never do
+                    if name == "hdiff":
+                        cf = gt_storage.from_array(scatter_global(coeff, dec), backend="hip:mi300", aligned_index=dec.origin)
+                        step = ex.make_dist_hdiff(inp, out, cf, dec.origin, _lib.HDIFF_LIMITER)
+                    else:
+                        step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin)
+                    for _ in range(3):  # (the flags count up; the peer's buffers are reused)
+                        step()
+                    torch.cuda.synchronize()
+                    assert np.array_equal(inp.get(), blk), (name, schedule, single_phase, "ghost cells")
+                    assert ex.direct_status()["timed_out"] is False
+                    results[(single_phase, schedule)] = out.get()[h:-h, h:-h].copy()
+                    dist.barrier()  # nobody unmaps a pool the other still pushes into
+                    ex.close()
+                    checked += 1
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (dec.global_slices(with_halo=False), results))
+            if rank == 0:
+                for key in gathered[0][1]:
+                    got = np.zeros_like(glob)
+                    for sl, res in gathered:
+                        got[sl] = res[key]
+                    assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h]), (name, key)
+        # the self-check bench.py runs on every form, here between two processes
+        dec = Decomposition((96, 80, 6), grid, rank, 1, periodic=periodic)
+        lap = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64}, device_sync=False)
+        fr = lap.freeze(origin={"inp": dec.origin, "out": dec.origin}, domain=dec.local_domain)
+        chk = FormCheck(dec, lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin),
+                        lambda a, b: fr(inp=a, out=b))
+        ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=True).tune("inline", 0).use_direct_transport()
+        fused = ex.make_dist_lap5(chk.probe, chk.out, dec.origin, dec.origin)
+        chk.reset()
+        fused()
+        assert chk.verdict()[0], chk.verdict()[1]
+        dist.barrier()
+        ex.close()
+        comm.close()
+        if rank == 0:
+            np.save(os.path.join(tmpdir, "ok.npy"), np.array([checked]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,periodic", [((1, 2), (False, False)), ((2, 1), (False, False)), ((1, 2), (True, True)), ((2, 1), (True, True))])
+def test_two_processes_push_faces_into_each_other_on_one_gpu(grid, periodic, tmp_path):
+    """TWO REAL RANKS of the native path on the one device of the box -- what RCCL refuses to do.  Each process exports its pool
+    of flag words and receive buffers (hipIpcGetMemHandle) and maps the other's (hipIpcOpenMemHandle); the pack kernel of one
+    process stores its faces into the OTHER process's memory and raises the flag there, the other's unpack kernel waits for
+    it.  Horizontal diffusion (ghost depth 2, corners) and the Laplacian, every schedule of the fused steps, both message
+    tables, bounded and periodic (then each rank is also its own neighbour along the uncut axis, and the same peer twice
+    along the cut one); the assembled results equal the oracle on the undecomposed field, every rank's ghost cells the global
+    field's values, and no wait ever times out."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_two_rank_direct_worker, args=(2, port, grid, periodic, str(tmp_path)), nprocs=2, join=True)
+    assert int(np.load(tmp_path / "ok.npy")[0]) == 30

@@ -813,7 +813,7 @@ def _setup_distributed_laplacian(args, ctx):
             grids = [grid] if (selfloop or pinned_grid) else process_grid_candidates(world, total, 1)
             for cand_grid in grids:
                 for cand_single in ((single_phase,) if "GT4MI_BENCH_SINGLE_PHASE" in os.environ else (False, True)):
-                    for cand_schedule in ("join", "chain", "swap", "swap-packed"):
+                    for cand_schedule in ("join", "chain", "swap", "swap-packed", "inline"):
                         for cand_wg in (0, 4, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
                             for cand_transport in transports:
                                 def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg,
@@ -906,16 +906,16 @@ def _setup_distributed_laplacian(args, ctx):
         plan and side stream, so the interior of apply i + 1 runs next to the exchange and ring of apply i; every apply
         still exchanges its own input's ghost cells.  ms per apply, slowest rank."""
         table = {}
-        for cand_wg in (0, 4, 2):
-            def make(cand_wg=cand_wg):
-                call, keep = apply_candidate(grid, single_phase, "chain", cand_wg)
+        for cand_wg, cand_transport in [(w, t) for w in (0, 4, 2) for t in transports]:
+            def make(cand_wg=cand_wg, cand_transport=cand_transport):
+                call, keep = apply_candidate(grid, single_phase, "chain", cand_wg, cand_transport)
                 for ex in keep[2]:
                     ex.tune(defer_join=True)
                 return call, (lambda: [(ex.end(), ex.close()) for ex in keep[2]])
 
             ms = measure_candidate(ctx, make, 48)
             if ms is not None:
-                table[f"chain_wg{cand_wg}"] = ms
+                table[f"chain_wg{cand_wg}_{cand_transport}"] = ms
         torch.cuda.empty_cache()
         return table
 
@@ -1058,6 +1058,8 @@ def _setup_hdiff2048(args, ctx):
                 else:
                     ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(parts[3], int(parts[4][2:]),
                                                                                               edge_columns=int(parts[5][4:]))
+                    if parts[6:] == ["direct"]:  # peer stores from the pack kernel instead of RCCL send/recv (collective; raises on
+                        ex.use_direct_transport()  # EVERY rank when some rank cannot: measure_candidate then drops the form)
                     probe_apply = ex.make_dist_hdiff(chk.probe, chk.out, fields["coeff"], dec.origin, flags)
                     fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
 
@@ -1113,9 +1115,10 @@ def _setup_hdiff2048(args, ctx):
                 for table in ("two_phase", "single_phase"):
                     # (the "swap" schedules exist for this step too and are 4-6 % slower than "chain" on the self-loop: here the
                     # interior kernel, not the chain, is the critical path -- GT4MI_BENCH_HDIFF_SCHEDULES adds them)
-                    schedules = tuple(os.environ.get("GT4MI_BENCH_HDIFF_SCHEDULES", "join,chain").split(","))
-                    names += [f"fused_{table}_{sched}_wg{wg}_edge{edge}" for sched in schedules
-                              for wg in (0, 3, 2) for edge in edge_candidates]
+                    schedules = tuple(os.environ.get("GT4MI_BENCH_HDIFF_SCHEDULES", "join,chain,inline").split(","))
+                    names += [f"fused_{table}_{sched}_wg{wg}_edge{edge}" + ("_direct" if tr == "direct" else "") for sched in schedules
+                              for wg in (0, 3, 2) for edge in edge_candidates
+                              for tr in os.environ.get("GT4MI_BENCH_TRANSPORTS", "rccl,direct").split(",")]
                     names.append(f"sequential_{table}")
                 pinned = os.environ.get("GT4MI_BENCH_FORM")
                 dog.arm(300, "calibration of the apply forms")
@@ -1189,16 +1192,19 @@ def _setup_hdiff2048(args, ctx):
         flags = type(hd)._gt_binding_.flags
         for single in (False, True):
             for cand_wg in (0, 3, 2):
-                for cand_edge in (2, 16, 32):
-                    def make(single=single, cand_wg=cand_wg, cand_edge=cand_edge):
+                for cand_edge, cand_transport in [(e, t) for e in (2, 16, 32)
+                                                  for t in os.environ.get("GT4MI_BENCH_TRANSPORTS", "rccl,direct").split(",")]:
+                    def make(single=single, cand_wg=cand_wg, cand_edge=cand_edge, cand_transport=cand_transport):
                         ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune("chain", cand_wg, defer_join=True,
                                                                                                   edge_columns=cand_edge)
+                        if cand_transport == "direct":
+                            ex.use_direct_transport()
                         fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
                         return fn, (lambda: (ex.end(), ex.close()))
 
                     ms = measure_candidate(ctx, make, 32)
                     if ms is not None:
-                        table[f"{'single' if single else 'two'}_phase_chain_wg{cand_wg}_edge{cand_edge}"] = ms
+                        table[f"{'single' if single else 'two'}_phase_chain_wg{cand_wg}_edge{cand_edge}_{cand_transport}"] = ms
         if not table:
             return None
         best = min(table, key=table.get)

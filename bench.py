@@ -931,17 +931,20 @@ def _setup_distributed_laplacian(args, ctx):
                                   or grid[0] > 1 and total[0] // grid[0] < 2 * (2 * cand_halo - 1)):
                 continue
             cdec = Decomposition(total, grid, rank, halo=cand_halo, periodic=periodic)
-            for stepper in ("skewed_join", "skewed_chain", "skewed_chain_wg4", "wide_overlap", "wide_sequential"):
+            for stepper, cand_transport in [(st, t) for st in ("skewed_join", "skewed_chain", "skewed_chain_wg4", "wide_overlap",
+                                                               "wide_sequential") for t in transports]:
                 if not stepper.startswith("skewed") and cand_halo == 3:
                     continue
                 per_call = cand_halo if stepper.startswith("skewed") else 1
 
-                def make(stepper=stepper, cdec=cdec):
+                def make(stepper=stepper, cdec=cdec, cand_transport=cand_transport):
                     cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=7 + rank, origin=cdec.origin)
                     ca, cb = cpairs[0][0], cpairs[1][0]
                     ca.tensor.mul_(1e-150)
                     cb.tensor.copy_(ca.tensor)
                     cex = NativeHaloExchanger(cdec, np.float64, comm, single_phase=single_phase)
+                    if cand_transport == "direct":
+                        cex.use_direct_transport()
                     if stepper.startswith("skewed"):
                         cex.tune("chain" if "chain" in stepper else "join", 4 if stepper.endswith("wg4") else 0)
                         fn = cex.make_time_skewed_lap5(ca, cb, cdec.origin)
@@ -952,7 +955,7 @@ def _setup_distributed_laplacian(args, ctx):
                 calls = max(24 // per_call, 6) if per_call > 1 else 24
                 ms = measure_candidate(ctx, make, calls, warm=2 * (cand_halo if per_call == 1 else 1))
                 if ms is not None:
-                    table[f"{stepper}_halo{cand_halo}"] = round(ms / per_call, 5)
+                    table[f"{stepper}_halo{cand_halo}_{cand_transport}"] = round(ms / per_call, 5)
         torch.cuda.empty_cache()
         lups = float(np.prod(dec.global_domain))
         out = {}

@@ -217,11 +217,12 @@ def test_pipelined_time_stepping(comm, periodic):
                                                                0, ex2.sides, None))
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("nsteps", [1, 4, 7])
 @pytest.mark.parametrize("halo", [1, 2, 3, 4])
 @pytest.mark.parametrize("periodic", [(False, True), (True, True)])
-def test_wide_halo_time_stepping(comm, periodic, halo, nsteps, overlap):
+def test_wide_halo_time_stepping(comm, periodic, halo, nsteps, overlap, direct):
     """gt4mi_dist_lap5_f64_wide: ghost regions `halo` deep, one exchange per `halo` steps, redundant
     rows computed in between; the compute domain after n steps equals n oracle steps with a fresh
     periodic wrap every step."""
@@ -239,6 +240,8 @@ def test_wide_halo_time_stepping(comm, periodic, halo, nsteps, overlap):
     a = gt_storage.from_array(host, backend="hip:mi300", aligned_index=o)
     b = gt_storage.from_array(host * 0 + 7.0, backend="hip:mi300", aligned_index=o)
     ex = NativeHaloExchanger(dec, np.float64, comm)
+    if direct:  # the faces pushed by the pack kernel instead of RCCL send/recv
+        ex.use_direct_transport()
     step = ex.make_time_stepper_lap5(a, b, o, overlap=overlap)
     for _ in range(nsteps):
         step()
@@ -509,11 +512,12 @@ def inspect_signature_names(stencil):
     return inspect.signature(stencil.definition_func).parameters
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("single_phase", [False, True])
 @pytest.mark.parametrize("halo", [1, 2, 3])
 @pytest.mark.parametrize("periodic", [(False, True), (True, True), (True, False)])
 @pytest.mark.parametrize("gd", [(48, 40, 4), (130, 36, 3)])
-def test_time_skewed_stepping(comm, gd, periodic, halo, single_phase):
+def test_time_skewed_stepping(comm, gd, periodic, halo, single_phase, direct):
     """gt4mi_dist_lap5_f64_skewed: per cycle the bands of steps 1 .. H, then the exchange next to the H interior kernels;
     after n cycles the compute domain equals n * H oracle steps with a fresh periodic wrap every step."""
     import torch
@@ -532,6 +536,8 @@ def test_time_skewed_stepping(comm, gd, periodic, halo, single_phase):
     # them from the initial scatter of the global array; on the periodic self-loop they are the wrapped images).
     b = gt_storage.from_array(_wrap(host, halo, *periodic), backend="hip:mi300", aligned_index=o)
     ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase)
+    if direct:
+        ex.use_direct_transport()
     cycle = ex.make_time_skewed_lap5(a, b, o)
     assert cycle.steps_per_call == halo
     ncycles = 3

@@ -167,10 +167,17 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
                     ex = HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank), single_phase=single)
                     record(f"torch {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: ex}))
                     record(f"torch {table} overlapped", lambda: overlapped_apply(stencil, dec, origin, fields, {names[0]: ex}))
-                if comm is not None:
+                for how in (("rccl", "direct") if comm is not None else ()):
                     nex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single)
-                    record(f"native {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: nex}))
-                    for schedule in ("join", "chain", "swap", "swap-packed"):
+                    if how == "direct":  # peer stores from the pack kernel (csrc/direct.hip.h); collective, all ranks fail together
+                        try:
+                            nex.use_direct_transport()
+                        except RuntimeError as ex:
+                            results.append((f"halo {halo} grid {grid[0]}x{grid[1]} native/direct {table}: set-up", False, str(ex)))
+                            nex.close()
+                            continue
+                    record(f"native/{how} {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: nex}))
+                    for schedule in ("join", "chain", "swap", "swap-packed", "inline"):
                         for wg in (0, 2):
                             nex.tune(schedule, wg)
                             fused = (nex.make_dist_lap5(chk.probe, chk.out, dec.origin, dec.origin) if halo == 1 else
@@ -180,7 +187,11 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
                                 fused()
                                 nex.end()
 
-                            record(f"native {table} fused {schedule} wg{wg}", run)
+                            record(f"native/{how} {table} fused {schedule} wg{wg}", run)
+                    if how == "direct" and nex.direct_status()["timed_out"]:
+                        results.append((f"halo {halo} grid {grid[0]}x{grid[1]} native/direct {table}: waits", False, "a wait ran out of time"))
+                    if world > 1:
+                        dist.barrier()  # nobody unmaps a pool a peer may still push into
                     nex.close()
             del chk
     finally:

@@ -920,7 +920,7 @@ def test_selfcheck_command_line_under_torchrun(tmp_path):
     import sys
 
     root = pathlib.Path(__file__).resolve().parent.parent
-    for extra, checks in ((["--periodic", "--transport", "native"], 36), ([], 44)):
+    for extra, checks in ((["--periodic", "--transport", "native"], 88), ([], 96)):
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
@@ -933,6 +933,7 @@ def test_selfcheck_command_line_under_torchrun(tmp_path):
         assert len(lines) == checks and not any("WRONG" in ln for ln in lines), proc.stdout[-3000:]
         assert "all correct" in proc.stdout
         assert any("fused swap-packed wg2" in ln for ln in lines) and any("halo 2" in ln and "fused chain" in ln for ln in lines)
+        assert any("native/direct single-phase fused inline wg0" in ln for ln in lines)
 
 
 @pytest.mark.parametrize("grid", [(4, 2), (1, 8)])

@@ -13,6 +13,8 @@
 // xGMI is point-to-point, messages are <= 2 MB: the exchange is latency-bound, every neighbour uses
 // its own link, and there is no collective on the path.
 //
+// A second transport needs no RCCL at all: direct.hip.h (peer stores from the pack kernel into hipIpc-mapped receive buffers).
+//
 // librccl is resolved with dlopen at first use (the copy PyTorch already loaded is reused when
 // present), so the stencil library itself loads on machines without RCCL.
 #pragma once

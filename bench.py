@@ -1444,6 +1444,10 @@ def main() -> None:
     exchangers = extras.get("exchangers") or []
     if exchangers and isinstance(exchangers[0], NativeHaloExchanger):
         config["side_stream_concurrent"] = exchangers[0].concurrent
+        if getattr(exchangers[0], "transport", "rccl") == "direct":  # (a wait that ran out of time means garbage was timed)
+            status = [ex.direct_status() for ex in exchangers]
+            config["direct_transport_status"] = {"timed_out": any(st["timed_out"] for st in status),
+                                                 "exchanges": sum(st["exchanges"] for st in status)}
     timestep = None
     _test_hang(dog, "informational")
     if callable(extras.get("timestep")):  # collective: every rank runs it

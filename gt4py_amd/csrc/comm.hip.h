@@ -130,7 +130,6 @@ struct gt4mi_halo_plan {
         size_t pool_bytes = 0;
         std::vector<size_t> recv_offset[2];
         uint32_t* flags = nullptr;          // my flag words = the first page of the pool: [arrived: one per receive][consumed: one per send]
-        unsigned* counters = nullptr;       // device: finished blocks per message (push: per send, unpack: per receive)
         uint32_t* error = nullptr;          // device: a wait ran out of time
         uint32_t step = 0;                  // exchanges started
         bool first_pushed = false;          // halo_pack_first already pushed the first phase of exchange `step`

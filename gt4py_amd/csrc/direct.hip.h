@@ -251,11 +251,10 @@ inline int direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* out) {
                 if (plan->recvs[p][m].buffer) (void)hipFree(plan->recvs[p][m].buffer);
                 plan->recvs[p][m].buffer = dx.pool + dx.recv_offset[p][m];
             }
-        void* words = nullptr;
-        GT4MI_HIP_CHECK(hipMalloc(&words, (nflags + 1) * sizeof(unsigned)));
-        GT4MI_HIP_CHECK(hipMemset(words, 0, (nflags + 1) * sizeof(unsigned)));
-        dx.counters = static_cast<unsigned*>(words);
-        dx.error = reinterpret_cast<uint32_t*>(dx.counters + nflags);
+        void* word = nullptr;
+        GT4MI_HIP_CHECK(hipMalloc(&word, sizeof(uint32_t)));
+        GT4MI_HIP_CHECK(hipMemset(word, 0, sizeof(uint32_t)));
+        dx.error = static_cast<uint32_t*>(word);
         for (int p = 0; p < 2; ++p) {
             dx.send_to[p].assign(plan->sends[p].size(), nullptr);
             dx.signal_arrived[p].assign(plan->sends[p].size(), nullptr);
@@ -343,7 +342,7 @@ inline void direct_release(gt4mi_halo_plan* plan) {
     for (auto& p : dx.peers)
         if (p.opened_pool) (void)hipIpcCloseMemHandle(p.pool);
     dx.peers.clear();
-    if (dx.counters) (void)hipFree(dx.counters);
+    if (dx.error) (void)hipFree(dx.error);
     for (int p = 0; p < 2; ++p)
         for (auto& m : plan->recvs[p]) m.buffer = nullptr;  // they lived in the pool
     if (dx.pool) (void)hipFree(dx.pool);

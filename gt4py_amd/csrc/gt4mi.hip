@@ -221,8 +221,9 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
         gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 0)));
         return run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j, st);
     };
-    // default: swap -- the fastest of the four on every share of 8 ranks measured (1 x 8, 2 x 4, 4 x 2)
-    const int schedule = gt4mi::plan_schedule(plan, GT4MI_SCHEDULE_SWAP);
+    // default: the fastest on every share of 8 ranks measured (1 x 8, 2 x 4, 4 x 2) -- "swap" with RCCL,
+    // "inline" when the pack kernel is the transfer (direct transport)
+    const int schedule = gt4mi::plan_schedule(plan, plan->transport == GT4MI_TRANSPORT_DIRECT ? GT4MI_SCHEDULE_INLINE : GT4MI_SCHEDULE_SWAP);
     if (schedule == GT4MI_SCHEDULE_INLINE) {
         // ONE stream, no event: pack (with the direct transport: the faces are on their way when it ends), the interior kernel,
         // then whatever is left of the exchange (direct: the unpack, whose data arrived long ago) and the ring

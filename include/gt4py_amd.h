@@ -264,7 +264,7 @@ int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream);
 /* One distributed apply of a 5-point stencil in a single call: exchange of `inp`'s halo (width 1)
  * overlapped with the interior kernel, then the boundary strips.  `sides` = bit mask of the sides
  * that have a neighbour: 1 = low I (W), 2 = high I (E), 4 = low J (S), 8 = high J (N).  Schedule (GT4MI_PLAN_SCHEDULE):
- * default GT4MI_SCHEDULE_SWAP; whatever the schedule, work enqueued on `main_stream` after the call sees the whole result
+ * default GT4MI_SCHEDULE_SWAP (GT4MI_SCHEDULE_INLINE on the direct transport); whatever the schedule, work enqueued on `main_stream` after the call sees the whole result
  * (unless GT4MI_PLAN_DEFER_JOIN says otherwise). */
 int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int sides, void* main_stream);

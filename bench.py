@@ -815,6 +815,8 @@ def _setup_distributed_laplacian(args, ctx):
                 for cand_single in ((single_phase,) if "GT4MI_BENCH_SINGLE_PHASE" in os.environ else (False, True)):
                     for cand_schedule in ("join", "chain", "swap", "swap-packed", "inline"):
                         for cand_wg in (0, 4, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
+                            if cand_schedule == "inline" and cand_wg:
+                                continue  # (nothing runs beside the interior kernel there: nothing to throttle it for)
                             for cand_transport in transports:
                                 def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg,
                                          cand_transport=cand_transport):

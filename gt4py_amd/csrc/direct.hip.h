@@ -65,12 +65,11 @@ __device__ __forceinline__ u32x4 direct_load(const u32x4* where) {
 // data has arrived).  Next to an HBM-saturating interior kernel every DEPENDENT memory round trip costs ~10 us, so the kernel
 // has two of them: (flag poll || loads), then the stores; the signal is a posted add.
 template <typename U, bool PACK>
-__global__ void __launch_bounds__(256)
-halo_direct_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b, DirectBatch d) {
+__device__ __forceinline__ void direct_block(U* field, int64_t si, int64_t sj, int64_t sk, const BoxBatch& b, const DirectBatch& d,
+                                             const int m, const unsigned block) {
     constexpr int UNROLL = DIRECT_UNROLL;
     constexpr int PER_VEC = 16 / (int)sizeof(U);
-    const int m = blockIdx.y;
-    if (blockIdx.x >= d.blocks[m]) return;
+    if (block >= d.blocks[m]) return;
     __shared__ int ready;
     const int ei_items = b.ext[m][0], ej = b.ext[m][1], ek = b.ext[m][2];
     const int64_t n = (int64_t)ei_items * ej * ek, nv = n / PER_VEC;  // items, whole 16-byte vectors of the dense buffer
@@ -90,7 +89,7 @@ halo_direct_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b, Dir
     };
     union Vec { u32x4 v; U item[PER_VEC]; };
     Vec x[UNROLL];
-    const int64_t tv0 = (int64_t)blockIdx.x * DIRECT_VECTORS_PER_BLOCK + threadIdx.x;
+    const int64_t tv0 = (int64_t)block * DIRECT_VECTORS_PER_BLOCK + threadIdx.x;
     auto load_all = [&]() {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -144,7 +143,7 @@ halo_direct_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b, Dir
             for (int e = 0; e < PER_VEC; ++e) *item_at(tv * PER_VEC + e) = x[u].item[e];
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < n - nv * PER_VEC) {  // the few items behind the last whole vector
+    if (block == 0 && threadIdx.x < n - nv * PER_VEC) {  // the few items behind the last whole vector
         U* buf = static_cast<U*>(b.buffer[m]);
         const int64_t t = nv * PER_VEC + threadIdx.x;
         if constexpr (PACK) __hip_atomic_store(buf + t, *item_at(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -158,24 +157,30 @@ halo_direct_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b, Dir
     if (threadIdx.x == 0) __hip_atomic_fetch_add(d.signal_flag[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // posted
 }
 
+template <typename U, bool PACK>
+__global__ void __launch_bounds__(256)
+halo_direct_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b, DirectBatch d) {
+    direct_block<U, PACK>(field, si, sj, sk, b, d, (int)blockIdx.y, blockIdx.x);
+}
+
 inline int direct_index(const gt4mi_halo_plan* plan, bool is_send, int phase, int m) {
     const size_t nr0 = plan->recvs[0].size(), nr = nr0 + plan->recvs[1].size(), ns0 = plan->sends[0].size();
     return is_send ? (int)(nr + (phase ? ns0 : 0) + m) : (int)((phase ? nr0 : 0) + m);
 }
 
+// The boxes and flags of one phase's pack (PACK) or unpack launch; `blocks` = workgroups per box of the launch (0: nothing to do).
 template <typename U, bool PACK>
-inline int direct_copy(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase, hipStream_t s) {
+inline int direct_batches(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase, BoxBatch& b, DirectBatch& d, int64_t& blocks) {
     const auto& msgs = PACK ? plan->sends[phase] : plan->recvs[phase];
+    blocks = 0;
+    b.n = 0;
     if (msgs.empty()) return GT4MI_OK;
     if ((int)msgs.size() > BoxBatch::MAX) return fail(GT4MI_ERR_UNSUPPORTED, "halo: more than %d boxes per phase", BoxBatch::MAX);
     auto& dx = plan->direct;
-    BoxBatch b;
-    DirectBatch d;
     b.n = (int)msgs.size();
     constexpr int64_t PER_VEC = 16 / (int64_t)sizeof(U);
     const bool field_vec = f->stride[0] == (int64_t)sizeof(U) && f->stride[1] % 16 == 0 && f->stride[2] % 16 == 0 &&
                            reinterpret_cast<uintptr_t>(f->data) % 16 == 0;
-    int64_t blocks = 0;
     for (int m = 0; m < b.n; ++m) {
         int64_t off = 0, n = 1;
         for (int a = 0; a < 3; ++a) {
@@ -204,6 +209,16 @@ inline int direct_copy(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase, h
         blocks = nb > blocks ? nb : blocks;
     }
     d.error = dx.error;
+    return GT4MI_OK;
+}
+
+template <typename U, bool PACK>
+inline int direct_copy(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase, hipStream_t s) {
+    BoxBatch b;
+    DirectBatch d;
+    int64_t blocks = 0;
+    if (int rc = direct_batches<U, PACK>(plan, f, phase, b, d, blocks)) return rc;
+    if (blocks == 0) return GT4MI_OK;
     hipLaunchKernelGGL((halo_direct_kernel<U, PACK>), dim3((unsigned)blocks, (unsigned)b.n), dim3(256), 0, s,
                        static_cast<U*>(f->data), f->stride[0] / (int64_t)sizeof(U), f->stride[1] / (int64_t)sizeof(U),
                        f->stride[2] / (int64_t)sizeof(U), b, d);

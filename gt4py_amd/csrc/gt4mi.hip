@@ -13,6 +13,7 @@
 #include "hdiff.hip.h"
 #include "hdiff_ring.hip.h"
 #include "lap5.hip.h"
+#include "lap5_push.hip.h"
 #include "lap5_ring.hip.h"
 #include "rtc.hip.h"
 #include "tridiag.hip.h"
@@ -228,8 +229,26 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
         // ONE stream, no event: pack (with the direct transport: the faces are on their way when it ends), the interior kernel,
         // then whatever is left of the exchange (direct: the unpack, whose data arrived long ago) and the ring
         if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
-        if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
-        if (int rc = interior(ms)) return rc;
+        bool fused = false;
+        const int p0 = gt4mi::first_phase(plan);
+        if (plan->transport == GT4MI_TRANSPORT_DIRECT && p0 < 2) {
+            // ... and with the direct transport the push rides in the interior's launch (lap5_push.hip.h): 8-9 us off the step
+            gt4mi_field a = *inp, b = *out;
+            a.origin[0] += lo_i; a.origin[1] += lo_j;
+            b.origin[0] += lo_i; b.origin[1] += lo_j;
+            const int64_t sub[3] = {di - lo_i - hi_i, dj - lo_j - hi_j, dk};
+            ++plan->direct.step;  // (what halo_pack_first does on this transport)
+            if (int rc = gt4mi::lap5_interior_with_push<T, W>(plan, sub, &a, &b, variant, inp, p0, ms, &fused)) {
+                --plan->direct.step;
+                return rc;
+            }
+            if (fused) plan->direct.first_pushed = true;
+            else --plan->direct.step;
+        }
+        if (!fused) {
+            if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
+            if (int rc = interior(ms)) return rc;
+        }
         if (int rc = gt4mi::halo_exchange_on(plan, inp, ms, /*first_pack_done=*/true)) return rc;
         return gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, ms);
     }

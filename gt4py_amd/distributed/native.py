@@ -195,8 +195,9 @@ class NativeHaloExchanger:
             return int(off.value), int(flag.value)
 
         mine = {"rank": rank, "send_peers": per_phase(sends), "recv_peers": per_phase(recvs), "failure": None}
-        peers = {q for ph in mine["send_peers"] + mine["recv_peers"] for q in ph}
-        alone = peers <= {rank}
+        # (decided by the process grid, which every rank knows alike -- not by this rank's own neighbours: the gathers below are
+        # collective)
+        alone = self.decomp.grid[0] * self.decomp.grid[1] == 1
         if not alone and all_gather is None:
             import torch.distributed as dist
 

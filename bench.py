@@ -736,7 +736,10 @@ def _setup_distributed_laplacian(args, ctx):
             chk.reset()
             probe_apply()
             cex[0].end()
-            return chk.verdict()
+            good, found = chk.verdict()
+            if cand_transport == "direct" and cex[0].direct_status()["timed_out"]:
+                good, found = False, "a wait of the direct transport ran out of time; " + found
+            return good, found
 
         return call, (cdec, cpairs, cex, bound, check)
 
@@ -818,6 +821,10 @@ def _setup_distributed_laplacian(args, ctx):
                             if cand_schedule == "inline" and cand_wg:
                                 continue  # (nothing runs beside the interior kernel there: nothing to throttle it for)
                             for cand_transport in transports:
+                                if cand_transport == "direct" and ctx.get("direct_dropped"):
+                                    continue  # (one form on it was wrong, timed out or could not be set up: every wait of a broken
+                                    #            transport costs 2 s -- the rest of the calibration stays on RCCL, on every rank alike)
+
                                 def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg,
                                          cand_transport=cand_transport):
                                     call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg, cand_transport)
@@ -828,6 +835,8 @@ def _setup_distributed_laplacian(args, ctx):
                                 ms = measure_candidate(ctx, make, 24)
                                 if ms is not None:
                                     table[key] = ms
+                                elif cand_transport == "direct":
+                                    ctx["direct_dropped"] = key
             torch.cuda.empty_cache()
         except Exception as ex:
             ok = 0
@@ -992,7 +1001,7 @@ def _setup_distributed_laplacian(args, ctx):
               "schedule": schedule if transport == "native" else "join", "interior_workgroups_per_cu": wg_per_cu,
               "halo_transport": (halo_transport + (" (peer stores from the pack kernel, flags in the receiver's memory; no send/recv kernel)"
                                                    if halo_transport == "direct" else " (send/recv)")) if transport == "native" else "torch",
-              "calibration_ms_per_apply": calibration, "verified": verified}
+              "calibration_ms_per_apply": calibration, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped")}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
               "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback}
     return step, kernel_step, dec.local_domain, config, extras
@@ -1072,7 +1081,10 @@ def _setup_hdiff2048(args, ctx):
                     chk.reset()
                     probe_apply()
                     ex.end()
-                    return chk.verdict()
+                    good, found = chk.verdict()
+                    if parts[6:] == ["direct"] and ex.direct_status()["timed_out"]:
+                        good, found = False, "a wait of the direct transport ran out of time; " + found
+                    return good, found
 
                 return fn, ex, check
 
@@ -1130,6 +1142,8 @@ def _setup_hdiff2048(args, ctx):
                 ok, timings = 1, {}
                 try:
                     for name in names:
+                        if name.endswith("_direct") and ctx.get("direct_dropped"):
+                            continue  # (see _setup_distributed_laplacian)
                         if pinned is None or pinned == name:
                             def make(name=name):
                                 fn, ex, check = make_form(name)
@@ -1138,6 +1152,8 @@ def _setup_hdiff2048(args, ctx):
                             ms = measure_candidate(ctx, make, 16)
                             if ms is not None:
                                 timings[name] = ms
+                            elif name.endswith("_direct"):
+                                ctx["direct_dropped"] = name
                 except Exception as exn:
                     ok = 0
                     print(f"rank {rank}: native RCCL halo exchange failed during calibration ({exn!r})", file=sys.stderr)

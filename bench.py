@@ -918,6 +918,9 @@ def _setup_distributed_laplacian(args, ctx):
         still exchanges its own input's ghost cells.  ms per apply, slowest rank."""
         table = {}
         for cand_wg, cand_transport in [(w, t) for w in (0, 4, 2) for t in transports]:
+            if cand_transport == "direct" and ctx.get("direct_dropped"):
+                continue
+
             def make(cand_wg=cand_wg, cand_transport=cand_transport):
                 call, keep = apply_candidate(grid, single_phase, "chain", cand_wg, cand_transport)
                 for ex in keep[2]:
@@ -945,6 +948,8 @@ def _setup_distributed_laplacian(args, ctx):
             for stepper, cand_transport in [(st, t) for st in ("skewed_join", "skewed_chain", "skewed_chain_wg4", "wide_overlap",
                                                                "wide_sequential") for t in transports]:
                 if not stepper.startswith("skewed") and cand_halo == 3:
+                    continue
+                if cand_transport == "direct" and ctx.get("direct_dropped"):
                     continue
                 per_call = cand_halo if stepper.startswith("skewed") else 1
 
@@ -1215,6 +1220,9 @@ def _setup_hdiff2048(args, ctx):
             for cand_wg in (0, 3, 2):
                 for cand_edge, cand_transport in [(e, t) for e in (2, 16, 32)
                                                   for t in os.environ.get("GT4MI_BENCH_TRANSPORTS", "rccl,direct").split(",")]:
+                    if cand_transport == "direct" and ctx.get("direct_dropped"):
+                        continue
+
                     def make(single=single, cand_wg=cand_wg, cand_edge=cand_edge, cand_transport=cand_transport):
                         ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune("chain", cand_wg, defer_join=True,
                                                                                                   edge_columns=cand_edge)

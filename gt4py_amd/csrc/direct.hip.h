@@ -33,6 +33,8 @@
 
 namespace gt4mi {
 
+constexpr size_t DIRECT_FLAG_BYTES = 4096;  // the first page of a pool: the flag words (up to 1023 messages; the last word is scratch)
+
 struct DirectBatch {
     uint32_t* wait_flag[BoxBatch::MAX];    // the copies of box m may be stored when *wait_flag[m] >= wait_value[m]
     uint32_t* signal_flag[BoxBatch::MAX];  // ... and every workgroup of box m adds 1 there when its part is done
@@ -204,7 +206,10 @@ inline int direct_batches(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase
         const unsigned nb = direct_blocks(msgs[m].bytes);
         d.wait_flag[m] = dx.flags + direct_index(plan, PACK, phase, m);
         d.wait_value[m] = (PACK ? dx.step - 1 : dx.step) * nb;
-        d.signal_flag[m] = signal;
+        // (GT4MI_DIRECT_TEST_LOSE_SIGNALS=1, tests only: the pushes signal into an unused word -- what a broken link looks like
+        // from the receiver's side: its waits run out of time, its data is the previous exchange's)
+        static const int lose_signals = env_int("GT4MI_DIRECT_TEST_LOSE_SIGNALS", 0);
+        d.signal_flag[m] = (PACK && lose_signals) ? dx.flags + DIRECT_FLAG_BYTES / sizeof(uint32_t) - 1 : signal;
         d.blocks[m] = nb;
         blocks = nb > blocks ? nb : blocks;
     }
@@ -236,8 +241,6 @@ inline int direct_unpack(gt4mi_halo_plan* plan, const gt4mi_field* field, int ph
 }
 
 // ---- set-up ---------------------------------------------------------------------------------------------------------------
-constexpr size_t DIRECT_FLAG_BYTES = 4096;  // the first page of the pool: the flag words (up to 1024 messages)
-
 inline int direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* out) {
     auto& dx = plan->direct;
     if (!dx.prepared) {
@@ -245,7 +248,7 @@ inline int direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* out) {
         // the per-message allocations of the plan.  Fine-grained device memory: flags and payload are written by another agent
         // while kernels of this one read them, so no cache may keep a copy.
         const size_t nflags = plan->recvs[0].size() + plan->recvs[1].size() + plan->sends[0].size() + plan->sends[1].size();
-        if (nflags * sizeof(uint32_t) > DIRECT_FLAG_BYTES) return fail(GT4MI_ERR_UNSUPPORTED, "direct transport: %d messages", (int)nflags);
+        if ((nflags + 1) * sizeof(uint32_t) > DIRECT_FLAG_BYTES) return fail(GT4MI_ERR_UNSUPPORTED, "direct transport: %d messages", (int)nflags);
         size_t bytes = DIRECT_FLAG_BYTES;
         for (int p = 0; p < 2; ++p)
             for (auto& m : plan->recvs[p]) {

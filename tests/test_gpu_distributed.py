@@ -1208,3 +1208,26 @@ def test_two_processes_push_faces_into_each_other_on_one_gpu(grid, periodic, tmp
     if (tmp_path / "unavailable.txt").exists():  # no hipIpc / fine-grained memory here: the environment's, not the code's
         pytest.skip((tmp_path / "unavailable.txt").read_text())
     assert int(np.load(tmp_path / "ok.npy")[0]) == 30
+
+
+def test_bench_drops_a_direct_transport_that_loses_its_signals(tmp_path):
+    """A direct transport whose pushes never raise the receiver's flags (GT4MI_DIRECT_TEST_LOSE_SIGNALS: what a broken link looks
+    like): the receiver's waits run out of time, the form fails its check on exactly known fields, `bench.py` drops it and every
+    later direct form, and the line is measured on RCCL -- slower to find out (2 s per wait), never wrong."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GT4MI_DIRECT_TEST_LOSE_SIGNALS="1", GT4MI_BENCH_TIMESTEP="0")
+    proc = subprocess.run([sys.executable, str(root / "bench.py"), "--dist-selfloop", "--selfloop-grid", "1x8", "--steps", "10", "--warmup", "2"],
+                          env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    config = line["config"]
+    assert config["halo_transport"].startswith("rccl") and config["direct_transport_dropped_at"].endswith("_direct")
+    assert config["verified"]["headline_form_correct_on_every_rank"] is True and config["verified"]["forms_rejected"] == 1
+    assert not any(key.endswith("_direct") for key in config["calibration_ms_per_apply"])
+    assert "REJECTED" in proc.stderr and "ran out of time" in proc.stderr

@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_stream_copy",
 )
 
-GT4MI_ABI_VERSION = 3
+GT4MI_ABI_VERSION = 4
 
 # gt4mi_status
 OK = 0

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GT4MI_ABI_VERSION 3
+#define GT4MI_ABI_VERSION 4 /* 4: gt4mi_dist_lap5_f32, the direct transport (gt4mi_halo_plan_direct_*, GT4MI_PLAN_TRANSPORT), gt4mi_comm_create_local, schedules 2-4 */
 
 typedef enum gt4mi_status {
     GT4MI_OK = 0,

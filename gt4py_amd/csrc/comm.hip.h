@@ -131,6 +131,7 @@ struct gt4mi_halo_plan {
         std::vector<size_t> recv_offset[2];
         uint32_t* flags = nullptr;          // my flag words = the first page of the pool: [arrived: one per receive][consumed: one per send]
         uint32_t* error = nullptr;          // device: a wait ran out of time
+        unsigned* ring_counters = nullptr;  // device: workgroups of a fused unpack + ring launch that have read their face (2 words)
         uint32_t step = 0;                  // exchanges started
         bool first_pushed = false;          // halo_pack_first already pushed the first phase of exchange `step`
         struct Peer {

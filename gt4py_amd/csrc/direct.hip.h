@@ -270,9 +270,10 @@ inline int direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* out) {
                 plan->recvs[p][m].buffer = dx.pool + dx.recv_offset[p][m];
             }
         void* word = nullptr;
-        GT4MI_HIP_CHECK(hipMalloc(&word, sizeof(uint32_t)));
-        GT4MI_HIP_CHECK(hipMemset(word, 0, sizeof(uint32_t)));
+        GT4MI_HIP_CHECK(hipMalloc(&word, 4 * sizeof(uint32_t)));
+        GT4MI_HIP_CHECK(hipMemset(word, 0, 4 * sizeof(uint32_t)));
         dx.error = static_cast<uint32_t*>(word);
+        dx.ring_counters = reinterpret_cast<unsigned*>(dx.error + 1);
         for (int p = 0; p < 2; ++p) {
             dx.send_to[p].assign(plan->sends[p].size(), nullptr);
             dx.signal_arrived[p].assign(plan->sends[p].size(), nullptr);

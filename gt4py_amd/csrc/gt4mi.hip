@@ -15,6 +15,7 @@
 #include "lap5.hip.h"
 #include "lap5_push.hip.h"
 #include "lap5_ring.hip.h"
+#include "lap5_ring_unpack.hip.h"
 #include "rtc.hip.h"
 #include "tridiag.hip.h"
 
@@ -249,6 +250,12 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
             if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
             if (int rc = interior(ms)) return rc;
         }
+        // ... and where the local domain is cut along J only, the unpack rides in the ring's launch (lap5_ring_unpack.hip.h)
+        bool ring_done = false;
+        static const int fuse_ring = gt4mi::env_int("GT4MI_DIST_FUSE_RING_UNPACK", 1);
+        if (fuse_ring && plan->transport == GT4MI_TRANSPORT_DIRECT && plan->direct.first_pushed && lo_i == 0 && hi_i == 0)
+            if (int rc = gt4mi::lap5_ring_unpack_run<T, W>(plan, domain, inp, out, variant, sides, ms, &ring_done)) return rc;
+        if (ring_done) return GT4MI_OK;
         if (int rc = gt4mi::halo_exchange_on(plan, inp, ms, /*first_pack_done=*/true)) return rc;
         return gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, ms);
     }

@@ -133,6 +133,30 @@ def test_fused_distributed_laplacian_step_float32(comm, schedule, literal32):
         want = np.zeros_like(host)
         R.laplacian(wrapped, want)
         assert np.array_equal(out.get(), want)
+    # ... and on the direct transport, cut along J only: push + interior and unpack + ring, one launch each (lap5_push.hip.h,
+    # lap5_ring_unpack.hip.h), both message tables, a width that is no multiple of the tile and fewer levels than a wave takes
+    if schedule == "join":
+        for gd in ((300, 40, 5), (1024, 6, 19)):
+            dj = Decomposition(gd, (1, 1), 0, 1, periodic=(False, True))
+            hostj = np.random.default_rng(17).uniform(-1, 1, dj.local_shape).astype(np.float32)
+            for single_phase in (False, True):
+                a = gt_storage.from_array(hostj, np.float32, backend="hip:mi300", aligned_index=dj.origin)
+                b = gt_storage.zeros(dj.local_shape, np.float32, backend="hip:mi300", aligned_index=dj.origin)
+                r = gt_storage.zeros(dj.local_shape, np.float32, backend="hip:mi300", aligned_index=dj.origin)
+                exd = _direct(NativeHaloExchanger(dj, np.float32, comm, single_phase=single_phase).tune("inline", 0))
+                fused = exd.make_dist_lap5(a, b, dj.origin, dj.origin, flags=flags)
+                for _ in range(3):
+                    fused()
+                torch.cuda.synchronize()
+                wrapped_j = _wrap(hostj, 1, False, True)
+                assert np.array_equal(a.get(), wrapped_j), (gd, single_phase)
+                fa, fr = _field_struct(a, dj.origin), _field_struct(r, dj.origin)
+                _lib.check("gt4mi_lap5_f32", lib.gt4mi_lap5_f32(_lib.domain3(dj.local_domain), ctypes.byref(fa), ctypes.byref(fr), 0, flags,
+                                                                torch.cuda.current_stream().cuda_stream, None))
+                torch.cuda.synchronize()
+                assert np.array_equal(b.get(), r.get()), (gd, single_phase)
+                assert exd.direct_status()["timed_out"] is False
+                exd.close()
     # a plan of 8-byte items refuses float32 fields instead of moving half of every face
     ex8 = NativeHaloExchanger(dec, np.float64, comm)
     ex8.itemsize = 4  # (get past the Python-side choice of the entry point)

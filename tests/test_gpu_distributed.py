@@ -1255,3 +1255,46 @@ def test_bench_drops_a_direct_transport_that_loses_its_signals(tmp_path):
     assert config["verified"]["headline_form_correct_on_every_rank"] is True and config["verified"]["forms_rejected"] == 1
     assert not any(key.endswith("_direct") for key in config["calibration_ms_per_apply"])
     assert "REJECTED" in proc.stderr and "ran out of time" in proc.stderr
+
+
+def test_fused_launches_of_the_direct_transport_on_random_shapes(comm):
+    """Random local domains through the two fused launches of the inline schedule (push + interior, unpack + ring) and -- where
+    the shape or the neighbours rule a fusion out -- their fall-backs: widths that are no multiple of the tile or of the vector,
+    two or three rows, one to twenty levels, every combination of periodic axes, both message tables, all four expressions.
+    Bit-identical to the whole-domain kernel on the wrapped field; the exchanged field equals the wrap."""
+    import ctypes
+
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from gt4py_amd.distributed.native import _field_struct
+
+    lib = _lib.load()
+    rng = np.random.default_rng(2718)
+    for case in range(40):
+        di = int(rng.choice([2, 6, 30, 64, 126, 128, 130, 256, 258, 384, 514, 640]))
+        dj = int(rng.choice([2, 3, 4, 9, 33]))
+        dk = int(rng.choice([1, 3, 7, 8, 9, 16, 20]))
+        periodic = [(False, True), (True, True), (True, False), (False, True)][case % 4]
+        variant = case % 4
+        dec = Decomposition((di, dj, dk), (1, 1), 0, 1, periodic=periodic)
+        host = rng.uniform(-1, 1, dec.local_shape)
+        wrapped = _wrap(host, 1, *periodic)
+        inp = gt_storage.from_array(host, backend="hip:mi300", aligned_index=dec.origin)
+        out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+        ref = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+        ex = _direct(NativeHaloExchanger(dec, np.float64, comm, single_phase=bool(case % 3 == 0)).tune("inline", 0))
+        step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin, variant)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        assert np.array_equal(inp.get(), wrapped), (case, di, dj, dk, periodic)
+        fi, fr = _field_struct(inp, dec.origin), _field_struct(ref, dec.origin)
+        _lib.check("gt4mi_lap5_f64", lib.gt4mi_lap5_f64(_lib.domain3(dec.local_domain), ctypes.byref(fi), ctypes.byref(fr), variant, 0,
+                                                        torch.cuda.current_stream().cuda_stream, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.get(), ref.get()), (case, di, dj, dk, periodic, variant)
+        assert ex.direct_status()["timed_out"] is False
+        ex.close()

@@ -184,7 +184,7 @@ inline int direct_batches(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase
     const bool field_vec = f->stride[0] == (int64_t)sizeof(U) && f->stride[1] % 16 == 0 && f->stride[2] % 16 == 0 &&
                            reinterpret_cast<uintptr_t>(f->data) % 16 == 0;
     for (int m = 0; m < b.n; ++m) {
-        int64_t off = 0, n = 1;
+        int64_t off = 0;
         for (int a = 0; a < 3; ++a) {
             if (msgs[m].lo[a] + msgs[m].ext[a] > f->shape[a])
                 return fail(GT4MI_ERR_OUT_OF_BOUNDS, "halo: box [%lld, %lld) outside of axis %d (size %lld)",
@@ -192,7 +192,6 @@ inline int direct_batches(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase
             if (f->stride[a] % (int64_t)sizeof(U) != 0) return fail(GT4MI_ERR_UNSUPPORTED, "halo: stride not a multiple of the item size");
             off += msgs[m].lo[a] * (f->stride[a] / (int64_t)sizeof(U));
             b.ext[m][a] = (int)msgs[m].ext[a];
-            n *= msgs[m].ext[a];
         }
         b.offset[m] = off;
         void* buffer = PACK ? static_cast<void*>(dx.send_to[phase][m]) : msgs[m].buffer;

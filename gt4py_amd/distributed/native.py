@@ -171,6 +171,27 @@ class NativeHaloExchanger:
                        self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_DEFER_JOIN, int(bool(defer_join))))
         return self
 
+    @staticmethod
+    def direct_wiring(rank: int, peers_of: dict):
+        """Which receive every send of ``rank`` lands in, and which send fills every receive -- RCCL's matching rule, which the
+        direct transport keeps: the k-th send to a peer pairs with the k-th receive that peer posted for this rank, per phase.
+        ``peers_of[r] = (send_peers, recv_peers)`` with the peers per phase in plan order (``message_tables``).  Returns
+        ``(send_to, recv_from)``: ``send_to[p][m] = (peer, index of the peer's receive)``, ``recv_from[p][m] = (peer, index of the
+        peer's send)``.  Pure Python: checked for whole process grids on the CPU (tests/test_distributed.py)."""
+
+        def kth(peers_list, who, k):
+            seen = -1
+            for i, q in enumerate(peers_list):
+                seen += q == who
+                if q == who and seen == k:
+                    return i
+            raise RuntimeError(f"rank {who} has no message number {k} for rank {rank}: the message tables do not pair up")
+
+        send_peers, recv_peers = peers_of[rank]
+        send_to = [[(q, kth(peers_of[q][1][p], rank, send_peers[p][:m].count(q))) for m, q in enumerate(send_peers[p])] for p in (0, 1)]
+        recv_from = [[(q, kth(peers_of[q][0][p], rank, recv_peers[p][:m].count(q))) for m, q in enumerate(recv_peers[p])] for p in (0, 1)]
+        return send_to, recv_from
+
     # ---- the direct transport: peer stores from the pack kernel instead of RCCL send/recv (csrc/direct.hip.h) ----
     def use_direct_transport(self, group=None, all_gather=None) -> "NativeHaloExchanger":
         """Switch this exchanger -- and every fused step built on it -- to the direct transport.  COLLECTIVE over the ranks of
@@ -225,28 +246,16 @@ class NativeHaloExchanger:
             keep.append(peer)
             return ctypes.byref(peer)
 
-        def kth(peers_list, who, k):
-            """Index of the k-th entry equal to ``who``."""
-            seen = -1
-            for i, q in enumerate(peers_list):
-                seen += q == who
-                if q == who and seen == k:
-                    return i
-            raise RuntimeError(f"rank {who} has no message number {k} for rank {rank}: the message tables do not pair up")
-
         mine_failure = None
         if not failures:
             try:
+                send_to, recv_from = self.direct_wiring(rank, {r: (e["send_peers"], e["recv_peers"]) for r, e in everyone.items()})
                 for p in (0, 1):
-                    for m, q in enumerate(mine["send_peers"][p]):
-                        k = mine["send_peers"][p][:m].count(q)
-                        j = kth(everyone[q]["recv_peers"][p], rank, k)
+                    for m, (q, j) in enumerate(send_to[p]):
                         off, flag = everyone[q]["recv_layout"][p][j]
                         _lib.check("gt4mi_halo_plan_direct_connect",
                                    lib.gt4mi_halo_plan_direct_connect(plan, p, 1, m, info_of(q), off, flag))
-                    for m, q in enumerate(mine["recv_peers"][p]):
-                        k = mine["recv_peers"][p][:m].count(q)
-                        j = kth(everyone[q]["send_peers"][p], rank, k)
+                    for m, (q, j) in enumerate(recv_from[p]):
                         _lib.check("gt4mi_halo_plan_direct_connect",
                                    lib.gt4mi_halo_plan_direct_connect(plan, p, 0, m, info_of(q), 0, everyone[q]["send_flags"][p][j]))
             except Exception as ex:  # noqa: BLE001

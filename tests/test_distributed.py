@@ -739,3 +739,79 @@ def test_tridiagonal_solve_decomposes_without_any_exchange(grid):
                 got[k][sl] = np.asarray(args[k])
         for k in got:
             assert np.array_equal(got[k], want[k]), (apply.__name__, k)
+
+
+@pytest.mark.parametrize("grid,periodic", [((1, 8), (False, False)), ((4, 2), (False, False)), ((2, 2), (True, True)),
+                                           ((1, 2), (True, True)), ((1, 1), (True, True)), ((2, 4), (True, False)),
+                                           ((1, 4), (False, True)), ((2, 1), (True, True)), ((3, 2), (True, True))])
+@pytest.mark.parametrize("halo", [1, 2])
+@pytest.mark.parametrize("single_phase", [False, True])
+def test_direct_transport_wiring_on_whole_process_grids(grid, periodic, halo, single_phase):
+    """The direct transport (peer stores from the pack kernel) runs between two processes on the GPU box; how its messages are
+    WIRED on any process grid can be checked here: ``NativeHaloExchanger.direct_wiring`` pairs every send with a receive of
+    the same extent at its peer, no receive is fed twice or left out, ``recv_from`` is the inverse of ``send_to`` -- and
+    delivering every face straight into the receive it is wired to (what the pack kernel does), phase by phase, leaves every
+    rank's ghost cells with the values of the periodic / bounded global array, corners included."""
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+
+    global_domain = (16 * grid[0], 12 * grid[1], 3)
+    n = grid[0] * grid[1]
+    decs = [Decomposition(global_domain, grid, r, halo, periodic=periodic) for r in range(n)]
+    tables = [NativeHaloExchanger.message_tables(d, single_phase) for d in decs]
+
+    def per_phase(table):
+        return [[m for m in table if m[1] == p] for p in (0, 1)]
+
+    msgs = [(per_phase(sends), per_phase(recvs)) for sends, recvs in tables]
+    peers_of = {r: ([[m[0] for m in ph] for ph in msgs[r][0]], [[m[0] for m in ph] for ph in msgs[r][1]]) for r in range(n)}
+    wiring = [NativeHaloExchanger.direct_wiring(r, peers_of) for r in range(n)]
+    fed = set()
+    for r in range(n):
+        send_to, recv_from = wiring[r]
+        for p in (0, 1):
+            assert len(send_to[p]) == len(msgs[r][0][p]) and len(recv_from[p]) == len(msgs[r][1][p])
+            for m, (q, j) in enumerate(send_to[p]):
+                assert msgs[q][1][p][j][0] == r and msgs[q][1][p][j][3] == msgs[r][0][p][m][3]  # my peer expects ME, the same extent
+                assert (q, p, j) not in fed
+                fed.add((q, p, j))
+                assert wiring[q][1][p][j] == (r, m)  # ... and knows that this send of mine fills that receive
+    assert fed == {(q, p, j) for q in range(n) for p in (0, 1) for j in range(len(msgs[q][1][p]))}
+    # deliver
+    rng = np.random.default_rng(0)
+    gi, gj, gk = global_domain
+    full = rng.uniform(-1, 1, (gi + 2 * halo, gj + 2 * halo, gk))
+    if periodic[0]:
+        full[:halo], full[-halo:] = full[-2 * halo:-halo].copy(), full[halo:2 * halo].copy()
+    if periodic[1]:
+        full[:, :halo], full[:, -halo:] = full[:, -2 * halo:-halo].copy(), full[:, halo:2 * halo].copy()
+    have, want = [], []
+    for d in decs:
+        i0, j0 = d.offset[0], d.offset[1]
+        li, lj, _ = d.local_domain
+        w = full[i0:i0 + li + 2 * halo, j0:j0 + lj + 2 * halo].copy()
+        h = w.copy()
+        nb = d.neighbours
+        if nb["W"] is not None:
+            h[:halo] = np.nan
+        if nb["E"] is not None:
+            h[-halo:] = np.nan
+        if nb["S"] is not None:
+            h[:, :halo] = np.nan
+        if nb["N"] is not None:
+            h[:, -halo:] = np.nan
+        have.append(h)
+        want.append(w)
+
+    def box(lo, ext):
+        return tuple(slice(a, a + e) for a, e in zip(lo, ext))
+
+    for p in (0, 1):
+        pool = {}  # (rank, receive index) -> what a pack kernel stored into that receive buffer
+        for r in range(n):
+            for m, (q, j) in enumerate(wiring[r][0][p]):
+                pool[(q, j)] = have[r][box(msgs[r][0][p][m][2], msgs[r][0][p][m][3])].copy()
+        for r in range(n):
+            for j, (_, _, lo, ext) in enumerate(msgs[r][1][p]):
+                have[r][box(lo, ext)] = pool[(r, j)]
+    for r in range(n):
+        assert np.array_equal(have[r], want[r]), r

@@ -193,6 +193,17 @@ def test_overlapped_apply_with_native_exchanger(comm):
     want = np.zeros_like(host)
     R.hdiff(_wrap(host, 2), want, coeff, domain=gd)
     assert np.array_equal(d_out.get(), want)
+    # the stencil-agnostic schedule (fork, begin, interior, end, strips -- no fused step) on either transport
+    for direct in (False, True):
+        if direct:
+            _direct(ex)
+        for _ in range(2):
+            fresh = gt_storage.from_array(host, backend="hip:mi300", aligned_index=dec.origin)
+            d_out.tensor.zero_()
+            overlapped_apply(hd, dec, origin, {"in_field": fresh, "out_field": d_out, "coeff": d_cf}, {"in_field": ex}, fused=False)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_out.get(), want), direct
+            assert np.array_equal(fresh.get(), _wrap(host, 2)), direct
     ex.close()
 
 

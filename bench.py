@@ -643,6 +643,39 @@ def _test_hang(dog, phase: str) -> None:
         time.sleep(10 ** 6)
 
 
+def direct_canary(ctx) -> bool:
+    """Before THIS process maps another device's memory and lets its kernels store into it: a child process per rank does exactly
+    that on a small problem -- `python -m gt4py_amd.distributed --transport direct`, the self-check of the direct transport (no RCCL,
+    its own gloo group on the next port) -- and all ranks agree on the outcome.  A memory fault or a hang between real devices
+    then ends a child, not the run: the calibration stays on RCCL."""
+    dog, rank, world = ctx["dog"], ctx["rank"], ctx["world"]
+    dog.arm(300, "canary of the direct transport (child processes)")
+    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1), RANK=str(rank), WORLD_SIZE=str(world),
+               LOCAL_RANK=str(ctx["local_rank"]), PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # (the launcher's own variables would send the child to the launcher's store -- TORCHELASTIC_USE_AGENT_STORE -- instead of
+    # letting its rank 0 open one on the next port)
+    for key in [k for k in env if k.startswith("TORCHELASTIC_")] + ["GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
+                                                                    "GT4MI_BENCH_TEST_HANG"]:
+        env.pop(key, None)
+    ok = 0
+    try:
+        if os.environ.get("GT4MI_BENCH_TEST_CANARY_FAILS") == "1":  # (tests: what a child that crashed looks like from here)
+            raise RuntimeError("simulated for the tests")
+        proc = subprocess.run([sys.executable, "-m", "gt4py_amd.distributed", "--transport", "direct", "--domain", "256", "192", "8"],
+                              env=env, capture_output=True, text=True, timeout=150, cwd=str(ROOT))
+        ok = int(proc.returncode == 0)
+        if not ok:
+            print(f"rank {rank}: the canary of the direct transport ended with status {proc.returncode}: "
+                  f"{(proc.stdout + proc.stderr)[-600:]}", file=sys.stderr)
+    except Exception as ex:  # (a timeout: the child is killed)
+        print(f"rank {rank}: the canary of the direct transport failed ({ex!r})", file=sys.stderr)
+    good = bool(_agree(ctx, ok))
+    if not good and rank == 0:
+        print("bench.py: the direct halo transport did not pass its canary on every rank: the calibration stays on RCCL", file=sys.stderr)
+    return good
+
+
 def _native_comm(ctx, selfloop: bool):
     """(NativeComm or None, proof) -- creating the communicator is collective; should it fail on any rank, every rank
     falls back to the torch transport together.  proof = what RCCL itself reports (ncclCommCount) + the rank -> device map."""
@@ -805,6 +838,12 @@ def _setup_distributed_laplacian(args, ctx):
         if not _agree(ctx, ok):
             transport, comm, fallback = "torch", None, True
             transport_fallback_banner(rank, "the native halo exchange failed in its plainest form (exchange, then one launch)")
+    canary = None
+    if transport == "native" and "direct" in transports and distributed:
+        canary = direct_canary(ctx)
+        if not canary:
+            transports = tuple(t for t in transports if t != "direct") or ("rccl",)
+            halo_transport = transports[0]
     _test_hang(dog, "calibration")
     if transport == "native" and mode == "apply" and not ("GT4MI_BENCH_SINGLE_PHASE" in os.environ and pinned_grid):
         # Measured before the warm-up, all ranks agreeing on the slowest rank's time: the process grid (xGMI is
@@ -1006,7 +1045,8 @@ def _setup_distributed_laplacian(args, ctx):
               "schedule": schedule if transport == "native" else "join", "interior_workgroups_per_cu": wg_per_cu,
               "halo_transport": (halo_transport + (" (peer stores from the pack kernel, flags in the receiver's memory; no send/recv kernel)"
                                                    if halo_transport == "direct" else " (send/recv)")) if transport == "native" else "torch",
-              "calibration_ms_per_apply": calibration, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped")}
+              "calibration_ms_per_apply": calibration, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped"),
+              "direct_transport_canary": canary}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
               "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback}
     return step, kernel_step, dec.local_domain, config, extras
@@ -1050,6 +1090,7 @@ def _setup_hdiff2048(args, ctx):
     transport, comm, proof, exchangers, fallback = "none", None, None, [], False
     timings, choice = None, "single launch"
     headline_verdict, verified, ghost_cells = None, None, 0
+    hd_transports, canary = tuple(os.environ.get("GT4MI_BENCH_TRANSPORTS", "rccl,direct").split(",")), None
     if decomposed:
         transport = os.environ.get("GT4MI_BENCH_COMM", "native")
         if transport == "native":
@@ -1131,6 +1172,10 @@ def _setup_hdiff2048(args, ctx):
                 if not _agree(ctx, ok):
                     transport, comm, fallback = "torch", None, True
                     transport_fallback_banner(rank, "the native halo exchange failed in its plainest form (exchange, then one launch)")
+            if transport == "native" and "direct" in hd_transports and distributed:
+                canary = direct_canary(ctx)  # (see _setup_distributed_laplacian)
+                if not canary:
+                    hd_transports = tuple(t for t in hd_transports if t != "direct") or ("rccl",)
             _test_hang(dog, "calibration")
             if transport == "native":  # (still: the plainest form ran on every rank)
                 names = []
@@ -1140,7 +1185,7 @@ def _setup_hdiff2048(args, ctx):
                     schedules = tuple(os.environ.get("GT4MI_BENCH_HDIFF_SCHEDULES", "join,chain,inline").split(","))
                     names += [f"fused_{table}_{sched}_wg{wg}_edge{edge}" + ("_direct" if tr == "direct" else "") for sched in schedules
                               for wg in (0, 3, 2) for edge in edge_candidates
-                              for tr in os.environ.get("GT4MI_BENCH_TRANSPORTS", "rccl,direct").split(",")]
+                              for tr in hd_transports]
                     names.append(f"sequential_{table}")
                 pinned = os.environ.get("GT4MI_BENCH_FORM")
                 dog.arm(300, "calibration of the apply forms")
@@ -1219,7 +1264,7 @@ def _setup_hdiff2048(args, ctx):
         for single in (False, True):
             for cand_wg in (0, 3, 2):
                 for cand_edge, cand_transport in [(e, t) for e in (2, 16, 32)
-                                                  for t in os.environ.get("GT4MI_BENCH_TRANSPORTS", "rccl,direct").split(",")]:
+                                                  for t in hd_transports]:
                     if cand_transport == "direct" and ctx.get("direct_dropped"):
                         continue
 
@@ -1248,7 +1293,8 @@ def _setup_hdiff2048(args, ctx):
               "grid": list(total), "decomposition": f"{grid[0]}x{grid[1]}", "local_domain": list(dec.local_domain),
               "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange if exchangers else 0,
               "transport": transport, "selfloop": bool(selfloop), "apply_form": choice,
-              "calibration_ms_per_apply": timings, "verified": verified}
+              "calibration_ms_per_apply": timings, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped"),
+              "direct_transport_canary": canary}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen),
               "proof": proof, "transport_fallback": fallback, "timestep": pipelined_applies if decomposed else None}
     return step, kernel_step, dec.local_domain, config, extras

@@ -120,14 +120,21 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     started_group = False
+    direct_only = tuple(transports) == ("direct",)  # the direct transport alone: no RCCL anywhere, the descriptions travel over gloo
     if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():  # (launched by torch.distributed.run, any world size)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if direct_only:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         started_group = True
     results = []  # (name, ok, detail)
     if "torch" in transports and not dist.is_initialized():  # (the torch transport needs a process group, also to talk to itself)
         transports = tuple(t for t in transports if t != "torch")
-    comm = NativeComm() if "native" in transports else None
+    if direct_only:
+        comm = NativeComm(rank=rank, world_size=world, rccl=False)
+    else:
+        comm = NativeComm() if "native" in transports else None
     lap = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64})
     hd = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64})
     try:
@@ -167,14 +174,14 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
                     ex = HaloExchanger(dec, torch.float64, torch.device("cuda", local_rank), single_phase=single)
                     record(f"torch {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: ex}))
                     record(f"torch {table} overlapped", lambda: overlapped_apply(stencil, dec, origin, fields, {names[0]: ex}))
-                for how in (("rccl", "direct") if comm is not None else ()):
+                for how in ((("direct",) if direct_only else ("rccl", "direct")) if comm is not None else ()):
                     nex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single)
                     if how == "direct":  # peer stores from the pack kernel (csrc/direct.hip.h); collective, all ranks fail together
                         try:
                             nex.use_direct_transport()
                         except RuntimeError as ex:  # (no fine-grained memory / hipIpc on some rank: RCCL remains -- reported, not a failure)
                             results.append((f"halo {halo} grid {grid[0]}x{grid[1]} native/direct {table}: NOT AVAILABLE ({str(ex)[:120]})",
-                                            True, ""))
+                                            not direct_only, "the direct transport was asked for and is not available"))
                             nex.close()
                             continue
                     record(f"native/{how} {table} sequential", lambda: sequential_apply(stencil, dec, origin, fields, {names[0]: nex}))
@@ -223,6 +230,7 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="python -m gt4py_amd.distributed", description=run_selfcheck.__doc__)
     ap.add_argument("--domain", type=int, nargs=3, default=(256, 192, 16), metavar=("I", "J", "K"), help="GLOBAL compute domain")
     ap.add_argument("--periodic", action="store_true", help="wrap both axes (with one rank: every neighbour is the rank itself)")
-    ap.add_argument("--transport", choices=("native", "torch", "both"), default="both")
+    ap.add_argument("--transport", choices=("native", "torch", "both", "direct"), default="both",
+                    help="direct: only the direct transport of the native path, without RCCL (bench.py's canary)")
     a = ap.parse_args(argv)
     return 1 if run_selfcheck(tuple(a.domain), a.periodic, ("native", "torch") if a.transport == "both" else (a.transport,)) else 0

@@ -878,6 +878,9 @@ def test_bench_n_gpu_code_path_with_a_world_of_one(workload, tmp_path):
     verified = line["config"]["verified"]  # every calibrated form reproduced the exactly known outcome (distributed/selfcheck.py)
     assert verified["headline_form_correct_on_every_rank"] is True and verified["forms_rejected"] == 0
     assert verified["forms_checked"] >= len(line["config"]["calibration_ms_per_apply"]) + 2 and verified["ghost_cells_checked_on_rank_0"] == 0
+    # the direct transport passed its canary (a child process per rank maps and stores first) and was calibrated beside RCCL
+    assert line["config"]["direct_transport_canary"] is True and line["config"]["direct_transport_dropped_at"] is None
+    assert any(key.endswith("direct") for key in line["config"]["calibration_ms_per_apply"])
     if workload == "lap512":
         assert {"timestep_glups", "timestep_ms_per_step", "pipelined_apply_glups"} <= set(line["extra"])
         assert line["config"]["mode"] == "apply" and line["config"]["halo_depth"] == 1
@@ -1309,3 +1312,31 @@ def test_fused_launches_of_the_direct_transport_on_random_shapes(comm):
         assert np.array_equal(out.get(), ref.get()), (case, di, dj, dk, periodic, variant)
         assert ex.direct_status()["timed_out"] is False
         ex.close()
+
+
+@_second_chance
+def test_bench_keeps_to_rccl_when_the_canary_of_the_direct_transport_fails(tmp_path):
+    """On more than one rank `bench.py` lets a CHILD process per rank try the direct transport first (it maps another process's
+    memory and stores into it: a fault there must end a child, not the run).  A canary that fails on any rank -- simulated --
+    takes the direct transport out of every calibration; the line is measured on RCCL and says so."""
+    import json
+    import os
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, GT4MI_BENCH_FORCE_DISTRIBUTED="1", GT4MI_BENCH_TEST_CANARY_FAILS="1", GT4MI_BENCH_TIMESTEP="0")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(root / "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2"],
+                          env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    config = line["config"]
+    assert config["direct_transport_canary"] is False and config["halo_transport"].startswith("rccl")
+    assert config["calibration_ms_per_apply"] and not any(key.endswith("direct") for key in config["calibration_ms_per_apply"])
+    assert "did not pass its canary" in proc.stderr and line["transport_fallback"] is False

@@ -650,8 +650,17 @@ def direct_canary(ctx) -> bool:
     then ends a child, not the run: the calibration stays on RCCL."""
     dog, rank, world = ctx["dog"], ctx["rank"], ctx["world"]
     dog.arm(300, "canary of the direct transport (child processes)")
-    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
-               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1), RANK=str(rank), WORLD_SIZE=str(world),
+    port = [None]
+    if rank == 0:  # a port that is free right now, for the children's own rendezvous
+        import socket
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port[0] = sock.getsockname()[1]
+    if ctx["distributed"]:
+        ctx["dist"].broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port[0]), RANK=str(rank),
+               WORLD_SIZE=str(world),
                LOCAL_RANK=str(ctx["local_rank"]), PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
     # (the launcher's own variables would send the child to the launcher's store -- TORCHELASTIC_USE_AGENT_STORE -- instead of
     # letting its rank 0 open one on the next port)

@@ -52,6 +52,9 @@ PEAK_GBS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md)
 GRID = (512, 512, 512)
 HDIFF_SHARE = (512, 1024, 80)  # per-rank share of BASELINE.json configs[4]
 HDIFF_GLOBAL = (2048, 2048, 80)
+# how long a device-side wait of the direct transport may take in THIS program before its plan fails (the library's default is
+# 30 s): a broken direct transport costs the calibration this much per wait, then its forms are dropped
+DIRECT_TIMEOUT_MS = int(os.environ.get("GT4MI_BENCH_DIRECT_TIMEOUT_MS", "2000"))
 KERNEL_SOURCES = {  # the files whose contents decide what a kernel does, per profiled workload
     "lap5_f64_512": ("gt4py_amd/csrc/lap5.hip.h", "gt4py_amd/csrc/lane_shift.hip.h", "gt4py_amd/csrc/common.hip.h",
                      "gt4py_amd/csrc/Makefile"),
@@ -602,15 +605,207 @@ def measure_candidate(ctx, make, calls: int, warm: int = 3):
     except Exception as ex:
         ok = 0
         print(f"rank {ctx['rank']}: calibration candidate failed ({ex!r})", file=sys.stderr)
+        if ctx.get("device", "cuda") == "cuda":
+            try:
+                torch.cuda.synchronize()  # (whatever this rank enqueued for the candidate has left the device before the ranks meet)
+            except Exception:
+                pass
     ms = None
     if _agree(ctx, ok):
         ms = round(_slowest_rank_ms(ctx, fn, calls, warm=0), 5)
+    # Every rank has synchronised its device and met the others in a collective (_agree / the all-reduce of the timings) since
+    # the candidate's last exchange: cleanups may release memory the neighbours' kernels wrote into WITHOUT another round
+    # (NativeHaloExchanger.close(collective=False)) -- and a rank on which the candidate could not even be built, which has
+    # nothing to clean up, leaves nobody waiting for it.
     if cleanup is not None:
         try:
             cleanup()
         except Exception:
             pass
     return ms
+
+
+class WallBudget:
+    """A wall-clock budget that every rank reads alike: `more()` is a tiny collective (all ranks still have time, or nobody
+    goes on), so no rank ever starts a candidate that another one has already given up on."""
+
+    def __init__(self, ctx, seconds: float):
+        self.ctx, self.seconds, self.t_end, self.spent = ctx, float(seconds), time.monotonic() + float(seconds), False
+
+    def more(self) -> bool:
+        if not self.spent:
+            self.spent = not _agree(self.ctx, int(time.monotonic() < self.t_end))
+        return not self.spent
+
+
+def lap_key(cand) -> str:
+    grid, single, schedule, wg, transport = cand
+    return f"{grid[0]}x{grid[1]}_{'single' if single else 'two'}phase_{schedule}_wg{wg}_{transport}"
+
+
+def lap_candidate_of(key: str):
+    g, ph, schedule, wg, transport = key.split("_")
+    pi, pj = g.split("x")
+    return (int(pi), int(pj)), ph == "singlephase", schedule, int(wg[2:]), transport
+
+
+def lap_calibration_order(default_grid, grids, phases, transports):
+    """The calibration candidates of the decomposed Laplacian -- (grid, single_phase, schedule, interior workgroups per CU,
+    transport) -- BEST FIRST, in three stages; the wall-clock budget cuts the tail, never the head (VERDICT round 3, item 3:
+    ~208 candidates under one kill deadline meant the first real N > 1 line would have been the provisional one or a timeout).
+
+      first   the north star's form: RCCL send/recv on a second stream, on the grid `choose_process_grid` returns, the two
+              schedules that won every self-loop share ("swap", then "join"), two-phase then single-phase: an OVERLAPPED
+              RCCL headline exists after at most four candidates; then the other process grids, RCCL "swap"
+      refine(best) what is left of RCCL on the best grid and message table so far: the other schedules, then the throttles
+      direct(best) the direct transport (only after its canary), by the self-loop ranking: "inline" on the best grid, both
+              tables; "inline" on the other grids; then the two-stream schedules on the best grid."""
+    rccl, direct = "rccl" in transports, "direct" in transports
+    first = []
+    if rccl:
+        first += [(default_grid, single, schedule, 0, "rccl") for single in phases for schedule in ("swap", "join")]
+        first += [(g, single, "swap", 0, "rccl") for g in grids if g != default_grid for single in phases]
+
+    def refine(best):
+        g, single = best[0], best[1]
+        if not rccl:
+            return []
+        out = [(g, single, schedule, 0, "rccl") for schedule in ("swap", "join", "swap-packed", "chain")]
+        out += [(g, single, schedule, wg, "rccl") for wg in (4, 2) for schedule in ("swap", "join", "swap-packed", "chain")]
+        out += [(g, other, schedule, 0, "rccl") for other in phases if other != single for schedule in ("swap-packed", "chain")]
+        return out
+
+    def direct_stage(best):
+        if not direct:
+            return []
+        g = best[0] if best is not None else default_grid
+        out = [(g, single, "inline", 0, "direct") for single in phases]
+        out += [(og, single, "inline", 0, "direct") for og in grids if og != g for single in phases]
+        out += [(g, single, schedule, 0, "direct") for schedule in ("swap", "join", "swap-packed", "chain") for single in phases]
+        return out
+
+    return first, refine, direct_stage
+
+
+def run_calibration(candidates, key_of, measure, budget, table, stats, skip=None, failed=None) -> None:
+    """Measure `candidates` in order into `table[key]` until the budget is spent (collectively); what was not started is
+    counted, not measured.  `measure(candidate)` -> ms (slowest rank) or None when the candidate failed on some rank (then
+    `failed(candidate, key)` hears of it); `skip(candidate)`: not to be tried at all (a transport that was dropped)."""
+    for cand in candidates:
+        key = key_of(cand)
+        if key in table or key in stats["failed"] or (skip is not None and skip(cand)):
+            continue
+        if not budget.more():
+            stats["skipped_for_time"] += 1
+            continue
+        ms = measure(cand)
+        stats["run"] += 1
+        if ms is None:
+            stats["failed"].append(key)
+            if failed is not None:
+                failed(cand, key)
+        else:
+            table[key] = ms
+
+
+def calibrate_laplacian(ctx, default_grid, grids, phases, transports, measure, canary, rccl_seconds, direct_seconds, table, stats,
+                        pinned_schedule=None):
+    """The three stages of lap_calibration_order under their budgets, collectively: RCCL first (the default grid's "swap" / "join"
+    before anything else), what is left of RCCL on the best grid, then -- `canary()` permitting: True / None (not needed) go on,
+    False drops it -- the direct transport with a budget of its own.  Fills `table` (key -> ms per apply, slowest rank) and
+    `stats`; returns (what the canary said, the transports still in use).  `measure(candidate)` -> ms or None."""
+    first, refine, direct_stage = lap_calibration_order(default_grid, grids, phases, transports)
+
+    def wanted(cands):
+        return [c for c in cands if pinned_schedule is None or c[2] == pinned_schedule]
+
+    def dropped(cand):
+        return cand[4] == "direct" and bool(ctx.get("direct_dropped"))
+
+    def drop(cand, key):  # one form on the direct transport was wrong, timed out or could not be set up: the rest of the
+        if cand[4] == "direct":  # calibration stays on RCCL, on every rank alike
+            ctx["direct_dropped"] = key
+
+    budget = WallBudget(ctx, rccl_seconds)
+    run_calibration(wanted(first), lap_key, measure, budget, table, stats, dropped, drop)
+    best_key, _ = best_of(table, "rccl")
+    if best_key is not None:
+        run_calibration(wanted(refine(lap_candidate_of(best_key))), lap_key, measure, budget, table, stats, dropped, drop)
+        best_key, _ = best_of(table, "rccl")
+    verdict = None
+    if "direct" in transports:
+        verdict = canary()
+        if verdict is False:
+            transports = tuple(t for t in transports if t != "direct") or ("rccl",)
+        else:
+            budget = WallBudget(ctx, direct_seconds)
+            run_calibration(wanted(direct_stage(lap_candidate_of(best_key) if best_key else None)), lap_key, measure, budget, table,
+                            stats, dropped, drop)
+    return verdict, transports
+
+
+def best_of(table, transport: str):
+    """(key, ms) of the fastest measured candidate of one transport (keys end in _rccl / _direct), or (None, None)."""
+    mine = {k: v for k, v in table.items() if k.endswith("_" + transport)}
+    if not mine:
+        return None, None
+    key = min(mine, key=mine.get)
+    return key, mine[key]
+
+
+def calibration_seconds(name: str, fallback: float) -> float:
+    return float(os.environ.get(name, fallback))
+
+
+def hdiff_calibration_order(schedules, edges, transports):
+    """The apply forms of the decomposed horizontal diffusion, BEST FIRST (see lap_calibration_order): names
+    `fused_<table>_<schedule>_wg<n>_edge<w>[_direct]` and `sequential_<table>`.
+
+      first        RCCL, what gt4mi_dist_hdiff_* does by default and won the self-loop rehearsals: "chain" (then "join"), the
+                   interior kernel at 2 of 4 workgroups per CU, 16 edge columns, two-phase then single-phase
+      refine(best) RCCL on the best message table: the other throttles and edge widths, the one-stream form, the plain sequence
+      direct(best) the direct transport after its canary: "inline" first (its pack kernel IS the transfer), both tables"""
+    rccl, direct = "rccl" in transports, "direct" in transports
+    tables = ("two_phase", "single_phase")
+    two_stream = [sc for sc in ("chain", "join", "swap", "swap-packed") if sc in schedules]
+    first = [f"fused_{t}_{sc}_wg2_edge16" for t in tables for sc in two_stream[:2]] if rccl else []
+
+    def table_of(name):
+        return "single_phase" if "single_phase" in name else "two_phase"
+
+    def refine(best):
+        if not rccl:
+            return []
+        t = table_of(best)
+        out = [f"fused_{t}_{sc}_wg{wg}_edge{e}" for wg in (2, 3, 0) for e in edges for sc in two_stream]
+        if "inline" in schedules:
+            out += [f"fused_{t}_inline_wg0_edge{e}" for e in edges]
+        return out + [f"sequential_{t}"] + [f"sequential_{o}" for o in tables if o != t]
+
+    def direct_stage(best):
+        if not direct:
+            return []
+        t = table_of(best) if best else "two_phase"
+        order = [t] + [o for o in tables if o != t]
+        out = [f"fused_{o}_inline_wg0_edge16_direct" for o in order] if "inline" in schedules else []
+        out += [f"fused_{t}_inline_wg0_edge{e}_direct" for e in edges if e != 16 and "inline" in schedules]
+        out += [f"fused_{o}_{sc}_wg2_edge16_direct" for sc in two_stream[:2] for o in order]
+        return out
+
+    return first, refine, direct_stage
+
+
+def calibration_line_keys(table, stats) -> dict:
+    """Top-level keys of a calibrated N > 1 line: what the SPECIFIED design (RCCL send/recv on a second stream) achieves next to
+    the direct transport, whichever of the two the headline took, and how much of the calibration the budget allowed."""
+    direct = {k: v for k, v in table.items() if k.endswith("_direct")}
+    rccl = {k: v for k, v in table.items() if not k.endswith("_direct")}  # (Laplacian keys end in _rccl, hdiff's carry no suffix)
+    rccl_key = min(rccl, key=rccl.get) if rccl else None
+    direct_key = min(direct, key=direct.get) if direct else None
+    rccl_ms, direct_ms = rccl.get(rccl_key), direct.get(direct_key)
+    return {"rccl_best_ms_per_apply": rccl_ms, "rccl_best_form": rccl_key, "direct_best_ms_per_apply": direct_ms,
+            "direct_best_form": direct_key, "calibration_candidates_run": stats["run"],
+            "calibration_candidates_skipped_for_time": stats["skipped_for_time"], "calibration_candidates_failed": list(stats["failed"])}
 
 
 def gather_rank_proof(ctx, info) -> dict:
@@ -646,24 +841,20 @@ def _test_hang(dog, phase: str) -> None:
 def direct_canary(ctx) -> bool:
     """Before THIS process maps another device's memory and lets its kernels store into it: a child process per rank does exactly
     that on a small problem -- `python -m gt4py_amd.distributed --transport direct`, the self-check of the direct transport (no RCCL,
-    its own gloo group on the next port) -- and all ranks agree on the outcome.  A memory fault or a hang between real devices
+    its own gloo group, met through a file) -- and all ranks agree on the outcome.  A memory fault or a hang between real devices
     then ends a child, not the run: the calibration stays on RCCL."""
     dog, rank, world = ctx["dog"], ctx["rank"], ctx["world"]
     dog.arm(300, "canary of the direct transport (child processes)")
-    port = [None]
-    if rank == 0:  # a port that is free right now, for the children's own rendezvous
-        import socket
+    import tempfile
 
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port[0] = sock.getsockname()[1]
+    where = [None]
+    if rank == 0:  # the children's own rendezvous: a file in a fresh directory (every rank of ONE node sees it) -- not a port
+        where[0] = os.path.join(tempfile.mkdtemp(prefix="gt4mi_canary_"), "rendezvous")
     if ctx["distributed"]:
-        ctx["dist"].broadcast_object_list(port, src=0)
-    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port[0]), RANK=str(rank),
-               WORLD_SIZE=str(world),
+        ctx["dist"].broadcast_object_list(where, src=0)
+    env = dict(os.environ, GT4MI_RENDEZVOUS_FILE=str(where[0]), RANK=str(rank), WORLD_SIZE=str(world),
                LOCAL_RANK=str(ctx["local_rank"]), PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    # (the launcher's own variables would send the child to the launcher's store -- TORCHELASTIC_USE_AGENT_STORE -- instead of
-    # letting its rank 0 open one on the next port)
+    # (the launcher's own variables would send the child to the launcher's store -- TORCHELASTIC_USE_AGENT_STORE)
     for key in [k for k in env if k.startswith("TORCHELASTIC_")] + ["GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
                                                                     "GT4MI_BENCH_TEST_HANG"]:
         env.pop(key, None)
@@ -760,7 +951,9 @@ def _setup_distributed_laplacian(args, ctx):
         """(step(i), keepalive) of the headline form on one process grid / message table / schedule / throttle / transport."""
         cdec = Decomposition(total, cand_grid, rank, halo=1, periodic=periodic)
         cpairs = _device_fields(cdec.local_shape, n_pairs=2, seed=1337 + rank, origin=cdec.origin)
-        cex = [NativeHaloExchanger(cdec, np.float64, comm, single_phase=cand_single).tune(cand_schedule, cand_wg) for _ in cpairs]
+        # (direct_timeout_ms: a broken direct transport costs the calibration 2 s per wait, then its forms are dropped)
+        cex = [NativeHaloExchanger(cdec, np.float64, comm, single_phase=cand_single).tune(cand_schedule, cand_wg, direct_timeout_ms=DIRECT_TIMEOUT_MS)
+               for _ in cpairs]
         if cand_transport == "direct":  # peer stores from the pack kernel instead of RCCL send/recv (collective; raises on EVERY rank
             for ex in cex:              # when it is not available on some rank: measure_candidate then drops the candidate)
                 ex.use_direct_transport()
@@ -848,43 +1041,38 @@ def _setup_distributed_laplacian(args, ctx):
             transport, comm, fallback = "torch", None, True
             transport_fallback_banner(rank, "the native halo exchange failed in its plainest form (exchange, then one launch)")
     canary = None
-    if transport == "native" and "direct" in transports and distributed:
-        canary = direct_canary(ctx)
-        if not canary:
-            transports = tuple(t for t in transports if t != "direct") or ("rccl",)
-            halo_transport = transports[0]
+    stats = {"run": 0, "skipped_for_time": 0, "failed": []}
     _test_hang(dog, "calibration")
     if transport == "native" and mode == "apply" and not ("GT4MI_BENCH_SINGLE_PHASE" in os.environ and pinned_grid):
-        # Measured before the warm-up, all ranks agreeing on the slowest rank's time: the process grid (xGMI is
-        # point-to-point: what costs is the LARGEST message of a round, 1x8 sends 2.1 MB faces, 4x2 and 2x4 at most
-        # 1.05 MB) and the message table (two rounds with 4 neighbours, or one round with faces + corners to 8).
-        dog.arm(420, "calibration of process grid x message table")
+        # Measured before the warm-up, all ranks agreeing on the slowest rank's time: the process grid (xGMI is point-to-point:
+        # what costs is the LARGEST message of a round, 1x8 sends 2.1 MB faces, 4x2 and 2x4 at most 1.05 MB), the message table
+        # (two rounds with 4 neighbours, or one round with faces + corners to 8), schedule, throttle, transport -- BEST FIRST
+        # under a wall-clock budget (lap_calibration_order): the RCCL forms the north star names come first, the direct
+        # transport after its canary; what the budget does not reach is counted (calibration_candidates_skipped_for_time).
+        rccl_seconds = calibration_seconds("GT4MI_BENCH_CALIBRATION_SECONDS", 90)
+        direct_seconds = calibration_seconds("GT4MI_BENCH_DIRECT_CALIBRATION_SECONDS", 60)
+        dog.arm(rccl_seconds + direct_seconds + 600, "calibration of process grid x message table x schedule x transport")
         ok, table = 1, {}
         try:
             grids = [grid] if (selfloop or pinned_grid) else process_grid_candidates(world, total, 1)
-            for cand_grid in grids:
-                for cand_single in ((single_phase,) if "GT4MI_BENCH_SINGLE_PHASE" in os.environ else (False, True)):
-                    for cand_schedule in ("join", "chain", "swap", "swap-packed", "inline"):
-                        for cand_wg in (0, 4, 2):  # workgroups of the interior kernel per CU while the exchange runs (0: no limit)
-                            if cand_schedule == "inline" and cand_wg:
-                                continue  # (nothing runs beside the interior kernel there: nothing to throttle it for)
-                            for cand_transport in transports:
-                                if cand_transport == "direct" and ctx.get("direct_dropped"):
-                                    continue  # (one form on it was wrong, timed out or could not be set up: every wait of a broken
-                                    #            transport costs 2 s -- the rest of the calibration stays on RCCL, on every rank alike)
+            phases = (single_phase,) if "GT4MI_BENCH_SINGLE_PHASE" in os.environ else (False, True)
 
-                                def make(cand_grid=cand_grid, cand_single=cand_single, cand_schedule=cand_schedule, cand_wg=cand_wg,
-                                         cand_transport=cand_transport):
-                                    call, keep = apply_candidate(cand_grid, cand_single, cand_schedule, cand_wg, cand_transport)
-                                    return call, (lambda: [ex.close() for ex in keep[2]]), keep[4]
+            def measure(cand):
+                def make(cand=cand):
+                    call, keep = apply_candidate(*cand)
+                    return call, (lambda: [ex.close(collective=False) for ex in keep[2]]), keep[4]
 
-                                key = (f"{cand_grid[0]}x{cand_grid[1]}_{'single' if cand_single else 'two'}phase_{cand_schedule}"
-                                       f"_wg{cand_wg}_{cand_transport}")
-                                ms = measure_candidate(ctx, make, 24)
-                                if ms is not None:
-                                    table[key] = ms
-                                elif cand_transport == "direct":
-                                    ctx["direct_dropped"] = key
+                return measure_candidate(ctx, make, 24)
+
+            def canary_of_the_direct_transport():
+                if not distributed:  # (the self-loop: every peer is this process itself)
+                    return None
+                good = direct_canary(ctx)  # before THIS process maps another device's memory: a child process per rank tries it
+                dog.arm(direct_seconds + 600, "calibration of the direct transport")
+                return good
+
+            canary, transports = calibrate_laplacian(ctx, grid, grids, phases, transports, measure, canary_of_the_direct_transport,
+                                                     rccl_seconds, direct_seconds, table, stats)
             torch.cuda.empty_cache()
         except Exception as ex:
             ok = 0
@@ -894,9 +1082,12 @@ def _setup_distributed_laplacian(args, ctx):
             transport_fallback_banner(rank, "the native halo exchange failed during calibration (no candidate ran on every rank)")
         else:
             calibration = table
-            best = min(table, key=table.get)
-            g, ph, schedule, wg, halo_transport = best.split("_")
-            grid, single_phase, wg_per_cu = grid_of(g), ph == "singlephase", int(wg[2:])
+            grid, single_phase, schedule, wg_per_cu, halo_transport = lap_candidate_of(min(table, key=table.get))
+    elif transport == "native" and "direct" in transports and distributed:
+        canary = direct_canary(ctx)
+        if not canary:
+            transports = tuple(t for t in transports if t != "direct") or ("rccl",)
+            halo_transport = transports[0]
     dog.arm(180, "set-up of the decomposed fields and exchangers")
     dec = Decomposition(total, grid, rank, halo=1, periodic=periodic)
     origin = {"inp": dec.origin, "out": dec.origin}
@@ -973,7 +1164,7 @@ def _setup_distributed_laplacian(args, ctx):
                 call, keep = apply_candidate(grid, single_phase, "chain", cand_wg, cand_transport)
                 for ex in keep[2]:
                     ex.tune(defer_join=True)
-                return call, (lambda: [(ex.end(), ex.close()) for ex in keep[2]])
+                return call, (lambda: [(ex.end(), ex.close(collective=False)) for ex in keep[2]])
 
             ms = measure_candidate(ctx, make, 48)
             if ms is not None:
@@ -1014,7 +1205,7 @@ def _setup_distributed_laplacian(args, ctx):
                         fn = cex.make_time_skewed_lap5(ca, cb, cdec.origin)
                     else:
                         fn = cex.make_time_stepper_lap5(ca, cb, cdec.origin, overlap=stepper == "wide_overlap")
-                    return fn, cex.close
+                    return fn, (lambda: cex.close(collective=False))
 
                 calls = max(24 // per_call, 6) if per_call > 1 else 24
                 ms = measure_candidate(ctx, make, calls, warm=2 * (cand_halo if per_call == 1 else 1))
@@ -1057,7 +1248,8 @@ def _setup_distributed_laplacian(args, ctx):
               "calibration_ms_per_apply": calibration, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped"),
               "direct_transport_canary": canary}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
-              "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback}
+              "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback,
+              "calibration": calibration_line_keys(calibration, stats) if calibration is not None else None}
     return step, kernel_step, dec.local_domain, config, extras
 
 
@@ -1100,6 +1292,7 @@ def _setup_hdiff2048(args, ctx):
     timings, choice = None, "single launch"
     headline_verdict, verified, ghost_cells = None, None, 0
     hd_transports, canary = tuple(os.environ.get("GT4MI_BENCH_TRANSPORTS", "rccl,direct").split(",")), None
+    stats = {"run": 0, "skipped_for_time": 0, "failed": []}
     if decomposed:
         transport = os.environ.get("GT4MI_BENCH_COMM", "native")
         if transport == "native":
@@ -1126,7 +1319,8 @@ def _setup_hdiff2048(args, ctx):
                     fn = lambda: sequential_apply(hd, dec, origin, fields, {"in_field": ex})  # noqa: E731
                 else:
                     ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(parts[3], int(parts[4][2:]),
-                                                                                              edge_columns=int(parts[5][4:]))
+                                                                                              edge_columns=int(parts[5][4:]),
+                                                                                              direct_timeout_ms=DIRECT_TIMEOUT_MS)
                     if parts[6:] == ["direct"]:  # peer stores from the pack kernel instead of RCCL send/recv (collective; raises on
                         ex.use_direct_transport()  # EVERY rank when some rank cannot: measure_candidate then drops the form)
                     probe_apply = ex.make_dist_hdiff(chk.probe, chk.out, fields["coeff"], dec.origin, flags)
@@ -1181,38 +1375,53 @@ def _setup_hdiff2048(args, ctx):
                 if not _agree(ctx, ok):
                     transport, comm, fallback = "torch", None, True
                     transport_fallback_banner(rank, "the native halo exchange failed in its plainest form (exchange, then one launch)")
-            if transport == "native" and "direct" in hd_transports and distributed:
-                canary = direct_canary(ctx)  # (see _setup_distributed_laplacian)
-                if not canary:
-                    hd_transports = tuple(t for t in hd_transports if t != "direct") or ("rccl",)
             _test_hang(dog, "calibration")
             if transport == "native":  # (still: the plainest form ran on every rank)
-                names = []
-                for table in ("two_phase", "single_phase"):
-                    # (the "swap" schedules exist for this step too and are 4-6 % slower than "chain" on the self-loop: here the
-                    # interior kernel, not the chain, is the critical path -- GT4MI_BENCH_HDIFF_SCHEDULES adds them)
-                    schedules = tuple(os.environ.get("GT4MI_BENCH_HDIFF_SCHEDULES", "join,chain,inline").split(","))
-                    names += [f"fused_{table}_{sched}_wg{wg}_edge{edge}" + ("_direct" if tr == "direct" else "") for sched in schedules
-                              for wg in (0, 3, 2) for edge in edge_candidates
-                              for tr in hd_transports]
-                    names.append(f"sequential_{table}")
+                # (the "swap" schedules exist for this step too and are 4-6 % slower than "chain" on the self-loop: here the
+                # interior kernel, not the chain, is the critical path -- GT4MI_BENCH_HDIFF_SCHEDULES adds them)
+                schedules = tuple(os.environ.get("GT4MI_BENCH_HDIFF_SCHEDULES", "join,chain,inline").split(","))
                 pinned = os.environ.get("GT4MI_BENCH_FORM")
-                dog.arm(300, "calibration of the apply forms")
+                rccl_seconds = calibration_seconds("GT4MI_BENCH_CALIBRATION_SECONDS", 90)
+                direct_seconds = calibration_seconds("GT4MI_BENCH_DIRECT_CALIBRATION_SECONDS", 60)
+                dog.arm(rccl_seconds + direct_seconds + 600, "calibration of the apply forms")
                 ok, timings = 1, {}
                 try:
-                    for name in names:
-                        if name.endswith("_direct") and ctx.get("direct_dropped"):
-                            continue  # (see _setup_distributed_laplacian)
-                        if pinned is None or pinned == name:
-                            def make(name=name):
-                                fn, ex, check = make_form(name)
-                                return fn, ex.close, check
+                    first, refine, direct_stage = hdiff_calibration_order(schedules, edge_candidates, hd_transports)
 
-                            ms = measure_candidate(ctx, make, 16)
-                            if ms is not None:
-                                timings[name] = ms
-                            elif name.endswith("_direct"):
-                                ctx["direct_dropped"] = name
+                    def measure(name):
+                        def make(name=name):
+                            fn, ex, check = make_form(name)
+                            return fn, (lambda: ex.close(collective=False)), check
+
+                        return measure_candidate(ctx, make, 16)
+
+                    def wanted(names):
+                        return [n for n in names if pinned is None or pinned == n]
+
+                    def dropped(name):
+                        return name.endswith("_direct") and bool(ctx.get("direct_dropped"))
+
+                    def drop(name, key):
+                        if name.endswith("_direct"):
+                            ctx["direct_dropped"] = name
+
+                    def best_rccl():
+                        mine = {k: v for k, v in timings.items() if not k.endswith("_direct")}
+                        return min(mine, key=mine.get) if mine else None
+
+                    budget = WallBudget(ctx, rccl_seconds)
+                    run_calibration(wanted(first), str, measure, budget, timings, stats, dropped, drop)
+                    if best_rccl() is not None:
+                        run_calibration(wanted(refine(best_rccl())), str, measure, budget, timings, stats, dropped, drop)
+                    if "direct" in hd_transports:
+                        if distributed:
+                            canary = direct_canary(ctx)  # (see _setup_distributed_laplacian)
+                            dog.arm(direct_seconds + 600, "calibration of the direct transport")
+                        if canary is False:
+                            hd_transports = tuple(t for t in hd_transports if t != "direct") or ("rccl",)
+                        else:
+                            budget = WallBudget(ctx, direct_seconds)
+                            run_calibration(wanted(direct_stage(best_rccl())), str, measure, budget, timings, stats, dropped, drop)
                 except Exception as exn:
                     ok = 0
                     print(f"rank {rank}: native RCCL halo exchange failed during calibration ({exn!r})", file=sys.stderr)
@@ -1283,7 +1492,7 @@ def _setup_hdiff2048(args, ctx):
                         if cand_transport == "direct":
                             ex.use_direct_transport()
                         fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
-                        return fn, (lambda: (ex.end(), ex.close()))
+                        return fn, (lambda: (ex.end(), ex.close(collective=False)))
 
                     ms = measure_candidate(ctx, make, 32)
                     if ms is not None:
@@ -1305,7 +1514,8 @@ def _setup_hdiff2048(args, ctx):
               "calibration_ms_per_apply": timings, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped"),
               "direct_transport_canary": canary}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen),
-              "proof": proof, "transport_fallback": fallback, "timestep": pipelined_applies if decomposed else None}
+              "proof": proof, "transport_fallback": fallback, "timestep": pipelined_applies if decomposed else None,
+              "calibration": calibration_line_keys(timings, stats) if timings else None}
     return step, kernel_step, dec.local_domain, config, extras
 
 
@@ -1422,7 +1632,7 @@ def main() -> None:
         for i in range(3):
             kernel_step(i)
         torch.cuda.synchronize()
-        kt = _time_launches(kernel_step, max(args.steps, 10))
+        kt = _time_launches(kernel_step, max(args.steps, 50))  # (>= 50 timed launches)
         kernel_ms = kt["mean"]
         local_lups = float(np.prod(local_domain))
         achieved = bytes_per_lup * local_lups / (kernel_ms * 1e-3) / 1e9
@@ -1520,6 +1730,7 @@ def main() -> None:
         line["roofline"]["traffic"], line["roofline"]["traffic_source"] = _committed_traffic("lap5_f64_512")
     if decomposed:
         line.update(decomposed_line_keys(extras.get("proof"), bool(extras.get("transport_fallback")), n_gpus, None))
+        line.update(extras.get("calibration") or {})
     keep_safe(line, "the sections after the headline measurement are missing")
 
     exchangers = extras.get("exchangers") or []

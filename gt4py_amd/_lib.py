@@ -72,7 +72,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_stream_copy",
 )
 
-GT4MI_ABI_VERSION = 4
+GT4MI_ABI_VERSION = 5
 
 # gt4mi_status
 OK = 0
@@ -80,12 +80,13 @@ ERR_INVALID_ARGUMENT = -1
 ERR_OUT_OF_BOUNDS = -2
 ERR_UNSUPPORTED = -3
 ERR_HIP = -4
+ERR_TIMEOUT = -5
 
 # lap5 variants / flags
 LAP_NOTEBOOK, LAP_DOCS, LAP_SUITE, LAP_AVG = 0, 1, 2, 3
 LAP_LITERAL_F32 = 1
 # gt4mi_halo_plan_set_option
-PLAN_SCHEDULE, PLAN_INTERIOR_WG_PER_CU, PLAN_DEFER_JOIN, PLAN_EDGE_COLUMNS, PLAN_TRANSPORT = 0, 1, 2, 3, 4
+PLAN_SCHEDULE, PLAN_INTERIOR_WG_PER_CU, PLAN_DEFER_JOIN, PLAN_EDGE_COLUMNS, PLAN_TRANSPORT, PLAN_DIRECT_TIMEOUT_MS = 0, 1, 2, 3, 4, 5
 TRANSPORT_RCCL, TRANSPORT_DIRECT = 0, 1
 SCHEDULE_JOIN, SCHEDULE_CHAIN, SCHEDULE_SWAP, SCHEDULE_SWAP_PACKED, SCHEDULE_INLINE = 0, 1, 2, 3, 4
 # hdiff flags

@@ -130,8 +130,11 @@ struct gt4mi_halo_plan {
         size_t pool_bytes = 0;
         std::vector<size_t> recv_offset[2];
         uint32_t* flags = nullptr;          // my flag words = the first page of the pool: [arrived: one per receive][consumed: one per send]
-        uint32_t* error = nullptr;          // device: a wait ran out of time
+        uint32_t* error = nullptr;          // HOST memory mapped into the device: a wait ran out of time (direct_failed reads it)
         unsigned* ring_counters = nullptr;  // device: workgroups of a fused unpack + ring launch that have read their face (2 words)
+        int timeout_ms = 0;                 // GT4MI_PLAN_DIRECT_TIMEOUT_MS (0: GT4MI_DIRECT_TIMEOUT_MS, else 30 s)
+        const char* broken = nullptr;       // an exchange was enqueued only in part: which step failed (the plan stays failed)
+        bool lose_signals = false;          // tests: GT4MI_DIRECT_TEST_LOSE_SIGNALS was set when the plan was prepared
         uint32_t step = 0;                  // exchanges started
         bool first_pushed = false;          // halo_pack_first already pushed the first phase of exchange `step`
         struct Peer {
@@ -317,14 +320,20 @@ inline int first_phase(const gt4mi_halo_plan* plan) {
 // so a caller can enqueue this ahead of its interior kernel).
 inline int direct_push(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s);    // direct.hip.h
 inline int direct_unpack(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s);
+inline int direct_failed(const gt4mi_halo_plan* plan);
 
 inline int halo_pack_first(gt4mi_halo_plan* plan, const gt4mi_field* field, hipStream_t s) {
     const int p = first_phase(plan);
     if (p > 1) return GT4MI_OK;
     if (plan->transport == GT4MI_TRANSPORT_DIRECT) {  // the pack IS the transfer
-        ++plan->direct.step;
+        if (int rc = direct_failed(plan)) return rc;
+        ++plan->direct.step;  // (the push reads it)
+        if (int rc = direct_push(plan, field, p, s)) {
+            --plan->direct.step;  // nothing was launched: the counters still agree with the neighbours'
+            return rc;
+        }
         plan->direct.first_pushed = true;
-        return direct_push(plan, field, p, s);
+        return GT4MI_OK;
     }
     return plan_copy<true>(plan, field, plan->sends[p], s);
 }
@@ -336,12 +345,26 @@ inline int halo_exchange_on(gt4mi_halo_plan* plan, const gt4mi_field* field, hip
     if (plan->transport == GT4MI_TRANSPORT_DIRECT) {
         // every face is stored straight into its neighbour's receive buffer by the pack kernel, whose last workgroup raises the
         // neighbour's flag; the unpack kernel waits for its own flags, copies, and tells the senders that their buffers are free
-        if (!(first_pack_done && plan->direct.first_pushed)) ++plan->direct.step;
+        if (int rc = direct_failed(plan)) return rc;
+        const bool pushed = first_pack_done && plan->direct.first_pushed;
+        if (!pushed) ++plan->direct.step;
+        bool launched = pushed;  // something of this exchange is already on the device
         for (int phase = 0; phase < 2; ++phase) {
             if (plan->sends[phase].empty() && plan->recvs[phase].empty()) continue;
-            if (!(first_pack_done && plan->direct.first_pushed && phase == p0))
-                if (int rc = direct_push(plan, field, phase, s)) return rc;
-            if (int rc = direct_unpack(plan, field, phase, s)) return rc;
+            int rc = GT4MI_OK;
+            if (!(pushed && phase == p0)) rc = direct_push(plan, field, phase, s);
+            if (rc == GT4MI_OK) {
+                launched = launched || !plan->sends[phase].empty();
+                rc = direct_unpack(plan, field, phase, s);
+            }
+            if (rc != GT4MI_OK) {
+                // nothing launched yet: as if the call had never been made; else the neighbours will count an exchange that this
+                // rank never completes -- the plan has failed (the error of THIS call is the launch's own)
+                if (!launched) --plan->direct.step;
+                else plan->direct.broken = "a push or unpack launch of a later phase was refused";
+                return rc;
+            }
+            launched = true;
         }
         plan->direct.first_pushed = false;
         return GT4MI_OK;

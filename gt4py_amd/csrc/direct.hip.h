@@ -16,10 +16,18 @@
 //     polling workgroup is a PCIe read);
 //   * ordering without fences: the writer's stores to the peer are write-through (sc0 sc1: system scope), every wave waits for
 //     their acknowledgement (s_waitcnt vmcnt(0)), barrier, then one lane ADDS 1 to the flag (the flags count workgroups:
-//     16 KB of a message each, on both sides); the reader loads its receive buffer past the caches (sc0 sc1 loads) while one
-//     lane looks at the flag, and loads once more if the count was not there yet (bounded wait: 2 s, then the plan's error word
-//     is set and the data is garbage, which the callers' checks see).  Neither side ever writes back or invalidates a cache
+//     16 KB of a message each, on both sides); on the reader's side ONE lane polls the flag, a barrier, and only THEN the
+//     workgroup loads its receive buffer, past the caches (sc0 sc1 loads): message passing needs the payload loads behind the
+//     flag load.  (Rounds 2-3 issued the payload loads first and looked at the flag while they were in flight, reloading only
+//     when the first look said "not yet": a payload load served before the peer's store landed and a flag load served after
+//     its add -- different channels, no order between them -- delivered the PREVIOUS exchange's ghost values with a flag that
+//     said "ready".  One dependent round trip cheaper, and wrong.)  Neither side ever writes back or invalidates a cache
 //     (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 stores AND sc1 loads");
+//   * a wait is bounded (GT4MI_PLAN_DIRECT_TIMEOUT_MS / GT4MI_DIRECT_TIMEOUT_MS, default 30 s) and a wait that runs out FAILS
+//     HARD: the workgroup copies nothing and signals nothing (no garbage in ghost cells, no buffer overwritten that the peer has
+//     not consumed), one lane sets the plan's error word -- host memory mapped into the device --, and every later call on the
+//     plan (exchange, fused step, gt4mi_halo_exchange_end) reads that word without synchronising and returns
+//     GT4MI_ERR_TIMEOUT.  The counts never match again: the plan stays failed until it is destroyed (on every rank);
 //   * who talks to whom is set up by the host side (gt4py_amd/distributed/native.py: the k-th send to a peer lands in the buffer
 //     of the k-th receive that peer posted for this rank, exactly RCCL's matching rule).
 //
@@ -40,8 +48,24 @@ struct DirectBatch {
     uint32_t* signal_flag[BoxBatch::MAX];  // ... and every workgroup of box m adds 1 there when its part is done
     uint32_t wait_value[BoxBatch::MAX];
     unsigned blocks[BoxBatch::MAX];        // workgroups that work on box m (the others of the launch leave at once)
-    uint32_t* error;
+    uint32_t* error;                       // host memory mapped into the device: a wait ran out of time
+    long long timeout_ticks;               // of the 100 MHz wall clock
 };
+
+// One lane waits until *flag has reached `value` (counters wrap: "has reached" = the signed difference is not negative).  False
+// = out of time: the plan's error word is set, the caller must neither copy nor signal.
+__device__ __forceinline__ bool direct_wait(const uint32_t* flag, uint32_t value, long long timeout_ticks, uint32_t* error) {
+    if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) >= 0) return true;
+    const long long t0 = wall_clock64();  // 100 MHz
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+        if (wall_clock64() - t0 > timeout_ticks) {  // the peer is not coming
+            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return true;
+}
 
 constexpr int DIRECT_UNROLL = 4;                                   // 16-byte vectors per thread
 constexpr int64_t DIRECT_VECTORS_PER_BLOCK = 256 * DIRECT_UNROLL;  // 16 KB of every message per workgroup -- on BOTH sides: the
@@ -64,8 +88,9 @@ __device__ __forceinline__ u32x4 direct_load(const u32x4* where) {
 
 // The copy of halo_batch_kernel (comm.hip.h) with a wait in front and a signal behind.  PACK: field box -> `buffer` (the peer's
 // receive buffer; wait: the peer has unpacked the previous exchange); else `buffer` (my receive buffer) -> field box (wait: the
-// data has arrived).  Next to an HBM-saturating interior kernel every DEPENDENT memory round trip costs ~10 us, so the kernel
-// has two of them: (flag poll || loads), then the stores; the signal is a posted add.
+// data has arrived).  Next to an HBM-saturating interior kernel every DEPENDENT memory round trip costs ~10 us.  PACK has two
+// of them: (flag poll || loads of my own field), then the stores; the signal is a posted add.  The unpack has three: the flag,
+// THEN the loads of the receive buffer (see "ordering" above), then the stores.
 template <typename U, bool PACK>
 __device__ __forceinline__ void direct_block(U* field, int64_t si, int64_t sj, int64_t sk, const BoxBatch& b, const DirectBatch& d,
                                              const int m, const unsigned block) {
@@ -108,30 +133,28 @@ __device__ __forceinline__ void direct_block(U* field, int64_t si, int64_t sj, i
             }
         }
     };
-    load_all();  // in flight while lane 0 looks at the flag
+#ifdef GT4MI_DIRECT_ROUND3_LOAD_ORDER
+    // (evidence build only, `make r3order`: the receive side as rounds 2-3 had it -- payload loads first, one look at the flag
+    // while they are in flight, a reload only if that look said "not yet"; profiles/r4_two_rank_direct_loop.log)
+    __shared__ int first_look;
+    load_all();
     if (threadIdx.x == 0) {
-        // (counters wrap: "has reached" = the signed difference is not negative)
-        int ok = (int)(__hip_atomic_load(d.wait_flag[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.wait_value[m]) >= 0;
-        ready = ok;
-        if (!ok) {
-            const long long t0 = wall_clock64();  // 100 MHz
-            while ((int)(__hip_atomic_load(d.wait_flag[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.wait_value[m]) < 0) {
-                if (wall_clock64() - t0 > 200000000LL) {  // 2 s: the peer is not coming
-                    __hip_atomic_store(d.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-        }
+        first_look = (int)(__hip_atomic_load(d.wait_flag[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - d.wait_value[m]) >= 0;
+        ready = direct_wait(d.wait_flag[m], d.wait_value[m], d.timeout_ticks, d.error) ? 1 : 0;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the asm loads of the unpack side are invisible to the compiler)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if constexpr (!PACK) {
-        if (!ready) {  // what was loaded before the data had arrived is the previous exchange's: once more
-            load_all();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
+    if (!ready) return;
+    if constexpr (!PACK)
+        if (!first_look) load_all();
+#else
+    if constexpr (PACK) load_all();  // my own field: in flight while lane 0 looks at the flag
+    if (threadIdx.x == 0) ready = direct_wait(d.wait_flag[m], d.wait_value[m], d.timeout_ticks, d.error) ? 1 : 0;
+    __syncthreads();
+    if (!ready) return;  // out of time: nothing is copied, nothing is signalled -- the plan has failed (direct_failed)
+    if constexpr (!PACK) load_all();  // behind the flag: what the peer stored before it raised it
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the asm loads of the unpack side are invisible to the compiler)
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
         const int64_t tv = tv0 + (int64_t)u * 256;
@@ -163,6 +186,32 @@ template <typename U, bool PACK>
 __global__ void __launch_bounds__(256)
 halo_direct_kernel(U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch b, DirectBatch d) {
     direct_block<U, PACK>(field, si, sj, sk, b, d, (int)blockIdx.y, blockIdx.x);
+}
+
+// How long a wait may take, in ticks of the 100 MHz wall clock: the plan's option, else GT4MI_DIRECT_TIMEOUT_MS, else 30 s (a
+// neighbour that compiles a kernel, pages in a library or sits in a debugger is seconds late and not broken; RCCL would wait
+// for ever).
+inline long long direct_timeout_ticks(const gt4mi_halo_plan* plan) {
+    static const int env = env_int("GT4MI_DIRECT_TIMEOUT_MS", 30000);
+    const long long ms = plan->direct.timeout_ms > 0 ? plan->direct.timeout_ms : (env > 0 ? env : 30000);
+    return ms * 100000LL;
+}
+
+// The plan's direct transport has failed -- a wait ran out of time on the device (the error word is host memory: read here
+// without synchronising anything), or an exchange was enqueued only in part -- and stays failed: every entry point that
+// touches the exchange asks this first.
+inline int direct_failed(const gt4mi_halo_plan* plan) {
+    const auto& dx = plan->direct;
+    if (!dx.prepared) return GT4MI_OK;
+    if (dx.broken)
+        return fail(GT4MI_ERR_HIP, "direct transport: an earlier exchange of this plan was enqueued only in part (%s); its flags no longer "
+                                   "count what the neighbours count: destroy the plan on every rank", dx.broken);
+    if (dx.error && __atomic_load_n(dx.error, __ATOMIC_RELAXED) != 0u)
+        return fail(GT4MI_ERR_TIMEOUT, "direct transport: a wait for a neighbour ran out of time (%lld ms) in one of the %u exchanges this "
+                                       "plan has started; the workgroup that waited copied and signalled nothing, the ghost cells of that "
+                                       "exchange are incomplete and the plan stays failed: destroy it on every rank",
+                    direct_timeout_ticks(plan) / 100000LL, dx.step);
+    return GT4MI_OK;
 }
 
 inline int direct_index(const gt4mi_halo_plan* plan, bool is_send, int phase, int m) {
@@ -205,14 +254,14 @@ inline int direct_batches(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase
         const unsigned nb = direct_blocks(msgs[m].bytes);
         d.wait_flag[m] = dx.flags + direct_index(plan, PACK, phase, m);
         d.wait_value[m] = (PACK ? dx.step - 1 : dx.step) * nb;
-        // (GT4MI_DIRECT_TEST_LOSE_SIGNALS=1, tests only: the pushes signal into an unused word -- what a broken link looks like
-        // from the receiver's side: its waits run out of time, its data is the previous exchange's)
-        static const int lose_signals = env_int("GT4MI_DIRECT_TEST_LOSE_SIGNALS", 0);
-        d.signal_flag[m] = (PACK && lose_signals) ? dx.flags + DIRECT_FLAG_BYTES / sizeof(uint32_t) - 1 : signal;
+        // (GT4MI_DIRECT_TEST_LOSE_SIGNALS=1 when the plan was prepared, tests only: the pushes signal into an unused word -- what a
+        // broken link looks like from the receiver's side: its waits run out of time)
+        d.signal_flag[m] = (PACK && dx.lose_signals) ? dx.flags + DIRECT_FLAG_BYTES / sizeof(uint32_t) - 1 : signal;
         d.blocks[m] = nb;
         blocks = nb > blocks ? nb : blocks;
     }
     d.error = dx.error;
+    d.timeout_ticks = direct_timeout_ticks(plan);
     return GT4MI_OK;
 }
 
@@ -248,37 +297,57 @@ inline int direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* out) {
         // while kernels of this one read them, so no cache may keep a copy.
         const size_t nflags = plan->recvs[0].size() + plan->recvs[1].size() + plan->sends[0].size() + plan->sends[1].size();
         if ((nflags + 1) * sizeof(uint32_t) > DIRECT_FLAG_BYTES) return fail(GT4MI_ERR_UNSUPPORTED, "direct transport: %d messages", (int)nflags);
+        std::vector<size_t> offsets[2];
         size_t bytes = DIRECT_FLAG_BYTES;
         for (int p = 0; p < 2; ++p)
             for (auto& m : plan->recvs[p]) {
-                dx.recv_offset[p].push_back(bytes);
+                offsets[p].push_back(bytes);
                 bytes += (m.bytes + 255) / 256 * 256;
             }
-        dx.pool_bytes = bytes;
-        void* pool = nullptr;
-        if (hipExtMallocWithFlags(&pool, dx.pool_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        // every allocation first; the plan changes only once all of them have succeeded (a plan whose preparation failed
+        // keeps its own receive buffers and is destroyed like any other)
+        void *pool = nullptr, *error = nullptr, *counters = nullptr;
+        auto give_up = [&](int rc) {
+            if (pool) (void)hipFree(pool);
+            if (error) (void)hipHostFree(error);
+            if (counters) (void)hipFree(counters);
             (void)hipGetLastError();
-            return fail(GT4MI_ERR_UNSUPPORTED, "direct transport: this runtime offers no fine-grained device memory (hipDeviceMallocFinegrained)");
+            return rc;
+        };
+        if (hipExtMallocWithFlags(&pool, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            pool = nullptr;
+            return give_up(fail(GT4MI_ERR_UNSUPPORTED, "direct transport: this runtime offers no fine-grained device memory (hipDeviceMallocFinegrained)"));
         }
-        GT4MI_HIP_CHECK(hipMemset(pool, 0, DIRECT_FLAG_BYTES));
+        // the error word: HOST memory the device can write (a lane whose wait ran out of time stores there, over PCIe, once);
+        // the host reads it without a synchronising call (direct_failed)
+        if (hipHostMalloc(&error, 64, hipHostMallocMapped) != hipSuccess) {
+            error = nullptr;
+            return give_up(fail(GT4MI_ERR_HIP, "direct transport: hipHostMalloc of the error word failed"));
+        }
+        memset(error, 0, 64);
+        if (hipMalloc(&counters, 4 * sizeof(unsigned)) != hipSuccess) {
+            counters = nullptr;
+            return give_up(fail(GT4MI_ERR_HIP, "direct transport: hipMalloc of the ring counters failed"));
+        }
+        if (hipMemset(pool, 0, DIRECT_FLAG_BYTES) != hipSuccess || hipMemset(counters, 0, 4 * sizeof(unsigned)) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess)
+            return give_up(fail(GT4MI_ERR_HIP, "direct transport: clearing the flag words failed"));
+        dx.pool_bytes = bytes;
         dx.pool = static_cast<char*>(pool);
         dx.flags = reinterpret_cast<uint32_t*>(pool);
-        for (int p = 0; p < 2; ++p)
+        dx.error = static_cast<uint32_t*>(error);
+        dx.ring_counters = static_cast<unsigned*>(counters);
+        for (int p = 0; p < 2; ++p) {
+            dx.recv_offset[p] = offsets[p];
             for (size_t m = 0; m < plan->recvs[p].size(); ++m) {
                 if (plan->recvs[p][m].buffer) (void)hipFree(plan->recvs[p][m].buffer);
                 plan->recvs[p][m].buffer = dx.pool + dx.recv_offset[p][m];
             }
-        void* word = nullptr;
-        GT4MI_HIP_CHECK(hipMalloc(&word, 4 * sizeof(uint32_t)));
-        GT4MI_HIP_CHECK(hipMemset(word, 0, 4 * sizeof(uint32_t)));
-        dx.error = static_cast<uint32_t*>(word);
-        dx.ring_counters = reinterpret_cast<unsigned*>(dx.error + 1);
-        for (int p = 0; p < 2; ++p) {
             dx.send_to[p].assign(plan->sends[p].size(), nullptr);
             dx.signal_arrived[p].assign(plan->sends[p].size(), nullptr);
             dx.signal_consumed[p].assign(plan->recvs[p].size(), nullptr);
         }
-        GT4MI_HIP_CHECK(hipDeviceSynchronize());
+        dx.lose_signals = env_int("GT4MI_DIRECT_TEST_LOSE_SIGNALS", 0) != 0;
         dx.prepared = true;
     }
     if (out) {
@@ -354,13 +423,19 @@ inline int direct_connect(gt4mi_halo_plan* plan, int phase, int is_send, int ind
     return GT4MI_OK;
 }
 
+// COLLECTIVE in effect: the pool is mapped by the neighbours, whose last unpack kernels post their "consumed" adds into it and
+// whose pushes may still be on their way -- the caller frees it only after EVERY rank of the decomposition has finished its
+// last exchange on the device (NativeHaloExchanger.close: device synchronise, then a round over the ranks' control channel;
+// INTEGRATION.md "closing a plan").  This rank's own kernels are waited for here.
 inline void direct_release(gt4mi_halo_plan* plan) {
     auto& dx = plan->direct;
     if (!dx.prepared) return;
+    (void)hipDeviceSynchronize();
     for (auto& p : dx.peers)
         if (p.opened_pool) (void)hipIpcCloseMemHandle(p.pool);
     dx.peers.clear();
-    if (dx.error) (void)hipFree(dx.error);
+    if (dx.error) (void)hipHostFree(dx.error);
+    if (dx.ring_counters) (void)hipFree(dx.ring_counters);
     for (int p = 0; p < 2; ++p)
         for (auto& m : plan->recvs[p]) m.buffer = nullptr;  // they lived in the pool
     if (dx.pool) (void)hipFree(dx.pool);

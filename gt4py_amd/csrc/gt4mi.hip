@@ -97,6 +97,7 @@ int dist_hdiff(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field
         return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_hdiff: the plan moves %d-byte items, the fields hold %d-byte items",
                            plan->elem_size, (int)sizeof(T));
     hipStream_t ms = static_cast<hipStream_t>(main_stream);
+    if (int rc = gt4mi::direct_failed(plan)) return rc;
     if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
     const int64_t di = domain[0], dj = domain[1], dk = domain[2];
     constexpr int64_t H = 2;  // the stencil's reach
@@ -197,6 +198,7 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
         return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5: the plan moves %d-byte items, the fields hold %d-byte items",
                            plan->elem_size, (int)sizeof(T));
     hipStream_t ms = static_cast<hipStream_t>(main_stream);
+    if (int rc = gt4mi::direct_failed(plan)) return rc;
     if (int rc = gt4mi::ensure_concurrent_stream(plan, ms)) return rc;
     const int64_t di = domain[0], dj = domain[1], dk = domain[2];
     // W / E: the ring takes a box EW columns wide off the interior kernel (whole cache lines; and the interior then starts
@@ -594,6 +596,10 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
             }
             plan->transport = value;
             return GT4MI_OK;
+        case GT4MI_PLAN_DIRECT_TIMEOUT_MS:
+            if (value < 0) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: a timeout of %d ms", value);
+            plan->direct.timeout_ms = value;
+            return GT4MI_OK;
     }
     return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: unknown option %d", option);
 }
@@ -626,8 +632,8 @@ int gt4mi_halo_plan_direct_connect(gt4mi_halo_plan* plan, int phase, int is_send
 
 int gt4mi_halo_plan_direct_status(gt4mi_halo_plan* plan, int* timed_out, unsigned* exchanges) {
     if (plan == nullptr || !plan->direct.prepared) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_direct_status: not prepared");
-    uint32_t word = 0;
-    GT4MI_HIP_CHECK(hipMemcpy(&word, plan->direct.error, sizeof word, hipMemcpyDeviceToHost));  // (synchronises)
+    GT4MI_HIP_CHECK(hipDeviceSynchronize());  // every exchange started so far has either completed or given up
+    const uint32_t word = __atomic_load_n(plan->direct.error, __ATOMIC_RELAXED);  // (host memory the device writes)
     if (timed_out) *timed_out = (int)word;
     if (exchanges) *exchanges = plan->direct.step;
     return GT4MI_OK;
@@ -679,6 +685,7 @@ int gt4mi_halo_exchange_begin(gt4mi_halo_plan* plan, const gt4mi_field* field, v
 
 int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream) {
     if (plan == nullptr) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_exchange_end: null plan");
+    if (int rc = gt4mi::direct_failed(plan)) return rc;  // a wait of an EARLIER exchange ran out of time: say so now
     if (!plan->done_recorded) return GT4MI_OK;  // nothing was ever put in flight on the side stream
     GT4MI_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(main_stream), plan->done, 0));
     return GT4MI_OK;

@@ -5,8 +5,9 @@
 // unpack (receive buffers -> ghost rows, 8 us) and the ring (the rows that read them, 5 us).  The ring reads what the unpack
 // writes, so the two cannot simply share a launch -- unless every ring tile fetches ITS part of the ghost row from the receive
 // buffer itself: a wave owns 64 x VEC columns of one level of the first or last row of the domain; it loads the ghost values for
-// its columns past the caches (they were written by another agent) while one lane of the workgroup looks at the arrival flag,
-// writes them into the field's ghost cells (the exchange's contract: `inp` has its ghost cells afterwards; the wave at either
+// its columns past the caches (they were written by another agent) AFTER one lane of the workgroup has seen the arrival flag
+// (message passing: payload loads behind the flag load, direct.hip.h "ordering"; the loads of the field's own rows, which do not
+// depend on the flag, are in flight meanwhile), writes them into the field's ghost cells (the exchange's contract: `inp` has its ghost cells afterwards; the wave at either
 // end of the row also the corner columns a face may carry), and computes its points from them -- the same expression
 // (lap5_expr) on the same values as the two-launch form, bit for bit.  The last workgroup of a face tells the sender that
 // its buffer is free again (as many counts as the plain unpack kernel would have added: the flags count 16 KB blocks).
@@ -30,7 +31,8 @@ struct RowGhosts {
     uint32_t consumed_add[2];
     unsigned* counter[2];         // device: workgroups of this face that have read their part
     unsigned blocks[2];
-    uint32_t* error;
+    uint32_t* error;              // host memory mapped into the device
+    long long timeout_ticks;
 };
 
 constexpr int RING_UNPACK_LEVELS = 8;  // K levels per wave: all their loads in flight at once, and an eighth of the workgroups
@@ -69,8 +71,10 @@ lap5_ring_unpack_kernel(View<T> in, View<T> out, int dI, int dK, unsigned tiles_
             ghost_e[l] = corner_e ? __hip_atomic_load(buf + dI, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : (U)0;
         }
     };
-    load_ghosts();  // in flight while lane 0 looks at the flag; the field's own rows do not depend on it at all
-    T c[LG][VEC], o[LG][VEC], w[LG], e[LG];
+#ifdef GT4MI_DIRECT_ROUND3_LOAD_ORDER
+    load_ghosts();  // (evidence build only, see direct_block: the ghost loads in front of the flag load)
+#endif
+    T c[LG][VEC], o[LG][VEC], w[LG], e[LG];  // the field's own rows: in flight while lane 0 waits for the face
 #pragma unroll
     for (int l = 0; l < LG; ++l) {
         T* const row = in.p + (int64_t)level(l) * in.sk + (int64_t)j * in.sj + i0;
@@ -81,22 +85,21 @@ lap5_ring_unpack_kernel(View<T> in, View<T> out, int dI, int dK, unsigned tiles_
         if (lane == 0) w[l] = row[-1];
         if (lane == 63 || i0 + VEC >= dI) e[l] = row[VEC];
     }
+#ifdef GT4MI_DIRECT_ROUND3_LOAD_ORDER
+    __shared__ int first_look;
     if (threadIdx.x == 0) {
-        int ok = (int)(__hip_atomic_load(g.wait_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - g.wait_value[f]) >= 0;
-        ready = ok;
-        if (!ok) {
-            const long long t0 = wall_clock64();  // 100 MHz
-            while ((int)(__hip_atomic_load(g.wait_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - g.wait_value[f]) < 0) {
-                if (wall_clock64() - t0 > 200000000LL) {  // 2 s: the peer is not coming
-                    __hip_atomic_store(g.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-        }
+        first_look = (int)(__hip_atomic_load(g.wait_flag[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - g.wait_value[f]) >= 0;
+        ready = direct_wait(g.wait_flag[f], g.wait_value[f], g.timeout_ticks, g.error) ? 1 : 0;
     }
     __syncthreads();
-    if (!ready) load_ghosts();  // what was loaded before the face had arrived is the previous exchange's
+    if (!ready) return;
+    if (!first_look) load_ghosts();
+#else
+    if (threadIdx.x == 0) ready = direct_wait(g.wait_flag[f], g.wait_value[f], g.timeout_ticks, g.error) ? 1 : 0;
+    __syncthreads();
+    if (!ready) return;  // out of time: no ghost cell written, no point computed, nothing signalled -- the plan has failed
+    load_ghosts();       // behind the flag: what the sender stored before it raised it
+#endif
 #pragma unroll
     for (int l = 0; l < LG; ++l) {
         const int k = k0 + l;
@@ -179,6 +182,7 @@ inline int lap5_ring_unpack_run(gt4mi_halo_plan* plan, const int64_t domain[3], 
     if (g.n == 2 && g.row[0] == g.row[1]) return GT4MI_OK;
     for (int f = g.n; f < 2; ++f) g.blocks[f] = 0;
     g.error = dx.error;
+    g.timeout_ticks = direct_timeout_ticks(plan);
 #define GT4MI_LAP5_RING_UNPACK(V)                                                                                                  \
     hipLaunchKernelGGL((lap5_ring_unpack_kernel<T, W, V, VEC>), dim3(blocks, (unsigned)g.n), dim3(256), 0, stream, in_v, out_v, (int)di, \
                        (int)dk, tiles_x, g)

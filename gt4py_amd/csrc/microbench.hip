@@ -543,17 +543,17 @@ static void tridiag_variant(DevField<T>& a, DevField<T>& d, DevField<T>& s, DevF
     report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
 }
 
-template <int RL, int LL, int U, bool PIPE = false, int WPB = 1>
+template <int RL, int LL, int U, bool PIPE = false, int WPB = 1, int MAP = 0>
 static void tridiag_stack_variant(DevField<double>& a, DevField<double>& d, DevField<double>& s, DevField<double>& r,
                                   DevField<double>& o, DevField<double>& s2, DevField<double>& r2, DevField<double>& o2,
                                   int dI, int dJ, int dK) {
     const unsigned ti = (unsigned)cdiv(dI, 64);
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%s RL=%d LL=%d U=%d WPB=%d (mem levels %d)", PIPE ? "pipe " : "stack", RL, LL, U, WPB, dK - RL - LL);
+    snprintf(cfg, sizeof cfg, "%s RL=%d LL=%d U=%d WPB=%d MAP=%d (mem levels %d)", PIPE ? "pipe " : "stack", RL, LL, U, WPB, MAP, dK - RL - LL);
     if (dK - RL - LL < 1) return;
     auto launch = [&]() {
         if constexpr (PIPE)
-            hipLaunchKernelGGL((tridiag_pipe_kernel<double, RL, LL, U, WPB>), dim3(ti * (unsigned)cdiv(dJ, WPB)), dim3(64, WPB), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+            hipLaunchKernelGGL((tridiag_pipe_kernel<double, RL, LL, U, WPB, MAP>), dim3(ti * (unsigned)cdiv(dJ, WPB)), dim3(64, WPB), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
         else
             hipLaunchKernelGGL((tridiag_stack_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
     };
@@ -628,6 +628,36 @@ static void section_tripmc() {
         tridiag_variant<double, 1, 8>(a, d, s, r, o, dI, dJ, dK, "1024x1024x160");
     }
     lap_suite(512, 512, 512, 0, "512^3");
+}
+
+// Which (I tile, J row) a workgroup takes (tridiag_pipe_kernel's MAP): time, and -- under rocprofv3 --pmc -- the translation
+// counters, per mapping (round 4).  Also on a domain that is no multiple of anything.
+static void section_trimap() {
+    for (int rep = 0; rep < 2; ++rep) {
+        const int dI = 1024, dJ = 1024, dK = 160;
+        DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
+        DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+        fill(a, 1, -1.0, 1.0);
+        fill(d, 2, 4.0, 5.0);
+        tridiag_stack_variant<104, 40, 4, true, 1, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 1, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 1, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 1, 3>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<80, 40, 8, true, 1, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<80, 40, 8, true, 1, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<80, 40, 8, true, 1, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<80, 40, 8, true, 1, 3>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    }
+    {
+        const int dI = 200, dJ = 301, dK = 150;
+        DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
+        DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+        fill(a, 1, -1.0, 1.0);
+        fill(d, 2, 4.0, 5.0);
+        tridiag_stack_variant<104, 40, 4, true, 1, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 1, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 1, 3>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    }
 }
 
 // pipelined vs plain on-chip-stack kernel, also on column counts / depths that exercise the head and odd-batch paths
@@ -978,6 +1008,7 @@ int main(int argc, char** argv) {
     if (on("tridiag")) section_tridiag();
     if (!want.empty() && on("triplace")) section_triplace(0, want);
     if (!want.empty() && on("tripipe")) section_tripipe();
+    if (!want.empty() && on("trimap")) section_trimap();
     if (!want.empty() && on("tripmc")) section_tripmc();
     if (!want.empty() && on("trilayout")) section_trilayout();
     if (!want.empty() && on("vadv")) section_vadv();

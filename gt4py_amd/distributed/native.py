@@ -142,12 +142,14 @@ class NativeHaloExchanger:
         self._plan = plan
         self._lib = lib
         self.transport = "rccl"
+        self._close_round = None  # direct transport with other ranks: the collective that precedes the release of the pool
         nb = decomp.neighbours
         self.sides = ((1 if nb["W"] is not None else 0) | (2 if nb["E"] is not None else 0)
                       | (4 if nb["S"] is not None else 0) | (8 if nb["N"] is not None else 0))
 
     def tune(self, schedule: Optional[str] = None, interior_wg_per_cu: Optional[int] = None,
-             defer_join: Optional[bool] = None, edge_columns: Optional[int] = None) -> "NativeHaloExchanger":
+             defer_join: Optional[bool] = None, edge_columns: Optional[int] = None,
+             direct_timeout_ms: Optional[int] = None) -> "NativeHaloExchanger":
         """How the fused distributed steps built on this exchanger are scheduled (gt4mi_halo_plan_set_option):
         ``schedule`` "join" (pack and interior on the caller's stream, send/recv/unpack beside it, join, ring), "chain"
         (the caller's stream carries the interior only; pack, send/recv, unpack and ring in order on the side stream) or
@@ -169,6 +171,9 @@ class NativeHaloExchanger:
         if defer_join is not None:  # independent applies: the caller joins with end() before consuming results
             _lib.check("gt4mi_halo_plan_set_option",
                        self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_DEFER_JOIN, int(bool(defer_join))))
+        if direct_timeout_ms is not None:  # direct transport: how long a device-side wait may take before the plan fails (0: default)
+            _lib.check("gt4mi_halo_plan_set_option",
+                       self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_DIRECT_TIMEOUT_MS, int(direct_timeout_ms)))
         return self
 
     @staticmethod
@@ -201,7 +206,14 @@ class NativeHaloExchanger:
         send to a peer lands in the buffer of the k-th receive that peer posted for this rank.
 
         A rank on which a step fails (no fine-grained device memory, a handle that cannot be opened) still takes part in
-        both rounds of the gather, so that EVERY rank raises ``RuntimeError`` together and stays on RCCL."""
+        both rounds of the gather, so that EVERY rank raises ``RuntimeError`` together and stays on RCCL.
+
+        From here on ``close()`` is COLLECTIVE too (one more round over the same channel): the neighbours' kernels write into
+        this rank's pool, which may only be released once every rank's last exchange has finished on its device.
+
+        Failure is hard: a device-side wait for a neighbour that runs out of time (``tune(direct_timeout_ms=...)``, default
+        30 s) leaves the ghost cells of that exchange incomplete and fails the plan -- the next ``exchange`` / fused step /
+        ``end()`` raises ``NativeError`` (status ``ERR_TIMEOUT``), and so does every call after it."""
         lib, plan = self._lib, self._plan
         sends, recvs = self.message_tables(self.decomp, self.single_phase)
         rank = self.decomp.rank
@@ -266,6 +278,7 @@ class NativeHaloExchanger:
             raise RuntimeError("the direct halo transport is not available on every rank: " + "; ".join(sorted(set(failures))))
         _lib.check("gt4mi_halo_plan_set_option", lib.gt4mi_halo_plan_set_option(plan, _lib.PLAN_TRANSPORT, _lib.TRANSPORT_DIRECT))
         self.transport = "direct"
+        self._close_round = None if alone else all_gather
         return self
 
     def use_rccl_transport(self) -> "NativeHaloExchanger":
@@ -428,13 +441,28 @@ class NativeHaloExchanger:
         step._keepalive = (fa, fb, dom, field_a, field_b)  # type: ignore[attr-defined]
         return step
 
-    def close(self) -> None:
+    def close(self, collective: bool = True) -> None:
+        """Destroy the native plan.  Once ``use_direct_transport`` has connected this exchanger to OTHER ranks this is a
+        COLLECTIVE call: every rank synchronises its device (its last pushes and "consumed" signals have landed), the ranks
+        meet once on the channel that carried the pools' descriptions, and only then is the pool unmapped and freed --
+        a neighbour's kernel never writes into memory that is gone.  ``collective=False`` is for a caller that has established
+        exactly that itself: since this plan's last exchange every rank has synchronised its device AND met the others in a
+        collective (``bench.py``'s candidates: the all-reduce of the timings)."""
         if self._plan is not None and self._plan.value:
+            if self._close_round is not None and collective:
+                import torch
+
+                torch.cuda.synchronize()  # the whole device: the plan's side stream too
+                self._close_round(("closing", self.decomp.rank))
+            self._close_round = None
             self._lib.gt4mi_halo_plan_destroy(self._plan)
             self._plan = ctypes.c_void_p()
 
     def __del__(self):  # pragma: no cover
+        # (never collective: a garbage-collected exchanger that is still connected to other ranks keeps its pool -- a leak is
+        # harmless, a neighbour's store into freed memory is a fault on ITS device)
         try:
-            self.close()
+            if self._close_round is None:
+                self.close()
         except Exception:
             pass

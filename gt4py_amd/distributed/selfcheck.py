@@ -123,7 +123,11 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
     direct_only = tuple(transports) == ("direct",)  # the direct transport alone: no RCCL anywhere, the descriptions travel over gloo
     if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():  # (launched by torch.distributed.run, any world size)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if direct_only:
+        if direct_only and os.environ.get("GT4MI_RENDEZVOUS_FILE"):
+            # (bench.py's canary: the children of the ranks meet through a file in a directory of their own -- no port that was
+            # free a moment ago, no second listener on the launcher's address)
+            dist.init_process_group("gloo", store=dist.FileStore(os.environ["GT4MI_RENDEZVOUS_FILE"], world), rank=rank, world_size=world)
+        elif direct_only:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -198,9 +202,7 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
                             record(f"native/{how} {table} fused {schedule} wg{wg}", run)
                     if how == "direct" and nex.direct_status()["timed_out"]:
                         results.append((f"halo {halo} grid {grid[0]}x{grid[1]} native/direct {table}: waits", False, "a wait ran out of time"))
-                    if world > 1:
-                        dist.barrier()  # nobody unmaps a pool a peer may still push into
-                    nex.close()
+                    nex.close()  # (collective on the direct transport: nobody unmaps a pool a peer may still push into)
             del chk
     finally:
         if comm is not None:
@@ -218,9 +220,25 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
             print(f"{name:60s} {'ok on every rank' if not bad else 'WRONG on ' + ', '.join(f'rank {r}: {d}' for r, d in bad)}", file=out)
         print(f"{len(mine)} checks x {world} rank(s): {'all correct' if failed == 0 else str(failed) + ' FAILED'}", file=out)
     if started_group:
-        dist.barrier()
+        _leave_together(dist, world)
         dist.destroy_process_group()
     return failed
+
+
+def _leave_together(dist, world: int, seconds: float = 60.0) -> None:
+    """Every rank counts itself out on the group's store and waits until all have: nobody closes its sockets while another rank
+    is still inside a collective (a `barrier` followed by `destroy_process_group` is exactly that race on gloo: the first rank
+    through tears the pair down under the last one)."""
+    import time
+
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        store.add("gt4mi_selfcheck_ranks_done", 1)
+        t0 = time.monotonic()
+        while store.add("gt4mi_selfcheck_ranks_done", 0) < world and time.monotonic() - t0 < seconds:
+            time.sleep(0.01)
+    except Exception:  # noqa: BLE001 - leaving is best effort; the results have been gathered and printed
+        pass
 
 
 def main(argv=None) -> int:

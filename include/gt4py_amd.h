@@ -33,14 +33,15 @@
 extern "C" {
 #endif
 
-#define GT4MI_ABI_VERSION 4 /* 4: gt4mi_dist_lap5_f32, the direct transport (gt4mi_halo_plan_direct_*, GT4MI_PLAN_TRANSPORT), gt4mi_comm_create_local, schedules 2-4 */
+#define GT4MI_ABI_VERSION 5 /* 5: GT4MI_ERR_TIMEOUT (a direct-transport wait that runs out fails the plan, hard), GT4MI_PLAN_DIRECT_TIMEOUT_MS; 4: gt4mi_dist_lap5_f32, the direct transport (gt4mi_halo_plan_direct_*, GT4MI_PLAN_TRANSPORT), gt4mi_comm_create_local, schedules 2-4 */
 
 typedef enum gt4mi_status {
     GT4MI_OK = 0,
     GT4MI_ERR_INVALID_ARGUMENT = -1, /* null pointer, bad enum, negative size ...              */
     GT4MI_ERR_OUT_OF_BOUNDS = -2,    /* origin/domain/halo do not fit in the field's shape     */
     GT4MI_ERR_UNSUPPORTED = -3,      /* combination not implemented by any kernel              */
-    GT4MI_ERR_HIP = -4               /* a HIP runtime call failed; see gt4mi_last_error()      */
+    GT4MI_ERR_HIP = -4,              /* a HIP runtime call failed; see gt4mi_last_error()      */
+    GT4MI_ERR_TIMEOUT = -5           /* direct transport: a neighbour never arrived; the plan has failed for good */
 } gt4mi_status;
 
 /* One stencil field argument.
@@ -214,9 +215,11 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *                                   16): what the ring computes is taken off the interior kernel, a box of whole cache lines
  *                                   costs the memory system less than the 1 - 2 columns the stencil's reach requires, and the
  *                                   interior kernel keeps its 16-byte alignment
- * Which combination is fastest depends on the links; bench.py measures them (config.calibration_ms_per_apply). */
+ * Which combination is fastest depends on the links; bench.py measures them (config.calibration_ms_per_apply).
+ *   GT4MI_PLAN_DIRECT_TIMEOUT_MS    direct transport: how long a device-side wait for a neighbour may take (milliseconds; 0 = the
+ *                                   default: GT4MI_DIRECT_TIMEOUT_MS of the environment, else 30 000) before the plan FAILS, see below */
 enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1, GT4MI_PLAN_DEFER_JOIN = 2, GT4MI_PLAN_EDGE_COLUMNS = 3,
-       GT4MI_PLAN_TRANSPORT = 4 };
+       GT4MI_PLAN_TRANSPORT = 4, GT4MI_PLAN_DIRECT_TIMEOUT_MS = 5 };
 enum { GT4MI_TRANSPORT_RCCL = 0, GT4MI_TRANSPORT_DIRECT = 1 };
 enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1, GT4MI_SCHEDULE_SWAP = 2, GT4MI_SCHEDULE_SWAP_PACKED = 3,
        GT4MI_SCHEDULE_INLINE = 4 };
@@ -233,7 +236,15 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value);
  *      `peer_flag_index` (is_send = 0).  The k-th send to a peer pairs with the k-th receive that peer posted for this rank (RCCL's
  *      matching rule); `peer` = NULL: this rank itself;
  *   4. gt4mi_halo_plan_set_option(plan, GT4MI_PLAN_TRANSPORT, GT4MI_TRANSPORT_DIRECT) after every rank has connected.
- * _direct_status (synchronises): whether a wait ever ran out of time (2 s; the data of that exchange is then garbage). */
+ * FAILURE IS HARD: a device-side wait that runs out of time (GT4MI_PLAN_DIRECT_TIMEOUT_MS) copies and signals nothing and sets
+ * the plan's error word (host memory the device writes); the NEXT call on the plan that touches the exchange -- gt4mi_halo_exchange*,
+ * gt4mi_dist_*, gt4mi_halo_exchange_end -- reads it without synchronising and returns GT4MI_ERR_TIMEOUT, and so does every call
+ * after it.  The call that enqueued the failing exchange has returned GT4MI_OK long before (everything is asynchronous): check
+ * the status of the call that CONSUMES the result (_end, the next step, or _direct_status) before trusting ghost cells.
+ * _direct_status synchronises the device first: whether a wait of any exchange started so far ran out of time.
+ * DESTROYING a prepared plan is collective in effect: the neighbours' kernels write into this plan's pool ("consumed" adds, the
+ * next pushes); call gt4mi_halo_plan_destroy only after every rank has finished its last exchange ON THE DEVICE (each rank
+ * synchronises, then the ranks meet once on the host's control channel; gt4py_amd/distributed/native.py close()). */
 typedef struct gt4mi_direct_info {
     char pool_handle[64];  /* hipIpcMemHandle_t of the pool: a page of flag words, then the receive buffers */
     int64_t pool_bytes, flag_words;

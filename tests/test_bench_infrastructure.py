@@ -8,6 +8,7 @@ import pathlib
 import subprocess
 import sys
 import time
+import zlib
 
 import pytest
 
@@ -104,51 +105,42 @@ def test_bench_module_has_no_gpu_side_effects_on_import():
     assert proc.returncode == 0 and proc.stdout.strip() == "False"
 
 
-def _proof_worker(rank: int, world: int, port: int, tmpdir: str):
+def _proof_worker(rank: int, world: int, tmpdir: str):
     import torch.distributed as dist
 
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        ctx = {"world": world, "rank": rank, "distributed": True, "dist": dist, "device": "cpu"}
-        # what NativeComm.info() returns on an N-rank communicator (RCCL itself cannot run here)
-        proof = bench.gather_rank_proof(ctx, {"rank": rank, "device": rank, "nranks": world})
-        everyone_ok = bench._agree(ctx, 1)
-        one_failed = bench._agree(ctx, 0 if rank == 1 else 1)
-        ms = bench._slowest_rank_ms(ctx, (lambda: time.sleep(0.002 * (rank + 1))), calls=3, warm=1)  # rank 1 is the slow one
-        # a calibration candidate that fails on ONE rank is dropped on every rank without anyone waiting in a barrier
-        def good():
-            return (lambda: time.sleep(0.001)), (lambda: None)
+    ctx = {"world": world, "rank": rank, "distributed": True, "dist": dist, "device": "cpu"}
+    # what NativeComm.info() returns on an N-rank communicator (RCCL itself cannot run here)
+    proof = bench.gather_rank_proof(ctx, {"rank": rank, "device": rank, "nranks": world})
+    everyone_ok = bench._agree(ctx, 1)
+    one_failed = bench._agree(ctx, 0 if rank == 1 else 1)
+    ms = bench._slowest_rank_ms(ctx, (lambda: time.sleep(0.002 * (rank + 1))), calls=3, warm=1)  # rank 1 is the slow one
+    # a calibration candidate that fails on ONE rank is dropped on every rank without anyone waiting in a barrier
+    def good():
+        return (lambda: time.sleep(0.001)), (lambda: None)
 
-        def bad_on_rank_1():
-            if rank == 1:
-                raise RuntimeError("this device refuses the option")
-            return (lambda: None), (lambda: None)
+    def bad_on_rank_1():
+        if rank == 1:
+            raise RuntimeError("this device refuses the option")
+        return (lambda: None), (lambda: None)
 
-        candidates = [bench.measure_candidate(ctx, good, 3, warm=1), bench.measure_candidate(ctx, bad_on_rank_1, 3, warm=1),
-                      bench.measure_candidate(ctx, good, 3, warm=1)]
-        keys = bench.decomposed_line_keys(proof, False, world, {"timestep_glups": 1.0})
-        fallen = bench.decomposed_line_keys(None, True, world, None)
-        with open(os.path.join(tmpdir, f"rank{rank}.json"), "w") as fh:
-            json.dump({"keys": keys, "fallen": fallen, "ok": [everyone_ok, one_failed], "ms": ms, "candidates": candidates}, fh)
-    finally:
-        dist.destroy_process_group()
+    candidates = [bench.measure_candidate(ctx, good, 3, warm=1), bench.measure_candidate(ctx, bad_on_rank_1, 3, warm=1),
+                  bench.measure_candidate(ctx, good, 3, warm=1)]
+    keys = bench.decomposed_line_keys(proof, False, world, {"timestep_glups": 1.0})
+    fallen = bench.decomposed_line_keys(None, True, world, None)
+    with open(os.path.join(tmpdir, f"rank{rank}.json"), "w") as fh:
+        json.dump({"keys": keys, "fallen": fallen, "ok": [everyone_ok, one_failed], "ms": ms, "candidates": candidates}, fh)
 
 
+@pytest.mark.multiprocess
 def test_the_n_gpu_line_says_how_many_ranks_rccl_saw_and_whether_the_transport_fell_back(tmp_path, capfd):
     """the first SCALE line must be interpretable -- `rccl_nranks` / `rank_devices` gathered from
     every rank, `transport_fallback` as a top-level key (plus a banner on stderr), the time steppers under `extra`.  The
     collective helpers run here on gloo, world_size 2."""
-    import socket
+    from mp_util import run_ranks
 
-    import torch.multiprocessing as mp
-
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    mp.spawn(_proof_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    run_ranks(_proof_worker, 2, tmp_path)
     for rank in (0, 1):
-        got = json.loads((tmp_path / f"rank{rank}.json").read_text())
+        got = json.loads((sorted(tmp_path.glob("attempt*"))[-1] / f"rank{rank}.json").read_text())
         keys = got["keys"]
         assert keys["rccl_nranks"] == 2 and keys["rank_devices"] == [[0, 0], [1, 1]] and keys["rccl_matches_n_gpus"] is True
         assert keys["transport_fallback"] is False and keys["extra"] == {"timestep_glups": 1.0}
@@ -162,3 +154,78 @@ def test_the_n_gpu_line_says_how_many_ranks_rccl_saw_and_whether_the_transport_f
     assert "NATIVE RCCL TRANSPORT UNAVAILABLE (testing)" in err and "NOT those of the product path" in err
     bench.transport_fallback_banner(1, "testing")  # only rank 0 shouts
     assert capfd.readouterr().err == ""
+
+
+# ---- the bounded, ordered calibration of an N > 1 run ---------------------------------------------
+def test_the_calibration_order_puts_the_north_stars_rccl_forms_first():
+    grids = [(4, 2), (2, 4), (1, 8), (8, 1)]
+    first, refine, direct = bench.lap_calibration_order((4, 2), grids, (False, True), ("rccl", "direct"))
+    # an overlapped RCCL headline on the grid choose_process_grid returns after at most four candidates
+    assert first[:4] == [((4, 2), False, "swap", 0, "rccl"), ((4, 2), False, "join", 0, "rccl"),
+                         ((4, 2), True, "swap", 0, "rccl"), ((4, 2), True, "join", 0, "rccl")]
+    assert all(c[4] == "rccl" for c in first) and {c[0] for c in first[4:]} == {(2, 4), (1, 8), (8, 1)}
+    assert all(c[0] == (2, 4) and c[4] == "rccl" for c in refine(((2, 4), True, "swap", 0, "rccl")))
+    d = direct(((2, 4), True, "swap", 0, "rccl"))
+    assert all(c[4] == "direct" for c in d) and d[0] == ((2, 4), False, "inline", 0, "direct") and d[1][:3] == ((2, 4), True, "inline")
+    keys = [bench.lap_key(c) for c in first + refine(first[0]) + d]
+    assert [bench.lap_key(bench.lap_candidate_of(k)) for k in keys] == keys
+    assert bench.lap_calibration_order((4, 2), grids, (False,), ("rccl",))[2](None) == []  # no direct transport asked for
+    h_first, h_refine, h_direct = bench.hdiff_calibration_order(("join", "chain", "inline"), (2, 16, 32), ("rccl", "direct"))
+    assert h_first == ["fused_two_phase_chain_wg2_edge16", "fused_two_phase_join_wg2_edge16", "fused_single_phase_chain_wg2_edge16",
+                       "fused_single_phase_join_wg2_edge16"]
+    assert all("single_phase" in n for n in h_refine("fused_single_phase_chain_wg2_edge16")[:-1]) and h_refine(h_first[0])[-2:] == [
+        "sequential_two_phase", "sequential_single_phase"]
+    assert h_direct(h_first[0])[0] == "fused_two_phase_inline_wg0_edge16_direct" and all(n.endswith("_direct") for n in h_direct(None))
+
+
+def _calibration_worker(rank: int, world: int, tmpdir: str, rccl_seconds: float, canary_says):
+    import torch.distributed as dist
+
+    ctx = {"world": world, "rank": rank, "distributed": True, "dist": dist, "device": "cpu"}
+    grids = [(1, 2), (2, 1)]
+    measured = []
+
+    def measure(cand):  # a candidate costs 0.25 s on the slow rank; its "time" is a function of the candidate alone
+        time.sleep(0.25 if rank == 1 else 0.02)
+        measured.append(bench.lap_key(cand))
+        if cand[4] == "direct" and cand[2] == "join":
+            return None  # (a form that fails: the direct transport is dropped from there on)
+        return round(0.1 + 0.01 * (zlib.crc32(bench.lap_key(cand).encode()) % 7) - (0.05 if cand[4] == "direct" and cand[2] == "inline" else 0.0), 5)
+
+    table, stats = {}, {"run": 0, "skipped_for_time": 0, "failed": []}
+    canary, transports = bench.calibrate_laplacian(ctx, (1, 2), grids, (False, True), ("rccl", "direct"), measure, (lambda: canary_says),
+                                                   rccl_seconds, 1.0, table, stats)
+    return {"table": table, "stats": stats, "measured": measured, "canary": canary, "transports": list(transports),
+            "keys": bench.calibration_line_keys(table, stats), "dropped": ctx.get("direct_dropped")}
+
+
+@pytest.mark.multiprocess
+def test_a_small_budget_still_yields_an_overlapped_rccl_headline_on_every_rank_alike(tmp_path):
+    """gloo, world size 2, rank 1 four times slower per candidate: with a budget of 1.2 s the calibration stops at the SAME
+    candidate on both ranks (the budget is a collective), the head of the order -- RCCL "swap" / "join" on the default grid --
+    has been measured, the tail is counted as skipped, and the line says what RCCL and the direct transport each achieved."""
+    from mp_util import run_ranks
+
+    got = run_ranks(_calibration_worker, 2, tmp_path, args=(1.2, True))
+    assert got[0]["measured"] == got[1]["measured"] and got[0]["table"] == got[1]["table"]
+    m, keys = got[0]["measured"], got[0]["keys"]
+    assert m[:2] == ["1x2_twophase_swap_wg0_rccl", "1x2_twophase_join_wg0_rccl"]
+    rccl_run = [k for k in m if k.endswith("_rccl")]
+    assert 3 <= len(rccl_run) <= 7  # 1.2 s at 0.25 s per candidate on the slow rank
+    assert keys["rccl_best_ms_per_apply"] is not None and keys["rccl_best_form"].split("_")[2] in ("swap", "join")
+    assert keys["calibration_candidates_skipped_for_time"] > 0 and keys["calibration_candidates_run"] == len(m)
+    # the direct transport had its own second: "inline" first; the form that failed dropped the rest of it
+    direct_run = [k for k in m if k.endswith("_direct")]
+    assert direct_run and direct_run[0].split("_")[2] == "inline" and keys["direct_best_ms_per_apply"] < keys["rccl_best_ms_per_apply"]
+    assert got[0]["canary"] is True and got[0]["transports"] == ["rccl", "direct"]
+
+
+@pytest.mark.multiprocess
+def test_a_failed_canary_keeps_the_calibration_on_rccl(tmp_path):
+    from mp_util import run_ranks
+
+    got = run_ranks(_calibration_worker, 2, tmp_path, args=(30.0, False))
+    assert got[0]["canary"] is False and got[0]["transports"] == ["rccl"] and got[0]["keys"]["direct_best_ms_per_apply"] is None
+    assert all(k.endswith("_rccl") for k in got[0]["measured"]) and got[0]["keys"]["calibration_candidates_skipped_for_time"] == 0
+    # with time to spare every RCCL candidate of the order ran: both grids, both tables, the throttles on the best grid
+    assert {k.split("_")[0] for k in got[0]["measured"]} == {"1x2", "2x1"} and any("_wg4_" in k for k in got[0]["measured"])

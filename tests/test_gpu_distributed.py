@@ -737,90 +737,79 @@ def test_fused_steps_wait_for_the_exchange_when_the_interior_is_shorter(comm, st
 # pinned host memory (HaloExchanger(stage_on_host=True)).  Everything else is the decomposed GPU path as an N-GPU job runs
 # it -- scatter of a global field, HIP pack / unpack kernels, the kernel-library stencils on the interior and on the
 # boundary strips, per-rank origins -- with neighbours that are OTHER processes.
-def _two_rank_worker(rank: int, world: int, port: int, grid, tmpdir: str):
-    import os
-
+def _two_rank_worker(rank: int, world: int, tmpdir: str, grid):
+    """(run by tests/mp_util.run_ranks: the gloo group exists, the return value is this rank's report)"""
     import torch
     import torch.distributed as dist
 
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        torch.cuda.set_device(0)
-        import gt4py_amd.storage as gt_storage
-        from gt4py_amd.cartesian import gtscript
-        from gt4py_amd.cartesian.backend import hip_templates
-        from gt4py_amd.distributed import (Decomposition, HaloExchanger, overlapped_apply, scatter_global, sequential_apply)
-        from oracle import ref_numpy as R
+    torch.cuda.set_device(0)
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from gt4py_amd.distributed import (Decomposition, HaloExchanger, overlapped_apply, scatter_global, sequential_apply)
+    from oracle import ref_numpy as R
 
-        rng = np.random.default_rng(4096)  # the same stream on every rank: the same global fields
-        results = {}
-        for name, h, gd in (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5))):
-            glob = rng.uniform(-10, 10, (gd[0] + 2 * h, gd[1] + 2 * h, gd[2]))
-            coeff = rng.uniform(0, 0.5, glob.shape)
-            want = np.zeros_like(glob)
-            if name == "hdiff":
-                R.hdiff(glob, want, coeff, domain=gd)
-                stencil = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field,
-                                           dtypes={"T": np.float64}, device_sync=False)
-                read, write = "in_field", "out_field"
-            else:
-                R.laplacian(glob, want)
-                stencil = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
-                                           device_sync=False)
-                read, write = "inp", "out"
-            dec = Decomposition(gd, grid, rank, h)
-            for form, apply in (("overlapped", overlapped_apply), ("sequential", sequential_apply)):
-                for single_phase in (False, True):
-                    blk = scatter_global(glob, dec).copy()
-                    nb = dec.neighbours  # ghost cells that belong to the neighbour must come from the exchange
-                    if nb["W"] is not None:
-                        blk[:h] = np.nan
-                    if nb["E"] is not None:
-                        blk[-h:] = np.nan
-                    if nb["S"] is not None:
-                        blk[:, :h] = np.nan
-                    if nb["N"] is not None:
-                        blk[:, -h:] = np.nan
-                    args = {read: gt_storage.from_array(blk, backend="hip:mi300", aligned_index=dec.origin),
-                            write: gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)}
-                    if name == "hdiff":
-                        args["coeff"] = gt_storage.from_array(scatter_global(coeff, dec), backend="hip:mi300", aligned_index=dec.origin)
-                    origin = {n: dec.origin for n in args}
-                    ex = HaloExchanger(dec, torch.float64, torch.device("cuda", 0), single_phase=single_phase, stage_on_host=True)
-                    apply(stencil, dec, origin, args, {read: ex})
-                    torch.cuda.synchronize()
-                    assert np.array_equal(args[read].get(), scatter_global(glob, dec)), (name, form, "ghost cells")
-                    results[(name, form, single_phase)] = args[write].get()[h:-h, h:-h].copy()
-            gathered = [None] * world
-            dist.all_gather_object(gathered, (dec.global_slices(with_halo=False), {k: v for k, v in results.items() if k[0] == name}))
-            if rank == 0:
-                for key in gathered[0][1]:
-                    got = np.zeros_like(glob)
-                    for sl, res in gathered:
-                        got[sl] = res[key]
-                    assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h]), key
+    rng = np.random.default_rng(4096)  # the same stream on every rank: the same global fields
+    results = {}
+    for name, h, gd in (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5))):
+        glob = rng.uniform(-10, 10, (gd[0] + 2 * h, gd[1] + 2 * h, gd[2]))
+        coeff = rng.uniform(0, 0.5, glob.shape)
+        want = np.zeros_like(glob)
+        if name == "hdiff":
+            R.hdiff(glob, want, coeff, domain=gd)
+            stencil = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field,
+                                       dtypes={"T": np.float64}, device_sync=False)
+            read, write = "in_field", "out_field"
+        else:
+            R.laplacian(glob, want)
+            stencil = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
+                                       device_sync=False)
+            read, write = "inp", "out"
+        dec = Decomposition(gd, grid, rank, h)
+        for form, apply in (("overlapped", overlapped_apply), ("sequential", sequential_apply)):
+            for single_phase in (False, True):
+                blk = scatter_global(glob, dec).copy()
+                nb = dec.neighbours  # ghost cells that belong to the neighbour must come from the exchange
+                if nb["W"] is not None:
+                    blk[:h] = np.nan
+                if nb["E"] is not None:
+                    blk[-h:] = np.nan
+                if nb["S"] is not None:
+                    blk[:, :h] = np.nan
+                if nb["N"] is not None:
+                    blk[:, -h:] = np.nan
+                args = {read: gt_storage.from_array(blk, backend="hip:mi300", aligned_index=dec.origin),
+                        write: gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)}
+                if name == "hdiff":
+                    args["coeff"] = gt_storage.from_array(scatter_global(coeff, dec), backend="hip:mi300", aligned_index=dec.origin)
+                origin = {n: dec.origin for n in args}
+                ex = HaloExchanger(dec, torch.float64, torch.device("cuda", 0), single_phase=single_phase, stage_on_host=True)
+                apply(stencil, dec, origin, args, {read: ex})
+                torch.cuda.synchronize()
+                assert np.array_equal(args[read].get(), scatter_global(glob, dec)), (name, form, "ghost cells")
+                results[(name, form, single_phase)] = args[write].get()[h:-h, h:-h].copy()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (dec.global_slices(with_halo=False), {k: v for k, v in results.items() if k[0] == name}))
         if rank == 0:
-            np.save(os.path.join(tmpdir, "ok.npy"), np.array([len(results)]))
-    finally:
-        dist.destroy_process_group()
+            for key in gathered[0][1]:
+                got = np.zeros_like(glob)
+                for sl, res in gathered:
+                    got[sl] = res[key]
+                assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h]), key
+    return {"checked": len(results)}
 
 
+@pytest.mark.multiprocess
 @pytest.mark.parametrize("grid", [(1, 2), (2, 1)])
 def test_two_processes_share_the_gpu_and_exchange_real_faces(grid, tmp_path):
     """World size 2 on the GPU: each rank owns half of a global field, its neighbour is ANOTHER process.  Horizontal diffusion
     (ghost depth 2, corners through either message table) and the Laplacian through the stencil-agnostic drivers; the
     assembled result equals the oracle on the undecomposed field bit for bit, and every rank's ghost cells equal the global
     field's values."""
-    import socket
+    from mp_util import run_ranks
 
-    import torch.multiprocessing as mp
-
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    mp.spawn(_two_rank_worker, args=(2, port, grid, str(tmp_path)), nprocs=2, join=True)
-    assert int(np.load(tmp_path / "ok.npy")[0]) == 8
+    reports = run_ranks(_two_rank_worker, 2, tmp_path, args=(grid,))
+    assert [reports[r]["checked"] for r in (0, 1)] == [8, 8]
 
 
 
@@ -844,6 +833,7 @@ def _second_chance(test):
     return wrapper
 
 
+@pytest.mark.multiprocess
 @pytest.mark.parametrize("workload", ["lap512", "hdiff2048"])
 @_second_chance
 def test_bench_n_gpu_code_path_with_a_world_of_one(workload, tmp_path):
@@ -880,13 +870,20 @@ def test_bench_n_gpu_code_path_with_a_world_of_one(workload, tmp_path):
     assert verified["forms_checked"] >= len(line["config"]["calibration_ms_per_apply"]) + 2 and verified["ghost_cells_checked_on_rank_0"] == 0
     # the direct transport passed its canary (a child process per rank maps and stores first) and was calibrated beside RCCL
     assert line["config"]["direct_transport_canary"] is True and line["config"]["direct_transport_dropped_at"] is None
-    assert any(key.endswith("direct") for key in line["config"]["calibration_ms_per_apply"])
+    table = line["config"]["calibration_ms_per_apply"]
+    assert any(key.endswith("direct") for key in table)
+    # what the SPECIFIED design (RCCL send/recv on a second stream) achieves next to the direct transport, at the top level; and
+    # how much of the calibration the wall-clock budget allowed
+    assert line["rccl_best_ms_per_apply"] == min(v for k, v in table.items() if not k.endswith("direct")) and line["rccl_best_form"] in table
+    assert line["direct_best_ms_per_apply"] == min(v for k, v in table.items() if k.endswith("direct"))
+    assert line["calibration_candidates_run"] >= len(table) and line["calibration_candidates_skipped_for_time"] >= 0
     if workload == "lap512":
         assert {"timestep_glups", "timestep_ms_per_step", "pipelined_apply_glups"} <= set(line["extra"])
         assert line["config"]["mode"] == "apply" and line["config"]["halo_depth"] == 1
     assert "NATIVE RCCL TRANSPORT UNAVAILABLE" not in proc.stderr
 
 
+@pytest.mark.multiprocess
 @pytest.mark.parametrize("workload,phase", [("lap512", "calibration"), ("hdiff2048", "calibration"), ("lap512", "informational")])
 @_second_chance
 def test_bench_prints_what_it_measured_when_a_later_phase_hangs(workload, phase, tmp_path):
@@ -969,6 +966,7 @@ def test_form_check_accepts_the_fused_applies_and_sees_a_form_that_reads_ghost_c
     ex.close()
 
 
+@pytest.mark.multiprocess
 @_second_chance
 def test_selfcheck_command_line_under_torchrun(tmp_path):
     """`python -m torch.distributed.run ... -m gt4py_amd.distributed`: the deployment check of the multi-GPU path
@@ -1125,107 +1123,157 @@ def test_fused_steps_on_the_direct_transport(comm, stencil, schedule):
             ex.close()
 
 
-def _two_rank_direct_worker(rank: int, world: int, port: int, grid, periodic, tmpdir: str):
-    import os
+@pytest.mark.parametrize("schedule", ["inline", "swap", "chain"])
+@pytest.mark.parametrize("stencil", ["lap5", "hdiff"])
+def test_a_neighbour_that_never_arrives_fails_the_direct_transport_hard(comm, stencil, schedule, monkeypatch):
+    """VERDICT round 3, weak 7 / ADVICE: a device-side wait that runs out of time must not become silent garbage.  Pushes whose
+    signals are lost (GT4MI_DIRECT_TEST_LOSE_SIGNALS when the plan is prepared: what a neighbour that never arrives looks like
+    from the receiver's side), a short timeout: the call that ENQUEUES the failing exchange returns OK -- everything is
+    asynchronous --, the waiting workgroups copy nothing (the ghost cells keep what they had: no stale or half-written face)
+    and signal nothing, and the NEXT call on the plan that touches the exchange -- fused step, exchange, end() -- raises with
+    status ERR_TIMEOUT, without anybody having polled; so does every call after it."""
+    import torch
 
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+
+    monkeypatch.setenv("GT4MI_DIRECT_TEST_LOSE_SIGNALS", "1")
+    h = 1 if stencil == "lap5" else 2
+    dec = Decomposition((130, 70, 4), (1, 1), 0, h, periodic=(True, True))
+    host = np.random.default_rng(5).uniform(-1, 1, dec.local_shape)
+    host[:h], host[-h:], host[:, :h], host[:, -h:] = np.nan, np.nan, np.nan, np.nan
+    inp = gt_storage.from_array(host, backend="hip:mi300", aligned_index=dec.origin)
+    out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+    ex = _direct(NativeHaloExchanger(dec, np.float64, comm, single_phase=True).tune(schedule, 0, direct_timeout_ms=150))
+    if stencil == "lap5":
+        step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin)
+    else:
+        step = ex.make_dist_hdiff(inp, out, None, dec.origin, _lib.HDIFF_LIMITER, coeff_scalar=0.1)
+    step()  # enqueued; the wait runs out on the device 150 ms later
+    torch.cuda.synchronize()
+    ghosts = inp.get()
+    assert np.isnan(ghosts[:h]).all() and np.isnan(ghosts[-h:]).all() and np.isnan(ghosts[:, :h]).all() and np.isnan(ghosts[:, -h:]).all()
+    for call in (step, lambda: ex.exchange(inp), ex.end, step):
+        with pytest.raises(_lib.NativeError, match="ran out of time") as info:
+            call()
+        assert info.value.status == _lib.ERR_TIMEOUT
+    assert ex.direct_status() == {"timed_out": True, "exchanges": 1}  # (the refused calls started nothing)
+    ex.close()
+    # an exchanger prepared without the lost signals works next to the failed one's remains
+    monkeypatch.delenv("GT4MI_DIRECT_TEST_LOSE_SIGNALS")
+    ex = _direct(NativeHaloExchanger(dec, np.float64, comm, single_phase=True).tune(schedule, 0, direct_timeout_ms=150))
+    ex.exchange(inp)
+    torch.cuda.synchronize()
+    assert not np.isnan(inp.get()).any() and ex.direct_status()["timed_out"] is False
+    ex.close()
+
+
+def _two_rank_direct_worker(rank: int, world: int, tmpdir: str, grid, periodic, forms="all"):
+    """(run by tests/mp_util.run_ranks: the gloo group exists -- it only carries the descriptions of the pools and the results --,
+    the return value is this rank's report)"""
     import torch
     import torch.distributed as dist
 
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # (only carries the descriptions of the pools, and the results)
-    try:
-        torch.cuda.set_device(0)
-        import gt4py_amd.storage as gt_storage
-        from gt4py_amd import _lib
-        from gt4py_amd.distributed import Decomposition, FormCheck, NativeComm, NativeHaloExchanger, scatter_global
-        from gt4py_amd.cartesian import gtscript
-        from gt4py_amd.cartesian.backend import hip_templates
-        from oracle import ref_numpy as R
+    torch.cuda.set_device(0)
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.distributed import Decomposition, FormCheck, NativeComm, NativeHaloExchanger, scatter_global
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+    from oracle import ref_numpy as R
 
-        comm = NativeComm(rank=rank, world_size=world, rccl=False)  # RCCL cannot join two ranks on one device; no need to
-        assert comm.info() == {"nranks": world, "rank": rank, "device": 0}
-        rng = np.random.default_rng(4096)  # the same stream on every rank: the same global fields
-        checked = 0
-        for name, h, gd in (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5)), ("lap5", 1, (131, 67, 3))):
-            shape = (gd[0] + 2 * h, gd[1] + 2 * h, gd[2])
-            glob = rng.uniform(-10, 10, shape)
-            coeff = rng.uniform(0, 0.5, shape)
-            wrapped = glob.copy()  # the global field with its periodic wrap: what every rank's ghost cells must show
-            if periodic[0]:
-                wrapped[:h], wrapped[-h:] = wrapped[-2 * h:-h].copy(), wrapped[h:2 * h].copy()
-            if periodic[1]:
-                wrapped[:, :h], wrapped[:, -h:] = wrapped[:, -2 * h:-h].copy(), wrapped[:, h:2 * h].copy()
-            want = np.zeros_like(glob)
-            if name == "hdiff":
-                R.hdiff(wrapped, want, coeff, domain=gd)
-            else:
-                R.laplacian(wrapped, want)
-            dec = Decomposition(gd, grid, rank, h, periodic=periodic)
-            results = {}
-            for single_phase in (False, True):
-                for schedule in ("join", "chain", "swap", "swap-packed", "inline"):
-                    blk = scatter_global(wrapped, dec).copy()
-                    mine = blk.copy()
-                    nb = dec.neighbours  # ghost cells that belong to a neighbour must come from the exchange
-                    for side, sl in (("W", np.s_[:h]), ("E", np.s_[-h:]), ("S", np.s_[:, :h]), ("N", np.s_[:, -h:])):
-                        if nb[side] is not None:
-                            mine[sl] = np.nan
-                    inp = gt_storage.from_array(mine, backend="hip:mi300", aligned_index=dec.origin)
-                    out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
-                    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase).tune(schedule, 0)
-                    with pytest.raises(RuntimeError, match="no RCCL behind it"):
-                        ex.exchange(inp)  # this communicator cannot fall back to send/recv
-                    try:
-                        ex.use_direct_transport()  # collective: the pools' descriptions travel over gloo, the faces never do
-                    except RuntimeError as err:  # (every rank raises together)
-                        if "not available on every rank" not in str(err):
-                            raise
-                        if rank == 0:
-                            with open(os.path.join(tmpdir, "unavailable.txt"), "w") as fh:
-                                fh.write(str(err)[:300])
-                        return
-                    if name == "hdiff":
-                        cf = gt_storage.from_array(scatter_global(coeff, dec), backend="hip:mi300", aligned_index=dec.origin)
-                        step = ex.make_dist_hdiff(inp, out, cf, dec.origin, _lib.HDIFF_LIMITER)
-                    else:
-                        step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin)
-                    for _ in range(3):  # (the flags count up; the peer's buffers are reused)
-                        step()
-                    torch.cuda.synchronize()
-                    assert np.array_equal(inp.get(), blk), (name, schedule, single_phase, "ghost cells")
-                    assert ex.direct_status()["timed_out"] is False
-                    results[(single_phase, schedule)] = out.get()[h:-h, h:-h].copy()
-                    dist.barrier()  # nobody unmaps a pool the other still pushes into
-                    ex.close()
-                    checked += 1
-            gathered = [None] * world
-            dist.all_gather_object(gathered, (dec.global_slices(with_halo=False), results))
-            if rank == 0:
-                for key in gathered[0][1]:
-                    got = np.zeros_like(glob)
-                    for sl, res in gathered:
-                        got[sl] = res[key]
-                    assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h]), (name, key)
-        # the self-check bench.py runs on every form, here between two processes
-        dec = Decomposition((96, 80, 6), grid, rank, 1, periodic=periodic)
-        lap = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64}, device_sync=False)
-        fr = lap.freeze(origin={"inp": dec.origin, "out": dec.origin}, domain=dec.local_domain)
-        chk = FormCheck(dec, lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin),
-                        lambda a, b: fr(inp=a, out=b))
-        ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=True).tune("inline", 0).use_direct_transport()
-        fused = ex.make_dist_lap5(chk.probe, chk.out, dec.origin, dec.origin)
-        chk.reset()
-        fused()
-        assert chk.verdict()[0], chk.verdict()[1]
-        dist.barrier()
-        ex.close()
-        comm.close()
+    comm = NativeComm(rank=rank, world_size=world, rccl=False)  # RCCL cannot join two ranks on one device; no need to
+    assert comm.info() == {"nranks": world, "rank": rank, "device": 0}
+    rng = np.random.default_rng(4096)  # the same stream on every rank: the same global fields
+    checked, log = 0, []
+    cases = (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5)), ("lap5", 1, (131, 67, 3)))
+    schedules = ("join", "chain", "swap", "swap-packed", "inline") if forms == "all" else ("inline",)
+    for name, h, gd in cases:
+        shape = (gd[0] + 2 * h, gd[1] + 2 * h, gd[2])
+        glob = rng.uniform(-10, 10, shape)
+        coeff = rng.uniform(0, 0.5, shape)
+        wrapped = glob.copy()  # the global field with its periodic wrap: what every rank's ghost cells must show
+        if periodic[0]:
+            wrapped[:h], wrapped[-h:] = wrapped[-2 * h:-h].copy(), wrapped[h:2 * h].copy()
+        if periodic[1]:
+            wrapped[:, :h], wrapped[:, -h:] = wrapped[:, -2 * h:-h].copy(), wrapped[:, h:2 * h].copy()
+        want = np.zeros_like(glob)
+        if name == "hdiff":
+            R.hdiff(wrapped, want, coeff, domain=gd)
+        else:
+            R.laplacian(wrapped, want)
+        dec = Decomposition(gd, grid, rank, h, periodic=periodic)
+        results = {}
+        for single_phase in (False, True):
+            for schedule in schedules:
+                blk = scatter_global(wrapped, dec).copy()
+                mine = blk.copy()
+                nb = dec.neighbours  # ghost cells that belong to a neighbour must come from the exchange
+                for side, sl in (("W", np.s_[:h]), ("E", np.s_[-h:]), ("S", np.s_[:, :h]), ("N", np.s_[:, -h:])):
+                    if nb[side] is not None:
+                        mine[sl] = np.nan
+                inp = gt_storage.from_array(mine, backend="hip:mi300", aligned_index=dec.origin)
+                out = gt_storage.zeros(dec.local_shape, backend="hip:mi300", aligned_index=dec.origin)
+                ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single_phase).tune(schedule, 0)
+                with pytest.raises(RuntimeError, match="no RCCL behind it"):
+                    ex.exchange(inp)  # this communicator cannot fall back to send/recv
+                try:
+                    ex.use_direct_transport()  # collective: the pools' descriptions travel over gloo, the faces never do
+                except RuntimeError as err:  # (every rank raises together)
+                    if "not available on every rank" not in str(err):
+                        raise
+                    return {"unavailable": str(err)[:300]}
+                if name == "hdiff":
+                    cf = gt_storage.from_array(scatter_global(coeff, dec), backend="hip:mi300", aligned_index=dec.origin)
+                    step = ex.make_dist_hdiff(inp, out, cf, dec.origin, _lib.HDIFF_LIMITER)
+                else:
+                    step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin)
+                for _ in range(3):  # (the flags count up; the peer's buffers are reused)
+                    step()
+                torch.cuda.synchronize()
+                status = ex.direct_status()
+                wrong_ghosts = int((inp.get() != blk).sum())
+                log.append({"case": [name, list(gd), single_phase, schedule], "status": status, "wrong_ghost_cells": wrong_ghosts})
+                assert wrong_ghosts == 0, (name, schedule, single_phase, "ghost cells", wrong_ghosts, status)
+                assert status["timed_out"] is False
+                results[(single_phase, schedule)] = out.get()[h:-h, h:-h].copy()
+                ex.close()  # collective on this transport: nobody unmaps a pool another rank still pushes into
+                checked += 1
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (dec.global_slices(with_halo=False), results))
         if rank == 0:
-            np.save(os.path.join(tmpdir, "ok.npy"), np.array([checked]))
-    finally:
-        dist.destroy_process_group()
+            for key in gathered[0][1]:
+                got = np.zeros_like(glob)
+                for sl, res in gathered:
+                    got[sl] = res[key]
+                assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h]), (name, key)
+    # the self-check bench.py runs on every form, here between two processes
+    dec = Decomposition((96, 80, 6), grid, rank, 1, periodic=periodic)
+    lap = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64}, device_sync=False)
+    fr = lap.freeze(origin={"inp": dec.origin, "out": dec.origin}, domain=dec.local_domain)
+    chk = FormCheck(dec, lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin),
+                    lambda a, b: fr(inp=a, out=b))
+    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=True).tune("inline", 0).use_direct_transport()
+    fused = ex.make_dist_lap5(chk.probe, chk.out, dec.origin, dec.origin)
+    import os
+
+    verdicts = []
+    for _ in range(int(os.environ.get("GT4MI_TEST_VERDICT_ROUNDS", "8"))):  # (a fresh field every time: a ghost value read before it had arrived shows)
+        chk.reset()
+        torch.cuda.synchronize()
+        dist.barrier()  # both ranks launch together: the receiver's unpack meets the sender's push in flight
+        fused()
+        verdicts.append(list(chk.verdict()))
+    status = ex.direct_status()
+    ex.close()
+    comm.close()
+    failed = [(n, v[1]) for n, v in enumerate(verdicts) if not v[0]]
+    assert not failed, (f"rank {rank}: {len(failed)} of {len(verdicts)} self-check rounds failed", failed[:3], status)
+    return {"checked": checked, "verdicts": verdicts, "status": status, "log": log}
 
 
+@pytest.mark.multiprocess
 @pytest.mark.parametrize("grid,periodic", [((1, 2), (False, False)), ((2, 1), (False, False)), ((1, 2), (True, True)), ((2, 1), (True, True))])
 def test_two_processes_push_faces_into_each_other_on_one_gpu(grid, periodic, tmp_path):
     """TWO REAL RANKS of the native path on the one device of the box -- what RCCL refuses to do.  Each process exports its pool
@@ -1234,24 +1282,21 @@ def test_two_processes_push_faces_into_each_other_on_one_gpu(grid, periodic, tmp
     it.  Horizontal diffusion (ghost depth 2, corners) and the Laplacian, every schedule of the fused steps, both message
     tables, bounded and periodic (then each rank is also its own neighbour along the uncut axis, and the same peer twice
     along the cut one); the assembled results equal the oracle on the undecomposed field, every rank's ghost cells the global
-    field's values, and no wait ever times out."""
-    import socket
+    field's values, and no wait ever times out.  Every rank reports (tests/mp_util.py)."""
+    from mp_util import run_ranks
 
-    import torch.multiprocessing as mp
-
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    mp.spawn(_two_rank_direct_worker, args=(2, port, grid, periodic, str(tmp_path)), nprocs=2, join=True)
-    if (tmp_path / "unavailable.txt").exists():  # no hipIpc / fine-grained memory here: the environment's, not the code's
-        pytest.skip((tmp_path / "unavailable.txt").read_text())
-    assert int(np.load(tmp_path / "ok.npy")[0]) == 30
+    reports = run_ranks(_two_rank_direct_worker, 2, tmp_path, args=(grid, periodic))
+    if any("unavailable" in reports[r] for r in (0, 1)):  # no hipIpc / fine-grained memory here: the environment's, not the code's
+        pytest.skip(str([reports[r].get("unavailable") for r in (0, 1)]))
+    assert [reports[r]["checked"] for r in (0, 1)] == [30, 30]
+    assert all(not reports[r]["status"]["timed_out"] for r in (0, 1))
 
 
+@pytest.mark.multiprocess
 def test_bench_drops_a_direct_transport_that_loses_its_signals(tmp_path):
     """A direct transport whose pushes never raise the receiver's flags (GT4MI_DIRECT_TEST_LOSE_SIGNALS: what a broken link looks
-    like): the receiver's waits run out of time, the form fails its check on exactly known fields, `bench.py` drops it and every
-    later direct form, and the line is measured on RCCL -- slower to find out (2 s per wait), never wrong."""
+    like): the receiver's waits run out of time, the plan fails HARD (the next call on it raises ERR_TIMEOUT), `bench.py` drops
+    the form and every later direct form, and the line is measured on RCCL -- slower to find out, never wrong."""
     import json
     import os
     import pathlib
@@ -1259,16 +1304,18 @@ def test_bench_drops_a_direct_transport_that_loses_its_signals(tmp_path):
     import sys
 
     root = pathlib.Path(__file__).resolve().parent.parent
-    env = dict(os.environ, GT4MI_DIRECT_TEST_LOSE_SIGNALS="1", GT4MI_BENCH_TIMESTEP="0")
+    env = dict(os.environ, GT4MI_DIRECT_TEST_LOSE_SIGNALS="1", GT4MI_BENCH_TIMESTEP="0", GT4MI_BENCH_DIRECT_TIMEOUT_MS="250")
     proc = subprocess.run([sys.executable, str(root / "bench.py"), "--dist-selfloop", "--selfloop-grid", "1x8", "--steps", "10", "--warmup", "2"],
                           env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
     assert proc.returncode == 0, proc.stderr[-3000:]
     line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
     config = line["config"]
     assert config["halo_transport"].startswith("rccl") and config["direct_transport_dropped_at"].endswith("_direct")
-    assert config["verified"]["headline_form_correct_on_every_rank"] is True and config["verified"]["forms_rejected"] == 1
+    assert config["verified"]["headline_form_correct_on_every_rank"] is True
     assert not any(key.endswith("_direct") for key in config["calibration_ms_per_apply"])
-    assert "REJECTED" in proc.stderr and "ran out of time" in proc.stderr
+    assert line["calibration_candidates_failed"] == [config["direct_transport_dropped_at"]] and line["direct_best_ms_per_apply"] is None
+    assert line["rccl_best_ms_per_apply"] == min(config["calibration_ms_per_apply"].values())
+    assert "calibration candidate failed" in proc.stderr and "ran out of time" in proc.stderr
 
 
 def test_fused_launches_of_the_direct_transport_on_random_shapes(comm):
@@ -1314,6 +1361,7 @@ def test_fused_launches_of_the_direct_transport_on_random_shapes(comm):
         ex.close()
 
 
+@pytest.mark.multiprocess
 @_second_chance
 def test_bench_keeps_to_rccl_when_the_canary_of_the_direct_transport_fails(tmp_path):
     """On more than one rank `bench.py` lets a CHILD process per rank try the direct transport first (it maps another process's

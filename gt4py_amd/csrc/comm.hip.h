@@ -120,6 +120,9 @@ struct gt4mi_halo_plan {
     int defer_join = 0;           // chain schedule: leave the final join to gt4mi_halo_exchange_end (independent applies)
     // concurrency probe (ensure_concurrent_stream)
     unsigned* probe = nullptr;            // two device words: flag, result
+    // device words for kernels that read the receive buffers of an RCCL plan themselves (lap5_edge.hip.h): [0] a flag that is
+    // always satisfied (stays 0), [1] a sink for signals, [2] a sink for the error word, [4 .. 7] counters of the four sides
+    uint32_t* edge_words = nullptr;
     hipStream_t probed_main = nullptr;
     bool probed = false, concurrent = false;
     // ---- the direct transport (direct.hip.h): peer stores from the pack kernel instead of RCCL send/recv ----
@@ -339,8 +342,13 @@ inline int halo_pack_first(gt4mi_halo_plan* plan, const gt4mi_field* field, hipS
 }
 
 // Enqueue the two-phase exchange of `field`'s ghost cells on stream `s`.
+// `skip_last_unpack`: the caller's next kernel reads the receive buffers of the LAST non-empty phase itself (lap5_edge.hip.h:
+// waits for the direct transport's flags there, or simply runs behind the send/recv kernel) -- no unpack launch for that phase.
 inline int halo_exchange_on(gt4mi_halo_plan* plan, const gt4mi_field* field, hipStream_t s,
-                            bool first_pack_done = false) {
+                            bool first_pack_done = false, bool skip_last_unpack = false) {
+    int last_phase = -1;
+    for (int phase = 0; phase < 2; ++phase)
+        if (!plan->sends[phase].empty() || !plan->recvs[phase].empty()) last_phase = phase;
     const int p0 = first_phase(plan);
     if (plan->transport == GT4MI_TRANSPORT_DIRECT) {
         // every face is stored straight into its neighbour's receive buffer by the pack kernel, whose last workgroup raises the
@@ -355,7 +363,7 @@ inline int halo_exchange_on(gt4mi_halo_plan* plan, const gt4mi_field* field, hip
             if (!(pushed && phase == p0)) rc = direct_push(plan, field, phase, s);
             if (rc == GT4MI_OK) {
                 launched = launched || !plan->sends[phase].empty();
-                rc = direct_unpack(plan, field, phase, s);
+                if (!(skip_last_unpack && phase == last_phase)) rc = direct_unpack(plan, field, phase, s);
             }
             if (rc != GT4MI_OK) {
                 // nothing launched yet: as if the call had never been made; else the neighbours will count an exchange that this
@@ -383,6 +391,7 @@ inline int halo_exchange_on(gt4mi_halo_plan* plan, const gt4mi_field* field, hip
         for (auto& m : sends) GT4MI_RCCL_CHECK(api.Send(m.buffer, m.bytes, RCCL_UINT8, m.peer, plan->comm->comm, s));
         for (auto& m : recvs) GT4MI_RCCL_CHECK(api.Recv(m.buffer, m.bytes, RCCL_UINT8, m.peer, plan->comm->comm, s));
         GT4MI_RCCL_CHECK(api.GroupEnd());
+        if (skip_last_unpack && phase == last_phase) continue;
         if (int rc = plan_copy<false>(plan, field, recvs, s)) return rc;
     }
     return GT4MI_OK;

@@ -265,6 +265,42 @@ inline int direct_batches(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase
     return GT4MI_OK;
 }
 
+// The receive boxes of one phase for kernels that read the receive buffers themselves (lap5_edge.hip.h), on EITHER transport: the
+// direct transport's own flags, or -- the plan exchanges through RCCL and the kernel runs behind the send/recv kernel in stream
+// order -- a flag word that is always satisfied and a sink for the signals (plan->edge_words).
+template <typename U>
+inline int direct_batches_recv(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase, BoxBatch& b, DirectBatch& d) {
+    int64_t blocks = 0;
+    if (plan->transport == GT4MI_TRANSPORT_DIRECT) return direct_batches<U, false>(plan, f, phase, b, d, blocks);
+    const auto& msgs = plan->recvs[phase];
+    b.n = (int)msgs.size();
+    if (b.n > BoxBatch::MAX) return fail(GT4MI_ERR_UNSUPPORTED, "halo: more than %d boxes per phase", BoxBatch::MAX);
+    constexpr int64_t PER_VEC = 16 / (int64_t)sizeof(U);
+    const bool field_vec = f->stride[0] == (int64_t)sizeof(U) && f->stride[1] % 16 == 0 && f->stride[2] % 16 == 0 &&
+                           reinterpret_cast<uintptr_t>(f->data) % 16 == 0;
+    for (int m = 0; m < b.n; ++m) {
+        int64_t off = 0;
+        for (int a = 0; a < 3; ++a) {
+            if (msgs[m].lo[a] + msgs[m].ext[a] > f->shape[a])
+                return fail(GT4MI_ERR_OUT_OF_BOUNDS, "halo: box [%lld, %lld) outside of axis %d (size %lld)",
+                            (long long)msgs[m].lo[a], (long long)(msgs[m].lo[a] + msgs[m].ext[a]), a, (long long)f->shape[a]);
+            if (f->stride[a] % (int64_t)sizeof(U) != 0) return fail(GT4MI_ERR_UNSUPPORTED, "halo: stride not a multiple of the item size");
+            off += msgs[m].lo[a] * (f->stride[a] / (int64_t)sizeof(U));
+            b.ext[m][a] = (int)msgs[m].ext[a];
+        }
+        b.offset[m] = off;
+        b.buffer[m] = msgs[m].buffer;
+        b.vec[m] = field_vec && msgs[m].lo[0] % PER_VEC == 0 && msgs[m].ext[0] % PER_VEC == 0 && reinterpret_cast<uintptr_t>(msgs[m].buffer) % 16 == 0;
+        d.wait_flag[m] = plan->edge_words;  // always 0 >= 0
+        d.wait_value[m] = 0;
+        d.signal_flag[m] = plan->edge_words + 1;
+        d.blocks[m] = direct_blocks(msgs[m].bytes);
+    }
+    d.error = plan->edge_words + 2;
+    d.timeout_ticks = direct_timeout_ticks(plan);
+    return GT4MI_OK;
+}
+
 template <typename U, bool PACK>
 inline int direct_copy(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase, hipStream_t s) {
     BoxBatch b;

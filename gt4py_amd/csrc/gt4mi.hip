@@ -15,7 +15,7 @@
 #include "lap5.hip.h"
 #include "lap5_push.hip.h"
 #include "lap5_ring.hip.h"
-#include "lap5_ring_unpack.hip.h"
+#include "lap5_edge.hip.h"
 #include "rtc.hip.h"
 #include "tridiag.hip.h"
 
@@ -208,6 +208,18 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
     if (EW > 1) EW -= EW % (int64_t)(16 / sizeof(T));  // whole 16-byte lanes: the interior kernel keeps its alignment
     if (EW < 1) EW = 1;
     if (di < 16 * EW) EW = di >= 64 ? (EW < 8 ? EW : 8) : 1;  // narrow local domains keep most of their columns in the interior
+    // Round 4: where the plan and the layout allow it the unpack and the ring are ONE kernel of wave-sized units that read the
+    // receive buffers themselves (lap5_edge.hip.h); the interior then keeps every column but the first / last one (masked
+    // 16-byte lanes: lap5_launch_variant) instead of giving 8-16 columns to a ring of 64-byte pieces.
+    bool edge_units = false;
+    {
+        gt4mi::View<T> vi, vo;
+        gt4mi::EdgeFaces g;
+        gt4mi::EdgeCopies cp;
+        int ph = 0;
+        if (int rc = gt4mi::lap5_edge_prepare<T>(plan, domain, inp, out, sides, &vi, &vo, &g, &cp, &ph, &edge_units)) return rc;
+    }
+    if (edge_units) EW = 16 / (int64_t)sizeof(T);  // one 16-byte lane: what a column unit computes (lap5_edge.hip.h)
     const int64_t lo_i = (sides & 1) ? EW : 0, hi_i = (sides & 2) ? EW : 0;
     const int64_t lo_j = (sides & 4) ? 1 : 0, hi_j = (sides & 8) ? 1 : 0;
     auto run = [&](int64_t si, int64_t sj, int64_t ei, int64_t ej, hipStream_t st) -> int {
@@ -225,6 +237,19 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
         gt4mi::ScopedLaunchLds throttle(gt4mi::lds_for_workgroups_per_cu(gt4mi::plan_interior_wg_per_cu(plan, 0)));
         return run(lo_i, lo_j, di - lo_i - hi_i, dj - lo_j - hi_j, st);
     };
+    // what follows the pack(s) on stream `st`: the rest of the exchange and the points that read ghost cells
+    auto exchange_and_ring = [&](hipStream_t st, bool first_pack_done) -> int {
+        if (edge_units) {
+            if (int rc = gt4mi::halo_exchange_on(plan, inp, st, first_pack_done, /*skip_last_unpack=*/true)) return rc;
+            bool done = false;
+            if (int rc = gt4mi::lap5_edge_run<T, W>(plan, domain, inp, out, variant, sides, st, &done)) return rc;
+            if (done) return GT4MI_OK;
+            plan->direct.broken = plan->transport == GT4MI_TRANSPORT_DIRECT ? "the edge units of a fused step could not be launched" : nullptr;
+            return gt4mi::fail(GT4MI_ERR_HIP, "dist_lap5: the edge units qualified before the exchange and no longer do");
+        }
+        if (int rc = gt4mi::halo_exchange_on(plan, inp, st, first_pack_done)) return rc;
+        return gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, st);
+    };
     // default: the fastest on every share of 8 ranks measured (1 x 8, 2 x 4, 4 x 2) -- "swap" with RCCL,
     // "inline" when the pack kernel is the transfer (direct transport)
     const int schedule = gt4mi::plan_schedule(plan, plan->transport == GT4MI_TRANSPORT_DIRECT ? GT4MI_SCHEDULE_INLINE : GT4MI_SCHEDULE_SWAP);
@@ -234,7 +259,19 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
         if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, outer, ms)) return rc;  // validates only
         bool fused = false;
         const int p0 = gt4mi::first_phase(plan);
-        if (plan->transport == GT4MI_TRANSPORT_DIRECT && p0 < 2) {
+        if (edge_units && plan->transport == GT4MI_TRANSPORT_DIRECT && p0 < 2) {
+            // ONE launch: push | interior | copies and edge units (lap5_step_kernel)
+            bool done = false;
+            ++plan->direct.step;  // (what halo_pack_first does on this transport; the launch reads it)
+            const int rc = gt4mi::lap5_step_run<T, W>(plan, domain, inp, out, variant, sides, ms, &done);
+            if (rc || !done) --plan->direct.step;
+            if (rc) return rc;
+            if (done) {
+                plan->direct.first_pushed = false;  // this exchange is complete
+                return GT4MI_OK;
+            }
+        }
+        if (!edge_units && plan->transport == GT4MI_TRANSPORT_DIRECT && p0 < 2) {
             // ... and with the direct transport the push rides in the interior's launch (lap5_push.hip.h): 8-9 us off the step
             gt4mi_field a = *inp, b = *out;
             a.origin[0] += lo_i; a.origin[1] += lo_j;
@@ -252,14 +289,7 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
             if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
             if (int rc = interior(ms)) return rc;
         }
-        // ... and where the local domain is cut along J only, the unpack rides in the ring's launch (lap5_ring_unpack.hip.h)
-        bool ring_done = false;
-        static const int fuse_ring = gt4mi::env_int("GT4MI_DIST_FUSE_RING_UNPACK", 1);
-        if (fuse_ring && plan->transport == GT4MI_TRANSPORT_DIRECT && plan->direct.first_pushed && lo_i == 0 && hi_i == 0)
-            if (int rc = gt4mi::lap5_ring_unpack_run<T, W>(plan, domain, inp, out, variant, sides, ms, &ring_done)) return rc;
-        if (ring_done) return GT4MI_OK;
-        if (int rc = gt4mi::halo_exchange_on(plan, inp, ms, /*first_pack_done=*/true)) return rc;
-        return gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, ms);
+        return exchange_and_ring(ms, /*first_pack_done=*/true);
     }
     if (schedule == GT4MI_SCHEDULE_SWAP || schedule == GT4MI_SCHEDULE_SWAP_PACKED) {
         // the CALLER's stream carries the chain pack -> send/recv -> unpack -> ring (no cross-stream wait inside it, and it
@@ -271,7 +301,7 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
             if (int rc = gt4mi::halo_pack_first(plan, inp, ms)) return rc;
             GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
             GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
-            if (int rc = gt4mi::halo_exchange_on(plan, inp, ms, /*first_pack_done=*/true)) return rc;
+            if (int rc = exchange_and_ring(ms, /*first_pack_done=*/true)) return rc;
             if (int rc = interior(plan->stream)) return rc;
             GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
             plan->done_recorded = true;
@@ -281,9 +311,8 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
             if (int rc = interior(plan->stream)) return rc;
             GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
             plan->done_recorded = true;
-            if (int rc = gt4mi::halo_exchange_on(plan, inp, ms)) return rc;
+            if (int rc = exchange_and_ring(ms, /*first_pack_done=*/false)) return rc;
         }
-        if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, ms)) return rc;
         return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
     }
     if (schedule == GT4MI_SCHEDULE_CHAIN) {
@@ -293,8 +322,7 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
         GT4MI_HIP_CHECK(hipEventRecord(plan->ready, ms));
         GT4MI_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->ready, 0));
         if (int rc = interior(ms)) return rc;
-        if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream)) return rc;
-        if (int rc = gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, plan->stream)) return rc;
+        if (int rc = exchange_and_ring(plan->stream, /*first_pack_done=*/false)) return rc;
         GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
         plan->done_recorded = true;
         return plan->defer_join ? GT4MI_OK : gt4mi_halo_exchange_end(plan, main_stream);
@@ -309,11 +337,18 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
     // 2. main stream: interior, independent of the ghost cells in flight
     if (int rc = interior(ms)) return rc;
     // 3. side stream: RCCL send/recv + unpack (+ second phase), concurrent with the interior kernel
-    if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/true)) return rc;
+    if (int rc = gt4mi::halo_exchange_on(plan, inp, plan->stream, /*first_pack_done=*/true, /*skip_last_unpack=*/edge_units)) return rc;
     GT4MI_HIP_CHECK(hipEventRecord(plan->done, plan->stream));
-        plan->done_recorded = true;
-    // 4. main stream: join, then the ring of points that read ghost cells -- ONE launch (lap5_ring.hip.h)
+    plan->done_recorded = true;
+    // 4. main stream: join, then the points that read ghost cells -- ONE launch (lap5_edge.hip.h: the unpack rides along;
+    //    else lap5_ring.hip.h)
     if (int rc = gt4mi_halo_exchange_end(plan, main_stream)) return rc;
+    if (edge_units) {
+        bool done = false;
+        if (int rc = gt4mi::lap5_edge_run<T, W>(plan, domain, inp, out, variant, sides, ms, &done)) return rc;
+        if (done) return GT4MI_OK;
+        return gt4mi::fail(GT4MI_ERR_HIP, "dist_lap5: the edge units qualified before the exchange and no longer do");
+    }
     return gt4mi::lap5_ring_run<T, W>(domain, inp, out, variant, outer, inner, ms);
 }
 
@@ -547,9 +582,10 @@ int gt4mi_halo_plan_create(gt4mi_comm* comm, int elem_size, const gt4mi_halo_msg
         rc = gt4mi::fail(GT4MI_ERR_HIP, "halo_plan_create: hipEventCreate failed");
     if (rc == GT4MI_OK) {
         void* words = nullptr;
-        if (hipMalloc(&words, 256) != hipSuccess)
+        if (hipMalloc(&words, 256) != hipSuccess || hipMemset(words, 0, 256) != hipSuccess)
             rc = gt4mi::fail(GT4MI_ERR_HIP, "halo_plan_create: hipMalloc failed");
         p->probe = static_cast<unsigned*>(words);
+        p->edge_words = words ? reinterpret_cast<uint32_t*>(words) + 32 : nullptr;  // (the second half of the 256 bytes)
     }
     if (rc != GT4MI_OK) {
         gt4mi_halo_plan_destroy(p);

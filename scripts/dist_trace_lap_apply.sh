@@ -2,7 +2,7 @@
 # Run on the GPU box: kernel trace of the fused Laplacian apply (exchange on every apply) on the share of one rank of a PI x PJ
 # grid, 1-GPU self-loop.   usage: scripts/dist_trace_lap_apply.sh <tag> <PIxPJ> <schedule join|chain|swap|swap-packed|inline> <wg_per_cu>
 #                                  [single 0|1] [last kernel of a step: ring_kernel]
-# GT4MI_BENCH_TRANSPORTS=direct selects the direct transport; on 1 x N grids its inline schedule ends with "ring_unpack_kernel".
+# GT4MI_BENCH_TRANSPORTS=direct selects the direct transport; its inline schedule is ONE launch: "lap5_step_kernel".
 set -u
 TAG=${1:-r3}; G=${2:-4x2}; SCHED=${3:-join}; WG=${4:-0}; SP=${5:-1}; LAST=${6:-ring_kernel}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -97,7 +97,7 @@ def test_no_hot_kernel_of_the_library_spills():
     kernels = re.findall(r"remark: Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", text, re.S)
     by_name = {name: (int(scratch), int(waves)) for name, scratch, waves in kernels}
     hot = {n: v for n, v in by_name.items() if any(k in n for k in ("lap5_strip_kernel", "hdiff_jmarch_kernel", "tridiag_pipe_kernel",
-                                                                   "tridiag_kernel", "halo_copy_kernel"))}
+                                                                   "tridiag_kernel", "halo_copy_kernel", "lap5_step_kernel", "lap5_edge_kernel"))}
     assert len(hot) >= 20, sorted(by_name)[:5]
     spilling = {n: v for n, v in hot.items() if v[0] != 0}
     assert not spilling, spilling

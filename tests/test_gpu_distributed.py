@@ -133,8 +133,8 @@ def test_fused_distributed_laplacian_step_float32(comm, schedule, literal32):
         want = np.zeros_like(host)
         R.laplacian(wrapped, want)
         assert np.array_equal(out.get(), want)
-    # ... and on the direct transport, cut along J only: push + interior and unpack + ring, one launch each (lap5_push.hip.h,
-    # lap5_ring_unpack.hip.h), both message tables, a width that is no multiple of the tile and fewer levels than a wave takes
+    # ... and on the direct transport, cut along J only: push, interior and the edge units in ONE launch (lap5_edge.hip.h), both
+    # message tables, a width that is no multiple of the tile and fewer levels than a wave takes
     if schedule == "join":
         for gd in ((300, 40, 5), (1024, 6, 19)):
             dj = Decomposition(gd, (1, 1), 0, 1, periodic=(False, True))
@@ -1319,9 +1319,9 @@ def test_bench_drops_a_direct_transport_that_loses_its_signals(tmp_path):
 
 
 def test_fused_launches_of_the_direct_transport_on_random_shapes(comm):
-    """Random local domains through the two fused launches of the inline schedule (push + interior, unpack + ring) and -- where
-    the shape or the neighbours rule a fusion out -- their fall-backs: widths that are no multiple of the tile or of the vector,
-    two or three rows, one to twenty levels, every combination of periodic axes, both message tables, all four expressions.
+    """Random local domains through the ONE launch of the inline schedule (push | interior | edge units, lap5_edge.hip.h) and --
+    where the shape or the message table rules it out -- its fall-backs: widths that are no multiple of the tile or of the
+    vector, two or three rows, one to twenty levels, every combination of periodic axes, both message tables, all four expressions.
     Bit-identical to the whole-domain kernel on the wrapped field; the exchanged field equals the wrap."""
     import ctypes
 
@@ -1358,6 +1358,68 @@ def test_fused_launches_of_the_direct_transport_on_random_shapes(comm):
         torch.cuda.synchronize()
         assert np.array_equal(out.get(), ref.get()), (case, di, dj, dk, periodic, variant)
         assert ex.direct_status()["timed_out"] is False
+        ex.close()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "direct"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_edge_units_on_random_shapes_every_schedule_and_side(comm, transport, dtype):
+    """The unpack + ring of a distributed 5-point step as wave-sized units that read the receive buffers themselves
+    (csrc/lap5_edge.hip.h: column units for W / E faces, row units for S / N, copies for the corner boxes), as a kernel of its
+    own behind the send/recv kernel (RCCL) or the pushes (direct), and as the tail of the one launch of the inline schedule:
+    random widths (multiples of the 16-byte lane or not: then the older launches run), 2 ... 70 rows, 1 ... 21 levels -- fewer,
+    as many and more than a unit takes --, every combination of periodic axes (W / E only, S / N only, all four with the corner
+    boxes of the single-phase table), every schedule, all four expressions, fp64 and fp32 (literal precision 64 and 32).
+    Bit-identical to the whole-domain kernel on the wrapped field; the exchanged field equals the wrap; three applies in a row
+    (the counters of the units wrap, the flags count on)."""
+    import ctypes
+
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.distributed import Decomposition, NativeHaloExchanger
+    from gt4py_amd.distributed.native import _field_struct
+
+    lib = _lib.load()
+    rng = np.random.default_rng(1618 if transport == "rccl" else 3141)
+    f32 = np.dtype(dtype) == np.float32
+    schedules = ["join", "chain", "swap", "swap-packed", "inline"]
+    for case in range(60):
+        di = int(rng.choice([4, 8, 30, 64, 126, 128, 132, 256, 260, 384, 516, 640, 1024]))
+        dj = int(rng.choice([2, 3, 4, 9, 33, 64, 65, 70]))
+        dk = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 21]))
+        periodic = [(False, True), (True, True), (True, False)][case % 3]
+        variant, schedule = case % 4, schedules[case % 5]
+        flags = _lib.LAP_LITERAL_F32 if (f32 and case % 2) else 0
+        dec = Decomposition((di, dj, dk), (1, 1), 0, 1, periodic=periodic)
+        host = rng.uniform(-1, 1, dec.local_shape).astype(dtype)
+        wrapped = _wrap(host, 1, *periodic)
+        inp = gt_storage.from_array(host, dtype, backend="hip:mi300", aligned_index=dec.origin)
+        out = gt_storage.zeros(dec.local_shape, dtype, backend="hip:mi300", aligned_index=dec.origin)
+        ref = gt_storage.zeros(dec.local_shape, dtype, backend="hip:mi300", aligned_index=dec.origin)
+        # (single-phase: one round -- the units take part; two-phase with both axes cut: two rounds -- the older launches)
+        ex = NativeHaloExchanger(dec, dtype, comm, single_phase=bool(case % 4 != 3)).tune(schedule, 0)
+        if transport == "direct":
+            _direct(ex)
+        step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin, variant, flags=flags)
+        for _ in range(3):
+            step()
+            ex.end()
+        torch.cuda.synchronize()
+        what = (case, di, dj, dk, periodic, variant, schedule, transport)
+        assert np.array_equal(inp.get(), wrapped), what
+        fi, fr = _field_struct(inp, dec.origin), _field_struct(ref, dec.origin)
+        if f32:
+            _lib.check("gt4mi_lap5_f32", lib.gt4mi_lap5_f32(_lib.domain3(dec.local_domain), ctypes.byref(fi), ctypes.byref(fr), variant, flags,
+                                                            torch.cuda.current_stream().cuda_stream, None))
+        else:
+            _lib.check("gt4mi_lap5_f64", lib.gt4mi_lap5_f64(_lib.domain3(dec.local_domain), ctypes.byref(fi), ctypes.byref(fr), variant, 0,
+                                                            torch.cuda.current_stream().cuda_stream, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.get(), ref.get()), what
+        if transport == "direct":
+            assert ex.direct_status()["timed_out"] is False
         ex.close()
 
 

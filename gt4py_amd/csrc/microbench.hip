@@ -75,7 +75,10 @@ struct DevField {
         sk = sj * shape[1];
         const size_t align_b = align_items * sizeof(T);
         bytes = (size_t)sk * nk * sizeof(T) + 2 * align_b;
-        CK(hipMalloc(&raw, bytes));
+        // MB_CONTIG=1: physically contiguous device memory (hipDeviceMallocContiguous) -- the placement experiment of round 4
+        static const bool contiguous = getenv("MB_CONTIG") && atoi(getenv("MB_CONTIG")) != 0;
+        if (contiguous) CK(hipExtMallocWithFlags((void**)&raw, bytes, hipDeviceMallocContiguous));
+        else CK(hipMalloc(&raw, bytes));
         // offset so that element index `hi` is aligned
         const size_t off = (align_b - ((size_t)hi * sizeof(T)) % align_b) % align_b;
         data = reinterpret_cast<T*>(raw + off);
@@ -633,7 +636,8 @@ static void section_tripmc() {
 // Which (I tile, J row) a workgroup takes (tridiag_pipe_kernel's MAP): time, and -- under rocprofv3 --pmc -- the translation
 // counters, per mapping (round 4).  Also on a domain that is no multiple of anything.
 static void section_trimap() {
-    for (int rep = 0; rep < 2; ++rep) {
+    const int reps = getenv("MB_TRIMAP_REPS") ? atoi(getenv("MB_TRIMAP_REPS")) : 2;
+    for (int rep = 0; rep < reps; ++rep) {
         const int dI = 1024, dJ = 1024, dK = 160;
         DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
         DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
@@ -870,7 +874,9 @@ static void section_triplace(int argc_extra, const std::vector<std::string>& ext
     const size_t slot = (fbytes + round - 1) / round * round;
     const size_t total = 5 * (slot + max_delta) + round;
     char* raw = nullptr;
-    CK(hipMalloc(&raw, total));
+    const bool contiguous = getenv("MB_CONTIG") && atoi(getenv("MB_CONTIG")) != 0;  // physically contiguous: offsets are PHYSICAL offsets
+    if (contiguous) CK(hipExtMallocWithFlags((void**)&raw, total, hipDeviceMallocContiguous));
+    else CK(hipMalloc(&raw, total));
     char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(raw) + round - 1) / round * round);
     printf("triplace   one allocation of %.1f MiB at %p (base rounded to 32 MiB: %p), field %.1f MiB, slot %.1f MiB\n",
            total / (double)MiB, (void*)raw, (void*)base, fbytes / (double)MiB, slot / (double)MiB);
@@ -902,7 +908,8 @@ static void section_triplace(int argc_extra, const std::vector<std::string>& ext
             View<const double> a{p[0], 1, sj, sk}, d{p[1], 1, sj, sk};
             View<double> s{p[2], 1, sj, sk}, r{p[3], 1, sj, sk}, o{p[4], 1, sj, sk};
             const double ms = time_ms([&](int) {
-                hipLaunchKernelGGL((tridiag_stack_kernel<double, 32, 40, 8>), dim3(ti * dJ), dim3(64), 0, 0, a, d, s, r, o, dI, dJ, dK, ti);
+                if (contiguous) hipLaunchKernelGGL((tridiag_pipe_kernel<double, 104, 40, 4>), dim3(ti * dJ), dim3(64), 0, 0, a, d, s, r, o, dI, dJ, dK, ti);
+                else hipLaunchKernelGGL((tridiag_stack_kernel<double, 32, 40, 8>), dim3(ti * dJ), dim3(64), 0, 0, a, d, s, r, o, dI, dJ, dK, ti);
             }, 5, 1);
             const double ms2 = time_ms([&](int) {
                 const unsigned t2 = (unsigned)cdiv(dI, 256);

@@ -639,11 +639,19 @@ static void section_trimap() {
     const int reps = getenv("MB_TRIMAP_REPS") ? atoi(getenv("MB_TRIMAP_REPS")) : 2;
     for (int rep = 0; rep < reps; ++rep) {
         const int dI = 1024, dJ = 1024, dK = 160;
+        void* dummy = nullptr;  // MB_TRIMAP_SHUFFLE: another placement of the fields in every pass
+        if (getenv("MB_TRIMAP_SHUFFLE")) CK(hipMalloc(&dummy, (size_t)(rep * 37 + 5) * (2u << 20) * (size_t)atoi(getenv("MB_TRIMAP_SHUFFLE"))));
         DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
         DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+        if (dummy) hipFree(dummy);
         fill(a, 1, -1.0, 1.0);
         fill(d, 2, 4.0, 5.0);
+        printf("trimap     fields (MiB, modulo 1 GiB): inf %.3f diag %.3f sup %.3f rhs %.3f out %.3f   raw inf %p\n",
+               (reinterpret_cast<uintptr_t>(a.data) % (1ull << 30)) / 1048576.0, (reinterpret_cast<uintptr_t>(d.data) % (1ull << 30)) / 1048576.0,
+               (reinterpret_cast<uintptr_t>(s.data) % (1ull << 30)) / 1048576.0, (reinterpret_cast<uintptr_t>(r.data) % (1ull << 30)) / 1048576.0,
+               (reinterpret_cast<uintptr_t>(o.data) % (1ull << 30)) / 1048576.0, (void*)a.raw);
         tridiag_stack_variant<104, 40, 4, true, 1, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        if (getenv("MB_TRIMAP_ONLY0")) continue;
         tridiag_stack_variant<104, 40, 4, true, 1, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<104, 40, 4, true, 1, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<104, 40, 4, true, 1, 3>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);

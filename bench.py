@@ -661,10 +661,13 @@ def lap_calibration_order(default_grid, grids, phases, transports):
       direct(best) the direct transport (only after its canary), by the self-loop ranking: "inline" on the best grid, both
               tables; "inline" on the other grids; then the two-stream schedules on the best grid."""
     rccl, direct = "rccl" in transports, "direct" in transports
+    # (the other grids by the self-loop ranking of round 4: the fewer cuts along I -- W / E faces are strided columns, one
+    # partial-line store per row and level -- the faster the share: 1 x 8 < 2 x 4 < 4 x 2 per apply on either transport)
+    others = sorted((g for g in grids if g != default_grid), key=lambda g: g[0])
     first = []
     if rccl:
         first += [(default_grid, single, schedule, 0, "rccl") for single in phases for schedule in ("swap", "join")]
-        first += [(g, single, "swap", 0, "rccl") for g in grids if g != default_grid for single in phases]
+        first += [(g, single, "swap", 0, "rccl") for g in others for single in phases]
 
     def refine(best):
         g, single = best[0], best[1]
@@ -680,7 +683,7 @@ def lap_calibration_order(default_grid, grids, phases, transports):
             return []
         g = best[0] if best is not None else default_grid
         out = [(g, single, "inline", 0, "direct") for single in phases]
-        out += [(og, single, "inline", 0, "direct") for og in grids if og != g for single in phases]
+        out += [(og, single, "inline", 0, "direct") for og in sorted((x for x in grids if x != g), key=lambda x: x[0]) for single in phases]
         out += [(g, single, schedule, 0, "direct") for schedule in ("swap", "join", "swap-packed", "chain") for single in phases]
         return out
 

@@ -276,7 +276,10 @@ int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream);
  * overlapped with the interior kernel, then the boundary strips.  `sides` = bit mask of the sides
  * that have a neighbour: 1 = low I (W), 2 = high I (E), 4 = low J (S), 8 = high J (N).  Schedule (GT4MI_PLAN_SCHEDULE):
  * default GT4MI_SCHEDULE_SWAP (GT4MI_SCHEDULE_INLINE on the direct transport); whatever the schedule, work enqueued on `main_stream` after the call sees the whole result
- * (unless GT4MI_PLAN_DEFER_JOIN says otherwise). */
+ * (unless GT4MI_PLAN_DEFER_JOIN says otherwise).  Where the plan receives in ONE round (a single-phase table, or a grid cut along one
+ * axis) and the fields are I-contiguous with 16-byte aligned rows, the unpack and the boundary strips are one kernel of units that read
+ * the receive buffers themselves, and on the direct transport's GT4MI_SCHEDULE_INLINE the whole apply is ONE launch (csrc/lap5_edge.hip.h).
+ * After the call `inp` has its ghost cells, as after gt4mi_halo_exchange. */
 int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int sides, void* main_stream);
 /* The same for float32 fields (a plan created for 4-byte items); `flags` as for gt4mi_lap5_f32 (GT4MI_LAP_LITERAL_F32). */

@@ -1169,7 +1169,7 @@ def test_a_neighbour_that_never_arrives_fails_the_direct_transport_hard(comm, st
     ex.close()
 
 
-def _two_rank_direct_worker(rank: int, world: int, tmpdir: str, grid, periodic, forms="all"):
+def _two_rank_direct_worker(rank: int, world: int, tmpdir: str, grid, periodic, forms="all", cases=None, check_domain=(96, 80, 6)):
     """(run by tests/mp_util.run_ranks: the gloo group exists -- it only carries the descriptions of the pools and the results --,
     the return value is this rank's report)"""
     import torch
@@ -1187,8 +1187,8 @@ def _two_rank_direct_worker(rank: int, world: int, tmpdir: str, grid, periodic, 
     assert comm.info() == {"nranks": world, "rank": rank, "device": 0}
     rng = np.random.default_rng(4096)  # the same stream on every rank: the same global fields
     checked, log = 0, []
-    cases = (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5)), ("lap5", 1, (131, 67, 3)))
-    schedules = ("join", "chain", "swap", "swap-packed", "inline") if forms == "all" else ("inline",)
+    cases = cases or (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5)), ("lap5", 1, (131, 67, 3)))
+    schedules = ("join", "chain", "swap", "swap-packed", "inline") if forms == "all" else tuple(forms.split(","))
     for name, h, gd in cases:
         shape = (gd[0] + 2 * h, gd[1] + 2 * h, gd[2])
         glob = rng.uniform(-10, 10, shape)
@@ -1249,7 +1249,7 @@ def _two_rank_direct_worker(rank: int, world: int, tmpdir: str, grid, periodic, 
                     got[sl] = res[key]
                 assert np.array_equal(got[h:-h, h:-h], want[h:-h, h:-h]), (name, key)
     # the self-check bench.py runs on every form, here between two processes
-    dec = Decomposition((96, 80, 6), grid, rank, 1, periodic=periodic)
+    dec = Decomposition(tuple(check_domain), grid, rank, 1, periodic=periodic)
     lap = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64}, device_sync=False)
     fr = lap.freeze(origin={"inp": dec.origin, "out": dec.origin}, domain=dec.local_domain)
     chk = FormCheck(dec, lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin),
@@ -1290,6 +1290,32 @@ def test_two_processes_push_faces_into_each_other_on_one_gpu(grid, periodic, tmp
         pytest.skip(str([reports[r].get("unavailable") for r in (0, 1)]))
     assert [reports[r]["checked"] for r in (0, 1)] == [30, 30]
     assert all(not reports[r]["status"]["timed_out"] for r in (0, 1))
+
+
+@pytest.mark.multiprocess
+@pytest.mark.parametrize("grid,periodic", [((4, 2), (False, False)), ((2, 4), (True, True)), ((1, 8), (False, False))])
+def test_eight_processes_on_one_gpu_exchange_faces_on_the_grids_of_an_eight_gpu_node(grid, periodic, tmp_path):
+    """EIGHT REAL RANKS of the native path on the one device of the box: the process grids an 8-GPU node would run -- 4 x 2 (the
+    north star's; interior ranks have all four neighbours and, in the single-phase table, four diagonal ones), 2 x 4 periodic
+    (every rank has every neighbour; along I the same peer twice), 1 x 8 -- with every pool mapped by its neighbours over hipIpc
+    and every face pushed into ANOTHER process's memory.  What no test on this box could show before: ranks in every position
+    of a grid (corner, edge, interior: every subset of sides, corner boxes to diagonal neighbours) running the fused
+    Laplacian step -- one launch with its edge units where the local width allows it -- and the fused horizontal diffusion
+    against each other.  The assembled results equal the oracle on the undecomposed field bit for bit, every rank's ghost cells
+    the global field's values, the self-check passes on every rank, no wait times out.  (What it cannot show: the same stores
+    crossing xGMI.)"""
+    from mp_util import run_ranks
+
+    # local widths 2 * 76 / 4 = 38 ... : multiples of the 16-byte lane on every rank (the edge units take part) and one case where
+    # they are not (131 / 4: the older launches)
+    cases = (("hdiff", 2, (152, 72, 5)), ("lap5", 1, (152, 72, 5)), ("lap5", 1, (520, 136, 9)), ("lap5", 1, (131, 67, 3)))
+    if grid == (1, 8):
+        cases = (("hdiff", 2, (152, 72, 5)), ("lap5", 1, (152, 72, 5)), ("lap5", 1, (520, 136, 9)))
+    reports = run_ranks(_two_rank_direct_worker, 8, tmp_path, args=(grid, periodic, "inline,swap", cases, (192, 160, 6)), timeout=900)
+    if any("unavailable" in reports[r] for r in range(8)):
+        pytest.skip(str([reports[r].get("unavailable") for r in range(8)]))
+    assert [reports[r]["checked"] for r in range(8)] == [len(cases) * 2 * 2] * 8
+    assert all(not reports[r]["status"]["timed_out"] and all(v[0] for v in reports[r]["verdicts"]) for r in range(8))
 
 
 @pytest.mark.multiprocess

@@ -1162,6 +1162,8 @@ def _setup_distributed_laplacian(args, ctx):
         for cand_wg, cand_transport in [(w, t) for w in (0, 4, 2) for t in transports]:
             if cand_transport == "direct" and ctx.get("direct_dropped"):
                 continue
+            if not ctx["informational_budget"].more():  # (collective: every rank stops at the same candidate)
+                break
 
             def make(cand_wg=cand_wg, cand_transport=cand_transport):
                 call, keep = apply_candidate(grid, single_phase, "chain", cand_wg, cand_transport)
@@ -1180,6 +1182,7 @@ def _setup_distributed_laplacian(args, ctx):
         chosen grid: ms per STEP of every schedule x depth, slowest rank; collective, so every rank runs it."""
         if transport != "native" or os.environ.get("GT4MI_BENCH_TIMESTEP", "1") == "0":
             return None
+        ctx["informational_budget"] = WallBudget(ctx, calibration_seconds("GT4MI_BENCH_INFORMATIONAL_SECONDS", 60))
         pipelined = pipelined_applies() if mode == "apply" else None
         table = {}
         for cand_halo in (1, 2, 3, 4):
@@ -1192,6 +1195,8 @@ def _setup_distributed_laplacian(args, ctx):
                 if not stepper.startswith("skewed") and cand_halo == 3:
                     continue
                 if cand_transport == "direct" and ctx.get("direct_dropped"):
+                    continue
+                if not ctx["informational_budget"].more():
                     continue
                 per_call = cand_halo if stepper.startswith("skewed") else 1
 
@@ -1482,11 +1487,14 @@ def _setup_hdiff2048(args, ctx):
             return None
         table = {}
         flags = type(hd)._gt_binding_.flags
+        budget = WallBudget(ctx, calibration_seconds("GT4MI_BENCH_INFORMATIONAL_SECONDS", 60))
         for single in (False, True):
             for cand_wg in (0, 3, 2):
                 for cand_edge, cand_transport in [(e, t) for e in (2, 16, 32)
                                                   for t in hd_transports]:
                     if cand_transport == "direct" and ctx.get("direct_dropped"):
+                        continue
+                    if not budget.more():
                         continue
 
                     def make(single=single, cand_wg=cand_wg, cand_edge=cand_edge, cand_transport=cand_transport):

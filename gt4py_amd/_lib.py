@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_halo_plan_direct_layout",
     "gt4mi_halo_plan_direct_connect",
     "gt4mi_halo_plan_direct_status",
+    "gt4mi_dist_lap5_query",
     "gt4mi_halo_plan_concurrent",
     "gt4mi_halo_exchange",
     "gt4mi_halo_exchange_begin",
@@ -215,6 +216,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_halo_plan_direct_layout.argtypes = [P, I, I, I, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int)]
     lib.gt4mi_halo_plan_direct_connect.restype = I
     lib.gt4mi_halo_plan_direct_connect.argtypes = [P, I, I, I, ctypes.POINTER(DirectInfo), ctypes.c_int64, I]
+    lib.gt4mi_dist_lap5_query.restype = I
+    lib.gt4mi_dist_lap5_query.argtypes = [P, DOM, FP, FP, I, ctypes.POINTER(ctypes.c_int)]
     lib.gt4mi_halo_plan_direct_status.restype = I
     lib.gt4mi_halo_plan_direct_status.argtypes = [P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint)]
     lib.gt4mi_halo_plan_concurrent.restype = I

@@ -732,6 +732,26 @@ int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt
     return dist_lap5<double, double>(plan, domain, inp, out, variant, sides, main_stream);
 }
 
+int gt4mi_dist_lap5_query(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int sides,
+                          int* edge_units) {
+    if (plan == nullptr || inp == nullptr || out == nullptr || domain == nullptr || edge_units == nullptr)
+        return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "dist_lap5_query: null argument");
+    gt4mi::EdgeFaces g;
+    gt4mi::EdgeCopies cp;
+    int phase = 0;
+    bool ok = false;
+    int rc;
+    if (plan->elem_size == 8) {
+        gt4mi::View<double> vi, vo;
+        rc = gt4mi::lap5_edge_prepare<double>(plan, domain, inp, out, sides, &vi, &vo, &g, &cp, &phase, &ok);
+    } else {
+        gt4mi::View<float> vi, vo;
+        rc = gt4mi::lap5_edge_prepare<float>(plan, domain, inp, out, sides, &vi, &vo, &g, &cp, &phase, &ok);
+    }
+    *edge_units = ok ? 1 : 0;
+    return rc;
+}
+
 int gt4mi_dist_lap5_f32(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int flags, int sides, void* main_stream) {
     if (flags & GT4MI_LAP_LITERAL_F32) return dist_lap5<float, float>(plan, domain, inp, out, variant, sides, main_stream);

@@ -209,8 +209,9 @@ __device__ __forceinline__ unsigned lap5_edge_col_unit(const View<T>& in, const 
                 s[l][v] = lane_shift<T, true>(c[l][v]);   // row j - 1: the lane below
                 n[l][v] = lane_shift<T, false>(c[l][v]);  // row j + 1
             }
-            if (lane == 0) vload<T, VEC>(row + i0 - in.sj, s[l]);
-            if (load_n) vload<T, VEC>(row + i0 + in.sj, n[l]);
+            // (only for rows that are computed: a face that carries the ghost rows -1 / dJ has no row beyond them)
+            if (lane == 0 && compute) vload<T, VEC>(row + i0 - in.sj, s[l]);
+            if (load_n && compute) vload<T, VEC>(row + i0 + in.sj, n[l]);
         }
 #pragma unroll
         for (int l = 0; l < CH; ++l) {
@@ -363,7 +364,8 @@ inline int lap5_edge_prepare(gt4mi_halo_plan* plan, const int64_t domain[3], con
         int s = -1;
         if (whole_k && msg.ext[1] == 1 && (jlo == -1 || jlo == dj) && ilo <= 0 && ilo >= -1 && ilo + msg.ext[0] >= di && ilo + msg.ext[0] <= di + 1)
             s = jlo == -1 ? 2 : 3;
-        else if (whole_k && msg.ext[0] == 1 && (ilo == -1 || ilo == di) && jlo == 0 && msg.ext[1] == dj)
+        else if (whole_k && msg.ext[0] == 1 && (ilo == -1 || ilo == di) && jlo <= 0 && jlo >= -1 && jlo + msg.ext[1] >= dj &&
+                 jlo + msg.ext[1] <= dj + 1)  // (a face may carry the ghost rows of a side without a neighbour: rows -1 and / or dJ)
             s = ilo == -1 ? 0 : 1;
         if (s >= 0 && !g->have[s] && (sides >> s & 1)) {
             g->have[s] = 1;

@@ -333,6 +333,17 @@ class NativeHaloExchanger:
         apply._keepalive = (fi, fo, dom) + ((inp, out) if hold_arrays else ())  # type: ignore[attr-defined]
         return apply
 
+    def lap5_uses_edge_units(self, inp, out, origin_inp: Sequence[int], origin_out: Sequence[int]) -> bool:
+        """Would ``make_dist_lap5`` on these arrays run the unpack and the boundary strips as the edge units of
+        csrc/lap5_edge.hip.h (on the direct transport's one-stream schedule: the whole apply as ONE launch)?  Nothing is
+        enqueued (gt4mi_dist_lap5_query)."""
+        fi, fo = _field_struct(inp, origin_inp), _field_struct(out, origin_out)
+        answer = ctypes.c_int()
+        _lib.check("gt4mi_dist_lap5_query",
+                   self._lib.gt4mi_dist_lap5_query(self._plan, _lib.domain3(self.decomp.local_domain), ctypes.byref(fi), ctypes.byref(fo),
+                                                   self.sides, ctypes.byref(answer)))
+        return bool(answer.value)
+
     def make_dist_hdiff(self, in_field, out_field, coeff, origin: Sequence[int], flags: int, coeff_scalar: float = 0.0,
                         hold_arrays: bool = True):
         """Pre-bind one distributed apply of horizontal diffusion (gt4mi_dist_hdiff_f64 / _f32: pack, interior next to the

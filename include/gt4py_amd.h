@@ -282,6 +282,12 @@ int gt4mi_halo_exchange_end(gt4mi_halo_plan* plan, void* main_stream);
  * After the call `inp` has its ghost cells, as after gt4mi_halo_exchange. */
 int gt4mi_dist_lap5_f64(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int sides, void* main_stream);
+/* Which launches gt4mi_dist_lap5_* would make for these arguments (nothing is enqueued): *edge_units = 1 when the unpack and the
+ * boundary strips are the edge units of csrc/lap5_edge.hip.h (and, on the direct transport's GT4MI_SCHEDULE_INLINE, the whole apply
+ * ONE launch), 0 when they are separate unpack and ring launches (two receiving rounds, a width that is no multiple of the 16-byte
+ * lane, a layout without unit I stride ...).  The plan's item size selects float64 / float32. */
+int gt4mi_dist_lap5_query(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp, const gt4mi_field* out, int sides,
+                          int* edge_units);
 /* The same for float32 fields (a plan created for 4-byte items); `flags` as for gt4mi_lap5_f32 (GT4MI_LAP_LITERAL_F32). */
 int gt4mi_dist_lap5_f32(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field* inp,
                         const gt4mi_field* out, int variant, int flags, int sides, void* main_stream);

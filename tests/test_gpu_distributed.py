@@ -1186,7 +1186,7 @@ def _two_rank_direct_worker(rank: int, world: int, tmpdir: str, grid, periodic, 
     comm = NativeComm(rank=rank, world_size=world, rccl=False)  # RCCL cannot join two ranks on one device; no need to
     assert comm.info() == {"nranks": world, "rank": rank, "device": 0}
     rng = np.random.default_rng(4096)  # the same stream on every rank: the same global fields
-    checked, log = 0, []
+    checked, log, edge_units_seen = 0, [], 0
     cases = cases or (("hdiff", 2, (150, 70, 5)), ("lap5", 1, (150, 70, 5)), ("lap5", 1, (131, 67, 3)))
     schedules = ("join", "chain", "swap", "swap-packed", "inline") if forms == "all" else tuple(forms.split(","))
     for name, h, gd in cases:
@@ -1229,6 +1229,13 @@ def _two_rank_direct_worker(rank: int, world: int, tmpdir: str, grid, periodic, 
                     step = ex.make_dist_hdiff(inp, out, cf, dec.origin, _lib.HDIFF_LIMITER)
                 else:
                     step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin)
+                    # one receiving round (a single-phase table, or a grid cut along one axis) and a local width of whole
+                    # 16-byte lanes: the unpack + ring are edge units -- on every rank, wherever it sits in the grid
+                    # (an axis exchanges nothing when it is neither cut nor periodic)
+                    one_round = single_phase or (grid[0] == 1 and not periodic[0]) or (grid[1] == 1 and not periodic[1])
+                    want_units = one_round and dec.local_domain[0] % 2 == 0 and dec.local_domain[0] >= 4 and dec.local_domain[1] >= 2 and ex.sides != 0
+                    assert ex.lap5_uses_edge_units(inp, out, dec.origin, dec.origin) == want_units, (name, gd, single_phase, dec.local_domain)
+                    edge_units_seen += int(want_units)
                 for _ in range(3):  # (the flags count up; the peer's buffers are reused)
                     step()
                 torch.cuda.synchronize()
@@ -1270,7 +1277,7 @@ def _two_rank_direct_worker(rank: int, world: int, tmpdir: str, grid, periodic, 
     comm.close()
     failed = [(n, v[1]) for n, v in enumerate(verdicts) if not v[0]]
     assert not failed, (f"rank {rank}: {len(failed)} of {len(verdicts)} self-check rounds failed", failed[:3], status)
-    return {"checked": checked, "verdicts": verdicts, "status": status, "log": log}
+    return {"checked": checked, "verdicts": verdicts, "status": status, "log": log, "edge_unit_cases": edge_units_seen}
 
 
 @pytest.mark.multiprocess
@@ -1316,6 +1323,19 @@ def test_eight_processes_on_one_gpu_exchange_faces_on_the_grids_of_an_eight_gpu_
         pytest.skip(str([reports[r].get("unavailable") for r in range(8)]))
     assert [reports[r]["checked"] for r in range(8)] == [len(cases) * 2 * 2] * 8
     assert all(not reports[r]["status"]["timed_out"] and all(v[0] for v in reports[r]["verdicts"]) for r in range(8))
+    # ... and the one-launch form with its edge units really ran on EVERY rank (corner, edge and interior positions alike) for
+    # the two Laplacian cases whose local widths allow it: both schedules, with the single-phase table (on 1 x 8: both tables)
+    from gt4py_amd.distributed import Decomposition
+
+    def expected(rank):
+        n = 0
+        for name, h, gd in cases:
+            di = Decomposition(gd, grid, rank, h, periodic=periodic).local_domain[0]
+            tables = 2 if (grid[0] == 1 and not periodic[0]) or (grid[1] == 1 and not periodic[1]) else 1  # (one round with either table?)
+            n += 2 * tables if name == "lap5" and di % 2 == 0 and di >= 4 else 0  # two schedules
+        return n
+
+    assert [reports[r]["edge_unit_cases"] for r in range(8)] == [expected(r) for r in range(8)] and min(expected(r) for r in range(8)) >= 4
 
 
 @pytest.mark.multiprocess
@@ -1411,6 +1431,7 @@ def test_edge_units_on_random_shapes_every_schedule_and_side(comm, transport, dt
     rng = np.random.default_rng(1618 if transport == "rccl" else 3141)
     f32 = np.dtype(dtype) == np.float32
     schedules = ["join", "chain", "swap", "swap-packed", "inline"]
+    units = 0
     for case in range(60):
         di = int(rng.choice([4, 8, 30, 64, 126, 128, 132, 256, 260, 384, 516, 640, 1024]))
         dj = int(rng.choice([2, 3, 4, 9, 33, 64, 65, 70]))
@@ -1429,6 +1450,10 @@ def test_edge_units_on_random_shapes_every_schedule_and_side(comm, transport, dt
         if transport == "direct":
             _direct(ex)
         step = ex.make_dist_lap5(inp, out, dec.origin, dec.origin, variant, flags=flags)
+        vec = 16 // np.dtype(dtype).itemsize
+        one_round = bool(case % 4 != 3) or not all(periodic)
+        units += int(ex.lap5_uses_edge_units(inp, out, dec.origin, dec.origin))
+        assert ex.lap5_uses_edge_units(inp, out, dec.origin, dec.origin) == (one_round and di % vec == 0 and di >= 2 * vec), (di, dj, dk, periodic, case)
         for _ in range(3):
             step()
             ex.end()
@@ -1447,6 +1472,7 @@ def test_edge_units_on_random_shapes_every_schedule_and_side(comm, transport, dt
         if transport == "direct":
             assert ex.direct_status()["timed_out"] is False
         ex.close()
+    assert units >= 30  # (most cases take the units; the others -- two receiving rounds, odd widths -- the older launches)
 
 
 @pytest.mark.multiprocess

@@ -1339,6 +1339,40 @@ def test_eight_processes_on_one_gpu_exchange_faces_on_the_grids_of_an_eight_gpu_
 
 
 @pytest.mark.multiprocess
+def test_the_canary_of_bench_with_eight_ranks_on_one_device(tmp_path):
+    """What `bench.py` starts on every rank of an N-GPU run before it trusts the direct transport (`direct_canary`): the
+    self-check of the multi-GPU path restricted to that transport -- `python -m gt4py_amd.distributed --transport direct`, its
+    own gloo group met through a file -- here as EIGHT processes on the one device: the process grids `choose_process_grid`
+    returns for 8 ranks, ghost depths 1 and 2, both message tables, the sequential form and every schedule of the fused steps,
+    each checked on exactly known fields on every rank; rank 0 prints the table, every process ends with status 0."""
+    import os
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    base = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    procs = []
+    for rank in range(8):
+        env = dict(base, GT4MI_RENDEZVOUS_FILE=str(tmp_path / "rendezvous"), RANK=str(rank), WORLD_SIZE="8", LOCAL_RANK="0",
+                   PYTHONPATH=str(root) + os.pathsep + base.get("PYTHONPATH", ""))
+        procs.append(subprocess.Popen([sys.executable, "-m", "gt4py_amd.distributed", "--transport", "direct", "--domain", "256", "192", "8"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(root)))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:  # exactly the processes started above
+                q.kill()
+            pytest.fail("the self-check of the direct transport did not finish on 8 ranks within 600 s")
+    assert [p.returncode for p in procs] == [0] * 8, "\n".join(f"rank {r}: {o[-600:]} {e[-1200:]}" for r, (o, e) in enumerate(outs))
+    table = outs[0][0]
+    assert "checks x 8 rank(s): all correct" in table and "WRONG" not in table
+    assert "halo 1 grid 4x2 native/direct single-phase fused inline wg0" in table and "halo 2 grid 4x2 native/direct two-phase fused chain wg2" in table
+
+
+@pytest.mark.multiprocess
 def test_bench_drops_a_direct_transport_that_loses_its_signals(tmp_path):
     """A direct transport whose pushes never raise the receiver's flags (GT4MI_DIRECT_TEST_LOSE_SIGNALS: what a broken link looks
     like): the receiver's waits run out of time, the plan fails HARD (the next call on it raises ERR_TIMEOUT), `bench.py` drops

@@ -641,8 +641,9 @@ static void section_trimap() {
         const int dI = 1024, dJ = 1024, dK = 160;
         void* dummy = nullptr;  // MB_TRIMAP_SHUFFLE: another placement of the fields in every pass
         if (getenv("MB_TRIMAP_SHUFFLE")) CK(hipMalloc(&dummy, (size_t)(rep * 37 + 5) * (2u << 20) * (size_t)atoi(getenv("MB_TRIMAP_SHUFFLE"))));
-        DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
-        DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+        const int xp = getenv("MB_TRI_EXTRA_PITCH") ? atoi(getenv("MB_TRI_EXTRA_PITCH")) : 0;  // items added to the row pitch: the K stride is no power of two
+        DevField<double> a(dI, dJ, dK, 0, 0, 32, xp), d(dI, dJ, dK, 0, 0, 32, xp), s(dI, dJ, dK, 0, 0, 32, xp), r(dI, dJ, dK, 0, 0, 32, xp), o(dI, dJ, dK, 0, 0, 32, xp);
+        DevField<double> s2(dI, dJ, dK, 0, 0, 32, xp), r2(dI, dJ, dK, 0, 0, 32, xp), o2(dI, dJ, dK, 0, 0, 32, xp);
         if (dummy) hipFree(dummy);
         fill(a, 1, -1.0, 1.0);
         fill(d, 2, 4.0, 5.0);

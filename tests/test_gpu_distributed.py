@@ -1467,7 +1467,7 @@ def test_edge_units_on_random_shapes_every_schedule_and_side(comm, transport, dt
     schedules = ["join", "chain", "swap", "swap-packed", "inline"]
     units = 0
     for case in range(60):
-        di = int(rng.choice([4, 8, 30, 64, 126, 128, 132, 256, 260, 384, 516, 640, 1024]))
+        di = int(rng.choice([4, 8, 30, 33, 64, 126, 128, 129, 132, 256, 260, 384, 516, 640, 1024]))
         dj = int(rng.choice([2, 3, 4, 9, 33, 64, 65, 70]))
         dk = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 21]))
         periodic = [(False, True), (True, True), (True, False)][case % 3]
@@ -1506,7 +1506,7 @@ def test_edge_units_on_random_shapes_every_schedule_and_side(comm, transport, dt
         if transport == "direct":
             assert ex.direct_status()["timed_out"] is False
         ex.close()
-    assert units >= 30  # (most cases take the units; the others -- two receiving rounds, odd widths -- the older launches)
+    assert units >= 25  # (most cases take the units; the others -- two receiving rounds, odd widths -- the older launches)
 
 
 @pytest.mark.multiprocess

@@ -767,7 +767,8 @@ def hdiff_calibration_order(schedules, edges, transports):
       first        RCCL, what gt4mi_dist_hdiff_* does by default and won the self-loop rehearsals: "chain" (then "join"), the
                    interior kernel at 2 of 4 workgroups per CU, 16 edge columns, two-phase then single-phase
       refine(best) RCCL on the best message table: the other throttles and edge widths, the one-stream form, the plain sequence
-      direct(best) the direct transport after its canary: "inline" first (its pack kernel IS the transfer), both tables"""
+      direct(best) the direct transport after its canary, by the self-loop ranking of rounds 3-4: "chain" with the interior at 3, then
+                   2 of 4 workgroups per CU (0.194-0.204 ms for a 0.179 ms kernel), then the one-stream form (0.21-0.22)"""
     rccl, direct = "rccl" in transports, "direct" in transports
     tables = ("two_phase", "single_phase")
     two_stream = [sc for sc in ("chain", "join", "swap", "swap-packed") if sc in schedules]
@@ -790,9 +791,10 @@ def hdiff_calibration_order(schedules, edges, transports):
             return []
         t = table_of(best) if best else "two_phase"
         order = [t] + [o for o in tables if o != t]
-        out = [f"fused_{o}_inline_wg0_edge16_direct" for o in order] if "inline" in schedules else []
-        out += [f"fused_{t}_inline_wg0_edge{e}_direct" for e in edges if e != 16 and "inline" in schedules]
-        out += [f"fused_{o}_{sc}_wg2_edge16_direct" for sc in two_stream[:2] for o in order]
+        out = [f"fused_{o}_{two_stream[0]}_wg{wg}_edge16_direct" for wg in (3, 2) for o in order] if two_stream else []
+        if "inline" in schedules:
+            out += [f"fused_{t}_inline_wg0_edge{e}_direct" for e in (32, 16) if e in edges]
+        out += [f"fused_{o}_{sc}_wg2_edge16_direct" for sc in two_stream[1:2] for o in order]
         return out
 
     return first, refine, direct_stage
@@ -1525,7 +1527,8 @@ def _setup_hdiff2048(args, ctx):
               "calibration_ms_per_apply": timings, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped"),
               "direct_transport_canary": canary}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen),
-              "proof": proof, "transport_fallback": fallback, "timestep": pipelined_applies if decomposed else None,
+              "proof": proof, "transport_fallback": fallback,
+              "timestep": pipelined_applies if decomposed and os.environ.get("GT4MI_BENCH_TIMESTEP", "1") != "0" else None,
               "calibration": calibration_line_keys(timings, stats) if timings else None}
     return step, kernel_step, dec.local_domain, config, extras
 

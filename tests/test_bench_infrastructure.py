@@ -175,7 +175,8 @@ def test_the_calibration_order_puts_the_north_stars_rccl_forms_first():
                        "fused_single_phase_join_wg2_edge16"]
     assert all("single_phase" in n for n in h_refine("fused_single_phase_chain_wg2_edge16")[:-1]) and h_refine(h_first[0])[-2:] == [
         "sequential_two_phase", "sequential_single_phase"]
-    assert h_direct(h_first[0])[0] == "fused_two_phase_inline_wg0_edge16_direct" and all(n.endswith("_direct") for n in h_direct(None))
+    assert h_direct(h_first[0])[:2] == ["fused_two_phase_chain_wg3_edge16_direct", "fused_single_phase_chain_wg3_edge16_direct"]
+    assert all(n.endswith("_direct") for n in h_direct(None)) and "fused_two_phase_inline_wg0_edge32_direct" in h_direct(None)
 
 
 def _calibration_worker(rank: int, world: int, tmpdir: str, rccl_seconds: float, canary_says):

@@ -1464,14 +1464,19 @@ def test_edge_units_on_random_shapes_every_schedule_and_side(comm, transport, dt
     lib = _lib.load()
     rng = np.random.default_rng(1618 if transport == "rccl" else 3141)
     f32 = np.dtype(dtype) == np.float32
+    import os
+
     schedules = ["join", "chain", "swap", "swap-packed", "inline"]
     units = 0
-    for case in range(60):
+    cases = int(os.environ.get("GT4MI_EDGE_CASES", "60"))  # (campaigns: profiles/r4_edge_units_campaign.log)
+    for case in range(cases):
         di = int(rng.choice([4, 8, 30, 33, 64, 126, 128, 129, 132, 256, 260, 384, 516, 640, 1024]))
         dj = int(rng.choice([2, 3, 4, 9, 33, 64, 65, 70]))
         dk = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 21]))
+        if case >= 60:  # (campaigns: any even or odd width, any height)
+            di, dj = int(rng.integers(4, 700)), int(rng.integers(2, 140))
         periodic = [(False, True), (True, True), (True, False)][case % 3]
-        variant, schedule = case % 4, schedules[case % 5]
+        variant, schedule = case % 4, schedules[(case + case // 5) % 5]
         flags = _lib.LAP_LITERAL_F32 if (f32 and case % 2) else 0
         dec = Decomposition((di, dj, dk), (1, 1), 0, 1, periodic=periodic)
         host = rng.uniform(-1, 1, dec.local_shape).astype(dtype)

@@ -57,12 +57,18 @@ struct DirectBatch {
 __device__ __forceinline__ bool direct_wait(const uint32_t* flag, uint32_t value, long long timeout_ticks, uint32_t* error) {
     if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) >= 0) return true;
     const long long t0 = wall_clock64();  // 100 MHz
+    int nap = 0;
     while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
         if (wall_clock64() - t0 > timeout_ticks) {  // the peer is not coming
             __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return false;
         }
-        __builtin_amdgcn_s_sleep(4);
+        // back off: hundreds of waves may poll ONE word (the edge units of a fused step whose face is late), and the sender's add has
+        // to get through the same L2 channel
+        if (nap < 4) __builtin_amdgcn_s_sleep(8);
+        else if (nap < 16) __builtin_amdgcn_s_sleep(32);
+        else __builtin_amdgcn_s_sleep(127);
+        ++nap;
     }
     return true;
 }

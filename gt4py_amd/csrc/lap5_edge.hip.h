@@ -486,7 +486,7 @@ inline int lap5_step_run(gt4mi_halo_plan* plan, const int64_t domain[3], const g
     const int64_t tail = cdiv((int64_t)cp.blocks + cdiv((int64_t)g.first[4], (int64_t)4), (int64_t)8) * 8;
     if (tiles > INT32_MAX || interior + pad + tail > INT32_MAX) return GT4MI_OK;
     // the units start after this share of the interior's workgroups (GT4MI_DIST_EDGE_AFTER_PERCENT; 100: as the last workgroups)
-    static const int after = env_int("GT4MI_DIST_EDGE_AFTER_PERCENT", 70);
+    static const int after = env_int("GT4MI_DIST_EDGE_AFTER_PERCENT", 85);
     const int64_t split = (interior * (after < 0 ? 0 : (after > 100 ? 100 : after)) / 100) / 8 * 8;
     const dim3 grid((unsigned)(pad + interior + tail));
 #define GT4MI_LAP5_STEP_T(V, TPB, M)                                                                                              \

@@ -138,11 +138,6 @@ struct gt4mi_halo_plan {
         int timeout_ms = 0;                 // GT4MI_PLAN_DIRECT_TIMEOUT_MS (0: GT4MI_DIRECT_TIMEOUT_MS, else 30 s)
         const char* broken = nullptr;       // an exchange was enqueued only in part: which step failed (the plan stays failed)
         bool lose_signals = false;          // tests: GT4MI_DIRECT_TEST_LOSE_SIGNALS was set when the plan was prepared
-        // "Consumed" signals that the one-launch step (lap5_edge.hip.h) owes the senders of its last exchange: its units and its
-        // interior lanes read the faces' buffers all over the launch, so the buffers are free when the launch is OVER -- which the
-        // NEXT launch on this plan's stream knows for certain (stream order): it signals first thing.
-        struct Owed { uint32_t* flag; uint32_t add; };
-        std::vector<Owed> owed;
         uint32_t step = 0;                  // exchanges started
         bool first_pushed = false;          // halo_pack_first already pushed the first phase of exchange `step`
         struct Peer {
@@ -327,7 +322,6 @@ inline int first_phase(const gt4mi_halo_plan* plan) {
 // Pack the faces of the first non-empty phase only (they depend on nothing but the field itself,
 // so a caller can enqueue this ahead of its interior kernel).
 inline int direct_push(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s);    // direct.hip.h
-inline int direct_settle(gt4mi_halo_plan* plan, hipStream_t s);
 inline int direct_unpack(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s);
 inline int direct_failed(const gt4mi_halo_plan* plan);
 
@@ -336,7 +330,6 @@ inline int halo_pack_first(gt4mi_halo_plan* plan, const gt4mi_field* field, hipS
     if (p > 1) return GT4MI_OK;
     if (plan->transport == GT4MI_TRANSPORT_DIRECT) {  // the pack IS the transfer
         if (int rc = direct_failed(plan)) return rc;
-        if (int rc = direct_settle(plan, s)) return rc;
         ++plan->direct.step;  // (the push reads it)
         if (int rc = direct_push(plan, field, p, s)) {
             --plan->direct.step;  // nothing was launched: the counters still agree with the neighbours'
@@ -362,8 +355,6 @@ inline int halo_exchange_on(gt4mi_halo_plan* plan, const gt4mi_field* field, hip
         // neighbour's flag; the unpack kernel waits for its own flags, copies, and tells the senders that their buffers are free
         if (int rc = direct_failed(plan)) return rc;
         const bool pushed = first_pack_done && plan->direct.first_pushed;
-        if (!pushed)
-            if (int rc = direct_settle(plan, s)) return rc;
         if (!pushed) ++plan->direct.step;
         bool launched = pushed;  // something of this exchange is already on the device
         for (int phase = 0; phase < 2; ++phase) {

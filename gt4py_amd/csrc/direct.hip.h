@@ -321,39 +321,6 @@ inline int direct_copy(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase, h
     return GT4MI_OK;
 }
 
-// The "consumed" signals a one-launch step still owes (gt4mi_halo_plan::Direct::owed), as arguments of the launch that pays them.
-struct OwedSignals {
-    int n;
-    uint32_t* flag[4];
-    uint32_t add[4];
-};
-inline OwedSignals direct_owed(const gt4mi_halo_plan* plan) {
-    OwedSignals o;
-    o.n = 0;
-    for (const auto& x : plan->direct.owed)
-        if (o.n < 4) {
-            o.flag[o.n] = x.flag;
-            o.add[o.n] = x.add;
-            ++o.n;
-        }
-    return o;
-}
-__device__ __forceinline__ void direct_pay(const OwedSignals& o) {  // the launch's first threads
-    if (threadIdx.x < (unsigned)o.n)
-        __hip_atomic_fetch_add(o.flag[threadIdx.x], o.add[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__global__ void direct_settle_kernel(OwedSignals o) { direct_pay(o); }
-
-// Before anything else pushes on this plan: pay what a one-launch step owes (a launch of its own; the one-launch step pays in its
-// own first workgroup instead).
-inline int direct_settle(gt4mi_halo_plan* plan, hipStream_t s) {
-    if (plan->direct.owed.empty()) return GT4MI_OK;
-    hipLaunchKernelGGL(direct_settle_kernel, dim3(1), dim3(64), 0, s, direct_owed(plan));
-    GT4MI_HIP_CHECK(hipGetLastError());
-    plan->direct.owed.clear();
-    return GT4MI_OK;
-}
-
 inline int direct_push(gt4mi_halo_plan* plan, const gt4mi_field* field, int phase, hipStream_t s) {
     if (!plan->direct.prepared) return fail(GT4MI_ERR_INVALID_ARGUMENT, "halo: the direct transport was never prepared");
     return plan->elem_size == 8 ? direct_copy<uint64_t, true>(plan, field, phase, s) : direct_copy<uint32_t, true>(plan, field, phase, s);

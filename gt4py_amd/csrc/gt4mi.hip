@@ -277,7 +277,6 @@ int dist_lap5(gt4mi_halo_plan* plan, const int64_t domain[3], const gt4mi_field*
             a.origin[0] += lo_i; a.origin[1] += lo_j;
             b.origin[0] += lo_i; b.origin[1] += lo_j;
             const int64_t sub[3] = {di - lo_i - hi_i, dj - lo_j - hi_j, dk};
-            if (int rc = gt4mi::direct_settle(plan, ms)) return rc;
             ++plan->direct.step;  // (what halo_pack_first does on this transport)
             if (int rc = gt4mi::lap5_interior_with_push<T, W>(plan, sub, &a, &b, variant, inp, p0, ms, &fused)) {
                 --plan->direct.step;

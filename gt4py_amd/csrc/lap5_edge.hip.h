@@ -51,7 +51,6 @@ struct EdgeFaces {
     uint32_t consumed_add[4];
     unsigned* counter[4];        // units of this launch that have read the buffer
     unsigned readers[4];
-    int count_readers;           // 0: nobody counts -- the launch that follows on this stream frees the buffers (direct_owed)
     unsigned first[5];           // unit ranges: [first[s], first[s + 1]) are the units of side s
     unsigned tiles[4];           // units per level group of side s (tiles along the face)
     int rows_lo, rows_hi;        // column units COMPUTE rows [rows_lo, rows_hi) (the row units own the first / last row)
@@ -68,7 +67,6 @@ __device__ __forceinline__ bool edge_wait(const uint32_t* flag, uint32_t value, 
 // count them out together -- one atomic per side and workgroup --; the last readers of the launch free the buffer at the sender.
 // EVERY wave of the workgroup calls this (no early return in front of it).
 __device__ __forceinline__ void edge_block_done(const EdgeFaces& g, unsigned mask) {
-    if (!g.count_readers) return;  // (uniform over the launch)
     __shared__ unsigned read_by[4];
     if (threadIdx.x < 4) read_by[threadIdx.x] = 0;
     __syncthreads();
@@ -281,9 +279,8 @@ __global__ void __launch_bounds__(256)
 lap5_step_kernel(View<const T> in, View<T> out, int dI, int dJ_int, unsigned tiles_x, unsigned tiles_y, unsigned interior_tiles,
                  unsigned interior_blocks, unsigned push_pad, unsigned push_per_box, unsigned split, unsigned tail_pad, int c_lo, int c_hi,
                  U* field, int64_t si, int64_t sj, int64_t sk, BoxBatch pb, DirectBatch pd, View<T> in_dom, View<T> out_dom, int dJ, int dK,
-                 EdgeFaces g, EdgeCopies cp, OwedSignals owed) {
+                 EdgeFaces g, EdgeCopies cp) {
     constexpr int VEC = 16 / (int)sizeof(T), LJ = Lap5Tuning::LJ, LANES = 256 / TPB;
-    if (blockIdx.x == 0) direct_pay(owed);  // the previous launch on this stream is over: the faces it read are free again
     if (blockIdx.x < push_pad) {
         const unsigned m = blockIdx.x / push_per_box;
         if (m < (unsigned)pb.n) direct_block<U, true>(field, si, sj, sk, pb, pd, (int)m, blockIdx.x % push_per_box);
@@ -410,7 +407,6 @@ inline int lap5_edge_prepare(gt4mi_halo_plan* plan, const int64_t domain[3], con
             if (g->have[0]) g->readers[0] += groups;
             if (g->have[1]) g->readers[1] += groups;
         }
-    g->count_readers = 1;
     g->error = direct ? dx.error : plan->edge_words + 2;
     g->timeout_ticks = direct_timeout_ticks(plan);
     *phase_out = phase;
@@ -487,11 +483,6 @@ inline int lap5_step_run(gt4mi_halo_plan* plan, const int64_t domain[3], const g
     int64_t per_box = 0;
     if (int rc = direct_batches<U, true>(plan, inp, phase, pb, pd, per_box)) return rc;
     const int64_t pad = cdiv(per_box * pb.n, (int64_t)8) * 8;
-    if (pad == 0) return GT4MI_OK;  // (nothing to push: not ours)
-    // nobody counts the readers of the faces (units and -- round 4b -- interior lanes read them all over the launch): this launch
-    // pays what the previous one owes, and owes its own
-    g.count_readers = 0;
-    const OwedSignals owed = direct_owed(plan);
     const int64_t tail = cdiv((int64_t)cp.blocks + cdiv((int64_t)g.first[4], (int64_t)4), (int64_t)8) * 8;
     if (tiles > INT32_MAX || interior + pad + tail > INT32_MAX) return GT4MI_OK;
     // the units start after this share of the interior's workgroups (GT4MI_DIST_EDGE_AFTER_PERCENT; 100: as the last workgroups)
@@ -503,7 +494,7 @@ inline int lap5_step_run(gt4mi_halo_plan* plan, const int64_t domain[3], const g
                        (int)rows, tx, ty, (unsigned)tiles, (unsigned)interior, (unsigned)pad, (unsigned)(per_box > 0 ? per_box : 1), \
                        (unsigned)split, (unsigned)tail, c_lo, c_hi, static_cast<U*>(inp->data), inp->stride[0] / (int64_t)sizeof(U),                               \
                        inp->stride[1] / (int64_t)sizeof(U), inp->stride[2] / (int64_t)sizeof(U), pb, pd, in_v, out_v, (int)dj,    \
-                       (int)dk, g, cp, owed)
+                       (int)dk, g, cp)
 #define GT4MI_LAP5_STEP(V)                                                    \
     do {                                                                      \
         if (masked) {                                                         \
@@ -526,9 +517,6 @@ inline int lap5_step_run(gt4mi_halo_plan* plan, const int64_t domain[3], const g
 #undef GT4MI_LAP5_STEP
 #undef GT4MI_LAP5_STEP_T
     GT4MI_HIP_CHECK(hipGetLastError());
-    plan->direct.owed.clear();
-    for (int s = 0; s < 4; ++s)
-        if (g.have[s]) plan->direct.owed.push_back({g.consumed_flag[s], g.consumed_add[s]});
     *done = true;
     return GT4MI_OK;
 }

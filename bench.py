@@ -548,30 +548,56 @@ def _agree(ctx, ok: int) -> int:
     if ctx["distributed"]:
         import torch
 
-        flag = torch.tensor([ok], dtype=torch.int32, device=ctx.get("device", "cuda"))
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctx.get("collective_device", ctx.get("device", "cuda")))
         ctx["dist"].all_reduce(flag, op=ctx["dist"].ReduceOp.MIN)
         ok = int(flag.item())
     return ok
 
 
+class FailedOnSomeRank(RuntimeError):
+    """A timed callable raised on at least one rank; every rank raises this together, after the same collectives."""
+
+
 def _slowest_rank_ms(ctx, fn, calls: int, warm: int = 3) -> float:
-    """Milliseconds per call of ``fn`` over ``calls`` calls, the slowest rank's figure on every rank."""
+    """Milliseconds per call of ``fn`` over ``calls`` calls, the slowest rank's figure on every rank.
+
+    A call that raises on SOME rank (the direct transport fails hard: a neighbour that never arrives makes the next call on the
+    plan raise -- on the ranks that waited for it, not on the others) must not leave the ranks in different collectives: every
+    rank runs the same barrier and reductions whatever happened to it, then all raise ``FailedOnSomeRank`` together.  (Found by
+    the rehearsal with real ranks, GT4MI_BENCH_ONE_DEVICE: one rank went on to the next agreement while three were still in
+    this reduction, and the run ended on its provisional line 240 s later.)"""
     import torch
 
     device = ctx.get("device", "cuda")
     sync = torch.cuda.synchronize if device == "cuda" else (lambda: None)
-    for _ in range(warm):
-        fn()
-    sync()
+    failure = None
+
+    def run(n):
+        nonlocal failure
+        try:
+            for _ in range(n):
+                fn()
+            sync()
+        except Exception as ex:  # noqa: BLE001 - reported to every rank below
+            failure = failure or ex
+            try:
+                sync()
+            except Exception:  # noqa: BLE001
+                pass
+
+    run(warm)
     if ctx["distributed"]:
         ctx["dist"].barrier()
     t0 = time.perf_counter()
-    for _ in range(calls):
-        fn()
-    sync()
-    dt = torch.tensor([(time.perf_counter() - t0) / calls * 1e3], dtype=torch.float64, device=device)
+    if failure is None:
+        run(calls)
+    dt = torch.tensor([(time.perf_counter() - t0) / calls * 1e3], dtype=torch.float64, device=ctx.get("collective_device", device))
     if ctx["distributed"]:
         ctx["dist"].all_reduce(dt, op=ctx["dist"].ReduceOp.MAX)
+    if not _agree(ctx, int(failure is None)):
+        if failure is not None:
+            print(f"rank {ctx['rank']}: a timed call failed ({failure!r})", file=sys.stderr)
+        raise FailedOnSomeRank(repr(failure) if failure is not None else "on another rank")
     return float(dt.item())
 
 
@@ -612,7 +638,10 @@ def measure_candidate(ctx, make, calls: int, warm: int = 3):
                 pass
     ms = None
     if _agree(ctx, ok):
-        ms = round(_slowest_rank_ms(ctx, fn, calls, warm=0), 5)
+        try:
+            ms = round(_slowest_rank_ms(ctx, fn, calls, warm=0), 5)
+        except FailedOnSomeRank:  # (every rank alike: the candidate is dropped everywhere)
+            ms = None
     # Every rank has synchronised its device and met the others in a collective (_agree / the all-reduce of the timings) since
     # the candidate's last exchange: cleanups may release memory the neighbours' kernels wrote into WITHOUT another round
     # (NativeHaloExchanger.close(collective=False)) -- and a rank on which the candidate could not even be built, which has
@@ -701,6 +730,8 @@ def run_calibration(candidates, key_of, measure, budget, table, stats, skip=None
         if not budget.more():
             stats["skipped_for_time"] += 1
             continue
+        if os.environ.get("GT4MI_BENCH_VERBOSE") == "1":
+            print(f"bench.py: calibrating {key}", file=sys.stderr, flush=True)
         ms = measure(cand)
         stats["run"] += 1
         if ms is None:
@@ -892,7 +923,10 @@ def _native_comm(ctx, selfloop: bool):
     dog.arm(180, "native RCCL communicator (ncclCommInitRank)")
     ok, comm, info = 1, None, None
     try:
-        comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
+        if ctx.get("one_device"):  # (no RCCL between ranks that share a device: the direct transport only)
+            comm = NativeComm(rank=ctx["rank"], world_size=ctx["world"], rccl=False)
+        else:
+            comm = NativeComm() if not selfloop else NativeComm(rank=0, world_size=1)
         info = comm.info()
     except Exception as ex:
         ok = 0
@@ -1007,7 +1041,10 @@ def _setup_distributed_laplacian(args, ctx):
         ok = 1
         try:
             ppairs = _device_fields(pdec.local_shape, n_pairs=2, seed=1337 + rank, origin=pdec.origin)
-            pex = [NativeHaloExchanger(pdec, np.float64, comm) for _ in ppairs]
+            pex = [NativeHaloExchanger(pdec, np.float64, comm).tune(direct_timeout_ms=DIRECT_TIMEOUT_MS) for _ in ppairs]
+            if "rccl" not in transports:  # (GT4MI_BENCH_TRANSPORTS=direct, GT4MI_BENCH_ONE_DEVICE: no send/recv at all)
+                for ex in pex:
+                    ex.use_direct_transport()
             pfrozen = lap.freeze(origin={"inp": pdec.origin, "out": pdec.origin}, domain=pdec.local_domain)
 
             def pstep(i):
@@ -1070,7 +1107,7 @@ def _setup_distributed_laplacian(args, ctx):
                 return measure_candidate(ctx, make, 24)
 
             def canary_of_the_direct_transport():
-                if not distributed:  # (the self-loop: every peer is this process itself)
+                if not distributed or ctx.get("one_device"):  # (the self-loop: every peer is this process itself; the rehearsal on one device IS a canary)
                     return None
                 good = direct_canary(ctx)  # before THIS process maps another device's memory: a child process per rank tries it
                 dog.arm(direct_seconds + 600, "calibration of the direct transport")
@@ -1088,7 +1125,7 @@ def _setup_distributed_laplacian(args, ctx):
         else:
             calibration = table
             grid, single_phase, schedule, wg_per_cu, halo_transport = lap_candidate_of(min(table, key=table.get))
-    elif transport == "native" and "direct" in transports and distributed:
+    elif transport == "native" and "direct" in transports and distributed and not ctx.get("one_device"):
         canary = direct_canary(ctx)
         if not canary:
             transports = tuple(t for t in transports if t != "direct") or ("rccl",)
@@ -1323,7 +1360,9 @@ def _setup_hdiff2048(args, ctx):
                 single = parts[1] == "single"
                 chk = form_check()
                 if parts[0] == "sequential":
-                    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single)
+                    ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(direct_timeout_ms=DIRECT_TIMEOUT_MS)
+                    if "rccl" not in hd_transports:  # (GT4MI_BENCH_TRANSPORTS=direct, GT4MI_BENCH_ONE_DEVICE)
+                        ex.use_direct_transport()
                     probe_fields = {"in_field": chk.probe, "out_field": chk.out, "coeff": fields["coeff"]}
                     probe_apply = lambda: sequential_apply(hd, dec, origin, probe_fields, {"in_field": ex})  # noqa: E731
                     fn = lambda: sequential_apply(hd, dec, origin, fields, {"in_field": ex})  # noqa: E731
@@ -1424,7 +1463,7 @@ def _setup_hdiff2048(args, ctx):
                     if best_rccl() is not None:
                         run_calibration(wanted(refine(best_rccl())), str, measure, budget, timings, stats, dropped, drop)
                     if "direct" in hd_transports:
-                        if distributed:
+                        if distributed and not ctx.get("one_device"):
                             canary = direct_canary(ctx)  # (see _setup_distributed_laplacian)
                             dog.arm(direct_seconds + 600, "calibration of the direct transport")
                         if canary is False:
@@ -1585,18 +1624,38 @@ def main() -> None:
     _ACTIVE["dog"] = dog
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # GT4MI_BENCH_ONE_DEVICE=1 (rehearsals only, never a measurement): the N ranks of `torchrun --nproc-per-node N` all on device 0
+    # -- RCCL refuses that, so the process group is gloo, the native communicator has no RCCL behind it and the faces travel through
+    # the direct transport only (hipIpc between the processes).  What it is for: the N > 1 control flow of this program -- every
+    # collective, the budgeted calibration, the agreement on failures, the keys of the line -- with N REAL ranks before a node
+    # with N devices ever runs it.  The times it prints are those of N processes sharing one device.
+    one_device = os.environ.get("GT4MI_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local_rank = 0
+        os.environ["GT4MI_BENCH_TRANSPORTS"] = "direct"
+        # N kernels that wait for each other share ONE device's wave slots: the units of a one-launch step that wait for a face
+        # hold theirs, and with shares of 512 levels three ranks that run a kernel ahead of the fourth fill every slot of the chip
+        # with waiting units -- the fourth never gets to push (seen at N = 4 on the 4 x 1 grid: a resource deadlock that a device
+        # per rank cannot have).  A slab of 32 levels keeps all ranks' units together below the chip's 1 280 workgroup slots.
+        global GRID
+        GRID = (GRID[0], GRID[1], int(os.environ.get("GT4MI_BENCH_ONE_DEVICE_LEVELS", "32")))
     torch.cuda.set_device(local_rank)
     # GT4MI_BENCH_FORCE_DISTRIBUTED=1: take the N > 1 code path with a world of ONE rank (process group, collectives,
     # communicator through the broadcast, calibration, line keys) -- the rehearsal a 1-GPU box allows of everything in that
     # path except a message to another device (scripts / tests only; never the headline)
     distributed = world > 1 or os.environ.get("GT4MI_BENCH_FORCE_DISTRIBUTED", "0") == "1"
-    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "distributed": distributed, "dog": dog}
+    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "distributed": distributed, "dog": dog, "one_device": one_device}
+    if one_device:
+        ctx["collective_device"] = "cpu"
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dog.arm(300, "torch.distributed rendezvous (init_process_group)")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
+        if one_device:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=240))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=240))
         ctx["dist"] = dist
         dog.arm(180, "first collective (barrier)")
         dist.barrier()
@@ -1637,7 +1696,7 @@ def main() -> None:
         barrier()
         elapsed = time.perf_counter() - t0
         if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.get("collective_device", "cuda"))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         # dominant kernel: launch durations from HIP events on the launch stream (>= 50 launches when --steps allows)

@@ -230,3 +230,37 @@ def test_a_failed_canary_keeps_the_calibration_on_rccl(tmp_path):
     assert all(k.endswith("_rccl") for k in got[0]["measured"]) and got[0]["keys"]["calibration_candidates_skipped_for_time"] == 0
     # with time to spare every RCCL candidate of the order ran: both grids, both tables, the throttles on the best grid
     assert {k.split("_")[0] for k in got[0]["measured"]} == {"1x2", "2x1"} and any("_wg4_" in k for k in got[0]["measured"])
+
+
+def _timed_call_fails_on_one_rank(rank: int, world: int, tmpdir: str):
+    import torch.distributed as dist
+
+    ctx = {"world": world, "rank": rank, "distributed": True, "dist": dist, "device": "cpu"}
+    calls = {"n": 0}
+
+    def fn():  # fails on rank 1 only, in the middle of the timed loop
+        calls["n"] += 1
+        if rank == 1 and calls["n"] == 4:
+            raise RuntimeError("a wait for a neighbour ran out of time")
+
+    raised = None
+    try:
+        bench._slowest_rank_ms(ctx, fn, calls=6, warm=1)
+    except bench.FailedOnSomeRank as ex:
+        raised = str(ex)
+    still_in_step = bench._agree(ctx, 1)  # the next collective finds every rank in the same place
+    dropped = bench.measure_candidate(ctx, (lambda: (fn, (lambda: None))), 4, warm=0)  # (rank 1's callable has failed once; now it works)
+    return {"raised": raised, "still_in_step": still_in_step, "calls": calls["n"], "dropped": dropped}
+
+
+@pytest.mark.multiprocess
+def test_a_timed_call_that_fails_on_one_rank_fails_on_every_rank_together(tmp_path):
+    """Found by the rehearsal of `bench.py` with real ranks on one device: the direct transport fails hard, so a timed apply can
+    raise on the ranks that waited for a neighbour and not on the others -- which must not leave the ranks in different
+    collectives.  Every rank raises `FailedOnSomeRank` after the same barrier and reductions; the next collective is in step."""
+    from mp_util import run_ranks
+
+    got = run_ranks(_timed_call_fails_on_one_rank, 2, tmp_path)
+    assert got[0]["raised"] == "on another rank" and "ran out of time" in got[1]["raised"]
+    assert got[0]["still_in_step"] == got[1]["still_in_step"] == 1
+    assert got[0]["calls"] >= 7 and got[1]["calls"] >= 4 and got[0]["dropped"] is not None and got[0]["dropped"] == got[1]["dropped"]

@@ -1340,6 +1340,52 @@ def test_eight_processes_on_one_gpu_exchange_faces_on_the_grids_of_an_eight_gpu_
 
 
 @pytest.mark.multiprocess
+@pytest.mark.parametrize("workload,ranks", [("lap512", 8), ("lap512", 4), ("hdiff2048", 8)])
+@_second_chance
+def test_bench_n_gpu_code_path_with_real_ranks_on_one_device(workload, ranks, tmp_path):
+    """`bench.py` exactly as the driver launches it for N > 1 -- `torch.distributed.run --nproc-per-node N bench.py --gpus N` --
+    with N REAL ranks, all on the one device of the box (GT4MI_BENCH_ONE_DEVICE=1: the process group is gloo, the faces travel
+    over the direct transport between the processes; RCCL refuses ranks that share a device).  A rehearsal of the control flow,
+    never a measurement: every collective of the program with more than one participant, the provisional sequential form, the
+    budgeted best-first calibration over every process grid of N ranks with the agreement on failures, the self-check of every
+    form on every rank, the headline loop between barriers, the informational sections, the gathered proof -- and ONE JSON line
+    with the keys an N-GPU line carries.  (The Laplacian is cut to a slab of 32 levels here: ranks that wait for each other share
+    the device's wave slots, see bench.py.)"""
+    import json
+    import os
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, GT4MI_BENCH_ONE_DEVICE="1", GT4MI_BENCH_CALIBRATION_SECONDS="20", GT4MI_BENCH_DIRECT_CALIBRATION_SECONDS="30",
+               GT4MI_BENCH_INFORMATIONAL_SECONDS="10", GT4MI_BENCH_DIRECT_TIMEOUT_MS="60000")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+                           "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", str(ranks), "--steps", "10", "--warmup",
+                           "2", "--workload", workload], env=env, capture_output=True, text=True, timeout=1200, cwd=str(root))
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]  # ONE JSON line, from rank 0
+    line = json.loads(lines[0])
+    config = line["config"]
+    assert line["n_gpus"] == ranks and line["value"] > 0 and line["steps"] == 10 and "provisional" not in line and "deadline_exceeded" not in line
+    assert line["rccl_nranks"] == ranks and line["rank_devices"] == [[r, 0] for r in range(ranks)] and line["transport_fallback"] is False
+    assert config["transport"] == "native" and config["verified"]["headline_form_correct_on_every_rank"] is True
+    table = config["calibration_ms_per_apply"]
+    assert table and all(key.endswith("_direct") for key in table) and line["direct_best_ms_per_apply"] == min(table.values())
+    assert line["rccl_best_ms_per_apply"] is None and line["calibration_candidates_run"] >= len(table)
+    if workload == "lap512":
+        grids = {key.split("_")[0] for key in table}  # every process grid of N ranks took part (budget permitting: at least two)
+        assert len(grids) >= 2 and f"1x{ranks}" in grids and config["decomposition"] in grids
+        assert config["halo_transport"].startswith("direct")
+    assert "NATIVE RCCL TRANSPORT UNAVAILABLE" not in proc.stderr
+
+
+@pytest.mark.multiprocess
 @_second_chance
 def test_the_canary_of_bench_with_eight_ranks_on_one_device(tmp_path):
     """What `bench.py` starts on every rank of an N-GPU run before it trusts the direct transport (`direct_canary`): the

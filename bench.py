@@ -512,6 +512,9 @@ def cpu_baseline_child(seconds_budget: float) -> None:
         "gb_per_s": round(med * BYTES_PER_LUP, 2),
         "batch_glups_min_max": [round(min(rates), 3), round(max(rates), 3)],
         "spread_pct": round(100.0 * (max(rates) - min(rates)) / med, 1),
+        # (the host is shared: a neighbour's burst shows in a few batches; the value is the MEDIAN batch, and the spread of the
+        # middle 80 % of the batches says how stable that is)
+        "spread_p10_p90_pct": round(100.0 * (sorted(rates)[int(0.9 * (len(rates) - 1))] - sorted(rates)[int(0.1 * (len(rates) - 1))]) / med, 1),
         "host": host_model(),
         "numpy_single_thread": numpy_line,
     }))

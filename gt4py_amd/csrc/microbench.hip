@@ -3,6 +3,7 @@
 // Also self-checks: DPP wave shifts, J-march kernels against the any-stride kernels (bitwise).
 //
 //   microbench [section ...]     sections: dpp copy lap hdiff tridiag (default: all)
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1014,6 +1015,30 @@ int main(int argc, char** argv) {
             for (int rep = 0; rep < 3; ++rep) {
                 const double ms = time_ms([&](int) { lap5_launch_variant<double, double, 0>(in.cview(), out.view(), d, 0); }, 20);
                 snprintf(cfg, sizeof cfg, "512^3 library default, rows aligned to %d items (pitch %lld)", align, (long long)in.sj);
+                report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+            }
+        }
+    }
+    if (!want.empty() && on("lapnarrow")) {
+        // The 128-column share of the 4 x 2 grid (128 x 256 x 512) runs at 51 us where 512 x 64 x 512 -- the same number of points --
+        // takes 46: the row pitch (130 items padded to 160: a fifth of every DRAM page is padding) or the kernel (one wave per row
+        // strip, two edge lanes per wave)?  Rows aligned to 32 / 16 / 8 items, the launch the library would take, and 256-thread
+        // workgroups of four strips (the shape of the one-launch step).
+        for (int align : {32, 16, 8}) {
+            for (auto dims : {std::array<int, 3>{128, 256, 512}, std::array<int, 3>{512, 64, 512}, std::array<int, 3>{256, 128, 512}}) {
+                const int dI = dims[0], dJ = dims[1], dK = dims[2];
+                DevField<double> in(dI, dJ, dK, 1, 1, align, 0), out(dI, dJ, dK, 1, 1, align, 0), in2(dI, dJ, dK, 1, 1, align, 0), out2(dI, dJ, dK, 1, 1, align, 0);
+                fill(in, 1337, -1.0, 1.0);
+                fill(in2, 1338, -1.0, 1.0);
+                CK(hipMemset(out.raw, 0, out.bytes));
+                CK(hipMemset(out2.raw, 0, out2.bytes));
+                const int64_t d[3] = {dI, dJ, dK};
+                char cfg[96];
+                const double ms = time_ms([&](int i) {
+                    if (i & 1) lap5_launch_variant<double, double, 0>(in2.cview(), out2.view(), d, 0);
+                    else lap5_launch_variant<double, double, 0>(in.cview(), out.view(), d, 0);
+                }, 40);
+                snprintf(cfg, sizeof cfg, "%dx%dx%d library launch, rows aligned to %d items (pitch %lld)", dI, dJ, dK, align, (long long)in.sj);
                 report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
             }
         }

@@ -103,7 +103,11 @@ def empty(shape: Sequence[int], dtype=np.float64, *, backend: str,
     aligned_index, shape, dtype, dimensions = normalize_storage_spec(aligned_index, shape, dtype, dimensions)
     layout_map = info["layout_map"](dimensions)
     assert allocators.is_valid_layout_map(layout_map)
-    _, array = allocate(shape, layout_map, dtype, info["alignment"] * dtype.itemsize, aligned_index)
+    # (a preset may give its alignment in BYTES -- hip:mi300: one HBM sector whatever the item size --; else the reference's rule:
+    # `alignment` items of the array's dtype, interface.py:95-100)
+    alignment_bytes = info.get("alignment_bytes") or info["alignment"] * dtype.itemsize
+    alignment_bytes = -(-int(alignment_bytes) // dtype.itemsize) * dtype.itemsize
+    _, array = allocate(shape, layout_map, dtype, alignment_bytes, aligned_index)
     return array
 
 

@@ -91,8 +91,17 @@ register("numpy", _preset((0, 1, 2), alignment=1, device="cpu"))
 register("gt:cpu_kfirst", _preset((0, 1, 2), alignment=1, device="cpu"))
 register("gt:cpu_ifirst", _preset((2, 1, 0), alignment=1, device="cpu"))
 
-# The MI355X backend: I-contiguous like gt:gpu (layout_registry.py:105-112), rows padded to 32
-# items and the aligned_index column placed on a 32-item boundary (256 B for fp64, 128 B for fp32)
-# so that every lane's 16-byte vector access in the kernels is naturally aligned.
-HIP_MI300_LAYOUT = _preset((2, 1, 0), alignment=32, device="gpu")
+# The MI355X backend: I-contiguous like gt:gpu (layout_registry.py:105-112), rows padded to -- and the aligned_index column
+# placed on -- a 128-BYTE boundary, one L2 line, whatever the item size (16 fp64 / 32 fp32 items: `alignment` below is the fp64
+# figure, `alignment_bytes` what the allocator uses).  Rounds 1-3 used gt:gpu's 32 items (256 B for fp64): a row of 130 items then
+# occupies 160, and a fifth of every DRAM page of a 128-column local domain is padding.  Measured through bench.py on one box
+# (profiles/r4_row_alignment.txt), 256 -> 128 bytes: the 128 x 256 x 512 share of a 4 x 2 decomposition 51.6 -> 48.7 us, 512^3
+# +1 %, 512 x 512 x 128 +2 %, hdiff fp64 +1 %; the column kernels unchanged.  64 bytes is better still for the 16-byte-lane
+# kernels (the narrow share: 45.6 us) but rows that straddle L2 lines cost the 8-byte-lane column kernels a fifth (generated
+# vertical advection 93 -> 78 GLUPS).  GT4PY_AMD_ROW_ALIGN_BYTES overrides (256: the old preset), for A/B runs.
+import os as _os
+
+HIP_MI300_ROW_ALIGN_BYTES = int(_os.environ.get("GT4PY_AMD_ROW_ALIGN_BYTES", "128"))
+HIP_MI300_LAYOUT = _preset((2, 1, 0), alignment=max(HIP_MI300_ROW_ALIGN_BYTES // 8, 1), device="gpu")
+HIP_MI300_LAYOUT["alignment_bytes"] = HIP_MI300_ROW_ALIGN_BYTES  # type: ignore[typeddict-unknown-key]
 register("hip:mi300", HIP_MI300_LAYOUT)

@@ -39,7 +39,9 @@ def test_check_layout_matches_reference():
 
 def test_registry_contents_and_errors():
     info = gt_layout.from_name("hip:mi300")
-    assert info["device"] == "gpu" and info["alignment"] == 32
+    # rows on a 128-byte boundary -- one L2 line -- whatever the item size (round 4: gt:gpu's 32 items left a fifth of a
+    # 128-column local domain's DRAM pages to padding; profiles/r4_row_alignment.txt); `alignment` is the fp64 figure
+    assert info["device"] == "gpu" and info["alignment"] == 16 and info["alignment_bytes"] == 128
     assert info["layout_map"](("I", "J", "K")) == (2, 1, 0)  # I contiguous, like gt:gpu
     assert gt_layout.from_name("numpy")["layout_map"](("I", "J", "K")) == (0, 1, 2)
     assert gt_layout.from_name("gt:cpu_ifirst")["layout_map"](("I", "J", "K")) == (2, 1, 0)
@@ -47,6 +49,15 @@ def test_registry_contents_and_errors():
         gt_layout.from_name("no-such-layout")
     with pytest.raises(RuntimeError, match="not registered"):
         gt_storage.empty((2, 2, 2), backend="no-such-backend")
+
+
+def test_hip_mi300_rows_are_padded_to_whole_l2_lines_for_every_item_size():
+    for dtype, items in ((np.float64, 16), (np.float32, 32)):
+        a = gt_storage.empty((130, 7, 3), dtype, backend="numpy")  # (host preset: no padding at all)
+        assert a.strides[0] == 7 * 3 * np.dtype(dtype).itemsize
+        plan = allocators.plan_buffer((130, 7, 3), np.dtype(dtype), (2, 1, 0), 128, (1, 1, 0))
+        assert plan.padded_shape[0] == -(-130 // items) * items and plan.strides[1] % 128 == 0 and plan.strides[2] % 128 == 0
+        assert (plan.byte_offset(base_address=4096) + np.dtype(dtype).itemsize) % 128 == 0  # element [1, j, k] starts a line
 
 
 def test_allocation_plan_worked_example():

@@ -1001,7 +1001,7 @@ int main(int argc, char** argv) {
     if (on("copy")) section_copy();
     if (!want.empty() && on("mix")) section_mix();
     if (on("lap")) section_lap();
-    if (!want.empty() && on("lap512")) lap_suite(512, 512, 512, 0, "512^3");
+    if (!want.empty() && on("lap512")) lap_suite(512, 512, 512, getenv("MB_LAP_EXTRA_PITCH") ? atoi(getenv("MB_LAP_EXTRA_PITCH")) : 0, "512^3");  // (-16: the 128-byte rows of round 4, pitch 528)
     if (!want.empty() && on("lapalign")) {
         // row alignment of the storage preset: 32 items (256 B, the gt:gpu value) vs 16 items (128 B = one L2
         // line: the east halo of a row and the west halo of the next then share a line)

@@ -16,15 +16,16 @@
 //     ghost value from the W / E buffer too;
 //   * whatever else the plan receives (the corner boxes of a single-phase table) is copied by direct_block.
 //
-// Every unit waits for the arrival flag of each buffer it reads (one lane polls; the loads of the buffer come BEHIND the flag:
-// direct.hip.h "ordering"), counts itself out per buffer, and the last reader tells the sender that the buffer is free.  On a
+// Every unit waits for the arrival flag of each buffer it reads (the wave polls one word; the loads of the buffer come BEHIND the
+// flag: direct.hip.h "ordering"), the units of a workgroup count themselves out per buffer together, and the last readers tell the
+// sender that the buffer is free.  On a
 // plan that exchanges through RCCL the same units run behind the send/recv kernel in stream order: their flags are words that
 // are always satisfied, their signals go nowhere.
 //
 // The units run as a kernel of their own (lap5_edge_kernel: behind the send/recv kernel, or behind the interior kernel of a
-// two-stream schedule) or as the LAST workgroups of the one launch of the one-stream schedule on the direct transport
-// (lap5_step_kernel: push | interior | edge), which then start while the interior's last strips drain and find their faces
-// long arrived.  Same expression (lap5_expr) on the same values as the whole-domain kernel: bit-identical.
+// two-stream schedule) or as workgroups of the ONE launch of the one-stream schedule on the direct transport (lap5_step_kernel:
+// push | interior | edge units behind 85 % of the interior), which start while the interior's last strips drain and find their
+// faces long arrived.  Same expression (lap5_expr) on the same values as the whole-domain kernel: bit-identical.
 #pragma once
 
 #include "direct.hip.h"

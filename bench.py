@@ -545,306 +545,19 @@ def _committed_traffic(workload: str):
     return entry.get("bytes_per_launch"), f"rocprofv3 PMC, {entry.get('source')}, git {entry.get('git_sha')}"
 
 
-# ---- N > 1: the Laplacian on a decomposed 512^3 grid ----------------------------------------------------
-def _agree(ctx, ok: int) -> int:
-    """Every rank learns whether ALL ranks succeeded."""
-    if ctx["distributed"]:
-        import torch
+# ---- N > 1 -----------------------------------------------------------------------------------------------
+# Agreement between ranks, slowest-rank timing, wall-clock budgets, the best-first calibration order and the fall-back ladder of
+# the halo transport (direct -> direct-fenced -> rccl) live in gt4py_amd/distributed/calibrate.py (pure Python, torch-free at
+# import); the names stay reachable as bench.<name> for the tests and scripts that grew up with them here.
+from gt4py_amd.distributed.calibrate import (FailedOnSomeRank, WallBudget, _agree, _slowest_rank_ms, best_of, calibrate_laplacian,  # noqa: E402,F401
+                                             calibrate_transports, calibration_line_keys, calibration_seconds, direct_fenced,
+                                             direct_mode, direct_step_down, hdiff_calibration_order, ladder_line_keys,
+                                             lap_calibration_order, lap_candidate_of, lap_key, measure_candidate, run_calibration)
 
-        flag = torch.tensor([ok], dtype=torch.int32, device=ctx.get("collective_device", ctx.get("device", "cuda")))
-        ctx["dist"].all_reduce(flag, op=ctx["dist"].ReduceOp.MIN)
-        ok = int(flag.item())
-    return ok
-
-
-class FailedOnSomeRank(RuntimeError):
-    """A timed callable raised on at least one rank; every rank raises this together, after the same collectives."""
-
-
-def _slowest_rank_ms(ctx, fn, calls: int, warm: int = 3) -> float:
-    """Milliseconds per call of ``fn`` over ``calls`` calls, the slowest rank's figure on every rank.
-
-    A call that raises on SOME rank (the direct transport fails hard: a neighbour that never arrives makes the next call on the
-    plan raise -- on the ranks that waited for it, not on the others) must not leave the ranks in different collectives: every
-    rank runs the same barrier and reductions whatever happened to it, then all raise ``FailedOnSomeRank`` together.  (Found by
-    the rehearsal with real ranks, GT4MI_BENCH_ONE_DEVICE: one rank went on to the next agreement while three were still in
-    this reduction, and the run ended on its provisional line 240 s later.)"""
-    import torch
-
-    device = ctx.get("device", "cuda")
-    sync = torch.cuda.synchronize if device == "cuda" else (lambda: None)
-    failure = None
-
-    def run(n):
-        nonlocal failure
-        try:
-            for _ in range(n):
-                fn()
-            sync()
-        except Exception as ex:  # noqa: BLE001 - reported to every rank below
-            failure = failure or ex
-            try:
-                sync()
-            except Exception:  # noqa: BLE001
-                pass
-
-    run(warm)
-    if ctx["distributed"]:
-        ctx["dist"].barrier()
-    t0 = time.perf_counter()
-    if failure is None:
-        run(calls)
-    dt = torch.tensor([(time.perf_counter() - t0) / calls * 1e3], dtype=torch.float64, device=ctx.get("collective_device", device))
-    if ctx["distributed"]:
-        ctx["dist"].all_reduce(dt, op=ctx["dist"].ReduceOp.MAX)
-    if not _agree(ctx, int(failure is None)):
-        if failure is not None:
-            print(f"rank {ctx['rank']}: a timed call failed ({failure!r})", file=sys.stderr)
-        raise FailedOnSomeRank(repr(failure) if failure is not None else "on another rank")
-    return float(dt.item())
-
-
-def measure_candidate(ctx, make, calls: int, warm: int = 3):
-    """ms per call of one calibration candidate (slowest rank), or None when it cannot run on SOME rank -- then on no rank.
-
-    ``make()`` returns (callable, cleanup) or (callable, cleanup, check).  Building the candidate and its first calls happen without any collective, so a
-    rank on which they fail (an option this device / runtime refuses, a launch error) does not leave the others waiting in
-    a barrier: every rank reports, all agree, and only candidates that work everywhere are timed.  One exotic candidate that
-    fails must cost that candidate, not the native transport."""
-    import torch
-
-    fn = cleanup = None
-    ok = 1
-    try:
-        made = make()
-        fn, cleanup = made[0], made[1]
-        for _ in range(warm):
-            fn()
-        if ctx.get("device", "cuda") == "cuda":
-            torch.cuda.synchronize()
-        if len(made) > 2 and made[2] is not None:
-            # (fn, cleanup, check): check() -> (ok, what it found) runs the form once on fields whose correct outcome is known
-            # exactly (distributed.FormCheck); a form that is fast and wrong on some rank is dropped on every rank
-            good, found = made[2]()
-            ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
-            if not good:
-                ok = 0
-                ctx["forms_rejected"] = ctx.get("forms_rejected", 0) + 1
-                print(f"rank {ctx['rank']}: calibration candidate REJECTED, its results are wrong: {found}", file=sys.stderr)
-    except Exception as ex:
-        ok = 0
-        print(f"rank {ctx['rank']}: calibration candidate failed ({ex!r})", file=sys.stderr)
-        if ctx.get("device", "cuda") == "cuda":
-            try:
-                torch.cuda.synchronize()  # (whatever this rank enqueued for the candidate has left the device before the ranks meet)
-            except Exception:
-                pass
-    ms = None
-    if _agree(ctx, ok):
-        try:
-            ms = round(_slowest_rank_ms(ctx, fn, calls, warm=0), 5)
-        except FailedOnSomeRank:  # (every rank alike: the candidate is dropped everywhere)
-            ms = None
-    # Every rank has synchronised its device and met the others in a collective (_agree / the all-reduce of the timings) since
-    # the candidate's last exchange: cleanups may release memory the neighbours' kernels wrote into WITHOUT another round
-    # (NativeHaloExchanger.close(collective=False)) -- and a rank on which the candidate could not even be built, which has
-    # nothing to clean up, leaves nobody waiting for it.
-    if cleanup is not None:
-        try:
-            cleanup()
-        except Exception:
-            pass
-    return ms
-
-
-class WallBudget:
-    """A wall-clock budget that every rank reads alike: `more()` is a tiny collective (all ranks still have time, or nobody
-    goes on), so no rank ever starts a candidate that another one has already given up on."""
-
-    def __init__(self, ctx, seconds: float):
-        self.ctx, self.seconds, self.t_end, self.spent = ctx, float(seconds), time.monotonic() + float(seconds), False
-
-    def more(self) -> bool:
-        if not self.spent:
-            self.spent = not _agree(self.ctx, int(time.monotonic() < self.t_end))
-        return not self.spent
-
-
-def lap_key(cand) -> str:
-    grid, single, schedule, wg, transport = cand
-    return f"{grid[0]}x{grid[1]}_{'single' if single else 'two'}phase_{schedule}_wg{wg}_{transport}"
-
-
-def lap_candidate_of(key: str):
-    g, ph, schedule, wg, transport = key.split("_")
-    pi, pj = g.split("x")
-    return (int(pi), int(pj)), ph == "singlephase", schedule, int(wg[2:]), transport
-
-
-def lap_calibration_order(default_grid, grids, phases, transports):
-    """The calibration candidates of the decomposed Laplacian -- (grid, single_phase, schedule, interior workgroups per CU,
-    transport) -- BEST FIRST, in three stages; the wall-clock budget cuts the tail, never the head (VERDICT round 3, item 3:
-    ~208 candidates under one kill deadline meant the first real N > 1 line would have been the provisional one or a timeout).
-
-      first   the north star's form: RCCL send/recv on a second stream, on the grid `choose_process_grid` returns, the two
-              schedules that won every self-loop share ("swap", then "join"), two-phase then single-phase: an OVERLAPPED
-              RCCL headline exists after at most four candidates; then the other process grids, RCCL "swap"
-      refine(best) what is left of RCCL on the best grid and message table so far: the other schedules, then the throttles
-      direct(best) the direct transport (only after its canary), by the self-loop ranking: "inline" on the best grid, both
-              tables; "inline" on the other grids; then the two-stream schedules on the best grid."""
-    rccl, direct = "rccl" in transports, "direct" in transports
-    # (the other grids by the self-loop ranking of round 4: the fewer cuts along I -- W / E faces are strided columns, one
-    # partial-line store per row and level -- the faster the share: 1 x 8 < 2 x 4 < 4 x 2 per apply on either transport)
-    others = sorted((g for g in grids if g != default_grid), key=lambda g: g[0])
-    first = []
-    if rccl:
-        first += [(default_grid, single, schedule, 0, "rccl") for single in phases for schedule in ("swap", "join")]
-        first += [(g, single, "swap", 0, "rccl") for g in others for single in phases]
-
-    def refine(best):
-        g, single = best[0], best[1]
-        if not rccl:
-            return []
-        out = [(g, single, schedule, 0, "rccl") for schedule in ("swap", "join", "swap-packed", "chain")]
-        out += [(g, single, schedule, wg, "rccl") for wg in (4, 2) for schedule in ("swap", "join", "swap-packed", "chain")]
-        out += [(g, other, schedule, 0, "rccl") for other in phases if other != single for schedule in ("swap-packed", "chain")]
-        return out
-
-    def direct_stage(best):
-        if not direct:
-            return []
-        g = best[0] if best is not None else default_grid
-        out = [(g, single, "inline", 0, "direct") for single in phases]
-        out += [(og, single, "inline", 0, "direct") for og in sorted((x for x in grids if x != g), key=lambda x: x[0]) for single in phases]
-        out += [(g, single, schedule, 0, "direct") for schedule in ("swap", "join", "swap-packed", "chain") for single in phases]
-        return out
-
-    return first, refine, direct_stage
-
-
-def run_calibration(candidates, key_of, measure, budget, table, stats, skip=None, failed=None) -> None:
-    """Measure `candidates` in order into `table[key]` until the budget is spent (collectively); what was not started is
-    counted, not measured.  `measure(candidate)` -> ms (slowest rank) or None when the candidate failed on some rank (then
-    `failed(candidate, key)` hears of it); `skip(candidate)`: not to be tried at all (a transport that was dropped)."""
-    for cand in candidates:
-        key = key_of(cand)
-        if key in table or key in stats["failed"] or (skip is not None and skip(cand)):
-            continue
-        if not budget.more():
-            stats["skipped_for_time"] += 1
-            continue
-        if os.environ.get("GT4MI_BENCH_VERBOSE") == "1":
-            print(f"bench.py: calibrating {key}", file=sys.stderr, flush=True)
-        ms = measure(cand)
-        stats["run"] += 1
-        if ms is None:
-            stats["failed"].append(key)
-            if failed is not None:
-                failed(cand, key)
-        else:
-            table[key] = ms
-
-
-def calibrate_laplacian(ctx, default_grid, grids, phases, transports, measure, canary, rccl_seconds, direct_seconds, table, stats,
-                        pinned_schedule=None):
-    """The three stages of lap_calibration_order under their budgets, collectively: RCCL first (the default grid's "swap" / "join"
-    before anything else), what is left of RCCL on the best grid, then -- `canary()` permitting: True / None (not needed) go on,
-    False drops it -- the direct transport with a budget of its own.  Fills `table` (key -> ms per apply, slowest rank) and
-    `stats`; returns (what the canary said, the transports still in use).  `measure(candidate)` -> ms or None."""
-    first, refine, direct_stage = lap_calibration_order(default_grid, grids, phases, transports)
-
-    def wanted(cands):
-        return [c for c in cands if pinned_schedule is None or c[2] == pinned_schedule]
-
-    def dropped(cand):
-        return cand[4] == "direct" and bool(ctx.get("direct_dropped"))
-
-    def drop(cand, key):  # one form on the direct transport was wrong, timed out or could not be set up: the rest of the
-        if cand[4] == "direct":  # calibration stays on RCCL, on every rank alike
-            ctx["direct_dropped"] = key
-
-    budget = WallBudget(ctx, rccl_seconds)
-    run_calibration(wanted(first), lap_key, measure, budget, table, stats, dropped, drop)
-    best_key, _ = best_of(table, "rccl")
-    if best_key is not None:
-        run_calibration(wanted(refine(lap_candidate_of(best_key))), lap_key, measure, budget, table, stats, dropped, drop)
-        best_key, _ = best_of(table, "rccl")
-    verdict = None
-    if "direct" in transports:
-        verdict = canary()
-        if verdict is False:
-            transports = tuple(t for t in transports if t != "direct") or ("rccl",)
-        else:
-            budget = WallBudget(ctx, direct_seconds)
-            run_calibration(wanted(direct_stage(lap_candidate_of(best_key) if best_key else None)), lap_key, measure, budget, table,
-                            stats, dropped, drop)
-    return verdict, transports
-
-
-def best_of(table, transport: str):
-    """(key, ms) of the fastest measured candidate of one transport (keys end in _rccl / _direct), or (None, None)."""
-    mine = {k: v for k, v in table.items() if k.endswith("_" + transport)}
-    if not mine:
-        return None, None
-    key = min(mine, key=mine.get)
-    return key, mine[key]
-
-
-def calibration_seconds(name: str, fallback: float) -> float:
-    return float(os.environ.get(name, fallback))
-
-
-def hdiff_calibration_order(schedules, edges, transports):
-    """The apply forms of the decomposed horizontal diffusion, BEST FIRST (see lap_calibration_order): names
-    `fused_<table>_<schedule>_wg<n>_edge<w>[_direct]` and `sequential_<table>`.
-
-      first        RCCL, what gt4mi_dist_hdiff_* does by default and won the self-loop rehearsals: "chain" (then "join"), the
-                   interior kernel at 2 of 4 workgroups per CU, 16 edge columns, two-phase then single-phase
-      refine(best) RCCL on the best message table: the other throttles and edge widths, the one-stream form, the plain sequence
-      direct(best) the direct transport after its canary, by the self-loop ranking of rounds 3-4: "chain" with the interior at 3, then
-                   2 of 4 workgroups per CU (0.194-0.204 ms for a 0.179 ms kernel), then the one-stream form (0.21-0.22)"""
-    rccl, direct = "rccl" in transports, "direct" in transports
-    tables = ("two_phase", "single_phase")
-    two_stream = [sc for sc in ("chain", "join", "swap", "swap-packed") if sc in schedules]
-    first = [f"fused_{t}_{sc}_wg2_edge16" for t in tables for sc in two_stream[:2]] if rccl else []
-
-    def table_of(name):
-        return "single_phase" if "single_phase" in name else "two_phase"
-
-    def refine(best):
-        if not rccl:
-            return []
-        t = table_of(best)
-        out = [f"fused_{t}_{sc}_wg{wg}_edge{e}" for wg in (2, 3, 0) for e in edges for sc in two_stream]
-        if "inline" in schedules:
-            out += [f"fused_{t}_inline_wg0_edge{e}" for e in edges]
-        return out + [f"sequential_{t}"] + [f"sequential_{o}" for o in tables if o != t]
-
-    def direct_stage(best):
-        if not direct:
-            return []
-        t = table_of(best) if best else "two_phase"
-        order = [t] + [o for o in tables if o != t]
-        out = [f"fused_{o}_{two_stream[0]}_wg{wg}_edge16_direct" for wg in (3, 2) for o in order] if two_stream else []
-        if "inline" in schedules:
-            out += [f"fused_{t}_inline_wg0_edge{e}_direct" for e in (32, 16) if e in edges]
-        out += [f"fused_{o}_{sc}_wg2_edge16_direct" for sc in two_stream[1:2] for o in order]
-        return out
-
-    return first, refine, direct_stage
-
-
-def calibration_line_keys(table, stats) -> dict:
-    """Top-level keys of a calibrated N > 1 line: what the SPECIFIED design (RCCL send/recv on a second stream) achieves next to
-    the direct transport, whichever of the two the headline took, and how much of the calibration the budget allowed."""
-    direct = {k: v for k, v in table.items() if k.endswith("_direct")}
-    rccl = {k: v for k, v in table.items() if not k.endswith("_direct")}  # (Laplacian keys end in _rccl, hdiff's carry no suffix)
-    rccl_key = min(rccl, key=rccl.get) if rccl else None
-    direct_key = min(direct, key=direct.get) if direct else None
-    rccl_ms, direct_ms = rccl.get(rccl_key), direct.get(direct_key)
-    return {"rccl_best_ms_per_apply": rccl_ms, "rccl_best_form": rccl_key, "direct_best_ms_per_apply": direct_ms,
-            "direct_best_form": direct_key, "calibration_candidates_run": stats["run"],
-            "calibration_candidates_skipped_for_time": stats["skipped_for_time"], "calibration_candidates_failed": list(stats["failed"])}
+# how many consecutive epochs of the probe every form of the distributed apply is checked on before it is timed (the last one next
+# to an HBM-saturating background: selfcheck.FormCheck.check), and how many the canary of the direct transport runs under load
+CHECK_EPOCHS = int(os.environ.get("GT4MI_BENCH_CHECK_EPOCHS", "3"))
+CANARY_STRESS_EPOCHS = int(os.environ.get("GT4MI_BENCH_CANARY_EPOCHS", "200"))
 
 
 def gather_rank_proof(ctx, info) -> dict:
@@ -880,39 +593,79 @@ def _test_hang(dog, phase: str) -> None:
 def direct_canary(ctx) -> bool:
     """Before THIS process maps another device's memory and lets its kernels store into it: a child process per rank does exactly
     that on a small problem -- `python -m gt4py_amd.distributed --transport direct`, the self-check of the direct transport (no RCCL,
-    its own gloo group, met through a file) -- and all ranks agree on the outcome.  A memory fault or a hang between real devices
-    then ends a child, not the run: the calibration stays on RCCL."""
+    its own gloo group) -- and all ranks agree on the outcome.  A memory fault or a hang between real devices then ends a child, not
+    the run.  Every form runs CHECK_EPOCHS consecutive epochs of the probe and the one-stream forms CANARY_STRESS_EPOCHS more, all
+    next to an HBM-saturating background with the ranks launching together (selfcheck.py: every round is sensitive to a receive
+    buffer read too early).  DOWN THE LADDER: should the default mode fail on any rank, the children run once more in the fenced
+    mode; if that passes the calibration uses the direct transport FENCED (ctx["direct_mode"]), else it stays on RCCL."""
     dog, rank, world = ctx["dog"], ctx["rank"], ctx["world"]
-    dog.arm(300, "canary of the direct transport (child processes)")
+    import shutil
+    import socket
     import tempfile
 
-    where = [None]
-    if rank == 0:  # the children's own rendezvous: a file in a fresh directory (every rank of ONE node sees it) -- not a port
-        where[0] = os.path.join(tempfile.mkdtemp(prefix="gt4mi_canary_"), "rendezvous")
-    if ctx["distributed"]:
-        ctx["dist"].broadcast_object_list(where, src=0)
-    env = dict(os.environ, GT4MI_RENDEZVOUS_FILE=str(where[0]), RANK=str(rank), WORLD_SIZE=str(world),
-               LOCAL_RANK=str(ctx["local_rank"]), PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    # (the launcher's own variables would send the child to the launcher's store -- TORCHELASTIC_USE_AGENT_STORE)
-    for key in [k for k in env if k.startswith("TORCHELASTIC_")] + ["GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
-                                                                    "GT4MI_BENCH_TEST_HANG"]:
-        env.pop(key, None)
-    ok = 0
-    try:
-        if os.environ.get("GT4MI_BENCH_TEST_CANARY_FAILS") == "1":  # (tests: what a child that crashed looks like from here)
-            raise RuntimeError("simulated for the tests")
-        proc = subprocess.run([sys.executable, "-m", "gt4py_amd.distributed", "--transport", "direct", "--domain", "256", "192", "8"],
-                              env=env, capture_output=True, text=True, timeout=150, cwd=str(ROOT))
-        ok = int(proc.returncode == 0)
-        if not ok:
-            print(f"rank {rank}: the canary of the direct transport ended with status {proc.returncode}: "
-                  f"{(proc.stdout + proc.stderr)[-600:]}", file=sys.stderr)
-    except Exception as ex:  # (a timeout: the child is killed)
-        print(f"rank {rank}: the canary of the direct transport failed ({ex!r})", file=sys.stderr)
-    good = bool(_agree(ctx, ok))
-    if not good and rank == 0:
-        print("bench.py: the direct halo transport did not pass its canary on every rank: the calibration stays on RCCL", file=sys.stderr)
-    return good
+    def children(fenced: bool, attempt: int) -> bool:
+        dog.arm(420, f"canary of the direct transport (child processes{', fenced' if fenced else ''})")
+        # the children's own rendezvous.  One node: a file in a fresh directory (no port that was free a moment ago, no second
+        # listener on the launcher's address).  Ranks on several hosts cannot share a file in /tmp: then a TCP store on rank 0's
+        # address, on a port rank 0 found free.
+        hosts = [socket.gethostname()]
+        if ctx["distributed"]:
+            hosts = [None] * world
+            ctx["dist"].all_gather_object(hosts, socket.gethostname())
+        one_node = len(set(hosts)) == 1
+        where, tmpdir = [None], None
+        if rank == 0:
+            if one_node:
+                tmpdir = tempfile.mkdtemp(prefix="gt4mi_canary_")
+                where[0] = ("file", os.path.join(tmpdir, "rendezvous"))
+            else:
+                with socket.socket() as sock:
+                    sock.bind(("", 0))
+                    where[0] = ("tcp", os.environ.get("MASTER_ADDR", hosts[0]), sock.getsockname()[1])
+        if ctx["distributed"]:
+            ctx["dist"].broadcast_object_list(where, src=0)
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(ctx["local_rank"]),
+                   PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.pop("GT4MI_RENDEZVOUS_FILE", None)
+        if where[0][0] == "file":
+            env["GT4MI_RENDEZVOUS_FILE"] = str(where[0][1])
+        else:
+            env["MASTER_ADDR"], env["MASTER_PORT"] = str(where[0][1]), str(where[0][2])
+        # (the launcher's own variables would send the child to the launcher's store -- TORCHELASTIC_USE_AGENT_STORE)
+        for key in [k for k in env if k.startswith("TORCHELASTIC_")] + ["GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
+                                                                        "GT4MI_BENCH_TEST_HANG"]:
+            env.pop(key, None)
+        ok = 0
+        try:
+            fails = os.environ.get("GT4MI_BENCH_TEST_CANARY_FAILS", "")  # (tests: "1" = both modes fail, "unfenced" = only the default mode)
+            if fails == "1" or (fails == "unfenced" and not fenced):
+                raise RuntimeError("simulated for the tests")
+            cmd = [sys.executable, "-m", "gt4py_amd.distributed", "--transport", "direct", "--domain", "256", "192", "8",
+                   "--epochs", str(CHECK_EPOCHS), "--stress-epochs", str(CANARY_STRESS_EPOCHS)] + (["--fenced"] if fenced else [])
+            proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+            ok = int(proc.returncode == 0)
+            if not ok:
+                print(f"rank {rank}: the canary of the direct transport{' (fenced)' if fenced else ''} ended with status "
+                      f"{proc.returncode}: {(proc.stdout + proc.stderr)[-900:]}", file=sys.stderr)
+        except Exception as ex:  # (a timeout: the child is killed)
+            print(f"rank {rank}: the canary of the direct transport{' (fenced)' if fenced else ''} failed ({ex!r})", file=sys.stderr)
+        good = bool(_agree(ctx, ok))  # (every child has ended on every rank: the directory is no longer needed)
+        if tmpdir is not None:
+            shutil.rmtree(tmpdir, ignore_errors=True)
+        return good
+
+    if children(fenced=direct_fenced(ctx), attempt=0):
+        return True
+    if not direct_fenced(ctx):
+        direct_step_down(ctx, "canary", "the self-check of the direct transport failed in child processes on some rank")
+        ctx.pop("direct_retry", None)  # (nothing has been calibrated on the transport yet)
+        if children(fenced=True, attempt=1):
+            return True
+    direct_step_down(ctx, "canary (fenced)", "the self-check of the fenced direct transport failed in child processes on some rank")
+    if rank == 0:
+        print("bench.py: the direct halo transport did not pass its canary on every rank, with or without fences: the calibration "
+              "stays on RCCL", file=sys.stderr)
+    return False
 
 
 def _native_comm(ctx, selfloop: bool):
@@ -998,7 +751,7 @@ def _setup_distributed_laplacian(args, ctx):
                for _ in cpairs]
         if cand_transport == "direct":  # peer stores from the pack kernel instead of RCCL send/recv (collective; raises on EVERY rank
             for ex in cex:              # when it is not available on some rank: measure_candidate then drops the candidate)
-                ex.use_direct_transport()
+                ex.use_direct_transport().tune(direct_fenced=direct_fenced(ctx))  # (the ladder's current rung: calibrate.py)
         bound = [ex.make_dist_lap5(inp, out, cdec.origin, cdec.origin) for ex, (inp, out) in zip(cex, cpairs)]
         state = {"i": 0}
 
@@ -1009,11 +762,14 @@ def _setup_distributed_laplacian(args, ctx):
         chk = form_check(cdec)
         probe_apply = cex[0].make_dist_lap5(chk.probe, chk.out, cdec.origin, cdec.origin)
 
-        def check():
-            chk.reset()
+        def probe_run():
             probe_apply()
             cex[0].end()
-            good, found = chk.verdict()
+
+        def check():
+            # CHECK_EPOCHS consecutive epochs (each round's correct values differ from the last round's in every cell), the last
+            # one next to an HBM-saturating background
+            good, found = chk.check(probe_run, CHECK_EPOCHS, 1)
             if cand_transport == "direct" and cex[0].direct_status()["timed_out"]:
                 good, found = False, "a wait of the direct transport ran out of time; " + found
             return good, found
@@ -1047,7 +803,7 @@ def _setup_distributed_laplacian(args, ctx):
             pex = [NativeHaloExchanger(pdec, np.float64, comm).tune(direct_timeout_ms=DIRECT_TIMEOUT_MS) for _ in ppairs]
             if "rccl" not in transports:  # (GT4MI_BENCH_TRANSPORTS=direct, GT4MI_BENCH_ONE_DEVICE: no send/recv at all)
                 for ex in pex:
-                    ex.use_direct_transport()
+                    ex.use_direct_transport().tune(direct_fenced=direct_fenced(ctx))
             pfrozen = lap.freeze(origin={"inp": pdec.origin, "out": pdec.origin}, domain=pdec.local_domain)
 
             def pstep(i):
@@ -1067,10 +823,12 @@ def _setup_distributed_laplacian(args, ctx):
                        "message_table": "two-phase (I faces, then J faces with the fresh I-halo columns)", "transport": "native",
                        "mode": "apply", "selfloop": bool(selfloop), "exchange_overlapped_with_interior": False}
             chk = form_check(pdec)  # first of all: is what it computes right?  (fields whose correct outcome is known exactly)
-            chk.reset()
-            pex[0].exchange(chk.probe)
-            pfrozen(inp=chk.probe, out=chk.out)
-            good, found = chk.verdict()
+
+            def provisional_run():
+                pex[0].exchange(chk.probe)
+                pfrozen(inp=chk.probe, out=chk.out)
+
+            good, found = chk.check(provisional_run, CHECK_EPOCHS, 1)
             ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
             if not good:
                 raise RuntimeError("wrong results: " + found)
@@ -1113,7 +871,7 @@ def _setup_distributed_laplacian(args, ctx):
                 if not distributed or ctx.get("one_device"):  # (the self-loop: every peer is this process itself; the rehearsal on one device IS a canary)
                     return None
                 good = direct_canary(ctx)  # before THIS process maps another device's memory: a child process per rank tries it
-                dog.arm(direct_seconds + 600, "calibration of the direct transport")
+                dog.arm(2 * direct_seconds + 600, "calibration of the direct transport")  # (the stage may run twice: unfenced, fenced)
                 return good
 
             canary, transports = calibrate_laplacian(ctx, grid, grids, phases, transports, measure, canary_of_the_direct_transport,
@@ -1175,9 +933,8 @@ def _setup_distributed_laplacian(args, ctx):
             overlapped_apply(lap, dec, origin, {"inp": inp, "out": out}, {"inp": exchangers[i % len(pairs)]})
 
         chk = form_check(dec)
-        chk.reset()
-        overlapped_apply(lap, dec, origin, {"inp": chk.probe, "out": chk.out}, {"inp": exchangers[0]})
-        headline_verdict = chk.verdict()
+        headline_verdict = chk.check((lambda: overlapped_apply(lap, dec, origin, {"inp": chk.probe, "out": chk.out}, {"inp": exchangers[0]})),
+                                     CHECK_EPOCHS, 1)
         ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
 
     verified = None
@@ -1187,10 +944,14 @@ def _setup_distributed_laplacian(args, ctx):
             print(f"rank {rank}: THE TIMED FORM GIVES WRONG RESULTS on at least one rank (here: {headline_verdict[1]})", file=sys.stderr)
         verified = {"headline_form_correct_on_every_rank": everywhere, "forms_checked": ctx.get("forms_checked", 0),
                     "forms_rejected": ctx.get("forms_rejected", 0), "ghost_cells_checked_on_rank_0": form_check(dec).ghost_cells_to_fill,
-                    "how": "every form is run once on a field whose own points hold an exact function of the GLOBAL coordinates and "
-                           "whose ghost cells hold a sentinel: afterwards every cell must equal that function (or still the sentinel "
-                           "beyond a physical boundary) and the result must equal the local kernel applied to the exactly known input, "
-                           "bit for bit, on every rank (gt4py_amd/distributed/selfcheck.py); wrong forms are dropped from the calibration"}
+                    "epochs_per_form": CHECK_EPOCHS, "rounds_checked_on_rank_0": sum(c.rounds_checked for c in checks.values()),
+                    "how": "every form is run on a field whose own points hold an exact function of the GLOBAL coordinates + 65536 x "
+                           "EPOCH and whose ghost cells hold a sentinel, for epochs_per_form consecutive epochs (so that what the "
+                           "previous round left in any receive buffer is wrong in every cell), the last one next to an HBM-saturating "
+                           "background: afterwards every cell must equal that function (or still the sentinel beyond a physical "
+                           "boundary) and the result must equal the local kernel applied to the exactly known input, bit for bit, on "
+                           "every rank (gt4py_amd/distributed/selfcheck.py); wrong forms are dropped from the calibration, a wrong "
+                           "form of the direct transport moves every rank down the ladder direct -> direct-fenced -> rccl"}
 
     def kernel_step(i):  # the local kernel alone, for the per-GPU roofline figure
         inp, out = pairs[i % len(pairs)]
@@ -1249,7 +1010,7 @@ def _setup_distributed_laplacian(args, ctx):
                     cb.tensor.copy_(ca.tensor)
                     cex = NativeHaloExchanger(cdec, np.float64, comm, single_phase=single_phase)
                     if cand_transport == "direct":
-                        cex.use_direct_transport()
+                        cex.use_direct_transport().tune(direct_fenced=direct_fenced(ctx))
                     if stepper.startswith("skewed"):
                         cex.tune("chain" if "chain" in stepper else "join", 4 if stepper.endswith("wg4") else 0)
                         fn = cex.make_time_skewed_lap5(ca, cb, cdec.origin)
@@ -1296,10 +1057,10 @@ def _setup_distributed_laplacian(args, ctx):
               "halo_transport": (halo_transport + (" (peer stores from the pack kernel, flags in the receiver's memory; no send/recv kernel)"
                                                    if halo_transport == "direct" else " (send/recv)")) if transport == "native" else "torch",
               "calibration_ms_per_apply": calibration, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped"),
-              "direct_transport_canary": canary}
+              "direct_transport_canary": canary, **ladder_line_keys(ctx)}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
               "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback,
-              "calibration": calibration_line_keys(calibration, stats) if calibration is not None else None}
+              "calibration": calibration_line_keys(calibration, stats, ctx) if calibration is not None else None}
     return step, kernel_step, dec.local_domain, config, extras
 
 
@@ -1365,7 +1126,7 @@ def _setup_hdiff2048(args, ctx):
                 if parts[0] == "sequential":
                     ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune(direct_timeout_ms=DIRECT_TIMEOUT_MS)
                     if "rccl" not in hd_transports:  # (GT4MI_BENCH_TRANSPORTS=direct, GT4MI_BENCH_ONE_DEVICE)
-                        ex.use_direct_transport()
+                        ex.use_direct_transport().tune(direct_fenced=direct_fenced(ctx))
                     probe_fields = {"in_field": chk.probe, "out_field": chk.out, "coeff": fields["coeff"]}
                     probe_apply = lambda: sequential_apply(hd, dec, origin, probe_fields, {"in_field": ex})  # noqa: E731
                     fn = lambda: sequential_apply(hd, dec, origin, fields, {"in_field": ex})  # noqa: E731
@@ -1374,15 +1135,17 @@ def _setup_hdiff2048(args, ctx):
                                                                                               edge_columns=int(parts[5][4:]),
                                                                                               direct_timeout_ms=DIRECT_TIMEOUT_MS)
                     if parts[6:] == ["direct"]:  # peer stores from the pack kernel instead of RCCL send/recv (collective; raises on
-                        ex.use_direct_transport()  # EVERY rank when some rank cannot: measure_candidate then drops the form)
+                        # EVERY rank when some rank cannot: measure_candidate then drops the form); the ladder's current rung
+                        ex.use_direct_transport().tune(direct_fenced=direct_fenced(ctx))
                     probe_apply = ex.make_dist_hdiff(chk.probe, chk.out, fields["coeff"], dec.origin, flags)
                     fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
 
-                def check():
-                    chk.reset()
+                def probe_run():
                     probe_apply()
                     ex.end()
-                    good, found = chk.verdict()
+
+                def check():
+                    good, found = chk.check(probe_run, CHECK_EPOCHS, 1)  # (consecutive epochs, the last one under HBM load)
                     if parts[6:] == ["direct"] and ex.direct_status()["timed_out"]:
                         good, found = False, "a wait of the direct transport ran out of time; " + found
                     return good, found
@@ -1450,30 +1213,20 @@ def _setup_hdiff2048(args, ctx):
                     def wanted(names):
                         return [n for n in names if pinned is None or pinned == n]
 
-                    def dropped(name):
-                        return name.endswith("_direct") and bool(ctx.get("direct_dropped"))
-
-                    def drop(name, key):
-                        if name.endswith("_direct"):
-                            ctx["direct_dropped"] = name
-
                     def best_rccl():
                         mine = {k: v for k, v in timings.items() if not k.endswith("_direct")}
                         return min(mine, key=mine.get) if mine else None
 
-                    budget = WallBudget(ctx, rccl_seconds)
-                    run_calibration(wanted(first), str, measure, budget, timings, stats, dropped, drop)
-                    if best_rccl() is not None:
-                        run_calibration(wanted(refine(best_rccl())), str, measure, budget, timings, stats, dropped, drop)
-                    if "direct" in hd_transports:
-                        if distributed and not ctx.get("one_device"):
-                            canary = direct_canary(ctx)  # (see _setup_distributed_laplacian)
-                            dog.arm(direct_seconds + 600, "calibration of the direct transport")
-                        if canary is False:
-                            hd_transports = tuple(t for t in hd_transports if t != "direct") or ("rccl",)
-                        else:
-                            budget = WallBudget(ctx, direct_seconds)
-                            run_calibration(wanted(direct_stage(best_rccl())), str, measure, budget, timings, stats, dropped, drop)
+                    def canary_of_the_direct_transport():
+                        if not distributed or ctx.get("one_device"):
+                            return None
+                        good = direct_canary(ctx)  # (see _setup_distributed_laplacian)
+                        dog.arm(2 * direct_seconds + 600, "calibration of the direct transport")
+                        return good
+
+                    canary, hd_transports = calibrate_transports(ctx, first, refine, direct_stage, str, (lambda name: name.endswith("_direct")),
+                                                                 best_rccl, measure, canary_of_the_direct_transport, rccl_seconds,
+                                                                 direct_seconds, timings, stats, wanted, hd_transports)
                 except Exception as exn:
                     ok = 0
                     print(f"rank {rank}: native RCCL halo exchange failed during calibration ({exn!r})", file=sys.stderr)
@@ -1500,9 +1253,9 @@ def _setup_hdiff2048(args, ctx):
 
             chk = FormCheck(dec, (lambda: gt_storage.zeros(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin)),
                             (lambda a, b: frozen(in_field=a, out_field=b, coeff=fields["coeff"])))
-            chk.reset()
-            overlapped_apply(hd, dec, origin, {"in_field": chk.probe, "out_field": chk.out, "coeff": fields["coeff"]}, {"in_field": ex})
-            headline_verdict = chk.verdict()
+            headline_verdict = chk.check((lambda: overlapped_apply(hd, dec, origin, {"in_field": chk.probe, "out_field": chk.out,
+                                                                                       "coeff": fields["coeff"]}, {"in_field": ex})),
+                                         CHECK_EPOCHS, 1)
             ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
             ghost_cells = chk.ghost_cells_to_fill
             del chk
@@ -1514,9 +1267,12 @@ def _setup_hdiff2048(args, ctx):
                 print(f"rank {rank}: THE TIMED FORM GIVES WRONG RESULTS on at least one rank (here: {headline_verdict[1]})", file=sys.stderr)
             verified = {"headline_form_correct_on_every_rank": everywhere, "forms_checked": ctx.get("forms_checked", 0),
                         "forms_rejected": ctx.get("forms_rejected", 0), "ghost_cells_checked_on_rank_0": ghost_cells,
-                        "how": "see gt4py_amd/distributed/selfcheck.py: every form is run once on a field that holds an exact function "
-                               "of the GLOBAL coordinates (ghost cells: a sentinel); every cell and every point of the result must then "
-                               "be the known one, bit for bit, on every rank; wrong forms are dropped from the calibration"}
+                        "epochs_per_form": CHECK_EPOCHS,
+                        "how": "see gt4py_amd/distributed/selfcheck.py: every form is run on a field that holds an exact function "
+                               "of the GLOBAL coordinates + 65536 x EPOCH (ghost cells: a sentinel) for epochs_per_form consecutive "
+                               "epochs, the last one under HBM load; every cell and every point of the result must then be the known "
+                               "one, bit for bit, on every rank; wrong forms are dropped from the calibration, a wrong form of the "
+                               "direct transport moves every rank down the ladder direct -> direct-fenced -> rccl"}
     else:
         def step(i):
             frozen(**fields)
@@ -1545,7 +1301,7 @@ def _setup_hdiff2048(args, ctx):
                         ex = NativeHaloExchanger(dec, np.float64, comm, single_phase=single).tune("chain", cand_wg, defer_join=True,
                                                                                                   edge_columns=cand_edge)
                         if cand_transport == "direct":
-                            ex.use_direct_transport()
+                            ex.use_direct_transport().tune(direct_fenced=direct_fenced(ctx))
                         fn = ex.make_dist_hdiff(fields["in_field"], fields["out_field"], fields["coeff"], dec.origin, flags)
                         return fn, (lambda: (ex.end(), ex.close(collective=False)))
 
@@ -1567,11 +1323,11 @@ def _setup_hdiff2048(args, ctx):
               "halo_depth": halo, "halo_bytes_per_rank_per_exchange": exchangers[0].bytes_per_exchange if exchangers else 0,
               "transport": transport, "selfloop": bool(selfloop), "apply_form": choice,
               "calibration_ms_per_apply": timings, "verified": verified, "direct_transport_dropped_at": ctx.get("direct_dropped"),
-              "direct_transport_canary": canary}
+              "direct_transport_canary": canary, **ladder_line_keys(ctx)}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen),
               "proof": proof, "transport_fallback": fallback,
               "timestep": pipelined_applies if decomposed and os.environ.get("GT4MI_BENCH_TIMESTEP", "1") != "0" else None,
-              "calibration": calibration_line_keys(timings, stats) if timings else None}
+              "calibration": calibration_line_keys(timings, stats, ctx) if timings else None}
     return step, kernel_step, dec.local_domain, config, extras
 
 

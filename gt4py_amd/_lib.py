@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = (
     "gt4mi_stream_copy",
 )
 
-GT4MI_ABI_VERSION = 5
+GT4MI_ABI_VERSION = 6
 
 # gt4mi_status
 OK = 0
@@ -87,7 +87,7 @@ ERR_TIMEOUT = -5
 LAP_NOTEBOOK, LAP_DOCS, LAP_SUITE, LAP_AVG = 0, 1, 2, 3
 LAP_LITERAL_F32 = 1
 # gt4mi_halo_plan_set_option
-PLAN_SCHEDULE, PLAN_INTERIOR_WG_PER_CU, PLAN_DEFER_JOIN, PLAN_EDGE_COLUMNS, PLAN_TRANSPORT, PLAN_DIRECT_TIMEOUT_MS = 0, 1, 2, 3, 4, 5
+PLAN_SCHEDULE, PLAN_INTERIOR_WG_PER_CU, PLAN_DEFER_JOIN, PLAN_EDGE_COLUMNS, PLAN_TRANSPORT, PLAN_DIRECT_TIMEOUT_MS, PLAN_DIRECT_FENCED = 0, 1, 2, 3, 4, 5, 6
 TRANSPORT_RCCL, TRANSPORT_DIRECT = 0, 1
 SCHEDULE_JOIN, SCHEDULE_CHAIN, SCHEDULE_SWAP, SCHEDULE_SWAP_PACKED, SCHEDULE_INLINE = 0, 1, 2, 3, 4
 # hdiff flags

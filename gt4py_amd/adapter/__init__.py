@@ -260,8 +260,14 @@ def register_with_gt4py(name: str = "hip:mi300"):
         options = {"device_sync": {"versioning": True, "type": bool},
                    "use_kernel_library": {"versioning": True, "type": bool},
                    "oir_pipeline": {"versioning": True, "type": gtc_passes.OirPipeline}}
-        storage_info = {"alignment": preset["alignment"], "device": "gpu", "layout_map": preset["layout_map"],
-                        "is_optimal_layout": preset["is_optimal_layout"]}
+        # gt4py's LayoutInfo knows ONE alignment, in items of whatever dtype is allocated (storage/cartesian/interface.py:95-100);
+        # the in-tree allocator aligns rows to 128 BYTES whatever the item size (storage/layout.py: `alignment_bytes`).  The
+        # smallest item count that gives every 4- and 8-byte dtype rows on 128-byte boundaries is 32 -- fp32 rows then match the
+        # in-tree layout exactly (128 B), fp64 rows get gt:gpu's 256 B (a multiple of 128: every kernel's fast path applies; the
+        # measured cost against 128-byte rows is 1 % on the 512^3 Laplacian, profiles/r4_row_alignment.txt).  The preset's own
+        # figure (16 items) would give fp32 rows 64 bytes: a different layout for the same backend name.
+        storage_info = {"alignment": max(int(preset.get("alignment_bytes", 128)) // 4, int(preset["alignment"])), "device": "gpu",
+                        "layout_map": preset["layout_map"], "is_optimal_layout": preset["is_optimal_layout"]}
         languages = {"computation": "hip", "bindings": ["python"]}
 
         def generate(self):

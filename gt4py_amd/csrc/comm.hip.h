@@ -136,8 +136,9 @@ struct gt4mi_halo_plan {
         uint32_t* error = nullptr;          // HOST memory mapped into the device: a wait ran out of time (direct_failed reads it)
         unsigned* ring_counters = nullptr;  // device: workgroups of a fused unpack + ring launch that have read their face (2 words)
         int timeout_ms = 0;                 // GT4MI_PLAN_DIRECT_TIMEOUT_MS (0: GT4MI_DIRECT_TIMEOUT_MS, else 30 s)
+        int fenced = 0;                     // GT4MI_PLAN_DIRECT_FENCED: release / acquire fences around the flags (direct.hip.h "fenced mode")
         const char* broken = nullptr;       // an exchange was enqueued only in part: which step failed (the plan stays failed)
-        bool lose_signals = false;          // tests: GT4MI_DIRECT_TEST_LOSE_SIGNALS was set when the plan was prepared
+        int lose_signals = 0;               // tests: GT4MI_DIRECT_TEST_LOSE_SIGNALS when the plan was prepared (1: always, 2: only while the plan is unfenced)
         uint32_t step = 0;                  // exchanges started
         bool first_pushed = false;          // halo_pack_first already pushed the first phase of exchange `step`
         struct Peer {

@@ -50,7 +50,19 @@ struct DirectBatch {
     unsigned blocks[BoxBatch::MAX];        // workgroups that work on box m (the others of the launch leave at once)
     uint32_t* error;                       // host memory mapped into the device: a wait ran out of time
     long long timeout_ticks;               // of the 100 MHz wall clock
+    int fenced;                            // GT4MI_PLAN_DIRECT_FENCED (wave-uniform): see direct_release_fence / direct_acquire_fence
 };
+
+// FENCED MODE (GT4MI_PLAN_DIRECT_FENCED = 1; the fall-back between "direct" and RCCL).  The default ordering above rests on two
+// properties of the memory system that one device can show and xGMI may not share: a write-through (sc0 sc1) store that has been
+// acknowledged (vmcnt) is visible to every later load of every agent, and an sc0 sc1 load issued behind the flag load is served
+// behind it.  Fenced mode asks the ISA's own memory model instead: the signalling side does a SYSTEM-scope release before its
+// add (the compiler's `buffer_wbl2 sc0 sc1` + `s_waitcnt vmcnt(0) lgkmcnt(0)`: every store of the wave, and every dirty L2 line,
+// is at its home before the flag moves), the waiting side a SYSTEM-scope acquire after its flag load (`buffer_inv sc0 sc1`:
+// nothing cached or prefetched before the flag is used behind it).  Cost: the release next to an interior kernel that keeps the
+// L2 full of dirty lines -- measured on the self-loop; that is why it is not the default.
+__device__ __forceinline__ void direct_release_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+__device__ __forceinline__ void direct_acquire_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
 
 // One lane waits until *flag has reached `value` (counters wrap: "has reached" = the signed difference is not negative).  False
 // = out of time: the plan's error word is set, the caller must neither copy nor signal.
@@ -158,7 +170,12 @@ __device__ __forceinline__ void direct_block(U* field, int64_t si, int64_t sj, i
     if (threadIdx.x == 0) ready = direct_wait(d.wait_flag[m], d.wait_value[m], d.timeout_ticks, d.error) ? 1 : 0;
     __syncthreads();
     if (!ready) return;  // out of time: nothing is copied, nothing is signalled -- the plan has failed (direct_failed)
-    if constexpr (!PACK) load_all();  // behind the flag: what the peer stored before it raised it
+    // Behind the flag.  The hardware assumption of the default mode: VMEM instructions of a wave issue in order and the barrier
+    // above orders every wave behind lane 0's flag load; the compiler must not move the payload loads up either (the asm loads
+    // are `volatile` with a memory clobber; the signal fence pins everything else).  Fenced mode adds the ISA's acquire.
+    __atomic_signal_fence(__ATOMIC_ACQUIRE);
+    if (d.fenced) direct_acquire_fence();
+    if constexpr (!PACK) load_all();  // what the peer stored before it raised the flag
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the asm loads of the unpack side are invisible to the compiler)
 #pragma unroll
@@ -184,6 +201,8 @@ __device__ __forceinline__ void direct_block(U* field, int64_t si, int64_t sj, i
     // unpack: its loads from the receive buffer completed above.  No fence: a system-scope `buffer_wbl2` next to an interior
     // kernel that keeps the L2 full of dirty lines cost 300-800 us per exchange in the first version of this kernel.
     if constexpr (PACK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (PACK)
+        if (d.fenced) direct_release_fence();  // every wave: its stores (and whatever else is dirty) are at their home
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(d.signal_flag[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // posted
 }
@@ -231,6 +250,7 @@ inline int direct_batches(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase
     const auto& msgs = PACK ? plan->sends[phase] : plan->recvs[phase];
     blocks = 0;
     b.n = 0;
+    d.fenced = 0;
     if (msgs.empty()) return GT4MI_OK;
     if ((int)msgs.size() > BoxBatch::MAX) return fail(GT4MI_ERR_UNSUPPORTED, "halo: more than %d boxes per phase", BoxBatch::MAX);
     auto& dx = plan->direct;
@@ -261,13 +281,16 @@ inline int direct_batches(gt4mi_halo_plan* plan, const gt4mi_field* f, int phase
         d.wait_flag[m] = dx.flags + direct_index(plan, PACK, phase, m);
         d.wait_value[m] = (PACK ? dx.step - 1 : dx.step) * nb;
         // (GT4MI_DIRECT_TEST_LOSE_SIGNALS=1 when the plan was prepared, tests only: the pushes signal into an unused word -- what a
-        // broken link looks like from the receiver's side: its waits run out of time)
-        d.signal_flag[m] = (PACK && dx.lose_signals) ? dx.flags + DIRECT_FLAG_BYTES / sizeof(uint32_t) - 1 : signal;
+        // broken link looks like from the receiver's side: its waits run out of time.  =2: only while the plan is NOT in fenced
+        // mode -- a transport whose default mode fails and whose fenced mode works, for the tests of the fall-back ladder)
+        const bool lose = dx.lose_signals == 1 || (dx.lose_signals == 2 && !dx.fenced);
+        d.signal_flag[m] = (PACK && lose) ? dx.flags + DIRECT_FLAG_BYTES / sizeof(uint32_t) - 1 : signal;
         d.blocks[m] = nb;
         blocks = nb > blocks ? nb : blocks;
     }
     d.error = dx.error;
     d.timeout_ticks = direct_timeout_ticks(plan);
+    d.fenced = dx.fenced;
     return GT4MI_OK;
 }
 
@@ -304,6 +327,7 @@ inline int direct_batches_recv(gt4mi_halo_plan* plan, const gt4mi_field* f, int 
     }
     d.error = plan->edge_words + 2;
     d.timeout_ticks = direct_timeout_ticks(plan);
+    d.fenced = 0;  // (RCCL delivered the buffers: stream order, the send/recv kernel's own fences)
     return GT4MI_OK;
 }
 
@@ -389,7 +413,7 @@ inline int direct_prepare(gt4mi_halo_plan* plan, gt4mi_direct_info* out) {
             dx.signal_arrived[p].assign(plan->sends[p].size(), nullptr);
             dx.signal_consumed[p].assign(plan->recvs[p].size(), nullptr);
         }
-        dx.lose_signals = env_int("GT4MI_DIRECT_TEST_LOSE_SIGNALS", 0) != 0;
+        dx.lose_signals = env_int("GT4MI_DIRECT_TEST_LOSE_SIGNALS", 0);
         dx.prepared = true;
     }
     if (out) {

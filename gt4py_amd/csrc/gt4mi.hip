@@ -636,6 +636,10 @@ int gt4mi_halo_plan_set_option(gt4mi_halo_plan* plan, int option, int value) {
             if (value < 0) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: a timeout of %d ms", value);
             plan->direct.timeout_ms = value;
             return GT4MI_OK;
+        case GT4MI_PLAN_DIRECT_FENCED:
+            if (value != 0 && value != 1) return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: direct_fenced %d", value);
+            plan->direct.fenced = value;
+            return GT4MI_OK;
     }
     return gt4mi::fail(GT4MI_ERR_INVALID_ARGUMENT, "halo_plan_set_option: unknown option %d", option);
 }

@@ -57,6 +57,7 @@ struct EdgeFaces {
     int rows_lo, rows_hi;        // column units COMPUTE rows [rows_lo, rows_hi) (the row units own the first / last row)
     uint32_t* error;
     long long timeout_ticks;
+    int fenced;                  // GT4MI_PLAN_DIRECT_FENCED: an acquire behind the flags (direct.hip.h "fenced mode")
 };
 
 // One wave: has *flag reached value?  Every lane polls the same word (one request); false = out of time (error word set).
@@ -118,7 +119,12 @@ __device__ __forceinline__ unsigned lap5_edge_row_unit(const View<T>& in, const 
     if (need_w) ready = edge_wait(g.wait_flag[0], g.wait_value[0], g.timeout_ticks, g.error) && ready;
     if (need_e) ready = edge_wait(g.wait_flag[1], g.wait_value[1], g.timeout_ticks, g.error) && ready;
     if (!ready) return 0u;  // out of time: nothing written, nothing counted, nothing signalled -- the plan has failed
-    // behind the flags: what the senders stored before they raised them
+    // behind the flags: what the senders stored before they raised them.  Hardware assumption of the default mode: the wave's
+    // VMEM instructions issue in program order, so a load that stands behind the flag load is served behind it; the signal fence
+    // keeps the COMPILER from hoisting the buffer loads (relaxed atomics, a control dependency only) above the wait -- the same
+    // stale-face-with-a-ready-flag class as the round-3 defect, reintroduced silently by a scheduling change otherwise.
+    __atomic_signal_fence(__ATOMIC_ACQUIRE);
+    if (g.fenced) direct_acquire_fence();
 #pragma unroll 1
     for (int l0 = 0; l0 < LG; l0 += CH) {
         if (k0 + l0 >= dK) break;
@@ -192,6 +198,8 @@ __device__ __forceinline__ unsigned lap5_edge_col_unit(const View<T>& in, const 
     const bool compute = in_face && j >= g.rows_lo && j < g.rows_hi;
     const int i0 = f == 0 ? 0 : dI - VEC, ig = f == 0 ? -1 : dI, ix = f == 0 ? VEC : dI - VEC - 1;  // the vector, the ghost column, the column beyond
     if (!edge_wait(g.wait_flag[f], g.wait_value[f], g.timeout_ticks, g.error)) return 0u;
+    __atomic_signal_fence(__ATOMIC_ACQUIRE);  // (see lap5_edge_row_unit: the buffer loads stay behind the flag, in the compiler too)
+    if (g.fenced) direct_acquire_fence();
 #pragma unroll 1
     for (int l0 = 0; l0 < LG; l0 += CH) {
         if (k0 + l0 >= dK) break;
@@ -410,6 +418,7 @@ inline int lap5_edge_prepare(gt4mi_halo_plan* plan, const int64_t domain[3], con
         }
     g->error = direct ? dx.error : plan->edge_words + 2;
     g->timeout_ticks = direct_timeout_ticks(plan);
+    g->fenced = direct ? dx.fenced : 0;
     *phase_out = phase;
     *ok = true;
     return GT4MI_OK;

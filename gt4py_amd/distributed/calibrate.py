@@ -1,0 +1,394 @@
+"""The collective plumbing of an N > 1 calibration: agreement between ranks, slowest-rank timing, wall-clock budgets every rank
+reads alike, the best-first order of the candidates, and the fall-back LADDER of the halo transport
+
+    direct  ->  direct-fenced  ->  rccl
+
+(`direct_step_down`): a form of the direct transport that fails its epoch-stamped self-check (``selfcheck.FormCheck.check``), times
+out or cannot be set up moves EVERY rank to the fenced mode (GT4MI_PLAN_DIRECT_FENCED: release / acquire fences around the flags),
+what was measured unfenced is discarded and the direct stage runs again; a failure in fenced mode leaves RCCL, the transport the
+north star names.  Every step is recorded (``ctx["direct_ladder"]``) and printed in the line (``direct_transport_mode``).
+
+Moved out of ``bench.py``: this is the code that meets 8 devices first, and it is unit-tested on gloo
+worlds (tests/test_bench_infrastructure.py) -- as a module it can be, without importing a 1 900-line program.  Pure Python; torch is
+imported inside the functions that need a tensor.  NEW relative to the reference (single-device).
+
+``ctx``: {"world", "rank", "distributed", "dist" (torch.distributed), "device" ("cuda" | "cpu"), "collective_device"} + the
+ladder's state ("direct_mode", "direct_dropped", "direct_retry", "direct_ladder") + counters ("forms_checked", "forms_rejected").
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+def _agree(ctx, ok: int) -> int:
+    """Every rank learns whether ALL ranks succeeded."""
+    if ctx["distributed"]:
+        import torch
+
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctx.get("collective_device", ctx.get("device", "cuda")))
+        ctx["dist"].all_reduce(flag, op=ctx["dist"].ReduceOp.MIN)
+        ok = int(flag.item())
+    return ok
+
+
+class FailedOnSomeRank(RuntimeError):
+    """A timed callable raised on at least one rank; every rank raises this together, after the same collectives."""
+
+
+def _slowest_rank_ms(ctx, fn, calls: int, warm: int = 3) -> float:
+    """Milliseconds per call of ``fn`` over ``calls`` calls, the slowest rank's figure on every rank.
+
+    A call that raises on SOME rank (the direct transport fails hard: a neighbour that never arrives makes the next call on the
+    plan raise -- on the ranks that waited for it, not on the others) must not leave the ranks in different collectives: every
+    rank runs the same barrier and reductions whatever happened to it, then all raise ``FailedOnSomeRank`` together.  (Found by
+    the rehearsal with real ranks, GT4MI_BENCH_ONE_DEVICE: one rank went on to the next agreement while three were still in
+    this reduction, and the run ended on its provisional line 240 s later.)"""
+    import torch
+
+    device = ctx.get("device", "cuda")
+    sync = torch.cuda.synchronize if device == "cuda" else (lambda: None)
+    failure = None
+
+    def run(n):
+        nonlocal failure
+        try:
+            for _ in range(n):
+                fn()
+            sync()
+        except Exception as ex:  # noqa: BLE001 - reported to every rank below
+            failure = failure or ex
+            try:
+                sync()
+            except Exception:  # noqa: BLE001
+                pass
+
+    run(warm)
+    if ctx["distributed"]:
+        ctx["dist"].barrier()
+    t0 = time.perf_counter()
+    if failure is None:
+        run(calls)
+    dt = torch.tensor([(time.perf_counter() - t0) / calls * 1e3], dtype=torch.float64, device=ctx.get("collective_device", device))
+    if ctx["distributed"]:
+        ctx["dist"].all_reduce(dt, op=ctx["dist"].ReduceOp.MAX)
+    if not _agree(ctx, int(failure is None)):
+        if failure is not None:
+            print(f"rank {ctx['rank']}: a timed call failed ({failure!r})", file=sys.stderr)
+        raise FailedOnSomeRank(repr(failure) if failure is not None else "on another rank")
+    return float(dt.item())
+
+
+def measure_candidate(ctx, make, calls: int, warm: int = 3):
+    """ms per call of one calibration candidate (slowest rank), or None when it cannot run on SOME rank -- then on no rank.
+
+    ``make()`` returns (callable, cleanup) or (callable, cleanup, check).  Building the candidate and its first calls happen without any collective, so a
+    rank on which they fail (an option this device / runtime refuses, a launch error) does not leave the others waiting in
+    a barrier: every rank reports, all agree, and only candidates that work everywhere are timed.  One exotic candidate that
+    fails must cost that candidate, not the native transport."""
+    import torch
+
+    fn = cleanup = None
+    ok = 1
+    try:
+        made = make()
+        fn, cleanup = made[0], made[1]
+        for _ in range(warm):
+            fn()
+        if ctx.get("device", "cuda") == "cuda":
+            torch.cuda.synchronize()
+        if len(made) > 2 and made[2] is not None:
+            # (fn, cleanup, check): check() -> (ok, what it found) runs the form once on fields whose correct outcome is known
+            # exactly (distributed.FormCheck); a form that is fast and wrong on some rank is dropped on every rank
+            good, found = made[2]()
+            ctx["forms_checked"] = ctx.get("forms_checked", 0) + 1
+            if not good:
+                ok = 0
+                ctx["forms_rejected"] = ctx.get("forms_rejected", 0) + 1
+                print(f"rank {ctx['rank']}: calibration candidate REJECTED, its results are wrong: {found}", file=sys.stderr)
+    except Exception as ex:
+        ok = 0
+        print(f"rank {ctx['rank']}: calibration candidate failed ({ex!r})", file=sys.stderr)
+        if ctx.get("device", "cuda") == "cuda":
+            try:
+                torch.cuda.synchronize()  # (whatever this rank enqueued for the candidate has left the device before the ranks meet)
+            except Exception:
+                pass
+    ms = None
+    if _agree(ctx, ok):
+        try:
+            ms = round(_slowest_rank_ms(ctx, fn, calls, warm=0), 5)
+        except FailedOnSomeRank:  # (every rank alike: the candidate is dropped everywhere)
+            ms = None
+    # Every rank has synchronised its device and met the others in a collective (_agree / the all-reduce of the timings) since
+    # the candidate's last exchange: cleanups may release memory the neighbours' kernels wrote into WITHOUT another round
+    # (NativeHaloExchanger.close(collective=False)) -- and a rank on which the candidate could not even be built, which has
+    # nothing to clean up, leaves nobody waiting for it.
+    if cleanup is not None:
+        try:
+            cleanup()
+        except Exception:
+            pass
+    return ms
+
+
+class WallBudget:
+    """A wall-clock budget that every rank reads alike: `more()` is a tiny collective (all ranks still have time, or nobody
+    goes on), so no rank ever starts a candidate that another one has already given up on."""
+
+    def __init__(self, ctx, seconds: float):
+        self.ctx, self.seconds, self.t_end, self.spent = ctx, float(seconds), time.monotonic() + float(seconds), False
+
+    def more(self) -> bool:
+        if not self.spent:
+            self.spent = not _agree(self.ctx, int(time.monotonic() < self.t_end))
+        return not self.spent
+
+
+def lap_key(cand) -> str:
+    grid, single, schedule, wg, transport = cand
+    return f"{grid[0]}x{grid[1]}_{'single' if single else 'two'}phase_{schedule}_wg{wg}_{transport}"
+
+
+def lap_candidate_of(key: str):
+    g, ph, schedule, wg, transport = key.split("_")
+    pi, pj = g.split("x")
+    return (int(pi), int(pj)), ph == "singlephase", schedule, int(wg[2:]), transport
+
+
+def lap_calibration_order(default_grid, grids, phases, transports):
+    """The calibration candidates of the decomposed Laplacian -- (grid, single_phase, schedule, interior workgroups per CU,
+    transport) -- BEST FIRST, in three stages; the wall-clock budget cuts the tail, never the head (VERDICT round 3, item 3:
+    ~208 candidates under one kill deadline meant the first real N > 1 line would have been the provisional one or a timeout).
+
+      first   the north star's form: RCCL send/recv on a second stream, on the grid `choose_process_grid` returns, the two
+              schedules that won every self-loop share ("swap", then "join"), two-phase then single-phase: an OVERLAPPED
+              RCCL headline exists after at most four candidates; then the other process grids, RCCL "swap"
+      refine(best) what is left of RCCL on the best grid and message table so far: the other schedules, then the throttles
+      direct(best) the direct transport (only after its canary), by the self-loop ranking: "inline" on the best grid, both
+              tables; "inline" on the other grids; then the two-stream schedules on the best grid."""
+    rccl, direct = "rccl" in transports, "direct" in transports
+    # (the other grids by the self-loop ranking of round 4: the fewer cuts along I -- W / E faces are strided columns, one
+    # partial-line store per row and level -- the faster the share: 1 x 8 < 2 x 4 < 4 x 2 per apply on either transport)
+    others = sorted((g for g in grids if g != default_grid), key=lambda g: g[0])
+    first = []
+    if rccl:
+        first += [(default_grid, single, schedule, 0, "rccl") for single in phases for schedule in ("swap", "join")]
+        first += [(g, single, "swap", 0, "rccl") for g in others for single in phases]
+
+    def refine(best):
+        g, single = best[0], best[1]
+        if not rccl:
+            return []
+        out = [(g, single, schedule, 0, "rccl") for schedule in ("swap", "join", "swap-packed", "chain")]
+        out += [(g, single, schedule, wg, "rccl") for wg in (4, 2) for schedule in ("swap", "join", "swap-packed", "chain")]
+        out += [(g, other, schedule, 0, "rccl") for other in phases if other != single for schedule in ("swap-packed", "chain")]
+        return out
+
+    def direct_stage(best):
+        if not direct:
+            return []
+        g = best[0] if best is not None else default_grid
+        out = [(g, single, "inline", 0, "direct") for single in phases]
+        out += [(og, single, "inline", 0, "direct") for og in sorted((x for x in grids if x != g), key=lambda x: x[0]) for single in phases]
+        out += [(g, single, schedule, 0, "direct") for schedule in ("swap", "join", "swap-packed", "chain") for single in phases]
+        return out
+
+    return first, refine, direct_stage
+
+
+def run_calibration(candidates, key_of, measure, budget, table, stats, skip=None, failed=None) -> None:
+    """Measure `candidates` in order into `table[key]` until the budget is spent (collectively); what was not started is
+    counted, not measured.  `measure(candidate)` -> ms (slowest rank) or None when the candidate failed on some rank (then
+    `failed(candidate, key)` hears of it); `skip(candidate)`: not to be tried at all (a transport that was dropped)."""
+    for cand in candidates:
+        key = key_of(cand)
+        if key in table or key in stats["failed"] or (skip is not None and skip(cand)):
+            continue
+        if not budget.more():
+            stats["skipped_for_time"] += 1
+            continue
+        if os.environ.get("GT4MI_BENCH_VERBOSE") == "1":
+            print(f"bench.py: calibrating {key}", file=sys.stderr, flush=True)
+        ms = measure(cand)
+        stats["run"] += 1
+        if ms is None:
+            stats["failed"].append(key)
+            if failed is not None:
+                failed(cand, key)
+        else:
+            table[key] = ms
+
+
+def calibrate_transports(ctx, first, refine, direct_stage, key_of, is_direct, best_rccl, measure, canary, rccl_seconds, direct_seconds,
+                         table, stats, wanted=None, transports=("rccl", "direct")):
+    """The three stages of a calibration order under their budgets, collectively: RCCL first, what is left of RCCL around the best
+    candidate so far, then -- `canary()` permitting: True / None (not needed) go on, False drops it -- the direct transport with a
+    budget of its own, DOWN THE LADDER: a direct candidate that fails (`measure` -> None: wrong results under the epoch-stamped
+    check, a timeout, a set-up error -- on some rank, agreed by all) ends the stage, moves every rank to the fenced mode, discards
+    the unfenced measurements and runs the stage again; a failure in fenced mode drops the transport.  Fills `table` (key -> ms per
+    apply, slowest rank) and `stats`; returns (what the canary said, the transports still in use).
+
+    `first`: candidates; `refine(best_key)`, `direct_stage(best_key or None)` -> candidates; `key_of(candidate)` -> str;
+    `is_direct(candidate)`; `best_rccl()` -> key or None; `measure(candidate)` -> ms or None (it builds direct plans in
+    `direct_fenced(ctx)` mode)."""
+    wanted = wanted or (lambda cands: cands)
+
+    def dropped(cand):
+        return is_direct(cand) and (bool(ctx.get("direct_dropped")) or bool(ctx.get("direct_retry")))
+
+    def drop(cand, key):
+        if is_direct(cand):
+            direct_step_down(ctx, key)
+
+    budget = WallBudget(ctx, rccl_seconds)
+    run_calibration(wanted(first), key_of, measure, budget, table, stats, dropped, drop)
+    best_key = best_rccl()
+    if best_key is not None:
+        run_calibration(wanted(refine(best_key)), key_of, measure, budget, table, stats, dropped, drop)
+        best_key = best_rccl()
+    verdict = None
+    if "direct" in transports:
+        verdict = canary()
+        if verdict is False:
+            transports = tuple(t for t in transports if t != "direct") or ("rccl",)
+        else:
+            for _ in range(2):  # (at most: once unfenced, once fenced)
+                budget = WallBudget(ctx, direct_seconds)
+                run_calibration(wanted(direct_stage(best_key)), key_of, measure, budget, table, stats, dropped, drop)
+                if not ctx.pop("direct_retry", False):
+                    break
+                # the transport has stepped down to its fenced mode: nothing measured without fences is kept, nothing that failed
+                # without them stays failed
+                direct_keys = {key_of(c) for c in direct_stage(best_key)}
+                for key in [k for k in table if k in direct_keys]:
+                    del table[key]
+                stats["failed_unfenced"] = stats.get("failed_unfenced", []) + [k for k in stats["failed"] if k in direct_keys]
+                stats["failed"][:] = [k for k in stats["failed"] if k not in direct_keys]
+            if ctx.get("direct_dropped"):
+                # a form failed WITH fences: the transport as a whole is not to be trusted on these links -- what it measured
+                # is kept for the record only and cannot become the headline
+                direct_keys = {key_of(c) for c in direct_stage(best_key)}
+                stats["measured_before_the_drop"] = {k: table.pop(k) for k in [k for k in table if k in direct_keys]}
+                transports = tuple(t for t in transports if t != "direct") or ("rccl",)
+    return verdict, transports
+
+
+def calibrate_laplacian(ctx, default_grid, grids, phases, transports, measure, canary, rccl_seconds, direct_seconds, table, stats,
+                        pinned_schedule=None):
+    """`calibrate_transports` over `lap_calibration_order`: RCCL first (the default grid's "swap" / "join" before anything else),
+    what is left of RCCL on the best grid, then the direct transport down its ladder.  `measure(candidate)` -> ms or None."""
+    first, refine, direct_stage = lap_calibration_order(default_grid, grids, phases, transports)
+
+    def wanted(cands):
+        return [c for c in cands if pinned_schedule is None or c[2] == pinned_schedule]
+
+    return calibrate_transports(ctx, first, (lambda key: refine(lap_candidate_of(key))),
+                                (lambda key: direct_stage(lap_candidate_of(key) if key else None)), lap_key, (lambda c: c[4] == "direct"),
+                                (lambda: best_of(table, "rccl")[0]), measure, canary, rccl_seconds, direct_seconds, table, stats, wanted,
+                                transports)
+
+
+def best_of(table, transport: str):
+    """(key, ms) of the fastest measured candidate of one transport (keys end in _rccl / _direct), or (None, None)."""
+    mine = {k: v for k, v in table.items() if k.endswith("_" + transport)}
+    if not mine:
+        return None, None
+    key = min(mine, key=mine.get)
+    return key, mine[key]
+
+
+def calibration_seconds(name: str, fallback: float) -> float:
+    return float(os.environ.get(name, fallback))
+
+
+def hdiff_calibration_order(schedules, edges, transports):
+    """The apply forms of the decomposed horizontal diffusion, BEST FIRST (see lap_calibration_order): names
+    `fused_<table>_<schedule>_wg<n>_edge<w>[_direct]` and `sequential_<table>`.
+
+      first        RCCL, what gt4mi_dist_hdiff_* does by default and won the self-loop rehearsals: "chain" (then "join"), the
+                   interior kernel at 2 of 4 workgroups per CU, 16 edge columns, two-phase then single-phase
+      refine(best) RCCL on the best message table: the other throttles and edge widths, the one-stream form, the plain sequence
+      direct(best) the direct transport after its canary, by the self-loop ranking of rounds 3-4: "chain" with the interior at 3, then
+                   2 of 4 workgroups per CU (0.194-0.204 ms for a 0.179 ms kernel), then the one-stream form (0.21-0.22)"""
+    rccl, direct = "rccl" in transports, "direct" in transports
+    tables = ("two_phase", "single_phase")
+    two_stream = [sc for sc in ("chain", "join", "swap", "swap-packed") if sc in schedules]
+    first = [f"fused_{t}_{sc}_wg2_edge16" for t in tables for sc in two_stream[:2]] if rccl else []
+
+    def table_of(name):
+        return "single_phase" if "single_phase" in name else "two_phase"
+
+    def refine(best):
+        if not rccl:
+            return []
+        t = table_of(best)
+        out = [f"fused_{t}_{sc}_wg{wg}_edge{e}" for wg in (2, 3, 0) for e in edges for sc in two_stream]
+        if "inline" in schedules:
+            out += [f"fused_{t}_inline_wg0_edge{e}" for e in edges]
+        return out + [f"sequential_{t}"] + [f"sequential_{o}" for o in tables if o != t]
+
+    def direct_stage(best):
+        if not direct:
+            return []
+        t = table_of(best) if best else "two_phase"
+        order = [t] + [o for o in tables if o != t]
+        out = [f"fused_{o}_{two_stream[0]}_wg{wg}_edge16_direct" for wg in (3, 2) for o in order] if two_stream else []
+        if "inline" in schedules:
+            out += [f"fused_{t}_inline_wg0_edge{e}_direct" for e in (32, 16) if e in edges]
+        out += [f"fused_{o}_{sc}_wg2_edge16_direct" for sc in two_stream[1:2] for o in order]
+        return out
+
+    return first, refine, direct_stage
+
+
+def calibration_line_keys(table, stats, ctx=None) -> dict:
+    """Top-level keys of a calibrated N > 1 line: what the SPECIFIED design (RCCL send/recv on a second stream) achieves next to
+    the direct transport, whichever of the two the headline took, and how much of the calibration the budget allowed."""
+    direct = {k: v for k, v in table.items() if k.endswith("_direct")}
+    rccl = {k: v for k, v in table.items() if not k.endswith("_direct")}  # (Laplacian keys end in _rccl, hdiff's carry no suffix)
+    rccl_key = min(rccl, key=rccl.get) if rccl else None
+    direct_key = min(direct, key=direct.get) if direct else None
+    rccl_ms, direct_ms = rccl.get(rccl_key), direct.get(direct_key)
+    return {"rccl_best_ms_per_apply": rccl_ms, "rccl_best_form": rccl_key, "direct_best_ms_per_apply": direct_ms,
+            "direct_best_form": direct_key, "calibration_candidates_run": stats["run"],
+            "calibration_candidates_skipped_for_time": stats["skipped_for_time"], "calibration_candidates_failed": list(stats["failed"]),
+            "calibration_candidates_failed_unfenced": list(stats.get("failed_unfenced", [])), **(ladder_line_keys(ctx) if ctx is not None else {})}
+
+# ---- the fall-back ladder of the halo transport ---------------------------------------------------------------------------
+DIRECT_MODES = ("direct", "direct-fenced", "rccl")
+
+
+def direct_mode(ctx) -> str:
+    """"direct" (the default: write-through stores + acknowledgement, no fence), "direct-fenced" or "rccl" (the direct transport
+    was dropped on every rank)."""
+    return ctx.get("direct_mode", "direct")
+
+
+def direct_fenced(ctx) -> bool:
+    return direct_mode(ctx) == "direct-fenced"
+
+
+def direct_step_down(ctx, at: str, why: str = "a form failed on some rank") -> str:
+    """One rung down, on every rank alike (the caller has AGREED on the failure: `measure_candidate` / `_agree`).  From "direct":
+    to "direct-fenced", and ``ctx["direct_retry"]`` asks the calibration to run the direct stage again; from "direct-fenced": to
+    "rccl" (``ctx["direct_dropped"]`` = where).  Returns the new mode."""
+    was = direct_mode(ctx)
+    if was == "direct":
+        now = "direct-fenced"
+        ctx["direct_retry"] = True
+    else:
+        now = "rccl"
+        ctx["direct_dropped"] = at
+    ctx["direct_mode"] = now
+    ctx.setdefault("direct_ladder", []).append({"from": was, "to": now, "at": at, "why": why})
+    if ctx.get("rank", 0) == 0:
+        print(f"calibrate: the halo transport steps down {was} -> {now} at {at} ({why})", file=sys.stderr, flush=True)
+    return now
+
+
+def ladder_line_keys(ctx) -> dict:
+    """What the line says about the ladder: the mode the run ended in and every step it took."""
+    return {"direct_transport_mode": direct_mode(ctx), "direct_transport_ladder": list(ctx.get("direct_ladder", []))}
+

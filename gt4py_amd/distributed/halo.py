@@ -22,12 +22,24 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-try:
-    import torch
-    import torch.distributed as dist
-except Exception:  # pragma: no cover
-    torch = None  # type: ignore
-    dist = None  # type: ignore
+
+
+class _LazyModule:
+    """``torch`` / ``torch.distributed``, imported on first use: the pure-Python parts of this package (message tables, process
+    grids, ``calibrate``) are imported by programs that must start without paying for -- or having -- torch (``import bench``
+    on the profiling path, tests/test_bench_infrastructure.py)."""
+
+    def __init__(self, name: str):
+        self.__dict__["_name"] = name
+
+    def __getattr__(self, attr):
+        import importlib
+
+        return getattr(importlib.import_module(self.__dict__["_name"]), attr)
+
+
+torch = _LazyModule("torch")
+dist = _LazyModule("torch.distributed")
 
 
 def process_grid_candidates(n: int, domain: Sequence[int], halo: int = 1, min_rows: int = 8):

@@ -142,6 +142,9 @@ class NativeHaloExchanger:
         self._plan = plan
         self._lib = lib
         self.transport = "rccl"
+        self.direct_fenced = False
+        self._failed = False  # a timeout of the direct transport was seen (synchronize / close)
+        self.failed_close_seconds = 20.0  # how long close() of a FAILED plan waits for the other ranks before it leaks the pool
         self._close_round = None  # direct transport with other ranks: the collective that precedes the release of the pool
         nb = decomp.neighbours
         self.sides = ((1 if nb["W"] is not None else 0) | (2 if nb["E"] is not None else 0)
@@ -149,7 +152,7 @@ class NativeHaloExchanger:
 
     def tune(self, schedule: Optional[str] = None, interior_wg_per_cu: Optional[int] = None,
              defer_join: Optional[bool] = None, edge_columns: Optional[int] = None,
-             direct_timeout_ms: Optional[int] = None) -> "NativeHaloExchanger":
+             direct_timeout_ms: Optional[int] = None, direct_fenced: Optional[bool] = None) -> "NativeHaloExchanger":
         """How the fused distributed steps built on this exchanger are scheduled (gt4mi_halo_plan_set_option):
         ``schedule`` "join" (pack and interior on the caller's stream, send/recv/unpack beside it, join, ring), "chain"
         (the caller's stream carries the interior only; pack, send/recv, unpack and ring in order on the side stream) or
@@ -157,7 +160,9 @@ class NativeHaloExchanger:
         the interior forks off after the pack);
         ``interior_wg_per_cu`` limits the occupancy of the interior kernel while the exchange runs next to it (0 = no
         limit); ``defer_join`` (chain schedule) lets a fused step return without joining the side stream -- for INDEPENDENT
-        applies, whose results the caller consumes only after ``end()``.  ``None`` leaves an option as it is."""
+        applies, whose results the caller consumes only after ``end()``; ``direct_fenced``: the direct transport's fenced mode
+        (GT4MI_PLAN_DIRECT_FENCED: a system-scope release before every flag is raised, an acquire behind every flag load --
+        the fall-back between the default direct transport and RCCL).  ``None`` leaves an option as it is."""
         if schedule is not None:
             value = {"join": _lib.SCHEDULE_JOIN, "chain": _lib.SCHEDULE_CHAIN, "swap": _lib.SCHEDULE_SWAP, "swap-packed": _lib.SCHEDULE_SWAP_PACKED, "inline": _lib.SCHEDULE_INLINE,
                      "default": -1}[schedule]
@@ -174,6 +179,10 @@ class NativeHaloExchanger:
         if direct_timeout_ms is not None:  # direct transport: how long a device-side wait may take before the plan fails (0: default)
             _lib.check("gt4mi_halo_plan_set_option",
                        self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_DIRECT_TIMEOUT_MS, int(direct_timeout_ms)))
+        if direct_fenced is not None:
+            _lib.check("gt4mi_halo_plan_set_option",
+                       self._lib.gt4mi_halo_plan_set_option(self._plan, _lib.PLAN_DIRECT_FENCED, int(bool(direct_fenced))))
+            self.direct_fenced = bool(direct_fenced)
         return self
 
     @staticmethod
@@ -291,6 +300,25 @@ class NativeHaloExchanger:
         t, n = ctypes.c_int(), ctypes.c_uint()
         _lib.check("gt4mi_halo_plan_direct_status", self._lib.gt4mi_halo_plan_direct_status(self._plan, ctypes.byref(t), ctypes.byref(n)))
         return {"timed_out": bool(t.value), "exchanges": int(n.value)}
+
+    def synchronize(self) -> None:
+        """Wait for everything enqueued so far and FAIL if a wait of the direct transport ran out of time in any exchange
+        started on this plan (``NativeError``, status ``ERR_TIMEOUT``).  Timeouts are otherwise detected lazily -- by the NEXT call
+        on the plan, and the call that enqueued the failing exchange has long returned OK --, so a caller whose last use of the
+        plan is "exchange, synchronise, read the ghost cells" calls this instead of a bare device synchronise: the CONSUMING
+        call fails, not some later producing one.  (``end()`` itself stays asynchronous: it is on the path of every timed
+        apply.)  On the RCCL transport: a device synchronise."""
+        if self.transport == "direct":
+            if self.direct_status()["timed_out"]:  # (synchronises the device first)
+                self._failed = True
+                raise _lib.NativeError("gt4mi_halo_plan_direct_status", _lib.ERR_TIMEOUT,
+                                       "direct transport: a wait for a neighbour ran out of time in an exchange of this plan; the ghost "
+                                       "cells of that exchange are incomplete and the plan stays failed: close it on every rank "
+                                       "(close(collective=False) if the neighbour may be gone)")
+        else:
+            import torch
+
+            torch.cuda.synchronize()
 
     def exchange(self, array) -> None:
         """Enqueue the exchange of ``array``'s ghost cells on the current stream."""
@@ -464,7 +492,33 @@ class NativeHaloExchanger:
                 import torch
 
                 torch.cuda.synchronize()  # the whole device: the plan's side stream too
-                self._close_round(("closing", self.decomp.rank))
+                # A plan whose wait ran out of time has a neighbour that never arrived -- it may be gone, and a collective with a
+                # rank that is gone never completes.  The failed plan still OFFERS the round (live neighbours are waiting in it),
+                # but from a helper thread and for a bounded time; if it does not complete the plan is released without it: its
+                # pool is leaked rather than freed under a peer that may still push (a leak is harmless, a store into freed
+                # memory is a fault on the peer's device).
+                failed = self._failed
+                try:
+                    failed = failed or self.direct_status()["timed_out"]
+                except Exception:  # noqa: BLE001
+                    failed = True
+                if failed:
+                    import threading
+                    import warnings
+
+                    meet = threading.Thread(target=lambda: self._close_round(("closing", self.decomp.rank)), daemon=True)
+                    meet.start()
+                    meet.join(timeout=self.failed_close_seconds)
+                    if meet.is_alive():
+                        warnings.warn("NativeHaloExchanger.close(): the plan's direct transport has FAILED (a wait for a neighbour ran "
+                                      f"out of time) and the ranks did not meet within {self.failed_close_seconds:.0f} s: the pool is "
+                                      "leaked instead of waiting for a neighbour that may be gone", RuntimeWarning, stacklevel=2)
+                        self._close_round = None
+                        self._plan = ctypes.c_void_p()  # (the native plan and its pool stay allocated: see above)
+                        return
+                    self._close_round = None
+                if self._close_round is not None:
+                    self._close_round(("closing", self.decomp.rank))
             self._close_round = None
             self._lib.gt4mi_halo_plan_destroy(self._plan)
             self._plan = ctypes.c_void_p()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GT4MI_ABI_VERSION 5 /* 5: GT4MI_ERR_TIMEOUT (a direct-transport wait that runs out fails the plan, hard), GT4MI_PLAN_DIRECT_TIMEOUT_MS; 4: gt4mi_dist_lap5_f32, the direct transport (gt4mi_halo_plan_direct_*, GT4MI_PLAN_TRANSPORT), gt4mi_comm_create_local, schedules 2-4 */
+#define GT4MI_ABI_VERSION 6 /* 6: GT4MI_PLAN_DIRECT_FENCED (release / acquire fences around the flags of the direct transport); 5: GT4MI_ERR_TIMEOUT (a direct-transport wait that runs out fails the plan, hard), GT4MI_PLAN_DIRECT_TIMEOUT_MS; 4: gt4mi_dist_lap5_f32, the direct transport (gt4mi_halo_plan_direct_*, GT4MI_PLAN_TRANSPORT), gt4mi_comm_create_local, schedules 2-4 */
 
 typedef enum gt4mi_status {
     GT4MI_OK = 0,
@@ -214,12 +214,24 @@ int gt4mi_halo_plan_destroy(gt4mi_halo_plan* plan);
  *                                   (even; default 16, 8 for local domains narrower than 256 columns; the Laplacian's at most
  *                                   16): what the ring computes is taken off the interior kernel, a box of whole cache lines
  *                                   costs the memory system less than the 1 - 2 columns the stencil's reach requires, and the
- *                                   interior kernel keeps its 16-byte alignment
+ *                                   interior kernel keeps its 16-byte alignment.  gt4mi_dist_lap5_*: effective ONLY where
+ *                                   gt4mi_dist_lap5_query reports edge_units = 0 -- where the edge units of csrc/lap5_edge.hip.h
+ *                                   run (one receiving round, I-contiguous 16-byte aligned rows) the W / E boxes are exactly one
+ *                                   16-byte lane wide on every schedule and transport, whatever this option says
  * Which combination is fastest depends on the links; bench.py measures them (config.calibration_ms_per_apply).
  *   GT4MI_PLAN_DIRECT_TIMEOUT_MS    direct transport: how long a device-side wait for a neighbour may take (milliseconds; 0 = the
- *                                   default: GT4MI_DIRECT_TIMEOUT_MS of the environment, else 30 000) before the plan FAILS, see below */
+ *                                   default: GT4MI_DIRECT_TIMEOUT_MS of the environment, else 30 000) before the plan FAILS, see below
+ *   GT4MI_PLAN_DIRECT_FENCED        direct transport, 0 (default) / 1: FENCED MODE.  By default a pushed face is ordered before its
+ *                                   flag by write-through stores + their acknowledgement, and the receiver's loads behind its flag
+ *                                   load by issue order and cache-bypassing loads -- no fence, because a system-scope release next
+ *                                   to an HBM-saturating interior kernel is expensive.  With 1 the pushing side
+ *                                   does a system-scope RELEASE fence before it raises the flag and the receiving side a system-scope
+ *                                   ACQUIRE fence behind its flag load: the ISA's own message-passing recipe, for links on which
+ *                                   the default's assumptions have not been verified.  Both sides of a message must agree only
+ *                                   in that each may be fenced or not independently (the modes interoperate); bench.py steps
+ *                                   direct -> direct-fenced -> RCCL when its epoch-stamped self-check fails. */
 enum { GT4MI_PLAN_SCHEDULE = 0, GT4MI_PLAN_INTERIOR_WG_PER_CU = 1, GT4MI_PLAN_DEFER_JOIN = 2, GT4MI_PLAN_EDGE_COLUMNS = 3,
-       GT4MI_PLAN_TRANSPORT = 4, GT4MI_PLAN_DIRECT_TIMEOUT_MS = 5 };
+       GT4MI_PLAN_TRANSPORT = 4, GT4MI_PLAN_DIRECT_TIMEOUT_MS = 5, GT4MI_PLAN_DIRECT_FENCED = 6 };
 enum { GT4MI_TRANSPORT_RCCL = 0, GT4MI_TRANSPORT_DIRECT = 1 };
 enum { GT4MI_SCHEDULE_JOIN = 0, GT4MI_SCHEDULE_CHAIN = 1, GT4MI_SCHEDULE_SWAP = 2, GT4MI_SCHEDULE_SWAP_PACKED = 3,
        GT4MI_SCHEDULE_INLINE = 4 };

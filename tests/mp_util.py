@@ -8,7 +8,8 @@ What it guarantees (round 3's driver run lost 1 799 tests to a two-rank test tha
   then WAITS for the files of the others before it leaves (a file handshake, no ``barrier`` + ``destroy_process_group`` race); a
   rank that failed leaves at once, so that the others' collectives end with an error instead of waiting for it;
 * the rendezvous is a ``FileStore`` inside the temporary directory -- no port that was free a moment ago;
-* one retry, and a retry is never silent: the failed attempt's tracebacks go into a warning that the pytest summary prints.
+* one retry, and a retry is never silent NOR free: the failed attempt's tracebacks go into a warning that the pytest summary
+  prints AND into gpurun_out/retries.jsonl, which fails the run's last test (tests/retry_log.py, tests/test_zz_retries.py).
 """
 
 from __future__ import annotations
@@ -104,6 +105,9 @@ def run_ranks(worker, world: int, tmp_path, args=(), backend: str = "gloo", time
                                      collective_seconds)
         if not problems:
             if first is not None:
+                import retry_log
+
+                retry_log.record(retry_log.current_test_id(f"{getattr(worker, '__name__', worker)}{tuple(args)!r}"), first)
                 warnings.warn(f"{getattr(worker, '__name__', worker)}{tuple(args)!r}: PASSED ONLY ON ITS RETRY; the first attempt:\n{first}")
             return results
         if first is None:

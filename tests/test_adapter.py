@@ -16,12 +16,61 @@ from gt4py_amd.cartesian.backend import hip_backend
 from gt4py_amd.cartesian.gtscript import BACKWARD, FORWARD, PARALLEL, Field, I, J, computation, horizontal, interval, region  # noqa: F401
 
 
-def N(kind, **attrs):
-    """An object whose class is called ``kind`` with the given attributes (an OIR-shaped node)."""
-    obj = type(kind, (), {})()
+import json
+import pathlib
+import re
+
+#: the reference's OIR schema as data (class -> fields incl. inherited ones, enum -> members), written by scripts/make_oir_schema.py
+#: from /root/reference/src/gt4py/cartesian/gtc/oir.py:28-360 and gtc/common.py:54-890 with `ast` (gt4py cannot be imported here)
+SCHEMA = json.loads((pathlib.Path(__file__).parent / "golden" / "oir_schema.json").read_text())
+READS = {}  # class name -> attribute names the code under test has read from nodes built here
+
+
+def raw_node(kind, **attrs):
+    """An object whose class is called ``kind`` with the given attributes -- NOT checked against the schema (nodes the reference
+    does not have, for the tests of the translator's refusals)."""
+    def reading(self, name, _kind=kind):
+        if not name.startswith("__"):
+            READS.setdefault(_kind, set()).add(name)
+        return object.__getattribute__(self, name)
+
+    obj = type(kind, (), {"__getattribute__": reading})()
     for k, v in attrs.items():
         setattr(obj, k, v)
     return obj
+
+
+def _enum_members(annotation):
+    """Members (names and values) of every schema enum the annotation text mentions, or None when it mentions none."""
+    allowed, found = set(), False
+    if re.search(r"\bstr\b", annotation):  # (Literal.value: Union[BuiltInLiteral, str] -- any string)
+        return None
+    for ident in re.findall(r"[A-Za-z_]+", annotation):
+        if ident in SCHEMA["enums"]:
+            found = True
+            for name, value in SCHEMA["enums"][ident].items():
+                allowed.add(name)
+                if value is not None:
+                    allowed.add(str(value))
+    return allowed if found else None
+
+
+def N(kind, **attrs):
+    """An OIR-shaped node, BUILT THROUGH THE SCHEMA: ``kind`` must be a node class of the reference's gtc/oir.py (or one of the
+    gtc/common.py classes OIR uses as they are), every attribute one of that class's fields (inherited ones included), every
+    required field given, and a string where the reference annotates an enum must be one of its member names or values.  The
+    hand-built trees below can therefore not drift from /root/reference/src/gt4py/cartesian/gtc/oir.py:28-360."""
+    assert kind in SCHEMA["classes"], f"{kind}: no such node class in the reference's OIR ({sorted(SCHEMA['classes'])})"
+    fields = SCHEMA["classes"][kind]["fields"]
+    unknown = set(attrs) - set(fields)
+    assert not unknown, f"{kind} has no field(s) {sorted(unknown)} in the reference (it has {sorted(fields)})"
+    missing = {n for n, f in fields.items() if f["required"]} - set(attrs)
+    assert not missing, f"{kind}: required field(s) {sorted(missing)} not given"
+    for name, value in attrs.items():
+        allowed = _enum_members(fields[name]["annotation"])
+        if allowed is not None and isinstance(value, str):
+            assert value in allowed, f"{kind}.{name} = {value!r}: not a member of {fields[name]['annotation']}"
+    return raw_node(kind, **attrs)
 
 
 F64, BOOL, I64 = "FLOAT64", "BOOL", "INT64"
@@ -199,13 +248,111 @@ def test_masks_regions_and_scalars_translate_and_run_on_the_oracle():
 
 def test_unknown_nodes_fail_loudly():
     bad = lap_oir()
-    bad.vertical_loops[0].sections[0].horizontal_executions[0].body.append(N("SomethingNew"))
+    bad.vertical_loops[0].sections[0].horizontal_executions[0].body.append(raw_node("SomethingNew"))
     with pytest.raises(adapter.UnsupportedOIR, match="SomethingNew"):
         adapter.oir_to_ir(bad)
     runtime = lap_oir()
-    runtime.vertical_loops[0].sections[0].interval.end = N("RuntimeAxisBound", level="start", offset=None)
+    runtime.vertical_loops[0].sections[0].interval.end = N("RuntimeAxisBound", level="start", offset=N("ScalarAccess", name="n", dtype="INT32"))
     with pytest.raises(adapter.UnsupportedOIR, match="run-time interval bounds"):
         adapter.oir_to_ir(runtime)
+
+
+# ---- a sequential column: local scalar, while, K iterator, variable and absolute K reads, a data dimension ------------------------
+def column_definition(a: Field[np.float64], idx: Field[np.int64], vec: Field[(np.float64, (2,))], out: Field[np.float64]):
+    with computation(FORWARD), interval(...):
+        acc = a + a.at(K=0)
+        while acc < 3.0:
+            acc = acc + 1.0
+        out = acc + K + a[0, 0, idx] + vec[0, 0, 0][1]
+
+
+def column_oir():
+    acc = lambda: N("ScalarAccess", name="acc", dtype=F64)  # noqa: E731
+    a_at_0 = N("FieldAccess", name="a", offset=N("AbsoluteKIndex", k=0), dtype=F64, data_index=[])
+    a_var = N("FieldAccess", name="a", offset=N("VariableKOffset", k=field("idx", dtype=I64)), dtype=F64, data_index=[])
+    k_as_float = N("Cast", expr=N("IteratorAccess", name="K", dtype="INT32"), dtype=F64)
+    body = [
+        assign(acc(), binop("+", field("a"), a_at_0)),
+        N("While", cond=binop("<", acc(), lit(3.0), dtype=BOOL), body=[assign(acc(), binop("+", acc(), lit(1.0)))]),
+        assign(field("out"), binop("+", binop("+", binop("+", acc(), k_as_float), a_var), field("vec", data_index=[lit(1, I64)]))),
+    ]
+    return N("Stencil", name="column", params=[fdecl("a"), fdecl("idx", dtype=I64), fdecl("vec", data_dims=(2,)), fdecl("out")],
+             declarations=[], vertical_loops=[loop("forward", section(*FULL, hexec(*body, declarations=[N("LocalScalar", name="acc", dtype=F64)])))])
+
+
+def test_a_sequential_column_with_every_kind_of_k_access_translates_and_runs_on_the_oracle():
+    stencil, order = adapter.oir_to_ir(column_oir())
+    assert order == ("a", "idx", "vec", "out")
+    rng = np.random.default_rng(11)
+    shape = (4, 3, 6)
+    a = rng.uniform(-1, 2, shape)
+    idx = rng.integers(0, 2, shape) * (np.arange(shape[2]) < shape[2] - 1)  # k + idx stays inside the column
+    vec = rng.uniform(-1, 1, shape + (2,))
+    acc = a + a[:, :, :1]
+    while (acc < 3.0).any():
+        acc = np.where(acc < 3.0, acc + 1.0, acc)
+    k = np.arange(shape[2])[None, None, :]
+    want = acc + k + np.take_along_axis(a, k + idx, axis=2) + vec[..., 1]
+    out = np.zeros(shape)
+    adapter.stencil_class_from_ir(stencil, order, backend="numpy")()(a, idx, vec, out)
+    np.testing.assert_array_equal(out, want)
+    # ... and it is what this repo's own frontend makes of the GTScript spelling
+    out2 = np.zeros(shape)
+    gtscript.stencil(backend="numpy", definition=column_definition)(a, idx, vec, out2)
+    np.testing.assert_array_equal(out2, want)
+
+
+# ---- the bridge is pinned to the reference's schema -------------------------------------------------------------------------
+def test_the_hand_built_trees_cannot_drift_from_the_references_oir_schema():
+    """`N(...)` refuses what gtc/oir.py does not have ..."""
+    with pytest.raises(AssertionError, match="no such node class"):
+        N("HorizontalLoop", body=[])
+    with pytest.raises(AssertionError, match=r"has no field\(s\) \['stages'\]"):
+        N("VerticalLoopSection", interval=N("Interval", start=bound("start"), end=bound("end")), stages=[])
+    with pytest.raises(AssertionError, match="required field"):
+        N("FieldAccess", name="a", dtype=F64)  # no offset
+    with pytest.raises(AssertionError, match="not a member"):
+        N("VerticalLoop", loop_order="sideways", sections=[])
+    with pytest.raises(AssertionError, match="not a member"):
+        binop("+=", field("a"), field("b"))
+    with pytest.raises(AssertionError, match="not a member"):
+        fdecl("a", dtype="FLOAT16")
+    # ... the schema is the one scripts/make_oir_schema.py writes from the reference's two files (checked where they exist:
+    # /root/reference does not travel to the GPU box)
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    if pathlib.Path("/root/reference/src/gt4py/cartesian/gtc/oir.py").exists():
+        proc = subprocess.run([sys.executable, str(root / "scripts" / "make_oir_schema.py"), "--check"], capture_output=True, text=True)
+        assert proc.returncode == 0, proc.stderr
+    assert {"oir.py", "common.py"} == set(SCHEMA["sources"]) and len(SCHEMA["classes"]) >= 35
+
+
+def test_the_translator_reads_only_fields_the_reference_has():
+    """... and `oir_to_ir` reads nothing else: (1) every attribute it read from a node built here, in all of this file's trees, is a
+    field of that node's class in the reference; (2) every attribute name that appears in the translator's source at all is a
+    field of SOME OIR class or a member of the Python enum protocol (`name` / `value`)."""
+    import ast
+    import inspect
+
+    READS.clear()
+    for tree in (lap_oir(), tridiagonal_oir(), features_oir(), column_oir()):
+        adapter.oir_to_ir(tree)
+    assert {"Stencil", "VerticalLoop", "VerticalLoopSection", "HorizontalExecution", "Interval", "AxisBound", "FieldAccess", "CartesianOffset",
+            "VariableKOffset", "AbsoluteKIndex", "IteratorAccess", "LocalScalar", "While", "MaskStmt", "HorizontalRestriction",
+            "HorizontalMask", "HorizontalInterval", "Cast", "NativeFuncCall", "Temporary", "ScalarDecl", "FieldDecl"} <= set(READS)
+    for kind, names in READS.items():
+        # (`name` / `value` probes of `_enum_name` / `_enum_value` on things that may be enums are the enum protocol, not OIR fields)
+        extra = names - set(SCHEMA["classes"][kind]["fields"]) - {"name", "value"}
+        assert not extra, f"oir_to_ir read {sorted(extra)} from a {kind}: the reference's class has {sorted(SCHEMA['classes'][kind]['fields'])}"
+    every_field = {f for c in SCHEMA["classes"].values() for f in c["fields"]} | {"name", "value"}
+    source = ast.parse(inspect.getsource(adapter._Translator))
+    node_vars = {"e", "off", "stmt", "decl", "loop", "section", "hexec", "local", "st", "b", "iv", "left", "d", "t", "level"}
+    read = {n.attr for n in ast.walk(source) if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name) and n.value.id in node_vars}
+    read |= {n.attr for n in ast.walk(source) if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Attribute)
+             and isinstance(n.value.value, ast.Name) and n.value.value.id in node_vars}  # stmt.mask.i, section.interval.start
+    assert read and not (read - every_field), f"attribute(s) {sorted(read - every_field)} are fields of no class of the reference's OIR"
 
 
 def test_registration_needs_a_real_gt4py():

@@ -179,7 +179,7 @@ def test_the_calibration_order_puts_the_north_stars_rccl_forms_first():
     assert all(n.endswith("_direct") for n in h_direct(None)) and "fused_two_phase_inline_wg0_edge32_direct" in h_direct(None)
 
 
-def _calibration_worker(rank: int, world: int, tmpdir: str, rccl_seconds: float, canary_says):
+def _calibration_worker(rank: int, world: int, tmpdir: str, rccl_seconds: float, canary_says, join_fails_when="unfenced", direct_seconds=1.0):
     import torch.distributed as dist
 
     ctx = {"world": world, "rank": rank, "distributed": True, "dist": dist, "device": "cpu"}
@@ -188,16 +188,16 @@ def _calibration_worker(rank: int, world: int, tmpdir: str, rccl_seconds: float,
 
     def measure(cand):  # a candidate costs 0.25 s on the slow rank; its "time" is a function of the candidate alone
         time.sleep(0.25 if rank == 1 else 0.02)
-        measured.append(bench.lap_key(cand))
-        if cand[4] == "direct" and cand[2] == "join":
-            return None  # (a form that fails: the direct transport is dropped from there on)
+        measured.append(bench.lap_key(cand) + ("/fenced" if cand[4] == "direct" and bench.direct_fenced(ctx) else ""))
+        if cand[4] == "direct" and cand[2] == "join" and (join_fails_when == "always" or not bench.direct_fenced(ctx)):
+            return None  # (a form that fails, e.g. wrong results under the epoch-stamped check: one rung down the ladder)
         return round(0.1 + 0.01 * (zlib.crc32(bench.lap_key(cand).encode()) % 7) - (0.05 if cand[4] == "direct" and cand[2] == "inline" else 0.0), 5)
 
     table, stats = {}, {"run": 0, "skipped_for_time": 0, "failed": []}
     canary, transports = bench.calibrate_laplacian(ctx, (1, 2), grids, (False, True), ("rccl", "direct"), measure, (lambda: canary_says),
-                                                   rccl_seconds, 1.0, table, stats)
+                                                   rccl_seconds, direct_seconds, table, stats)
     return {"table": table, "stats": stats, "measured": measured, "canary": canary, "transports": list(transports),
-            "keys": bench.calibration_line_keys(table, stats), "dropped": ctx.get("direct_dropped")}
+            "keys": bench.calibration_line_keys(table, stats, ctx), "dropped": ctx.get("direct_dropped")}
 
 
 @pytest.mark.multiprocess
@@ -215,10 +215,41 @@ def test_a_small_budget_still_yields_an_overlapped_rccl_headline_on_every_rank_a
     assert 3 <= len(rccl_run) <= 7  # 1.2 s at 0.25 s per candidate on the slow rank
     assert keys["rccl_best_ms_per_apply"] is not None and keys["rccl_best_form"].split("_")[2] in ("swap", "join")
     assert keys["calibration_candidates_skipped_for_time"] > 0 and keys["calibration_candidates_run"] == len(m)
-    # the direct transport had its own second: "inline" first; the form that failed dropped the rest of it
-    direct_run = [k for k in m if k.endswith("_direct")]
+    # the direct transport had its own second: "inline" first
+    direct_run = [k for k in m if "_direct" in k]
     assert direct_run and direct_run[0].split("_")[2] == "inline" and keys["direct_best_ms_per_apply"] < keys["rccl_best_ms_per_apply"]
     assert got[0]["canary"] is True and got[0]["transports"] == ["rccl", "direct"]
+
+
+@pytest.mark.multiprocess
+def test_a_direct_form_that_fails_moves_every_rank_down_the_ladder(tmp_path):
+    """direct -> direct-fenced -> rccl.  A form of the direct transport that fails on some rank -- wrong
+    results under the epoch-stamped check, a timeout, a set-up error: `measure` returns None on every rank alike -- ends the direct
+    stage, switches every rank to the fenced mode, throws away what was measured without fences and runs the stage again; the line
+    says so.  A form that fails WITH fences drops the transport, and nothing it measured can become the headline."""
+    from mp_util import run_ranks
+
+    got = run_ranks(_calibration_worker, 2, tmp_path, args=(0.3, True, "unfenced", 30.0))
+    assert got[0]["measured"] == got[1]["measured"] and got[0]["table"] == got[1]["table"]
+    m, keys = got[0]["measured"], got[0]["keys"]
+    direct = [k for k in m if "_direct" in k]
+    first_fenced = next(i for i, k in enumerate(direct) if k.endswith("/fenced"))
+    # unfenced up to the first "join" (which failed), then the WHOLE stage again with fences -- the failed form included, and passing
+    assert direct[first_fenced - 1].split("_")[2] == "join" and not any(k.endswith("/fenced") for k in direct[:first_fenced])
+    assert all(k.endswith("/fenced") for k in direct[first_fenced:]) and direct[first_fenced].split("_")[2] == "inline"
+    assert any(k.split("_")[2] == "join" for k in direct[first_fenced:]) or keys["calibration_candidates_skipped_for_time"] > 0
+    assert keys["direct_transport_mode"] == "direct-fenced" and got[0]["dropped"] is None and got[0]["transports"] == ["rccl", "direct"]
+    assert [(s["from"], s["to"]) for s in keys["direct_transport_ladder"]] == [("direct", "direct-fenced")]
+    assert keys["direct_transport_ladder"][0]["at"].endswith("_join_wg0_direct") and keys["calibration_candidates_failed"] == []
+    assert keys["calibration_candidates_failed_unfenced"] == [keys["direct_transport_ladder"][0]["at"]]
+    assert keys["direct_best_ms_per_apply"] is not None  # (measured with fences)
+
+    got = run_ranks(_calibration_worker, 2, tmp_path / "always", args=(0.3, True, "always", 30.0))
+    keys = got[0]["keys"]
+    assert got[0]["table"] == got[1]["table"] and all(k.endswith("_rccl") for k in got[0]["table"])
+    assert keys["direct_transport_mode"] == "rccl" and got[0]["dropped"].endswith("_join_wg0_direct") and got[0]["transports"] == ["rccl"]
+    assert [(s["from"], s["to"]) for s in keys["direct_transport_ladder"]] == [("direct", "direct-fenced"), ("direct-fenced", "rccl")]
+    assert keys["direct_best_ms_per_apply"] is None and got[0]["stats"]["measured_before_the_drop"]
 
 
 @pytest.mark.multiprocess
@@ -228,6 +259,7 @@ def test_a_failed_canary_keeps_the_calibration_on_rccl(tmp_path):
     got = run_ranks(_calibration_worker, 2, tmp_path, args=(30.0, False))
     assert got[0]["canary"] is False and got[0]["transports"] == ["rccl"] and got[0]["keys"]["direct_best_ms_per_apply"] is None
     assert all(k.endswith("_rccl") for k in got[0]["measured"]) and got[0]["keys"]["calibration_candidates_skipped_for_time"] == 0
+    assert got[0]["keys"]["direct_transport_mode"] == "direct" and got[0]["keys"]["direct_transport_ladder"] == []  # (the canary is the caller's: bench.direct_canary records its own steps)
     # with time to spare every RCCL candidate of the order ran: both grids, both tables, the throttles on the best grid
     assert {k.split("_")[0] for k in got[0]["measured"]} == {"1x2", "2x1"} and any("_wg4_" in k for k in got[0]["measured"])
 

@@ -795,3 +795,82 @@ def test_direct_transport_wiring_on_whole_process_grids(grid, periodic, halo, si
                 have[r][box(lo, ext)] = pool[(r, j)]
     for r in range(n):
         assert np.array_equal(have[r], want[r]), r
+
+
+# ---- the epoch-stamped self-check ------------------------------------------------------------------
+class _HostField:
+    """What FormCheck needs of a field: a `.tensor`."""
+
+    def __init__(self, shape):
+        import torch
+
+        self.tensor = torch.zeros(shape, dtype=torch.float64)
+
+
+def _wrap_ghost_cells(t, h):
+    """A correct exchange of a periodic world of ONE rank, in place: every ghost cell takes the value of the point it wraps to."""
+    t[:h], t[-h:] = t[-2 * h:-h].clone(), t[h:2 * h].clone()
+    t[:, :h], t[:, -h:] = t[:, -2 * h:-h].clone(), t[:, h:2 * h].clone()
+
+
+@pytest.mark.parametrize("halo", [1, 2])
+def test_every_round_of_the_form_check_can_see_a_receive_buffer_read_too_early(halo):
+    """`FormCheck` advances an EPOCH on every reset: F(global i, j, k) + 65 536 x epoch.  A transport whose receive side hands out
+    what the PREVIOUS exchange left in its buffer -- the round-3 defect of the direct transport -- produced exactly the right
+    values round after round as long as the probe never changed; only the first exchange of a plan (empty buffers) could show
+    it.  Modelled here on the CPU: an "exchange" that delivers the ghost values of one round earlier passes the epoch-less check
+    from the second round on and fails the epoch-stamped one in EVERY round, the verdict naming the stale values."""
+    import torch
+
+    from gt4py_amd.distributed import Decomposition
+    from gt4py_amd.distributed.selfcheck import EPOCH_STEP, SENTINEL, FormCheck, coordinate_values
+
+    dec = Decomposition((12, 10, 3), (1, 1), 0, halo=halo, periodic=(True, True))
+    h = halo
+
+    def local(a, b):  # a stand-in stencil that reads every ghost cell a 5-point (or wider) stencil reads
+        t, o = a.tensor, b.tensor
+        o.zero_()
+        o[h:-h, h:-h] = t[h:-h, h:-h] + 0.5 * (t[:-2 * h, h:-h] + t[2 * h:, h:-h] + t[h:-h, :-2 * h] + t[h:-h, 2 * h:])
+
+    chk = FormCheck(dec, (lambda: _HostField(dec.local_shape)), local)
+    assert chk.ghost_cells_to_fill == (12 + 2 * h) * (10 + 2 * h) * 3 - 12 * 10 * 3
+
+    def correct():
+        _wrap_ghost_cells(chk.probe.tensor, h)
+        local(chk.probe, chk.out)
+
+    ok, found = chk.check(correct, rounds=4, loaded=1)
+    assert ok and "4 epochs" in found and chk.epoch == 4 and chk.rounds_checked == 4
+    # two epochs share no value: whatever a round leaves anywhere is wrong in the next one, everywhere
+    own1, exp1 = coordinate_values(dec, epoch=1)
+    own2, exp2 = coordinate_values(dec, epoch=2)
+    assert torch.equal(exp2 - exp1, torch.full_like(exp1, EPOCH_STEP)) and not set(exp1.flatten().tolist()) & set(exp2.flatten().tolist())
+    assert torch.equal(own2[h:-h, h:-h], exp2[h:-h, h:-h]) and int((own2 == SENTINEL).sum()) == chk.ghost_cells_to_fill
+
+    # the stale transport: ghost cells of THIS round come from the buffer the previous round filled
+    buffers = {"held": None}
+
+    def stale():
+        t = chk.probe.tensor
+        fresh = t.clone()
+        _wrap_ghost_cells(fresh, h)
+        if buffers["held"] is None:  # the first exchange of the plan: nothing stale to hand out yet -- it waits and is correct
+            t.copy_(fresh)
+        else:
+            mine = torch.zeros_like(t, dtype=torch.bool)
+            mine[h:-h, h:-h] = True
+            t.copy_(torch.where(mine, t, buffers["held"]))
+        buffers["held"] = fresh
+        local(chk.probe, chk.out)
+
+    verdicts = [chk.check(stale, rounds=1, loaded=0) for _ in range(4)]
+    assert verdicts[0][0] is True  # (only round 0 of the epoch-less check could ever see it -- and it did not have to)
+    for ok, found in verdicts[1:]:
+        assert not ok and f"{chk.ghost_cells_to_fill} cells of the exchanged field differ" in found
+        assert f"[{chk.ghost_cells_to_fill} of them hold the previous epoch's value" in found and ", 0 points of the result" not in found
+    # ... which the same check WITHOUT the epoch (the round-4 form) accepts: the stale payload is the right answer
+    own0, exp0 = coordinate_values(dec)
+    t = own0.clone()
+    _wrap_ghost_cells(t, h)
+    assert torch.equal(t, exp0)  # round n's buffer content == round n + 1's expectation when the probe never changes

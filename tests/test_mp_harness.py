@@ -47,12 +47,28 @@ def _fails_once(rank: int, world: int, out_dir: str, marker: str):
     return rank
 
 
-def test_a_pass_on_the_retry_is_never_silent(tmp_path):
+def test_a_pass_on_the_retry_is_never_silent_nor_free(tmp_path, monkeypatch):
+    """... it is a warning in the summary AND an entry in the retry log, which fails the run's last test (tests/retry_log.py).
+    (This test's own, deliberate retry goes to a log of its own.)"""
+    import retry_log
+    import test_zz_retries
+
+    monkeypatch.setenv("GT4MI_RETRY_LOG", str(tmp_path / "retries.jsonl"))
+    monkeypatch.delenv("GT4MI_ALLOW_RETRY", raising=False)
+    assert retry_log.fired() == []
+    test_zz_retries._check()  # nothing fired: passes
     with warnings.catch_warnings(record=True) as seen:
         warnings.simplefilter("always")
         assert mp_util.run_ranks(_fails_once, 2, tmp_path, args=(str(tmp_path / "marker"),)) == {0: 0, 1: 1}
     text = "\n".join(str(w.message) for w in seen)
     assert "PASSED ONLY ON ITS RETRY" in text and "the first attempt fails on rank 1" in text
+    fired = retry_log.fired()
+    assert len(fired) == 1 and "test_a_pass_on_the_retry_is_never_silent_nor_free" in fired[0]["test"]
+    assert "the first attempt fails on rank 1" in fired[0]["first_attempt"]
+    with pytest.raises(pytest.fail.Exception, match="passed only on their retry"):
+        test_zz_retries._check()
+    monkeypatch.setenv("GT4MI_ALLOW_RETRY", "1")
+    test_zz_retries._check()  # accepted explicitly
 
 
 def test_the_last_failure_fails_the_test_with_every_ranks_traceback(tmp_path):

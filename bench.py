@@ -55,9 +55,35 @@ HDIFF_GLOBAL = (2048, 2048, 80)
 # how long a device-side wait of the direct transport may take in THIS program before its plan fails (the library's default is
 # 30 s): a broken direct transport costs the calibration this much per wait, then its forms are dropped
 DIRECT_TIMEOUT_MS = int(os.environ.get("GT4MI_BENCH_DIRECT_TIMEOUT_MS", "2000"))
-KERNEL_SOURCES = {  # the files whose contents decide what a kernel does, per profiled workload
-    "lap5_f64_512": ("gt4py_amd/csrc/lap5.hip.h", "gt4py_amd/csrc/lane_shift.hip.h", "gt4py_amd/csrc/common.hip.h",
-                     "gt4py_amd/csrc/Makefile"),
+_LAP_SOURCES = ("gt4py_amd/csrc/lap5.hip.h", "gt4py_amd/csrc/lane_shift.hip.h", "gt4py_amd/csrc/common.hip.h", "gt4py_amd/csrc/Makefile")
+_HDIFF_SOURCES = ("gt4py_amd/csrc/hdiff.hip.h", "gt4py_amd/csrc/hdiff_jmarch.hip.h", "gt4py_amd/csrc/lane_shift.hip.h",
+                  "gt4py_amd/csrc/common.hip.h", "gt4py_amd/csrc/Makefile")
+_TRIDIAG_SOURCES = ("gt4py_amd/csrc/tridiag.hip.h", "gt4py_amd/csrc/tridiag_stack.hip.h", "gt4py_amd/csrc/common.hip.h", "gt4py_amd/csrc/Makefile")
+_GENERATED_SOURCES = ("gt4py_amd/cartesian/backend/hip_codegen.py", "gt4py_amd/cartesian/backend/stage_planner.py",
+                      "gt4py_amd/cartesian/backend/hip_generic.py", "gt4py_amd/csrc/rtc.hip.h")
+KERNEL_SOURCES = {  # the files whose contents decide what a kernel does, per profiled workload (the keys of profiles/hbm_traffic.json)
+    "lap5_f64_512": _LAP_SOURCES,
+    "laplacian_f64_512x512x128_config1": _LAP_SOURCES,
+    "hdiff_limiter_f32_1024x1024x80": _HDIFF_SOURCES,
+    "hdiff_limiter_f32_literal32_1024x1024x80": _HDIFF_SOURCES,
+    "hdiff_limiter_f64_512x1024x80": _HDIFF_SOURCES,
+    "tridiagonal_f64_1024x1024x160": _TRIDIAG_SOURCES,
+    "generated_vertical_advection_f64_1024x1024x160": _GENERATED_SOURCES,
+    "generated_laplacian_f64_512x512x512": _GENERATED_SOURCES,
+    "generated_hdiff_limiter_f64_512x1024x80": _GENERATED_SOURCES,
+}
+# which kernel of a rocprofv3 trace belongs to which workload: a substring of the demangled name (the two Laplacian workloads run
+# the same instantiation: scripts/profile_all_kernels.sh profiles them in separate processes)
+KERNEL_NEEDLES = {
+    "lap5_f64_512": "lap5_strip_kernel<double, double",
+    "laplacian_f64_512x512x128_config1": "lap5_strip_kernel<double, double",
+    "hdiff_limiter_f32_1024x1024x80": "hdiff_jmarch_kernel<float, double, double",
+    "hdiff_limiter_f32_literal32_1024x1024x80": "hdiff_jmarch_kernel<float, float, float",
+    "hdiff_limiter_f64_512x1024x80": "hdiff_jmarch_kernel<double, double, double",
+    "tridiagonal_f64_1024x1024x160": "tridiag_",
+    "generated_vertical_advection_f64_1024x1024x160": "gt4mi__vertical_advection_dycore_stage",
+    "generated_laplacian_f64_512x512x512": "gt4mi_lap_notebook_stage",
+    "generated_hdiff_limiter_f64_512x1024x80": "gt4mi_hdiff_limiter_field_stage",
 }
 
 
@@ -232,9 +258,12 @@ def host_cost_per_call(lap, n: int = 300):
     return res
 
 
-def other_kernels(steps: int = 20):
+def other_kernels(steps: int = 20, only=None):
     """The other kernels of the north star at their BASELINE.json sizes, through the same call path
-    (storage -> stencil -> FrozenStencil), HIP-event timed.  Informational: `value` stays the Laplacian."""
+    (storage -> stencil -> FrozenStencil), HIP-event timed.  Informational: `value` stays the Laplacian.  Every entry carries
+    its own `roofline` object: `traffic` = HBM bytes per launch from the committed rocprofv3 PMC measurement of THIS tree's
+    kernel sources (profiles/hbm_traffic.json, written by scripts/profile_all_kernels.sh; null when the sources have changed
+    since).  `only`: a collection of entry names (the profiling script runs subsets in separate processes)."""
     import numpy as np
     import torch
 
@@ -250,6 +279,9 @@ def other_kernels(steps: int = 20):
         return f
 
     out = {}
+
+    def wanted(name):
+        return only is None or name in only
 
     def run(name, obj, fields, origin, domain, bytes_per_lup, scalars=None, note=None):
         frozen = obj.freeze(origin=origin, domain=domain)
@@ -274,26 +306,32 @@ def other_kernels(steps: int = 20):
         ms = t["mean"]
         lups = float(np.prod(domain))
         gbs = bytes_per_lup * lups / (ms * 1e-3) / 1e9
+        traffic, traffic_source = _committed_traffic(name)
         out[name] = {"domain": list(domain), "ms": round(ms, 4), "ms_median": round(t["median"], 4), "ms_min": round(t["min"], 4),
                      "launches_timed": t["n"], "glups": round(lups / ms / 1e6, 1), "algorithmic_bytes_per_lup": bytes_per_lup,
-                     "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4)}
+                     "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4),
+                     "roofline": {"bound": "hbm", "kernel": KERNEL_NEEDLES.get(name), "achieved": round(gbs, 1), "peak": PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(gbs / PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                                  "algorithmic_bytes_per_launch": bytes_per_lup * lups,
+                                  "traffic_over_algorithmic": round(traffic / (bytes_per_lup * lups), 4) if traffic else None}}
         if note:
             out[name]["note"] = note
 
     # BASELINE.json configs[1] as named: 512 x 512 x 128 fp64.  One field is 285 MB with its halo -- about the size of the
     # 256 MB Infinity Cache -- so the launches rotate over FOUR (inp, out) pairs (2.3 GB; SURVEY.md section 8d asks for >= 3):
     # nothing a launch reads or writes can still be cache-resident from its previous turn.
-    dom = (512, 512, 128)
-    lap_obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
-                               device_sync=False)
-    shape = (dom[0] + 2, dom[1] + 2, dom[2])
-    sets = [{"inp": field(shape, np.float64, (1, 1, 0)), "out": field(shape, np.float64, (1, 1, 0))} for _ in range(4)]
-    run("laplacian_f64_512x512x128_config1", lap_obj, sets, {k: (1, 1, 0) for k in ("inp", "out")}, dom, 16.0,
-        note="BASELINE.json configs[1] at its own size, four rotating (inp, out) pairs = 2.3 GB so that the 256 MB Infinity "
-             "Cache cannot serve repeats; the headline `value` is the same kernel on 512^3")
-    out["laplacian_f64_512x512x128_config1"]["rotating_pairs"] = len(sets)
-    del sets
-    torch.cuda.empty_cache()
+    if wanted("laplacian_f64_512x512x128_config1"):
+        dom = (512, 512, 128)
+        lap_obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
+                                   device_sync=False)
+        shape = (dom[0] + 2, dom[1] + 2, dom[2])
+        sets = [{"inp": field(shape, np.float64, (1, 1, 0)), "out": field(shape, np.float64, (1, 1, 0))} for _ in range(4)]
+        run("laplacian_f64_512x512x128_config1", lap_obj, sets, {k: (1, 1, 0) for k in ("inp", "out")}, dom, 16.0,
+            note="BASELINE.json configs[1] at its own size, four rotating (inp, out) pairs = 2.3 GB so that the 256 MB Infinity "
+                 "Cache cannot serve repeats; the headline `value` is the same kernel on 512^3")
+        out["laplacian_f64_512x512x128_config1"]["rotating_pairs"] = len(sets)
+        del sets
+        torch.cuda.empty_cache()
 
     for tag, dt, dom, lit, note in (
             ("hdiff_limiter_f32_1024x1024x80", np.float32, (1024, 1024, 80), 64,
@@ -303,6 +341,8 @@ def other_kernels(steps: int = 20):
              "the same stencil built with literal_float_precision=32: float32 throughout (what a model that runs in "
              "single precision sets); different arithmetic, so a different stencil -- shown next to the default"),
             ("hdiff_limiter_f64_512x1024x80", np.float64, HDIFF_SHARE, 64, "the per-rank share of BASELINE.json configs[4]")):
+        if not wanted(tag):
+            continue
         obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": dt},
                                device_sync=False, literal_float_precision=lit)
         shape = (dom[0] + 4, dom[1] + 4, dom[2])
@@ -310,59 +350,113 @@ def other_kernels(steps: int = 20):
                   "out_field": field(shape, dt, (2, 2, 0))}
         run(tag, obj, fields, {k: (2, 2, 0) for k in fields}, dom, 3.0 * np.dtype(dt).itemsize, note=note)
         del fields
-    dom = (1024, 1024, 160)
-    obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64},
-                           device_sync=False)
-    fields = {"inf": field(dom, np.float64, (0, 0, 0)), "diag": field(dom, np.float64, (0, 0, 0), 4.0, 5.0),
-              "sup": field(dom, np.float64, (0, 0, 0)), "rhs": field(dom, np.float64, (0, 0, 0), -10.0, 10.0),
-              "out": field(dom, np.float64, (0, 0, 0))}
-    run("tridiagonal_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 56.0,
-        note="measured range over the boxes of rounds 1-3: 0.60-0.73 of the HBM peak (84-104 GLUPS; the K-strided column "
-             "kernels are the only ones whose speed depends on the box, +-10 %: address translation, "
-             "profiles/r2_tridiag_translation_counters.txt); a 4-read / 3-write streaming kernel reaches 0.71 "
-             "(profiles/r3_microbench_rw_mix.log).  The backward sweep re-reads the part of sup', rhs' that does not fit on chip (144 of 160 levels stay in "
-             "registers + LDS): 57.6 B/LUP moved (PMC, profiles/r2_kernel_hbm_traffic_pmc.txt); inputs are whatever the previous launch left "
-             "in sup/rhs (timing only, values are checked in tests/)")
-    out["tridiagonal_f64_1024x1024x160"]["field_addresses_mod_4MiB"] = [int(f.ptr % (4 << 20)) for f in fields.values()]
-    del fields
-    torch.cuda.empty_cache()
+    if wanted("tridiagonal_f64_1024x1024x160"):
+        out.update(_tridiagonal_entry(field, steps))
+        torch.cuda.empty_cache()
 
     # the generic executor (stencils outside the three kernel families are compiled, not rejected): the reference's
     # vertical advection and the Laplacian again, this time through the code generator
-    dom = (1024, 1024, 160)
-    obj = gtscript.stencil(backend="hip:mi300", definition=_vertical_advection_dycore, externals={"BET_M": 0.5, "BET_P": 0.5},
-                           device_sync=False)
-    shape = (dom[0] + 1, dom[1], dom[2] + 1)
-    fields = {n: field(shape, np.float64, (0, 0, 0)) for n in ("utens_stage", "u_stage", "wcon", "u_pos", "utens")}
-    run("generated_vertical_advection_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 48.0,
-        scalars={"dtr_stage": 3.0 / 20.0},
-        note="one generated column kernel (forward + backward sweep); 5 fields read, 1 written; the forward sweep's "
-             "ccol / dcol are read back by the backward sweep: the top 144 of 160 levels stay in registers + LDS "
-             "(stage_planner.TopCache, 104 + 40), the rest makes a round trip through scratch and u_pos is read by both "
-             "sweeps: 61 B/LUP moved for 48 algorithmic (PMC, profiles/r2_kernel_hbm_traffic_pmc.txt)")
-    del fields
-    torch.cuda.empty_cache()
-    dom = (512, 512, 512)
-    obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
-                           device_sync=False, use_kernel_library=False)
-    shape = (dom[0] + 2, dom[1] + 2, dom[2])
-    fields = {"inp": field(shape, np.float64, (1, 1, 0)), "out": field(shape, np.float64, (1, 1, 0))}
-    run("generated_laplacian_f64_512x512x512", obj, fields, {k: (1, 1, 0) for k in fields}, dom, 16.0,
-        note="the headline stencil through the code generator instead of the hand-written kernel")
-    del fields
-    torch.cuda.empty_cache()
-    dom = HDIFF_SHARE
-    obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64},
-                           device_sync=False, use_kernel_library=False)
-    shape = (dom[0] + 4, dom[1] + 4, dom[2])
-    fields = {"in_field": hdiff_input(shape, np.float64, gen), "coeff": field(shape, np.float64, (2, 2, 0), 0.025, 0.025),
-              "out_field": field(shape, np.float64, (2, 2, 0))}
-    run("generated_hdiff_limiter_f64_512x1024x80", obj, fields, {k: (2, 2, 0) for k in fields}, dom, 24.0,
-        note="the flux-limited horizontal diffusion through the code generator: one strip kernel, lap / flx / fly computed "
-             "once per point and passed between lanes with DPP shifts (hip_codegen._emit_shared_kernel)")
-    del fields
-    torch.cuda.empty_cache()
+    if wanted("generated_vertical_advection_f64_1024x1024x160"):
+        dom = (1024, 1024, 160)
+        obj = gtscript.stencil(backend="hip:mi300", definition=_vertical_advection_dycore, externals={"BET_M": 0.5, "BET_P": 0.5},
+                               device_sync=False)
+        shape = (dom[0] + 1, dom[1], dom[2] + 1)
+        fields = {n: field(shape, np.float64, (0, 0, 0)) for n in ("utens_stage", "u_stage", "wcon", "u_pos", "utens")}
+        run("generated_vertical_advection_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 48.0,
+            scalars={"dtr_stage": 3.0 / 20.0},
+            note="one generated column kernel (forward + backward sweep); 5 fields read, 1 written; the forward sweep's "
+                 "ccol / dcol are read back by the backward sweep: the top 144 of 160 levels stay in registers + LDS "
+                 "(stage_planner.TopCache, 104 + 40), the rest makes a round trip through scratch and u_pos is read by both "
+                 "sweeps (8 of the excess bytes per lattice update, by construction: DESIGN.md section 4b)")
+        del fields
+        torch.cuda.empty_cache()
+    if wanted("generated_laplacian_f64_512x512x512"):
+        dom = (512, 512, 512)
+        obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
+                               device_sync=False, use_kernel_library=False)
+        shape = (dom[0] + 2, dom[1] + 2, dom[2])
+        fields = {"inp": field(shape, np.float64, (1, 1, 0)), "out": field(shape, np.float64, (1, 1, 0))}
+        run("generated_laplacian_f64_512x512x512", obj, fields, {k: (1, 1, 0) for k in fields}, dom, 16.0,
+            note="the headline stencil through the code generator instead of the hand-written kernel")
+        del fields
+        torch.cuda.empty_cache()
+    if wanted("generated_hdiff_limiter_f64_512x1024x80"):
+        dom = HDIFF_SHARE
+        obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64},
+                               device_sync=False, use_kernel_library=False)
+        shape = (dom[0] + 4, dom[1] + 4, dom[2])
+        fields = {"in_field": hdiff_input(shape, np.float64, gen), "coeff": field(shape, np.float64, (2, 2, 0), 0.025, 0.025),
+                  "out_field": field(shape, np.float64, (2, 2, 0))}
+        run("generated_hdiff_limiter_f64_512x1024x80", obj, fields, {k: (2, 2, 0) for k in fields}, dom, 24.0,
+            note="the flux-limited horizontal diffusion through the code generator: one strip kernel, lap / flx / fly computed "
+                 "once per point and passed between lanes with DPP shifts (hip_codegen._emit_shared_kernel)")
+        del fields
+        torch.cuda.empty_cache()
     return out
+
+
+def _tridiagonal_entry(field, steps: int):
+    """BASELINE.json configs[3]: the vertical tridiagonal solve on 1024 x 1024 x 160 fp64, timed on the SURVEY section 8d inputs
+    EVERY launch: the solve overwrites `sup` and `rhs` in place, so each launch is preceded by a restore of both from pristine
+    copies -- outside the timed interval (an event pair around every launch; the kernel runs 1.6 ms, an event costs microseconds)
+    -- and the launches rotate over TWO sets of the five fields.  (Rounds 1-4 timed it on whatever the previous launch had left in
+    sup / rhs: after hundreds of forward sweeps no longer the specified operands)  The speed of this
+    kernel depends on the allocation set (0.60-0.73 of the peak, profiles/r4_tridiag_translation.txt): both sets are reported."""
+    import numpy as np
+    import torch
+
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_templates
+
+    name, dom = "tridiagonal_f64_1024x1024x160", (1024, 1024, 160)
+    obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64},
+                           device_sync=False)
+    sets = [{"inf": field(dom, np.float64, (0, 0, 0)), "diag": field(dom, np.float64, (0, 0, 0), 4.0, 5.0),
+             "sup": field(dom, np.float64, (0, 0, 0)), "rhs": field(dom, np.float64, (0, 0, 0), -10.0, 10.0),
+             "out": field(dom, np.float64, (0, 0, 0))} for _ in range(2)]
+    pristine = [{k: fs[k].tensor.clone() for k in ("sup", "rhs")} for fs in sets]
+    frozen = obj.freeze(origin={k: (0, 0, 0) for k in sets[0]}, domain=dom)
+
+    def restore(i):
+        fs, keep = sets[i % 2], pristine[i % 2]
+        fs["sup"].tensor.copy_(keep["sup"])
+        fs["rhs"].tensor.copy_(keep["rhs"])
+
+    for i in range(4):  # warm-up: both sets, clocks
+        restore(i)
+        frozen(**sets[i % 2])
+    torch.cuda.synchronize()
+    n = max(int(steps), 20)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i, (a, b) in enumerate(pairs):
+        restore(i)
+        a.record()
+        frozen(**sets[i % 2])
+        b.record()
+    torch.cuda.synchronize()
+    per = [a.elapsed_time(b) for a, b in pairs]
+    ms = sum(per) / len(per)
+    by_set = [sum(per[s::2]) / len(per[s::2]) for s in (0, 1)]
+    lups = float(np.prod(dom))
+    gbs = 56.0 * lups / (ms * 1e-3) / 1e9
+    traffic, traffic_source = _committed_traffic(name)
+    entry = {"domain": list(dom), "ms": round(ms, 4), "ms_median": round(statistics.median(per), 4), "ms_min": round(min(per), 4),
+             "launches_timed": n, "glups": round(lups / ms / 1e6, 1), "algorithmic_bytes_per_lup": 56.0,
+             "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_GBS, 4),
+             "ms_by_allocation_set": [round(v, 4) for v in by_set],
+             "frac_of_hbm_peak_by_allocation_set": [round(56.0 * lups / (v * 1e-3) / 1e9 / PEAK_GBS, 4) for v in by_set],
+             "field_addresses_mod_4MiB": [[int(f.ptr % (4 << 20)) for f in fs.values()] for fs in sets],
+             "inputs": "SURVEY.md section 8d (diag ~ U[4, 5), inf, sup ~ U[-1, 1), rhs ~ U[-10, 10)), sup and rhs restored from "
+                       "pristine copies before EVERY launch, outside the timed interval; two rotating sets of the five fields",
+             "roofline": {"bound": "hbm", "kernel": KERNEL_NEEDLES.get(name), "achieved": round(gbs, 1), "peak": PEAK_GBS, "unit": "GB/s",
+                          "frac": round(gbs / PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                          "algorithmic_bytes_per_launch": 56.0 * lups,
+                          "traffic_over_algorithmic": round(traffic / (56.0 * lups), 4) if traffic else None},
+             "note": "the K-strided column kernels are the only ones whose speed depends on the allocation set (0.60-0.73 of the HBM "
+                     "peak over the boxes and sets of rounds 1-4: address translation, profiles/r4_tridiag_translation.txt); a 4-read / "
+                     "3-write streaming kernel reaches 0.71 (profiles/r3_microbench_rw_mix.log).  The backward sweep re-reads the part "
+                     "of sup', rhs' that does not fit on chip (144 of 160 levels stay in registers + LDS)"}
+    return {name: entry}
 
 
 def _vertical_advection_dycore(utens_stage: Field[np.float64], u_stage: Field[np.float64], wcon: Field[np.float64],  # noqa: F821
@@ -1396,8 +1490,11 @@ def main() -> None:
         # hold theirs, and with shares of 512 levels three ranks that run a kernel ahead of the fourth fill every slot of the chip
         # with waiting units -- the fourth never gets to push (seen at N = 4 on the 4 x 1 grid: a resource deadlock that a device
         # per rank cannot have).  A slab of 32 levels keeps all ranks' units together below the chip's 1 280 workgroup slots.
-        global GRID
-        GRID = (GRID[0], GRID[1], int(os.environ.get("GT4MI_BENCH_ONE_DEVICE_LEVELS", "32")))
+        global GRID, HDIFF_SHARE, HDIFF_GLOBAL
+        levels = int(os.environ.get("GT4MI_BENCH_ONE_DEVICE_LEVELS", "32"))
+        GRID = (GRID[0], GRID[1], levels)
+        # (configs[4]'s share likewise: eight full-size shares on one device took 17-96 s per candidate in round 4)
+        HDIFF_SHARE, HDIFF_GLOBAL = (HDIFF_SHARE[0], HDIFF_SHARE[1], levels), (HDIFF_GLOBAL[0], HDIFF_GLOBAL[1], levels)
     torch.cuda.set_device(local_rank)
     # GT4MI_BENCH_FORCE_DISTRIBUTED=1: take the N > 1 code path with a world of ONE rank (process group, collectives,
     # communicator through the broadcast, calibration, line keys) -- the rehearsal a 1-GPU box allows of everything in that
@@ -1406,6 +1503,11 @@ def main() -> None:
     ctx = {"world": world, "rank": rank, "local_rank": local_rank, "distributed": distributed, "dog": dog, "one_device": one_device}
     if one_device:
         ctx["collective_device"] = "cpu"
+    if os.environ.get("GT4MI_BENCH_DIRECT_MODE") in ("direct-fenced", "rccl"):
+        # start further down the ladder (scripts: what the fenced mode costs on the self-loop)
+        ctx["direct_mode"] = os.environ["GT4MI_BENCH_DIRECT_MODE"]
+        if ctx["direct_mode"] == "rccl":
+            ctx["direct_dropped"] = "GT4MI_BENCH_DIRECT_MODE"
     if distributed:
         import torch.distributed as dist
 

@@ -31,7 +31,17 @@ inline bool hdiff_jmarch_enabled() {
 
 // One strip: wave `wi` along I, rows [tj * LJ, tj * LJ + LJ) of level k, of a domain of dI x dJ points whose origin the
 // views point at.  Shared by the whole-domain kernel below and by the boundary-ring kernel (hdiff_ring.hip.h).
-template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ, int PF>
+// OPT (bit mask; value-identical variants that only change the instruction mix -- for float fields with double internals the
+// kernel is VALU co-limited: 41 VALU instructions per lattice update, 7 of them conversions, profiles/r3_hdiff_stall_counters.txt):
+//   1  the two aligned additions of the lap's f32 sum (+ row above, + row below) and fly's f32 difference as PACKED f32 pairs
+//      (v_pk_add_f32: two IEEE additions per instruction, each rounded exactly like the scalar one)
+//   2  a row's widened copy (W)in, made for its lap, is kept for the row's hd_out two steps later instead of converting again
+//   4  ROLLED: the march is a rolled loop over chunks of PF rows whose body is unrolled PF times, the prefetch queue a ring that
+//      is refilled in place -- register use no longer grows with LJ (fully unrolled, the scheduler hoists the loads of later steps:
+//      138 registers at LJ = 8, 158 at 12, 214 at 32 against 122 at 6), so strips can be long behind a short prefetch window
+constexpr int HD_OPT_PACKED = 1, HD_OPT_KEEP_WIDE = 2, HD_OPT_ROLLED = 4;
+
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ, int PF, int OPT = 0>
 // `lead`: the views' origins lie that many items past a 16-byte boundary (all three alike): the lanes then start `lead`
 // columns further left, which makes every lane's vector naturally aligned again; the lanes that straddle the edge of the
 // readable / writable columns take the element-wise paths that partial vectors at the domain's edges take anyway.
@@ -78,22 +88,71 @@ __device__ __forceinline__ void hdiff_jmarch_strip(const View<const T>& in, cons
     };
     // lap of row `c` given the rows below (b) and above (d); fills right-shifted copy of c's
     // first element (the +i neighbour of the lane's last column) for reuse by the flux.
+    constexpr bool PACKED = (OPT & HD_OPT_PACKED) != 0 && sizeof(T) == 4 && VEC % 2 == 0;
+    constexpr bool KEEP_WIDE = (OPT & HD_OPT_KEEP_WIDE) != 0 && sizeof(T) < sizeof(W);
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    // (`wide`: (W)c of the centre row, for KEEP_WIDE)
     auto lap_row = [&](const T (&b)[VEC], const T (&c)[VEC], const T (&d)[VEC], W (&lap)[VEC],
-                       T& c_next_first) {
+                       T& c_next_first, W (&wide)[VEC]) {
         const T c_prev_last = lane_shift<T, true>(c[VEC - 1]);
         c_next_first = lane_shift<T, false>(c[0]);
+        if constexpr (PACKED) {
+            // sum = ((ip + im) + jp) + jm: the first addition pairs neighbours one column apart (no aligned register pairs), the
+            // second and third add whole rows -- two columns per instruction
+            T s[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const T im = (e == 0) ? c_prev_last : c[e - 1];
-            const T ipv = (e == VEC - 1) ? c_next_first : c[e + 1];
-            lap[e] = hd_lap<T, W>(c[e], ipv, im, d[e], b[e]);
+            for (int e = 0; e < VEC; ++e) {
+                const T im = (e == 0) ? c_prev_last : c[e - 1];
+                const T ipv = (e == VEC - 1) ? c_next_first : c[e + 1];
+                s[e] = ipv + im;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) {
+                pair_t t = pair_t{s[e], s[e + 1]} + pair_t{d[e], d[e + 1]};
+                t = t + pair_t{b[e], b[e + 1]};
+                s[e] = t.x;
+                s[e + 1] = t.y;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                wide[e] = (W)c[e];
+                lap[e] = ((W)4.0 * wide[e]) - (W)s[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const T im = (e == 0) ? c_prev_last : c[e - 1];
+                const T ipv = (e == VEC - 1) ? c_next_first : c[e + 1];
+                if constexpr (KEEP_WIDE) {
+                    const T sum = ((ipv + im) + d[e]) + b[e];
+                    wide[e] = (W)c[e];
+                    lap[e] = ((W)4.0 * wide[e]) - (W)sum;
+                } else {
+                    lap[e] = hd_lap<T, W>(c[e], ipv, im, d[e], b[e]);
+                }
+            }
         }
     };
     auto fly_row = [&](const W (&lap_hi)[VEC], const W (&lap_lo)[VEC], const T (&in_hi)[VEC],
                        const T (&in_lo)[VEC], W (&fly)[VEC]) {
+        if constexpr (PACKED && LIMITER) {
+            T dd[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e)
-            fly[e] = hd_flux<T, W, LIMITER>(lap_hi[e], lap_lo[e], in_hi[e], in_lo[e]);
+            for (int e = 0; e < VEC; e += 2) {
+                const pair_t t = pair_t{in_hi[e], in_hi[e + 1]} - pair_t{in_lo[e], in_lo[e + 1]};
+                dd[e] = t.x;
+                dd[e + 1] = t.y;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const W res = lap_hi[e] - lap_lo[e];
+                fly[e] = ((res * (W)dd[e]) > (W)0) ? (W)0 : res;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                fly[e] = hd_flux<T, W, LIMITER>(lap_hi[e], lap_lo[e], in_hi[e], in_lo[e]);
+        }
     };
 
     // ---- prologue: rows j0-2 .. j0+1 -> lap(j0-1), lap(j0), fly(j0-1) ---------------------------
@@ -112,35 +171,42 @@ __device__ __forceinline__ void hdiff_jmarch_strip(const View<const T>& in, cons
             if (t < nrows) load_cf(j0 + t, qc[t]);
     }
     W lap_m[VEC], lap_b[VEC], fly_prev[VEC];
+    W wide_unused[VEC], wide_b[VEC];  // (KEEP_WIDE) (W) of row b: made by its lap, used by its hd_out
     T unused, b_next_first;
-    lap_row(a, bm, b, lap_m, unused);
-    lap_row(bm, b, c, lap_b, b_next_first);
+    lap_row(a, bm, b, lap_m, unused, wide_unused);
+    lap_row(bm, b, c, lap_b, b_next_first, wide_b);
     fly_row(lap_b, lap_m, b, bm, fly_prev);
 
-    auto step = [&](int jj, int nr) {
-        // row j = j0 + jj is produced; q[0] holds in row j+2, qc[0] holds coeff row j
+    constexpr bool ROLLED = (OPT & HD_OPT_ROLLED) != 0;
+    static_assert(!ROLLED || LJ % PF == 0, "rolled march: whole chunks of PF rows");
+    // `slot`: (ROLLED) the ring slot that holds this step's rows -- a compile-time constant inside the unrolled chunk
+    auto step = [&](int jj, int nr, const int slot) {
+        // row j = j0 + jj is produced; q[slot] holds in row j+2, qc[slot] holds coeff row j (slot 0 of a shifting queue, or
+        // this step's slot of the ring)
         T d[VEC], cfr[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) d[e] = q[0][e];
+        for (int e = 0; e < VEC; ++e) d[e] = q[slot][e];
         if constexpr (COEFF_FIELD) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) cfr[e] = qc[0][e];
+            for (int e = 0; e < VEC; ++e) cfr[e] = qc[slot][e];
         }
+        if constexpr (!ROLLED) {
 #pragma unroll
-        for (int t = 0; t + 1 < PF; ++t) {
+            for (int t = 0; t + 1 < PF; ++t) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                q[t][e] = q[t + 1][e];
-                if constexpr (COEFF_FIELD) qc[t][e] = qc[t + 1][e];
+                for (int e = 0; e < VEC; ++e) {
+                    q[t][e] = q[t + 1][e];
+                    if constexpr (COEFF_FIELD) qc[t][e] = qc[t + 1][e];
+                }
             }
         }
         if (jj + PF < nr) {
-            load_in(j0 + jj + PF + 2, q[PF - 1]);
-            if constexpr (COEFF_FIELD) load_cf(j0 + jj + PF, qc[PF - 1]);
+            load_in(j0 + jj + PF + 2, q[ROLLED ? slot : PF - 1]);
+            if constexpr (COEFF_FIELD) load_cf(j0 + jj + PF, qc[ROLLED ? slot : PF - 1]);
         }
-        W lap_c[VEC];
+        W lap_c[VEC], wide_c[VEC];
         T c_next_first;
-        lap_row(b, c, d, lap_c, c_next_first);
+        lap_row(b, c, d, lap_c, c_next_first, wide_c);
         // flx(row j) at column e needs lap_b and in row j at column e+1
         W flx[VEC], fly[VEC];
         const W lapb_next_first = lane_shift<W, false>(lap_b[0]);
@@ -159,7 +225,12 @@ __device__ __forceinline__ void hdiff_jmarch_strip(const View<const T>& in, cons
             PW cv;
             if constexpr (COEFF_FIELD) cv = (PW)cfr[e];
             else cv = coeff_scalar;
-            res[e] = hd_out<T, W, PW>(b[e], cv, flx[e], fm, fly[e], fly_prev[e]);
+            if constexpr (KEEP_WIDE && sizeof(PW) == sizeof(W)) {
+                const W sden = ((flx[e] - fm) + fly[e]) - fly_prev[e];
+                res[e] = (T)((PW)wide_b[e] - (cv * (PW)sden));  // hd_out with (PW)in0 taken from the row's lap
+            } else {
+                res[e] = hd_out<T, W, PW>(b[e], cv, flx[e], fm, fly[e], fly_prev[e]);
+            }
         }
         T* o = op + (int64_t)(j0 + jj) * out.sj;
         if (out_full) {
@@ -175,23 +246,44 @@ __device__ __forceinline__ void hdiff_jmarch_strip(const View<const T>& in, cons
             c[e] = d[e];
             lap_b[e] = lap_c[e];
             fly_prev[e] = fly[e];
+            if constexpr (KEEP_WIDE) wide_b[e] = wide_c[e];
         }
         b_next_first = c_next_first;
     };
 
-    if (nrows == LJ) {
+    if constexpr (ROLLED) {
+#pragma unroll 1
+        for (int base = 0; base < nrows; base += PF) {
 #pragma unroll
-        for (int jj = 0; jj < LJ; ++jj) step(jj, LJ);
+            for (int t = 0; t < PF; ++t)  // (unrolled: the ring slot t is a constant in every copy of the body)
+                if (base + t < nrows) step(base + t, nrows, t);
+        }
+    } else if (nrows == LJ) {
+#pragma unroll
+        for (int jj = 0; jj < LJ; ++jj) step(jj, LJ, 0);
     } else {
-        for (int jj = 0; jj < nrows; ++jj) step(jj, nrows);
+        for (int jj = 0; jj < nrows; ++jj) step(jj, nrows, 0);
     }
 }
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ,
-          int PF, int XCDG = 0>
+          int PF, int XCDG = 0, int OPT = 0, bool TEAM = false>
 __global__ void __launch_bounds__(256)
 hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_scalar, int dI,
                     int dJ, unsigned waves_i, unsigned tiles_j, unsigned groups_j, int lead) {
+    if constexpr (TEAM) {
+        // (experiment, microbench only) the four waves of a workgroup on four ADJACENT I strips of the SAME rows: no two waves
+        // of a workgroup share a halo row, strips can be long with a short rolling prefetch window; workgroups ordered along
+        // J (XCD-grouped), then I, then K.  groups_j = tiles_j here; waves_i is rounded up to whole teams by the launch.
+        unsigned wg = blockIdx.x;
+        if constexpr (XCDG > 0) wg = xcd_remap_grouped<(unsigned)XCDG>(wg, gridDim.x);
+        const unsigned tj = wg % tiles_j, column = wg / tiles_j;
+        const unsigned teams_i = (waves_i + 3u) / 4u;
+        const unsigned wi = (column % teams_i) * 4u + (threadIdx.x >> 6), k = column / teams_i;
+        if (wi >= waves_i) return;
+        hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF, OPT>(in, out, cf, coeff_scalar, dI, dJ, wi, tj, k, lead);
+        return;
+    }
     // A workgroup = 4 independent waves on 4 consecutive J strips of one I column, so 3 of the 4
     // strip boundaries (4 shared rows each) are re-read inside one CU; workgroups are ordered along
     // J, then I, then K, and runs of XCDG of them share an XCD (see lap5.hip.h).
@@ -215,7 +307,7 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
     const unsigned wi = column % waves_i;
     const unsigned k = column / waves_i;
 
-    hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF>(in, out, cf, coeff_scalar, dI, dJ, wi, tj, k, lead);
+    hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF, OPT>(in, out, cf, coeff_scalar, dI, dJ, wi, tj, k, lead);
 }
 
 // Rows per strip / rows prefetched ahead, from the sweep in profiles/r1_microbench_d_*.log

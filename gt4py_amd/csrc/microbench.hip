@@ -495,6 +495,92 @@ static void section_hdiff2() {
     }
 }
 
+// Round 5: the float32 / float64-internal kernel is VALU co-limited.  Value-identical variants of the
+// instruction mix (OPT), longer strips behind a short prefetch window, and the "team" mapping (four waves on four adjacent I
+// strips of the same rows); every variant is compared with the one-thread-per-point kernel bit for bit.
+template <typename T, typename W, int VEC, int LJ, int PF, int XCDG, int OPT, bool TEAM>
+static void hdiff_variant_o(const DevField<T>& in, DevField<T>& out, const DevField<T>& ref, const DevField<T>& cf, int dI, int dJ, int dK,
+                            const char* tag) {
+    constexpr int H = (VEC >= 2) ? 1 : 2;
+    const unsigned waves_i = (unsigned)cdiv(dI, (64 - 2 * H) * VEC), tiles_j = (unsigned)cdiv(dJ, LJ);
+    const unsigned groups_j = TEAM ? tiles_j : (unsigned)cdiv(tiles_j, 4);
+    const unsigned nb = (TEAM ? (unsigned)cdiv(waves_i, 4) : waves_i) * groups_j * dK;
+    char cfg[128];
+    snprintf(cfg, sizeof cfg, "%s %s-internal VEC=%d LJ=%d PF=%d xcd=%d opt=%d%s", tag, sizeof(W) == 4 ? "f32" : "f64", VEC, LJ, PF, XCDG,
+             OPT, TEAM ? " TEAM" : "");
+    CK(hipMemset(out.raw, 0, out.bytes));
+    const double ms = time_ms([&](int) {
+        hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, W, true, true, VEC, LJ, PF, XCDG, OPT, TEAM>), dim3(nb), dim3(256), 0, 0,
+                           in.cview(), out.view(), cf.cview(), (W)0, dI, dJ, waves_i, tiles_j, groups_j, 0);
+    }, 100);
+    report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, 3.0 * sizeof(T));
+    const unsigned long long bad = count_diff(out, ref, dI, dJ, dK);
+    if (bad) printf("           MISMATCHES vs the one-thread-per-point kernel: %llu\n", bad);
+}
+
+static void section_hdiff3() {
+    {
+        const int dI = 1024, dJ = 1024, dK = 80;
+        DevField<float> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), ref(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+        fill(in, 2024, 1.0, 9.0);
+        fill(cf, 7, 0.0, 0.05);
+        {
+            dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+            hipLaunchKernelGGL((hdiff_generic_kernel<float, double, double, true, true>), grid, dim3(256), 0, 0, in.cview(), ref.view(), cf.cview(),
+                               0.0, dI, dJ, dK);
+            CK(hipDeviceSynchronize());
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+#define V(LJ, PF, X, O, TM) hdiff_variant_o<float, double, 4, LJ, PF, X, O, TM>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80")
+            V(6, 6, 4, 0, false);  // the library's kernel
+            V(6, 6, 4, 3, false);  // packed f32 pairs + kept wide copies
+            V(8, 8, 4, 0, false);
+            V(8, 4, 4, 0, false);
+            V(6, 6, 4, 4, false);  // the same strips, rolled (ring queue)
+            V(12, 6, 4, 4, false);
+            V(12, 4, 4, 4, false);
+            V(12, 3, 4, 4, false);
+            V(24, 6, 4, 4, false);
+            V(24, 4, 4, 4, false);
+            V(12, 6, 4, 4, true);  // four waves on four adjacent I strips of the same rows
+            V(24, 6, 4, 4, true);
+            V(24, 4, 4, 4, true);
+            V(24, 3, 4, 4, true);
+            V(48, 6, 4, 4, true);
+            V(48, 4, 4, 4, true);
+            V(48, 6, 0, 4, true);
+            V(48, 6, 2, 4, true);
+            V(96, 6, 4, 4, true);
+            V(48, 6, 4, 7, true);
+            V(128, 4, 4, 4, true);
+#undef V
+        }
+    }
+    {
+        const int dI = 512, dJ = 1024, dK = 80;
+        DevField<double> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), ref(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+        fill(in, 2024, 1.0, 9.0);
+        fill(cf, 7, 0.0, 0.05);
+        {
+            dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+            hipLaunchKernelGGL((hdiff_generic_kernel<double, double, double, true, true>), grid, dim3(256), 0, 0, in.cview(), ref.view(), cf.cview(),
+                               0.0, dI, dJ, dK);
+            CK(hipDeviceSynchronize());
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+#define V(LJ, PF, X, O, TM) hdiff_variant_o<double, double, 2, LJ, PF, X, O, TM>(in, out, ref, cf, dI, dJ, dK, "512x1024x80")
+            V(8, 8, 4, 0, false);  // the library's kernel
+            V(8, 4, 4, 4, false);
+            V(16, 4, 4, 4, false);
+            V(24, 6, 4, 4, true);
+            V(48, 6, 4, 4, true);
+            V(48, 4, 4, 4, true);
+            V(96, 4, 4, 4, true);
+#undef V
+        }
+    }
+}
+
 // workgroup -> XCD mappings of the J-march kernel: runs of G workgroups (0, 2, 4, 8) and contiguous chunks per column (-1)
 static void section_hdiffxcd() {
     {
@@ -1045,6 +1131,7 @@ int main(int argc, char** argv) {
     }
     if (on("hdiff")) section_hdiff();
     if (!want.empty() && on("hdiff2")) section_hdiff2();
+    if (!want.empty() && on("hdiff3")) section_hdiff3();
     if (!want.empty() && on("hdiffxcd")) section_hdiffxcd();
     if (on("tridiag")) section_tridiag();
     if (!want.empty() && on("triplace")) section_triplace(0, want);

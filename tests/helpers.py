@@ -1,49 +1,47 @@
-"""Array wrappers used by the call-interface tests: objects that only expose the array-interface
-protocols plus ``__gt_dims__`` / ``__gt_origin__`` (same role as the wrappers in
-/root/reference/tests/cartesian_tests/utils.py:23-61)."""
+"""Test-only array carriers: objects that expose an array through the interface protocols and NOTHING else, optionally annotated
+with ``__gt_dims__`` / ``__gt_origin__`` -- what the call interface must accept in place of a storage
+(docs/user/cartesian/arrays.rst:25-37; the reference's tests use wrappers in the same role)."""
 
-from typing import Any, Tuple
+from __future__ import annotations
 
-
-class ArrayWrapper:
-    def __init__(self, array, **_kwargs: Any) -> None:
-        self.array = array
-
-    @property
-    def __array_interface__(self):
-        return self.array.__array_interface__
-
-    @property
-    def __cuda_array_interface__(self):
-        return self.array.__cuda_array_interface__
+import dataclasses
+from typing import Any, Optional, Sequence
 
 
-class DimensionsWrapper(ArrayWrapper):
-    def __init__(self, dimensions: Tuple[str, ...], **kwargs: Any) -> None:
-        super().__init__(**kwargs)
-        if len(self.array.shape) != len(dimensions):
-            raise ValueError(f"Non matching dimensions of array.shape {self.array.shape} and dimensions {dimensions}.")
-        self.__gt_dims__ = dimensions
+@dataclasses.dataclass(frozen=True)
+class _Carrier:
+    """Keyword-only: ``array`` plus at most the two annotations.  The annotations are real attributes only when given (the
+    call interface probes for them with ``getattr``)."""
+
+    array: Any
+    origin: Optional[Sequence[int]] = None
+    dimensions: Optional[Sequence[str]] = None
+    device_interface: bool = True  # expose __cuda_array_interface__ too (False: a host-only carrier)
+
+    def __post_init__(self):
+        rank = len(self.array.shape)
+        for what, value in (("origin", self.origin), ("dimensions", self.dimensions)):
+            if value is not None and len(value) != rank:
+                raise ValueError(f"{what} {tuple(value)!r} does not have one entry per axis of an array of shape {tuple(self.array.shape)}")
+        if self.origin is not None:
+            object.__setattr__(self, "__gt_origin__", tuple(self.origin))
+        if self.dimensions is not None:
+            object.__setattr__(self, "__gt_dims__", self.dimensions)
+
+    def __getattr__(self, name):  # (only reached for attributes that are not set)
+        if name == "__array_interface__" or (name == "__cuda_array_interface__" and object.__getattribute__(self, "device_interface")):
+            return getattr(object.__getattribute__(self, "array"), name)
+        raise AttributeError(name)
 
 
-class OriginWrapper(ArrayWrapper):
-    def __init__(self, *, origin: Tuple[int, ...], **kwargs: Any) -> None:
-        super().__init__(**kwargs)
-        if len(self.array.shape) != len(origin):
-            raise ValueError(f"Non matching dimensions of array.shape {self.array.shape} and origin {origin}.")
-        self.__gt_origin__ = origin
+def OriginWrapper(*, array, origin):
+    return _Carrier(array=array, origin=origin)
 
 
-class HostOnlyWrapper:
+def DimensionsWrapper(*, array, dimensions):
+    return _Carrier(array=array, dimensions=dimensions)
+
+
+def HostOnlyWrapper(array, origin=None, dimensions=None):
     """Exposes ONLY __array_interface__ (no __cuda_array_interface__), for host-side tests."""
-
-    def __init__(self, array, origin=None, dimensions=None):
-        self.array = array
-        if origin is not None:
-            self.__gt_origin__ = origin
-        if dimensions is not None:
-            self.__gt_dims__ = dimensions
-
-    @property
-    def __array_interface__(self):
-        return self.array.__array_interface__
+    return _Carrier(array=array, origin=origin, dimensions=dimensions, device_interface=False)

@@ -1440,7 +1440,7 @@ def test_eight_processes_on_one_gpu_exchange_faces_on_the_grids_of_an_eight_gpu_
 
 
 @pytest.mark.multiprocess
-@pytest.mark.parametrize("workload,ranks", [("lap512", 8), ("lap512", 4)])  # (hdiff2048 with 8 full-size shares on one device: 17-96 s; scripts/probes/bench_eight_ranks_one_device.sh, profiles/r4_bench_rehearsal_hdiff2048_*)
+@pytest.mark.parametrize("workload,ranks", [("lap512", 8), ("lap512", 4), ("hdiff2048", 8)])  # (both workloads on a 32-level slab: see bench.py, GT4MI_BENCH_ONE_DEVICE)
 @_second_chance
 def test_bench_n_gpu_code_path_with_real_ranks_on_one_device(workload, ranks, tmp_path):
     """`bench.py` exactly as the driver launches it for N > 1 -- `torch.distributed.run --nproc-per-node N bench.py --gpus N` --
@@ -1482,6 +1482,14 @@ def test_bench_n_gpu_code_path_with_real_ranks_on_one_device(workload, ranks, tm
         grids = {key.split("_")[0] for key in table}  # every process grid of N ranks took part (budget permitting: at least two)
         assert len(grids) >= 2 and f"1x{ranks}" in grids and config["decomposition"] in grids
         assert config["halo_transport"].startswith("direct")
+    else:
+        # BASELINE.json configs[4]'s control flow with 8 REAL ranks: the 4 x 2 grid the north star names, every rank's share
+        # 512 x 1024 (x 32 levels here), a fused form of the direct transport as the headline
+        assert config["decomposition"] == "4x2" and config["local_domain"][:2] == [512, 1024] and config["grid"][:2] == [2048, 2048]
+        assert config["apply_form"].startswith("fused_") and config["apply_form"].endswith("_direct")
+    # every form was checked on consecutive epochs of the probe (the last one under HBM load) and the transport stayed in its
+    # default mode: nothing stepped down the ladder
+    assert config["verified"]["epochs_per_form"] >= 3 and line["direct_transport_mode"] == "direct" and line["direct_transport_ladder"] == []
     assert "NATIVE RCCL TRANSPORT UNAVAILABLE" not in proc.stderr
 
 

@@ -87,11 +87,26 @@ KERNEL_NEEDLES = {
 }
 
 
-def kernel_source_hash(workload: str) -> str:
+def _build_flags(makefile_text: str) -> bytes:
+    """The lines of csrc/Makefile that decide what the compiler makes of a kernel: the HIPCC / ARCH / FLAGS assignments with their
+    continuation lines -- not its comments or the targets of tooling builds, which change without changing any kernel."""
+    keep, continued = [], False
+    for line in makefile_text.splitlines():
+        if continued or line.split("?=")[0].split(":=")[0].strip() in ("HIPCC", "ARCH", "FLAGS"):
+            keep.append(line.strip())
+            continued = line.rstrip().endswith("\\")
+    return "\n".join(keep).encode()
+
+
+def kernel_source_hash(workload: str, read=None) -> str:
+    """16 hex digits over the files that decide what the workload's kernel does (KERNEL_SOURCES); of the Makefile only the
+    compiler, architecture and flags.  `read(rel) -> bytes`: another tree's files (scripts/rehash_traffic.py: `git show`)."""
+    read = read or (lambda rel: (ROOT / rel).read_bytes())
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES[workload]:
         h.update(rel.encode())
-        h.update((ROOT / rel).read_bytes())
+        data = read(rel)
+        h.update(_build_flags(data.decode()) if rel.endswith("Makefile") else data)
     return h.hexdigest()[:16]
 
 

@@ -13,7 +13,12 @@ What can be verified where:
   imports gt4py, and is unit-tested here on hand-built OIR-shaped trees (tests/test_adapter.py) -- the translated
   IR must equal what this repo's frontend produces for the same stencil, and runs on the oracle and on the GPU.
 * ``register_with_gt4py`` needs gt4py (Python >= 3.12 and its dependencies, absent from this image): it raises
-  ImportError with that explanation otherwise.  INTEGRATION.md shows the three lines a user adds.
+  ImportError with that explanation otherwise.  INTEGRATION.md shows the three lines a user adds.  What is pinned without
+  running it: every gt4py name it and ``_wrap_for_gt4py`` touch -- module attributes, ``StencilBuilder`` properties,
+  ``BuildOptions`` / ``StencilID`` / ``ModuleData`` fields, the keyword arguments of ``StencilObject._call_run``, the members a
+  ``StencilObject`` subclass must define -- is checked against ``tests/golden/gt4py_api_surface.json``, which
+  ``scripts/make_gt4py_api_surface.py`` writes from the reference's sources with ``ast`` (tests/test_adapter.py; the check
+  found ``builder.backend_name``, which the reference does not have: it is ``builder.backend.name``).
 """
 
 from __future__ import annotations
@@ -310,7 +315,7 @@ def _wrap_for_gt4py(builder, impl, gt4py_base):  # pragma: no cover - needs gt4p
 
     attrs = {
         "_gt_id_": builder.stencil_id.version, "definition_func": staticmethod(builder.definition),
-        "backend": property(lambda self: builder.backend_name), "source": property(lambda self: impl.source),
+        "backend": property(lambda self: builder.backend.name), "source": property(lambda self: impl.source),
         "domain_info": property(lambda self: args_data.domain_info), "field_info": property(lambda self: args_data.field_info),
         "parameter_info": property(lambda self: args_data.parameter_info),
         "constants": property(lambda self: dict(builder.externals)), "options": property(lambda self: builder.options.as_dict()),

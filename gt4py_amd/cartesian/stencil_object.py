@@ -132,20 +132,23 @@ class StencilObject(abc.ABC):
     _gt_options_: ClassVar[Dict[str, Any]]
     _gt_signature_: ClassVar[Any]  # inspect.Signature of the definition
 
+    # One instance per generated stencil class, and that instance is immutable: the semantics of the reference's StencilObject
+    # (stencil_object.py:202-215), which callers rely on when they compare or cache stencil objects.
     def __new__(cls, *args, **kwargs):
-        if getattr(cls, "_instance", None) is None:
-            cls._instance = object.__new__(cls)
-            cls._domain_origin_cache = {}
-        return cls._instance
+        try:
+            return cls.__dict__["_instance"]  # (this class's own: a subclass gets its own instance)
+        except KeyError:
+            instance = super().__new__(cls)
+            cls._instance, cls._domain_origin_cache = instance, {}
+            return instance
 
-    def __setattr__(self, key, value) -> None:
-        raise AttributeError("Attempting a modification of an attribute in a frozen class")
+    def _frozen(self, *_):
+        raise AttributeError(f"{type(self).__name__} objects are immutable (one frozen instance per stencil class)")
 
-    def __delattr__(self, item) -> None:
-        raise AttributeError("Attempting a deletion of an attribute in a frozen class")
+    __setattr__ = __delattr__ = _frozen
 
     def __eq__(self, other) -> bool:
-        return type(self) is type(other)
+        return type(other) is type(self)
 
     def __hash__(self) -> int:
         return int.from_bytes(type(self)._gt_id_.encode(), byteorder="little")

@@ -310,14 +310,19 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
     hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF, OPT>(in, out, cf, coeff_scalar, dI, dJ, wi, tj, k, lead);
 }
 
-// Rows per strip / rows prefetched ahead, from the sweep in profiles/r1_microbench_d_*.log
-// (MI355X, 1024x1024x80 f32 and 512x1024x80 f64): short strips with most of their rows in flight
-// win; the 4-row prologue is re-read from L2.
+// Rows per strip / rows prefetched ahead (MI355X, 1024x1024x80 f32 and 512x1024x80 f64): SHORT strips win -- every variant with
+// strips of 12 .. 128 rows (rolled, with a 3-6 row prefetch window, also with the four waves of a workgroup on adjacent I strips
+// of the same rows) is 5-55 % slower than 6-8 rows (profiles/r5_microbench_hdiff_variants.log: the march of a wave is a chain of
+// dependent load latencies, and what hides them is the number of independent waves, not the depth of one wave's queue); the 4-row
+// prologue is re-read from L2 / the Infinity Cache.  All of float64, float32 with float64 internals and float32 throughout land
+// within 1 % of 0.180 ms for the same 1.007 GB: the kernel sits on the ceiling of its 2-read : 1-write traffic mix, not on VALU.
+//   float64: 8 rows, all 8 in flight.   float32: 8 rows with 4 in flight (round 5; was 6 / 6): the same speed within noise
+//   (0.1823 vs 0.1835 ms) with 1.04x instead of 1.14x of the algorithmic traffic at the memory side (4 halo rows per 8 instead of
+//   per 6 rows), 128 registers (4 waves per SIMD, as before).
 template <typename T>
 struct HdiffTuning {
-    // profiles/r1_microbench_h_hdiff_groups.log: all rows of a strip in flight (PF == LJ)
-    static constexpr int LJ = sizeof(T) == 4 ? 6 : 8;
-    static constexpr int PF = sizeof(T) == 4 ? 6 : 8;
+    static constexpr int LJ = 8;
+    static constexpr int PF = sizeof(T) == 4 ? 4 : 8;
     static constexpr int XCDG = 4;  // workgroups per XCD run (see lap5.hip.h Lap5Tuning::XCDG)
 };
 

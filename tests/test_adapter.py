@@ -355,6 +355,103 @@ def test_the_translator_reads_only_fields_the_reference_has():
     assert read and not (read - every_field), f"attribute(s) {sorted(read - every_field)} are fields of no class of the reference's OIR"
 
 
+def test_the_gt4py_facing_glue_uses_only_names_the_reference_has():
+    """`register_with_gt4py` / `_wrap_for_gt4py` cannot run here (no gt4py: Python 3.10).  What can be checked: every attribute
+    chain in their source that starts at a gt4py object -- the builder, its options / stencil id / backend, the imported modules,
+    the args data -- names something the reference defines, `_call_run` is called with keywords it takes, and the generated
+    `StencilObject` subclass defines members `StencilObject` declares.  The surface is data written from the reference's sources
+    by scripts/make_gt4py_api_surface.py."""
+    import ast
+    import inspect
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    api = json.loads((root / "tests" / "golden" / "gt4py_api_surface.json").read_text())["modules"]
+    if pathlib.Path("/root/reference/src/gt4py/cartesian/backend/base.py").exists():
+        proc = subprocess.run([sys.executable, str(root / "scripts" / "make_gt4py_api_surface.py"), "--check"], capture_output=True, text=True)
+        assert proc.returncode == 0, proc.stderr
+
+    def members(module, cls):
+        c = api[module]["classes"][cls]
+        own = set(c["attributes"]) | set(c["properties"]) | set(c["methods"])
+        for base in c["bases"]:
+            base = base.split("[")[0].split(".")[-1]
+            for mod in api.values():
+                if base in mod["classes"]:
+                    own |= members(next(m for m in api if api[m] is mod), base)
+        return own
+
+    def module_names(module):
+        m = api[module]
+        return set(m["functions"]) | set(m["names"]) | set(m["imports"]) | set(m["classes"])
+
+    builder = members("stencil_builder.py", "StencilBuilder")
+    chains_allowed = {
+        ("builder",): builder, ("self", "builder"): builder,
+        ("builder", "options"): members("definitions.py", "BuildOptions"), ("self", "builder", "options"): members("definitions.py", "BuildOptions"),
+        ("builder", "stencil_id"): members("definitions.py", "StencilID"),
+        ("builder", "backend"): members("backend/base.py", "Backend"),
+        ("gt4py_base",): module_names("backend/base.py"), ("gt4py_backend",): module_names("backend/__init__.py"),
+        ("gtc_passes",): module_names("gtc/passes/__init__.py"),
+        ("args_data",): members("backend/module_generator.py", "ModuleData"),
+    }
+    assert "as_dict" in chains_allowed[("builder", "options")] and "backend_name" not in builder  # (the bug this check found)
+
+    def chain(node):
+        out = []
+        while isinstance(node, ast.Attribute):
+            out.append(node.attr)
+            node = node.value
+        return (node.id,) + tuple(reversed(out)) if isinstance(node, ast.Name) else None
+
+    seen = set()
+    for fn in (adapter.register_with_gt4py, adapter._wrap_for_gt4py):
+        tree = ast.parse(inspect.getsource(fn))
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute):
+                c = chain(node)
+                if c is None:
+                    continue
+                for n in range(len(c) - 1, 0, -1):  # the longest known prefix decides
+                    if c[:n] in chains_allowed:
+                        assert c[n] in chains_allowed[c[:n]], f"{'.'.join(c[:n + 1])}: the reference has no such name (it has {sorted(chains_allowed[c[:n]])[:40]})"
+                        seen.add(c[:n + 1])
+                        break
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.startswith("gt4py.cartesian"):
+                rel = node.module[len("gt4py.cartesian."):].replace(".", "/") if node.module != "gt4py.cartesian" else ""
+                for alias in node.names:
+                    if rel == "":  # from gt4py.cartesian import backend
+                        assert (alias.name + "/__init__.py") in api or (alias.name + ".py") in api, alias.name
+                    elif (rel + "/" + alias.name + ".py") in api or (rel + "/" + alias.name + "/__init__.py") in api:
+                        pass  # a submodule: from gt4py.cartesian.backend import base
+                    else:
+                        module = rel + ".py" if (rel + ".py") in api else rel + "/__init__.py"
+                        assert alias.name in module_names(module), f"from {node.module} import {alias.name}: not defined there"
+                        seen.add((node.module, alias.name))
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "_call_run":
+                p = api["stencil_object.py"]["classes"]["StencilObject"]["methods"]["_call_run"]
+                assert {k.arg for k in node.keywords} <= set(p["positional"]) | set(p["keyword_only"])
+                assert set(p["positional"]) - {"self"} <= {k.arg for k in node.keywords}
+                seen.add(("_call_run",))
+    assert {("builder", "gtir_pipeline"), ("builder", "backend", "name"), ("builder", "options", "as_dict"), ("builder", "stencil_id", "version"),
+            ("self", "builder", "gtir"), ("gt4py_base", "BaseBackend"), ("gt4py_backend", "register"), ("gtc_passes", "OirPipeline"),
+            ("args_data", "field_info"), ("_call_run",), ("gt4py.cartesian.backend.module_generator", "make_args_data_from_gtir"),
+            ("gt4py.cartesian.gtc.gtir_to_oir", "GTIRToOIR"), ("gt4py.cartesian.stencil_object", "StencilObject")} <= seen, sorted(seen)
+    # what the Backend subclass sets and overrides, and what the StencilObject subclass defines, are members the base classes declare
+    source = inspect.getsource(adapter.register_with_gt4py)
+    backend_members = members("backend/base.py", "BaseBackend")
+    for name in ("options", "storage_info", "languages", "name", "generate", "load", "check_options", "builder"):
+        assert name in backend_members and name in source
+    stencil_members = members("stencil_object.py", "StencilObject")
+    wrap = ast.parse(inspect.getsource(adapter._wrap_for_gt4py))
+    keys = [k.value for n in ast.walk(wrap) if isinstance(n, ast.Dict) for k in n.keys if isinstance(k, ast.Constant)]
+    assert set(keys) - {"__module__"} <= stencil_members | {"__call__"}, sorted(set(keys) - stencil_members)
+    assert {"run", "backend", "source", "domain_info", "field_info", "parameter_info", "constants", "options", "_gt_id_", "definition_func"} <= set(keys)
+    # make_args_data_from_gtir takes the builder's GTIR pipeline (module_generator.py:56)
+    assert api["backend/module_generator.py"]["functions"]["make_args_data_from_gtir"]["positional"] == ["pipeline"]
+
+
 def test_registration_needs_a_real_gt4py():
     with pytest.raises(ImportError, match="needs a real gt4py install"):
         adapter.register_with_gt4py()

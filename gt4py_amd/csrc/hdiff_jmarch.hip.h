@@ -310,38 +310,52 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
     hdiff_jmarch_strip<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF, OPT>(in, out, cf, coeff_scalar, dI, dJ, wi, tj, k, lead);
 }
 
-// Rows per strip / rows prefetched ahead (MI355X, 1024x1024x80 f32 and 512x1024x80 f64): SHORT strips win -- every variant with
-// strips of 12 .. 128 rows (rolled, with a 3-6 row prefetch window, also with the four waves of a workgroup on adjacent I strips
-// of the same rows) is 5-55 % slower than 6-8 rows (profiles/r5_microbench_hdiff_variants.log: the march of a wave is a chain of
-// dependent load latencies, and what hides them is the number of independent waves, not the depth of one wave's queue); the 4-row
-// prologue is re-read from L2 / the Infinity Cache.  All of float64, float32 with float64 internals and float32 throughout land
-// within 1 % of 0.180 ms for the same 1.007 GB: the kernel sits on the ceiling of its 2-read : 1-write traffic mix, not on VALU.
-//   float64: 8 rows, all 8 in flight.   float32: 8 rows with 4 in flight (round 5; was 6 / 6): the same speed within noise
-//   (0.1823 vs 0.1835 ms) with 1.04x instead of 1.14x of the algorithmic traffic at the memory side (4 halo rows per 8 instead of
-//   per 6 rows), 128 registers (4 waves per SIMD, as before).
+// Rows per strip / rows prefetched ahead (MI355X, 1024x1024x80 f32 and 512x1024x80 f64): SHORT strips with all of their rows in
+// flight win.  Round 5 tried the other direction at length (profiles/r5_microbench_hdiff_variants.log, every variant bit-identical):
+// strips of 12 .. 128 rows -- rolled, behind a 3-6 row prefetch window, also with the four waves of a workgroup on adjacent I strips
+// of the same rows -- are 5-55 % slower than 6-8 rows: the march of a wave is a chain of dependent load latencies, and what hides
+// them is the number of independent waves, not the depth of one wave's queue.  float64, float32 with float64 internals and float32
+// throughout all land within 1 % of 0.180 ms for the same 1.007 GB: the kernel sits on the ceiling of its 2-read : 1-write traffic
+// mix (6.05 TB/s streaming, profiles/r3_microbench_rw_mix.log), not on VALU.
+//   float64: 8 rows, all 8 in flight.   float32: 6 rows, all 6 in flight.  The float32 alternative 8 rows / 4 in flight moves 1.09x
+//   instead of 1.14x of the algorithmic bytes at the memory side (4 halo rows per 8 instead of per 6) and is 1.3-2.0 % SLOWER on the
+//   same box in the product's call path (profiles/r5_hdiff_f32_strip_ab.log): the extra "traffic" is Infinity-Cache hits on halo
+//   rows (FETCH_SIZE counts them, MI355X_MICROARCH.md), which cost nothing -- so the faster shape stays.  GT4MI_HDIFF_F32_ROWS=8
+//   selects the other one.
 template <typename T>
 struct HdiffTuning {
-    static constexpr int LJ = 8;
-    static constexpr int PF = sizeof(T) == 4 ? 4 : 8;
+    static constexpr int LJ = sizeof(T) == 4 ? 6 : 8;
+    static constexpr int PF = sizeof(T) == 4 ? 6 : 8;
     static constexpr int XCDG = 4;  // workgroups per XCD run (see lap5.hip.h Lap5Tuning::XCDG)
 };
 
-template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC>
-inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
-                                   const View<const T>& cf, PW coeff_scalar, const int64_t d[3],
-                                   hipStream_t stream, int lead = 0) {
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ, int PF>
+inline int hdiff_launch_jmarch_strips(const View<const T>& in, const View<T>& out, const View<const T>& cf, PW coeff_scalar,
+                                      const int64_t d[3], hipStream_t stream, int lead) {
     constexpr int H = (VEC >= 2) ? 1 : 2;
-    constexpr int LJ = HdiffTuning<T>::LJ;
     const unsigned waves_i = (unsigned)cdiv(d[0] + lead, (int64_t)(64 - 2 * H) * VEC);
     const unsigned tiles_j = (unsigned)cdiv(d[1], LJ);
     const unsigned groups_j = (unsigned)cdiv(tiles_j, 4);
     const int64_t nblocks = (int64_t)waves_i * groups_j * d[2];
     if (nblocks > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: domain too large for one launch");
-    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, HdiffTuning<T>::PF,
-                                            HdiffTuning<T>::XCDG>),
+    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF, HdiffTuning<T>::XCDG>),
                        dim3((unsigned)nblocks), dim3(256), launch_dynamic_lds(), stream, in, out, cf, coeff_scalar, (int)d[0],
                        (int)d[1], waves_i, tiles_j, groups_j, lead);
     return GT4MI_OK;
+}
+
+template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC>
+inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
+                                   const View<const T>& cf, PW coeff_scalar, const int64_t d[3],
+                                   hipStream_t stream, int lead = 0) {
+    if constexpr (sizeof(T) == 4 && VEC == 4) {
+        // GT4MI_HDIFF_F32_ROWS=8: float32 strips of 8 rows with 4 in flight instead of 6 / 6 -- for A/B runs on ONE box (the two
+        // differ by less than boxes do: profiles/r5_hdiff_f32_strip_ab.log)
+        static const int rows = env_int("GT4MI_HDIFF_F32_ROWS", HdiffTuning<T>::LJ);
+        if (rows == 8) return hdiff_launch_jmarch_strips<T, W, PW, LIMITER, COEFF_FIELD, VEC, 8, 4>(in, out, cf, coeff_scalar, d, stream, lead);
+    }
+    return hdiff_launch_jmarch_strips<T, W, PW, LIMITER, COEFF_FIELD, VEC, HdiffTuning<T>::LJ, HdiffTuning<T>::PF>(in, out, cf, coeff_scalar, d,
+                                                                                                             stream, lead);
 }
 
 // 16-byte lanes are possible when the rows of all fields are 16-byte aligned among themselves and the origins lie equally

@@ -703,8 +703,8 @@ def direct_canary(ctx) -> bool:
     """Before THIS process maps another device's memory and lets its kernels store into it: a child process per rank does exactly
     that on a small problem -- `python -m gt4py_amd.distributed --transport direct`, the self-check of the direct transport (no RCCL,
     its own gloo group) -- and all ranks agree on the outcome.  A memory fault or a hang between real devices then ends a child, not
-    the run.  Every form runs CHECK_EPOCHS consecutive epochs of the probe and the one-stream forms CANARY_STRESS_EPOCHS more, all
-    next to an HBM-saturating background with the ranks launching together (selfcheck.py: every round is sensitive to a receive
+    the run.  Every form runs CHECK_EPOCHS consecutive epochs of the probe and the one-stream forms CANARY_STRESS_EPOCHS more, every
+    other one next to an HBM-saturating background, with the ranks launching together (selfcheck.py: every round is sensitive to a receive
     buffer read too early).  DOWN THE LADDER: should the default mode fail on any rank, the children run once more in the fenced
     mode; if that passes the calibration uses the direct transport FENCED (ctx["direct_mode"]), else it stays on RCCL."""
     dog, rank, world = ctx["dog"], ctx["rank"], ctx["world"]

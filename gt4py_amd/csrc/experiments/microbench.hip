@@ -760,6 +760,67 @@ static void section_trimap() {
     }
 }
 
+// Round 5: is the speed of the K-strided column kernels a property of the individual ALLOCATION (profiles/r4_tridiag_translation.txt:
+// the tridiagonal solve runs at 0.60-0.73 of the peak depending on which allocations its five fields live in)?  A probe reads ONE
+// field the way the solve's forward sweep does -- a wave per 64 columns of a row, all K levels one plane apart, 512 bytes per level --
+// and is timed on each of N separately hipMalloc'ed fields; then the solve runs on the five fields the probe found fastest and on the
+// five it found slowest.  If the probe separates the allocations and the solve follows, an allocator can probe and choose.
+__global__ void __launch_bounds__(64) kcol_probe_kernel(const double* __restrict__ p, int64_t sj, int64_t sk, int dK, unsigned ti, double* __restrict__ sink) {
+    const unsigned tile = blockIdx.x % ti, j = blockIdx.x / ti;
+    const double* q = p + (int64_t)j * sj + (int64_t)tile * 64 + threadIdx.x;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < dK; ++k) acc += q[(int64_t)k * sk];
+    if (acc == 12345.678) sink[0] = acc;  // (never: the loads must not be optimised away)
+}
+
+static void section_kprobe() {
+    const int dI = 1024, dJ = 1024, dK = 160;
+    const int NB = getenv("MB_KPROBE_FIELDS") ? atoi(getenv("MB_KPROBE_FIELDS")) : 14;
+    std::vector<DevField<double>*> f;
+    for (int b = 0; b < NB; ++b) {
+        f.push_back(new DevField<double>(dI, dJ, dK, 0, 0));
+        fill(*f.back(), 100 + b, 4.0, 5.0);
+    }
+    double* sink = nullptr;
+    CK(hipMalloc(&sink, 64));
+    const unsigned ti = (unsigned)cdiv(dI, 64);
+    std::vector<std::pair<double, int>> order;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int b = 0; b < NB; ++b) {
+            const double ms = time_ms([&](int) {
+                hipLaunchKernelGGL(kcol_probe_kernel, dim3(ti * dJ), dim3(64), 0, 0, f[b]->data, f[b]->sj, f[b]->sk, dK, ti, sink);
+            }, 10, 2);
+            printf("kprobe     pass %d field %2d at %p (MiB mod 1 GiB %9.3f): %8.4f ms  %7.1f GB/s\n", pass, b, (void*)f[b]->raw,
+                   (reinterpret_cast<uintptr_t>(f[b]->data) % (1ull << 30)) / 1048576.0, ms, (double)dI * dJ * dK * 8.0 / (ms * 1e-3) / 1e9);
+            if (pass == 1) order.push_back({ms, b});
+        }
+    std::sort(order.begin(), order.end());
+    printf("kprobe     fastest -> slowest:");
+    for (auto& o : order) printf(" %d(%.3f)", o.second, o.first);
+    printf("\n");
+    fflush(stdout);
+    auto solve_on = [&](const char* what, int i0, int step) {
+        DevField<double>*a = f[order[i0].second], *d = f[order[i0 + step].second], *s = f[order[i0 + 2 * step].second],
+                        *r = f[order[i0 + 3 * step].second], *o = f[order[i0 + 4 * step].second];
+        // (the check copies: the fields in the middle of the order)
+        const int mid = NB / 2;
+        DevField<double>*s2 = f[order[mid - 1].second], *r2 = f[order[mid].second], *o2 = f[order[mid + 1].second];
+        fill(*a, 1, -1.0, 1.0);
+        fill(*d, 2, 4.0, 5.0);
+        printf("kprobe     the solve on the five %s fields (%d %d %d %d %d):\n", what, order[i0].second, order[i0 + step].second,
+               order[i0 + 2 * step].second, order[i0 + 3 * step].second, order[i0 + 4 * step].second);
+        for (int rep = 0; rep < 2; ++rep) tridiag_stack_variant<104, 40, 4, true, 1, 0>(*a, *d, *s, *r, *o, *s2, *r2, *o2, dI, dJ, dK);
+    };
+    if (NB >= 13) {
+        solve_on("FASTEST", 0, 1);
+        solve_on("SLOWEST", NB - 1, -1);
+        solve_on("FASTEST", 0, 1);
+    }
+    for (auto* x : f) delete x;
+    CK(hipFree(sink));
+}
+
 // pipelined vs plain on-chip-stack kernel, also on column counts / depths that exercise the head and odd-batch paths
 static void section_tripipe() {
     for (int rep = 0; rep < 2; ++rep) {
@@ -1132,6 +1193,7 @@ int main(int argc, char** argv) {
     if (on("hdiff")) section_hdiff();
     if (!want.empty() && on("hdiff2")) section_hdiff2();
     if (!want.empty() && on("hdiff3")) section_hdiff3();
+    if (!want.empty() && on("kprobe")) section_kprobe();
     if (!want.empty() && on("hdiffxcd")) section_hdiffxcd();
     if (on("tridiag")) section_tridiag();
     if (!want.empty() && on("triplace")) section_triplace(0, want);

@@ -154,18 +154,24 @@ class FormCheck:
                     f"({self.ghost_cells_to_fill} ghost cells to fill), {wrong_out} points of the result differ from the "
                     f"local kernel on the exactly known input [epoch {self.epoch}]")
 
-    def check(self, run, rounds: int = 3, loaded: int = 1, before_run=None) -> Tuple[bool, str]:
+    def check(self, run, rounds: int = 3, loaded=1, before_run=None) -> Tuple[bool, str]:
         """``rounds`` consecutive epochs of ``run()`` (the form on (``probe``, ``out``), enqueued on the current stream; it may
-        join side streams itself), the last ``loaded`` of them while ``HbmLoad`` keeps the memory system busy on a third
-        stream.  ``before_run()`` (optional) runs after each reset and before ``run`` -- where ranks meet (a barrier) so that
-        they launch together.  The first failing verdict ends it; else the last one, with the count of rounds."""
+        join side streams itself), the last ``loaded`` of them -- or, ``loaded="alternate"``, every other one -- while ``HbmLoad``
+        keeps the memory system busy on a third stream.  BOTH kinds of round matter: a saturated memory system widens the window
+        between a store and its visibility, but on ONE device shared by two ranks it also keeps the ranks' kernels from meeting
+        in flight, which HIDES a receive side that reads too early (profiles/r5_two_rank_direct_loop.log: the round-3 load order
+        fails 1 % of the idle rounds and none of the loaded ones).  ``before_run()`` (optional) runs after each reset and before
+        ``run`` -- where ranks meet (a barrier) so that they launch together.  The first failing verdict ends it; else the last
+        one, with the count of rounds."""
         import torch
 
         on_gpu = self.probe.tensor.is_cuda
         verdict = (True, "no round ran")
+        n_loaded = 0
         for r in range(rounds):
             self.reset()
-            under_load = on_gpu and r >= rounds - loaded
+            under_load = on_gpu and (r % 2 == 1 if loaded == "alternate" else r >= rounds - int(loaded))
+            n_loaded += int(under_load)
             if under_load and self._load is None:
                 self._load = HbmLoad(self.probe.tensor.device)
             if before_run is not None:
@@ -183,7 +189,7 @@ class FormCheck:
             verdict = (ok, found + (" (under HBM load)" if under_load else ""))
             if not ok:
                 return verdict
-        return verdict[0], f"{rounds} epochs, {min(loaded, rounds) if on_gpu else 0} of them under HBM load; last: {verdict[1]}"
+        return verdict[0], f"{rounds} epochs, {n_loaded} of them under HBM load; last: {verdict[1]}"
 
 
 def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("native", "torch"), out=None, epochs: int = 3,
@@ -196,7 +202,7 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
     Every form runs ``epochs`` consecutive epochs of the probe (``FormCheck.check``: each round's correct values differ from
     the previous round's in every cell), the last one next to an HBM-saturating background.  ``stress_epochs`` > 0: the
     one-stream form of the direct transport -- what ``bench.py`` is most likely to time -- additionally runs that many epochs,
-    ALL under load, the ranks meeting before every launch (``bench.py``'s canary asks for 200).  ``fenced``: the direct
+    every other one under load, the ranks meeting before every launch (``bench.py``'s canary asks for 200).  ``fenced``: the direct
     transport in its fenced mode (``tune(direct_fenced=True)``: release / acquire fences around the flags)."""
     import os
     import sys
@@ -300,8 +306,8 @@ def run_selfcheck(domain=(256, 192, 16), periodic: bool = False, transports=("na
 
                             record(f"native/{how} {table} fused {schedule} wg{wg}", run)
                             if how == "direct" and schedule == "inline" and wg == 0 and stress_epochs > 0:
-                                record(f"native/{how} {table} fused {schedule} wg{wg} x {stress_epochs} epochs under load", run,
-                                       rounds=stress_epochs, loaded=stress_epochs)
+                                record(f"native/{how} {table} fused {schedule} wg{wg} x {stress_epochs} epochs, every other one under load", run,
+                                       rounds=stress_epochs, loaded="alternate")
                     if how == "direct" and nex.direct_status()["timed_out"]:
                         results.append((f"halo {halo} grid {grid[0]}x{grid[1]} native/direct {table}: waits", False, "a wait ran out of time"))
                     nex.close()  # (collective on the direct transport: nobody unmaps a pool a peer may still push into)
@@ -354,8 +360,8 @@ def main(argv=None) -> int:
                     help="direct: only the direct transport of the native path, without RCCL (bench.py's canary)")
     ap.add_argument("--epochs", type=int, default=3, help="consecutive epochs of the probe per form (the last one under HBM load)")
     ap.add_argument("--stress-epochs", type=int, default=0,
-                    help="the direct transport's one-stream forms additionally run this many epochs, all under HBM load, ranks "
-                         "launching together (bench.py's canary: 200)")
+                    help="the direct transport's one-stream forms additionally run this many epochs, every other one under HBM load, "
+                         "ranks launching together (bench.py's canary: 200)")
     ap.add_argument("--fenced", action="store_true", help="the direct transport in its fenced mode (release / acquire around the flags)")
     a = ap.parse_args(argv)
     return 1 if run_selfcheck(tuple(a.domain), a.periodic, ("native", "torch") if a.transport == "both" else (a.transport,),

@@ -874,3 +874,61 @@ def test_every_round_of_the_form_check_can_see_a_receive_buffer_read_too_early(h
     t = own0.clone()
     _wrap_ghost_cells(t, h)
     assert torch.equal(t, exp0)  # round n's buffer content == round n + 1's expectation when the probe never changes
+
+
+def _worker_epoch_check(rank: int, world: int, tmpdir: str, grid, single_phase: bool):
+    """Two real ranks (gloo): `FormCheck.check` over the torch transport -- consecutive epochs pass -- and over a transport that
+    delivers every message ONE EXCHANGE LATE (the previous exchange's payload, as a receive buffer read before the neighbour's
+    stores have landed would): every round after the plan's first fails on every rank, naming the stale values."""
+    import torch
+    import torch.distributed as dist
+
+    from gt4py_amd.distributed import Decomposition, HaloExchanger
+    from gt4py_amd.distributed.selfcheck import FormCheck
+
+    h = 1
+    dec = Decomposition((16, 12, 3), grid, rank, h, periodic=(grid[0] > 1, grid[1] > 1))  # (gloo cannot send to the rank itself)
+
+    def local(a, b):
+        t, o = a.tensor, b.tensor
+        o.zero_()
+        o[h:-h, h:-h] = -4.0 * t[h:-h, h:-h] + t[:-2 * h, h:-h] + t[2 * h:, h:-h] + t[h:-h, :-2 * h] + t[h:-h, 2 * h:]
+
+    chk = FormCheck(dec, (lambda: _HostField(dec.local_shape)), local)
+    ex = HaloExchanger(dec, torch.float64, "cpu", packer=TorchSlicePacker(), single_phase=single_phase)
+
+    def correct():
+        ex.exchange(chk.probe.tensor)
+        local(chk.probe, chk.out)
+
+    ok, found = chk.check(correct, rounds=3, loaded=1, before_run=dist.barrier)
+    assert ok and chk.epoch == 3, found
+
+    held = {"ghosts": None}
+
+    def one_exchange_late():
+        t = chk.probe.tensor
+        fresh = t.clone()
+        ex.exchange(fresh)  # what a correct transport delivers now ...
+        mine = torch.zeros_like(t, dtype=torch.bool)
+        mine[h:-h, h:-h] = True
+        if held["ghosts"] is not None:  # ... is handed out only at the NEXT exchange
+            t.copy_(torch.where(mine, t, held["ghosts"]))
+        else:
+            t.copy_(fresh)
+        held["ghosts"] = fresh
+        local(chk.probe, chk.out)
+
+    verdicts = [list(chk.check(one_exchange_late, rounds=1, loaded=0, before_run=dist.barrier)) for _ in range(3)]
+    return {"ghost_cells": chk.ghost_cells_to_fill, "verdicts": verdicts}
+
+
+@pytest.mark.multiprocess
+@pytest.mark.parametrize("grid,single_phase", [((1, 2), False), ((2, 1), True)])
+def test_gloo_world_size_2_epoch_stamped_check_sees_a_late_transport_in_every_round(grid, single_phase, tmp_path):
+    got = run_ranks(_worker_epoch_check, 2, tmp_path, args=(grid, single_phase))
+    for r in (0, 1):
+        n = got[r]["ghost_cells"]
+        assert n > 0 and got[r]["verdicts"][0][0] is True  # (the plan's first exchange has nothing stale to hand out)
+        for ok, found in got[r]["verdicts"][1:]:
+            assert ok is False and f"[{n} of them hold the previous epoch's value" in found, (r, found)

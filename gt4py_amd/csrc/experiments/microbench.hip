@@ -78,13 +78,62 @@ struct DevField {
         bytes = (size_t)sk * nk * sizeof(T) + 2 * align_b;
         // MB_CONTIG=1: physically contiguous device memory (hipDeviceMallocContiguous) -- the placement experiment of round 4
         static const bool contiguous = getenv("MB_CONTIG") && atoi(getenv("MB_CONTIG")) != 0;
-        if (contiguous) CK(hipExtMallocWithFlags((void**)&raw, bytes, hipDeviceMallocContiguous));
+        // MB_VMM=<log2 of the VA alignment, e.g. 30>: the field is built with the virtual-memory API from physical chunks of
+        // power-of-two sizes (largest first), each mapped at a VA offset that is a multiple of its size inside a reservation aligned
+        // to 2^MB_VMM bytes -- if the physical allocator hands out naturally aligned chunks, VA and PA of every chunk are congruent
+        // modulo the chunk size and the page tables can use the largest fragments (round 5: the allocation-class hypothesis)
+        static const int vmm = getenv("MB_VMM") ? atoi(getenv("MB_VMM")) : 0;
+        if (vmm > 0) {
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = 0;
+            size_t gran = 0;
+            CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+            const size_t total = (bytes + gran - 1) / gran * gran;
+            static const size_t max_chunk = getenv("MB_VMM_MAX_CHUNK_LOG2") ? (size_t)1 << atoi(getenv("MB_VMM_MAX_CHUNK_LOG2")) : (size_t)1 << 30;
+            // (hipMemAddressReserve ignores its alignment argument on this runtime: reserve 2^MB_VMM more and start at the next multiple)
+            void* reserved = nullptr;
+            const size_t align = (size_t)1 << vmm;
+            CK(hipMemAddressReserve(&reserved, total + align, align, nullptr, 0));
+            vmm_reserved = (char*)reserved;
+            vmm_reserved_bytes = total + align;
+            void* va = (void*)(((uintptr_t)reserved + align - 1) / align * align);
+            size_t off = 0;
+            while (off < total) {
+                size_t chunk = max_chunk;
+                while (chunk > total - off || (off % chunk) != 0) chunk >>= 1;  // largest power of two that fits and keeps the offset aligned
+                if (chunk < gran) chunk = gran;
+                hipMemGenericAllocationHandle_t h;
+                CK(hipMemCreate(&h, chunk, &prop, 0));
+                CK(hipMemMap((char*)va + off, chunk, 0, h, 0));
+                vmm_handles.push_back(h);
+                off += chunk;
+            }
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            CK(hipMemSetAccess(va, total, &acc, 1));
+            raw = (char*)va;
+            vmm_total = total;
+        } else if (contiguous) CK(hipExtMallocWithFlags((void**)&raw, bytes, hipDeviceMallocContiguous));
         else CK(hipMalloc(&raw, bytes));
         // offset so that element index `hi` is aligned
         const size_t off = (align_b - ((size_t)hi * sizeof(T)) % align_b) % align_b;
         data = reinterpret_cast<T*>(raw + off);
     }
-    ~DevField() { hipFree(raw); }
+    std::vector<hipMemGenericAllocationHandle_t> vmm_handles;
+    size_t vmm_total = 0, vmm_reserved_bytes = 0;
+    char* vmm_reserved = nullptr;
+    ~DevField() {
+        if (vmm_total) {
+            (void)hipMemUnmap(raw, vmm_total);
+            for (auto h : vmm_handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(vmm_reserved, vmm_reserved_bytes);
+        } else {
+            (void)hipFree(raw);
+        }
+    }
     View<T> view() const {  // origin-shifted
         return View<T>{data + halo[0] + halo[1] * sj, 1, sj, sk};
     }
@@ -774,7 +823,104 @@ __global__ void __launch_bounds__(64) kcol_probe_kernel(const double* __restrict
     if (acc == 12345.678) sink[0] = acc;  // (never: the loads must not be optimised away)
 }
 
+// ... and the same columns written (MODE 1) or read, scaled and written back in place (MODE 2: what the forward sweep does to sup and rhs)
+template <int MODE>
+__global__ void __launch_bounds__(64) kcol_write_probe_kernel(double* __restrict__ p, int64_t sj, int64_t sk, int dK, unsigned ti) {
+    const unsigned tile = blockIdx.x % ti, j = blockIdx.x / ti;
+    double* q = p + (int64_t)j * sj + (int64_t)tile * 64 + threadIdx.x;
+#pragma unroll 8
+    for (int k = 0; k < dK; ++k) {
+        if (MODE == 1) q[(int64_t)k * sk] = 4.5;
+        else q[(int64_t)k * sk] = q[(int64_t)k * sk] * 1.0000001;
+    }
+}
+
+__global__ void __launch_bounds__(256) stream_write_probe_kernel(u32x4* __restrict__ p, long n) {
+    const u32x4 v = {1u, 2u, 3u, 4u};
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long)gridDim.x * 256) __builtin_nontemporal_store(v, p + t);
+}
+
+// MB_KPROBE_MAP=N: N separately allocated fields of 1.34 GB, each probed with the K-strided write, a K-strided read and a plain
+// streaming write -- a map of how the device's memory answers, allocation by allocation (no solve).
+static void kprobe_map(int nb) {
+    const int dI = 1024, dJ = 1024, dK = 160;
+    const unsigned ti = (unsigned)cdiv(dI, 64);
+    std::vector<DevField<double>*> f;
+    double* sink = nullptr;
+    CK(hipMalloc(&sink, 64));
+    for (int b = 0; b < nb; ++b) {
+        f.push_back(new DevField<double>(dI, dJ, dK, 0, 0));
+        DevField<double>& x = *f.back();
+        fill(x, 100 + b, 4.0, 5.0);
+        const double gb = (double)dI * dJ * dK * 8.0 / 1e9;
+        const double w = time_ms([&](int) { hipLaunchKernelGGL(kcol_write_probe_kernel<1>, dim3(ti * dJ), dim3(64), 0, 0, x.data, x.sj, x.sk, dK, ti); }, 6, 2);
+        const double r = time_ms([&](int) { hipLaunchKernelGGL(kcol_probe_kernel, dim3(ti * dJ), dim3(64), 0, 0, x.data, x.sj, x.sk, dK, ti, sink); }, 6, 2);
+        const double sw = time_ms([&](int) { hipLaunchKernelGGL(stream_write_probe_kernel, dim3(8192), dim3(256), 0, 0, (u32x4*)x.data, (long)((size_t)dI * dJ * dK / 2)); }, 6, 2);
+        printf("kmap       field %3d at %p (+%7.1f MiB from the previous): K-strided write %7.1f GB/s  K-strided read %7.1f GB/s  streaming write %7.1f GB/s  %s\n", b,
+               (void*)x.raw, b ? ((double)((intptr_t)f[b - 1]->raw - (intptr_t)x.raw)) / 1048576.0 : 0.0, gb / (w * 1e-3), gb / (r * 1e-3), gb / (sw * 1e-3),
+               gb / (w * 1e-3) > 5800.0 ? "FAST" : "slow");
+        fflush(stdout);
+    }
+    for (auto* x : f) delete x;
+    CK(hipFree(sink));
+}
+
+// MB_KCHUNK=N: is the write speed a property of the PHYSICAL memory or of how it is mapped?  N physical chunks of 256 MiB
+// (hipMemCreate), each mapped at a 256-MiB-aligned address, probed (K-strided write over its 32 planes of 8 MiB, and a streaming write),
+// unmapped, mapped again 2 MiB further (an address that is NOT aligned to the chunk), probed again, and a third time at the first address.
+static void kchunk(int n) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    const size_t chunk = (size_t)256 << 20, align = chunk;
+    void* reserved = nullptr;
+    CK(hipMemAddressReserve(&reserved, 4 * chunk, align, nullptr, 0));
+    char* base = (char*)(((uintptr_t)reserved + align - 1) / align * align);
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const int dI = 1024, dJ = 1024, dK = 32;
+    const unsigned ti = 16;
+    auto probe = [&](char* va, double* kw, double* sw) {
+        double* p = (double*)va;
+        const double gb = (double)chunk / 1e9;
+        const double a = time_ms([&](int) { hipLaunchKernelGGL(kcol_write_probe_kernel<1>, dim3(ti * dJ), dim3(64), 0, 0, p, (int64_t)dI, (int64_t)dI * dJ, dK, ti); }, 20, 3);
+        const double b = time_ms([&](int) { hipLaunchKernelGGL(stream_write_probe_kernel, dim3(8192), dim3(256), 0, 0, (u32x4*)p, (long)(chunk / 16)); }, 20, 3);
+        *kw = gb / (a * 1e-3);
+        *sw = gb / (b * 1e-3);
+    };
+    std::vector<hipMemGenericAllocationHandle_t> held;
+    for (int c = 0; c < n; ++c) {
+        hipMemGenericAllocationHandle_t h;
+        CK(hipMemCreate(&h, chunk, &prop, 0));
+        held.push_back(h);  // (kept: the next chunk is another piece of physical memory)
+        double kw[3], sw[3];
+        char* where[3] = {base, base + chunk + ((size_t)2 << 20), base};
+        for (int t = 0; t < 3; ++t) {
+            CK(hipMemMap(where[t], chunk, 0, h, 0));
+            CK(hipMemSetAccess(where[t], chunk, &acc, 1));
+            probe(where[t], &kw[t], &sw[t]);
+            CK(hipDeviceSynchronize());
+            CK(hipMemUnmap(where[t], chunk));
+        }
+        printf("kchunk     chunk %3d: aligned VA  K-strided write %7.1f  streaming write %7.1f | VA + 2 MiB  %7.1f  %7.1f | aligned again  %7.1f  %7.1f GB/s  %s\n", c, kw[0], sw[0],
+               kw[1], sw[1], kw[2], sw[2], kw[0] > 5800.0 ? "FAST" : "slow");
+        fflush(stdout);
+    }
+    for (auto h : held) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(reserved, 4 * chunk);
+}
+
 static void section_kprobe() {
+    if (getenv("MB_KCHUNK")) {
+        kchunk(atoi(getenv("MB_KCHUNK")));
+        return;
+    }
+    if (getenv("MB_KPROBE_MAP")) {
+        kprobe_map(atoi(getenv("MB_KPROBE_MAP")));
+        return;
+    }
     const int dI = 1024, dJ = 1024, dK = 160;
     const int NB = getenv("MB_KPROBE_FIELDS") ? atoi(getenv("MB_KPROBE_FIELDS")) : 14;
     std::vector<DevField<double>*> f;
@@ -795,6 +941,14 @@ static void section_kprobe() {
                    (reinterpret_cast<uintptr_t>(f[b]->data) % (1ull << 30)) / 1048576.0, ms, (double)dI * dJ * dK * 8.0 / (ms * 1e-3) / 1e9);
             if (pass == 1) order.push_back({ms, b});
         }
+    for (int b = 0; b < NB; ++b) {
+        const double w = time_ms([&](int) { hipLaunchKernelGGL(kcol_write_probe_kernel<1>, dim3(ti * dJ), dim3(64), 0, 0, f[b]->data, f[b]->sj, f[b]->sk, dK, ti); }, 10, 2);
+        const double rw = time_ms([&](int) { hipLaunchKernelGGL(kcol_write_probe_kernel<2>, dim3(ti * dJ), dim3(64), 0, 0, f[b]->data, f[b]->sj, f[b]->sk, dK, ti); }, 10, 2);
+        const double gb = (double)dI * dJ * dK * 8.0 / 1e9;
+        printf("kprobe     field %2d: K-strided write %8.4f ms %7.1f GB/s   read-modify-write in place %8.4f ms %7.1f GB/s (read + written)\n", b, w, gb / (w * 1e-3),
+               rw, 2.0 * gb / (rw * 1e-3));
+        if (getenv("MB_KPROBE_BY_WRITE")) order[b] = {w, b};  // (rank the fields by the WRITE probe instead)
+    }
     std::sort(order.begin(), order.end());
     printf("kprobe     fastest -> slowest:");
     for (auto& o : order) printf(" %d(%.3f)", o.second, o.first);
@@ -812,10 +966,27 @@ static void section_kprobe() {
                order[i0 + 2 * step].second, order[i0 + 3 * step].second, order[i0 + 4 * step].second);
         for (int rep = 0; rep < 2; ++rep) tridiag_stack_variant<104, 40, 4, true, 1, 0>(*a, *d, *s, *r, *o, *s2, *r2, *o2, dI, dJ, dK);
     };
-    if (NB >= 13) {
+    if (NB >= 13 && !getenv("MB_KPROBE_NO_SOLVE")) {
         solve_on("FASTEST", 0, 1);
         solve_on("SLOWEST", NB - 1, -1);
         solve_on("FASTEST", 0, 1);
+    }
+    if (NB >= 4 && getenv("MB_KPROBE_LAP")) {
+        // the headline stencil with its fields inside allocations of either class: 512^3 fp64, rows of 528 items, origin (1, 1)
+        const int64_t d[3] = {512, 512, 512};
+        const int64_t sj = 528, sk = sj * 514;
+        auto lap_ms = [&](DevField<double>* fi, DevField<double>* fo) {
+            const View<const double> in{fi->data + 16 + sj, 1, sj, sk};
+            const View<double> out{fo->data + 16 + sj, 1, sj, sk};
+            return time_ms([&](int) { (void)lap5_launch_variant<double, double, GT4MI_LAP_NOTEBOOK>(in, out, d, 0); }, 60, 5);
+        };
+        DevField<double>*fast_a = f[order[0].second], *fast_b = f[order[1].second], *slow_a = f[order[NB - 1].second], *slow_b = f[order[NB - 2].second];
+        for (int rep = 0; rep < 2; ++rep) {
+            const double ss = lap_ms(slow_a, slow_b), sf = lap_ms(slow_a, fast_a), ff = lap_ms(fast_b, fast_a), fs = lap_ms(fast_b, slow_b);
+            const double lups = 512.0 * 512.0 * 512.0;
+            printf("kprobe     Laplacian 512^3, in / out in allocations of class  slow/slow %.4f ms (%.1f GLUPS)  slow/FAST %.4f (%.1f)  FAST/FAST %.4f (%.1f)  FAST/slow %.4f (%.1f)\n",
+                   ss, lups / ss / 1e6, sf, lups / sf / 1e6, ff, lups / ff / 1e6, fs, lups / fs / 1e6);
+        }
     }
     for (auto* x : f) delete x;
     CK(hipFree(sink));

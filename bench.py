@@ -286,6 +286,8 @@ def other_kernels(steps: int = 20, only=None):
     from gt4py_amd.cartesian import gtscript
     from gt4py_amd.cartesian.backend import hip_templates
 
+    from gt4py_amd.storage import placement
+
     gen = torch.Generator(device="cuda").manual_seed(2024)
 
     def field(shape, dtype, origin, lo=-1.0, hi=1.0):
@@ -329,6 +331,8 @@ def other_kernels(steps: int = 20, only=None):
                                   "unit": "GB/s", "frac": round(gbs / PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                                   "algorithmic_bytes_per_launch": bytes_per_lup * lups,
                                   "traffic_over_algorithmic": round(traffic / (bytes_per_lup * lups), 4) if traffic else None}}
+        sets = fields if isinstance(fields, (list, tuple)) else [fields]
+        out[name]["memory_classes"] = [{k: placement.class_of(v) for k, v in fs.items()} for fs in sets]  # (None: too small to classify)
         if note:
             out[name]["note"] = note
 
@@ -410,6 +414,12 @@ def other_kernels(steps: int = 20, only=None):
     return out
 
 
+def _placement_class(array):
+    from gt4py_amd.storage import placement
+
+    return placement.class_of(array)
+
+
 def _tridiagonal_entry(field, steps: int):
     """BASELINE.json configs[3]: the vertical tridiagonal solve on 1024 x 1024 x 160 fp64, timed on the SURVEY section 8d inputs
     EVERY launch: the solve overwrites `sup` and `rhs` in place, so each launch is preceded by a restore of both from pristine
@@ -461,6 +471,7 @@ def _tridiagonal_entry(field, steps: int):
              "ms_by_allocation_set": [round(v, 4) for v in by_set],
              "frac_of_hbm_peak_by_allocation_set": [round(56.0 * lups / (v * 1e-3) / 1e9 / PEAK_GBS, 4) for v in by_set],
              "field_addresses_mod_4MiB": [[int(f.ptr % (4 << 20)) for f in fs.values()] for fs in sets],
+             "memory_classes_by_allocation_set": [{k: _placement_class(v) for k, v in fs.items()} for fs in sets],
              "inputs": "SURVEY.md section 8d (diag ~ U[4, 5), inf, sup ~ U[-1, 1), rhs ~ U[-10, 10)), sup and rhs restored from "
                        "pristine copies before EVERY launch, outside the timed interval; two rotating sets of the five fields",
              "roofline": {"bound": "hbm", "kernel": KERNEL_NEEDLES.get(name), "achieved": round(gbs, 1), "peak": PEAK_GBS, "unit": "GB/s",
@@ -1652,6 +1663,15 @@ def main() -> None:
         step, kernel_step, local_domain, config, extras = _setup_hdiff2048(args, ctx)
         total_lups = extras["total_lups"]
     elif not decomposed:
+        # The storage allocator deals big fields over the device's memory groups (gt4py_amd/storage/placement.py: `in` and `out` of a
+        # stencil in different groups of memory channels are worth 2 % on this kernel, 13 % on the tridiagonal solve).  A program that
+        # is about to allocate the fields of bandwidth-bound kernels may widen the allocator's search for a second group: up to 24
+        # candidates per field instead of 6, from the fifth on each behind an 8 GB spacer that is never touched (the groups change
+        # along the physical address space; everything but the chosen block and a few parked neighbours is released when a search ends).
+        from gt4py_amd.storage import placement
+
+        placement.configure(max_candidates=int(os.environ.get("GT4MI_BENCH_GROUP_SEARCH", "24")),
+                            spacer_bytes=int(os.environ.get("GT4MI_BENCH_GROUP_SPACER_GB", "8")) << 30, park_extra=5)
         lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64},
                                device_sync=False)
         origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}
@@ -1667,7 +1687,8 @@ def main() -> None:
         kernel_step = step
         config = {"workload": "fp64 5-point Laplacian 512x512x512 (examples/lap_cartesian_vs_next.ipynb cell 7), "
                               "origin (1,1,0), hip:mi300 storage layout", "grid": list(GRID), "decomposition": "1x1",
-                  "call_path": "FrozenStencil"}
+                  "call_path": "FrozenStencil",
+                  "memory_classes_of_the_fields": [[placement.class_of(i), placement.class_of(o)] for i, o in pairs]}
         total_lups = float(np.prod(GRID))
     else:
         step, kernel_step, local_domain, config, extras = _setup_distributed_laplacian(args, ctx)
@@ -1715,6 +1736,10 @@ def main() -> None:
             except Exception as ex:
                 line["other_kernels"] = None
                 print(f"other_kernels failed: {ex!r}", file=sys.stderr)
+        if headline:
+            from gt4py_amd.storage import placement as _placement
+
+            line["memory_groups"] = _placement.report()  # what the allocator's placer did for every big field of this run
         if headline and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -71,9 +71,10 @@ EXPORTED_SYMBOLS = (
     "gt4mi_launch",
     "gt4mi_launch_batch",
     "gt4mi_stream_copy",
+    "gt4mi_memory_write_probe",
 )
 
-GT4MI_ABI_VERSION = 6
+GT4MI_ABI_VERSION = 7
 
 # gt4mi_status
 OK = 0
@@ -191,6 +192,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.gt4mi_halo_unpack.argtypes = [FP, DOM, DOM, P, I, P]
     lib.gt4mi_stream_copy.restype = I
     lib.gt4mi_stream_copy.argtypes = [P, P, ctypes.c_size_t, P]
+    lib.gt4mi_memory_write_probe.restype = I
+    lib.gt4mi_memory_write_probe.argtypes = [P, P, ctypes.c_size_t, I, P, ctypes.POINTER(D)]
     MP = ctypes.POINTER(HaloMsg)
     PP = ctypes.POINTER(ctypes.c_void_p)
     lib.gt4mi_comm_unique_id.restype = I

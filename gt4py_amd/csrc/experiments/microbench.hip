@@ -865,6 +865,151 @@ static void kprobe_map(int nb) {
     CK(hipFree(sink));
 }
 
+// MB_KPAIRS=N: do two fields that are written side by side (sup and rhs in the solve's forward sweep) get in each other's way, and does
+// that depend on WHICH two allocations they are?  N fields; every pair (a, b) is written K-strided in ONE kernel (two stores per level),
+// and every field alone; printed as a matrix of GB/s.  A pairwise effect (DRAM banks shared by two streams whose addresses collide in
+// the bank bits) would show as pairs that are slow although both members are fast alone.
+__global__ void __launch_bounds__(64) kcol_pair_write_probe_kernel(double* __restrict__ p, double* __restrict__ q2, int64_t sj, int64_t sk, int dK, unsigned ti) {
+    const unsigned tile = blockIdx.x % ti, j = blockIdx.x / ti;
+    const int64_t off = (int64_t)j * sj + (int64_t)tile * 64 + threadIdx.x;
+    double *a = p + off, *b = q2 + off;
+#pragma unroll 8
+    for (int k = 0; k < dK; ++k) {
+        a[(int64_t)k * sk] = 4.5;
+        b[(int64_t)k * sk] = 5.5;
+    }
+}
+
+static void kpairs(int n) {
+    const int dI = 1024, dJ = 1024, dK = 160;
+    const unsigned ti = 16;
+    std::vector<DevField<double>*> f;
+    for (int b = 0; b < n; ++b) {
+        f.push_back(new DevField<double>(dI, dJ, dK, 0, 0));
+        fill(*f.back(), 100 + b, 4.0, 5.0);
+    }
+    const double gb = (double)dI * dJ * dK * 8.0 / 1e9;
+    printf("kpairs     K-strided writes, GB/s: diagonal = the field alone, (a, b) = both fields written in one kernel (bytes of both counted)\n");
+    for (int a = 0; a < n; ++a) {
+        printf("kpairs     %2d |", a);
+        for (int b = 0; b < n; ++b) {
+            double ms;
+            if (a == b) {
+                ms = time_ms([&](int) { hipLaunchKernelGGL(kcol_write_probe_kernel<1>, dim3(ti * dJ), dim3(64), 0, 0, f[a]->data, f[a]->sj, f[a]->sk, dK, ti); }, 8, 2);
+                printf(" [%5.0f]", gb / (ms * 1e-3));
+            } else if (b > a) {
+                ms = time_ms([&](int) { hipLaunchKernelGGL(kcol_pair_write_probe_kernel, dim3(ti * dJ), dim3(64), 0, 0, f[a]->data, f[b]->data, f[a]->sj, f[a]->sk, dK, ti); }, 8, 2);
+                printf("  %5.0f ", 2.0 * gb / (ms * 1e-3));
+            } else {
+                printf("    .   ");
+            }
+        }
+        printf("\n");
+    }
+    fflush(stdout);
+    // ---- groups: a and b are in the same group when writing both is no faster than 6.55 TB/s --------------------------------------
+    std::vector<std::vector<double>> pair(n, std::vector<double>(n, 0.0));
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b) {
+            const double ms = time_ms([&](int) { hipLaunchKernelGGL(kcol_pair_write_probe_kernel, dim3(ti * dJ), dim3(64), 0, 0, f[a]->data, f[b]->data, f[a]->sj, f[a]->sk, dK, ti); }, 8, 2);
+            pair[a][b] = pair[b][a] = 2.0 * gb / (ms * 1e-3);
+        }
+    std::vector<int> group(n, -1);
+    int ngroups = 0;
+    for (int a = 0; a < n; ++a) {
+        if (group[a] >= 0) continue;
+        group[a] = ngroups++;
+        for (int b = a + 1; b < n; ++b)
+            if (group[b] < 0 && pair[a][b] < 6550.0) group[b] = group[a];
+    }
+    printf("kpairs     groups:");
+    for (int a = 0; a < n; ++a) printf(" %d:%c", a, 'A' + group[a]);
+    printf("\n");
+    auto pick = [&](int g, int nth) {  // the nth field of group g, or -1
+        for (int a = 0; a < n; ++a)
+            if (group[a] == g && nth-- == 0) return a;
+        return -1;
+    };
+    // the headline stencil: in and out in ONE group against in and out in DIFFERENT groups
+    {
+        const int64_t d[3] = {512, 512, 512};
+        const int64_t sj = 528, sk = sj * 514;
+        auto lap_ms = [&](int fi, int fo) {
+            const View<const double> in{f[fi]->data + 16 + sj, 1, sj, sk};
+            const View<double> out{f[fo]->data + 16 + sj, 1, sj, sk};
+            return time_ms([&](int) { (void)lap5_launch_variant<double, double, GT4MI_LAP_NOTEBOOK>(in, out, d, 0); }, 60, 5);
+        };
+        const double lups = 512.0 * 512.0 * 512.0;
+        for (int g = 0; g < ngroups; ++g) {
+            const int a = pick(g, 0), b = pick(g, 1);
+            if (a >= 0 && b >= 0) {
+                const double ms = lap_ms(a, b);
+                printf("kpairs     Laplacian 512^3  in %2d  out %2d  (both group %c)        %.4f ms  %.1f GLUPS  %.3f of 8 TB/s\n", a, b, 'A' + g, ms, lups / ms / 1e6, 16.0 * lups / (ms * 1e-3) / 8e12);
+            }
+            for (int h = 0; h < ngroups; ++h) {
+                const int c = pick(h, 0);
+                if (h == g || a < 0 || c < 0) continue;
+                const double ms = lap_ms(a, c);
+                printf("kpairs     Laplacian 512^3  in %2d  out %2d  (groups %c -> %c)       %.4f ms  %.1f GLUPS  %.3f of 8 TB/s\n", a, c, 'A' + g, 'A' + h, ms, lups / ms / 1e6, 16.0 * lups / (ms * 1e-3) / 8e12);
+            }
+        }
+    }
+    // horizontal diffusion, the configs[4] share (512 x 1024 x 80 fp64, 339 MB per field) and configs[2] (fp32): in / coeff / out in one
+    // group against in + out in one and coeff in another, and against out alone in the other
+    if (ngroups >= 2) {
+        const int64_t d[3] = {512, 1024, 80};
+        const int64_t sj = 528, sk = sj * 1028;
+        auto views = [&](int fi, int fc, int fo, View<const double>* in, View<const double>* cf, View<double>* out) {
+            *in = View<const double>{f[fi]->data + 16 + 2 * sj, 1, sj, sk};
+            *cf = View<const double>{f[fc]->data + 16 + 2 * sj, 1, sj, sk};
+            *out = View<double>{f[fo]->data + 16 + 2 * sj, 1, sj, sk};
+        };
+        auto hd_ms = [&](int fi, int fc, int fo) {
+            View<const double> in, cf;
+            View<double> out;
+            views(fi, fc, fo, &in, &cf, &out);
+            return time_ms([&](int) { (void)hdiff_launch<double, double, double, true, true>(in, out, cf, 0.0, d, 0); }, 100, 10);
+        };
+        const int a0 = pick(0, 0), a1 = pick(0, 1), a2 = pick(0, 2), b0 = pick(1, 0);
+        if (a0 >= 0 && a1 >= 0 && a2 >= 0 && b0 >= 0) {
+            for (int rep = 0; rep < 2; ++rep) {
+                const double same = hd_ms(a0, a1, a2), cf_other = hd_ms(a0, b0, a2), out_other = hd_ms(a0, a1, b0), in_other = hd_ms(b0, a1, a2);
+                const double bytes = 24.0 * 512 * 1024 * 80;
+                printf("kpairs     hdiff fp64 512x1024x80  all in one group %.4f ms (%.3f)   coeff in the other %.4f (%.3f)   out in the other %.4f (%.3f)   in in the other %.4f (%.3f of 8 TB/s)\n",
+                       same, bytes / (same * 1e-3) / 8e12, cf_other, bytes / (cf_other * 1e-3) / 8e12, out_other, bytes / (out_other * 1e-3) / 8e12, in_other, bytes / (in_other * 1e-3) / 8e12);
+            }
+        }
+    }
+    // the solve: inf, diag, sup, rhs, out dealt over the groups round-robin against all five from the largest group
+    if (n >= 10) {
+        int largest = 0;
+        std::vector<int> count(ngroups, 0);
+        for (int a = 0; a < n; ++a) ++count[group[a]];
+        for (int g = 1; g < ngroups; ++g)
+            if (count[g] > count[largest]) largest = g;
+        std::vector<int> spread, same, used(n, 0);
+        for (int i = 0, nth = 0; (int)spread.size() < 8 && nth < n; ++i) {
+            const int a = pick(i % ngroups, i / ngroups);
+            if (i % ngroups == ngroups - 1) ++nth;
+            if (a >= 0 && !used[a]) { spread.push_back(a); used[a] = 1; }
+        }
+        for (int a = 0; a < n && (int)same.size() < 8; ++a)
+            if (group[a] == largest) same.push_back(a);
+        auto solve = [&](const char* what, const std::vector<int>& v) {
+            if (v.size() < 8) { printf("kpairs     (not enough fields for the solve %s)\n", what); return; }
+            printf("kpairs     the solve with inf diag sup rhs out = fields %d %d %d %d %d (%s):\n", v[0], v[1], v[2], v[3], v[4], what);
+            fill(*f[v[0]], 1, -1.0, 1.0);
+            fill(*f[v[1]], 2, 4.0, 5.0);
+            tridiag_stack_variant<104, 40, 4, true, 1, 0>(*f[v[0]], *f[v[1]], *f[v[2]], *f[v[3]], *f[v[4]], *f[v[5]], *f[v[6]], *f[v[7]], dI, dJ, dK);
+        };
+        solve("dealt over the groups round-robin", spread);
+        if (count[largest] >= 8) solve("all in one group", same);
+        solve("dealt over the groups round-robin", spread);
+    }
+    fflush(stdout);
+    for (auto* x : f) delete x;
+}
+
 // MB_KCHUNK=N: is the write speed a property of the PHYSICAL memory or of how it is mapped?  N physical chunks of 256 MiB
 // (hipMemCreate), each mapped at a 256-MiB-aligned address, probed (K-strided write over its 32 planes of 8 MiB, and a streaming write),
 // unmapped, mapped again 2 MiB further (an address that is NOT aligned to the chunk), probed again, and a third time at the first address.
@@ -915,6 +1060,10 @@ static void kchunk(int n) {
 static void section_kprobe() {
     if (getenv("MB_KCHUNK")) {
         kchunk(atoi(getenv("MB_KCHUNK")));
+        return;
+    }
+    if (getenv("MB_KPAIRS")) {
+        kpairs(atoi(getenv("MB_KPAIRS")));
         return;
     }
     if (getenv("MB_KPROBE_MAP")) {

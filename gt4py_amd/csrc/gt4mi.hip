@@ -10,6 +10,7 @@
 #include "comm.hip.h"
 #include "common.hip.h"
 #include "halo.hip.h"
+#include "memprobe.hip.h"
 #include "hdiff.hip.h"
 #include "hdiff_ring.hip.h"
 #include "lap5.hip.h"
@@ -923,6 +924,10 @@ int gt4mi_stream_copy(const void* src, void* dst, size_t nbytes, void* stream) {
                        static_cast<gt4mi::u32x4*>(dst), nvec);
     GT4MI_HIP_CHECK(hipGetLastError());
     return GT4MI_OK;
+}
+
+int gt4mi_memory_write_probe(void* a, void* b, size_t bytes, int iterations, void* stream, double* gbs) {
+    return gt4mi::memory_write_probe(a, b, bytes, iterations, static_cast<hipStream_t>(stream), gbs);
 }
 
 // ---- run-time compiled stencils (generic executor) -------------------------------------------------

@@ -133,7 +133,15 @@ def allocate_gpu(shape, layout_map, dtype, alignment_bytes, aligned_index) -> Tu
     tdt = torch_dtype(dtype)
     plan = plan_buffer(shape, dtype, layout_map, alignment_bytes, aligned_index)
     if plan.total_bytes >= PLACEMENT_MIN_BYTES:
-        raw = torch.empty((plan.total_bytes + PLACEMENT_PERIOD,), dtype=torch.uint8, device="cuda")
+        # big fields are dealt over the device's memory groups (placement.py: two fields a kernel streams side by side are up to
+        # 15 % faster when they do NOT share a group of memory channels); sizes the placer does not handle come back unclassified
+        from . import placement
+
+        placer = placement.device_placer()
+        if placer is not None:
+            raw, _ = placer.place(plan.total_bytes + PLACEMENT_PERIOD)
+        else:
+            raw = torch.empty((plan.total_bytes + PLACEMENT_PERIOD,), dtype=torch.uint8, device="cuda")
         skew = _placement_shift(raw.data_ptr(), alignment_bytes)
     else:
         raw = torch.empty((plan.total_bytes,), dtype=torch.uint8, device="cuda")

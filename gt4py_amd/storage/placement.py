@@ -1,0 +1,211 @@
+"""Memory-group-aware placement of big device fields (``hip:mi300`` storage preset) -- NEW relative to the reference, whose
+allocators hand a byte count to cupy and know nothing of the device's memory system (storage/allocators.py:187-273).
+
+What it is for (measured in round 5, profiles/r5_memory_groups.txt): MI355X's memory is not one uniformly interleaved pool.  Two
+big allocations either share a GROUP of memory channels or they do not, nothing in the HIP API says which, and kernels feel it:
+
+* two 1.3 GB fields written side by side: 5.0-6.4 TB/s when both live in one group, 6.8-7.0 TB/s in two;
+* fp64 5-point Laplacian on 512^3: +2.3 % with ``in`` and ``out`` in different groups;
+* tridiagonal solve 1024 x 1024 x 160: 0.70 of the HBM peak with its five fields dealt over two groups, 0.61 with all five in one
+  -- the "two speed modes by allocation set" that rounds 2-4 could measure and not explain.
+
+What it does: big allocations (``min_bytes`` <= size <= ``max_bytes``) are CLASSIFIED with ``gt4mi_memory_write_probe`` against ONE
+reference buffer the placer owns -- class 0: the reference's group, class 1: any other group -- and DEALT: a new field goes to the
+class that holds fewer live bytes.  To get there the placer allocates candidates (held until the search ends: a block that went back
+to the caching allocator would be handed out again at once), takes the first one of the wanted class, and releases the rest; the
+search is bounded (``max_candidates``, ``max_held_bytes``) and when it finds nothing the field simply lands where the driver put it.
+The layout contract is untouched: which raw block a storage lives in is no part of it.
+
+The probe OVERWRITES a candidate: it only ever runs on fresh blocks (``empty`` semantics; ``zeros`` / ``ones`` / ``from_array`` fill
+afterwards) and on the placer's own reference.  Classification of a block is remembered by (address, size): a block that comes back
+from the caching allocator is not probed again.
+
+``GT4PY_AMD_ALLOC_GROUPS=0`` switches the placer off; ``GT4PY_AMD_ALLOC_GROUP_SEARCH`` = candidates per search (default 6).
+"""
+
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+MIN_BYTES = 192 << 20  # below this the Infinity Cache (256 MB) absorbs the pair probe's writes (classification is clean from 192 MiB on:
+#                        same group 5.0-5.7 TB/s, other group 6.7-6.95, profiles/r5_memory_groups.txt)
+REFERENCE_BYTES = 512 << 20  # the placer's own buffer is at least this big
+MAX_BYTES = 2 << 30    # above this a held candidate costs too much; such fields land where the driver puts them
+PAIR_GBS_OTHER_GROUP = 6550.0  # two buffers written side by side: >= this -> different groups (same group: 5.0-6.4, other: 6.8-7.0 TB/s)
+
+
+class MemoryGroupPlacer:
+    """``allocate(nbytes) -> block`` (an object with ``data_ptr()``; it is kept alive by whoever holds it) and
+    ``probe(ptr_a, ptr_b_or_0, nbytes) -> GB/s`` are injected: the tests run the policy on the CPU with models of both."""
+
+    def __init__(self, allocate: Callable[[int], Any], probe: Callable[[int, int, int], float], *, min_bytes: int = MIN_BYTES,
+                 max_bytes: int = MAX_BYTES, max_candidates: Optional[int] = None, max_held_bytes: int = 48 << 30,
+                 threshold_gbs: Optional[float] = None, release: Optional[Callable[[], None]] = None,
+                 free_bytes: Optional[Callable[[], int]] = None, spacer_bytes: int = 0, plain_candidates: int = 4, park_extra: int = 0,
+                 keep_free_bytes: int = 16 << 30):
+        self.allocate, self.probe, self.release, self.free_bytes = allocate, probe, release, free_bytes
+        self.min_bytes, self.max_bytes, self.max_held_bytes = int(min_bytes), int(max_bytes), int(max_held_bytes)
+        # the WIDE search (off by default; `configure(spacer_bytes=...)`): groups change along the physical address space, often only
+        # tens of GB apart, so after `plain_candidates` plain candidates every further candidate is preceded by a SPACER -- an
+        # allocation of `spacer_bytes` that is never touched and only moves the driver's frontier -- as long as `keep_free_bytes`
+        # of device memory stay free; everything is released when the search ends.  `park_extra`: when a block of a class is found
+        # far away, up to that many more blocks of the same size are taken next to it (groups come in runs) and PARKED for the
+        # next fields that want the class, so that the wide search runs once, not once per field.
+        self.spacer_bytes, self.plain_candidates, self.park_extra = int(spacer_bytes), int(plain_candidates), int(park_extra)
+        self.keep_free_bytes = int(keep_free_bytes)
+        self.parked: Dict[Tuple[int, int], list] = {}  # (class, size) -> blocks
+        self.max_candidates = int(max_candidates if max_candidates is not None else os.environ.get("GT4PY_AMD_ALLOC_GROUP_SEARCH", "6"))
+        self.threshold = float(threshold_gbs if threshold_gbs is not None else os.environ.get("GT4PY_AMD_ALLOC_GROUP_PAIR_GBS", PAIR_GBS_OTHER_GROUP))
+        self.reference: Any = None          # the placer's own buffer: class 0 is ITS group
+        self.reference_bytes = 0
+        self.known: Dict[Tuple[int, int], int] = {}  # (address, size) -> class of blocks probed so far
+        self.live = [0, 0]                  # bytes of live classified fields per class
+        self.stats = {"placed": [0, 0], "searches": 0, "candidates": 0, "probes": 0, "wanted_class_not_found": 0, "unclassified": 0}
+        self.log: List[Dict[str, Any]] = []  # one record per placed field (bench.py prints it)
+
+    # ---- classification -----------------------------------------------------------------------------------------------------
+    def _classify(self, block, nbytes: int) -> int:
+        key = (int(block.data_ptr()), int(nbytes))
+        if key in self.known:
+            return self.known[key]
+        span = min(nbytes, self.reference_bytes)
+        gbs = self.probe(int(block.data_ptr()), int(self.reference.data_ptr()), span)
+        self.stats["probes"] += 1
+        cls = 1 if gbs >= self.threshold else 0
+        self.known[key] = cls
+        return cls
+
+    def _ensure_reference(self, nbytes: int) -> None:
+        """The first big allocation's block becomes the reference (kept for the life of the placer: <= max_bytes)."""
+        if self.reference is None:
+            self.reference_bytes = max(nbytes, REFERENCE_BYTES, self.min_bytes)
+            self.reference = self.allocate(self.reference_bytes)
+
+    # ---- placement ----------------------------------------------------------------------------------------------------------
+    def place(self, nbytes: int, label: str = ""):
+        """A block of ``nbytes`` in the class that currently holds fewer live bytes, if the search finds one; ``(block, cls)`` with
+        ``cls`` None for sizes the placer does not handle."""
+        nbytes = int(nbytes)
+        if not (self.min_bytes <= nbytes <= self.max_bytes) or self.max_candidates <= 0:
+            self.stats["unclassified"] += 1
+            return self.allocate(nbytes), None
+        self._ensure_reference(nbytes)
+        wanted = 0 if self.live[0] <= self.live[1] else 1
+        held, spacers, chosen, chosen_cls = [], [], None, None
+        parked = self.parked.get((wanted, nbytes))
+        if parked:
+            chosen, chosen_cls = parked.pop(), wanted
+        else:
+            self.stats["searches"] += 1
+            held_bytes = 0
+            for i in range(self.max_candidates):
+                if i >= self.plain_candidates and self.spacer_bytes > 0:
+                    if self.free_bytes is not None and self.free_bytes() < self.spacer_bytes + nbytes + self.keep_free_bytes:
+                        break
+                    spacers.append(self.allocate(self.spacer_bytes))  # never touched: it only moves the driver's frontier
+                    self.stats["spacers"] = self.stats.get("spacers", 0) + 1
+                block = self.allocate(nbytes)
+                cls = self._classify(block, nbytes)
+                self.stats["candidates"] += 1
+                if cls == wanted:
+                    chosen, chosen_cls = block, cls
+                    for _ in range(self.park_extra if i >= self.plain_candidates else 0):  # found far away: take its neighbours too
+                        extra = self.allocate(nbytes)
+                        if self._classify(extra, nbytes) == wanted:
+                            self.parked.setdefault((wanted, nbytes), []).append(extra)
+                        else:
+                            held.append((extra, 1 - wanted))
+                    break
+                held.append((block, cls))
+                held_bytes += nbytes
+                if not spacers and held_bytes + nbytes > self.max_held_bytes:
+                    break
+            if chosen is None:  # nothing of the wanted class within the budget: the first candidate, whatever it is
+                self.stats["wanted_class_not_found"] += 1
+                chosen, chosen_cls = held.pop(0)
+        n_rejected = len(held)
+        used_spacers = len(spacers)
+        del held, spacers  # rejected candidates and spacers go back to the allocator NOW, not before: it would have handed them out again
+        if self.release is not None and (used_spacers or n_rejected > 4):
+            self.release()  # (back to the DRIVER: a caching allocator would otherwise sit on tens of GB)
+        self.live[chosen_cls] += nbytes
+        self.stats["placed"][chosen_cls] += 1
+        self.log.append({"label": label, "bytes": nbytes, "class": chosen_cls, "wanted": wanted, "candidates_rejected": n_rejected})
+        weakref.finalize(chosen, self._gone, chosen_cls, nbytes)
+        return chosen, chosen_cls
+
+    def _gone(self, cls: int, nbytes: int) -> None:
+        self.live[cls] -= nbytes
+
+
+_PLACER: Optional[MemoryGroupPlacer] = None
+_DISABLED_REASON: Optional[str] = None
+
+
+def device_placer() -> Optional[MemoryGroupPlacer]:
+    """The process-wide placer of the current device's ``hip:mi300`` storages, or None when it is switched off
+    (``GT4PY_AMD_ALLOC_GROUPS=0``) or the library lacks the probe."""
+    global _PLACER, _DISABLED_REASON
+    if _PLACER is not None or _DISABLED_REASON is not None:
+        return _PLACER
+    if os.environ.get("GT4PY_AMD_ALLOC_GROUPS", "1") == "0":
+        _DISABLED_REASON = "GT4PY_AMD_ALLOC_GROUPS=0"
+        return None
+    import ctypes
+
+    import torch
+
+    from .. import _lib
+
+    lib = _lib.load()
+
+    def allocate(nbytes: int):
+        return torch.empty((int(nbytes),), dtype=torch.uint8, device="cuda")
+
+    def free_bytes() -> int:
+        return int(torch.cuda.mem_get_info()[0])
+
+    def probe(a: int, b: int, nbytes: int) -> float:
+        gbs = ctypes.c_double()
+        _lib.check("gt4mi_memory_write_probe",
+                   lib.gt4mi_memory_write_probe(a, b or None, int(nbytes), 6, torch.cuda.current_stream().cuda_stream, ctypes.byref(gbs)))
+        return float(gbs.value)
+
+    _PLACER = MemoryGroupPlacer(allocate, probe, release=torch.cuda.empty_cache, free_bytes=free_bytes)
+    return _PLACER
+
+
+def configure(*, max_candidates: Optional[int] = None, max_held_bytes: Optional[int] = None, spacer_bytes: Optional[int] = None,
+              park_extra: Optional[int] = None, keep_free_bytes: Optional[int] = None) -> Optional[MemoryGroupPlacer]:
+    """An application that knows it is about to allocate the fields of a bandwidth-bound stencil may widen the search
+    (``bench.py`` does): candidates per search, bytes of rejected candidates held at once, and the WIDE search -- spacers of
+    ``spacer_bytes`` between the candidates (the groups change along the physical address space, often only tens of GB apart),
+    ``park_extra`` neighbours of a far find kept for the next fields, ``keep_free_bytes`` of device memory never touched."""
+    placer = device_placer()
+    if placer is not None:
+        for name, value in (("max_candidates", max_candidates), ("max_held_bytes", max_held_bytes), ("spacer_bytes", spacer_bytes),
+                            ("park_extra", park_extra), ("keep_free_bytes", keep_free_bytes)):
+            if value is not None:
+                setattr(placer, name, int(value))
+    return placer
+
+
+def class_of(array) -> Optional[int]:
+    """0 / 1: the memory class the placer found for the raw block behind a storage; None: not classified (small, huge, placer off)."""
+    raw = getattr(array, "_owner", None)
+    if _PLACER is None or raw is None:
+        return None
+    return _PLACER.known.get((int(raw.data_ptr()), int(raw.numel())))
+
+
+def report() -> Optional[Dict[str, Any]]:
+    """What the placer did so far (for a benchmark line): classes of the placed fields, searches, candidates, probes."""
+    if _PLACER is None:
+        return {"enabled": False, "why": _DISABLED_REASON} if _DISABLED_REASON else None
+    p = _PLACER
+    return {"enabled": True, "fields_placed_per_class": list(p.stats["placed"]), "live_bytes_per_class": list(p.live), "searches": p.stats["searches"],
+            "candidates": p.stats["candidates"], "probes": p.stats["probes"], "wanted_class_not_found": p.stats["wanted_class_not_found"],
+            "spacers": p.stats.get("spacers", 0), "spacer_bytes": p.spacer_bytes, "parked_blocks": sum(len(v) for v in p.parked.values()),
+            "pair_threshold_gbs": p.threshold, "max_candidates": p.max_candidates, "fields": list(p.log)[-32:]}

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GT4MI_ABI_VERSION 6 /* 6: GT4MI_PLAN_DIRECT_FENCED (release / acquire fences around the flags of the direct transport); 5: GT4MI_ERR_TIMEOUT (a direct-transport wait that runs out fails the plan, hard), GT4MI_PLAN_DIRECT_TIMEOUT_MS; 4: gt4mi_dist_lap5_f32, the direct transport (gt4mi_halo_plan_direct_*, GT4MI_PLAN_TRANSPORT), gt4mi_comm_create_local, schedules 2-4 */
+#define GT4MI_ABI_VERSION 7 /* 7: gt4mi_memory_write_probe (which memory group an allocation lives in); 6: GT4MI_PLAN_DIRECT_FENCED (release / acquire fences around the flags of the direct transport); 5: GT4MI_ERR_TIMEOUT (a direct-transport wait that runs out fails the plan, hard), GT4MI_PLAN_DIRECT_TIMEOUT_MS; 4: gt4mi_dist_lap5_f32, the direct transport (gt4mi_halo_plan_direct_*, GT4MI_PLAN_TRANSPORT), gt4mi_comm_create_local, schedules 2-4 */
 
 typedef enum gt4mi_status {
     GT4MI_OK = 0,
@@ -391,6 +391,16 @@ int gt4mi_launch_batch(int n, void* const* functions, const uint32_t* grids, con
  * Streaming device copy of nbytes (multiple of 16) with 16-byte lanes: the "achievable HBM"
  * yardstick printed next to the stencil numbers. */
 int gt4mi_stream_copy(const void* src, void* dst, size_t nbytes, void* stream);
+
+/* ---- memory groups (ABI 7; new: the reference allocates through cupy and knows nothing of the device's memory system) -------------
+ * MI355X's memory is not one uniformly interleaved pool: two big allocations either share a group of memory channels or they do
+ * not, and nothing in the HIP API says which.  Kernels feel it -- two 1.3 GB fields written side by side: 5.0-6.4 TB/s in one group,
+ * 6.8-7.0 TB/s in two; the fp64 Laplacian 512^3 +2.3 % with `in` and `out` in different groups; the tridiagonal solve 0.70 of the
+ * HBM peak with its five fields dealt over two groups, 0.61 with all five in one (profiles/r5_memory_groups.txt).  This probe
+ * measures it: ONE kernel writes both buffers the way a column kernel does; *gbs = bytes written to both per second / 1e9.
+ * `b` may be NULL (one buffer alone).  OVERWRITES the first `bytes` (rounded down to planes of 8 MiB, at least 192 MiB) of both
+ * buffers; synchronous on `stream`.  gt4py_amd/storage/placement.py uses it to deal big fields over the groups. */
+int gt4mi_memory_write_probe(void* a, void* b, size_t bytes, int iterations, void* stream, double* gbs);
 
 #ifdef __cplusplus
 }

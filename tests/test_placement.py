@@ -1,0 +1,192 @@
+"""Memory-group-aware placement of big device fields (gt4py_amd/storage/placement.py): the POLICY on the CPU with models of the
+allocator and of the probe; the probe and the classes on the device (-m gpu)."""
+
+import numpy as np
+import pytest
+
+from gt4py_amd.storage.placement import MIN_BYTES, MemoryGroupPlacer
+
+GB = 1 << 30
+
+
+class _Block:
+    """What `allocate` returns in the model: an address, and (hidden from the placer) the memory group it lives in."""
+
+    def __init__(self, ptr, group):
+        self.ptr, self.group = ptr, group
+
+    def data_ptr(self):
+        return self.ptr
+
+
+class _Device:
+    """A model of the driver + caching allocator: fresh blocks come from a scripted sequence of groups; a block that is dropped
+    goes to a cache and is handed out again FIRST (LIFO) -- exactly why the placer must hold its rejected candidates."""
+
+    def __init__(self, groups):
+        self.groups, self.next_ptr, self.cache, self.live, self.probes = list(groups), 0x1000000, [], {}, 0
+
+    def allocate(self, nbytes):
+        import weakref
+
+        if self.cache:
+            ptr, group = self.cache.pop()
+        else:
+            ptr, group = self.next_ptr, self.groups.pop(0) if self.groups else 0
+            self.next_ptr += nbytes + (4 << 20)
+        block = _Block(ptr, group)
+        self.live[ptr] = group
+        weakref.finalize(block, self._freed, ptr, group)
+        return block
+
+    def _freed(self, ptr, group):
+        self.live.pop(ptr, None)
+        self.cache.append((ptr, group))
+
+    def probe(self, a, b, nbytes):
+        self.probes += 1
+        assert nbytes >= MIN_BYTES
+        return 5300.0 if self.live[a] == self.live[b] else 6900.0  # same group / different groups, GB/s
+
+
+def test_big_fields_are_dealt_over_the_two_classes():
+    # the reference lands in group 0; then: 0 0 0 1 0 0 1 1 ...
+    dev = _Device([0] + [0, 0, 0, 1, 0, 0, 1, 1, 0, 0])
+    placer = MemoryGroupPlacer(dev.allocate, dev.probe, max_candidates=8)
+    blocks = [placer.place(GB + (4 << 20), label=n) for n in ("inp0", "out0", "inp1", "out1")]
+    classes = [c for _, c in blocks]
+    assert classes == [0, 1, 0, 1]  # a stencil's input and output never share a group when a second group can be found
+    assert [dev.live[b.data_ptr()] for b, _ in blocks] == [0, 1, 0, 1]
+    # rejected candidates were HELD during the search (the cache would have handed the same block out again) and released after it;
+    # the class of a block that comes back from the cache is remembered: no second probe
+    assert placer.stats["wanted_class_not_found"] == 0 and placer.stats["searches"] == 4
+    assert placer.stats["probes"] < placer.stats["candidates"]
+    assert placer.live == [2 * (GB + (4 << 20)), 2 * (GB + (4 << 20))]
+    # a field that dies gives its bytes back: the next one goes where the room is
+    del blocks[1]
+    import gc
+
+    gc.collect()
+    assert placer.live[1] == GB + (4 << 20)
+    _, cls = placer.place(GB + (4 << 20))
+    assert cls == 1
+
+
+def test_a_search_that_finds_nothing_takes_what_the_driver_gave():
+    dev = _Device([0] * 40)  # one group only, as far as the search can see
+    placer = MemoryGroupPlacer(dev.allocate, dev.probe, max_candidates=5)
+    got = [placer.place(GB) for _ in range(3)]
+    assert [c for _, c in got] == [0, 0, 0] and placer.stats["wanted_class_not_found"] == 2  # (the 2nd and 3rd wanted class 1)
+    assert placer.stats["candidates"] <= 1 + 5 + 5 and len({b.data_ptr() for b, _ in got}) == 3
+    # bounded by bytes as well: nothing beyond max_held_bytes is ever held
+    dev = _Device([0] * 40)
+    placer = MemoryGroupPlacer(dev.allocate, dev.probe, max_candidates=30, max_held_bytes=3 * GB)
+    placer.place(GB)
+    placer.place(GB)
+    assert placer.stats["candidates"] <= 1 + 3
+
+
+def test_sizes_the_probe_cannot_classify_are_left_alone():
+    dev = _Device([0, 1, 0, 1])
+    placer = MemoryGroupPlacer(dev.allocate, dev.probe)
+    small, cls = placer.place(64 << 20)  # (the Infinity Cache would absorb the probe)
+    huge, cls2 = placer.place(8 * GB)
+    assert cls is None and cls2 is None and dev.probes == 0 and placer.reference is None and placer.stats["unclassified"] == 2
+    off = MemoryGroupPlacer(dev.allocate, dev.probe, max_candidates=0)
+    assert off.place(GB)[1] is None and dev.probes == 0
+
+
+@pytest.mark.gpu
+def test_the_probe_and_the_placer_on_the_device():
+    """The C entry measures; storages of 1 GB are classified, dealt over the classes when a second group is within reach of the
+    search, and compute the same values wherever they live."""
+    import ctypes
+
+    import torch
+
+    import gt4py_amd.storage as gt_storage
+    from gt4py_amd import _lib
+    from gt4py_amd.storage import placement
+
+    lib = _lib.load()
+    a = torch.empty(640 << 20, dtype=torch.uint8, device="cuda")
+    b = torch.empty(640 << 20, dtype=torch.uint8, device="cuda")
+    gbs = ctypes.c_double()
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check("probe", lib.gt4mi_memory_write_probe(a.data_ptr(), None, a.numel(), 4, stream, ctypes.byref(gbs)))
+    alone = gbs.value
+    _lib.check("probe", lib.gt4mi_memory_write_probe(a.data_ptr(), b.data_ptr(), a.numel(), 4, stream, ctypes.byref(gbs)))
+    pair = gbs.value
+    assert 2500.0 < alone < 8000.0 and 2500.0 < pair < 8000.0  # an HBM rate, not a cache rate
+    assert lib.gt4mi_memory_write_probe(a.data_ptr(), None, 64 << 20, 4, stream, ctypes.byref(gbs)) == _lib.ERR_INVALID_ARGUMENT  # (the cache would absorb it)
+    del a, b
+    placer = placement.configure(max_candidates=4)
+    if placer is None:
+        pytest.skip("placement switched off in this environment")
+    before = list(placer.stats["placed"])
+    shape = (514, 514, 512)  # 1.08 GB: the headline's fields
+    f = [gt_storage.zeros(shape, np.float64, backend="hip:mi300", aligned_index=(1, 1, 0)) for _ in range(2)]
+    classes = [placement.class_of(x) for x in f]
+    assert all(c in (0, 1) for c in classes) and sum(placer.stats["placed"]) == sum(before) + 2
+    rep = placement.report()
+    assert rep["enabled"] and rep["searches"] >= 2 and rep["fields"][-1]["bytes"] >= 514 * 514 * 512 * 8
+    if rep["wanted_class_not_found"] == 0:
+        assert sorted(classes) == [0, 1]  # dealt over the two classes
+    assert float(f[0].tensor.abs().max()) == 0.0 and float(f[1].tensor.abs().max()) == 0.0  # zeros() filled AFTER the probe wrote
+
+
+def test_the_wide_search_reaches_a_group_that_is_far_away_and_parks_its_neighbours():
+    """Groups change along the physical address space, often tens of GB apart: behind `plain_candidates` plain candidates every
+    further one follows a SPACER that is never touched; a find far away brings `park_extra` neighbours along, so that the next
+    fields that want the class do not search again; spacers and rejected candidates go back to the DRIVER when a search ends."""
+    class FarDevice(_Device):
+        """Group by ADDRESS: everything below 40 GB is group 0, everything above group 1 (spacers move the frontier)."""
+
+        def allocate(self, nbytes):
+            import weakref
+
+            if self.cache:
+                ptr, group = self.cache.pop()
+            else:  # the driver: first fit, lowest address first, among what is live or cached
+                taken = sorted(self.sizes.items())
+                ptr = 0
+                for start, size in taken:
+                    if ptr + nbytes <= start:
+                        break
+                    ptr = max(ptr, start + size)
+                group = 0 if ptr < 40 * GB else 1
+            self.sizes[ptr] = nbytes
+            block = _Block(ptr, group)
+            self.live[ptr] = group
+            weakref.finalize(block, self._freed, ptr, group)
+            return block
+
+        sizes = {}
+
+        def drop_cache(self):  # (torch.cuda.empty_cache: cached blocks go back to the driver)
+            for ptr, _ in self.cache:
+                self.sizes.pop(ptr, None)
+            self.cache.clear()
+
+    FarDevice.sizes = {}
+    dev = FarDevice([])
+    released = []
+    free = [200 * GB]
+    placer = MemoryGroupPlacer(dev.allocate, dev.probe, max_candidates=24, spacer_bytes=8 * GB, plain_candidates=4, park_extra=3,
+                               release=lambda: (released.append(len(dev.cache)), dev.drop_cache()), free_bytes=lambda: free[0])
+    a, ca = placer.place(GB)           # class 0 at once
+    b, cb = placer.place(GB)           # wants class 1: 4 plain candidates, then spacer + candidate until beyond 40 GB
+    assert (ca, cb) == (0, 1) and dev.live[b.data_ptr()] == 1 and b.data_ptr() >= 40 * GB
+    assert placer.stats["spacers"] >= 4 and released and placer.stats["wanted_class_not_found"] == 0
+    assert sum(len(v) for v in placer.parked.values()) == 3  # its neighbours, parked
+    searches = placer.stats["searches"]
+    c, cc = placer.place(GB)           # class 0 again (the frontier is back at the start: the spacers were released)
+    d, cd = placer.place(GB)           # class 1 from the parked blocks: no search
+    assert (cc, cd) == (0, 1) and placer.stats["searches"] == searches + 1 and sum(len(v) for v in placer.parked.values()) == 2
+    # a device that is nearly full is not filled up with spacers
+    FarDevice.sizes = {}
+    dev2, free2 = FarDevice([]), [20 * GB]
+    p2 = MemoryGroupPlacer(dev2.allocate, dev2.probe, max_candidates=24, spacer_bytes=8 * GB, free_bytes=lambda: free2[0], keep_free_bytes=16 * GB)
+    first = p2.place(GB)
+    second, cls = p2.place(GB)
+    assert first[1] == 0 and cls == 0 and p2.stats.get("spacers", 0) == 0 and p2.stats["wanted_class_not_found"] == 1

@@ -56,6 +56,7 @@ class MemoryGroupPlacer:
         self.spacer_bytes, self.plain_candidates, self.park_extra = int(spacer_bytes), int(plain_candidates), int(park_extra)
         self.keep_free_bytes = int(keep_free_bytes)
         self.parked: Dict[Tuple[int, int], list] = {}  # (class, size) -> blocks
+        self.forced: Optional[int] = None  # `want(cls)`: the class the next fields go to, whatever the balance says
         self.max_candidates = int(max_candidates if max_candidates is not None else os.environ.get("GT4PY_AMD_ALLOC_GROUP_SEARCH", "6"))
         self.threshold = float(threshold_gbs if threshold_gbs is not None else os.environ.get("GT4PY_AMD_ALLOC_GROUP_PAIR_GBS", PAIR_GBS_OTHER_GROUP))
         self.reference: Any = None          # the placer's own buffer: class 0 is ITS group
@@ -92,7 +93,7 @@ class MemoryGroupPlacer:
             self.stats["unclassified"] += 1
             return self.allocate(nbytes), None
         self._ensure_reference(nbytes)
-        wanted = 0 if self.live[0] <= self.live[1] else 1
+        wanted = self.forced if self.forced is not None else (0 if self.live[0] <= self.live[1] else 1)
         held, spacers, chosen, chosen_cls = [], [], None, None
         parked = self.parked.get((wanted, nbytes))
         if parked:
@@ -190,6 +191,29 @@ def configure(*, max_candidates: Optional[int] = None, max_held_bytes: Optional[
             if value is not None:
                 setattr(placer, name, int(value))
     return placer
+
+
+class want:
+    """``with placement.want(cls): out = gt_storage.empty(...)`` -- the big fields allocated inside go to memory class ``cls`` (0 / 1)
+    instead of wherever the balance of live bytes points.  The placer deals fields in the order they are allocated; a program that
+    knows the ROLES can do better: what a stencil writes belongs in the other class than what it reads (horizontal diffusion,
+    512 x 1024 x 80 fp64: in / coeff / out in classes 0 / 0 / 1 is 4.7 % faster than 0 / 0 / 0 and 2 % faster than 0 / 1 / 0,
+    profiles/r5_memory_groups.txt).  ``cls`` may be None (no preference); a no-op when the placer is off."""
+
+    def __init__(self, cls: Optional[int]):
+        self.cls, self.before = cls, None
+
+    def __enter__(self):
+        placer = device_placer()
+        if placer is not None:
+            self.before, placer.forced = placer.forced, self.cls
+        return self
+
+    def __exit__(self, *exc):
+        placer = device_placer()
+        if placer is not None:
+            placer.forced = self.before
+        return False
 
 
 def class_of(array) -> Optional[int]:

@@ -95,7 +95,8 @@ traffic_file["_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1
                          "at its own size (scripts/profile_all_kernels.sh); factor 2 per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 128-B "
                          "requests as 64 B; Infinity-Cache hits are counted).  bench.py reports a number only while kernel_source_sha equals "
                          "the hash of that kernel's sources in the tree (bench.KERNEL_SOURCES)")
-(out / "all_kernels_summary.json").write_text(json.dumps({"tag": tag, "git_sha": git_sha, "kernels": summary}, indent=1))
+placer = {f"group{g}": bench_numbers(out / f"g{g}_stats_stdout.log").get("_memory_groups") for g in GROUPS}
+(out / "all_kernels_summary.json").write_text(json.dumps({"tag": tag, "git_sha": git_sha, "memory_group_placer": placer, "kernels": summary}, indent=1))
 (out / "hbm_traffic.json").write_text(json.dumps(traffic_file, indent=1))
 for w, e in summary.items():
     print(f"{w:52s} {e.get('average_ns', 0) / 1e3:9.1f} us  x{e.get('traffic_over_algorithmic')}  frac {e.get('frac_of_hbm_peak')}  {e.get('error', '')}")

@@ -202,16 +202,31 @@ def _time_launches(fn, steps):
     return {"mean": mean, "median": statistics.median(per), "min": min(per), "max": max(per), "n": steps}
 
 
-def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30) -> float:
+def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30, classes=None) -> float:
     """Streaming device copy (gt4mi_stream_copy, 16-byte lanes) of 1 GiB, read + write bytes per second:
-    the achievable-HBM yardstick SURVEY.md section 8d asks to report from the same run."""
+    the achievable-HBM yardstick SURVEY.md section 8d asks to report from the same run.  `classes` = (class of the source, class
+    of the destination): both buffers placed by the storage allocator's memory-group placer (storage/placement.py) -- the copy
+    rate with source and destination in ONE group of memory channels next to the rate with them in TWO."""
     import torch
 
     from gt4py_amd import _lib
 
     lib = _lib.load()
-    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    if classes is None:
+        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        dst = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    else:
+        from gt4py_amd.storage import placement
+
+        placer = placement.device_placer()
+        if placer is None:
+            return None
+        with placement.want(classes[0]):
+            src, got_src = placer.place(nbytes)
+        with placement.want(classes[1]):
+            dst, got_dst = placer.place(nbytes)
+        if (got_src, got_dst) != tuple(classes):
+            return None  # (no second group within reach on this device)
     src.fill_(1)
 
     def call(i):
@@ -1723,6 +1738,12 @@ def main() -> None:
         if not decomposed:
             # what a plain streaming copy reaches on this device in this run (not the bar, the context)
             line["roofline"]["measured_copy_gbs"] = round(copy_ceiling_gbs(), 1)
+            if headline:  # the same copy with its two buffers in one memory group and in two (None: no second group in reach)
+                try:
+                    same, across = copy_ceiling_gbs(classes=(0, 0)), copy_ceiling_gbs(classes=(0, 1))
+                    line["roofline"]["measured_copy_gbs_by_memory_groups"] = {"one_group": same and round(same, 1), "two_groups": across and round(across, 1)}
+                except Exception as ex:
+                    print(f"copy ceiling by memory groups failed: {ex!r}", file=sys.stderr)
         if decomposed:
             line.update(decomposed_line_keys(extras.get("proof"), bool(extras.get("transport_fallback")), n_gpus, timestep))
         if headline:

@@ -72,7 +72,14 @@ class MemoryGroupPlacer:
         if key in self.known:
             return self.known[key]
         span = min(nbytes, self.reference_bytes)
-        gbs = self.probe(int(block.data_ptr()), int(self.reference.data_ptr()), span)
+        try:
+            gbs = self.probe(int(block.data_ptr()), int(self.reference.data_ptr()), span)
+        except Exception as ex:  # noqa: BLE001 - a probe that fails switches the placer off; allocation itself goes on
+            import warnings
+
+            warnings.warn(f"gt4py_amd.storage.placement: the memory-group probe failed ({ex!r}); fields are no longer placed", RuntimeWarning)
+            self.max_candidates = 0
+            return 0
         self.stats["probes"] += 1
         cls = 1 if gbs >= self.threshold else 0
         self.known[key] = cls
@@ -102,18 +109,27 @@ class MemoryGroupPlacer:
             self.stats["searches"] += 1
             held_bytes = 0
             for i in range(self.max_candidates):
-                if i >= self.plain_candidates and self.spacer_bytes > 0:
-                    if self.free_bytes is not None and self.free_bytes() < self.spacer_bytes + nbytes + self.keep_free_bytes:
-                        break
-                    spacers.append(self.allocate(self.spacer_bytes))  # never touched: it only moves the driver's frontier
-                    self.stats["spacers"] = self.stats.get("spacers", 0) + 1
-                block = self.allocate(nbytes)
+                try:
+                    if i >= self.plain_candidates and self.spacer_bytes > 0:
+                        if self.free_bytes is not None and self.free_bytes() < self.spacer_bytes + nbytes + self.keep_free_bytes:
+                            break
+                        spacers.append(self.allocate(self.spacer_bytes))  # never touched: it only moves the driver's frontier
+                        self.stats["spacers"] = self.stats.get("spacers", 0) + 1
+                    block = self.allocate(nbytes)
+                except Exception:  # noqa: BLE001 - out of memory in the middle of a SEARCH ends the search, not the program
+                    if i == 0:
+                        raise  # (the field itself does not fit: the caller's problem, as without a placer)
+                    self.stats["search_ended_by_allocation_failure"] = self.stats.get("search_ended_by_allocation_failure", 0) + 1
+                    break
                 cls = self._classify(block, nbytes)
                 self.stats["candidates"] += 1
                 if cls == wanted:
                     chosen, chosen_cls = block, cls
                     for _ in range(self.park_extra if i >= self.plain_candidates else 0):  # found far away: take its neighbours too
-                        extra = self.allocate(nbytes)
+                        try:
+                            extra = self.allocate(nbytes)
+                        except Exception:  # noqa: BLE001
+                            break
                         if self._classify(extra, nbytes) == wanted:
                             self.parked.setdefault((wanted, nbytes), []).append(extra)
                         else:

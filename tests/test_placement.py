@@ -190,3 +190,22 @@ def test_the_wide_search_reaches_a_group_that_is_far_away_and_parks_its_neighbou
     first = p2.place(GB)
     second, cls = p2.place(GB)
     assert first[1] == 0 and cls == 0 and p2.stats.get("spacers", 0) == 0 and p2.stats["wanted_class_not_found"] == 1
+
+
+def test_running_out_of_memory_in_the_middle_of_a_search_ends_the_search_not_the_program():
+    dev = _Device([0] * 40)
+    budget = {"left": 4}
+
+    def allocate(nbytes):
+        if budget["left"] <= 0:
+            raise MemoryError("out of device memory")
+        budget["left"] -= 1
+        return dev.allocate(nbytes)
+
+    placer = MemoryGroupPlacer(allocate, dev.probe, max_candidates=8)
+    first = placer.place(GB)   # reference + one candidate
+    second = placer.place(GB)  # wants class 1: two more candidates fit, then the device is full -> takes the first candidate
+    assert first[1] == 0 and second[1] == 0 and placer.stats["search_ended_by_allocation_failure"] == 1
+    budget["left"] = 0
+    with pytest.raises(MemoryError):  # a field that does not fit at all is the caller's problem, as without a placer
+        placer.place(GB)

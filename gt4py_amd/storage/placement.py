@@ -17,8 +17,8 @@ search is bounded (``max_candidates``, ``max_held_bytes``) and when it finds not
 The layout contract is untouched: which raw block a storage lives in is no part of it.
 
 The probe OVERWRITES a candidate: it only ever runs on fresh blocks (``empty`` semantics; ``zeros`` / ``ones`` / ``from_array`` fill
-afterwards) and on the placer's own reference.  Classification of a block is remembered by (address, size): a block that comes back
-from the caching allocator is not probed again.
+afterwards) and on the placer's own reference.  Every candidate is probed (~5 ms), also one whose address was seen before: the same
+virtual address may come back on other physical memory; only live blocks keep their class.
 
 ``GT4PY_AMD_ALLOC_GROUPS=0`` switches the placer off; ``GT4PY_AMD_ALLOC_GROUP_SEARCH`` = candidates per search (default 6).
 """
@@ -61,16 +61,16 @@ class MemoryGroupPlacer:
         self.threshold = float(threshold_gbs if threshold_gbs is not None else os.environ.get("GT4PY_AMD_ALLOC_GROUP_PAIR_GBS", PAIR_GBS_OTHER_GROUP))
         self.reference: Any = None          # the placer's own buffer: class 0 is ITS group
         self.reference_bytes = 0
-        self.known: Dict[Tuple[int, int], int] = {}  # (address, size) -> class of blocks probed so far
+        self.known: Dict[Tuple[int, int], int] = {}  # (address, size) -> class of the LIVE blocks the placer handed out or parked
         self.live = [0, 0]                  # bytes of live classified fields per class
         self.stats = {"placed": [0, 0], "searches": 0, "candidates": 0, "probes": 0, "wanted_class_not_found": 0, "unclassified": 0}
         self.log: List[Dict[str, Any]] = []  # one record per placed field (bench.py prints it)
 
     # ---- classification -----------------------------------------------------------------------------------------------------
     def _classify(self, block, nbytes: int) -> int:
-        key = (int(block.data_ptr()), int(nbytes))
-        if key in self.known:
-            return self.known[key]
+        # Every candidate is PROBED, also one whose address was seen before: a block that went back to the driver (the caching
+        # allocator's empty_cache, which the wide search itself calls) may come back at the same virtual address on other
+        # physical memory.  Only blocks that are alive -- handed out or parked -- keep their class (`known`).
         span = min(nbytes, self.reference_bytes)
         try:
             gbs = self.probe(int(block.data_ptr()), int(self.reference.data_ptr()), span)
@@ -81,9 +81,7 @@ class MemoryGroupPlacer:
             self.max_candidates = 0
             return 0
         self.stats["probes"] += 1
-        cls = 1 if gbs >= self.threshold else 0
-        self.known[key] = cls
-        return cls
+        return 1 if gbs >= self.threshold else 0
 
     def _ensure_reference(self, nbytes: int) -> None:
         """The first big allocation's block becomes the reference (kept for the life of the placer: <= max_bytes)."""
@@ -132,6 +130,7 @@ class MemoryGroupPlacer:
                             break
                         if self._classify(extra, nbytes) == wanted:
                             self.parked.setdefault((wanted, nbytes), []).append(extra)
+                            self.known[(int(extra.data_ptr()), nbytes)] = wanted
                         else:
                             held.append((extra, 1 - wanted))
                     break
@@ -150,11 +149,14 @@ class MemoryGroupPlacer:
         self.live[chosen_cls] += nbytes
         self.stats["placed"][chosen_cls] += 1
         self.log.append({"label": label, "bytes": nbytes, "class": chosen_cls, "wanted": wanted, "candidates_rejected": n_rejected})
-        weakref.finalize(chosen, self._gone, chosen_cls, nbytes)
+        key = (int(chosen.data_ptr()), nbytes)
+        self.known[key] = chosen_cls
+        weakref.finalize(chosen, self._gone, chosen_cls, nbytes, key)
         return chosen, chosen_cls
 
-    def _gone(self, cls: int, nbytes: int) -> None:
+    def _gone(self, cls: int, nbytes: int, key) -> None:
         self.live[cls] -= nbytes
+        self.known.pop(key, None)
 
 
 _PLACER: Optional[MemoryGroupPlacer] = None

@@ -58,9 +58,9 @@ def test_big_fields_are_dealt_over_the_two_classes():
     assert classes == [0, 1, 0, 1]  # a stencil's input and output never share a group when a second group can be found
     assert [dev.live[b.data_ptr()] for b, _ in blocks] == [0, 1, 0, 1]
     # rejected candidates were HELD during the search (the cache would have handed the same block out again) and released after it;
-    # the class of a block that comes back from the cache is remembered: no second probe
+    # every candidate is probed, also one that comes back from the cache (the same address may be other memory by then)
     assert placer.stats["wanted_class_not_found"] == 0 and placer.stats["searches"] == 4
-    assert placer.stats["probes"] < placer.stats["candidates"]
+    assert placer.stats["probes"] == placer.stats["candidates"]
     assert placer.live == [2 * (GB + (4 << 20)), 2 * (GB + (4 << 20))]
     # a field that dies gives its bytes back: the next one goes where the room is
     del blocks[1]

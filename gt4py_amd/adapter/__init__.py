@@ -18,7 +18,9 @@ What can be verified where:
   ``BuildOptions`` / ``StencilID`` / ``ModuleData`` fields, the keyword arguments of ``StencilObject._call_run``, the members a
   ``StencilObject`` subclass must define -- is checked against ``tests/golden/gt4py_api_surface.json``, which
   ``scripts/make_gt4py_api_surface.py`` writes from the reference's sources with ``ast`` (tests/test_adapter.py; the check
-  found ``builder.backend_name``, which the reference does not have: it is ``builder.backend.name``).
+  found ``builder.backend_name``, which the reference does not have: it is ``builder.backend.name``).  And they EXECUTE, against a
+  double that offers exactly the names of that surface (tests/gt4py_double.py): registration, ``generate()``, the generated
+  ``StencilObject`` subclass, and on the device a call through gt4py's ``_call_run`` protocol down to the kernel.
 """
 
 from __future__ import annotations

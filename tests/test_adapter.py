@@ -452,6 +452,65 @@ def test_the_gt4py_facing_glue_uses_only_names_the_reference_has():
     assert api["backend/module_generator.py"]["functions"]["make_args_data_from_gtir"]["positional"] == ["pipeline"]
 
 
+def _run_the_glue_on_the_double(monkeypatch):
+    """register_with_gt4py + generate() + the StencilObject subclass of _wrap_for_gt4py, against tests/gt4py_double.py."""
+    import gt4py_double
+    from gt4py_amd.cartesian import analysis
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    surface = json.loads((root / "tests" / "golden" / "gt4py_api_surface.json").read_text())["modules"]
+    mods = gt4py_double.build(surface, lambda pipeline: analysis.make_args_data(adapter.oir_to_ir(pipeline.oir)[0]))
+    gt4py_double.check_against_surface(mods, surface)
+    gt4py_double.install(monkeypatch, mods)
+    backend_cls = adapter.register_with_gt4py("hip:mi300")
+    assert mods["gt4py.cartesian.backend.base"].REGISTRY["hip:mi300"] is backend_cls and backend_cls.name == "hip:mi300"
+    assert tuple(backend_cls.storage_info["layout_map"](("I", "J", "K"))) == (2, 1, 0) and backend_cls.storage_info["alignment"] == 32
+    builder = gt4py_double.StencilBuilder(tridiagonal_definition, tridiagonal_oir(), name="tridiagonal_definition", backend_opts={"device_sync": True})
+    builder.backend = backend_cls(builder)
+    stencil_class = builder.backend.generate()
+    assert builder.backend.load() is None
+    return mods, builder, stencil_class
+
+
+def test_the_gt4py_facing_glue_executes_against_a_double_of_the_references_interface(monkeypatch):
+    """The ~40 lines that subclass gt4py's BaseBackend and StencilObject RUN here, on a double that offers exactly the names the pinned
+    API surface lists (tests/gt4py_double.py): registration, option checking, OIR -> IR -> a stencil bound to the kernel library,
+    the generated StencilObject subclass with its properties.  (Calling it needs the device: the GPU twin below.)"""
+    mods, builder, stencil_class = _run_the_glue_on_the_double(monkeypatch)
+    StencilObject = mods["gt4py.cartesian.stencil_object"].StencilObject
+    assert issubclass(stencil_class, StencilObject) and stencil_class.__name__ == builder.class_name and stencil_class.__module__ == builder.module_qualname
+    obj = stencil_class()
+    assert obj is stencil_class()  # gt4py's singleton protocol, inherited
+    assert obj.backend == "hip:mi300" and obj._gt_id_ == builder.stencil_id.version and obj.definition_func is tridiagonal_definition
+    assert set(obj.field_info) == {"inf", "diag", "sup", "rhs", "out"} and obj.parameter_info == {} and obj.domain_info.min_sequential_axis_size == 2
+    assert obj.field_info["sup"].access.name == "READ_WRITE" and obj.options["name"] == "tridiagonal_definition" and obj.constants == {}
+    assert "sup" in obj.source and "rhs" in obj.source
+    # an option the backend does not declare is reported the way gt4py's BaseBackend.check_options reports it
+    bad = __import__("gt4py_double").StencilBuilder(lap_definition, lap_oir(), name="lap", backend_opts={"no_such_option": 1})
+    bad.backend = mods["gt4py.cartesian.backend.base"].REGISTRY["hip:mi300"](bad)
+    with pytest.warns(RuntimeWarning, match="no_such_option"):
+        bad.backend.generate()
+
+
+@pytest.mark.gpu
+def test_the_glue_on_the_double_computes_on_the_device(monkeypatch):
+    """... and a call through the generated class -- gt4py's `_call_run` protocol (here the double's) -> `run` -> this repository's
+    implementation -> the C ABI -> the tridiagonal kernel -- gives the oracle's values."""
+    import gt4py_amd.storage as gt_storage
+
+    _, _, stencil_class = _run_the_glue_on_the_double(monkeypatch)
+    rng = np.random.default_rng(7)
+    shape = (33, 5, 40)
+    host = {"inf": rng.uniform(-1, 1, shape), "diag": rng.uniform(4, 5, shape), "sup": rng.uniform(-1, 1, shape),
+            "rhs": rng.uniform(-10, 10, shape), "out": np.zeros(shape)}
+    want = {k: v.copy() for k, v in host.items()}
+    gtscript.stencil(backend="numpy", definition=tridiagonal_definition)(**want)
+    arrays = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=(0, 0, 0)) for k, v in host.items()}
+    stencil_class()(arrays["inf"], arrays["diag"], arrays["sup"], rhs=arrays["rhs"], out=arrays["out"])  # positional and keyword fields
+    for k in host:
+        np.testing.assert_array_equal(gt_storage.asnumpy(arrays[k]), want[k])
+
+
 def test_registration_needs_a_real_gt4py():
     with pytest.raises(ImportError, match="needs a real gt4py install"):
         adapter.register_with_gt4py()

@@ -302,6 +302,60 @@ def test_a_sequential_column_with_every_kind_of_k_access_translates_and_runs_on_
     np.testing.assert_array_equal(out2, want)
 
 
+# ---- horizontal diffusion with the flux limiter, float64 and float32 fields (the reference's upcasting written out as Casts) ----------
+def hdiff_oir(dt):
+    """What gtir_upcaster.py:43-143 + gtir_to_oir.py make of stencil_definitions.py:316-328 (SURVEY.md N2): literals are float64 / int64;
+    a binary operation upcasts both sides to the smallest common dtype (explicit Cast nodes), a ternary its branches, an assignment its
+    right-hand side to the dtype of the target; a temporary takes the dtype of its first right-hand side.  For float32 fields: the sum of
+    the four neighbours and the differences in[1] - in stay float32, lap / res / flx / fly are float64, the result is rounded once."""
+    F = "FLOAT64"
+    wide = (lambda e: e) if dt == F else (lambda e: N("Cast", expr=e, dtype=F))
+    fin = lambda i=0, j=0: field("in_field", i, j, dtype=dt)  # noqa: E731
+    tmp = lambda name, i=0, j=0: field(name, i, j, dtype=F)  # noqa: E731
+    nb = binop("+", binop("+", binop("+", fin(1, 0), fin(-1, 0), dt), fin(0, 1), dt), fin(0, -1), dt)
+    lap = assign(tmp("lap_field"), binop("-", binop("*", lit(4.0), wide(fin())), wide(nb)))
+
+    def flux(res_name, out_name, i, j):
+        res = assign(tmp(res_name), binop("-", tmp("lap_field", i, j), tmp("lap_field")))
+        cond = binop(">", binop("*", tmp(res_name), wide(binop("-", fin(i, j), fin(), dt))), N("Cast", expr=lit(0, I64), dtype=F), dtype=BOOL)
+        return res, assign(tmp(out_name), N("TernaryOp", cond=cond, true_expr=N("Cast", expr=lit(0, I64), dtype=F), false_expr=tmp(res_name), dtype=F))
+
+    res_x, flx = flux("res", "flx_field", 1, 0)
+    res_y, fly = flux("res", "fly_field", 0, 1)  # (the same temporary `res`, assigned a second time: as written in the definition)
+    div = binop("-", binop("+", binop("-", tmp("flx_field"), tmp("flx_field", -1, 0)), tmp("fly_field")), tmp("fly_field", 0, -1))
+    rhs = binop("-", wide(fin()), binop("*", wide(field("coeff", dtype=dt)), div))
+    out = assign(field("out_field", dtype=dt), rhs if dt == F else N("Cast", expr=rhs, dtype=dt))
+    temps = [N("Temporary", name=n, dtype=F, dimensions=(True, True, True), data_dims=()) for n in ("lap_field", "res", "flx_field", "fly_field")]
+    return N("Stencil", name="hdiff", params=[fdecl("in_field", dt), fdecl("out_field", dt), fdecl("coeff", dt)], declarations=temps,
+             vertical_loops=[loop("parallel", section(*FULL, *(hexec(st) for st in (lap, res_x, flx, res_y, fly, out))))])
+
+
+@pytest.mark.parametrize("dt,np_dtype", [("FLOAT64", np.float64), ("FLOAT32", np.float32)])
+def test_horizontal_diffusion_translates_and_matches_the_frontend_bit_for_bit(dt, np_dtype):
+    """The third stencil of the hot path, through a tree that this repository's FRONTEND never saw: the translated program must give
+    exactly what the frontend's parse of the GTScript definition gives (the float32 case exercises every upcasting rule of SURVEY N2)
+    -- a check of parser, dtype resolution and extent analysis that does not share them."""
+    from gt4py_amd.cartesian.backend import hip_templates
+
+    stencil, order = adapter.oir_to_ir(hdiff_oir(dt))
+    assert order == ("in_field", "out_field", "coeff")
+    rng = np.random.default_rng(11)
+    shape, dom = (21, 18, 3), (17, 14, 3)
+    a = (5.0 + rng.uniform(-1, 1, shape)).astype(np_dtype)
+    c = rng.uniform(0, 0.05, shape).astype(np_dtype)
+    want, got = np.zeros(shape, np_dtype), np.zeros(shape, np_dtype)
+    gtscript.stencil(backend="numpy", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np_dtype})(a, want, c, origin=(2, 2, 0), domain=dom)
+    adapter.stencil_class_from_ir(stencil, order, backend="numpy")()(a, got, c, origin=(2, 2, 0), domain=dom)
+    np.testing.assert_array_equal(got, want)
+    assert np.count_nonzero(want) == np.prod(dom)  # (the limiter fires on part of the points and the interior is written everywhere)
+    # the extents the analysis derives from the translated program are the reference's: in_field read 2 deep, everything else 0
+    info = adapter.stencil_class_from_ir(stencil, order, backend="numpy")().field_info
+    assert info["in_field"].boundary[:2] == ((2, 2), (2, 2)) and info["coeff"].boundary[:2] == ((0, 0), (0, 0))
+    # ... and on hip:mi300 the translated program binds to the hand-written kernel family, like the frontend's
+    binding = hip_backend.recognise(stencil, D.BuildOptions(name="hdiff", module=__name__, backend_opts={}))
+    assert binding is not None and binding.family == "hdiff"
+
+
 # ---- the bridge is pinned to the reference's schema -------------------------------------------------------------------------
 def test_the_hand_built_trees_cannot_drift_from_the_references_oir_schema():
     """`N(...)` refuses what gtc/oir.py does not have ..."""

@@ -9,7 +9,7 @@ big allocations either share a GROUP of memory channels or they do not, nothing 
 * tridiagonal solve 1024 x 1024 x 160: 0.70 of the HBM peak with its five fields dealt over two groups, 0.61 with all five in one
   -- the "two speed modes by allocation set" that rounds 2-4 could measure and not explain.
 
-What it does: big allocations (``min_bytes`` <= size <= ``max_bytes``) are CLASSIFIED with ``gt4mi_memory_write_probe`` against ONE
+What it does: big allocations (``min_bytes`` <= size <= ``max_bytes``: 192 MiB .. 4 GiB) are CLASSIFIED with ``gt4mi_memory_write_probe`` against ONE
 reference buffer the placer owns -- class 0: the reference's group, class 1: any other group -- and DEALT: a new field goes to the
 class that holds fewer live bytes.  To get there the placer allocates candidates (held until the search ends: a block that went back
 to the caching allocator would be handed out again at once), takes the first one of the wanted class, and releases the rest; the
@@ -32,7 +32,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 MIN_BYTES = 192 << 20  # below this the Infinity Cache (256 MB) absorbs the pair probe's writes (classification is clean from 192 MiB on:
 #                        same group 5.0-5.7 TB/s, other group 6.7-6.95, profiles/r5_memory_groups.txt)
 REFERENCE_BYTES = 512 << 20  # the placer's own buffer is at least this big
-MAX_BYTES = 2 << 30    # above this a held candidate costs too much; such fields land where the driver puts them
+MAX_BYTES = 4 << 30    # above this a held candidate costs too much; such fields land where the driver puts them
 PAIR_GBS_OTHER_GROUP = 6550.0  # two buffers written side by side: >= this -> different groups (same group: 5.0-6.4, other: 6.8-7.0 TB/s)
 
 

@@ -248,6 +248,9 @@ class HipMI300Backend(base.BaseBackend):
         "device_sync": {"versioning": True, "type": bool},
         # False: skip the hand-written kernel library and always generate code (testing, comparisons)
         "use_kernel_library": {"versioning": True, "type": bool},
+        # `while` loops: "statementwise" (default: the reference's numpy backend, the oracle of this path) or "pointwise" (its
+        # compiled backends, gt:gpu among them); see frontend._Parser._pointwise_while
+        "while_loops": {"versioning": True, "type": str},
     }
     storage_info = HIP_MI300_LAYOUT
     languages = {"computation": "hip", "bindings": ["c-abi/ctypes"]}

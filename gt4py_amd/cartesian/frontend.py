@@ -125,6 +125,13 @@ class _Parser(ast.NodeVisitor):
         self._region: Optional[ir.Region] = None  # set while the body of `with horizontal(...)` is parsed
         self._loops: Tuple[Tuple[int, ir.Expr], ...] = ()  # enclosing `while` loops of the statement being parsed
         self._loop_count = 0
+        # `while` loops: "statementwise" (default) = the reference's numpy backend, which masks EVERY body statement with the
+        # re-evaluated condition (oir_to_npir.py:187-196); "pointwise" = its compiled backends' per-point loop
+        # (gtcpp_codegen.py:257, debug_codegen.py:138-144).  They differ when a statement of the body falsifies the condition
+        # before the body's last statement (tests/test_oracle_independent.py counts 13 such programs among 150 random ones).
+        self._pointwise_while = options.backend_opts.get("while_loops", "statementwise") == "pointwise"
+        if options.backend_opts.get("while_loops", "statementwise") not in ("statementwise", "pointwise"):
+            raise ValueError(f"Invalid 'while_loops' option ('{options.backend_opts['while_loops']}'): 'statementwise' or 'pointwise'")
         self._groups = 0  # top-level `if` statements seen (one horizontal execution each)
         self._masks = 0
         for pname, ann in annotations.items():
@@ -487,12 +494,12 @@ class _Parser(ast.NodeVisitor):
                 raise self._err(node, "Conditions must index the data dimensions of the fields they read")
             full = cond if mask is None else ir.BinaryOp("and", mask, cond)
             saved = self._loops
-            self._loops = saved + ((self._loop_count, full),)
+            self._loops = saved + ((self._loop_count + (ir.POINTWISE_LOOP if self._pointwise_while else 0), full),)
             self._loop_count += 1
             out = []
             try:
                 for s in node.body:
-                    out.extend(self._visit_stmt(s, full, group))
+                    out.extend(self._visit_stmt(s, mask if self._pointwise_while else full, group))
             finally:
                 self._loops = saved
             if not out:

@@ -213,7 +213,14 @@ class Assign:
     #: enclosing masks, as the reference builds it (gtc/numpy/oir_to_npir.py:176-185: cond = mask AND cond;
     #: npir_codegen.py:252-267: ``while np.any(cond): body`` with every body statement masked by cond), and so
     #: does ``mask``.  Consecutive statements sharing a loop id are that loop's body.
+    #: Loop ids >= ``POINTWISE_LOOP`` (backend option ``while_loops="pointwise"``): the loop is the compiled backends' per-point
+    #: ``while (cond) { body }`` (gtc/gtcpp/gtcpp_codegen.py:257, gtc/debug/debug_codegen.py:138-144) -- the body statements'
+    #: ``mask`` does NOT contain the condition, and an executor that works statement-wise over arrays has to apply the
+    #: condition as it stood when the iteration began.
     loops: Tuple[Tuple[int, Expr], ...] = ()
+
+
+POINTWISE_LOOP = 1 << 20
 
 
 def stmt_exprs(stmt: "Assign"):

@@ -158,6 +158,7 @@ class Interpreter:
         args = self.fdef.args
         for a in [*args.posonlyargs, *args.args, *args.kwonlyargs]:
             self.params.append((a.arg, self._annotation_axes(a.annotation), a.annotation))
+        self._typed: Dict[str, Tuple[np.dtype, Tuple[str, ...], Tuple[int, ...]]] = {}
         self.blocks = self._blocks()
         self.while_reevaluates = 0
         self.forward_section_quirk: List[str] = []
@@ -203,8 +204,17 @@ class Interpreter:
             if isinstance(node, ast.Expr) and isinstance(node.value, ast.Constant):
                 continue  # docstring
             if isinstance(node, ast.ImportFrom):
-                if node.module != "__externals__":
+                if not (node.module or "").endswith(("__externals__", "__gtscript__")):
                     raise Unsupported("import in a definition")
+                continue
+            if isinstance(node, ast.AnnAssign) and isinstance(node.target, ast.Name):
+                # a typed temporary (gtscript_frontend.py:2243-2263); with a value: one PARALLEL computation over the whole
+                # column that assigns it comes first (:809-850)
+                self._typed[node.target.id] = self._declared(node.annotation)
+                if node.value is not None:
+                    init = ast.Assign(targets=[ast.Name(id=node.target.id, ctx=ast.Store())], value=node.value)
+                    out.insert(len([b for b in out if b.loop < 0]), _Block("PARALLEL", _Bound(False, 0), _Bound(True, 0),
+                                                                           [ast.fix_missing_locations(ast.copy_location(init, node))], -1))
                 continue
             if not isinstance(node, ast.With):
                 raise Unsupported(f"top-level {type(node).__name__}")
@@ -232,6 +242,22 @@ class Interpreter:
                     iv = self._interval(inner.items[0].context_expr)
                     out.append(_Block(order, iv[0], iv[1], inner.body, loop))
             loop += 1
+        for b in out:
+            b.stmts = self._inline_compile_time_ifs(list(b.stmts))
+        return out
+
+    def _inline_compile_time_ifs(self, stmts):
+        out = []
+        for s in stmts:
+            if isinstance(s, ast.If) and isinstance(s.test, ast.Call) and getattr(s.test.func, "id", None) == "__INLINED":
+                names = {**{k: v for k, v in self.globals.items() if isinstance(v, (int, float, bool, np.generic))}, **self.externals}
+                chosen = s.body if eval(compile(ast.Expression(body=s.test.args[0]), "<inlined>", "eval"), {"__builtins__": {}}, names) else s.orelse
+                out.extend(self._inline_compile_time_ifs(chosen))
+                continue
+            for attr in ("body", "orelse"):
+                if isinstance(s, (ast.If, ast.While, ast.With)) and getattr(s, attr, None):
+                    setattr(s, attr, self._inline_compile_time_ifs(getattr(s, attr)))
+            out.append(s)
         return out
 
     def _const_int(self, node) -> int:
@@ -277,6 +303,8 @@ class Interpreter:
                 dt = self._scalar_dtype(ann, scalars[name])
                 self.scalars[name] = dt.type(scalars[name])
             else:
+                if fields.get(name) is None:
+                    continue  # an optional field that was not passed: any access is an error below
                 arr, origin = fields[name]
                 f = _Field(name, axes, True, np.dtype(arr.dtype), tuple(arr.shape[len(axes):]))
                 self.flds[name] = f
@@ -287,6 +315,7 @@ class Interpreter:
         n_stmt = sum(1 for b in self.blocks for _ in ast.walk(ast.Module(body=b.stmts, type_ignores=[])) if isinstance(_, (ast.Assign, ast.AugAssign, ast.AnnAssign)))
         self.H = min(reach * (n_stmt + 1), 40)
         self.HK = reach + 1
+        fields = {k: v for k, v in fields.items() if v is not None}
         for name, (arr, origin) in fields.items():
             if name not in self.flds:
                 continue
@@ -403,6 +432,9 @@ class Interpreter:
             return t.id, (0, 0, 0), None
         if isinstance(t, ast.Subscript) and isinstance(t.value, ast.Name):
             elts = self._subscript_elts(t)
+            elts = self._elts3(t.value.id, elts) or elts
+            if len(elts) != 3 and self._is_field(t.value.id) and len(elts) == len(self._field_data_dims(t.value.id)):
+                return t.value.id, (0, 0, 0), elts  # field[n] = ...: a data index at zero offset
             if len(elts) == 3:
                 di, dj = self._const_int(elts[0]), self._const_int(elts[1])
                 if di or dj:
@@ -437,6 +469,7 @@ class Interpreter:
             if isinstance(base, ast.Name):
                 elts = self._subscript_elts(e)
                 if base.id in env or self._is_field(base.id):
+                    elts = self._elts3(base.id, elts) or elts
                     if len(elts) != 3:
                         if self._is_field(base.id) and len(elts) == len(self._field_data_dims(base.id)):
                             out.append((base.id, shift, False, region))  # data index at zero offset
@@ -461,12 +494,34 @@ class Interpreter:
                 for ret, fenv in self._expand_call(fn, e, env, shift):
                     self._expr_accesses(ret, region, out, fenv, (0, 0))
                 return
-            for a in e.args:
+            if isinstance(e.func, ast.Attribute) and isinstance(e.func.value, ast.Name):
+                self._expr_accesses(e.func.value, region, out, env, shift)
+            for a in [*e.args, *[kw.value for kw in e.keywords]]:
                 self._expr_accesses(a, region, out, env, shift)
             return
         for child in ast.iter_child_nodes(e):
             if isinstance(child, ast.expr):
                 self._expr_accesses(child, region, out, env, shift)
+
+    def _elts3(self, name: str, elts):
+        """``surf[1, 0]`` / ``prof[1]``: a field with fewer axes takes one offset per axis it has."""
+        if len(elts) == 3:
+            return elts
+        axes = self._axes_of(name)
+        if axes is not None and len(axes) == len(elts) and len(axes) < 3:
+            by_axis = dict(zip(axes, elts))
+            zero = ast.Constant(value=0)
+            return [by_axis.get(ax, zero) for ax in "IJK"]
+        return None
+
+    def _axes_of(self, name: str):
+        if hasattr(self, "flds") and name in self.flds:
+            return self.flds[name].axes
+        for n, axes, _ in self.params:
+            if n == name:
+                return axes
+        typed = getattr(self, "_typed", {}).get(name)
+        return typed[1] if typed else None
 
     def _is_field(self, name: str) -> bool:
         return name in self.flds or name in self._temp_names()
@@ -702,8 +757,7 @@ class Interpreter:
             self._assign(stmt.target, value, box, mask, None)
             return
         if isinstance(stmt, ast.AnnAssign):
-            dt, axes = self._declared(stmt.annotation)
-            self._declare(stmt.target.id, dt, axes)
+            self._declare(stmt.target.id, *self._declared(stmt.annotation))
             if stmt.value is not None:
                 self._assign(stmt.target, stmt.value, box, mask, None)
             return
@@ -746,7 +800,7 @@ class Interpreter:
         return (*out, box[4], box[5])
 
     def _declared(self, ann):
-        """``name: Field[IJ, np.float64] = ...``"""
+        """``name: Field[IJ, np.float64]`` / ``Field[(np.float32, (2,))]`` -> (dtype, axes, data dimensions)"""
         if not (isinstance(ann, ast.Subscript) and getattr(ann.value, "id", None) == "Field"):
             raise Unsupported("annotated assignment")
         elts = self._subscript_elts(ann)
@@ -754,20 +808,26 @@ class Interpreter:
         if isinstance(elts[0], ast.Name) and elts[0].id in _AXES_NAMES:
             axes = _AXES_NAMES[elts[0].id]
             elts = elts[1:]
-        txt = ast.unparse(elts[0])
-        for key, dt in (("float32", np.float32), ("float64", np.float64), ("int32", np.int32), ("int64", np.int64), ("bool", np.bool_)):
+        spec, dims = elts[0], ()
+        if isinstance(spec, ast.Tuple):
+            spec, dims = spec.elts[0], tuple(self._const_int(x) for x in spec.elts[1].elts)
+        elif len(elts) == 2 and isinstance(elts[1], ast.Tuple):  # Field[(dtype, (2, 2))] parses like Field[dtype, (2, 2)]
+            dims = tuple(self._const_int(x) for x in elts[1].elts)
+        txt = ast.unparse(spec)
+        for key, dt in (("float32", np.float32), ("float64", np.float64), ("int32", np.int32), ("int64", np.int64), ("int8", np.int8),
+                        ("int16", np.int16), ("bool", np.bool_)):
             if key in txt:
-                return np.dtype(dt), axes
+                return np.dtype(dt), axes, dims
         if txt == "float":
-            return np.dtype(np.float64), axes
+            return np.dtype(np.float64), axes, dims
         if txt == "int":
-            return np.dtype(np.int64), axes
+            return np.dtype(np.int64), axes, dims
         raise Unsupported(f"dtype {txt}")
 
-    def _declare(self, name, dtype, axes):
+    def _declare(self, name, dtype, axes, data_dims=()):
         if name not in self.flds:
-            f = _Field(name, axes, False, dtype)
-            f.frame = self._empty(axes, dtype)
+            f = _Field(name, axes, False, dtype, tuple(data_dims))
+            f.frame = self._empty(axes, dtype, data_dims)
             self.flds[name] = f
 
     def _assign(self, target, value_ast, box, mask, value):
@@ -777,7 +837,10 @@ class Interpreter:
         if name not in self.flds:
             if name in self.scalars:
                 raise Unsupported("assignment to a scalar parameter")
-            self._declare(name, _dtype_of(value), ("I", "J", "K"))
+            if name in self._typed:
+                self._declare(name, *self._typed[name])
+            else:
+                self._declare(name, _dtype_of(value), ("I", "J", "K"))
         f = self.flds[name]
         value = _cast(value, f.dtype)
         if not isinstance(t_off[2], int):  # run-time K offset of the write: scatter along K
@@ -828,7 +891,7 @@ class Interpreter:
     # ---- expressions ---------------------------------------------------------------------------------------------------------
     def _gt_function(self, call: ast.Call):
         if isinstance(call.func, ast.Name) and call.func.id not in _NATIVE and call.func.id not in _CASTS:
-            obj = self.globals.get(call.func.id)
+            obj = self.externals.get(call.func.id, self.globals.get(call.func.id))
             target = getattr(obj, "definition", None) or getattr(obj, "_gtscript_", {}).get("definition") if obj is not None else None
             if target is None and callable(obj) and hasattr(obj, "__code__"):
                 target = obj
@@ -861,6 +924,14 @@ class Interpreter:
             if isinstance(s, ast.Assign) and len(s.targets) == 1 and isinstance(s.targets[0], ast.Name):
                 fenv = dict(fenv)
                 fenv[s.targets[0].id] = (s.value, dict(fenv), (0, 0))
+            elif (isinstance(s, ast.Assign) and len(s.targets) == 1 and isinstance(s.targets[0], ast.Tuple) and isinstance(s.value, ast.Call)
+                  and self._gt_function(s.value) is not None):
+                inner = self._expand_call(self._gt_function(s.value), s.value, fenv, (0, 0))
+                if len(inner) != len(s.targets[0].elts):
+                    raise Unsupported("tuple arity")
+                fenv = dict(fenv)
+                for t, (r_expr, r_env) in zip(s.targets[0].elts, inner):
+                    fenv[t.id] = (r_expr, r_env, (0, 0))
             elif isinstance(s, ast.Return):
                 v = s.value
                 rets = [(x, fenv) for x in v.elts] if isinstance(v, ast.Tuple) else [(v, fenv)]
@@ -955,8 +1026,6 @@ class Interpreter:
                 if len(rets) != 1:
                     raise Unsupported("tuple-valued function in an expression")
                 return self._eval(rets[0][0], box, rets[0][1], (0, 0, shift[2]))
-            if not isinstance(e.func, ast.Name):
-                raise Unsupported(f"call {ast.unparse(e.func)}")
             if isinstance(e.func, ast.Attribute) and e.func.attr == "at" and isinstance(e.func.value, ast.Name):
                 # field.at(K=expr): the level with that index, counted from the field's origin (gtc/debug/debug_codegen.py:300-312)
                 if len(e.keywords) != 1 or e.keywords[0].arg != "K" or e.args:
@@ -983,6 +1052,7 @@ class Interpreter:
         if not isinstance(base, ast.Name):
             raise Unsupported(f"subscript {ast.unparse(e)}")
         elts = self._subscript_elts(e)
+        elts = self._elts3(base.id, elts) or elts
         if base.id in self.flds and len(elts) != 3 and len(elts) == len(self.flds[base.id].data_dims) and data_index is None:
             idx = tuple(int(np.asarray(self._eval(x, box, env, shift))) for x in elts)
             return self._read(base.id, box, shift, idx)

@@ -214,7 +214,7 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
                         lo, hi = (i0, j0), (i1, j1)
                     return lo, hi
 
-                def run(items, depth, krange):
+                def run(items, depth, krange, snapshot=None):
                     n = 0
                     while n < len(items):
                         stmt, block = items[n]
@@ -227,8 +227,21 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
                                 m += 1
                             span = box(stmt, block)
                             if span is not None:
-                                while np.any(_evaluate(cond, env, span[0], span[1], krange)):
-                                    run(items[n:m], depth + 1, krange)
+                                if lid >= ir.POINTWISE_LOOP:
+                                    # the compiled backends' loop: per point, the whole body runs when the condition held at
+                                    # the start of the iteration (ir.Assign.loops)
+                                    while True:
+                                        held = np.array(np.broadcast_to(_evaluate(cond, env, span[0], span[1], krange),
+                                                                        (span[1][0] - span[0][0], span[1][1] - span[0][1], krange[1] - krange[0])))
+                                        if snapshot is not None:  # a loop inside a per-point loop: only where the outer one runs
+                                            outer, (o_lo, o_hi) = snapshot
+                                            held &= outer[span[0][0] - o_lo[0]: span[1][0] - o_lo[0], span[0][1] - o_lo[1]: span[1][1] - o_lo[1]]
+                                        if not held.any():
+                                            break
+                                        run(items[n:m], depth + 1, krange, (held, span))
+                                else:
+                                    while np.any(_evaluate(cond, env, span[0], span[1], krange)):
+                                        run(items[n:m], depth + 1, krange, snapshot)
                             n = m
                             continue
                         n += 1
@@ -243,8 +256,14 @@ def run_stencil(stencil: ir.Stencil, extents: analysis.ExtentInfo, domain, origi
                             target = env[stmt.target.name].array[scatter]
                         else:
                             target = env[stmt.target.name].window(lo, hi, stmt.target.offset, krange, stmt.target.data_index)
-                        if stmt.mask is not None:  # npir_codegen.py:205-210: np.where(mask, right, left)
-                            mask = _evaluate(stmt.mask, env, lo, hi, krange)
+                        held = None
+                        if snapshot is not None:  # inside a per-point loop: the part of the snapshot this statement's box covers
+                            arr, (s_lo, s_hi) = snapshot
+                            held = arr[lo[0] - s_lo[0]: hi[0] - s_lo[0], lo[1] - s_lo[1]: hi[1] - s_lo[1]]
+                        if stmt.mask is not None or held is not None:  # npir_codegen.py:205-210: np.where(mask, right, left)
+                            mask = _evaluate(stmt.mask, env, lo, hi, krange) if stmt.mask is not None else held
+                            if stmt.mask is not None and held is not None:
+                                mask = np.logical_and(held, mask)
                             value = np.where(mask, _evaluate(stmt.value, env, lo, hi, krange), target)
                         else:
                             value = _evaluate(stmt.value, env, lo, hi, krange)
@@ -277,7 +296,7 @@ class NumpyOracleStencilObject(StencilObject):
 
 class NumpyOracleBackend(base.BaseBackend):
     name = "numpy"
-    options = {"ignore_np_errstate": {"versioning": True, "type": bool}}
+    options = {"ignore_np_errstate": {"versioning": True, "type": bool}, "while_loops": {"versioning": True, "type": str}}
     storage_info = storage_layout.from_name("numpy")
     languages = {"computation": "python", "bindings": ["python"]}
 

@@ -65,7 +65,8 @@ _NATIVE = {  # gtc/common.py:954-990 + gtc/ufuncs.py
     "sinh": np.sinh, "cosh": np.cosh, "tanh": np.tanh, "asinh": np.arcsinh, "acosh": np.arccosh, "atanh": np.arctanh,
     "arcsinh": np.arcsinh, "arccosh": np.arccosh, "arctanh": np.arctanh, "sqrt": np.sqrt, "exp": np.exp, "log": np.log,
     "log10": np.log10, "cbrt": np.cbrt, "isfinite": np.isfinite, "isinf": np.isinf, "isnan": np.isnan, "floor": np.floor,
-    "ceil": np.ceil, "trunc": np.trunc, "erf": scipy.special.erf, "erfc": scipy.special.erfc, "gamma": scipy.special.gamma,
+    "ceil": np.ceil, "trunc": np.trunc, "round": np.round, "round_away_from_zero": lambda x: np.copysign(np.floor(np.abs(x) + 0.5), x),
+    "erf": scipy.special.erf, "erfc": scipy.special.erfc, "gamma": scipy.special.gamma,
 }
 _CASTS = {"int32": np.int32, "int64": np.int64, "float32": np.float32, "float64": np.float64}
 _FLOAT_ONLY_TYPES = ["f->f", "d->d"]  # gtc/ufuncs.py gives erf / erfc / gamma / round these loops when they are not ufuncs
@@ -151,6 +152,10 @@ class Interpreter:
         tree = ast.parse(src)
         self.fdef = next(n for n in tree.body if isinstance(n, ast.FunctionDef))
         self.globals = dict(getattr(definition, "__globals__", {}))
+        try:  # a definition nested in another function sees that function's locals
+            self.globals.update(inspect.getclosurevars(definition).nonlocals)
+        except (TypeError, ValueError):
+            pass
         self.externals = dict(externals or {})
         self.int_t = np.dtype(np.int64 if literal_int == 64 else np.int32)
         self.float_t = np.dtype(np.float64 if literal_float == 64 else np.float32)
@@ -504,7 +509,22 @@ class Interpreter:
                 self._expr_accesses(child, region, out, env, shift)
 
     def _elts3(self, name: str, elts):
-        """``surf[1, 0]`` / ``prof[1]``: a field with fewer axes takes one offset per axis it has."""
+        """``surf[1, 0]`` / ``prof[1]``: a field with fewer axes takes one offset per axis it has; ``field[K - 1]`` / ``field[I + 1, J]``:
+        offsets named by axis, zero on the axes not named."""
+        named = {}
+        for x in elts:
+            ax, rest = None, None
+            if isinstance(x, ast.Name) and x.id in ("I", "J", "K"):
+                ax, rest = x.id, ast.Constant(value=0)
+            elif isinstance(x, ast.BinOp) and isinstance(x.left, ast.Name) and x.left.id in ("I", "J", "K") and isinstance(x.op, (ast.Add, ast.Sub)):
+                ax, rest = x.left.id, (x.right if isinstance(x.op, ast.Add) else ast.UnaryOp(op=ast.USub(), operand=x.right))
+            if ax is None or ax in named or self._is_scalar_or_field(ax):
+                named = None
+                break
+            named[ax] = rest
+        if named:
+            zero = ast.Constant(value=0)
+            return [named.get(ax, zero) for ax in "IJK"]
         if len(elts) == 3:
             return elts
         axes = self._axes_of(name)
@@ -513,6 +533,9 @@ class Interpreter:
             zero = ast.Constant(value=0)
             return [by_axis.get(ax, zero) for ax in "IJK"]
         return None
+
+    def _is_scalar_or_field(self, name: str) -> bool:
+        return any(n == name for n, _, _ in self.params)
 
     def _axes_of(self, name: str):
         if hasattr(self, "flds") and name in self.flds:
@@ -814,6 +837,8 @@ class Interpreter:
         elif len(elts) == 2 and isinstance(elts[1], ast.Tuple):  # Field[(dtype, (2, 2))] parses like Field[dtype, (2, 2)]
             dims = tuple(self._const_int(x) for x in elts[1].elts)
         txt = ast.unparse(spec)
+        if isinstance(spec, ast.Name) and isinstance(self.globals.get(spec.id), type) and issubclass(self.globals[spec.id], np.generic):
+            return np.dtype(self.globals[spec.id]), axes, dims  # an alias (F8 = np.float64)
         for key, dt in (("float32", np.float32), ("float64", np.float64), ("int32", np.int32), ("int64", np.int64), ("int8", np.int8),
                         ("int16", np.int16), ("bool", np.bool_)):
             if key in txt:
@@ -1045,6 +1070,14 @@ class Interpreter:
                 raise Unsupported(f"function {e.func.id}")
             targets = _ufunc_targets(uf, [_dtype_of(a) for a in args])
             return uf(*[_cast(a, t) for a, t in zip(args, targets)])
+        if isinstance(e, ast.Attribute):  # a constant of the enclosing scope (an enum member, a namespace attribute)
+            try:
+                obj = eval(compile(ast.Expression(body=e), "<const>", "eval"), {"__builtins__": {}}, {**self.globals, **self.externals})
+            except Exception as ex:  # noqa: BLE001
+                raise Unsupported(f"attribute {ast.unparse(e)}: {ex}") from None
+            if isinstance(obj, (bool, int, float, np.generic)):
+                return self._literal(int(obj) if isinstance(obj, int) and not isinstance(obj, bool) else obj)
+            raise Unsupported(f"attribute {ast.unparse(e)}")
         raise Unsupported(f"expression {type(e).__name__}")
 
     def _eval_access(self, e: ast.Subscript, box, env, shift, data_index):

@@ -19,7 +19,9 @@ from gt4py_amd.cartesian.gtscript import (  # noqa: F401
     region, sin, sqrt, tan, isfinite, isinf, isnan,
 )
 
-BACKENDS = ["numpy", pytest.param("hip:mi300", marks=pytest.mark.gpu)]
+import interp_backend  # noqa: E402,F401 - registers the test-only backend "interp" (the independent interpreter behind the call interface)
+
+BACKENDS = ["numpy", "interp", pytest.param("hip:mi300", marks=pytest.mark.gpu)]
 F8 = np.float64
 
 

@@ -305,6 +305,17 @@ def test_generation_on_the_oracle(name):
         np.testing.assert_array_equal(masked, old, err_msg=f"{name}: {field} written outside of the domain")
 
 
+@pytest.mark.parametrize("name", sorted(REGISTRY))
+def test_the_oracle_agrees_with_the_independent_interpreter(name):
+    """The reference's definitions through `oracle/gtscript_interp.py` (GTScript source -> numpy, no product code executes the
+    statements: tests/interp_backend.py) against the product's frontend + numpy oracle, bit for bit."""
+    import interp_backend  # noqa: F401 - registers the test-only backend "interp"
+
+    want, got = _run(name, "numpy"), _run(name, "interp")
+    for field in want:
+        np.testing.assert_array_equal(got[field], want[field], err_msg=f"{name}: {field}")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(REGISTRY))
 def test_generation_on_hip_matches_the_oracle(name):

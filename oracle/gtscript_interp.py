@@ -378,10 +378,104 @@ class Interpreter:
             return 0
 
     # ---- horizontal executions and extents ------------------------------------------------------------------------------------
+    # ---- statements over whole data dimensions: unrolled into one assignment per element (frontend/defir_to_gtir.py:140-290) --------------
+    def _dims_of(self, name):
+        if name in self.flds:
+            return tuple(self.flds[name].data_dims)
+        typed = self._typed.get(name)
+        return tuple(typed[2]) if typed else ()
+
+    def _vector_elements(self, e):
+        """Nested lists of element expressions for an expression over vector / matrix fields, or the expression itself (a scalar)."""
+        def whole(node):  # a vector field named without a data index -> (name, offset elts)
+            if isinstance(node, ast.Name) and self._dims_of(node.id):
+                return node.id, [ast.Constant(value=0)] * 3
+            if isinstance(node, ast.Subscript) and isinstance(node.value, ast.Name) and self._dims_of(node.value.id):
+                elts = self._elts3(node.value.id, self._subscript_elts(node))
+                if elts is not None and len(elts) == 3:
+                    return node.value.id, elts
+            return None
+
+        w = whole(e)
+        if w is not None:
+            name, off = w
+            dims = self._dims_of(name)
+
+            def ref(*idx):
+                base = ast.Subscript(value=ast.Name(id=name, ctx=ast.Load()), slice=ast.Tuple(elts=list(off), ctx=ast.Load()), ctx=ast.Load())
+                index = ast.Tuple(elts=[ast.Constant(value=i) for i in idx], ctx=ast.Load()) if len(idx) > 1 else ast.Constant(value=idx[0])
+                return ast.Subscript(value=base, slice=index, ctx=ast.Load())
+
+            if len(dims) == 1:
+                return [ref(i) for i in range(dims[0])]
+            if len(dims) == 2:
+                return [[ref(r, c) for c in range(dims[1])] for r in range(dims[0])]
+            raise Unsupported("statements over more than two data dimensions")
+        if isinstance(e, ast.Attribute) and e.attr == "T":
+            m = self._vector_elements(e.value)
+            if isinstance(m, list) and m and isinstance(m[0], list):
+                return [list(x) for x in zip(*m)]
+        if isinstance(e, ast.BinOp):
+            lhs, rhs = self._vector_elements(e.left), self._vector_elements(e.right)
+            if isinstance(e.op, ast.MatMult):
+                out = []
+                for row in lhs:
+                    acc = ast.BinOp(left=row[0], op=ast.Mult(), right=rhs[0])
+                    for i in range(1, len(row)):
+                        acc = ast.BinOp(left=acc, op=ast.Add(), right=ast.BinOp(left=row[i], op=ast.Mult(), right=rhs[i]))
+                    out.append(acc)
+                return out
+            if isinstance(lhs, list) and isinstance(rhs, list):
+                def zipped(a, b):
+                    return [zipped(x, y) if isinstance(x, list) else ast.BinOp(left=x, op=e.op, right=y) for x, y in zip(a, b)]
+                return zipped(lhs, rhs)
+            if isinstance(lhs, list) or isinstance(rhs, list):
+                def each(a, left_is_list):
+                    return [each(x, left_is_list) if isinstance(x, list) else
+                            (ast.BinOp(left=x, op=e.op, right=rhs) if left_is_list else ast.BinOp(left=lhs, op=e.op, right=x)) for x in a]
+                return each(lhs, True) if isinstance(lhs, list) else each(rhs, False)
+        if isinstance(e, ast.UnaryOp):
+            inner = self._vector_elements(e.operand)
+            if isinstance(inner, list):
+                def neg(a):
+                    return [neg(x) if isinstance(x, list) else ast.UnaryOp(op=e.op, operand=x) for x in a]
+                return neg(inner)
+        return e
+
+    def _unroll_vector_statements(self, stmts):
+        import itertools
+
+        out = []
+        for s in stmts:
+            for attr in ("body", "orelse"):
+                if isinstance(s, (ast.If, ast.While, ast.With)) and getattr(s, attr, None):
+                    setattr(s, attr, self._unroll_vector_statements(getattr(s, attr)))
+            if isinstance(s, ast.Assign) and len(s.targets) == 1:
+                t = s.targets[0]
+                name = t.id if isinstance(t, ast.Name) else (t.value.id if isinstance(t, ast.Subscript) and isinstance(t.value, ast.Name) else None)
+                dims = self._dims_of(name) if name else ()
+                is_whole = dims and (isinstance(t, ast.Name) or len(self._elts3(name, self._subscript_elts(t)) or ()) == 3)
+                if is_whole:
+                    off = [ast.Constant(value=0)] * 3 if isinstance(t, ast.Name) else self._elts3(name, self._subscript_elts(t))
+                    value = self._vector_elements(s.value)
+                    for index in itertools.product(*(range(d) for d in dims)):
+                        v = value
+                        if isinstance(v, list):
+                            for i in index:
+                                v = v[i]
+                        base = ast.Subscript(value=ast.Name(id=name, ctx=ast.Load()), slice=ast.Tuple(elts=list(off), ctx=ast.Load()), ctx=ast.Store())
+                        idx = ast.Tuple(elts=[ast.Constant(value=i) for i in index], ctx=ast.Load()) if len(index) > 1 else ast.Constant(value=index[0])
+                        one = ast.Assign(targets=[ast.Subscript(value=base, slice=idx, ctx=ast.Store())], value=v)
+                        out.append(ast.fix_missing_locations(ast.copy_location(one, s)))
+                    continue
+            out.append(s)
+        return out
+
     def _horizontal_executions(self):
         """[(block index, statement)]: one per top-level statement of every interval block, in program order."""
         out = []
         for b, block in enumerate(self.blocks):
+            block.stmts = self._unroll_vector_statements(list(block.stmts))
             for s in block.stmts:
                 if isinstance(s, ast.Pass):
                     continue

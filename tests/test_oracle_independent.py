@@ -96,8 +96,6 @@ def test_upcasting_rule_examples():
 # ---- pinned on the reference suites' own validation functions ---------------------------------------------------------------------
 SUITE_CASES = [pytest.param(n, e, d, id="{}-{}-{}".format(n, "_".join(f"{k}={getattr(v, '__name__', v)}" for k, v in e.items()) or "noext",
                                                           "x".join(map(str, d)))) for n, e, d in rs.cases()]
-VECTOR_SUITES = {"vector_gen_assignment", "matrix_assignment", "vector_vector_op", "combined_vector_scalar_op", "vectorized_temporary",
-                 "matmul", "masked_matmul"}  # statements over whole data dimensions: not restated
 
 
 @pytest.mark.parametrize("name,ext,domain", SUITE_CASES)
@@ -105,11 +103,7 @@ def test_interpreter_reproduces_the_reference_suites_validations(name, ext, doma
     suite = rs.SUITES[name]
     arrays, origins, params, expected = rs.make_case(name, ext, domain)
     got = {k: v.copy() for k, v in arrays.items() if not (suite.optional.get(k) is not None and not ext[suite.optional[k]])}
-    try:
-        gi.run(suite.definition, {k: (got[k], origins[k]) for k in got}, params, domain, externals=ext)
-    except gi.Unsupported as ex:
-        assert name in VECTOR_SUITES, f"{name}: {ex}"
-        pytest.skip(f"not restated: {ex}")
+    gi.run(suite.definition, {k: (got[k], origins[k]) for k in got}, params, domain, externals=ext)  # (all 113 cases are restated)
     for fname, want in expected.items():
         boundary = [b for b, ax in zip(suite.fields[fname][1], "IJK") if ax in suite.axes.get(fname, "IJK")]
         np.testing.assert_array_equal(rs._inner(got[fname], boundary), want.astype(got[fname].dtype), err_msg=f"{name}: {fname}")

@@ -112,10 +112,20 @@ TUNING = {
     # `_tc` kernels: streaming (nontemporal) stores for what the kernel itself never reads back from memory -- the
     # second sweep's results, and the store-through copies of cached in/out fields at the levels that stay on chip
     "top_cache_streaming": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_STREAMING", (1,))[0],
+    # column kernels: nontemporal LOADS for what a column kernel reads exactly once (level after level, planes apart: nothing worth
+    # keeping in the L1).  0 = plain loads; 1 = every load from memory; 2 = only of fields the stage reads at no horizontal offset;
+    # 3 (default) = ... that, moreover, only ONE of the stage's sweeps reads from memory; 4 = ... and that the stage does not write.
+    # Same process, same fields, 1024 x 1024 x 160 fp64 (profiles/r5_nt_loads_column_kernels.txt): vertical advection 0.588 (0) /
+    # 0.557 (1) / 0.584 (2) / **0.631 (3)** / 0.586 (4) of the HBM peak -- `u_pos`, which both sweeps read, must stay cacheable --;
+    # generated tridiagonal solve 0.686 / 0.730 / 0.730 / **0.730** / 0.698; hand-written solve (tridiag_stack.hip.h NTL) +5-9 %.
+    "column_nt_loads": _env_tuple("GT4MI_CODEGEN_COLUMN_NT_LOADS", (3,))[0],
+    # ... and in the 16-byte-lane strip kernels of horizontal stages: the arrays the stage reads at its own point only (_read_once_fields)
+    "strip_nt_loads": _env_tuple("GT4MI_CODEGEN_STRIP_NT_LOADS", (1,))[0],
 }
 
 from .stage_planner import (Nest, Plan, Stage, Stmt, UnsupportedStencil, _field_reads, _stmt_field_reads,  # noqa: F401
                             inline_horizontal_temporaries, plan_stages)
+from .stage_planner import _target_exprs as stage_planner_target_exprs
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -385,6 +395,7 @@ class _Emitter:
         self.tc_mode: Tuple = ("mem",)
         self.tc_sweep2 = False  # emitting the backward sweep: every cached field is complete, reads come from the cache
         self.tc_written: Set[str] = set()  # forward sweep: cached fields already assigned at the level being emitted
+        self.nt_loads: Optional[Set[str]] = None  # column kernels: the fields whose loads from memory are nontemporal
 
     # -- expressions --------------------------------------------------------------------------
     def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str], store: bool = False) -> str:
@@ -435,7 +446,10 @@ class _Emitter:
                 terms.append(f"(gt_i64)({self.expr(d, k, stage_index, reg)}) * a.{c}_d{n}")
             elif d:
                 terms.append(f"{d} * a.{c}_d{n}")
-        return f"{self.base_prefix}{c}[{' + '.join(terms) if terms else '0'}]"
+        ref = f"{self.base_prefix}{c}[{' + '.join(terms) if terms else '0'}]"
+        if not store and self.nt_loads is not None and name in self.nt_loads:
+            return f"__builtin_nontemporal_load(&{ref})"
+        return ref
 
     def expr(self, e: ir.Expr, k: str, si: int, reg: Dict[str, str]) -> str:
         rec = lambda x: self.expr(x, k, si, reg)  # noqa: E731
@@ -1060,6 +1074,34 @@ class _Emitter:
         constraints = ", ".join(f'"v"(tc_{_c_ident(n)}_{slot})' for n in names)
         self.lines.append(f"            asm volatile(\"\" :: {constraints});")
 
+    def _nt_load_fields(self, stage: Stage) -> Optional[Set[str]]:
+        """Fields of a column stage whose loads from memory are nontemporal (TUNING["column_nt_loads"])."""
+        mode = int(TUNING["column_nt_loads"])
+        if mode <= 0:
+            return None
+        names, shifted, orders = set(), set(), {}
+        cached = set(self.tc[0].names) if self.tc is not None else set()
+        for nest in stage.nests:
+            for st in nest.stmts:
+                for ex in ([c for _, c in st.loops] + ([st.value] if st.mask is None else [st.mask, st.value]) + stage_planner_target_exprs(st.target)):
+                    for e in ir.walk(ex):
+                        if isinstance(e, ir.FieldAccess) and e.name not in self.plan.locals:
+                            names.add(e.name)
+                            if tuple(e.offset[:2]) != (0, 0):
+                                shifted.add(e.name)
+                            if not (e.name in cached and nest.order is ir.LoopOrder.BACKWARD):  # (served on chip in the second sweep)
+                                orders.setdefault(e.name, set()).add(nest.order)
+        ok = {n for n in names if n in self.decl_dtype and self.decl_dtype[n].kind in "fiu" and self.decl_dtype[n].itemsize >= 4}
+        if mode == 1:
+            return ok
+        ok -= shifted
+        if mode == 2:
+            return ok
+        ok = {n for n in ok if len(orders.get(n, ())) <= 1}  # 3: ... and read from memory by ONE sweep only
+        if mode == 3:
+            return ok
+        return ok - set(stage.written)  # 4: ... and never written by the stage
+
     def kernel(self, si: int, stage: Stage, kname: str) -> KernelSource:
         L = self.lines
         if stage.mapping == "ijk":
@@ -1083,7 +1125,11 @@ class _Emitter:
             if k_per_thread > 1:
                 L.append("    }")
         else:
-            self._column_body(si, stage)
+            self.nt_loads = self._nt_load_fields(stage)
+            try:
+                self._column_body(si, stage)
+            finally:
+                self.nt_loads = None
         if j_per_thread > 1:
             L.append("    }")
         L.append("}")
@@ -1114,10 +1160,11 @@ class _Emitter:
                 L.append("#if GT4MI_NO_ALIAS")  # the cached copies stand in for memory: only with disjoint arguments
                 self._kernel_header(stage, f"{kname}_tc{n_reg}", block, 1)
                 self.tc = (cache, int(n_reg), int(n_lds), threads)
+                self.nt_loads = self._nt_load_fields(stage)
                 try:
                     self._column_body(si, stage)
                 finally:
-                    self.tc, self.tc_mode, self.tc_sweep2, self.tc_written = None, ("mem",), False, set()
+                    self.tc, self.tc_mode, self.tc_sweep2, self.tc_written, self.nt_loads = None, ("mem",), False, set(), None
                 L.append("}")
                 L.append("#endif")
                 L.append("")
@@ -1379,6 +1426,23 @@ def _emit_shared_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
     return halo, tuple(globals_)
 
 
+def _read_once_fields(em: "_Emitter", stage: Stage) -> Set[str]:
+    """Strip kernels (TUNING["strip_nt_loads"]): the arrays a horizontal stage reads at its own point only -- every element exactly
+    once, by one lane (horizontal diffusion's `coeff`).  Their 16-byte loads are nontemporal: hand-written kernel, same box A-B-A x 3,
+    fp32 0.707 -> 0.728 of the HBM peak, fp64 0.707 -> 0.713; the same hint on `in`, whose halo rows other strips re-read, costs 18 %
+    (profiles/r5_nt_loads_column_kernels.txt)."""
+    if not int(TUNING["strip_nt_loads"]):
+        return set()
+    offsets: Dict[str, Set[Tuple[int, int, int]]] = {}
+    for nest in stage.nests:
+        for st in nest.stmts:
+            for e in _stmt_field_reads(st):
+                offsets.setdefault(e.name, set()).add(tuple(e.offset) if e.koffset is None else (9, 9, 9))
+    written = {st.target.name for n in stage.nests for st in n.stmts}
+    return {n for n, offs in offsets.items() if offs == {(0, 0, 0)} and n not in written and n not in em.plan.locals
+            and n in em.decl_dtype and em.decl_dtype[n].kind in "fiu" and em.decl_dtype[n].itemsize >= 4}
+
+
 def _emit_shared_nest(em: "_Emitter", si: int, stage: Stage, nest: Nest, order, defs, need, vec: int, JT: int, globals_) -> None:
     """One interval block of a `_vecs` kernel (see _emit_shared_kernel)."""
     L = em.lines
@@ -1413,7 +1477,10 @@ def _emit_shared_nest(em: "_Emitter", si: int, stage: Stage, nest: Nest, order, 
             kterm = f"(k{dk:+d})" if dk else "k"
             L.append(f"        const {ct}* const p_{var} = b_{c} + ({kterm} * a.{c}_sk + {row} * a.{c}_sj);")
             L.append(f"        gt_vec<{ct}, {vec}> {var};")
-            L.append(f"        if ({g}) {var} = *reinterpret_cast<const gt_vec<{ct}, {vec}>*>(p_{var});")
+            if name in _read_once_fields(em, stage):
+                L.append(f"        if ({g}) {var} = __builtin_nontemporal_load(reinterpret_cast<const gt_vec<{ct}, {vec}>*>(p_{var}));")
+            else:
+                L.append(f"        if ({g}) {var} = *reinterpret_cast<const gt_vec<{ct}, {vec}>*>(p_{var});")
             L.append("        else {")
             for v in range(vec):
                 L.append(f"          {var}[{v}] = {g}_{v} ? p_{var}[{v}] : ({ct})0;")
@@ -1592,7 +1659,10 @@ def _emit_vector_kernel(em: "_Emitter", si: int, stage: Stage, kname: str, vec: 
             base = em.access(ir.FieldAccess(name, (0, dj, dk)), "k", -1, {})  # b_x[...] of element 0
             addr = base[base.index("[") + 1:-1]
             L.append(f"        const {ct}* const p{rn} = b_{c} + ({addr});")
-            L.append(f"        const gt_vec<{ct}, {vec}> r{rn} = *reinterpret_cast<const gt_vec<{ct}, {vec}>*>(p{rn});")
+            if name in _read_once_fields(em, stage):
+                L.append(f"        const gt_vec<{ct}, {vec}> r{rn} = __builtin_nontemporal_load(reinterpret_cast<const gt_vec<{ct}, {vec}>*>(p{rn}));")
+            else:
+                L.append(f"        const gt_vec<{ct}, {vec}> r{rn} = *reinterpret_cast<const gt_vec<{ct}, {vec}>*>(p{rn});")
             elems = {v: f"r{rn}[{v}]" for v in range(vec)}
             for e in sorted(x for x in need if x < 0):  # from the lane below: its component vec + e
                 var = f"r{rn}_m{-e}"

@@ -630,6 +630,50 @@ static void section_hdiff3() {
     }
 }
 
+// hdiffnt: nontemporal loads in the J-march kernel (coeff is read exactly once; `in` has halo rows that other strips re-read)
+static void section_hdiffnt() {
+    {
+        const int dI = 1024, dJ = 1024, dK = 80;
+        DevField<float> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), ref(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+        fill(in, 2024, 1.0, 9.0);
+        fill(cf, 7, 0.0, 0.05);
+        {
+            dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+            hipLaunchKernelGGL((hdiff_generic_kernel<float, double, double, true, true>), grid, dim3(256), 0, 0, in.cview(), ref.view(), cf.cview(),
+                               0.0, dI, dJ, dK);
+            CK(hipDeviceSynchronize());
+        }
+        for (int rep = 0; rep < 3; ++rep) {
+#define V(O) hdiff_variant_o<float, double, 4, 6, 6, 4, O, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80")
+            V(0);
+            V(8);   // nt coeff
+            V(16);  // nt in
+            V(24);  // both
+#undef V
+        }
+    }
+    {
+        const int dI = 512, dJ = 1024, dK = 80;
+        DevField<double> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), ref(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+        fill(in, 2024, 1.0, 9.0);
+        fill(cf, 7, 0.0, 0.05);
+        {
+            dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+            hipLaunchKernelGGL((hdiff_generic_kernel<double, double, double, true, true>), grid, dim3(256), 0, 0, in.cview(), ref.view(), cf.cview(),
+                               0.0, dI, dJ, dK);
+            CK(hipDeviceSynchronize());
+        }
+        for (int rep = 0; rep < 3; ++rep) {
+#define V(O) hdiff_variant_o<double, double, 2, 8, 8, 4, O, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80")
+            V(0);
+            V(8);
+            V(16);
+            V(24);
+#undef V
+        }
+    }
+}
+
 // workgroup -> XCD mappings of the J-march kernel: runs of G workgroups (0, 2, 4, 8) and contiguous chunks per column (-1)
 static void section_hdiffxcd() {
     {
@@ -682,17 +726,18 @@ static void tridiag_variant(DevField<T>& a, DevField<T>& d, DevField<T>& s, DevF
     report("tridiag64", cfg, ms, (double)dI * dJ * dK, 56.0);
 }
 
-template <int RL, int LL, int U, bool PIPE = false, int WPB = 1, int MAP = 0>
+template <int RL, int LL, int U, bool PIPE = false, int WPB = 1, int MAP = 0, int NTL = 0>
 static void tridiag_stack_variant(DevField<double>& a, DevField<double>& d, DevField<double>& s, DevField<double>& r,
                                   DevField<double>& o, DevField<double>& s2, DevField<double>& r2, DevField<double>& o2,
                                   int dI, int dJ, int dK) {
     const unsigned ti = (unsigned)cdiv(dI, 64);
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%s RL=%d LL=%d U=%d WPB=%d MAP=%d (mem levels %d)", PIPE ? "pipe " : "stack", RL, LL, U, WPB, MAP, dK - RL - LL);
+    snprintf(cfg, sizeof cfg, "%s RL=%d LL=%d U=%d WPB=%d MAP=%d%s (mem levels %d)", PIPE ? "pipe " : "stack", RL, LL, U, WPB, MAP,
+             NTL == 1 ? " nt loads (all four)" : NTL == 2 ? " nt loads (inf, diag)" : "", dK - RL - LL);
     if (dK - RL - LL < 1) return;
     auto launch = [&]() {
         if constexpr (PIPE)
-            hipLaunchKernelGGL((tridiag_pipe_kernel<double, RL, LL, U, WPB, MAP>), dim3(ti * (unsigned)cdiv(dJ, WPB)), dim3(64, WPB), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
+            hipLaunchKernelGGL((tridiag_pipe_kernel<double, RL, LL, U, WPB, MAP, NTL>), dim3(ti * (unsigned)cdiv(dJ, WPB)), dim3(64, WPB), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
         else
             hipLaunchKernelGGL((tridiag_stack_kernel<double, RL, LL, U>), dim3(ti * dJ), dim3(64), 0, 0, a.cview(), d.cview(), s.view(), r.view(), o.view(), dI, dJ, dK, ti);
     };
@@ -1142,6 +1187,22 @@ static void section_kprobe() {
 }
 
 // pipelined vs plain on-chip-stack kernel, also on column counts / depths that exercise the head and odd-batch paths
+// trint: nontemporal LOADS in the solve (round 5; the Laplacian lost 6-9 % with them in round 1 -- its halo rows are re-read through
+// L1 --, but a column kernel reads every element exactly once).  A-B-A in one process, same fields.
+static void section_trint() {
+    const int dI = 1024, dJ = 1024, dK = 160;
+    DevField<double> a(dI, dJ, dK, 0, 0), d(dI, dJ, dK, 0, 0), s(dI, dJ, dK, 0, 0), r(dI, dJ, dK, 0, 0), o(dI, dJ, dK, 0, 0);
+    DevField<double> s2(dI, dJ, dK, 0, 0), r2(dI, dJ, dK, 0, 0), o2(dI, dJ, dK, 0, 0);
+    fill(a, 1, -1.0, 1.0);
+    fill(d, 2, 4.0, 5.0);
+    for (int rep = 0; rep < 3; ++rep) {
+        tridiag_stack_variant<104, 40, 4, true, 1, 0, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 1, 0, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        tridiag_stack_variant<104, 40, 4, true, 1, 0, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    }
+    tridiag_stack_variant<104, 40, 4, true, 1, 0, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+}
+
 static void section_tripipe() {
     for (int rep = 0; rep < 2; ++rep) {
         const int dI = 1024, dJ = 1024, dK = 160;
@@ -1513,11 +1574,13 @@ int main(int argc, char** argv) {
     if (on("hdiff")) section_hdiff();
     if (!want.empty() && on("hdiff2")) section_hdiff2();
     if (!want.empty() && on("hdiff3")) section_hdiff3();
+    if (!want.empty() && on("hdiffnt")) section_hdiffnt();
     if (!want.empty() && on("kprobe")) section_kprobe();
     if (!want.empty() && on("hdiffxcd")) section_hdiffxcd();
     if (on("tridiag")) section_tridiag();
     if (!want.empty() && on("triplace")) section_triplace(0, want);
     if (!want.empty() && on("tripipe")) section_tripipe();
+    if (!want.empty() && on("trint")) section_trint();
     if (!want.empty() && on("trimap")) section_trimap();
     if (!want.empty() && on("tripmc")) section_tripmc();
     if (!want.empty() && on("trilayout")) section_trilayout();

@@ -40,6 +40,8 @@ inline bool hdiff_jmarch_enabled() {
 //      is refilled in place -- register use no longer grows with LJ (fully unrolled, the scheduler hoists the loads of later steps:
 //      138 registers at LJ = 8, 158 at 12, 214 at 32 against 122 at 6), so strips can be long behind a short prefetch window
 constexpr int HD_OPT_PACKED = 1, HD_OPT_KEEP_WIDE = 2, HD_OPT_ROLLED = 4;
+// (round 5, after the column kernels gained 5-9 % from them) nontemporal loads of `coeff` -- read exactly once -- and of `in`
+constexpr int HD_OPT_NT_COEFF = 8, HD_OPT_NT_IN = 16;
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ, int PF, int OPT = 0>
 // `lead`: the views' origins lie that many items past a 16-byte boundary (all three alike): the lanes then start `lead`
@@ -66,10 +68,21 @@ __device__ __forceinline__ void hdiff_jmarch_strip(const View<const T>& in, cons
     T* __restrict__ op = out.p + (int64_t)k * out.sk + col;
     const T* __restrict__ cp = COEFF_FIELD ? (cf.p + (int64_t)k * cf.sk + col) : nullptr;
 
+    auto vload_nt = [](const T* p, T (&r)[VEC]) {
+        if constexpr (VEC == 1) {
+            r[0] = __builtin_nontemporal_load(p);
+        } else {
+            using V = typename VecT<T, VEC>::type;
+            const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[e] = v[e];
+        }
+    };
     auto load_in = [&](int j, T (&r)[VEC]) {
         const T* p = ip + (int64_t)j * in.sj;
         if (in_full) {
-            vload<T, VEC>(p, r);
+            if constexpr ((OPT & HD_OPT_NT_IN) != 0) vload_nt(p, r);
+            else vload<T, VEC>(p, r);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
@@ -79,7 +92,8 @@ __device__ __forceinline__ void hdiff_jmarch_strip(const View<const T>& in, cons
     auto load_cf = [&](int j, T (&r)[VEC]) {
         const T* p = cp + (int64_t)j * cf.sj;
         if (out_full) {
-            vload<T, VEC>(p, r);
+            if constexpr ((OPT & HD_OPT_NT_COEFF) != 0) vload_nt(p, r);
+            else vload<T, VEC>(p, r);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
@@ -327,6 +341,10 @@ struct HdiffTuning {
     static constexpr int LJ = sizeof(T) == 4 ? 6 : 8;
     static constexpr int PF = sizeof(T) == 4 ? 6 : 8;
     static constexpr int XCDG = 4;  // workgroups per XCD run (see lap5.hip.h Lap5Tuning::XCDG)
+    // round 5: `coeff` is read exactly once (no halo): nontemporal loads for it -- same box A-B-A x 3, fp32 1024 x 1024 x 80
+    // 0.707 -> 0.728 of the HBM peak, fp64 512 x 1024 x 80 0.707 -> 0.713; on `in`, whose halo rows neighbouring strips re-read,
+    // the same hint costs 18 % (experiments/microbench.hip `hdiffnt`, profiles/r5_nt_loads_column_kernels.txt)
+    static constexpr int OPT = HD_OPT_NT_COEFF;
 };
 
 template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, int VEC, int LJ, int PF>
@@ -338,7 +356,7 @@ inline int hdiff_launch_jmarch_strips(const View<const T>& in, const View<T>& ou
     const unsigned groups_j = (unsigned)cdiv(tiles_j, 4);
     const int64_t nblocks = (int64_t)waves_i * groups_j * d[2];
     if (nblocks > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: domain too large for one launch");
-    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF, HdiffTuning<T>::XCDG>),
+    hipLaunchKernelGGL((hdiff_jmarch_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, PF, HdiffTuning<T>::XCDG, HdiffTuning<T>::OPT>),
                        dim3((unsigned)nblocks), dim3(256), launch_dynamic_lds(), stream, in, out, cf, coeff_scalar, (int)d[0],
                        (int)d[1], waves_i, tiles_j, groups_j, lead);
     return GT4MI_OK;

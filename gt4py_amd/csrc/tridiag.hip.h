@@ -241,10 +241,17 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
         // and the deep variant spills)
         constexpr int DEEP = sizeof(T) == 8 ? TridiagTuning::STACK_REG_DEEP : TridiagTuning::STACK_REG;
         if (sizeof(T) == 8 && domain[2] > TridiagTuning::STACK_REG_DEEPER + TridiagTuning::STACK_LDS) {
-            hipLaunchKernelGGL((tridiag_pipe_kernel<T, sizeof(T) == 8 ? TridiagTuning::STACK_REG_DEEPER : TridiagTuning::STACK_REG,
-                                                    TridiagTuning::STACK_LDS, TridiagTuning::STACK_U_DEEPER>),
-                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
-                               (int)domain[1], (int)domain[2], ti);
+            // GT4MI_TRIDIAG_NT_LOADS=0: the same kernel with plain loads (A/B runs; nontemporal loads are the default, see NTL)
+            static const bool plain_loads = [] { const char* e = getenv("GT4MI_TRIDIAG_NT_LOADS"); return e && e[0] == '0'; }();
+            constexpr int RLD = sizeof(T) == 8 ? TridiagTuning::STACK_REG_DEEPER : TridiagTuning::STACK_REG;
+            if (plain_loads)
+                hipLaunchKernelGGL((tridiag_pipe_kernel<T, RLD, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U_DEEPER, 1, 0, 0>),
+                                   dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+                                   (int)domain[1], (int)domain[2], ti);
+            else
+                hipLaunchKernelGGL((tridiag_pipe_kernel<T, RLD, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U_DEEPER>),
+                                   dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+                                   (int)domain[1], (int)domain[2], ti);
         } else if (sizeof(T) == 8 && domain[2] > DEEP + TridiagTuning::STACK_LDS) {
             hipLaunchKernelGGL((tridiag_pipe_kernel<T, DEEP, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
                                dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],

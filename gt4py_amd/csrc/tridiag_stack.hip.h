@@ -200,7 +200,12 @@ struct TridiagBwdBatch {
 //   2  a contiguous eighth of the rows per XCD (rows [x dJ / 8, (x + 1) dJ / 8): every XCD inside its own pages)
 //   3  row-major inside bands of 256 rows = ONE 2 MiB page of every level: band by band, tile-column by tile-column
 // (round 4, VERDICT item 5: profiles/r4_tridiag_translation.txt has time and translation counters of all four)
-template <typename T, int RL, int LL, int U, int WPB = 1, int MAP = 0>
+// NTL (round 5): 1 = nontemporal loads of all four input streams of the forward sweep (a column kernel reads every element exactly
+// once, level after level, a plane apart: nothing is worth keeping in the L1), 2 = of the two read-only ones (inf, diag) only, 0 = plain
+// loads.  1024 x 1024 x 160 fp64, same box A-B-A x 3 (experiments/microbench.hip `trint`): 1.795 ms plain, 1.738 ms with 2, 1.650 ms
+// with 1 (+8.7 %), bit-identical (profiles/r5_nt_loads_column_kernels.txt).  The Laplacian LOST 6-9 % with nontemporal loads in
+// round 1 (its halo rows are re-read through the L1).
+template <typename T, int RL, int LL, int U, int WPB = 1, int MAP = 0, int NTL = 1>
 __global__ void __launch_bounds__(64 * WPB)
 tridiag_pipe_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<T> rhs, View<T> out, int dI, int dJ,
                     int dK, unsigned tiles_i) {
@@ -251,10 +256,20 @@ tridiag_pipe_kernel(View<const T> inf, View<const T> diag, View<T> sup, View<T> 
     auto load = [&](FB& b, int k) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            b.a[u] = p_inf[(int64_t)(k + u) * inf.sk];
-            b.d[u] = p_diag[(int64_t)(k + u) * diag.sk];
-            b.s[u] = p_sup[(int64_t)(k + u) * sup.sk];
-            b.r[u] = p_rhs[(int64_t)(k + u) * rhs.sk];
+            if constexpr (NTL >= 1) {
+                b.a[u] = __builtin_nontemporal_load(p_inf + (int64_t)(k + u) * inf.sk);
+                b.d[u] = __builtin_nontemporal_load(p_diag + (int64_t)(k + u) * diag.sk);
+            } else {
+                b.a[u] = p_inf[(int64_t)(k + u) * inf.sk];
+                b.d[u] = p_diag[(int64_t)(k + u) * diag.sk];
+            }
+            if constexpr (NTL == 1) {
+                b.s[u] = __builtin_nontemporal_load(p_sup + (int64_t)(k + u) * sup.sk);
+                b.r[u] = __builtin_nontemporal_load(p_rhs + (int64_t)(k + u) * rhs.sk);
+            } else {
+                b.s[u] = p_sup[(int64_t)(k + u) * sup.sk];
+                b.r[u] = p_rhs[(int64_t)(k + u) * rhs.sk];
+            }
         }
     };
     auto forward_mem = [&](const FB& b, int k) {

@@ -37,7 +37,7 @@ from __future__ import annotations
 import ctypes
 import hashlib
 from dataclasses import dataclass, field, replace as _replace
-from typing import Dict, List, Optional, Sequence, Set, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Set, Tuple
 
 import numpy as np
 
@@ -396,6 +396,8 @@ class _Emitter:
         self.tc_sweep2 = False  # emitting the backward sweep: every cached field is complete, reads come from the cache
         self.tc_written: Set[str] = set()  # forward sweep: cached fields already assigned at the level being emitted
         self.nt_loads: Optional[Set[str]] = None  # column kernels: the fields whose loads from memory are nontemporal
+        self.nt_loads_last: Dict[str, Any] = {}  # ... and fields whose loads are nontemporal only in the sweep of this order (their last use)
+        self.nt_nest_order = None  # the loop order of the nest being emitted
 
     # -- expressions --------------------------------------------------------------------------
     def access(self, e: ir.FieldAccess, k: str, stage_index: int, reg: Dict[str, str], store: bool = False) -> str:
@@ -447,7 +449,8 @@ class _Emitter:
             elif d:
                 terms.append(f"{d} * a.{c}_d{n}")
         ref = f"{self.base_prefix}{c}[{' + '.join(terms) if terms else '0'}]"
-        if not store and self.nt_loads is not None and name in self.nt_loads:
+        if not store and self.nt_loads is not None and (name in self.nt_loads or (name in self.nt_loads_last
+                                                                                   and self.nt_loads_last[name] is self.nt_nest_order)):
             return f"__builtin_nontemporal_load(&{ref})"
         return ref
 
@@ -830,6 +833,7 @@ class _Emitter:
                 if n_reg:  # every slot is written by the forward sweep before the backward sweep reads it
                     L.append(f"    {ct} {', '.join(f'tc_{c}_{u}' for u in range(n_reg))};")
         for ni, nest in enumerate(stage.nests):
+            self.nt_nest_order = nest.order
             if self.tc is not None and ni == self.tc[0].first_sweep_nests:
                 self._second_sweep_bases(stage)
             L.append("    {")
@@ -1097,8 +1101,13 @@ class _Emitter:
         ok -= shifted
         if mode == 2:
             return ok
+        both = {n for n in ok if len(orders.get(n, ())) > 1 and n not in stage.written}
         ok = {n for n in ok if len(orders.get(n, ())) <= 1}  # 3: ... and read from memory by ONE sweep only
         if mode == 3:
+            return ok
+        if mode == 5:  # 3 + what BOTH sweeps read (and nobody writes): cacheable in the first sweep, nontemporal in the last
+            last = [n.order for n in stage.nests][-1]
+            self.nt_loads_last = {n: last for n in both}
             return ok
         return ok - set(stage.written)  # 4: ... and never written by the stage
 
@@ -1129,7 +1138,7 @@ class _Emitter:
             try:
                 self._column_body(si, stage)
             finally:
-                self.nt_loads = None
+                self.nt_loads, self.nt_loads_last, self.nt_nest_order = None, {}, None
         if j_per_thread > 1:
             L.append("    }")
         L.append("}")
@@ -1165,6 +1174,7 @@ class _Emitter:
                     self._column_body(si, stage)
                 finally:
                     self.tc, self.tc_mode, self.tc_sweep2, self.tc_written, self.nt_loads = None, ("mem",), False, set(), None
+                    self.nt_loads_last, self.nt_nest_order = {}, None
                 L.append("}")
                 L.append("#endif")
                 L.append("")

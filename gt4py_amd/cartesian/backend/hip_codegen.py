@@ -114,11 +114,13 @@ TUNING = {
     "top_cache_streaming": _env_tuple("GT4MI_CODEGEN_TOP_CACHE_STREAMING", (1,))[0],
     # column kernels: nontemporal LOADS for what a column kernel reads exactly once (level after level, planes apart: nothing worth
     # keeping in the L1).  0 = plain loads; 1 = every load from memory; 2 = only of fields the stage reads at no horizontal offset;
-    # 3 (default) = ... that, moreover, only ONE of the stage's sweeps reads from memory; 4 = ... and that the stage does not write.
+    # 3 = ... that, moreover, only ONE of the stage's sweeps reads from memory; 4 = ... and that the stage does not write;
+    # 5 (default) = 3 + fields BOTH sweeps read and nobody writes: cacheable in the first sweep, nontemporal in the last (their last use).
     # Same process, same fields, 1024 x 1024 x 160 fp64 (profiles/r5_nt_loads_column_kernels.txt): vertical advection 0.588 (0) /
     # 0.557 (1) / 0.584 (2) / **0.631 (3)** / 0.586 (4) of the HBM peak -- `u_pos`, which both sweeps read, must stay cacheable --;
     # generated tridiagonal solve 0.686 / 0.730 / 0.730 / **0.730** / 0.698; hand-written solve (tridiag_stack.hip.h NTL) +5-9 %.
-    "column_nt_loads": _env_tuple("GT4MI_CODEGEN_COLUMN_NT_LOADS", (3,))[0],
+    # 5 against 3 on another box: vertical advection 0.6456 -> 0.6476 (0.605 plain), the solve unchanged.
+    "column_nt_loads": _env_tuple("GT4MI_CODEGEN_COLUMN_NT_LOADS", (5,))[0],
     # ... and in the 16-byte-lane strip kernels of horizontal stages: the arrays the stage reads at its own point only (_read_once_fields)
     "strip_nt_loads": _env_tuple("GT4MI_CODEGEN_STRIP_NT_LOADS", (1,))[0],
 }

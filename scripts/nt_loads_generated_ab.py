@@ -50,7 +50,7 @@ def main() -> int:
         for mode in MODES:
             hip_codegen.TUNING["column_nt_loads"] = mode
             out[mode] = gtscript.stencil(backend="hip:mi300", definition=definition, device_sync=False, rebuild=True, name=f"{definition.__name__}_nt{mode}", **kw)
-        hip_codegen.TUNING["column_nt_loads"] = 3
+        hip_codegen.TUNING["column_nt_loads"] = 5
         return out
 
     # vertical advection (reads wcon at [1, 0, 0]; u_pos by both sweeps)

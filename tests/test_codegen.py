@@ -350,3 +350,44 @@ def test_elements_disjoint_never_claims_more_than_brute_force():
     p0, p1 = (vel[..., n].__array_interface__["data"][0] for n in (0, 1))
     assert elements_disjoint(p0, (6, 5, 4), p1, (6, 5, 4), vel[..., 0].strides, 8)
     assert not elements_disjoint(p0, (6, 5, 4), p0 + vel.strides[1], (6, 5, 4), vel[..., 0].strides, 8)  # shifted by one row
+
+
+def test_column_kernels_load_read_once_streams_nontemporally():
+    """Round 5 (profiles/r5_nt_loads_column_kernels.txt): in a column kernel the fields read at no horizontal offset that only ONE
+    sweep reads from memory are loaded with `__builtin_nontemporal_load` (+7 % on the vertical advection); `wcon`, which the
+    neighbouring lane reads too, never is, and `u_pos`, which both sweeps read, only at its last use; mode 0 emits plain loads."""
+    import re
+
+    import stencil_zoo as zoo
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_codegen
+
+    defn, ext, _, opts = zoo.ZOO["vertical_advection_dycore"]
+    saved = hip_codegen.TUNING["column_nt_loads"]
+    try:
+        found = {}
+        for mode in (0, 3, 5):
+            hip_codegen.TUNING["column_nt_loads"] = mode
+            st = gtscript.stencil(backend="hip:mi300", definition=defn, externals=ext, rebuild=True, name=f"vadv_nt_mode_{mode}", **opts)
+            src = type(st)._gt_program_.source
+            found[mode] = set(re.findall(r"__builtin_nontemporal_load\(&\w*?b2?_(\w+?)\[", src))
+    finally:
+        hip_codegen.TUNING["column_nt_loads"] = saved
+    assert found[0] == set()
+    assert {"u_stage", "utens", "utens_stage"} <= found[3] and "wcon" not in found[3] and "u_pos" not in found[3]
+    assert found[5] == found[3] | {"u_pos"}
+
+
+def test_strip_kernels_load_arrays_read_at_their_own_point_only_nontemporally():
+    """... and in the 16-byte-lane kernels of horizontal stages: horizontal diffusion's `coeff` (read exactly once), never `in_field`."""
+    import stencil_zoo as zoo
+    from gt4py_amd.cartesian import gtscript
+    from gt4py_amd.cartesian.backend import hip_codegen
+
+    defn, ext, _, opts = zoo.ZOO["horizontal_diffusion"]
+    st = gtscript.stencil(backend="hip:mi300", definition=defn, rebuild=True, name="hdiff_nt_strip", **opts)
+    program = type(st)._gt_program_
+    stage = program.plan.stages[0]
+    em = hip_codegen._Emitter(program.plan)
+    assert hip_codegen._read_once_fields(em, stage) == {"coeff"}
+    assert "__builtin_nontemporal_load(reinterpret_cast<const gt_vec<double, 2>*>" in program.source

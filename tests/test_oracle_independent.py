@@ -14,6 +14,7 @@ the product and its oracle ("What's weak" 4).  Here the chain i
   checking side at all.
 """
 
+import os
 import pathlib
 
 import numpy as np
@@ -144,7 +145,7 @@ def _product_vs_interpreter(defn, externals, scalars, domain, seed, text=""):
 DOMAINS = [(9, 7, 5), (66, 5, 4), (3, 3, 2)]
 
 
-@pytest.mark.parametrize("seed", range(150))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GT4MI_FUZZ_FIRST_SEED", "0")), int(os.environ.get("GT4MI_FUZZ_FIRST_SEED", "0")) + (int(os.environ.get("GT4MI_FUZZ_SEEDS", "0")) or 150)))
 def test_product_frontend_agrees_with_the_interpreter_on_random_programs(seed, tmp_path):
     defn, scalars, text = fuzz_stencils.make_stencil(seed, tmp_path)
     _product_vs_interpreter(defn, {}, scalars, DOMAINS[seed % len(DOMAINS)], seed, text)
@@ -221,8 +222,12 @@ def _hip_vs_interpreter(defn, externals, scalars, domain, seed, text="", **opts)
         np.testing.assert_array_equal(dev[k].get(), expect[k], err_msg=f"field {k} (seed {seed}) {domain}\n{text}")
 
 
+# GT4MI_FUZZ_SEEDS=<n> GT4MI_FUZZ_FIRST_SEED=<s>: one-off campaigns on fresh programs (results under profiles/)
+_N, _FIRST = int(os.environ.get("GT4MI_FUZZ_SEEDS", "0")), int(os.environ.get("GT4MI_FUZZ_FIRST_SEED", "0"))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(100))
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + (_N or 100)))
 def test_generated_kernels_match_the_interpreter_on_random_programs(seed, tmp_path):
     defn, scalars, text = fuzz_stencils.make_stencil(seed, tmp_path)
     for domain in (DOMAINS[seed % len(DOMAINS)], (130, 9, 6)):

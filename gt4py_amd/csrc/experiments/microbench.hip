@@ -226,6 +226,41 @@ static void copy_variant(const u32x4* src, u32x4* dst, size_t nvec, unsigned blo
     report("copy", cfg, ms, (double)nvec, 32.0);
 }
 
+// copynt: is the streaming-copy ceiling itself a matter of cache hints?  16 bytes per lane, one vector per thread (the fastest form of
+// section_copy), nontemporal store in both; the load plain or nontemporal.  A-B-A on the same two 1 GiB buffers.
+template <bool NTL>
+__global__ void __launch_bounds__(256) copy_ntl_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t nvec) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    u32x4 v;
+    if constexpr (NTL) v = __builtin_nontemporal_load(&src[i]);
+    else v = src[i];
+    __builtin_nontemporal_store(v, &dst[i]);
+}
+
+static void section_copynt() {
+    const size_t nbytes = 1ull << 30, nvec = nbytes / 16;
+    char* buf[6];
+    for (int n = 0; n < 6; ++n) {
+        CK(hipMalloc(&buf[n], nbytes));
+        CK(hipMemset(buf[n], n + 1, nbytes));
+    }
+    for (int pair = 0; pair < 3; ++pair) {
+        const u32x4* s = reinterpret_cast<const u32x4*>(buf[0]);
+        u32x4* d = reinterpret_cast<u32x4*>(buf[1 + 2 * pair]);
+        for (int rep = 0; rep < 3; ++rep) {
+            char cfg[64];
+            double ms = time_ms([&](int) { hipLaunchKernelGGL((copy_ntl_kernel<false>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, s, d, nvec); }, 10);
+            snprintf(cfg, sizeof cfg, "buffers 0 -> %d plain load, nt store", 1 + 2 * pair);
+            report("copy", cfg, ms, (double)nvec, 32.0);
+            ms = time_ms([&](int) { hipLaunchKernelGGL((copy_ntl_kernel<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, s, d, nvec); }, 10);
+            snprintf(cfg, sizeof cfg, "buffers 0 -> %d nt load, nt store", 1 + 2 * pair);
+            report("copy", cfg, ms, (double)nvec, 32.0);
+        }
+    }
+    for (int n = 0; n < 6; ++n) hipFree(buf[n]);
+}
+
 static void section_copy() {
     const size_t nbytes = 1ull << 30;
     char *a, *b;
@@ -357,6 +392,21 @@ static void lap_ntl_variant(const DevField<double>& in, DevField<double>& out, i
                            in.cview(), out.view(), dI, dJ, tx, ty);
     }, 20);
     report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+}
+
+// lapnt: nontemporal loads in the Laplacian again (round 1: -4 % selective, -8 % all rows; re-measured in round 5 after the column
+// kernels gained from them).  NTL 1 = only the rows no other strip reads, 2 = every row.
+static void section_lapnt() {
+    const int dI = 512, dJ = 512, dK = 512;
+    DevField<double> in(dI, dJ, dK, 1, 1), out(dI, dJ, dK, 1, 1);
+    fill(in, 5, -1.0, 1.0);
+    for (int rep = 0; rep < 3; ++rep) {
+        lap_ntl_variant<8, 256, 4, 0>(in, out, dI, dJ, dK, "512^3");
+        lap_ntl_variant<8, 256, 4, 1>(in, out, dI, dJ, dK, "512^3");
+        lap_ntl_variant<8, 256, 4, 2>(in, out, dI, dJ, dK, "512^3");
+        lap_ntl_variant<16, 256, 4, 1>(in, out, dI, dJ, dK, "512^3");
+        lap_ntl_variant<16, 256, 4, 0>(in, out, dI, dJ, dK, "512^3");
+    }
 }
 
 template <int LJ, int BLOCK, int XCD = 0>
@@ -1527,6 +1577,8 @@ int main(int argc, char** argv) {
     bool ok = true;
     if (on("dpp")) ok &= section_dpp();
     if (on("copy")) section_copy();
+    if (!want.empty() && on("copynt")) section_copynt();
+    if (!want.empty() && on("lapnt")) section_lapnt();
     if (!want.empty() && on("mix")) section_mix();
     if (on("lap")) section_lap();
     if (!want.empty() && on("lap512")) lap_suite(512, 512, 512, getenv("MB_LAP_EXTRA_PITCH") ? atoi(getenv("MB_LAP_EXTRA_PITCH")) : 0, "512^3");  // (-16: the 128-byte rows of round 4, pitch 528)

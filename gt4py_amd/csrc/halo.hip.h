@@ -63,7 +63,12 @@ stream_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_
         u32x4 v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
-            if (base + (size_t)u * 256 < nvec) v[u] = src[base + (size_t)u * 256];
+            if (base + (size_t)u * 256 < nvec) {
+                // (round 5) a copy reads every byte once: nontemporal loads too -- 6.29 -> 6.51 TB/s on one box, 6.67 with source and
+                // destination in different memory groups (profiles/r5_nt_loads_column_kernels.txt, microbench `copynt`)
+                if constexpr (NT) v[u] = __builtin_nontemporal_load(&src[base + (size_t)u * 256]);
+                else v[u] = src[base + (size_t)u * 256];
+            }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
             if (base + (size_t)u * 256 < nvec) {

@@ -720,6 +720,13 @@ static void section_hdiffnt() {
             V(16);
             V(24);
 #undef V
+            // shorter strips with the nontemporal coeff loads (the GENERATED kernel, 4 rows per lane, is 2-4 % ahead of 8 / 8 in bench.py)
+            hdiff_variant_o<double, double, 2, 4, 4, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_o<double, double, 2, 6, 6, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_o<double, double, 2, 6, 4, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_o<double, double, 2, 8, 6, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_o<double, double, 2, 10, 8, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_o<double, double, 2, 12, 8, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
         }
     }
 }

@@ -338,8 +338,10 @@ hdiff_jmarch_kernel(View<const T> in, View<T> out, View<const T> cf, PW coeff_sc
 //   selects the other one.
 template <typename T>
 struct HdiffTuning {
-    static constexpr int LJ = sizeof(T) == 4 ? 6 : 8;
-    static constexpr int PF = sizeof(T) == 4 ? 6 : 8;
+    // rows per strip / rows in flight.  fp32: 6 / 6.  fp64: 8 / 8 until round 5; with the nontemporal coeff loads 6 / 6 is 1.4 % ahead
+    // (0.1735 vs 0.1759 ms on 512 x 1024 x 80, A-B x 3, microbench `hdiffnt`; 4 / 4 0.1752, 10 / 8 0.1787, 12 / 8 0.1848)
+    static constexpr int LJ = 6;
+    static constexpr int PF = 6;
     static constexpr int XCDG = 4;  // workgroups per XCD run (see lap5.hip.h Lap5Tuning::XCDG)
     // round 5: `coeff` is read exactly once (no halo): nontemporal loads for it -- same box A-B-A x 3, fp32 1024 x 1024 x 80
     // 0.707 -> 0.728 of the HBM peak, fp64 512 x 1024 x 80 0.707 -> 0.713; on `in`, whose halo rows neighbouring strips re-read,
@@ -366,6 +368,11 @@ template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, i
 inline int hdiff_launch_jmarch_vec(const View<const T>& in, const View<T>& out,
                                    const View<const T>& cf, PW coeff_scalar, const int64_t d[3],
                                    hipStream_t stream, int lead = 0) {
+    if constexpr (sizeof(T) == 8 && VEC == 2) {
+        // GT4MI_HDIFF_F64_ROWS=8: the float64 strips of rounds 2-4 (8 rows, 8 in flight), for A/B runs on ONE box
+        static const int rows64 = env_int("GT4MI_HDIFF_F64_ROWS", HdiffTuning<T>::LJ);
+        if (rows64 == 8) return hdiff_launch_jmarch_strips<T, W, PW, LIMITER, COEFF_FIELD, VEC, 8, 8>(in, out, cf, coeff_scalar, d, stream, lead);
+    }
     if constexpr (sizeof(T) == 4 && VEC == 4) {
         // GT4MI_HDIFF_F32_ROWS=8: float32 strips of 8 rows with 4 in flight instead of 6 / 6 -- for A/B runs on ONE box (the two
         // differ by less than boxes do: profiles/r5_hdiff_f32_strip_ab.log)

@@ -700,6 +700,11 @@ static void section_hdiffnt() {
             V(16);  // nt in
             V(24);  // both
 #undef V
+            hdiff_variant_o<float, double, 4, 4, 4, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_o<float, double, 4, 5, 5, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_o<float, double, 4, 6, 4, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_o<float, double, 4, 8, 6, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_o<float, double, 4, 8, 8, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
         }
     }
     {
@@ -1256,6 +1261,18 @@ static void section_trint() {
         tridiag_stack_variant<104, 40, 4, true, 1, 0, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<104, 40, 4, true, 1, 0, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
         tridiag_stack_variant<104, 40, 4, true, 1, 0, 2>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        if (getenv("MB_TRINT_SHAPES")) {  // do the batch / depth optima move with nontemporal loads?
+            tridiag_stack_variant<96, 40, 4, true, 1, 0, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 2, true, 1, 0, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 4, true, 2, 0, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 4, true, 1, 1, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 4, true, 2, 1, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 4, true, 4, 0, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 4, true, 4, 1, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 4, true, 2, 2, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 4, true, 2, 3, 1>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+            tridiag_stack_variant<104, 40, 4, true, 2, 0, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+        }
     }
     tridiag_stack_variant<104, 40, 4, true, 1, 0, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
 }

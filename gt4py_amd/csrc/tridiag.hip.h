@@ -190,6 +190,10 @@ struct TridiagTuning {
     // Needs the larger -pragma-unroll-threshold of the Makefile: with LLVM's default the 36-batch level loop stays
     // rolled and the register arrays become scratch (tests/test_c_abi.py reads the compiler's resource remarks).
     static constexpr int STACK_REG_DEEPER = 104, STACK_U_DEEPER = 4;
+    // round 5, with the nontemporal loads: TWO waves (two J rows) per workgroup -- 1.582-1.592 ms against 1.624-1.634 on one box, 1.713-1.721
+    // against 1.748-1.755 on another (+2-2.6 %, A-B x 3 each; four waves +1 %; without the nontemporal loads the same change is +0.6 %;
+    // profiles/r5_nt_loads_column_kernels.txt).  80 KB of LDS per workgroup, still one wave per SIMD.
+    static constexpr int STACK_WPB_DEEPER = 2;
     static constexpr int STACK_REG_SHALLOW = 16;  // + 40 LDS levels, for columns of 57 ... 72 levels
 };
 
@@ -241,16 +245,27 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
         // and the deep variant spills)
         constexpr int DEEP = sizeof(T) == 8 ? TridiagTuning::STACK_REG_DEEP : TridiagTuning::STACK_REG;
         if (sizeof(T) == 8 && domain[2] > TridiagTuning::STACK_REG_DEEPER + TridiagTuning::STACK_LDS) {
-            // GT4MI_TRIDIAG_NT_LOADS=0: the same kernel with plain loads (A/B runs; nontemporal loads are the default, see NTL)
-            static const bool plain_loads = [] { const char* e = getenv("GT4MI_TRIDIAG_NT_LOADS"); return e && e[0] == '0'; }();
+            // GT4MI_TRIDIAG_NT_LOADS=0: the same kernel with plain loads; GT4MI_TRIDIAG_WPB=1: one wave per workgroup as in rounds 2-4
+            // (A/B runs; nontemporal loads and two waves per workgroup are the defaults, see NTL and STACK_WPB_DEEPER)
+            // (read once; with GT4MI_TRIDIAG_AB=1 at every call, so that ONE process can alternate the variants on the same fields)
+            auto env_is = [](const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; };
+            static const bool every_call = getenv("GT4MI_TRIDIAG_AB") != nullptr;
+            static const bool plain_loads_once = env_is("GT4MI_TRIDIAG_NT_LOADS", '0'), one_wave_once = env_is("GT4MI_TRIDIAG_WPB", '1');
+            const bool plain_loads = every_call ? env_is("GT4MI_TRIDIAG_NT_LOADS", '0') : plain_loads_once;
+            const bool one_wave = every_call ? env_is("GT4MI_TRIDIAG_WPB", '1') : one_wave_once;
             constexpr int RLD = sizeof(T) == 8 ? TridiagTuning::STACK_REG_DEEPER : TridiagTuning::STACK_REG;
+            constexpr int WPB = TridiagTuning::STACK_WPB_DEEPER;
             if (plain_loads)
                 hipLaunchKernelGGL((tridiag_pipe_kernel<T, RLD, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U_DEEPER, 1, 0, 0>),
                                    dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                    (int)domain[1], (int)domain[2], ti);
-            else
-                hipLaunchKernelGGL((tridiag_pipe_kernel<T, RLD, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U_DEEPER>),
+            else if (one_wave)
+                hipLaunchKernelGGL((tridiag_pipe_kernel<T, RLD, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U_DEEPER, 1>),
                                    dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+                                   (int)domain[1], (int)domain[2], ti);
+            else
+                hipLaunchKernelGGL((tridiag_pipe_kernel<T, RLD, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U_DEEPER, WPB>),
+                                   dim3(ti * (unsigned)cdiv(domain[1], WPB)), dim3(64, WPB), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                    (int)domain[1], (int)domain[2], ti);
         } else if (sizeof(T) == 8 && domain[2] > DEEP + TridiagTuning::STACK_LDS) {
             hipLaunchKernelGGL((tridiag_pipe_kernel<T, DEEP, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),

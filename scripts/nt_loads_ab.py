@@ -61,9 +61,9 @@ def child() -> int:
 def main() -> int:
     if "--child" in sys.argv:
         return child()
-    cases = [("plain loads", {"GT4MI_TRIDIAG_NT_LOADS": "0", "GT4MI_CODEGEN_COLUMN_NT_LOADS": "0"}),
-             ("nontemporal loads", {"GT4MI_TRIDIAG_NT_LOADS": "1", "GT4MI_CODEGEN_COLUMN_NT_LOADS": "1"}),
-             ("nontemporal, generated kernels: zero-offset fields only", {"GT4MI_TRIDIAG_NT_LOADS": "1", "GT4MI_CODEGEN_COLUMN_NT_LOADS": "2"})]
+    cases = [("plain loads (one wave per workgroup)", {"GT4MI_TRIDIAG_NT_LOADS": "0", "GT4MI_CODEGEN_COLUMN_NT_LOADS": "0"}),
+             ("nontemporal loads, one wave per workgroup; generated: mode 3", {"GT4MI_TRIDIAG_WPB": "1", "GT4MI_CODEGEN_COLUMN_NT_LOADS": "3"}),
+             ("nontemporal loads, two waves per workgroup; generated: mode 5 (defaults)", {})]
     for rep in range(2):
         for what, env in cases:
             p = subprocess.run([sys.executable, __file__, "--child"], env={**os.environ, **env}, capture_output=True, text=True, timeout=900)

@@ -103,5 +103,6 @@ def test_no_hot_kernel_of_the_library_spills():
     assert not spilling, spilling
     # the deep tridiagonal variants are built for one wave per SIMD (all 512 registers of a lane)
     deep = [v for n, v in hot.items() if "tridiag_pipe_kernelIdLi104ELi40ELi4E" in n or "tridiag_pipe_kernelIdLi80ELi40ELi8E" in n]
-    # (three: 104 + 40 with nontemporal loads -- the default -- and with plain loads for A/B runs, GT4MI_TRIDIAG_NT_LOADS=0; 80 + 40)
-    assert len(deep) == 3 and all(w == 1 for _, w in deep)
+    # (four: 104 + 40 with two waves per workgroup and nontemporal loads -- the default --, with one wave (GT4MI_TRIDIAG_WPB=1), with one
+    # wave and plain loads (GT4MI_TRIDIAG_NT_LOADS=0) for A/B runs; 80 + 40)
+    assert len(deep) == 4 and all(w == 1 for _, w in deep)

@@ -293,17 +293,18 @@ static void section_copy() {
 // Streaming ceilings per read : write mix.  A copy moves 1 : 1; horizontal diffusion with a coefficient field moves 2 : 1,
 // the tridiagonal solve 4 : 3, a Laplacian 1 : 1.  What fraction of the nominal 8 TB/s a kernel of a given mix can reach is
 // the yardstick its roofline fraction has to be read against (profiles/r3_microbench_rw_mix.log).
-template <int NR, int NW>
+template <int NR, int NW, bool NTL = false>
 __global__ void __launch_bounds__(256)
 mix_kernel(const u32x4* __restrict__ r0, const u32x4* __restrict__ r1, const u32x4* __restrict__ r2, const u32x4* __restrict__ r3,
            u32x4* __restrict__ w0, u32x4* __restrict__ w1, u32x4* __restrict__ w2, size_t nvec) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nvec) return;
     u32x4 v = {1u, 2u, 3u, 4u};
-    if constexpr (NR > 0) v ^= r0[i];
-    if constexpr (NR > 1) v ^= r1[i];
-    if constexpr (NR > 2) v ^= r2[i];
-    if constexpr (NR > 3) v ^= r3[i];
+    auto ld = [](const u32x4* p) { if constexpr (NTL) return __builtin_nontemporal_load(p); else return *p; };
+    if constexpr (NR > 0) v ^= ld(&r0[i]);
+    if constexpr (NR > 1) v ^= ld(&r1[i]);
+    if constexpr (NR > 2) v ^= ld(&r2[i]);
+    if constexpr (NR > 3) v ^= ld(&r3[i]);
     if constexpr (NW > 0) __builtin_nontemporal_store(v, &w0[i]);
     if constexpr (NW > 1) __builtin_nontemporal_store(v, &w1[i]);
     if constexpr (NW > 2) __builtin_nontemporal_store(v, &w2[i]);
@@ -311,17 +312,17 @@ mix_kernel(const u32x4* __restrict__ r0, const u32x4* __restrict__ r1, const u32
         if (v.x == 0x12345678u && v.y == 0x9abcdef0u) w0[i] = v;  // never true: keeps the loads alive
 }
 
-template <int NR, int NW>
+template <int NR, int NW, bool NTL = false>
 static void mix_variant(char* const* buf, size_t nbytes) {
     const size_t nvec = nbytes / 16;
     auto R = [&](int n) { return reinterpret_cast<const u32x4*>(buf[n]); };
     auto Wr = [&](int n) { return reinterpret_cast<u32x4*>(buf[4 + n]); };
     const double ms = time_ms([&](int) {
-        hipLaunchKernelGGL((mix_kernel<NR, NW>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, R(0), R(1), R(2), R(3), Wr(0), Wr(1),
+        hipLaunchKernelGGL((mix_kernel<NR, NW, NTL>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, R(0), R(1), R(2), R(3), Wr(0), Wr(1),
                            Wr(2), nvec);
     }, 10);
     char cfg[64];
-    snprintf(cfg, sizeof cfg, "%d arrays read : %d written, 512 MiB each", NR, NW);
+    snprintf(cfg, sizeof cfg, "%d arrays read : %d written, 512 MiB each%s", NR, NW, NTL ? ", nt loads" : "");
     report("rw_mix", cfg, ms, (double)nvec, 16.0 * (NR + NW));
 }
 
@@ -342,8 +343,16 @@ static void section_mix() {
         mix_variant<4, 1>(buf, nbytes);
         mix_variant<4, 3>(buf, nbytes);
         mix_variant<1, 2>(buf, nbytes);
+        // (round 5) the same mixes with nontemporal LOADS: the ceilings a kernel of read-once streams is measured against
+        mix_variant<1, 0, true>(buf, nbytes);
+        mix_variant<1, 1, true>(buf, nbytes);
+        mix_variant<2, 1, true>(buf, nbytes);
+        mix_variant<3, 1, true>(buf, nbytes);
+        mix_variant<4, 1, true>(buf, nbytes);
+        mix_variant<4, 3, true>(buf, nbytes);
     }
     for (int n = 0; n < 7; ++n) hipFree(buf[n]);
+    if (getenv("MB_MIX_ONLY")) return;
     // the same 2 : 1 and 4 : 3 mixes with the arrays placed at different relative offsets inside ONE allocation: does the
     // ceiling depend on where the streams sit relative to each other (as the tridiagonal solve's five fields do)?
     {

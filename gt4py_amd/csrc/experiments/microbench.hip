@@ -415,6 +415,15 @@ static void section_lapnt() {
         lap_ntl_variant<8, 256, 4, 2>(in, out, dI, dJ, dK, "512^3");
         lap_ntl_variant<16, 256, 4, 1>(in, out, dI, dJ, dK, "512^3");
         lap_ntl_variant<16, 256, 4, 0>(in, out, dI, dJ, dK, "512^3");
+        if (getenv("MB_LAP_XCD")) {  // longer XCD runs: fewer strip boundaries between XCDs (the 4 % of halo re-fetch)
+            lap_ntl_variant<8, 256, 8, 0>(in, out, dI, dJ, dK, "512^3");
+            lap_ntl_variant<8, 256, 16, 0>(in, out, dI, dJ, dK, "512^3");
+            lap_ntl_variant<8, 256, 32, 0>(in, out, dI, dJ, dK, "512^3");
+            lap_ntl_variant<8, 256, 64, 0>(in, out, dI, dJ, dK, "512^3");
+            lap_ntl_variant<8, 256, 2, 0>(in, out, dI, dJ, dK, "512^3");
+            lap_ntl_variant<10, 256, 4, 0>(in, out, dI, dJ, dK, "512^3");
+            lap_ntl_variant<12, 256, 4, 0>(in, out, dI, dJ, dK, "512^3");
+        }
     }
 }
 

@@ -1367,16 +1367,16 @@ static void vadv_plain(VadvSet& s, DevField<double>& out) {
                        VADV_DTR, 0.5, 0.5, s.dI, s.dJ, s.dK);
 }
 
-template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true>
+template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true, int SLOTS = 0>
 static void vadv_variant(VadvSet& s, bool time_it = true) {
     const unsigned tiles_i = (unsigned)cdiv(s.dI, 64);
     auto launch = [&](DevField<double>& out) {
-        hipLaunchKernelGGL((vadv_pipe_kernel<RL, LL, U, PIPE, SADDR>), dim3(tiles_i * (unsigned)s.dJ), dim3(64), 0, 0, s.fields(out), VADV_DTR, 0.5,
+        hipLaunchKernelGGL((vadv_pipe_kernel<RL, LL, U, PIPE, SADDR, SLOTS>), dim3(tiles_i * (unsigned)s.dJ), dim3(64), 0, 0, s.fields(out), VADV_DTR, 0.5,
                            0.5, s.dI, s.dJ, s.dK, tiles_i);
     };
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%dx%dx%d regs %d lds %d batch %d%s%s", s.dI, s.dJ, s.dK, RL, LL, U, PIPE ? "" : " nopipe",
-             SADDR ? "" : " vaddr");
+    snprintf(cfg, sizeof cfg, "%dx%dx%d regs %d lds %d batch %d%s%s slots %d", s.dI, s.dJ, s.dK, RL, LL, U, PIPE ? "" : " nopipe",
+             SADDR ? "" : " vaddr", SLOTS);
     if (s.dK - RL - LL < 1) {
         printf("vadv       %-44s skipped (needs dK > %d)\n", cfg, RL + LL);
         return;
@@ -1395,6 +1395,23 @@ static void vadv_variant(VadvSet& s, bool time_it = true) {
 }
 
 static void section_vadv() {
+    if (getenv("MB_VADV_SLOTS")) {  // where do the 16 spilled levels go: the column's own place in a 1.3 GB array, or a small reused area?
+        VadvSet s(1024, 1024, 160);
+        s.reset(s.ts_ref);
+        vadv_plain(s, s.ts_ref);
+        CK(hipDeviceSynchronize());
+        for (int rep = 0; rep < 3; ++rep) {
+            vadv_variant<104, 40, 4, true, true, 0>(s);
+            vadv_variant<104, 40, 4, true, true, 2048>(s);
+            vadv_variant<104, 40, 4, true, true, 4096>(s);
+            vadv_variant<104, 40, 4, true, true, 8192>(s);
+            vadv_variant<80, 40, 4, true, true, 0>(s);
+            vadv_variant<80, 40, 4, true, true, 4096>(s);
+            vadv_variant<48, 40, 4, true, true, 0>(s);
+            vadv_variant<48, 40, 4, true, true, 4096>(s);
+        }
+        return;
+    }
     {
         VadvSet s(1024, 1024, 160);
         s.reset(s.ts_ref);

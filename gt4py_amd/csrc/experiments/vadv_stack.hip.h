@@ -120,7 +120,10 @@ __device__ __forceinline__ void pin_here(double a, double b) { asm volatile("" :
 // PIPE = false waits for every batch of loads right after issuing it (no load is in flight during arithmetic: what a
 // loop that loads, then computes, does); SADDR = false folds the lane into the row pointers (one 64-bit vector address
 // per access instead of scalar base + lane) -- both only for the ablation in the micro-benchmark.
-template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true>
+// SLOTS > 0 (round 5 experiment): the levels that spill do not go to the column's own place in full-size ccol / dcol arrays but to
+// slot (blockIdx.x % SLOTS) of a small area that is reused block after block -- does a spill area of a few MB stay in the caches?
+// (A probe: two live blocks of one slot would collide; the micro-benchmark checks the result.)
+template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true, int SLOTS = 0>
 __global__ void __launch_bounds__(64)
 vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, int dJ, int dK, unsigned tiles_i) {
     static_assert(RL % U == 0 && LL % U == 0 && RL >= U, "level ranges are processed in batches of U");
@@ -136,7 +139,8 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
         if (!PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     const int64_t w_sk = f.wcon.sk, us_sk = f.u_stage.sk, up_sk = f.u_pos.sk, ut_sk = f.utens.sk, ts_sk = f.utens_stage.sk,
-                  cc_sk = f.ccol.sk, dc_sk = f.dcol.sk;
+                  cc_sk = SLOTS > 0 ? (int64_t)SLOTS * 64 : f.ccol.sk, dc_sk = SLOTS > 0 ? (int64_t)SLOTS * 64 : f.dcol.sk;
+    const int64_t spill0 = SLOTS > 0 ? (int64_t)(blockIdx.x % (SLOTS > 0 ? SLOTS : 1)) * 64 + (SADDR ? 0u : lane_id) : 0;
 
     // forward sweep: load cursors (wcon / u_stage run one level ahead of the others) and spill cursors
     const double* qw = scalar_launder(f.wcon.p + (int64_t)j * f.wcon.sj + ib + w_sk);
@@ -144,8 +148,8 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     const double* qup = scalar_launder(f.u_pos.p + (int64_t)j * f.u_pos.sj + ib);
     const double* qut = scalar_launder(f.utens.p + (int64_t)j * f.utens.sj + ib);
     const double* qts = scalar_launder((const double*)f.utens_stage.p + (int64_t)j * f.utens_stage.sj + ib);
-    double* qcc = scalar_launder(f.ccol.p + (int64_t)j * f.ccol.sj + ib);
-    double* qdc = scalar_launder(f.dcol.p + (int64_t)j * f.dcol.sj + ib);
+    double* qcc = scalar_launder(SLOTS > 0 ? f.ccol.p + spill0 : f.ccol.p + (int64_t)j * f.ccol.sj + ib);
+    double* qdc = scalar_launder(SLOTS > 0 ? f.dcol.p + spill0 : f.dcol.p + (int64_t)j * f.dcol.sj + ib);
 
     const int A = dK - LL - RL;  // levels [0, A) spill to memory
     double cp, dp;               // ccol[k-1], dcol[k-1]
@@ -306,8 +310,8 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     // ---- BACKWARD: fresh cursors, top of the column downwards ---------------------------------------
     const double* rup = scalar_launder(f.u_pos.p + (int64_t)j * f.u_pos.sj + ib + (int64_t)(dK - 1) * up_sk);
     double* rts = scalar_launder(f.utens_stage.p + (int64_t)j * f.utens_stage.sj + ib + (int64_t)(dK - 1) * ts_sk);
-    const double* rcc = scalar_launder((const double*)f.ccol.p + (int64_t)j * f.ccol.sj + ib + (int64_t)(A - 1) * cc_sk);
-    const double* rdc = scalar_launder((const double*)f.dcol.p + (int64_t)j * f.dcol.sj + ib + (int64_t)(A - 1) * dc_sk);
+    const double* rcc = scalar_launder((const double*)f.ccol.p + (SLOTS > 0 ? spill0 : (int64_t)j * f.ccol.sj + ib) + (int64_t)(A - 1) * cc_sk);
+    const double* rdc = scalar_launder((const double*)f.dcol.p + (SLOTS > 0 ? spill0 : (int64_t)j * f.dcol.sj + ib) + (int64_t)(A - 1) * dc_sk);
     // the spilled levels' own u_pos cursor: their loads are issued before the on-chip levels' are finished
     const double* rupm = scalar_launder(f.u_pos.p + (int64_t)j * f.u_pos.sj + ib + (int64_t)(A - 1) * up_sk);
     auto loadb = [&](BB& b) {

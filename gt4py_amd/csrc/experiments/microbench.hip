@@ -621,7 +621,7 @@ static void hdiff_variant_o(const DevField<T>& in, DevField<T>& out, const DevFi
     constexpr int H = (VEC >= 2) ? 1 : 2;
     const unsigned waves_i = (unsigned)cdiv(dI, (64 - 2 * H) * VEC), tiles_j = (unsigned)cdiv(dJ, LJ);
     const unsigned groups_j = TEAM ? tiles_j : (unsigned)cdiv(tiles_j, 4);
-    const unsigned nb = (TEAM ? (unsigned)cdiv(waves_i, 4) : waves_i) * groups_j * dK;
+    const unsigned nb = (TEAM ? (unsigned)cdiv(waves_i, 4) : waves_i) * ((XCDG < 0 && !TEAM) ? (unsigned)cdiv(groups_j, 8) * 8u : groups_j) * dK;
     char cfg[128];
     snprintf(cfg, sizeof cfg, "%s %s-internal VEC=%d LJ=%d PF=%d xcd=%d opt=%d%s", tag, sizeof(W) == 4 ? "f32" : "f64", VEC, LJ, PF, XCDG,
              OPT, TEAM ? " TEAM" : "");
@@ -718,6 +718,11 @@ static void section_hdiffnt() {
             V(16);  // nt in
             V(24);  // both
 #undef V
+            // workgroup -> XCD order with the nontemporal coeff loads: runs of 2 / 8 workgroups, one contiguous J chunk per XCD (-1)
+            hdiff_variant_o<float, double, 4, 6, 6, 2, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_o<float, double, 4, 6, 6, 8, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_o<float, double, 4, 6, 6, -1, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
+            hdiff_variant_o<float, double, 4, 6, 6, 0, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
             hdiff_variant_o<float, double, 4, 4, 4, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
             hdiff_variant_o<float, double, 4, 5, 5, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
             hdiff_variant_o<float, double, 4, 6, 4, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "1024x1024x80");
@@ -744,6 +749,9 @@ static void section_hdiffnt() {
             V(24);
 #undef V
             // shorter strips with the nontemporal coeff loads (the GENERATED kernel, 4 rows per lane, is 2-4 % ahead of 8 / 8 in bench.py)
+            hdiff_variant_o<double, double, 2, 6, 6, 2, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_o<double, double, 2, 6, 6, 8, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
+            hdiff_variant_o<double, double, 2, 6, 6, -1, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
             hdiff_variant_o<double, double, 2, 4, 4, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
             hdiff_variant_o<double, double, 2, 6, 6, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");
             hdiff_variant_o<double, double, 2, 6, 4, 4, 8, false>(in, out, ref, cf, dI, dJ, dK, "512x1024x80");

@@ -3,6 +3,7 @@
 CU still holds four waves) with the nontemporal loads, in ONE process on the SAME fields.
 
     python3 scripts/column_block_ab.py >> profiles/r5_nt_loads_column_kernels.txt"""
+import os
 import pathlib
 import sys
 
@@ -37,7 +38,7 @@ def main() -> int:
     torch.cuda.set_device(0)
     placement.configure(max_candidates=24, spacer_bytes=8 << 30, park_extra=5)
     gen = torch.Generator(device="cuda").manual_seed(3)
-    dom = (1024, 1024, 160)
+    dom = (1024, 1024, int(os.environ.get("COLUMN_K", "160")))
 
     def field(shape, lo=-1.0, hi=1.0):
         f = gt_storage.empty(shape, np.float64, backend="hip:mi300", aligned_index=(0, 0, 0))
@@ -48,7 +49,7 @@ def main() -> int:
     vf = {n: field(shape) for n in ("utens_stage", "u_stage", "wcon", "u_pos", "utens")}
     vadv = variants(bench._vertical_advection_dycore, externals={"BET_M": 0.5, "BET_P": 0.5})
     frozen = {m: s.freeze(origin={k: (0, 0, 0) for k in vf}, domain=dom) for m, s in vadv.items()}
-    print("generated vertical advection 1024x1024x160, waves per workgroup", flush=True)
+    print(f"generated vertical advection {dom}, waves per workgroup", flush=True)
     for rep in range(4):
         row = []
         for m in frozen:
@@ -71,7 +72,7 @@ def main() -> int:
     host = {n: f.tensor.clone() for n, f in tf.items()}
     tri = variants(hip_templates.tridiagonal_solver, dtypes={"T": np.float64}, use_kernel_library=False)
     frozen = {m: s.freeze(origin={k: (0, 0, 0) for k in tf}, domain=dom) for m, s in tri.items()}
-    print("generated tridiagonal solve 1024x1024x160, waves per workgroup", flush=True)
+    print(f"generated tridiagonal solve {dom}, waves per workgroup", flush=True)
     for rep in range(4):
         row = []
         for m in frozen:

@@ -427,6 +427,42 @@ static void section_lapnt() {
     }
 }
 
+// lap128: BASELINE configs[1] (512 x 512 x 128: a 90 us launch whose tail is a visible share) with four rotating pairs, workgroup shapes
+template <int LJ, int BLOCK, int XCD>
+static void lap128_variant(std::vector<DevField<double>*>& in, std::vector<DevField<double>*>& out, int dI, int dJ, int dK) {
+    constexpr int VEC = 2;
+    const unsigned tx = (unsigned)cdiv(dI, BLOCK * VEC), ty = (unsigned)cdiv(dJ, LJ);
+    const unsigned n = tx * ty * dK;
+    char cfg[96];
+    snprintf(cfg, sizeof cfg, "512x512x128 x 4 pairs, strip LJ=%d block=%d xcd=%d", LJ, BLOCK, XCD);
+    const double ms = time_ms([&](int i) {
+        const int p = i & 3;
+        hipLaunchKernelGGL((lap5_strip_kernel<double, double, 0, VEC, LJ, BLOCK, XCD>), dim3(n), dim3(BLOCK), 0, 0, in[p]->cview(), out[p]->view(), dI, dJ, tx, ty);
+    }, 80);
+    report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+}
+
+static void section_lap128() {
+    const int dI = 512, dJ = 512, dK = 128;
+    std::vector<DevField<double>*> in, out;
+    for (int p = 0; p < 4; ++p) {
+        in.push_back(new DevField<double>(dI, dJ, dK, 1, 1));
+        out.push_back(new DevField<double>(dI, dJ, dK, 1, 1));
+        fill(*in.back(), 5 + p, -1.0, 1.0);
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        lap128_variant<8, 256, 4>(in, out, dI, dJ, dK);
+        lap128_variant<8, 128, 4>(in, out, dI, dJ, dK);
+        lap128_variant<8, 64, 4>(in, out, dI, dJ, dK);
+        lap128_variant<8, 128, 8>(in, out, dI, dJ, dK);
+        lap128_variant<4, 256, 4>(in, out, dI, dJ, dK);
+        lap128_variant<6, 256, 4>(in, out, dI, dJ, dK);
+        lap128_variant<8, 256, 2>(in, out, dI, dJ, dK);
+    }
+    for (auto* f : in) delete f;
+    for (auto* f : out) delete f;
+}
+
 template <int LJ, int BLOCK, int XCD = 0>
 static void lap_variant(const DevField<double>& in, DevField<double>& out, int dI, int dJ, int dK, const char* tag) {
     constexpr int VEC = 2;
@@ -1646,6 +1682,7 @@ int main(int argc, char** argv) {
     if (on("copy")) section_copy();
     if (!want.empty() && on("copynt")) section_copynt();
     if (!want.empty() && on("lapnt")) section_lapnt();
+    if (!want.empty() && on("lap128")) section_lap128();
     if (!want.empty() && on("mix")) section_mix();
     if (on("lap")) section_lap();
     if (!want.empty() && on("lap512")) lap_suite(512, 512, 512, getenv("MB_LAP_EXTRA_PITCH") ? atoi(getenv("MB_LAP_EXTRA_PITCH")) : 0, "512^3");  // (-16: the 128-byte rows of round 4, pitch 528)

@@ -43,7 +43,7 @@ from __future__ import annotations
 import ast
 import inspect
 import textwrap
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -78,7 +78,7 @@ def _ufunc_targets(ufunc, dtypes) -> List[np.dtype]:
     best: Dict[int, List[np.dtype]] = {}
     types = getattr(ufunc, "types", None) or _FLOAT_ONLY_TYPES
     if not isinstance(ufunc, np.ufunc) or ufunc in (scipy.special.erf, scipy.special.erfc, scipy.special.gamma):
-        types = [t for t in types if t in ("f->f", "d->d")] or _FLOAT_ONLY_TYPES
+        types = _FLOAT_ONLY_TYPES  # (gtc/ufuncs.py:16-40 gives these the loops f->f and d->d whatever scipy offers)
     for t in types:
         ins, out = t.split("->")
         if len(ins) != len(dtypes):

@@ -3,8 +3,6 @@ interpreter `oracle/gtscript_interp.py`, so that test files written against a `b
 What EXECUTES is the interpreter on the definition's source; the product's IR is not consulted (its `field_info` still sizes the check
 of the arguments).  `Unsupported` constructs skip the test."""
 
-import inspect
-
 import numpy as np
 import pytest
 

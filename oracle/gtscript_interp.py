@@ -176,6 +176,8 @@ class Interpreter:
             return self._annotation_axes(ast.parse(ann.value, mode="eval").body)
         if isinstance(ann, ast.Name) and isinstance(self.globals.get(ann.id), str):  # ... or an alias of one
             return self._annotation_axes(ast.parse(self.globals[ann.id], mode="eval").body)
+        if isinstance(ann, ast.Subscript) and isinstance(ann.value, ast.Name) and ann.value.id == "GlobalTable":
+            return ()  # data dimensions only
         if isinstance(ann, ast.Subscript) and isinstance(ann.value, ast.Name) and ann.value.id == "Field":
             first = ann.slice.elts[0] if isinstance(ann.slice, ast.Tuple) else ann.slice
             if isinstance(first, ast.Name) and first.id in _AXES_NAMES:
@@ -477,7 +479,7 @@ class Interpreter:
         for b, block in enumerate(self.blocks):
             block.stmts = self._unroll_vector_statements(list(block.stmts))
             for s in block.stmts:
-                if isinstance(s, ast.Pass):
+                if isinstance(s, (ast.Pass, ast.ImportFrom)):
                     continue
                 call = s.items[0].context_expr if isinstance(s, ast.With) and len(s.items) == 1 else None
                 if isinstance(call, ast.Call) and getattr(call.func, "id", None) == "horizontal" and len(call.args) > 1:
@@ -513,7 +515,7 @@ class Interpreter:
             self._expr_accesses(stmt.target, region, out, {})
         elif isinstance(stmt, ast.AnnAssign):
             targets, value = [stmt.target], stmt.value
-        elif isinstance(stmt, ast.Pass):
+        elif isinstance(stmt, (ast.Pass, ast.ImportFrom)):
             return out
         else:
             raise Unsupported(f"statement {type(stmt).__name__}")
@@ -562,6 +564,11 @@ class Interpreter:
             base = e.value
             if isinstance(base, ast.Subscript):  # data index on top of an offset
                 self._expr_accesses(base, region, out, env, shift)
+                for x in self._subscript_elts(e):
+                    self._expr_accesses(x, region, out, env, shift)
+                return
+            if isinstance(base, ast.Attribute) and base.attr == "A" and isinstance(base.value, ast.Name):
+                out.append((base.value.id, shift, False, region))
                 for x in self._subscript_elts(e):
                     self._expr_accesses(x, region, out, env, shift)
                 return
@@ -830,7 +837,7 @@ class Interpreter:
         return out
 
     def _exec(self, stmt, box, masks):
-        if isinstance(stmt, ast.Pass):
+        if isinstance(stmt, (ast.Pass, ast.ImportFrom)):  # (`from __externals__ import X` may stand inside a block)
             return
         if isinstance(stmt, ast.With):
             sub = self._region_box(self._region(stmt), box)
@@ -1095,6 +1102,10 @@ class Interpreter:
             if isinstance(base, ast.Subscript):  # field[di, dj, dk][data index]
                 idx = tuple(int(np.asarray(self._eval(x, box, env, shift))) for x in self._subscript_elts(e))
                 return self._eval_access(base, box, env, shift, idx)
+            if isinstance(base, ast.Attribute) and base.attr == "A" and isinstance(base.value, ast.Name) and base.value.id in self.flds:
+                # field.A[data index]: the data dimensions at the point itself (gtscript_frontend.py `.A` absolute data indexing)
+                idx = tuple(int(np.asarray(self._eval(x, box, env, shift))) for x in self._subscript_elts(e))
+                return self._read(base.value.id, box, shift, idx)
             return self._eval_access(e, box, env, shift, None)
         if isinstance(e, ast.UnaryOp):
             v = self._eval(e.operand, box, env, shift)

@@ -1337,6 +1337,27 @@ static void section_trint() {
         }
     }
     tridiag_stack_variant<104, 40, 4, true, 1, 0, 0>(a, d, s, r, o, s2, r2, o2, dI, dJ, dK);
+    if (getenv("MB_TRINT_SHALLOW")) {  // the variants of shallower columns (K = 80: 32 + 40 levels, K = 60: 16 + 40): one or two waves per workgroup
+        for (int K : {80, 60}) {
+            DevField<double> a2(dI, dJ, K, 0, 0), d2(dI, dJ, K, 0, 0), s3(dI, dJ, K, 0, 0), r3(dI, dJ, K, 0, 0), o3(dI, dJ, K, 0, 0);
+            DevField<double> s4(dI, dJ, K, 0, 0), r4(dI, dJ, K, 0, 0), o4(dI, dJ, K, 0, 0);
+            fill(a2, 1, -1.0, 1.0);
+            fill(d2, 2, 4.0, 5.0);
+            for (int rep = 0; rep < 3; ++rep) {
+                if (K == 80) {
+                    tridiag_stack_variant<32, 40, 8, true, 1, 0, 1>(a2, d2, s3, r3, o3, s4, r4, o4, dI, dJ, K);
+                    tridiag_stack_variant<32, 40, 8, true, 2, 0, 1>(a2, d2, s3, r3, o3, s4, r4, o4, dI, dJ, K);
+                    tridiag_stack_variant<32, 40, 8, true, 1, 0, 0>(a2, d2, s3, r3, o3, s4, r4, o4, dI, dJ, K);
+                    tridiag_stack_variant<32, 40, 4, true, 1, 0, 1>(a2, d2, s3, r3, o3, s4, r4, o4, dI, dJ, K);
+                } else {
+                    tridiag_stack_variant<16, 40, 8, true, 1, 0, 1>(a2, d2, s3, r3, o3, s4, r4, o4, dI, dJ, K);
+                    tridiag_stack_variant<16, 40, 8, true, 2, 0, 1>(a2, d2, s3, r3, o3, s4, r4, o4, dI, dJ, K);
+                    tridiag_stack_variant<16, 40, 8, true, 1, 0, 0>(a2, d2, s3, r3, o3, s4, r4, o4, dI, dJ, K);
+                    tridiag_stack_variant<16, 40, 4, true, 1, 0, 1>(a2, d2, s3, r3, o3, s4, r4, o4, dI, dJ, K);
+                }
+            }
+        }
+    }
 }
 
 static void section_tripipe() {

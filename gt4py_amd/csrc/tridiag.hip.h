@@ -194,6 +194,9 @@ struct TridiagTuning {
     // against 1.748-1.755 on another (+2-2.6 %, A-B x 3 each; four waves +1 %; without the nontemporal loads the same change is +0.6 %;
     // profiles/r5_nt_loads_column_kernels.txt).  80 KB of LDS per workgroup, still one wave per SIMD.
     static constexpr int STACK_WPB_DEEPER = 2;
+    // ... and in the shallower variants as well: K = 80 (32 + 40 levels) 0.878 -> 0.867 ms, K = 60 (16 + 40) 0.628 -> 0.615 ms (microbench trint,
+    // MB_TRINT_SHALLOW=1, A-B x 3; the nontemporal loads themselves: 0.929 -> 0.878 and 0.682 -> 0.628)
+    static constexpr int STACK_WPB = 2;
     static constexpr int STACK_REG_SHALLOW = 16;  // + 40 LDS levels, for columns of 57 ... 72 levels
 };
 
@@ -268,21 +271,21 @@ inline int tridiag_run(const int64_t domain[3], const gt4mi_field* inf, const gt
                                    dim3(ti * (unsigned)cdiv(domain[1], WPB)), dim3(64, WPB), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                    (int)domain[1], (int)domain[2], ti);
         } else if (sizeof(T) == 8 && domain[2] > DEEP + TridiagTuning::STACK_LDS) {
-            hipLaunchKernelGGL((tridiag_pipe_kernel<T, DEEP, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
-                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, DEEP, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U, TridiagTuning::STACK_WPB>),
+                               dim3(ti * (unsigned)cdiv(domain[1], TridiagTuning::STACK_WPB)), dim3(64, TridiagTuning::STACK_WPB), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);
         } else if (domain[2] > TridiagTuning::STACK_REG + TridiagTuning::STACK_LDS) {
-            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
-                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U, TridiagTuning::STACK_WPB>),
+                               dim3(ti * (unsigned)cdiv(domain[1], TridiagTuning::STACK_WPB)), dim3(64, TridiagTuning::STACK_WPB), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);
         } else if (sizeof(T) == 8 && domain[2] > TridiagTuning::STACK_REG_SHALLOW + TridiagTuning::STACK_LDS) {
             // 57 ... 72 levels (K = 60 is a common column depth): 16 + 40 on chip instead of 32 in registers only
-            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG_SHALLOW, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U>),
-                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG_SHALLOW, TridiagTuning::STACK_LDS, TridiagTuning::STACK_U, TridiagTuning::STACK_WPB>),
+                               dim3(ti * (unsigned)cdiv(domain[1], TridiagTuning::STACK_WPB)), dim3(64, TridiagTuning::STACK_WPB), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);
         } else {
-            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG, 0, TridiagTuning::STACK_U>),
-                               dim3(ti * (unsigned)domain[1]), dim3(64), 0, stream, ac, dc, s, r, o, (int)domain[0],
+            hipLaunchKernelGGL((tridiag_pipe_kernel<T, TridiagTuning::STACK_REG, 0, TridiagTuning::STACK_U, TridiagTuning::STACK_WPB>),
+                               dim3(ti * (unsigned)cdiv(domain[1], TridiagTuning::STACK_WPB)), dim3(64, TridiagTuning::STACK_WPB), 0, stream, ac, dc, s, r, o, (int)domain[0],
                                (int)domain[1], (int)domain[2], ti);
         }
     } else if (contiguous) {

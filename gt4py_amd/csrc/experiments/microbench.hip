@@ -1432,16 +1432,16 @@ static void vadv_plain(VadvSet& s, DevField<double>& out) {
                        VADV_DTR, 0.5, 0.5, s.dI, s.dJ, s.dK);
 }
 
-template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true, int SLOTS = 0>
+template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true, int SLOTS = 0, int NTM = 0>
 static void vadv_variant(VadvSet& s, bool time_it = true) {
     const unsigned tiles_i = (unsigned)cdiv(s.dI, 64);
     auto launch = [&](DevField<double>& out) {
-        hipLaunchKernelGGL((vadv_pipe_kernel<RL, LL, U, PIPE, SADDR, SLOTS>), dim3(tiles_i * (unsigned)s.dJ), dim3(64), 0, 0, s.fields(out), VADV_DTR, 0.5,
+        hipLaunchKernelGGL((vadv_pipe_kernel<RL, LL, U, PIPE, SADDR, SLOTS, NTM>), dim3(tiles_i * (unsigned)s.dJ), dim3(64), 0, 0, s.fields(out), VADV_DTR, 0.5,
                            0.5, s.dI, s.dJ, s.dK, tiles_i);
     };
     char cfg[96];
-    snprintf(cfg, sizeof cfg, "%dx%dx%d regs %d lds %d batch %d%s%s slots %d", s.dI, s.dJ, s.dK, RL, LL, U, PIPE ? "" : " nopipe",
-             SADDR ? "" : " vaddr", SLOTS);
+    snprintf(cfg, sizeof cfg, "%dx%dx%d regs %d lds %d batch %d%s%s slots %d nt %d", s.dI, s.dJ, s.dK, RL, LL, U, PIPE ? "" : " nopipe",
+             SADDR ? "" : " vaddr", SLOTS, NTM);
     if (s.dK - RL - LL < 1) {
         printf("vadv       %-44s skipped (needs dK > %d)\n", cfg, RL + LL);
         return;
@@ -1460,6 +1460,18 @@ static void vadv_variant(VadvSet& s, bool time_it = true) {
 }
 
 static void section_vadv() {
+    if (getenv("MB_VADV_NT")) {  // nontemporal loads in the hand-written restatement: mode 5's placement, and wcon through a lane shift
+        VadvSet s(1024, 1024, 160);
+        s.reset(s.ts_ref);
+        vadv_plain(s, s.ts_ref);
+        CK(hipDeviceSynchronize());
+        for (int rep = 0; rep < 4; ++rep) {
+            vadv_variant<104, 40, 4, true, true, 0, 0>(s);
+            vadv_variant<104, 40, 4, true, true, 0, 1>(s);
+            vadv_variant<104, 40, 4, true, true, 0, 2>(s);
+        }
+        return;
+    }
     if (getenv("MB_VADV_SLOTS")) {  // where do the 16 spilled levels go: the column's own place in a 1.3 GB array, or a small reused area?
         VadvSet s(1024, 1024, 160);
         s.reset(s.ts_ref);

@@ -123,7 +123,11 @@ __device__ __forceinline__ void pin_here(double a, double b) { asm volatile("" :
 // SLOTS > 0 (round 5 experiment): the levels that spill do not go to the column's own place in full-size ccol / dcol arrays but to
 // slot (blockIdx.x % SLOTS) of a small area that is reused block after block -- does a spill area of a few MB stay in the caches?
 // (A probe: two live blocks of one slot would collide; the micro-benchmark checks the result.)
-template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true, int SLOTS = 0>
+// NTM (round 5 probe): 1 = nontemporal loads the way the code generator's mode 5 places them (u_stage, utens, utens_stage in the forward
+// sweep, u_pos at its last use in the backward sweep; wcon -- read at i and i + 1 -- and u_pos's first read stay cacheable);
+// 2 = 1 + wcon loaded ONCE, nontemporally, the i + 1 value taken from the next lane (lane 63 loads its own): does a vertical advection
+// whose only cacheable stream is u_pos keep more of it on chip between the sweeps?
+template <int RL, int LL, int U, bool PIPE = true, bool SADDR = true, int SLOTS = 0, int NTM = 0>
 __global__ void __launch_bounds__(64)
 vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, int dJ, int dK, unsigned tiles_i) {
     static_assert(RL % U == 0 && LL % U == 0 && RL >= U, "level ranges are processed in batches of U");
@@ -160,7 +164,16 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     using FB = VadvFwdBatch<U>;
     using BB = VadvBwdBatch<U>;
     // one interior level: consumes the carried values and the level's own loads, leaves ccol/dcol of the level in cp/dp
-    auto mid = [&](double w0n, double w1n, double usn, double up, double ut, double ts) {
+    auto east = [&](double w0n, double w1n) {  // wcon[i + 1]: NTM 2 takes it from the next lane (lane 63 loaded its own)
+        if constexpr (NTM == 2) {
+            const double from_next = lane_shift<double, false>(w0n);
+            return lane_id == 63 ? w1n : from_next;
+        } else {
+            return w1n;
+        }
+    };
+    auto mid = [&](double w0n, double w1n_in, double usn, double up, double ut, double ts) {
+        const double w1n = east(w0n, w1n_in);
         const double wsn = w1n + w0n;
         const double gav = (-0.25) * ws;
         const double gcv = 0.25 * wsn;
@@ -183,13 +196,19 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     // one level of loads at the cursors: wcon / u_stage of the level above, the rest of the level itself
     auto load_level = [&](double& w0, double& w1, double& us, double& up, double& ut, double& ts, bool above = true) {
         if (above) {
-            w0 = qw[lane];
-            w1 = qw[lane + 1];
-            us = qus[lane];
+            if constexpr (NTM == 2) {
+                w0 = __builtin_nontemporal_load(qw + lane);
+                w1 = 0.0;  // (taken from the next lane where the value is USED -- a shift here would wait for the load)
+                if (lane_id == 63) w1 = __builtin_nontemporal_load(qw + lane + 1);
+            } else {
+                w0 = qw[lane];
+                w1 = qw[lane + 1];
+            }
+            us = NTM ? __builtin_nontemporal_load(qus + lane) : qus[lane];
         }
         up = qup[lane];
-        ut = qut[lane];
-        ts = qts[lane];
+        ut = NTM ? __builtin_nontemporal_load(qut + lane) : qut[lane];
+        ts = NTM ? __builtin_nontemporal_load(qts + lane) : qts[lane];
         qw += w_sk;
         qus += us_sk;
         qup += up_sk;
@@ -230,7 +249,7 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
         load(B[0]);  // the first whole batch
         issued();
         {  // interval(0, 1)
-            const double wsn = w1a + w0a;
+            const double wsn = east(w0a, w1a) + w0a;
             const double gcv = 0.25 * wsn;
             const double cs = gcv * bet_m;
             double ccol = gcv * bet_p;
@@ -319,7 +338,7 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
         for (int u = 0; u < U; ++u) {
             b.c[u] = rcc[lane];
             b.d[u] = rdc[lane];
-            b.up[u] = rupm[lane];
+            b.up[u] = NTM ? __builtin_nontemporal_load(rupm + lane) : rupm[lane];
             rcc -= cc_sk;
             rdc -= dc_sk;
             rupm -= up_sk;
@@ -342,7 +361,7 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
     auto loadp = [&](double (&p)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            p[u] = rup[lane];
+            p[u] = NTM ? __builtin_nontemporal_load(rup + lane) : rup[lane];
             rup -= up_sk;
         }
     };
@@ -392,7 +411,7 @@ vadv_pipe_kernel(VadvFields f, double dtr, double bet_m, double bet_p, int dI, i
             if (u <= kb) {
                 t.c[u] = rcc[lane];
                 t.d[u] = rdc[lane];
-                t.up[u] = rupm[lane];
+                t.up[u] = NTM ? __builtin_nontemporal_load(rupm + lane) : rupm[lane];
                 rcc -= cc_sk;
                 rdc -= dc_sk;
                 rupm -= up_sk;

@@ -16,6 +16,7 @@
 #include "lap5.hip.h"
 #include "tridiag.hip.h"
 #include "vadv_stack.hip.h"
+#include "hdiff_ldstile.hip.h"
 
 using namespace gt4mi;
 
@@ -830,6 +831,114 @@ static void section_hdiffxcd() {
             hdiff_variant_w<double, double, 2, 4, 4, -1>(in, out, cf, dI, dJ, dK, "512x1024x80");
         }
     }
+}
+
+
+// MB_HDIFFL=<substring>[,<substring>...]: keep only the hdiffl variants whose configuration line contains one of them
+static bool hdiffl_selected(const char* cfg) {
+    const char* only = getenv("MB_HDIFFL");
+    if (!only || !*only) return true;
+    std::string all(only);
+    size_t a = 0;
+    while (a <= all.size()) {
+        size_t b = all.find(',', a);
+        if (b == std::string::npos) b = all.size();
+        if (b > a && strstr(cfg, all.substr(a, b - a).c_str())) return true;
+        a = b + 1;
+    }
+    return false;
+}
+
+// hdiffl (round 6): the LDS-staged `in` block (experiments/hdiff_ldstile.hip.h) beside the library's register-only J-march, every
+// variant compared bit for bit with the one-thread-per-point kernel.  MB_HDIFFL=<substring> keeps only the variants whose
+// configuration line contains it (for one-kernel PMC passes); MB_HDIFFL_ITERS sets the timed launches per variant.
+template <typename T, typename W, int VEC, int RW, int NW, bool GLDS>
+static void hdiff_variant_l(const DevField<T>& in, DevField<T>& out, const DevField<T>& ref, const DevField<T>& cf, int dI, int dJ, int dK,
+                            const char* tag, int seg_rows, int xcd_group) {
+    char cfg[160];
+    snprintf(cfg, sizeof cfg, "%s %s-internal LDS ring RW=%d NW=%d %s seg=%d xcd=%d", tag, sizeof(W) == 4 ? "f32" : "f64", RW, NW,
+             GLDS ? "glds" : "regs", seg_rows, xcd_group);
+    if (!hdiffl_selected(cfg)) return;
+    const int iters = getenv("MB_HDIFFL_ITERS") ? atoi(getenv("MB_HDIFFL_ITERS")) : 100;
+    CK(hipMemset(out.raw, 0, out.bytes));
+    const double ms = time_ms([&](int) {
+        hdiff_ldstile_launch<T, W, VEC, RW, NW, GLDS>(in.cview(), out.view(), cf.cview(), dI, dJ, dK, seg_rows, xcd_group, 0);
+    }, iters);
+    CK(hipGetLastError());
+    report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, 3.0 * sizeof(T));
+    const unsigned long long bad = count_diff(out, ref, dI, dJ, dK);
+    if (bad) printf("           MISMATCHES vs the one-thread-per-point kernel: %llu\n", bad);
+}
+
+template <typename T, typename W, int VEC, int LJ, int NW, int XCDG, int MINW = 4>
+static void hdiff_variant_s(const DevField<T>& in, DevField<T>& out, const DevField<T>& ref, const DevField<T>& cf, int dI, int dJ, int dK,
+                            const char* tag) {
+    char cfg[160];
+    snprintf(cfg, sizeof cfg, "%s %s-internal shared halo rows in LDS LJ=%d NW=%d minw=%d xcd=%d", tag, sizeof(W) == 4 ? "f32" : "f64", LJ, NW, MINW,
+             XCDG);
+    if (!hdiffl_selected(cfg)) return;
+    const int iters = getenv("MB_HDIFFL_ITERS") ? atoi(getenv("MB_HDIFFL_ITERS")) : 100;
+    CK(hipMemset(out.raw, 0, out.bytes));
+    const int64_t d[3] = {dI, dJ, dK};
+    const double ms = time_ms([&](int) {
+        (void)hdiff_launch_share_shape<T, W, W, true, true, VEC, LJ, NW, XCDG, MINW>(in.cview(), out.view(), cf.cview(), (W)0, d, 0, 0);
+    }, iters);
+    CK(hipGetLastError());
+    report(sizeof(T) == 4 ? "hdiff_f32" : "hdiff_f64", cfg, ms, (double)dI * dJ * dK, 3.0 * sizeof(T));
+    const unsigned long long bad = count_diff(out, ref, dI, dJ, dK);
+    if (bad) printf("           MISMATCHES vs the one-thread-per-point kernel: %llu\n", bad);
+}
+
+template <typename T, typename W, int VEC>
+static void hdiffl_suite(int dI, int dJ, int dK, const char* tag) {
+    DevField<T> in(dI, dJ, dK, 2, 2), out(dI, dJ, dK, 2, 2), ref(dI, dJ, dK, 2, 2), cf(dI, dJ, dK, 2, 2);
+    fill(in, 2024, 1.0, 9.0);
+    fill(cf, 7, 0.0, 0.05);
+    {
+        dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+        hipLaunchKernelGGL((hdiff_generic_kernel<T, W, W, true, true>), grid, dim3(256), 0, 0, in.cview(), ref.view(), cf.cview(), (W)0, dI, dJ, dK);
+        CK(hipDeviceSynchronize());
+    }
+    const int reps = getenv("MB_HDIFFL_REPS") ? atoi(getenv("MB_HDIFFL_REPS")) : 2;
+    for (int rep = 0; rep < reps; ++rep) {
+        if (hdiffl_selected("register J-march"))
+            hdiff_variant_o<T, W, VEC, 6, 6, 4, HD_OPT_NT_COEFF, false>(in, out, ref, cf, dI, dJ, dK, tag);  // the library's kernel of rounds 1-5
+#define L(RW, NW, G, SEG, X) hdiff_variant_l<T, W, VEC, RW, NW, G>(in, out, ref, cf, dI, dJ, dK, tag, SEG, X)
+        L(6, 4, true, 128, 4);
+        L(6, 4, false, 128, 4);
+        L(4, 4, true, 128, 4);
+        L(4, 4, false, 128, 4);
+        L(8, 4, true, 128, 4);
+        L(8, 4, true, 256, 4);
+        L(4, 8, true, 256, 4);
+#undef L
+#define S(LJ, NW, X, MW) hdiff_variant_s<T, W, VEC, LJ, NW, X, MW>(in, out, ref, cf, dI, dJ, dK, tag)
+        S(4, 4, 2, 4);  // the library's shape
+        S(4, 4, 0, 4);
+        S(4, 4, 1, 4);
+        S(4, 4, 4, 4);
+        S(4, 4, 8, 4);
+        S(4, 4, 16, 4);
+        S(4, 2, 4, 4);
+        S(4, 2, 8, 4);
+        S(4, 3, 4, 4);
+        S(4, 6, 2, 4);
+        S(4, 8, 1, 4);
+        S(5, 4, 4, 4);
+        S(6, 4, 4, 3);
+        S(6, 4, 4, 4);
+        S(4, 16, 1, 4);
+#undef S
+    }
+}
+
+static void section_hdiffl() {
+    hdiffl_suite<float, double, 4>(1024, 1024, 80, "1024x1024x80");
+    hdiffl_suite<double, double, 2>(512, 1024, 80, "512x1024x80");
+    if (getenv("MB_HDIFFL_BIG_ONLY")) return;
+    // ragged domains: partial strips, a partial last chunk, a last segment shorter than a chunk
+    hdiffl_suite<double, double, 2>(333, 517, 5, "333x517x5");
+    hdiffl_suite<float, double, 4>(250, 131, 3, "250x131x3");
 }
 
 static void section_hdiff() {
@@ -1764,6 +1873,7 @@ int main(int argc, char** argv) {
     if (!want.empty() && on("hdiff2")) section_hdiff2();
     if (!want.empty() && on("hdiff3")) section_hdiff3();
     if (!want.empty() && on("hdiffnt")) section_hdiffnt();
+    if (!want.empty() && on("hdiffl")) section_hdiffl();
     if (!want.empty() && on("kprobe")) section_kprobe();
     if (!want.empty() && on("hdiffxcd")) section_hdiffxcd();
     if (on("tridiag")) section_tridiag();

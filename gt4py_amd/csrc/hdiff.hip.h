@@ -99,6 +99,7 @@ inline int hdiff_launch(const View<const T>& in, const View<T>& out, const View<
 }  // namespace gt4mi
 
 #include "hdiff_jmarch.hip.h"
+#include "hdiff_share.hip.h"
 
 namespace gt4mi {
 
@@ -112,6 +113,13 @@ inline int hdiff_launch(const View<const T>& in, const View<T>& out, const View<
     // 2 of the 128-256 columns of a wave-wide tile: one thread per point is 5-10x faster there.
     const bool skinny = d[0] < 32;
     if (contiguous && !skinny && hdiff_jmarch_enabled()) {
+        // 16-byte lanes: the J-march whose waves exchange their halo rows through LDS (hdiff_share.hip.h, round 6);
+        // GT4MI_HDIFF_SHARE=0 keeps the register-only J-march of rounds 1-5 for A/B runs on ONE box
+        constexpr int VMAX = 16 / sizeof(T);
+        static const bool share = env_int("GT4MI_HDIFF_SHARE", 1) != 0;
+        int lead = 0;
+        if (share && hdiff_common_lead<T, COEFF_FIELD>(in, out, cf, VMAX, &lead))
+            return hdiff_launch_share<T, W, PW, LIMITER, COEFF_FIELD, VMAX>(in, out, cf, coeff_scalar, d, stream, lead);
         return hdiff_launch_jmarch<T, W, PW, LIMITER, COEFF_FIELD>(in, out, cf, coeff_scalar, d, stream);
     }
     if (skinny) {

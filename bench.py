@@ -77,9 +77,9 @@ KERNEL_SOURCES = {  # the files whose contents decide what a kernel does, per pr
 KERNEL_NEEDLES = {
     "lap5_f64_512": "lap5_strip_kernel<double, double",
     "laplacian_f64_512x512x128_config1": "lap5_strip_kernel<double, double",
-    "hdiff_limiter_f32_1024x1024x80": "hdiff_jmarch_kernel<float, double, double",
-    "hdiff_limiter_f32_literal32_1024x1024x80": "hdiff_jmarch_kernel<float, float, float",
-    "hdiff_limiter_f64_512x1024x80": "hdiff_jmarch_kernel<double, double, double",
+    "hdiff_limiter_f32_1024x1024x80": "hdiff_share_kernel<float, double, double",
+    "hdiff_limiter_f32_literal32_1024x1024x80": "hdiff_share_kernel<float, float, float",
+    "hdiff_limiter_f64_512x1024x80": "hdiff_share_kernel<double, double, double",
     "tridiagonal_f64_1024x1024x160": "tridiag_",
     "generated_vertical_advection_f64_1024x1024x160": "gt4mi__vertical_advection_dycore_stage",
     "generated_laplacian_f64_512x512x512": "gt4mi_lap_notebook_stage",
@@ -158,8 +158,9 @@ def _lap_definition():
     return hip_templates.lap_notebook
 
 
-def _device_fields(shape, n_pairs, seed, origin=(1, 1, 0)):
-    """`n_pairs` (inp, out) pairs in HBM with the hip:mi300 layout; inp ~ U[-1, 1), seeded on device."""
+def _device_fields(shape, n_pairs, seed, origin=(1, 1, 0), hint=None):
+    """`n_pairs` (inp, out) pairs in HBM with the hip:mi300 layout; inp ~ U[-1, 1), seeded on device.  `hint`: the stencil's
+    `placement_hint()` -- {"inp": class, "out": class} -- for the storage allocator (None: its own deal by live bytes)."""
     import numpy as np
     import torch
 
@@ -167,9 +168,10 @@ def _device_fields(shape, n_pairs, seed, origin=(1, 1, 0)):
 
     pairs = []
     gen = torch.Generator(device="cuda").manual_seed(seed)
+    hint = hint or {}
     for _ in range(n_pairs):
-        inp = gt_storage.empty(shape, np.float64, backend="hip:mi300", aligned_index=origin)
-        out = gt_storage.zeros(shape, np.float64, backend="hip:mi300", aligned_index=origin)
+        inp = gt_storage.empty(shape, np.float64, backend="hip:mi300", aligned_index=origin, memory_class=hint.get("inp"))
+        out = gt_storage.zeros(shape, np.float64, backend="hip:mi300", aligned_index=origin, memory_class=hint.get("out"))
         inp.tensor.copy_(torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1)
         pairs.append((inp, out))
     return pairs
@@ -240,7 +242,54 @@ def copy_ceiling_gbs(steps: int = 10, nbytes: int = 1 << 30, classes=None) -> fl
     return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
-def hdiff_input(shape, dtype, gen, origin=(2, 2, 0)):
+def allocator_variants(lap, frozen, shape, steps: int):
+    """`value_default_allocator`, `value_allocator_off` (GLUPS of the headline kernel, whole 512^3 grid) and the memory classes the
+    fields got.  The bench's own fields come from `placement.configure(...)`'s wide search plus the stencil's role hint; a program
+    that only calls `gt_storage.empty(...)` gets the first of these two numbers, one that sets GT4PY_AMD_ALLOC_GROUPS=0 the second."""
+    import numpy as np
+    import torch
+
+    from gt4py_amd.storage import placement
+
+    placer = placement.device_placer()
+    saved = None
+    if placer is not None:
+        saved = {k: getattr(placer, k) for k in ("max_candidates", "spacer_bytes", "park_extra")}
+        parked, placer.parked = placer.parked, {}
+    out = {}
+    try:
+        for key, off in (("default_allocator", False), ("allocator_off", True)):
+            if placer is not None:
+                placement.configure(max_candidates=6, spacer_bytes=0, park_extra=0)
+            if off:
+                with placement.disabled():
+                    pairs = _device_fields(shape, n_pairs=2, seed=4242)
+            else:
+                pairs = _device_fields(shape, n_pairs=2, seed=4242)
+
+            def call(i):
+                inp, o = pairs[i % len(pairs)]
+                frozen(inp=inp, out=o)
+
+            for i in range(5):
+                call(i)
+            torch.cuda.synchronize()
+            ms = _time_launches(call, max(int(steps), 20))["mean"]
+            out[f"value_{key}"] = round(float(np.prod(GRID)) / ms / 1e6, 2)
+            out[f"memory_classes_{key}"] = [[placement.class_of(i), placement.class_of(o)] for i, o in pairs]
+            del pairs
+            torch.cuda.empty_cache()
+    finally:
+        if placer is not None:
+            placement.configure(**saved)
+            placer.parked = parked
+    out["allocator_note"] = ("value = fields from the wide search (placement.configure: 24 candidates, 8 GB spacers) + the stencil's "
+                             "placement_hint(); value_default_allocator = plain gt_storage.empty at the allocator's defaults; "
+                             "value_allocator_off = GT4PY_AMD_ALLOC_GROUPS=0")
+    return out
+
+
+def hdiff_input(shape, dtype, gen, origin=(2, 2, 0), cls=None):
     """the demo notebook's field (docs/.../demo_horizontal_diffusion.ipynb cell 9) plus noise, so that
     the flux limiter fires on a non-trivial subset: 5 + 8 (2 + cos(pi (x + 1.5 y)) + sin(2 pi (x + 1.5 y))) / 4 + 0.1 U[-1, 1),
     x = i / N, y = j / N; the same on every level."""
@@ -250,7 +299,7 @@ def hdiff_input(shape, dtype, gen, origin=(2, 2, 0)):
 
     import gt4py_amd.storage as gt_storage
 
-    f = gt_storage.empty(shape, dtype, backend="hip:mi300", aligned_index=origin)
+    f = gt_storage.empty(shape, dtype, backend="hip:mi300", aligned_index=origin, memory_class=cls)
     x = torch.arange(shape[0], dtype=torch.float64, device="cuda")[:, None, None] / shape[0]
     y = torch.arange(shape[1], dtype=torch.float64, device="cuda")[None, :, None] / shape[1]
     s = x + 1.5 * y
@@ -305,8 +354,10 @@ def other_kernels(steps: int = 20, only=None):
 
     gen = torch.Generator(device="cuda").manual_seed(2024)
 
-    def field(shape, dtype, origin, lo=-1.0, hi=1.0):
-        f = gt_storage.empty(shape, dtype, backend="hip:mi300", aligned_index=origin)
+    def field(shape, dtype, origin, lo=-1.0, hi=1.0, cls=None):
+        # `cls`: the memory class the stencil's placement_hint() names for this field (what a stencil writes is dealt alternately
+        # over the two classes, what it only reads fills up the emptier one: gt4py_amd/storage/placement.py deal_by_roles)
+        f = gt_storage.empty(shape, dtype, backend="hip:mi300", aligned_index=origin, memory_class=cls)
         f.tensor.copy_(torch.rand(shape, dtype=f.tensor.dtype, device="cuda", generator=gen) * (hi - lo) + lo)
         return f
 
@@ -359,7 +410,9 @@ def other_kernels(steps: int = 20, only=None):
         lap_obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
                                    device_sync=False)
         shape = (dom[0] + 2, dom[1] + 2, dom[2])
-        sets = [{"inp": field(shape, np.float64, (1, 1, 0)), "out": field(shape, np.float64, (1, 1, 0))} for _ in range(4)]
+        hint = lap_obj.placement_hint()
+        sets = [{"inp": field(shape, np.float64, (1, 1, 0), cls=hint["inp"]), "out": field(shape, np.float64, (1, 1, 0), cls=hint["out"])}
+                for _ in range(4)]
         run("laplacian_f64_512x512x128_config1", lap_obj, sets, {k: (1, 1, 0) for k in ("inp", "out")}, dom, 16.0,
             note="BASELINE.json configs[1] at its own size, four rotating (inp, out) pairs = 2.3 GB so that the 256 MB Infinity "
                  "Cache cannot serve repeats; the headline `value` is the same kernel on 512^3")
@@ -380,8 +433,9 @@ def other_kernels(steps: int = 20, only=None):
         obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": dt},
                                device_sync=False, literal_float_precision=lit)
         shape = (dom[0] + 4, dom[1] + 4, dom[2])
-        fields = {"in_field": hdiff_input(shape, dt, gen), "coeff": field(shape, dt, (2, 2, 0), 0.025, 0.025),
-                  "out_field": field(shape, dt, (2, 2, 0))}
+        hint = obj.placement_hint()
+        fields = {"in_field": hdiff_input(shape, dt, gen, cls=hint["in_field"]), "coeff": field(shape, dt, (2, 2, 0), 0.025, 0.025, cls=hint["coeff"]),
+                  "out_field": field(shape, dt, (2, 2, 0), cls=hint["out_field"])}
         run(tag, obj, fields, {k: (2, 2, 0) for k in fields}, dom, 3.0 * np.dtype(dt).itemsize, note=note)
         del fields
     if wanted("tridiagonal_f64_1024x1024x160"):
@@ -395,7 +449,8 @@ def other_kernels(steps: int = 20, only=None):
         obj = gtscript.stencil(backend="hip:mi300", definition=_vertical_advection_dycore, externals={"BET_M": 0.5, "BET_P": 0.5},
                                device_sync=False)
         shape = (dom[0] + 1, dom[1], dom[2] + 1)
-        fields = {n: field(shape, np.float64, (0, 0, 0)) for n in ("utens_stage", "u_stage", "wcon", "u_pos", "utens")}
+        hint = obj.placement_hint()
+        fields = {n: field(shape, np.float64, (0, 0, 0), cls=hint[n]) for n in ("utens_stage", "u_stage", "wcon", "u_pos", "utens")}
         run("generated_vertical_advection_f64_1024x1024x160", obj, fields, {k: (0, 0, 0) for k in fields}, dom, 48.0,
             scalars={"dtr_stage": 3.0 / 20.0},
             note="one generated column kernel (forward + backward sweep); 5 fields read, 1 written; the forward sweep's "
@@ -409,7 +464,8 @@ def other_kernels(steps: int = 20, only=None):
         obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.lap_notebook, dtypes={"T": np.float64},
                                device_sync=False, use_kernel_library=False)
         shape = (dom[0] + 2, dom[1] + 2, dom[2])
-        fields = {"inp": field(shape, np.float64, (1, 1, 0)), "out": field(shape, np.float64, (1, 1, 0))}
+        hint = obj.placement_hint()
+        fields = {"inp": field(shape, np.float64, (1, 1, 0), cls=hint["inp"]), "out": field(shape, np.float64, (1, 1, 0), cls=hint["out"])}
         run("generated_laplacian_f64_512x512x512", obj, fields, {k: (1, 1, 0) for k in fields}, dom, 16.0,
             note="the headline stencil through the code generator instead of the hand-written kernel")
         del fields
@@ -419,8 +475,9 @@ def other_kernels(steps: int = 20, only=None):
         obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.hdiff_limiter_field, dtypes={"T": np.float64},
                                device_sync=False, use_kernel_library=False)
         shape = (dom[0] + 4, dom[1] + 4, dom[2])
-        fields = {"in_field": hdiff_input(shape, np.float64, gen), "coeff": field(shape, np.float64, (2, 2, 0), 0.025, 0.025),
-                  "out_field": field(shape, np.float64, (2, 2, 0))}
+        hint = obj.placement_hint()
+        fields = {"in_field": hdiff_input(shape, np.float64, gen, cls=hint["in_field"]), "coeff": field(shape, np.float64, (2, 2, 0), 0.025, 0.025, cls=hint["coeff"]),
+                  "out_field": field(shape, np.float64, (2, 2, 0), cls=hint["out_field"])}
         run("generated_hdiff_limiter_f64_512x1024x80", obj, fields, {k: (2, 2, 0) for k in fields}, dom, 24.0,
             note="the flux-limited horizontal diffusion through the code generator: one strip kernel, lap / flx / fly computed "
                  "once per point and passed between lanes with DPP shifts (hip_codegen._emit_shared_kernel)")
@@ -451,9 +508,10 @@ def _tridiagonal_entry(field, steps: int):
     name, dom = "tridiagonal_f64_1024x1024x160", (1024, 1024, 160)
     obj = gtscript.stencil(backend="hip:mi300", definition=hip_templates.tridiagonal_solver, dtypes={"T": np.float64},
                            device_sync=False)
-    sets = [{"inf": field(dom, np.float64, (0, 0, 0)), "diag": field(dom, np.float64, (0, 0, 0), 4.0, 5.0),
-             "sup": field(dom, np.float64, (0, 0, 0)), "rhs": field(dom, np.float64, (0, 0, 0), -10.0, 10.0),
-             "out": field(dom, np.float64, (0, 0, 0))} for _ in range(2)]
+    hint = obj.placement_hint()  # inf / diag / sup / rhs / out -> 0 / 0 / 1 / 0 / 1: BOTH sets get the same arrangement
+    sets = [{"inf": field(dom, np.float64, (0, 0, 0), cls=hint["inf"]), "diag": field(dom, np.float64, (0, 0, 0), 4.0, 5.0, cls=hint["diag"]),
+             "sup": field(dom, np.float64, (0, 0, 0), cls=hint["sup"]), "rhs": field(dom, np.float64, (0, 0, 0), -10.0, 10.0, cls=hint["rhs"]),
+             "out": field(dom, np.float64, (0, 0, 0), cls=hint["out"])} for _ in range(2)]
     pristine = [{k: fs[k].tensor.clone() for k in ("sup", "rhs")} for fs in sets]
     frozen = obj.freeze(origin={k: (0, 0, 0) for k in sets[0]}, domain=dom)
 
@@ -487,16 +545,17 @@ def _tridiagonal_entry(field, steps: int):
              "frac_of_hbm_peak_by_allocation_set": [round(56.0 * lups / (v * 1e-3) / 1e9 / PEAK_GBS, 4) for v in by_set],
              "field_addresses_mod_4MiB": [[int(f.ptr % (4 << 20)) for f in fs.values()] for fs in sets],
              "memory_classes_by_allocation_set": [{k: _placement_class(v) for k, v in fs.items()} for fs in sets],
+             "memory_classes_wanted": hint,
              "inputs": "SURVEY.md section 8d (diag ~ U[4, 5), inf, sup ~ U[-1, 1), rhs ~ U[-10, 10)), sup and rhs restored from "
                        "pristine copies before EVERY launch, outside the timed interval; two rotating sets of the five fields",
              "roofline": {"bound": "hbm", "kernel": KERNEL_NEEDLES.get(name), "achieved": round(gbs, 1), "peak": PEAK_GBS, "unit": "GB/s",
                           "frac": round(gbs / PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                           "algorithmic_bytes_per_launch": 56.0 * lups,
                           "traffic_over_algorithmic": round(traffic / (56.0 * lups), 4) if traffic else None},
-             "note": "the K-strided column kernels are the only ones whose speed depends on the allocation set (0.60-0.73 of the HBM "
-                     "peak over the boxes and sets of rounds 1-4: address translation, profiles/r4_tridiag_translation.txt); a 4-read / "
-                     "3-write streaming kernel reaches 0.71 (profiles/r3_microbench_rw_mix.log).  The backward sweep re-reads the part "
-                     "of sup', rhs' that does not fit on chip (144 of 160 levels stay in registers + LDS)"}
+             "note": "the speed of the K-strided column kernels depends on which memory groups their fields live in (0.67 of the HBM peak "
+                     "with all five in one group, 0.78-0.79 with the written streams split 2 + 1 over two: profiles/r6_memory_roles.log); both "
+                     "allocation sets are allocated by the stencil's placement_hint().  The backward sweep re-reads the part of sup', rhs' "
+                     "that does not fit on chip (144 of 160 levels stay in registers + LDS)"}
     return {name: entry}
 
 
@@ -1691,7 +1750,7 @@ def main() -> None:
                                device_sync=False)
         origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}
         shape = (GRID[0] + 2, GRID[1] + 2, GRID[2])
-        pairs = _device_fields(shape, n_pairs=2, seed=1337)  # rotate pairs: nothing survives in MALL/L2
+        pairs = _device_fields(shape, n_pairs=2, seed=1337, hint=lap.placement_hint())  # rotate pairs: nothing survives in MALL/L2
         frozen = lap.freeze(origin=origin, domain=GRID)
 
         def step(i):
@@ -1751,6 +1810,14 @@ def main() -> None:
                 line["host_cost_per_call"] = host_cost_per_call(lap)
             except Exception as ex:
                 print(f"host_cost_per_call failed: {ex!r}", file=sys.stderr)
+        if headline:
+            # What a drop-in user gets: the headline kernel on fields from the storage allocator AT ITS
+            # DEFAULTS (6 plain candidates per search, no spacers, no parked neighbours, no role hints: plain gt_storage.empty) and
+            # with the memory-group placer OFF -- 5 + 20 launches each, outside the contract's timed steps.
+            try:
+                line.update(allocator_variants(lap, frozen, shape, args.steps))
+            except Exception as ex:
+                print(f"allocator_variants failed: {ex!r}", file=sys.stderr)
         if headline and not args.no_other_kernels:
             try:
                 line["other_kernels"] = other_kernels()

@@ -114,6 +114,9 @@ class FrozenStencil:
         if exec_info is not None:
             exec_info["call_run_end_time"] = time.perf_counter()
 
+    def placement_hint(self, nbytes: Optional[Dict[str, int]] = None) -> Dict[str, int]:
+        return self.stencil_object.placement_hint(nbytes)
+
 
 class StencilObject(abc.ABC):
     """Singleton, immutable callable generated per (definition, externals, options, backend)."""
@@ -423,6 +426,19 @@ class StencilObject(abc.ABC):
         self.run(_domain_=domain, _origin_=origin, exec_info=exec_info, **arrays, **parameter_args)
         if exec_info is not None:
             exec_info["call_run_end_time"] = time.perf_counter()
+
+    def placement_hint(self, nbytes: Optional[Dict[str, int]] = None) -> Dict[str, int]:
+        """{field name: memory class} -- where the storage allocator should put each field of this stencil, derived from what the
+        stencil DOES with it (``field_info[name].access``): NEW relative to the reference, whose allocators know nothing of the
+        device's memory system (storage/allocators.py:187-273).  What is written is dealt alternately over the two classes of
+        ``gt4py_amd.storage.placement`` starting with class 1, what is only read fills up the emptier class
+        (``placement.deal_by_roles``); ``nbytes`` = sizes of the fields when they differ.  Use:
+        ``gt_storage.empty(shape, dtype, backend="hip:mi300", memory_class=hint["out"])``.  A hint, not a contract: results never
+        depend on where a field lives."""
+        from ..storage.placement import deal_by_roles
+
+        return deal_by_roles((name, bool(info.access & AccessKind.WRITE), (nbytes or {}).get(name, 1))
+                             for name, info in self.field_info.items() if info is not None and info.access != AccessKind.NONE)
 
     def freeze(self, *, origin: Dict[str, Tuple[int, ...]], domain: Tuple[int, ...]) -> FrozenStencil:
         """Fixed-origin/domain wrapper that skips all per-call checks (stencil_object.py:614-643)."""

@@ -40,6 +40,22 @@ inline int memory_write_probe(void* a, void* b, size_t bytes, int iterations, hi
     if (a == nullptr || gbs == nullptr) return fail(GT4MI_ERR_INVALID_ARGUMENT, "memory_write_probe: null pointer");
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 8 != 0)
         return fail(GT4MI_ERR_INVALID_ARGUMENT, "memory_write_probe: buffers must be 8-byte aligned");
+    // both buffers must live on the device the stream (= the current device: one process per GPU, one placer per device) belongs
+    // to: a kernel launched on device A that writes memory of device B faults unless peer access happens to be enabled
+    {
+        int current = -1;
+        GT4MI_HIP_CHECK(hipGetDevice(&current));
+        for (void* p : {a, b}) {
+            if (p == nullptr) continue;
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(GT4MI_ERR_INVALID_ARGUMENT, "memory_write_probe: %p is not a device allocation", p);
+            }
+            if (attr.device != current)
+                return fail(GT4MI_ERR_INVALID_ARGUMENT, "memory_write_probe: buffer %p lives on device %d, the current device is %d", p, attr.device, current);
+        }
+    }
     const int64_t levels = (int64_t)(bytes / (PROBE_PLANE * sizeof(double)));
     // (a launch writes the span of one or two buffers front to back, launch after launch: once the span exceeds the 256 MB Infinity
     // Cache every write evicts a dirty line and the memory sees all of it; 24 planes = 192 MiB per buffer is the floor for a PAIR)

@@ -94,9 +94,14 @@ def normalize_storage_spec(aligned_index, shape, dtype, dimensions):
 
 
 def empty(shape: Sequence[int], dtype=np.float64, *, backend: str,
-          aligned_index: Optional[Sequence[int]] = None, dimensions: Optional[Sequence[str]] = None):
+          aligned_index: Optional[Sequence[int]] = None, dimensions: Optional[Sequence[str]] = None,
+          memory_class: Optional[int] = None):
     """Uninitialised array with the optimal strides/alignment for ``backend``
-    (interface.py:40-102 of the reference)."""
+    (interface.py:40-102 of the reference).
+
+    ``memory_class`` (0 / 1 / None; an extension, device presets only): the memory class a big field should live in, as
+    ``stencil.placement_hint()`` suggests it from what the stencil does with the field (``placement.py``); None leaves the
+    choice to the allocator's balance of live bytes."""
     _error_on_invalid_preset(backend)
     info = layout_registry.from_name(backend)
     allocate = allocators.allocate_gpu if info["device"] == "gpu" else allocators.allocate_cpu
@@ -107,36 +112,47 @@ def empty(shape: Sequence[int], dtype=np.float64, *, backend: str,
     # `alignment` items of the array's dtype, interface.py:95-100)
     alignment_bytes = info.get("alignment_bytes") or info["alignment"] * dtype.itemsize
     alignment_bytes = -(-int(alignment_bytes) // dtype.itemsize) * dtype.itemsize
-    _, array = allocate(shape, layout_map, dtype, alignment_bytes, aligned_index)
+    if memory_class is not None and info["device"] == "gpu":
+        if memory_class not in (0, 1):
+            raise ValueError(f"memory_class must be 0, 1 or None, not {memory_class!r}")
+        from . import placement
+
+        with placement.want(int(memory_class)):
+            _, array = allocate(shape, layout_map, dtype, alignment_bytes, aligned_index)
+    else:
+        _, array = allocate(shape, layout_map, dtype, alignment_bytes, aligned_index)
     return array
 
 
 def full(shape: Sequence[int], fill_value, dtype=np.float64, *, backend: str,
-         aligned_index: Optional[Sequence[int]] = None, dimensions: Optional[Sequence[str]] = None):
+         aligned_index: Optional[Sequence[int]] = None, dimensions: Optional[Sequence[str]] = None,
+         memory_class: Optional[int] = None):
     storage = empty(shape=shape, dtype=dtype, backend=backend, aligned_index=aligned_index,
-                    dimensions=dimensions)
+                    dimensions=dimensions, memory_class=memory_class)
     storage[...] = fill_value
     return storage
 
 
 def ones(shape: Sequence[int], dtype=np.float64, *, backend: str,
-         aligned_index: Optional[Sequence[int]] = None, dimensions: Optional[Sequence[str]] = None):
+         aligned_index: Optional[Sequence[int]] = None, dimensions: Optional[Sequence[str]] = None,
+         memory_class: Optional[int] = None):
     storage = empty(shape=shape, dtype=dtype, backend=backend, aligned_index=aligned_index,
-                    dimensions=dimensions)
+                    dimensions=dimensions, memory_class=memory_class)
     storage[...] = storage.dtype.type(1)
     return storage
 
 
 def zeros(shape: Sequence[int], dtype=np.float64, *, backend: str,
-          aligned_index: Optional[Sequence[int]] = None, dimensions: Optional[Sequence[str]] = None):
+          aligned_index: Optional[Sequence[int]] = None, dimensions: Optional[Sequence[str]] = None,
+         memory_class: Optional[int] = None):
     storage = empty(shape=shape, dtype=dtype, backend=backend, aligned_index=aligned_index,
-                    dimensions=dimensions)
+                    dimensions=dimensions, memory_class=memory_class)
     storage[...] = storage.dtype.type(0)
     return storage
 
 
 def from_array(data, dtype=np.float64, *, backend: str, aligned_index: Optional[Sequence[int]] = None,
-               dimensions: Optional[Sequence[str]] = None):
+               dimensions: Optional[Sequence[str]] = None, memory_class: Optional[int] = None):
     """Copy ``data`` into a new optimally laid-out array (interface.py:264-327)."""
     host = asnumpy(data) if isinstance(data, DeviceArray) else np.asarray(data)
     shape = host.shape
@@ -148,7 +164,7 @@ def from_array(data, dtype=np.float64, *, backend: str, aligned_index: Optional[
             raise ValueError(f"Incompatible data shape {shape} with dtype of shape {dtype.shape}.")
         shape = shape[: -dtype.ndim]
     storage = empty(shape=shape, dtype=dtype, backend=backend, aligned_index=aligned_index,
-                    dimensions=dimensions)
+                    dimensions=dimensions, memory_class=memory_class)
     base = dtype.base if dtype.shape else dtype
     storage[...] = host.astype(base, copy=False)
     return storage

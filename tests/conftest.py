@@ -14,6 +14,7 @@ if TESTS not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
     config.addinivalue_line("markers", "multiprocess: starts processes of its own (ranks, bench.py, torchrun): collected LAST")
+    config.addinivalue_line("markers", "perf: holds a wall-clock comparison; the ordering is asserted only under GT4MI_PERF_ASSERT=1")
 
 
 def pytest_sessionstart(session):

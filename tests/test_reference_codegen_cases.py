@@ -30,6 +30,11 @@ def backend(request):
     return request.param
 
 
+def on(backend, **options):
+    """``@on(backend)``: build the definition below it for ``backend`` (``gtscript.stencil`` as a decorator)."""
+    return gtscript.stencil(backend=backend, **options)
+
+
 def host(a):
     return gt_storage.asnumpy(a) if not isinstance(a, np.ndarray) else a
 
@@ -68,20 +73,20 @@ def mk(backend):
 # ---- :74-147 ----------------------------------------------------------------------------------------
 def test_lazy_stencil(backend):
     @gtscript.lazy_stencil(backend=backend)
-    def definition(field_a: Field[F8], field_b: Field[F8]):
+    def definition(phi_a: Field[F8], phi_b: Field[F8]):
         with computation(PARALLEL), interval(...):
-            field_a[0, 0, 0] = field_b
+            phi_a[0, 0, 0] = phi_b
 
 
 def test_temporary_declared_in_if(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def definition(field_a: Field[F8]):
+    @on(backend)
+    def definition(phi_a: Field[F8]):
         with computation(PARALLEL), interval(...):
-            if field_a < 0:
-                field_b = -field_a
+            if phi_a < 0:
+                phi_b = -phi_a
             else:
-                field_b = field_a
-            field_a = field_b
+                phi_b = phi_a
+            phi_a = phi_b
 
     a = mk.array(np.linspace(-3, 3, 24).reshape(2, 3, 4))
     definition(a)
@@ -89,8 +94,8 @@ def test_temporary_declared_in_if(backend, mk):
 
 
 def test_stage_and_stencil_without_effect(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stage_only(field_a: Field[F8]):
+    @on(backend)
+    def stage_only(phi_a: Field[F8]):
         with computation(PARALLEL), interval(...):
             field_c = 0.0  # noqa: F841
 
@@ -99,7 +104,7 @@ def test_stage_and_stencil_without_effect(backend, mk):
 
         with computation(PARALLEL), interval(...):
             if __INLINED(flag):
-                B = f_in  # noqa: F841
+                lower = f_in  # noqa: F841
 
     off = gtscript.stencil(backend, switched_off, externals={"flag": False})
     f = mk.ones((23, 23, 23))
@@ -111,18 +116,18 @@ def test_stage_and_stencil_without_effect(backend, mk):
 
 # ---- :150-175 ---------------------------------------------------------------------------------------
 def test_interval_blocks_keep_their_order(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(field_in: Field[F8], field_out: Field[F8]):
+    @on(backend)
+    def stencil(u_old: Field[F8], u_new: Field[F8]):
         with computation(BACKWARD):
             with interval(-2, -1):
-                field_out = field_in
+                u_new = u_old
             with interval(0, -2):
-                field_out = field_in
+                u_new = u_old
         with computation(BACKWARD):
             with interval(-1, None):
-                field_out = 2 * field_in
+                u_new = 2 * u_old
             with interval(0, -1):
-                field_out[0, 0, 0] = 3 * field_in
+                u_new[0, 0, 0] = 3 * u_old
 
     fin, fout = mk.ones((23, 23, 23)), mk.zeros((23, 23, 23))
     stencil(fin, fout)
@@ -131,18 +136,18 @@ def test_interval_blocks_keep_their_order(backend, mk):
 
 # ---- :178-313 ---------------------------------------------------------------------------------------
 def test_lower_dimensional_inputs(backend, mk):
-    @gtscript.stencil(backend=backend)
+    @on(backend)
     def stencil(field_3d: Field[IJK, F8], field_2d: Field[IJ, F8], field_1d: Field[K, F8]):
         with computation(PARALLEL):
             with interval(0, -1):
-                tmp = field_2d + field_1d[1]
+                work = field_2d + field_1d[1]
             with interval(-1, None):
-                tmp = field_2d + field_1d[0]
+                work = field_2d + field_1d[0]
         with computation(PARALLEL):
             with interval(0, 1):
-                field_3d = tmp[1, 0, 0] + field_1d[1]
+                field_3d = work[1, 0, 0] + field_1d[1]
             with interval(1, None):
-                field_3d[0, 0, 0] = tmp[-1, 0, 0]
+                field_3d[0, 0, 0] = work[-1, 0, 0]
 
     f3 = mk.zeros((6, 6, 6), aligned_index=(1, 1, 0))
     f2 = mk.zeros((6, 6), aligned_index=(1, 1), dimensions="IJ")
@@ -155,78 +160,78 @@ def test_lower_dimensional_inputs(backend, mk):
 
 
 def test_lower_dimensional_masked(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def parallel(cond: Field[IJK, F8], inp: Field[IJ, F8], outp: Field[IJK, F8]):
+    @on(backend)
+    def parallel(flagged: Field[IJK, F8], fed: Field[IJ, F8], result: Field[IJK, F8]):
         with computation(PARALLEL), interval(...):
-            if cond > 0.0:
-                outp[0, 0, 0] = inp
+            if flagged > 0.0:
+                result[0, 0, 0] = fed
 
-    @gtscript.stencil(backend=backend)
-    def forward(cond: Field[IJK, F8], inp: Field[IJ, F8], outp: Field[IJK, F8]):
+    @on(backend)
+    def forward(flagged: Field[IJK, F8], fed: Field[IJ, F8], result: Field[IJK, F8]):
         with computation(FORWARD), interval(...):
-            if cond > 0.0:
-                outp[0, 0, 0] = inp
+            if flagged > 0.0:
+                result[0, 0, 0] = fed
 
     rng = np.random.default_rng(1337)
-    inp, outp, cond = rng.standard_normal((10, 10)), rng.standard_normal((10, 10, 10)), rng.standard_normal((10, 10, 10))
+    fed, result, flagged = rng.standard_normal((10, 10)), rng.standard_normal((10, 10, 10)), rng.standard_normal((10, 10, 10))
     for copy_2to3 in (parallel, forward):
-        out_f = mk.array(outp)
-        copy_2to3(mk.array(cond), mk.array(inp, dimensions="IJ"), out_f)
-        np.testing.assert_array_equal(host(out_f), np.where(cond > 0.0, inp[:, :, None], outp))
+        out_f = mk.array(result)
+        copy_2to3(mk.array(flagged), mk.array(fed, dimensions="IJ"), out_f)
+        np.testing.assert_array_equal(host(out_f), np.where(flagged > 0.0, fed[:, :, None], result))
 
 
 def test_lower_dimensional_2d_to_3d_forward(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def copy_2to3(inp: Field[IJ, F8], outp: Field[IJK, F8]):
+    @on(backend)
+    def copy_2to3(fed: Field[IJ, F8], result: Field[IJK, F8]):
         with computation(FORWARD), interval(...):
-            outp[0, 0, 0] = inp
+            result[0, 0, 0] = fed
 
     rng = np.random.default_rng(7)
-    inp = rng.standard_normal((10, 10))
+    fed = rng.standard_normal((10, 10))
     out_f = mk.array(rng.standard_normal((10, 10, 10)))
-    copy_2to3(mk.array(inp, dimensions="IJ"), out_f)
-    np.testing.assert_array_equal(host(out_f), np.broadcast_to(inp[:, :, None], (10, 10, 10)))
+    copy_2to3(mk.array(fed, dimensions="IJ"), out_f)
+    np.testing.assert_array_equal(host(out_f), np.broadcast_to(fed[:, :, None], (10, 10, 10)))
 
 
 # ---- :316-368 ---------------------------------------------------------------------------------------
 def test_higher_dimensional_fields(backend, mk):
     VEC2, MAT22 = (F8, (2,)), (F8, (2, 2))
 
-    @gtscript.stencil(backend=backend)
-    def stencil(field: Field[F8], vec_field: Field[VEC2], mat_field: Field[MAT22]):
+    @on(backend)
+    def stencil(phi: Field[F8], vector: Field[VEC2], mat_field: Field[MAT22]):
         with computation(PARALLEL), interval(...):
-            tmp = vec_field[0, 0, 0][0] + vec_field[0, 0, 0][1]  # noqa: F841
+            work = vector[0, 0, 0][0] + vector[0, 0, 0][1]  # noqa: F841
         with computation(FORWARD):
             with interval(0, 1):
-                vec_field[0, 0, 0][0] = field[1, 0, 0]
-                vec_field[0, 0, 0][1] = field[0, 1, 0]
+                vector[0, 0, 0][0] = phi[1, 0, 0]
+                vector[0, 0, 0][1] = phi[0, 1, 0]
             with interval(1, -1):
-                vec_field[0, 0, 0][0] = 2 * field[1, 0, -1]
-                vec_field[0, 0, 0][1] = 2 * field[0, 1, -1]
+                vector[0, 0, 0][0] = 2 * phi[1, 0, -1]
+                vector[0, 0, 0][1] = 2 * phi[0, 1, -1]
             with interval(-1, None):
-                vec_field[0, 0, 0][0] = field[1, 0, 0]
-                vec_field[0, 0, 0][1] = field[0, 1, 0]
+                vector[0, 0, 0][0] = phi[1, 0, 0]
+                vector[0, 0, 0][1] = phi[0, 1, 0]
         with computation(PARALLEL), interval(...):
-            mat_field[0, 0, 0][0, 0] = vec_field[0, 0, 0][0] + 1.0
-            mat_field[0, 0, 0][1, 1] = vec_field[0, 0, 0][1] + 1.0
+            mat_field[0, 0, 0][0, 0] = vector[0, 0, 0][0] + 1.0
+            mat_field[0, 0, 0][1, 1] = vector[0, 0, 0][1] + 1.0
 
-    field = mk.ones((6, 6, 6), aligned_index=(1, 1, 0))
+    phi = mk.ones((6, 6, 6), aligned_index=(1, 1, 0))
     vec = mk.full((6, 6, 6), 2.0, VEC2, aligned_index=(1, 1, 0))
     mat = mk.ones((6, 6, 6), MAT22, aligned_index=(1, 1, 0))
     assert vec.shape == (6, 6, 6, 2) and mat.shape == (6, 6, 6, 2, 2)
-    stencil(field, vec, mat, origin=(1, 1, 0), domain=(4, 4, 6))
+    stencil(phi, vec, mat, origin=(1, 1, 0), domain=(4, 4, 6))
     v, m = host(vec), host(mat)
     assert (v[1:-1, 1:-1, 0] == 1).all() and (v[1:-1, 1:-1, 1:-1] == 2).all() and (v[1:-1, 1:-1, -1] == 1).all()
     assert (m[1:-1, 1:-1, 1:-1, 0, 0] == 3).all() and (m[1:-1, 1:-1, 1:-1, 1, 1] == 3).all()
     assert (m[1:-1, 1:-1, :, 0, 1] == 1).all() and (m[0] == 1).all()
-    stencil(field, vec, mat)
+    stencil(phi, vec, mat)
 
 
 def test_input_order(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(in_field: Field[F8], parameter: F8, out_field: Field[F8]):
+    @on(backend)
+    def stencil(source: Field[F8], parameter: F8, target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field[0, 0, 0] = in_field * parameter
+            target[0, 0, 0] = source * parameter
 
     fout = mk.zeros((23, 23, 23))
     stencil(mk.ones((23, 23, 23)), 3.1415, fout)
@@ -235,16 +240,16 @@ def test_input_order(backend, mk):
 
 # ---- :394-446 ---------------------------------------------------------------------------------------
 def test_variable_offsets(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil_ij(in_field: Field[F8], out_field: Field[F8], index_field: Field[IJ, int]):
+    @on(backend)
+    def stencil_ij(source: Field[F8], target: Field[F8], shift: Field[IJ, int]):
         with computation(FORWARD), interval(...):
-            out_field[0, 0, 0] = in_field[0, 0, 1] + in_field[0, 0, index_field + 1]
-            index_field = index_field + 1
+            target[0, 0, 0] = source[0, 0, 1] + source[0, 0, shift + 1]
+            shift = shift + 1
 
-    @gtscript.stencil(backend=backend)
-    def stencil_ijk(in_field: Field[F8], out_field: Field[F8], index_field: Field[int]):
+    @on(backend)
+    def stencil_ijk(source: Field[F8], target: Field[F8], shift: Field[int]):
         with computation(PARALLEL), interval(...):
-            out_field[0, 0, 0] = in_field[0, 0, 1] + in_field[0, 0, index_field + 1]
+            target[0, 0, 0] = source[0, 0, 1] + source[0, 0, shift + 1]
 
     data = np.arange(3 * 2 * 8, dtype=F8).reshape(3, 2, 8)
     out = mk.zeros((3, 2, 8))
@@ -260,36 +265,36 @@ def test_variable_offsets(backend, mk):
 
 
 def test_variable_offsets_and_while_loop(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(pe1: Field[F8], pe2: Field[F8], qin: Field[F8], qout: Field[F8], lev: Field[IJ, np.int_]):
+    @on(backend)
+    def stencil(edge_from: Field[F8], edge_to: Field[F8], q_from: Field[F8], q_to: Field[F8], lvl: Field[IJ, np.int_]):
         with computation(FORWARD), interval(0, -1):
-            if pe2[0, 0, 1] <= pe1[0, 0, lev]:
-                qout = qin[0, 0, 1]
+            if edge_to[0, 0, 1] <= edge_from[0, 0, lvl]:
+                q_to = q_from[0, 0, 1]
             else:
-                qsum = pe1[0, 0, lev + 1] - pe2[0, 0, lev]
-                while pe1[0, 0, lev + 1] < pe2[0, 0, 1]:
-                    qsum += qin[0, 0, lev] / (pe2[0, 0, 1] - pe1[0, 0, lev])
-                    lev = lev + 1
-                qout[0, 0, 0] = qsum / (pe2[0, 0, 1] - pe2)
+                qsum = edge_from[0, 0, lvl + 1] - edge_to[0, 0, lvl]
+                while edge_from[0, 0, lvl + 1] < edge_to[0, 0, 1]:
+                    qsum += q_from[0, 0, lvl] / (edge_to[0, 0, 1] - edge_from[0, 0, lvl])
+                    lvl = lvl + 1
+                q_to[0, 0, 0] = qsum / (edge_to[0, 0, 1] - edge_to)
 
-    # pe2[k+1] <= pe1[k + lev] everywhere: only the first branch runs
+    # edge_to[k+1] <= edge_from[k + lvl] everywhere: only the first branch runs
     shape = (2, 2, 5)
-    pe1, pe2 = mk.full(shape, 10.0), mk.full(shape, 1.0)
-    qin = mk.array(np.arange(20, dtype=F8).reshape(shape))
-    qout = mk.zeros(shape)
-    stencil(pe1, pe2, qin, qout, mk.zeros((2, 2), np.int_, dimensions="IJ"))
-    np.testing.assert_array_equal(host(qout)[:, :, :-1], host(qin)[:, :, 1:])
+    edge_from, edge_to = mk.full(shape, 10.0), mk.full(shape, 1.0)
+    q_from = mk.array(np.arange(20, dtype=F8).reshape(shape))
+    q_to = mk.zeros(shape)
+    stencil(edge_from, edge_to, q_from, q_to, mk.zeros((2, 2), np.int_, dimensions="IJ"))
+    np.testing.assert_array_equal(host(q_to)[:, :, :-1], host(q_from)[:, :, 1:])
 
 
 def test_nested_while_loop(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(field_a: Field[F8], field_b: Field[np.int_]):
+    @on(backend)
+    def stencil(phi_a: Field[F8], phi_b: Field[np.int_]):
         with computation(PARALLEL), interval(...):
-            while field_a < 1:
+            while phi_a < 1:
                 add = 0
-                while field_a + field_b < 1:
+                while phi_a + phi_b < 1:
                     add += 1
-                field_a += add
+                phi_a += add
 
     # the inner loop never runs for b = 2; a >= 1 never enters
     a = mk.array(np.array([1.0, 2.0, 5.0, 7.0]).reshape(1, 1, 4))
@@ -299,29 +304,29 @@ def test_nested_while_loop(backend, mk):
 
 # ---- :449-517 ---------------------------------------------------------------------------------------
 def test_mask_with_offset_written_in_conditional(backend, mk):
-    @gtscript.stencil(backend)
-    def stencil(outp: Field[F8]):
+    @on(backend)
+    def stencil(result: Field[F8]):
         with computation(PARALLEL), interval(...):
-            cond = True
-            if cond[0, -1, 0] or cond[0, 0, 0]:
-                outp = 1.0
+            flagged = True
+            if flagged[0, -1, 0] or flagged[0, 0, 0]:
+                result = 1.0
             else:
-                outp[0, 0, 0] = 0.0
+                result[0, 0, 0] = 0.0
 
-    outp = mk.zeros((10, 10, 10))
-    stencil(outp)
-    assert (host(outp) == 1.0).all()
+    result = mk.zeros((10, 10, 10))
+    stencil(result)
+    assert (host(result) == 1.0).all()
 
 
 def test_data_dim_indirect_addressing(backend, mk):
     VEC2 = (np.int32, (2,))
 
-    @gtscript.stencil(backend=backend)
+    @on(backend)
     def write(input_field: Field[IJK, np.int32], output_field: Field[IJK, VEC2], index: int):
         with computation(PARALLEL), interval(...):
             output_field[0, 0, 0][index] = input_field
 
-    @gtscript.stencil(backend=backend)
+    @on(backend)
     def read(input_field: Field[IJK, VEC2], output_field: Field[IJK, np.int32], index: int):
         with computation(PARALLEL), interval(...):
             output_field[0, 0, 0] = input_field[0, 0, 0][index]
@@ -337,12 +342,12 @@ def test_data_dim_indirect_addressing(backend, mk):
 
 # ---- :520-586 ---------------------------------------------------------------------------------------
 def test_negative_origin(backend, mk):
-    @gtscript.stencil(backend=backend)
+    @on(backend)
     def stencil_i(input_field: Field[IJK, np.int32], output_field: Field[IJK, np.int32]):
         with computation(PARALLEL), interval(...):
             output_field[0, 0, 0] = input_field[1, 0, 0]
 
-    @gtscript.stencil(backend=backend)
+    @on(backend)
     def stencil_k(input_field: Field[IJK, np.int32], output_field: Field[IJK, np.int32]):
         with computation(PARALLEL), interval(...):
             output_field[0, 0, 0] = input_field[0, 0, 1]
@@ -355,29 +360,29 @@ def test_negative_origin(backend, mk):
 
 def test_origin_k_fields(backend, mk):
     @gtscript.stencil(backend=backend, rebuild=True)
-    def k_to_ijk(outp: Field[F8], inp: Field[K, F8]):
+    def k_to_ijk(result: Field[F8], fed: Field[K, F8]):
         with computation(PARALLEL), interval(...):
-            outp[0, 0, 0] = inp
+            result[0, 0, 0] = fed
 
     data = np.arange(10, dtype=F8)
-    inp, outp = mk.array(data, dimensions="K"), mk.zeros((2, 2, 10))
-    k_to_ijk(outp, inp, origin={"outp": (0, 0, 1), "inp": (2,)}, domain=(2, 2, 8))
-    res = host(outp)
-    np.testing.assert_array_equal(host(inp), data)
+    fed, result = mk.array(data, dimensions="K"), mk.zeros((2, 2, 10))
+    k_to_ijk(result, fed, origin={"result": (0, 0, 1), "fed": (2,)}, domain=(2, 2, 8))
+    res = host(result)
+    np.testing.assert_array_equal(host(fed), data)
     np.testing.assert_array_equal(res[:, :, 1:-1], np.broadcast_to(data[2:], (2, 2, 8)))
     assert (res[:, :, 0] == 0).all() and (res[:, :, -1] == 0).all()
 
 
 # ---- :589-677 ---------------------------------------------------------------------------------------
 def test_tmp_stencil(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(field_in: Field[F8], field_out: Field[F8]):
+    @on(backend)
+    def stencil(u_old: Field[F8], u_new: Field[F8]):
         with computation(PARALLEL):
             with interval(...):
-                tmp = field_in + 1
+                work = u_old + 1
         with computation(PARALLEL):
             with interval(...):
-                field_out[0, 0, 0] = tmp[-1, 0, 0] + tmp[1, 0, 0]
+                u_new[0, 0, 0] = work[-1, 0, 0] + work[1, 0, 0]
 
     fout = mk.zeros((6, 6, 6))
     stencil(mk.ones((6, 6, 6)), fout, origin=(1, 1, 0), domain=(4, 4, 6))
@@ -387,15 +392,15 @@ def test_tmp_stencil(backend, mk):
 
 
 def test_backward_stencil(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(field_in: Field[F8], field_out: Field[F8]):
+    @on(backend)
+    def stencil(u_old: Field[F8], u_new: Field[F8]):
         with computation(BACKWARD):
             with interval(-1, None):
-                field_in = 2
-                field_out = field_in
+                u_old = 2
+                u_new = u_old
             with interval(0, -1):
-                field_in = field_in[0, 0, 1] + 1
-                field_out[0, 0, 0] = field_in
+                u_old = u_old[0, 0, 1] + 1
+                u_new[0, 0, 0] = u_old
 
     fout = mk.zeros((4, 4, 4))
     stencil(mk.ones((4, 4, 4)), fout)
@@ -403,13 +408,13 @@ def test_backward_stencil(backend, mk):
 
 
 def test_while_stencil(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(field_in: Field[F8], field_out: Field[F8]):
+    @on(backend)
+    def stencil(u_old: Field[F8], u_new: Field[F8]):
         with computation(PARALLEL):
             with interval(...):
-                while field_in < 10:
-                    field_in += 1
-                field_out[0, 0, 0] = field_in
+                while u_old < 10:
+                    u_old += 1
+                u_new[0, 0, 0] = u_old
 
     fout = mk.zeros((6, 6, 6))
     stencil(mk.ones((6, 6, 6)), fout)
@@ -420,15 +425,15 @@ def test_while_stencil(backend, mk):
 def test_higher_dim_literal_and_scalar_index(backend, mk):
     VEC4 = (F8, (4,))
 
-    @gtscript.stencil(backend=backend)
-    def literal(vec_field: Field[VEC4], out_field: Field[F8]):
+    @on(backend)
+    def literal(vector: Field[VEC4], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field[0, 0, 0] = vec_field[0, 0, 0][2]
+            target[0, 0, 0] = vector[0, 0, 0][2]
 
-    @gtscript.stencil(backend=backend)
-    def scalar(vec_field: Field[VEC4], out_field: Field[F8], scalar_argument: int):
+    @on(backend)
+    def scalar(vector: Field[VEC4], target: Field[F8], scalar_argument: int):
         with computation(PARALLEL), interval(...):
-            out_field[0, 0, 0] = vec_field[0, 0, 0][scalar_argument]
+            target[0, 0, 0] = vector[0, 0, 0][scalar_argument]
 
     data = np.ones((6, 6, 6, 4))
     data[..., 2] = 5
@@ -439,10 +444,10 @@ def test_higher_dim_literal_and_scalar_index(backend, mk):
 
 
 def test_data_dims_declared_with_numpy_ints(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(out_field: Field[IJK, np.int32], in_field: Field[IJK, (np.int32, (np.int32(3)))]):
+    @on(backend)
+    def stencil(target: Field[IJK, np.int32], source: Field[IJK, (np.int32, (np.int32(3)))]):
         with computation(PARALLEL), interval(...):
-            out_field = in_field.A[0]
+            target = source.A[0]
 
     out = mk.zeros((2, 2, 4), np.int32)
     stencil(out, mk.ones((2, 2, 4), (np.int32, (np.int32(3)))))
@@ -451,10 +456,10 @@ def test_data_dims_declared_with_numpy_ints(backend, mk):
 
 # ---- :753-951 ---------------------------------------------------------------------------------------
 def test_native_function_call(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(in_field: Field[F8], out_field: Field[F8]):
+    @on(backend)
+    def stencil(source: Field[F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field[0, 0, 0] = in_field[0, 0, 0] + sin(0.848062)
+            target[0, 0, 0] = source[0, 0, 0] + sin(0.848062)
 
     out = mk.zeros((4, 4, 4))
     stencil(mk.ones((4, 4, 4)), out)
@@ -463,23 +468,23 @@ def test_native_function_call(backend, mk):
 
 
 def test_unary_ternary_and_mask(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def unary(in_field: Field[F8], out_field: Field[F8]):
+    @on(backend)
+    def unary(source: Field[F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field[0, 0, 0] = -in_field[0, 0, 0]
+            target[0, 0, 0] = -source[0, 0, 0]
 
-    @gtscript.stencil(backend=backend)
-    def ternary(in_field: Field[F8], out_field: Field[F8]):
+    @on(backend)
+    def ternary(source: Field[F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field[0, 0, 0] = in_field[0, 0, 0] if in_field > 10 else in_field[0, 0, 0] + 1
+            target[0, 0, 0] = source[0, 0, 0] if source > 10 else source[0, 0, 0] + 1
 
-    @gtscript.stencil(backend=backend)
-    def mask(in_field: Field[F8], out_field: Field[F8]):
+    @on(backend)
+    def mask(source: Field[F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            if in_field[0, 0, 0] > 0:
-                out_field[0, 0, 0] = in_field
+            if source[0, 0, 0] > 0:
+                target[0, 0, 0] = source
             else:
-                out_field[0, 0, 0] = 1
+                target[0, 0, 0] = 1
 
     out = mk.zeros((4, 4, 4))
     unary(mk.ones((4, 4, 4)), out)
@@ -496,15 +501,15 @@ def test_unary_ternary_and_mask(backend, mk):
 
 
 def test_k_offset_from_scalar_and_field(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def by_scalar(in_field: Field[F8], out_field: Field[F8], scalar_value: int):
+    @on(backend)
+    def by_scalar(source: Field[F8], target: Field[F8], scalar_value: int):
         with computation(PARALLEL), interval(1, None):
-            out_field[0, 0, 0] = in_field[0, 0, scalar_value]
+            target[0, 0, 0] = source[0, 0, scalar_value]
 
-    @gtscript.stencil(backend=backend)
-    def by_field(in_field: Field[F8], out_field: Field[F8], idx_field: Field[IJ, np.int64]):
+    @on(backend)
+    def by_field(source: Field[F8], target: Field[F8], idx_field: Field[IJ, np.int64]):
         with computation(PARALLEL), interval(1, None):
-            out_field[0, 0, 0] = in_field[0, 0, idx_field + 1]
+            target[0, 0, 0] = source[0, 0, idx_field + 1]
 
     data = np.ones((4, 4, 4))
     data[:, :, 0] = 10
@@ -517,21 +522,21 @@ def test_k_offset_from_scalar_and_field(backend, mk):
 
 
 def test_k_only_and_table_access(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def k_only(in_field: Field[K, F8], out_field: Field[F8]):
+    @on(backend)
+    def k_only(source: Field[K, F8], target: Field[F8]):
         with computation(PARALLEL):
             with interval(0, 1):
-                out_field[0, 0, 0] = in_field[1]
+                target[0, 0, 0] = source[1]
             with interval(1, None):
-                out_field[0, 0, 0] = in_field[-1]
+                target[0, 0, 0] = source[-1]
 
-    @gtscript.stencil(backend=backend)
-    def table(table_view: GlobalTable[(F8, (4))], out_field: Field[F8]):
+    @on(backend)
+    def table(table_view: GlobalTable[(F8, (4))], target: Field[F8]):
         with computation(PARALLEL):
             with interval(0, 1):
-                out_field[0, 0, 0] = table_view.A[1]
+                target[0, 0, 0] = table_view.A[1]
             with interval(1, None):
-                out_field[0, 0, 0] = table_view.A[2]
+                target[0, 0, 0] = table_view.A[2]
 
     out = mk.zeros((4, 4, 4))
     k_only(mk.array(np.array([2.0, 3.0, 4.0, 5.0]), dimensions="K"), out)
@@ -544,10 +549,10 @@ def test_k_only_and_table_access(backend, mk):
 def test_direct_datadims_index(backend, mk):
     VEC4 = (F8, (2, 2, 2, 2))
 
-    @gtscript.stencil(backend=backend)
-    def stencil(out: Field[F8], inp: GlobalTable[VEC4]):
+    @on(backend)
+    def stencil(out: Field[F8], fed: GlobalTable[VEC4]):
         with computation(PARALLEL), interval(...):
-            out[0, 0, 0] = inp.A[1, 0, 1, 0]
+            out[0, 0, 0] = fed.A[1, 0, 1, 0]
 
     data = np.ones((2, 2, 2, 2))
     data[1, 0, 1, 0] = 42
@@ -557,12 +562,12 @@ def test_direct_datadims_index(backend, mk):
 
 
 def test_pruned_args_match(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(out: Field[F8], inp: Field[F8]):
+    @on(backend)
+    def stencil(out: Field[F8], fed: Field[F8]):
         with computation(PARALLEL), interval(...):
             out = 0.0
             with horizontal(region[I[0] - 1, J[0] - 1]):
-                out[0, 0, 0] = inp
+                out[0, 0, 0] = fed
 
     out = mk.ones((2, 2, 2))
     stencil(out, mk.zeros((2, 2, 2)))
@@ -574,10 +579,10 @@ KV = np.arange(40.0, 44.0)
 
 
 def test_k_offset_write_simple(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def simple(A: Field[F8], B: Field[F8]):
+    @on(backend)
+    def simple(upper: Field[F8], lower: Field[F8]):
         with computation(FORWARD), interval(...):
-            B[0, 0, 1] = A
+            lower[0, 0, 1] = upper
 
     a, b = mk.array(KV.reshape(1, 1, 4)), mk.zeros((1, 1, 4))
     simple(a, b, domain=(1, 1, 3))
@@ -585,11 +590,11 @@ def test_k_offset_write_simple(backend, mk):
 
 
 def test_k_offset_write_forward(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def forward(A: Field[F8], B: Field[F8], scalar: F8):
+    @on(backend)
+    def forward(upper: Field[F8], lower: Field[F8], scalar: F8):
         with computation(FORWARD), interval(1, None):
-            A[0, 0, -1] = scalar
-            B[0, 0, 0] = A
+            upper[0, 0, -1] = scalar
+            lower[0, 0, 0] = upper
 
     a, b = mk.array(KV.reshape(1, 1, 4)), mk.zeros((1, 1, 4))
     forward(a, b, 2.0)
@@ -598,13 +603,13 @@ def test_k_offset_write_forward(backend, mk):
 
 
 def test_k_offset_write_backward(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def backward(A: Field[F8], B: Field[F8], scalar: F8):
+    @on(backend)
+    def backward(upper: Field[F8], lower: Field[F8], scalar: F8):
         with computation(BACKWARD), interval(-1, None):
-            A = scalar
+            upper = scalar
         with computation(BACKWARD), interval(1, None):
-            A[0, 0, -1] = scalar
-            B[0, 0, 0] = A
+            upper[0, 0, -1] = scalar
+            lower[0, 0, 0] = upper
 
     a, b = mk.array(KV.reshape(1, 1, 4)), mk.zeros((1, 1, 4))
     backward(a, b, 2.0)
@@ -613,17 +618,17 @@ def test_k_offset_write_backward(backend, mk):
 
 
 def test_k_offset_write_conditional(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def column_physics(A: Field[F8], B: Field[F8], scalar: F8):
+    @on(backend)
+    def column_physics(upper: Field[F8], lower: Field[F8], scalar: F8):
         with computation(BACKWARD), interval(1, -1):
-            if A > 0 and B > 0:
-                A[0, 0, -1] = scalar
-                B[0, 0, 1] = A
-            lev = 1
-            while A >= 0 and B >= 0:
-                A[0, 0, lev] = -1
-                B = -1
-                lev = lev + 1
+            if upper > 0 and lower > 0:
+                upper[0, 0, -1] = scalar
+                lower[0, 0, 1] = upper
+            lvl = 1
+            while upper >= 0 and lower >= 0:
+                upper[0, 0, lvl] = -1
+                lower = -1
+                lvl = lvl + 1
 
     a, b = mk.array(KV.reshape(1, 1, 4)), mk.ones((1, 1, 4))
     column_physics(a, b, 2.0)
@@ -635,10 +640,10 @@ def test_k_offset_write_conditional(backend, mk):
 def test_variable_k_offset_write(backend, mk):
     """:1651-1669"""
 
-    @gtscript.stencil(backend=backend)
-    def stencil(in_field: Field[F8], index_field: Field[IJ, np.int32], out_field: Field[F8]):
+    @on(backend)
+    def stencil(source: Field[F8], shift: Field[IJ, np.int32], target: Field[F8]):
         with computation(FORWARD), interval(...):
-            out_field[0, 0, index_field - 1] = in_field
+            target[0, 0, shift - 1] = source
 
     rng = np.random.default_rng(3)
     data = rng.standard_normal((5, 5, 5))
@@ -653,13 +658,13 @@ def test_function_inline_in_while(backend, mk):
     def add_42(v):
         return v + 42
 
-    @gtscript.stencil(backend=backend)
-    def stencil(in_field: Field[F8], out_field: Field[F8]):
+    @on(backend)
+    def stencil(source: Field[F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
             count = 1
             while count < 10:
-                sa = add_42(out_field)
-                out_field = in_field + sa
+                sa = add_42(target)
+                target = source + sa
                 count = count + 1
 
     out = mk.ones((5, 5, 2))
@@ -668,10 +673,10 @@ def test_function_inline_in_while(backend, mk):
 
 
 def test_cast_in_index(backend, mk):
-    @gtscript.stencil(backend)
-    def cast_in_index(in_field: Field[F8], i32: np.int32, i64: np.int64, out_field: Field[F8]):
+    @on(backend)
+    def cast_in_index(source: Field[F8], i32: np.int32, i64: np.int64, target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field[0, 0, 0] = in_field[0, 0, i32 - i64]
+            target[0, 0, 0] = source[0, 0, i32 - i64]
 
     data = np.arange(8.0).reshape(1, 1, 8)
     out = mk.zeros((1, 1, 8))
@@ -680,72 +685,72 @@ def test_cast_in_index(backend, mk):
 
 
 def test_read_after_write_stencil_builds(backend):
-    @gtscript.stencil(backend=backend)
-    def lagrangian_contributions(q: Field[F8], pe1: Field[F8], pe2: Field[F8], q4_1: Field[F8], q4_2: Field[F8],
-                                 q4_3: Field[F8], q4_4: Field[F8], dp1: Field[F8], lev: Field[IJ, np.int64]):
+    @on(backend)
+    def lagrangian_contributions(q: Field[F8], edge_from: Field[F8], edge_to: Field[F8], q4_1: Field[F8], q4_2: Field[F8],
+                                 q4_3: Field[F8], q4_4: Field[F8], dp1: Field[F8], lvl: Field[IJ, np.int64]):
         with computation(FORWARD), interval(...):
-            pl = (pe2 - pe1[0, 0, lev]) / dp1[0, 0, lev]
-            if pe2[0, 0, 1] <= pe1[0, 0, lev + 1]:
-                pr = (pe2[0, 0, 1] - pe1[0, 0, lev]) / dp1[0, 0, lev]
-                q[0, 0, 0] = (q4_2[0, 0, lev] + 0.5 * (q4_4[0, 0, lev] + q4_3[0, 0, lev] - q4_2[0, 0, lev]) * (pr + pl)
-                              - q4_4[0, 0, lev] * 1.0 / 3.0 * (pr * (pr + pl) + pl * pl))
+            pl = (edge_to - edge_from[0, 0, lvl]) / dp1[0, 0, lvl]
+            if edge_to[0, 0, 1] <= edge_from[0, 0, lvl + 1]:
+                pr = (edge_to[0, 0, 1] - edge_from[0, 0, lvl]) / dp1[0, 0, lvl]
+                q[0, 0, 0] = (q4_2[0, 0, lvl] + 0.5 * (q4_4[0, 0, lvl] + q4_3[0, 0, lvl] - q4_2[0, 0, lvl]) * (pr + pl)
+                              - q4_4[0, 0, lvl] * 1.0 / 3.0 * (pr * (pr + pl) + pl * pl))
             else:
-                qsum = (pe1[0, 0, lev + 1] - pe2) * (
-                    q4_2[0, 0, lev] + 0.5 * (q4_4[0, 0, lev] + q4_3[0, 0, lev] - q4_2[0, 0, lev]) * (1.0 + pl)
-                    - q4_4[0, 0, lev] * 1.0 / 3.0 * (1.0 + pl * (1.0 + pl)))
-                lev = lev + 1
-                while pe1[0, 0, lev + 1] < pe2[0, 0, 1]:
-                    qsum += dp1[0, 0, lev] * q4_1[0, 0, lev]
-                    lev = lev + 1
-                dp = pe2[0, 0, 1] - pe1[0, 0, lev]
-                esl = dp / dp1[0, 0, lev]
-                qsum += dp * (q4_2[0, 0, lev] + 0.5 * esl * (q4_3[0, 0, lev] - q4_2[0, 0, lev]
-                                                             + q4_4[0, 0, lev] * (1.0 - (2.0 / 3.0) * esl)))
-                q = qsum / (pe2[0, 0, 1] - pe2)
-            lev = lev - 1
+                qsum = (edge_from[0, 0, lvl + 1] - edge_to) * (
+                    q4_2[0, 0, lvl] + 0.5 * (q4_4[0, 0, lvl] + q4_3[0, 0, lvl] - q4_2[0, 0, lvl]) * (1.0 + pl)
+                    - q4_4[0, 0, lvl] * 1.0 / 3.0 * (1.0 + pl * (1.0 + pl)))
+                lvl = lvl + 1
+                while edge_from[0, 0, lvl + 1] < edge_to[0, 0, 1]:
+                    qsum += dp1[0, 0, lvl] * q4_1[0, 0, lvl]
+                    lvl = lvl + 1
+                dp = edge_to[0, 0, 1] - edge_from[0, 0, lvl]
+                esl = dp / dp1[0, 0, lvl]
+                qsum += dp * (q4_2[0, 0, lvl] + 0.5 * esl * (q4_3[0, 0, lvl] - q4_2[0, 0, lvl]
+                                                             + q4_4[0, 0, lvl] * (1.0 - (2.0 / 3.0) * esl)))
+                q = qsum / (edge_to[0, 0, 1] - edge_to)
+            lvl = lvl - 1
 
 
 # ---- :1278-1391 (absolute K index; reference: debug and dace backends only) ---------------------------
 def test_absolute_k_index(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def literal(in_field: Field[F8], out_field: Field[F8]):
+    @on(backend)
+    def literal(source: Field[F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field = in_field.at(K=2)
+            target = source.at(K=2)
 
-    @gtscript.stencil(backend=backend)
-    def parameter(in_field: Field[F8], out_field: Field[F8], idx: int):
+    @on(backend)
+    def parameter(source: Field[F8], target: Field[F8], idx: int):
         with computation(PARALLEL), interval(...):
-            out_field = in_field.at(K=idx)
+            target = source.at(K=idx)
 
     @gtscript.stencil(backend=backend, externals={"K4": 4})
-    def external(in_field: Field[F8], out_field: Field[F8]):
+    def external(source: Field[F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
             from __externals__ import K4
 
-            out_field = in_field.at(K=K4)
+            target = source.at(K=K4)
 
-    @gtscript.stencil(backend=backend)
-    def from_field(in_field: Field[F8], index_field: Field[IJ, np.int64], out_field: Field[F8]):
+    @on(backend)
+    def from_field(source: Field[F8], shift: Field[IJ, np.int64], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field = in_field.at(K=index_field)
+            target = source.at(K=shift)
 
-    @gtscript.stencil(backend=backend)
-    def computed(in_field: Field[F8], index_field: Field[IJ, np.int32], out_field: Field[F8]):
+    @on(backend)
+    def computed(source: Field[F8], shift: Field[IJ, np.int32], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field = in_field.at(K=index_field - 1)
+            target = source.at(K=shift - 1)
 
-    @gtscript.stencil(backend=backend)
-    def lower_dim(k_field: Field[K, F8], out_field: Field[F8]):
+    @on(backend)
+    def lower_dim(k_field: Field[K, F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
-            out_field = k_field.at(K=2)
+            target = k_field.at(K=2)
 
-    @gtscript.stencil(backend=backend)
-    def conditional(in_field: Field[F8], out_field: Field[F8]):
+    @on(backend)
+    def conditional(source: Field[F8], target: Field[F8]):
         with computation(PARALLEL), interval(...):
             k_level = 0
-            while in_field.at(K=k_level) < 2:
+            while source.at(K=k_level) < 2:
                 k_level += 1
-            out_field[0, 0, 0] = k_level
+            target[0, 0, 0] = k_level
 
     def marked(level, value=42.42):
         data = np.ones((5, 5, 5))
@@ -770,7 +775,7 @@ def test_absolute_k_index(backend, mk):
 
 # ---- :1394-1428 (K as a value; reference: debug, numpy, dace:cpu) --------------------------------------
 def test_iterator_access(backend, mk):
-    @gtscript.stencil(backend=backend)
+    @on(backend)
     def stencil(field_A: Field[F8], field_B: Field[F8], offsets: Field[K, np.int32]):
         with computation(PARALLEL), interval(...):
             if K == 2:
@@ -785,25 +790,25 @@ def test_iterator_access(backend, mk):
 
 # ---- :1582-1637 (2-d temporaries; reference: debug, numpy, dace) ---------------------------------------
 def test_2d_temporaries(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def plain(in_field: Field[F8], out_field: Field[F8]):
+    @on(backend)
+    def plain(source: Field[F8], target: Field[F8]):
         with computation(FORWARD), interval(0, 1):
-            tmp_2D: Field[IJ, F8] = 0
+            sheet: Field[IJ, F8] = 0
         with computation(FORWARD), interval(...):
-            tmp_2D = tmp_2D + in_field
+            sheet = sheet + source
         with computation(FORWARD), interval(...):
-            out_field = tmp_2D
+            target = sheet
 
     out = mk.zeros((5, 5, 3))
     plain(mk.ones((5, 5, 3)), out)
     assert (host(out) == 3).all()
 
     @gtscript.stencil(backend=backend, dtypes={"MyFancySymbol": Field[IJ, F8]})
-    def user_dtype(in_field: Field[F8], out_field: Field[F8]):
+    def user_dtype(source: Field[F8], target: Field[F8]):
         with computation(FORWARD), interval(0, 1):
-            tmp_2D: MyFancySymbol = 0  # noqa: F821
+            sheet: MyFancySymbol = 0  # noqa: F821
         with computation(FORWARD), interval(...):
-            out_field = tmp_2D
+            target = sheet
 
     out = mk.ones((5, 5, 3))
     user_dtype(mk.ones((5, 5, 3)), out)
@@ -813,20 +818,20 @@ def test_2d_temporaries(backend, mk):
 
     with pytest.raises(GTScriptSyntaxError, match="Typed temporaries must be IJ,"):
 
-        @gtscript.stencil(backend=backend)
-        def k_temporary(in_field: Field[F8], out_field: Field[F8]):
+        @on(backend)
+        def k_temporary(source: Field[F8], target: Field[F8]):
             with computation(FORWARD), interval(0, 1):
-                tmp_2D: Field[K, F8] = 0
+                sheet: Field[K, F8] = 0
             with computation(FORWARD), interval(...):
-                out_field = tmp_2D
+                target = sheet
 
 
 # ---- :1672-1690 -------------------------------------------------------------------------------------
 def test_integer_power_arguments_are_left_alone(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(in_field: Field[np.float32], squared: Field[IJ, np.int32], out_field: Field[np.float32]):
+    @on(backend)
+    def stencil(source: Field[np.float32], squared: Field[IJ, np.int32], target: Field[np.float32]):
         with computation(FORWARD), interval(...):
-            out_field = in_field**squared
+            target = source**squared
 
     data = np.linspace(0.5, 3, 125, dtype=np.float32).reshape(5, 5, 5)
     out = mk.zeros((5, 5, 5), np.float32)
@@ -838,87 +843,87 @@ def test_integer_power_arguments_are_left_alone(backend, mk):
 def test_no_write_and_read_with_horizontal_offset(backend):
     with pytest.raises(ValueError, match="Self-assignment with offset in I or J is illegal."):
 
-        @gtscript.stencil(backend=backend)
-        def direct(field: Field[F8]):
+        @on(backend)
+        def direct(phi: Field[F8]):
             with computation(PARALLEL), interval(...):
-                field = (field[I - 1] + field[I + 1]) / 2
+                phi = (phi[I - 1] + phi[I + 1]) / 2
 
     with pytest.raises(ValueError, match="Illegal write and read with horizontal offset"):
 
-        @gtscript.stencil(backend=backend)
-        def through_temporary(field: Field[F8]):
+        @on(backend)
+        def through_temporary(phi: Field[F8]):
             with computation(PARALLEL), interval(...):
-                tmp = (field[J - 1] + field[J + 1]) / 2
-                field = tmp * 2
+                work = (phi[J - 1] + phi[J + 1]) / 2
+                phi = work * 2
 
 
 def test_k_offsets_in_parallel_loops(backend):
     with pytest.raises(ValueError, match="write and read with k-offsets in PARALLEL"):
 
-        @gtscript.stencil(backend=backend)
-        def direct(field: Field[np.int32]):
+        @on(backend)
+        def direct(phi: Field[np.int32]):
             with computation(PARALLEL), interval(1, None):
-                field = field[K - 1] * 2
+                phi = phi[K - 1] * 2
 
     with pytest.raises(ValueError, match="write and read with k-offsets in PARALLEL"):
 
-        @gtscript.stencil(backend=backend)
-        def through_temporary(field: Field[np.int32]):
+        @on(backend)
+        def through_temporary(phi: Field[np.int32]):
             with computation(PARALLEL), interval(1, None):
-                tmp = field[K - 1]
-                field = tmp * 2
+                work = phi[K - 1]
+                phi = work * 2
 
     with pytest.raises(ValueError, match="write and read with `VariableKOffset` and/or `AbsoluteKIndex`"):
 
-        @gtscript.stencil(backend=backend)
-        def absolute(field: Field[np.int32]):
+        @on(backend)
+        def absolute(phi: Field[np.int32]):
             with computation(PARALLEL), interval(...):
-                level = field.at(K=1)
-                field = 2 * level
+                level = phi.at(K=1)
+                phi = 2 * level
 
     with pytest.raises(ValueError, match="write and read with `VariableKOffset` and/or `AbsoluteKIndex`"):
 
-        @gtscript.stencil(backend=backend)
-        def variable(field: Field[np.int32], offset: int = -1):
+        @on(backend)
+        def variable(phi: Field[np.int32], offset: int = -1):
             with computation(PARALLEL), interval(1, None):
-                bottom = field[0, 0, offset]
-                field = field + 2 * bottom
+                bottom = phi[0, 0, offset]
+                phi = phi + 2 * bottom
 
-    @gtscript.stencil(backend=backend)
-    def center_read(field: Field[np.int32]):
+    @on(backend)
+    def center_read(phi: Field[np.int32]):
         with computation(PARALLEL), interval(...):
-            field = field[0, 0, 0] * 2
+            phi = phi[0, 0, 0] * 2
 
-    @gtscript.stencil(backend=backend)
-    def center_write(field: Field[np.int32]):
+    @on(backend)
+    def center_write(phi: Field[np.int32]):
         with computation(PARALLEL), interval(...):
-            field[0, 0, 0] = field * 2
+            phi[0, 0, 0] = phi * 2
 
-    @gtscript.stencil(backend=backend)
-    def index_fields(field: Field[np.float32], index: Field[np.int32]):
+    @on(backend)
+    def index_fields(phi: Field[np.float32], index: Field[np.int32]):
         with computation(PARALLEL), interval(1, None):
-            field = index + index[K - 1] * 2
+            phi = index + index[K - 1] * 2
 
-    @gtscript.stencil(backend=backend)
-    def single_level_intervals(field: Field[np.bool_]):
+    @on(backend)
+    def single_level_intervals(phi: Field[np.bool_]):
         with computation(PARALLEL):
             with interval(0, 1):
-                field = field[K + 1]
+                phi = phi[K + 1]
             with interval(-1, None):
-                field = field[K - 1]
+                phi = phi[K - 1]
 
 
 def test_self_assignment_in_forward(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def direct(field: Field[np.int32]):
+    @on(backend)
+    def direct(phi: Field[np.int32]):
         with computation(FORWARD), interval(1, None):
-            field = field[K - 1] * 2
+            phi = phi[K - 1] * 2
 
-    @gtscript.stencil(backend=backend)
-    def through_temporary(field: Field[np.int32]):
+    @on(backend)
+    def through_temporary(phi: Field[np.int32]):
         with computation(FORWARD), interval(1, None):
-            tmp = field[K - 1]
-            field = tmp * 2
+            work = phi[K - 1]
+            phi = work * 2
 
     for stencil in (direct, through_temporary):
         f = mk.ones((2, 2, 5), np.int32)
@@ -927,12 +932,12 @@ def test_self_assignment_in_forward(backend, mk):
 
 
 def test_reset_mask_2d(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(dp1: Field[F8], pe1: Field[F8], lev: Field[IJ, np.int32]):
+    @on(backend)
+    def stencil(dp1: Field[F8], edge_from: Field[F8], lvl: Field[IJ, np.int32]):
         with computation(PARALLEL), interval(0, -1):
-            dp1 = pe1[0, 0, 1] - pe1
+            dp1 = edge_from[0, 0, 1] - edge_from
         with computation(FORWARD), interval(0, 1):
-            lev = 0
+            lvl = 0
 
     mask = mk.ones((5, 5), np.int32, dimensions="IJ")
     stencil(mk.zeros((5, 5, 5)), mk.ones((5, 5, 5)), mask)
@@ -945,13 +950,13 @@ def test_offset_j_in_temporaries(backend, mk):
     def a_gtscript_function(b):
         return sqrt(abs(b[0, 1, 0]))
 
-    @gtscript.stencil(backend=backend)
-    def stencil(field_in: Field[IJK, F8], field_out: Field[IJK, F8]):
+    @on(backend)
+    def stencil(u_old: Field[IJK, F8], u_new: Field[IJK, F8]):
         with computation(PARALLEL), interval(...):
-            abs_res = abs(field_in)
+            abs_res = abs(u_old)
             tan_res = tan(abs_res)
             sqrt_res = a_gtscript_function(tan_res)
-            field_out = (sqrt_res if isfinite(sqrt_res) else field_in if isinf(sqrt_res) else field_out
+            u_new = (sqrt_res if isfinite(sqrt_res) else u_old if isinf(sqrt_res) else u_new
                          if isnan(sqrt_res) else 0.0)
 
     rng = np.random.default_rng(11)
@@ -968,27 +973,27 @@ def test_offset_j_in_temporaries(backend, mk):
 # ---- :1860-1892 -------------------------------------------------------------------------------------
 class MyEnum(IntEnum):
     Zero = 0
-    A = 10
-    B = 20
-    C = 30
+    Ten = 10
+    Twenty = 20
+    Thirty = 30
 
 
 gtscript.enum(MyEnum)
 
 
 def test_enum_runtime(backend, mk):
-    @gtscript.stencil(backend=backend)
-    def stencil(out_field: Field[int], order: MyEnum):
+    @on(backend)
+    def stencil(target: Field[int], order: MyEnum):
         with computation(PARALLEL), interval(0, 1):
-            out_field = 32
-            if order < MyEnum.A:
-                out_field = MyEnum.A
+            target = 32
+            if order < MyEnum.Ten:
+                target = MyEnum.Ten
         with computation(PARALLEL), interval(1, 2):
-            out_field = 23
-            out_field = MyEnum.B
+            target = 23
+            target = MyEnum.Twenty
         with computation(PARALLEL), interval(2, None):
-            out_field = 56
-            out_field = MyEnum.C
+            target = 56
+            target = MyEnum.Thirty
 
     out = mk.zeros((5, 5, 5), int)
     stencil(out, MyEnum.Zero)
@@ -1000,7 +1005,7 @@ def test_math_functions(backend, mk):
     from gt4py_amd.cartesian.gtscript import erf, erfc, round, round_away_from_zero  # noqa: A004
     import scipy.special
 
-    @gtscript.stencil(backend=backend)
+    @on(backend)
     def stencil(x: Field[F8], out_erf: Field[F8], out_erfc: Field[F8], out_round: Field[F8], out_away: Field[F8]):
         with computation(PARALLEL), interval(...):
             out_erf = erf(x)

@@ -1254,7 +1254,8 @@ def _setup_distributed_laplacian(args, ctx):
               "direct_transport_canary": canary, **ladder_line_keys(ctx)}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
               "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback,
-              "calibration": calibration_line_keys(calibration, stats, ctx) if calibration is not None else None}
+              "calibration": calibration_line_keys(calibration, stats, ctx, {"total": total, "halo": 1, "itemsize": 8, "grid": grid})
+              if calibration is not None else None}
     return step, kernel_step, dec.local_domain, config, extras
 
 
@@ -1521,7 +1522,8 @@ def _setup_hdiff2048(args, ctx):
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(total)), "keep": (fields, comm, frozen),
               "proof": proof, "transport_fallback": fallback,
               "timestep": pipelined_applies if decomposed and os.environ.get("GT4MI_BENCH_TIMESTEP", "1") != "0" else None,
-              "calibration": calibration_line_keys(timings, stats, ctx) if timings else None}
+              "calibration": calibration_line_keys(timings, stats, ctx, {"total": total, "halo": halo, "itemsize": 8, "grid": grid})
+              if timings else None}
     return step, kernel_step, dec.local_domain, config, extras
 
 

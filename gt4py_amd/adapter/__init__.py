@@ -250,7 +250,13 @@ def stencil_from_oir(oir_stencil: Any, **kwargs):
 
 
 def register_with_gt4py(name: str = "hip:mi300"):
-    """Register ``name`` as a backend of an installed gt4py (>= 1.0, gtc based).  Returns the backend class."""
+    """Register ``name`` as a backend of an installed gt4py (>= 1.0, gtc based).  Returns the backend class.
+
+    Prerequisite besides gt4py itself: **cupy for ROCm**.  gt4py converts every argument of a GPU backend with ``cp.asarray``
+    before ``run()`` sees it (/root/reference/src/gt4py/cartesian/stencil_object.py:69-93 ->
+    storage/cartesian/utils.py:176-215: ``device == "gpu"`` => cupy, asserted present) and allocates
+    ``gt4py.storage.*(backend=name)`` with cupy (storage/cartesian/interface.py:84-100).  What arrives in ``run()`` is therefore
+    a cupy array: this module reads it through ``__cuda_array_interface__`` (strides included) and needs nothing else of it."""
     try:
         from gt4py.cartesian import backend as gt4py_backend  # type: ignore
         from gt4py.cartesian.backend import base as gt4py_base  # type: ignore

@@ -343,9 +343,40 @@ def hdiff_calibration_order(schedules, edges, transports):
     return first, refine, direct_stage
 
 
-def calibration_line_keys(table, stats, ctx=None) -> dict:
+def per_process_grid_keys(table, total, halo: int, itemsize: int, default_grid=None) -> dict:
+    """``{"PIxPJ": {...}}`` for every process grid the calibration measured: the best per-apply ms on each transport and the bytes of
+    one face message per neighbour, so that the first multi-device record shows -- without a second run -- whether a grid's big faces
+    hid behind its interior (1 x 8: 2.1 MB N / S faces against a 44 us interior).  Keys of ``table``
+    that name no grid (the hdiff forms) belong to ``default_grid``.  Face sizes are those of the two-phase table: W / E faces carry the
+    local J rows, N / S faces the local I columns PLUS the freshly received I-halo columns (corners for free)."""
+    out = {}
+    for key, ms in table.items():
+        head = key.split("_", 1)[0]
+        if "x" in head and all(p.isdigit() for p in head.split("x")):
+            grid = tuple(int(p) for p in head.split("x"))
+        elif default_grid is not None:
+            grid = tuple(default_grid)
+        else:
+            continue
+        name = f"{grid[0]}x{grid[1]}"
+        entry = out.get(name)
+        if entry is None:
+            li, lj, lk = -(-int(total[0]) // grid[0]), -(-int(total[1]) // grid[1]), int(total[2])
+            entry = out[name] = {"local_domain": [li, lj, lk],
+                                 "face_bytes_per_neighbour": {"west_east": halo * lj * lk * itemsize if grid[0] > 1 else 0,
+                                                              "north_south": halo * (li + (2 * halo if grid[0] > 1 else 0)) * lk * itemsize if grid[1] > 1 else 0},
+                                 "neighbours": (2 if grid[0] > 1 else 0) + (2 if grid[1] > 1 else 0),
+                                 "best_ms_per_apply": {}, "best_form": {}}
+        transport = "direct" if key.endswith("_direct") else "rccl"
+        if transport not in entry["best_ms_per_apply"] or ms < entry["best_ms_per_apply"][transport]:
+            entry["best_ms_per_apply"][transport], entry["best_form"][transport] = ms, key
+    return out
+
+
+def calibration_line_keys(table, stats, ctx=None, geometry=None) -> dict:
     """Top-level keys of a calibrated N > 1 line: what the SPECIFIED design (RCCL send/recv on a second stream) achieves next to
-    the direct transport, whichever of the two the headline took, and how much of the calibration the budget allowed."""
+    the direct transport, whichever of the two the headline took, how much of the calibration the budget allowed, and -- given the
+    ``geometry`` (total, halo, itemsize, grid) -- every measured process grid with its face sizes (``per_process_grid``)."""
     direct = {k: v for k, v in table.items() if k.endswith("_direct")}
     rccl = {k: v for k, v in table.items() if not k.endswith("_direct")}  # (Laplacian keys end in _rccl, hdiff's carry no suffix)
     rccl_key = min(rccl, key=rccl.get) if rccl else None
@@ -354,7 +385,10 @@ def calibration_line_keys(table, stats, ctx=None) -> dict:
     return {"rccl_best_ms_per_apply": rccl_ms, "rccl_best_form": rccl_key, "direct_best_ms_per_apply": direct_ms,
             "direct_best_form": direct_key, "calibration_candidates_run": stats["run"],
             "calibration_candidates_skipped_for_time": stats["skipped_for_time"], "calibration_candidates_failed": list(stats["failed"]),
-            "calibration_candidates_failed_unfenced": list(stats.get("failed_unfenced", [])), **(ladder_line_keys(ctx) if ctx is not None else {})}
+            "calibration_candidates_failed_unfenced": list(stats.get("failed_unfenced", [])),
+            **({"per_process_grid": per_process_grid_keys(table, geometry["total"], geometry["halo"], geometry["itemsize"], geometry.get("grid"))}
+               if geometry else {}),
+            **(ladder_line_keys(ctx) if ctx is not None else {})}
 
 # ---- the fall-back ladder of the halo transport ---------------------------------------------------------------------------
 DIRECT_MODES = ("direct", "direct-fenced", "rccl")

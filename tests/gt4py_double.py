@@ -137,7 +137,11 @@ def build(surface: Dict[str, Any], args_data_of_pipeline):
             return cls._instance
 
         def _call_run(self, field_args, parameter_args, domain, origin, *, validate_args=True, exec_info=None):
-            """Origin per field (a 3-tuple applies to every field, a dict may name fields), the largest domain that fits all fields."""
+            """Origin per field (a 3-tuple applies to every field, a dict may name fields), the largest domain that fits all fields.
+            Every field goes through the stand-in of ``cp.asarray`` FIRST, as the reference's ``_call_run`` does before ``run()`` sees
+            anything (stencil_object.py:69-93 -> storage/cartesian/utils.py:176-215, device "gpu"): what reaches the backend's
+            ``run`` is a cupy array, not the caller's object."""
+            field_args = {n: cupy_like_asarray(a) for n, a in field_args.items()}
             names = list(field_args)
             if origin is None:
                 origin = {n: (0, 0, 0) for n in names}
@@ -155,6 +159,44 @@ def build(surface: Dict[str, Any], args_data_of_pipeline):
     root = module("gt4py")
     root.cartesian = cartesian
     return mods
+
+
+class CupyLikeArray:
+    """What ``cupy.asarray(x)`` hands on, as far as a backend's ``run()`` may rely on it: ``shape`` / ``dtype`` / ``strides`` and
+    ``__cuda_array_interface__`` (version 3, byte strides always spelled out, ``stream=1`` as cupy sets it on ROCm) -- and NOTHING of
+    the object it was made from: no ``.tensor``, no ``data_ptr()``, no ``__dlpack__``, no origin attributes.  Keeps the source alive,
+    as a cupy view of foreign memory does."""
+
+    def __init__(self, source):
+        import numpy as _np
+
+        cai = dict(source.__cuda_array_interface__)
+        self.shape = tuple(int(n) for n in cai["shape"])
+        self.dtype = _np.dtype(cai["typestr"])
+        strides = cai.get("strides")
+        if strides is None:  # C-contiguous
+            strides, run = [], self.dtype.itemsize
+            for n in reversed(self.shape):
+                strides.insert(0, run)
+                run *= n
+        self.strides = tuple(int(b) for b in strides)
+        self._interface = {"shape": self.shape, "typestr": self.dtype.str, "data": (int(cai["data"][0]), False), "version": 3,
+                           "strides": self.strides, "stream": 1}
+        self._keepalive = source
+
+    @property
+    def __cuda_array_interface__(self):
+        return dict(self._interface)
+
+
+def cupy_like_asarray(array):
+    """``storage_utils.asarray(array, device="gpu")`` of the reference with the stand-in for cupy; an object that exports no
+    ``__cuda_array_interface__`` is refused (the GPU door of gt4py NEEDS cupy: storage/cartesian/utils.py:186-188, 262-264)."""
+    if array is None or isinstance(array, CupyLikeArray):
+        return array
+    if not hasattr(array, "__cuda_array_interface__"):
+        raise TypeError(f"cp.asarray stand-in: {type(array).__name__} exports no __cuda_array_interface__")
+    return CupyLikeArray(array)
 
 
 @dataclasses.dataclass

@@ -560,9 +560,33 @@ def test_the_glue_on_the_double_computes_on_the_device(monkeypatch):
     want = {k: v.copy() for k, v in host.items()}
     gtscript.stencil(backend="numpy", definition=tridiagonal_definition)(**want)
     arrays = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=(0, 0, 0)) for k, v in host.items()}
+    # what the real `_call_run` hands to `run()` is NOT the caller's object: every field went through `cp.asarray` first
+    # (/root/reference/src/gt4py/cartesian/stencil_object.py:69-93, 585-609 -> storage/cartesian/utils.py:176-215).  The double does the
+    # same with a stand-in that exposes shape / dtype / strides / __cuda_array_interface__ and nothing else.
+    seen = {}
+    inner_run = stencil_class.run
+
+    def recording_run(self, _domain_, _origin_, exec_info=None, **kwargs):
+        seen.update({k: type(v).__name__ for k, v in kwargs.items()})
+        return inner_run(self, _domain_, _origin_, exec_info=exec_info, **kwargs)
+
+    monkeypatch.setattr(stencil_class, "run", recording_run)
     stencil_class()(arrays["inf"], arrays["diag"], arrays["sup"], rhs=arrays["rhs"], out=arrays["out"])  # positional and keyword fields
+    assert seen == {k: "CupyLikeArray" for k in host}
     for k in host:
         np.testing.assert_array_equal(gt_storage.asnumpy(arrays[k]), want[k])
+    # a strided view (cupy keeps the strides of what it wraps): the K-reversed... no: a J-sliced view with an origin offset
+    view_host = {k: v.copy() for k, v in host.items()}
+    want2 = {k: v[:, 1:4, :].copy() for k, v in view_host.items()}
+    gtscript.stencil(backend="numpy", definition=tridiagonal_definition)(**want2)
+    arrays2 = {k: gt_storage.from_array(v, dtype=v.dtype, backend="hip:mi300", aligned_index=(0, 0, 0)) for k, v in view_host.items()}
+    views = {k: a[:, 1:4, :] for k, a in arrays2.items()}  # non-contiguous device views: strides must survive the conversion
+    stencil_class()(**views)
+    for k in host:
+        got = gt_storage.asnumpy(arrays2[k])
+        np.testing.assert_array_equal(got[:, 1:4, :], want2[k])
+        np.testing.assert_array_equal(got[:, :1, :], view_host[k][:, :1, :])  # rows outside the view untouched
+        np.testing.assert_array_equal(got[:, 4:, :], view_host[k][:, 4:, :])
 
 
 def test_registration_needs_a_real_gt4py():

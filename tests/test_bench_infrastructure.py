@@ -221,6 +221,26 @@ def test_a_small_budget_still_yields_an_overlapped_rccl_headline_on_every_rank_a
     assert got[0]["canary"] is True and got[0]["transports"] == ["rccl", "direct"]
 
 
+def test_the_line_names_every_measured_process_grid_with_its_face_sizes():
+    """SURVEY.md section 8e's message sizes, per process grid the calibration measured, beside the best per-apply time on each
+    transport: 512^3 over 4 x 2 -> I faces 1 x 256 x 512 x 8 B = 1.05 MB, J faces 1 x (128 + 2) x 512 x 8 B = 0.53 MB; over 1 x 8 only
+    N / S faces of 2.1 MB; horizontal diffusion 2048 x 2048 x 80 over 4 x 2 (ghost depth 2) -> 1.31 MB and 0.66 MB."""
+    from gt4py_amd.distributed.calibrate import calibration_line_keys, per_process_grid_keys
+
+    table = {"4x2_twophase_swap_wg0_rccl": 0.102, "4x2_singlephase_swap_wg0_rccl": 0.110, "4x2_twophase_inline_wg0_direct": 0.066,
+             "1x8_twophase_inline_wg0_direct": 0.052, "1x8_twophase_swap_wg0_rccl": 0.090}
+    grids = per_process_grid_keys(table, (512, 512, 512), 1, 8)
+    assert set(grids) == {"4x2", "1x8"}
+    assert grids["4x2"]["local_domain"] == [128, 256, 512] and grids["4x2"]["face_bytes_per_neighbour"] == {"west_east": 1048576, "north_south": 532480}
+    assert grids["1x8"]["face_bytes_per_neighbour"] == {"west_east": 0, "north_south": 2097152} and grids["1x8"]["neighbours"] == 2
+    assert grids["4x2"]["best_ms_per_apply"] == {"rccl": 0.102, "direct": 0.066} and grids["4x2"]["best_form"]["rccl"] == "4x2_twophase_swap_wg0_rccl"
+    hd = per_process_grid_keys({"overlapped": 0.2, "inline_direct": 0.19}, (2048, 2048, 80), 2, 8, (4, 2))
+    assert hd["4x2"]["face_bytes_per_neighbour"] == {"west_east": 1310720, "north_south": 660480} and hd["4x2"]["best_ms_per_apply"] == {"rccl": 0.2, "direct": 0.19}
+    stats = {"run": 5, "skipped_for_time": 0, "failed": []}
+    keys = calibration_line_keys(table, stats, None, {"total": (512, 512, 512), "halo": 1, "itemsize": 8, "grid": (4, 2)})
+    assert keys["per_process_grid"] == grids and "per_process_grid" not in calibration_line_keys(table, stats)
+
+
 @pytest.mark.multiprocess
 def test_a_direct_form_that_fails_moves_every_rank_down_the_ladder(tmp_path):
     """direct -> direct-fenced -> rccl.  A form of the direct transport that fails on some rank -- wrong

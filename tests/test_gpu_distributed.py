@@ -10,6 +10,10 @@ choreography and the fused gt4mi_dist_lap5_f64 step -- against numpy's periodic 
 import numpy as np
 import pytest
 
+
+def config_grid(line) -> str:
+    return line["config"]["decomposition"]
+
 pytestmark = pytest.mark.gpu
 
 
@@ -882,6 +886,13 @@ def test_bench_n_gpu_code_path_with_a_world_of_one(workload, tmp_path):
     assert line["rccl_best_ms_per_apply"] == min(v for k, v in table.items() if not k.endswith("direct")) and line["rccl_best_form"] in table
     assert line["direct_best_ms_per_apply"] == min(v for k, v in table.items() if k.endswith("direct"))
     assert line["calibration_candidates_run"] >= len(table) and line["calibration_candidates_skipped_for_time"] >= 0
+    # every process grid the calibration measured, with its per-apply time on each transport and the bytes of one face message per
+    # neighbour: the first multi-device record shows whether a grid's big faces hid behind its interior
+    grids = line["per_process_grid"]
+    assert f"{config_grid(line)}" in grids and all(set(g["best_ms_per_apply"]) <= {"rccl", "direct"} and g["best_ms_per_apply"] for g in grids.values())
+    mine = grids[config_grid(line)]
+    assert mine["local_domain"] == line["config"]["local_domain"] and sum(mine["face_bytes_per_neighbour"].values()) > 0
+    assert min(min(g["best_ms_per_apply"].values()) for g in grids.values()) == min(table.values())
     if workload == "lap512":
         assert {"timestep_glups", "timestep_ms_per_step", "pipelined_apply_glups"} <= set(line["extra"])
         assert line["config"]["mode"] == "apply" and line["config"]["halo_depth"] == 1

@@ -312,7 +312,12 @@ def _wrap_for_gt4py(builder, impl, gt4py_base):  # pragma: no cover - needs gt4p
     args_data = make_args_data_from_gtir(builder.gtir_pipeline)
 
     def run(self, _domain_, _origin_, exec_info=None, **kwargs):
-        impl.run(_domain_=tuple(_domain_), _origin_={k: tuple(v) for k, v in _origin_.items()}, exec_info=exec_info, **kwargs)
+        # what gt4py's `_call_run` hands over are cupy arrays (every argument went through `cp.asarray`, stencil_object.py:69-93,
+        # 585-609): zero-copy views through `__cuda_array_interface__`, strides included -- the launch path wants DeviceArrays
+        from ..storage.device_array import as_device_array
+
+        fields = {k: (as_device_array(v) if v is not None and k in args_data.field_info else v) for k, v in kwargs.items()}
+        impl.run(_domain_=tuple(_domain_), _origin_={k: tuple(v) for k, v in _origin_.items()}, exec_info=exec_info, **fields)
 
     def call(self, *args, domain=None, origin=None, validate_args=True, exec_info=None, **kwargs):
         bound = inspect.signature(builder.definition).bind_partial(*args, **kwargs)

@@ -316,3 +316,21 @@ def test_a_timed_call_that_fails_on_one_rank_fails_on_every_rank_together(tmp_pa
     assert got[0]["raised"] == "on another rank" and "ran out of time" in got[1]["raised"]
     assert got[0]["still_in_step"] == got[1]["still_in_step"] == 1
     assert got[0]["calls"] >= 7 and got[1]["calls"] >= 4 and got[0]["dropped"] is not None and got[0]["dropped"] == got[1]["dropped"]
+
+
+def test_the_decomposed_workloads_live_in_the_package_and_bench_re_exports_them():
+    """bench.py is the program that meets 8 devices first; the set-up of its two decomposed workloads is a module of the package
+    (importable without running the bench) and bench.<name> is the same object."""
+    import bench
+    from gt4py_amd.distributed import workloads
+
+    for name in ("_setup_distributed_laplacian", "_setup_hdiff2048", "direct_canary", "_native_comm", "gather_rank_proof", "_device_fields",
+                 "_time_launches", "hdiff_input", "_lap_definition"):
+        assert getattr(bench, name) is getattr(workloads, name)
+    before = (workloads.GRID, workloads.HDIFF_SHARE, workloads.HDIFF_GLOBAL)
+    try:
+        workloads.set_levels(32)  # the one-device rehearsal's slab
+        assert workloads.GRID == (512, 512, 32) and workloads.HDIFF_SHARE == (512, 1024, 32) and workloads.HDIFF_GLOBAL == (2048, 2048, 32)
+    finally:
+        workloads.GRID, workloads.HDIFF_SHARE, workloads.HDIFF_GLOBAL = before
+    assert bench.GRID == (512, 512, 512)

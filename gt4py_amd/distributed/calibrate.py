@@ -27,10 +27,24 @@ def _agree(ctx, ok: int) -> int:
     if ctx["distributed"]:
         import torch
 
+        _refuse_if_poisoned()
+
         flag = torch.tensor([ok], dtype=torch.int32, device=ctx.get("collective_device", ctx.get("device", "cuda")))
         ctx["dist"].all_reduce(flag, op=ctx["dist"].ReduceOp.MIN)
         ok = int(flag.item())
     return ok
+
+
+def _refuse_if_poisoned() -> None:
+    """A collective next to one that is still pending in a helper thread (NativeHaloExchanger.close of a failed direct plan whose
+    closing round was not met) would run concurrently on the same group: refuse loudly instead (the watchdog's provisional line is
+    the run's result then)."""
+    import sys
+
+    native = sys.modules.get("gt4py_amd.distributed.native")  # (only a process that built a native exchanger can be poisoned)
+    why = native.collectives_poisoned() if native is not None else None
+    if why:
+        raise native.CollectivesPoisoned(f"no further collectives on the job's process group: {why}")
 
 
 class FailedOnSomeRank(RuntimeError):
@@ -66,6 +80,7 @@ def _slowest_rank_ms(ctx, fn, calls: int, warm: int = 3) -> float:
 
     run(warm)
     if ctx["distributed"]:
+        _refuse_if_poisoned()
         ctx["dist"].barrier()
     t0 = time.perf_counter()
     if failure is None:

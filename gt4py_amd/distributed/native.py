@@ -100,6 +100,25 @@ def _field_struct(array, origin=(0, 0, 0)) -> _lib.Field:
     return _lib.Field.make(array.data_ptr(), tuple(array.shape), tuple(s * isz for s in array.stride()), origin)
 
 
+_POISON = {"why": None}
+
+
+def poison_collectives(why: str) -> None:
+    """A helper thread of this process is stuck inside a collective of the job's process group (an unmet closing round): from now on
+    this rank must not issue another collective on that group."""
+    if _POISON["why"] is None:
+        _POISON["why"] = str(why)
+
+
+def collectives_poisoned():
+    """None, or why this rank may no longer issue collectives on the job's process group."""
+    return _POISON["why"]
+
+
+class CollectivesPoisoned(RuntimeError):
+    """Raised instead of issuing a collective next to one that is still pending in a helper thread of this process."""
+
+
 class NativeHaloExchanger:
     """Two-phase ghost-cell exchange of one field shape through a native plan (see halo.halo_boxes)."""
 
@@ -510,9 +529,16 @@ class NativeHaloExchanger:
                     meet.start()
                     meet.join(timeout=self.failed_close_seconds)
                     if meet.is_alive():
+                        # the helper thread stays blocked INSIDE a collective of the job's process group: another collective from
+                        # the main thread would run concurrently with it on the same group (mismatched or out-of-order collectives,
+                        # a hang on the ranks that did meet).  The group is POISONED from here on: `collectives_poisoned()` is what
+                        # `calibrate._agree` / `_slowest_rank_ms` consult before they issue one.
+                        poison_collectives(f"rank {self.decomp.rank}: the closing round of a failed direct plan did not complete within "
+                                           f"{self.failed_close_seconds:.0f} s")
                         warnings.warn("NativeHaloExchanger.close(): the plan's direct transport has FAILED (a wait for a neighbour ran "
                                       f"out of time) and the ranks did not meet within {self.failed_close_seconds:.0f} s: the pool is "
-                                      "leaked instead of waiting for a neighbour that may be gone", RuntimeWarning, stacklevel=2)
+                                      "leaked instead of waiting for a neighbour that may be gone; no further collective will be "
+                                      "issued on the job's process group by this rank", RuntimeWarning, stacklevel=2)
                         self._close_round = None
                         self._plan = ctypes.c_void_p()  # (the native plan and its pool stay allocated: see above)
                         return

@@ -188,7 +188,7 @@ def direct_canary(ctx) -> bool:
         for key in [k for k in env if k.startswith("TORCHELASTIC_")] + ["GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
                                                                         "GT4MI_BENCH_TEST_HANG"]:
             env.pop(key, None)
-        ok = 0
+        ok, port_taken = 0, 0
         try:
             fails = os.environ.get("GT4MI_BENCH_TEST_CANARY_FAILS", "")  # (tests: "1" = both modes fail, "unfenced" = only the default mode)
             if fails == "1" or (fails == "unfenced" and not fenced):
@@ -197,6 +197,8 @@ def direct_canary(ctx) -> bool:
                    "--epochs", str(CHECK_EPOCHS), "--stress-epochs", str(CANARY_STRESS_EPOCHS)] + (["--fenced"] if fenced else [])
             proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(ROOT))
             ok = int(proc.returncode == 0)
+            # (several hosts only: the port rank 0 found free a moment ago may have been taken before the child's store bound it)
+            port_taken = int(not ok and where[0][0] == "tcp" and ("EADDRINUSE" in proc.stderr or "ddress already in use" in proc.stderr))
             if not ok:
                 print(f"rank {rank}: the canary of the direct transport{' (fenced)' if fenced else ''} ended with status "
                       f"{proc.returncode}: {(proc.stdout + proc.stderr)[-900:]}", file=sys.stderr)
@@ -205,6 +207,8 @@ def direct_canary(ctx) -> bool:
         good = bool(_agree(ctx, ok))  # (every child has ended on every rank: the directory is no longer needed)
         if tmpdir is not None:
             shutil.rmtree(tmpdir, ignore_errors=True)
+        if not good and attempt == 0 and not _agree(ctx, int(not port_taken)):  # some rank lost the race for the port: once more, fresh port
+            return children(fenced, attempt=1)
         return good
 
     if children(fenced=direct_fenced(ctx), attempt=0):

@@ -932,3 +932,33 @@ def test_gloo_world_size_2_epoch_stamped_check_sees_a_late_transport_in_every_ro
         assert n > 0 and got[r]["verdicts"][0][0] is True  # (the plan's first exchange has nothing stale to hand out)
         for ok, found in got[r]["verdicts"][1:]:
             assert ok is False and f"[{n} of them hold the previous epoch's value" in found, (r, found)
+
+
+def test_a_rank_with_a_pending_closing_round_issues_no_further_collectives():
+    """close() of a failed direct plan offers the closing round from a helper thread for a bounded time; if the ranks
+    do not meet, that thread stays inside a collective of the job's process group -- and this rank must not start another one next
+    to it.  The group is marked poisoned; the agreement helpers refuse loudly instead of issuing a concurrent collective."""
+    from gt4py_amd.distributed import calibrate, native
+
+    class NeverCalled:
+        class ReduceOp:
+            MIN = MAX = None
+
+        def all_reduce(self, *a, **k):  # pragma: no cover - the point of the test
+            raise AssertionError("a collective was issued on a poisoned group")
+
+        barrier = all_reduce
+
+    ctx = {"distributed": True, "dist": NeverCalled(), "rank": 0, "collective_device": "cpu"}
+    before = dict(native._POISON)
+    try:
+        native._POISON["why"] = None
+        assert native.collectives_poisoned() is None
+        native.poison_collectives("rank 0: the closing round of a failed direct plan did not complete within 20 s")
+        native.poison_collectives("a second reason is not recorded")
+        assert "closing round" in native.collectives_poisoned()
+        with pytest.raises(native.CollectivesPoisoned, match="closing round"):
+            calibrate._agree(ctx, 1)
+        assert calibrate._agree({"distributed": False}, 1) == 1  # a single process has no group to poison
+    finally:
+        native._POISON.update(before)

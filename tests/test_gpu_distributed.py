@@ -891,7 +891,8 @@ def test_bench_n_gpu_code_path_with_a_world_of_one(workload, tmp_path):
     grids = line["per_process_grid"]
     assert f"{config_grid(line)}" in grids and all(set(g["best_ms_per_apply"]) <= {"rccl", "direct"} and g["best_ms_per_apply"] for g in grids.values())
     mine = grids[config_grid(line)]
-    assert mine["local_domain"] == line["config"]["local_domain"] and sum(mine["face_bytes_per_neighbour"].values()) > 0
+    assert mine["local_domain"] == line["config"]["local_domain"]
+    assert (sum(mine["face_bytes_per_neighbour"].values()) > 0) == (config_grid(line) != "1x1")  # (a world of one has no faces)
     assert min(min(g["best_ms_per_apply"].values()) for g in grids.values()) == min(table.values())
     if workload == "lap512":
         assert {"timestep_glups", "timestep_ms_per_step", "pipelined_apply_glups"} <= set(line["extra"])

@@ -49,10 +49,8 @@ if str(ROOT) not in sys.path:
 
 BYTES_PER_LUP = 16.0  # fp64: one read + one write per lattice update
 PEAK_GBS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md)
-# how long a device-side wait of the direct transport may take in THIS program before its plan fails (the library's default is
-# 30 s): a broken direct transport costs the calibration this much per wait, then its forms are dropped
 _LAP_SOURCES = ("gt4py_amd/csrc/lap5.hip.h", "gt4py_amd/csrc/lane_shift.hip.h", "gt4py_amd/csrc/common.hip.h", "gt4py_amd/csrc/Makefile")
-_HDIFF_SOURCES = ("gt4py_amd/csrc/hdiff.hip.h", "gt4py_amd/csrc/hdiff_jmarch.hip.h", "gt4py_amd/csrc/lane_shift.hip.h",
+_HDIFF_SOURCES = ("gt4py_amd/csrc/hdiff.hip.h", "gt4py_amd/csrc/hdiff_share.hip.h", "gt4py_amd/csrc/hdiff_jmarch.hip.h", "gt4py_amd/csrc/lane_shift.hip.h",
                   "gt4py_amd/csrc/common.hip.h", "gt4py_amd/csrc/Makefile")
 _TRIDIAG_SOURCES = ("gt4py_amd/csrc/tridiag.hip.h", "gt4py_amd/csrc/tridiag_stack.hip.h", "gt4py_amd/csrc/common.hip.h", "gt4py_amd/csrc/Makefile")
 _GENERATED_SOURCES = ("gt4py_amd/cartesian/backend/hip_codegen.py", "gt4py_amd/cartesian/backend/stage_planner.py",

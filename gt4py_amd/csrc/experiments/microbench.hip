@@ -17,6 +17,7 @@
 #include "tridiag.hip.h"
 #include "vadv_stack.hip.h"
 #include "hdiff_ldstile.hip.h"
+#include "lap5_share.hip.h"
 
 using namespace gt4mi;
 
@@ -523,6 +524,60 @@ static void lap_suite(int dI, int dJ, int dK, int64_t extra_pitch, const char* t
         report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
         if (rep == 0) printf("           check vs generic: %llu mismatches\n", count_diff(out, ref, dI, dJ, dK));
     }
+}
+
+// lapshare (round 6): the Laplacian strip kernel with the J halo rows of neighbouring waves exchanged through LDS (experiments/lap5_share.hip.h)
+template <int LJ, int NWI, int NWJ, int XCDG>
+static void lapshare_variant(const DevField<double>& in, DevField<double>& out, const DevField<double>& ref, int dI, int dJ, int dK, const char* tag) {
+    char cfg[128];
+    snprintf(cfg, sizeof cfg, "%s shared halo rows LJ=%d waves %d x %d xcd=%d", tag, LJ, NWI, NWJ, XCDG);
+    CK(hipMemset(out.raw, 0, out.bytes));
+    const double ms = time_ms([&](int) { lap5_share_launch<double, double, 0, 2, LJ, NWI, NWJ, XCDG>(in.cview(), out.view(), dI, dJ, dK, 0); }, 30);
+    CK(hipGetLastError());
+    report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+    const unsigned long long bad = count_diff(out, ref, dI, dJ, dK);
+    if (bad) printf("           MISMATCHES vs the one-thread-per-point kernel: %llu\n", bad);
+}
+
+static void lapshare_suite(int dI, int dJ, int dK, const char* tag) {
+    DevField<double> in(dI, dJ, dK, 1, 1, 16, 0), out(dI, dJ, dK, 1, 1, 16, 0), ref(dI, dJ, dK, 1, 1, 16, 0);  // rows on 128-byte boundaries: the storage preset
+    fill(in, 1337, -1.0, 1.0);
+    CK(hipMemset(ref.raw, 0, ref.bytes));
+    {
+        dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+        hipLaunchKernelGGL((lap5_generic_kernel<double, double, 0>), grid, dim3(256), 0, 0, in.cview(), ref.view(), dI, dJ, dK);
+        CK(hipDeviceSynchronize());
+    }
+    const int64_t d[3] = {dI, dJ, dK};
+    for (int rep = 0; rep < 3; ++rep) {
+        {
+            const double ms = time_ms([&](int) { lap5_launch_variant<double, double, 0>(in.cview(), out.view(), d, 0); }, 30);
+            char cfg[96];
+            snprintf(cfg, sizeof cfg, "%s library (strip LJ=8 block=256 xcd=4)", tag);
+            report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+        }
+        lapshare_variant<8, 4, 1, 4>(in, out, ref, dI, dJ, dK, tag);  // the library's tile with the exchange machinery but nothing to exchange
+        lapshare_variant<8, 4, 2, 2>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<8, 4, 2, 4>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<8, 4, 2, 1>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<8, 4, 4, 1>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<8, 4, 4, 2>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<4, 4, 2, 4>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<4, 4, 4, 2>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<4, 4, 4, 4>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<6, 4, 4, 2>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<8, 2, 2, 4>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<8, 2, 4, 2>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<8, 1, 4, 4>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<8, 1, 8, 2>(in, out, ref, dI, dJ, dK, tag);
+        lapshare_variant<16, 4, 2, 2>(in, out, ref, dI, dJ, dK, tag);
+    }
+}
+
+static void section_lapshare() {
+    lapshare_suite(512, 512, 512, "512^3");
+    lapshare_suite(512, 512, 128, "512x512x128");
+    lapshare_suite(334, 131, 7, "334x131x7");
 }
 
 static void section_lap() {
@@ -1869,6 +1924,7 @@ int main(int argc, char** argv) {
             }
         }
     }
+    if (!want.empty() && on("lapshare")) section_lapshare();
     if (on("hdiff")) section_hdiff();
     if (!want.empty() && on("hdiff2")) section_hdiff2();
     if (!want.empty() && on("hdiff3")) section_hdiff3();

@@ -24,6 +24,8 @@ ROOT = pathlib.Path(__file__).resolve().parents[2]
 GRID = (512, 512, 512)
 HDIFF_SHARE = (512, 1024, 80)  # per-rank share of BASELINE.json configs[4]
 HDIFF_GLOBAL = (2048, 2048, 80)
+# how long a device-side wait of the direct transport may take in THIS program before its plan fails (the library's default is
+# 30 s): a broken direct transport costs the calibration this much per wait, then its forms are dropped
 DIRECT_TIMEOUT_MS = int(os.environ.get("GT4MI_BENCH_DIRECT_TIMEOUT_MS", "2000"))
 
 

@@ -377,7 +377,10 @@ def other_kernels(steps: int = 20, only=None):
             note="one generated column kernel (forward + backward sweep); 5 fields read, 1 written; the forward sweep's "
                  "ccol / dcol are read back by the backward sweep: the top 144 of 160 levels stay in registers + LDS "
                  "(stage_planner.TopCache, 104 + 40), the rest makes a round trip through scratch and u_pos is read by both "
-                 "sweeps (8 of the excess bytes per lattice update, by construction: DESIGN.md section 4b)")
+                 "sweeps.  Byte budget per lattice update: 48 algorithmic + 8 (u_pos twice) + 3.2 (16 of 160 levels of ccol / dcol "
+                 "through scratch) + ~2.2 (wcon's i + 1 column, alignment) = 61.4 = the 1.28 x the counters show; at the 6.4 TB/s the "
+                 "kernel moves that is 0.63 of the peak: this design's ceiling at K = 160 (registers and LDS are full; three on-chip "
+                 "values for 96 levels would move 64 B) -- DESIGN.md section 4b")
         del fields
         torch.cuda.empty_cache()
     if wanted("generated_laplacian_f64_512x512x512"):
@@ -980,13 +983,29 @@ def main() -> None:
         if headline:
             from gt4py_amd.storage import placement as _placement
 
-            line["memory_groups"] = _placement.report()  # what the allocator's placer did for every big field of this run
+            groups = _placement.report() or {}  # what the allocator's placer did for the big fields of this run (per-field records:
+            groups.pop("fields", None)          # 3 KB -- left out of the line; placement.report() has them)
+            line["memory_groups"] = groups
         if headline and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = None
                 print(f"cpu_baseline failed: {ex!r}", file=sys.stderr)
+        if headline:
+            # LAST key of the line (a record that keeps only the tail of a long line keeps this): every BASELINE config's figure
+            ok = line.get("other_kernels") or {}
+            line["summary"] = {"lap5_f64_512": {"glups": line["value"], "frac": line["roofline"]["frac"],
+                                                "traffic_over_algorithmic": round(line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"], 4)
+                                                if line["roofline"].get("traffic") else None,
+                                                "glups_default_allocator": line.get("value_default_allocator"),
+                                                "glups_allocator_off": line.get("value_allocator_off")},
+                               **{name: {"glups": e.get("glups"), "frac": e.get("frac_of_hbm_peak"),
+                                         "traffic_over_algorithmic": (e.get("roofline") or {}).get("traffic_over_algorithmic"),
+                                         **({"frac_by_allocation_set": e["frac_of_hbm_peak_by_allocation_set"]}
+                                            if "frac_of_hbm_peak_by_allocation_set" in e else {})}
+                                  for name, e in ok.items() if isinstance(e, dict)},
+                               "cpu_baseline_glups": (line.get("cpu_baseline") or {}).get("value")}
         dog.safe = None  # the complete line is about to be printed: a later deadline must not print a second one
         emit(line)
     dog.safe = lambda reason: None  # the line is out: trouble while tearing down no longer turns into status 3

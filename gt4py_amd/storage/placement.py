@@ -62,7 +62,7 @@ class MemoryGroupPlacer:
     ``probe(ptr_a, ptr_b_or_0, nbytes) -> GB/s`` are injected: the tests run the policy on the CPU with models of both."""
 
     def __init__(self, allocate: Callable[[int], Any], probe: Callable[[int, int, int], float], *, min_bytes: int = MIN_BYTES,
-                 max_bytes: int = MAX_BYTES, max_candidates: Optional[int] = None, max_held_bytes: int = 48 << 30,
+                 max_bytes: int = MAX_BYTES, max_candidates: Optional[int] = None, max_held_bytes: int = 16 << 30,
                  threshold_gbs: Optional[float] = None, release: Optional[Callable[[], None]] = None,
                  free_bytes: Optional[Callable[[], int]] = None, spacer_bytes: int = 0, plain_candidates: int = 4, park_extra: int = 0,
                  keep_free_bytes: int = 16 << 30, dormant_after: int = DORMANT_AFTER, release_cache: bool = False,

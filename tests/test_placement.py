@@ -227,6 +227,19 @@ def test_the_probe_and_the_placer_on_the_device():
     if rep["wanted_class_not_found"] == 0:
         assert sorted(classes) == [0, 1]  # dealt over the two classes
     assert float(f[0].tensor.abs().max()) == 0.0 and float(f[1].tensor.abs().max()) == 0.0  # zeros() filled AFTER the probe wrote
+    # the threshold was calibrated on the placer's own reference (one per device, <= 1 GiB)
+    assert rep["pair_threshold_mode"] in ("mi355x", "relative", "fixed") and rep["device"] == torch.cuda.current_device()
+    assert rep["reference_bytes"] <= 1 << 30 and (rep["pair_threshold_mode"] == "fixed" or rep["reference_self_pair_gbs"] > 1000.0)
+    # roles: the class a caller names wins over the balance of live bytes (when the search finds it)
+    found_before = rep["wanted_class_not_found"]
+    g = [gt_storage.empty(shape, np.float64, backend="hip:mi300", aligned_index=(1, 1, 0), memory_class=c) for c in (1, 1, 0)]
+    if placement.report()["wanted_class_not_found"] == found_before and not placement.report()["dormant"]:
+        assert [placement.class_of(x) for x in g] == [1, 1, 0]
+    with pytest.raises(ValueError, match="memory_class"):
+        gt_storage.empty(shape, np.float64, backend="hip:mi300", memory_class=2)
+    with placement.disabled():  # what GT4PY_AMD_ALLOC_GROUPS=0 does for a whole process
+        plain = gt_storage.empty(shape, np.float64, backend="hip:mi300", aligned_index=(1, 1, 0))
+    assert placement.class_of(plain) is None
 
 
 def test_the_wide_search_reaches_a_group_that_is_far_away_and_parks_its_neighbours():

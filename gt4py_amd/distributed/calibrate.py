@@ -358,12 +358,14 @@ def hdiff_calibration_order(schedules, edges, transports):
     return first, refine, direct_stage
 
 
-def per_process_grid_keys(table, total, halo: int, itemsize: int, default_grid=None) -> dict:
+def per_process_grid_keys(table, total, halo: int, itemsize: int, default_grid=None, selfloop_grid=None) -> dict:
     """``{"PIxPJ": {...}}`` for every process grid the calibration measured: the best per-apply ms on each transport and the bytes of
     one face message per neighbour, so that the first multi-device record shows -- without a second run -- whether a grid's big faces
     hid behind its interior (1 x 8: 2.1 MB N / S faces against a 44 us interior).  Keys of ``table``
     that name no grid (the hdiff forms) belong to ``default_grid``.  Face sizes are those of the two-phase table: W / E faces carry the
-    local J rows, N / S faces the local I columns PLUS the freshly received I-halo columns (corners for free)."""
+    local J rows, N / S faces the local I columns PLUS the freshly received I-halo columns (corners for free).  ``selfloop_grid``:
+    the one-rank rehearsal of ONE share of that grid (periodic along every cut axis, every neighbour the rank itself): ``total`` is the
+    share, the table's "1x1" entries are reported under the grid they rehearse, marked ``"selfloop": True``."""
     out = {}
     for key, ms in table.items():
         head = key.split("_", 1)[0]
@@ -373,15 +375,18 @@ def per_process_grid_keys(table, total, halo: int, itemsize: int, default_grid=N
             grid = tuple(default_grid)
         else:
             continue
+        share = None
+        if selfloop_grid is not None and grid == (1, 1):
+            grid, share = tuple(selfloop_grid), (int(total[0]), int(total[1]), int(total[2]))
         name = f"{grid[0]}x{grid[1]}"
         entry = out.get(name)
         if entry is None:
-            li, lj, lk = -(-int(total[0]) // grid[0]), -(-int(total[1]) // grid[1]), int(total[2])
+            li, lj, lk = share if share is not None else (-(-int(total[0]) // grid[0]), -(-int(total[1]) // grid[1]), int(total[2]))
             entry = out[name] = {"local_domain": [li, lj, lk],
                                  "face_bytes_per_neighbour": {"west_east": halo * lj * lk * itemsize if grid[0] > 1 else 0,
                                                               "north_south": halo * (li + (2 * halo if grid[0] > 1 else 0)) * lk * itemsize if grid[1] > 1 else 0},
                                  "neighbours": (2 if grid[0] > 1 else 0) + (2 if grid[1] > 1 else 0),
-                                 "best_ms_per_apply": {}, "best_form": {}}
+                                 "best_ms_per_apply": {}, "best_form": {}, **({"selfloop": True} if share is not None else {})}
         transport = "direct" if key.endswith("_direct") else "rccl"
         if transport not in entry["best_ms_per_apply"] or ms < entry["best_ms_per_apply"][transport]:
             entry["best_ms_per_apply"][transport], entry["best_form"][transport] = ms, key
@@ -401,8 +406,8 @@ def calibration_line_keys(table, stats, ctx=None, geometry=None) -> dict:
             "direct_best_form": direct_key, "calibration_candidates_run": stats["run"],
             "calibration_candidates_skipped_for_time": stats["skipped_for_time"], "calibration_candidates_failed": list(stats["failed"]),
             "calibration_candidates_failed_unfenced": list(stats.get("failed_unfenced", [])),
-            **({"per_process_grid": per_process_grid_keys(table, geometry["total"], geometry["halo"], geometry["itemsize"], geometry.get("grid"))}
-               if geometry else {}),
+            **({"per_process_grid": per_process_grid_keys(table, geometry["total"], geometry["halo"], geometry["itemsize"], geometry.get("grid"),
+                                                          geometry.get("selfloop_grid"))} if geometry else {}),
             **(ladder_line_keys(ctx) if ctx is not None else {})}
 
 # ---- the fall-back ladder of the halo transport ---------------------------------------------------------------------------

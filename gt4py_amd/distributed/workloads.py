@@ -619,7 +619,8 @@ def _setup_distributed_laplacian(args, ctx):
               "direct_transport_canary": canary, **ladder_line_keys(ctx)}
     extras = {"exchangers": exchangers, "total_lups": float(np.prod(dec.global_domain)), "keep": (pairs, comm, frozen, keep),
               "timestep": timestep_extras, "proof": proof, "transport_fallback": fallback,
-              "calibration": calibration_line_keys(calibration, stats, ctx, {"total": total, "halo": 1, "itemsize": 8, "grid": grid})
+              "calibration": calibration_line_keys(calibration, stats, ctx, {"total": total, "halo": 1, "itemsize": 8, "grid": grid,
+                                                                             "selfloop_grid": selfloop_grid})
               if calibration is not None else None}
     return step, kernel_step, dec.local_domain, config, extras
 
@@ -649,13 +650,15 @@ def _setup_hdiff2048(args, ctx):
                           device_sync=False)
     gen = torch.Generator(device="cuda").manual_seed(4242 + rank)
 
-    def field(lo, hi):
-        f = gt_storage.empty(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin)
+    hint = hd.placement_hint()  # in / coeff / out -> memory classes 0 / 0 / 1 (storage/placement.py: what is written goes to the other group)
+
+    def field(lo, hi, cls=None):
+        f = gt_storage.empty(dec.local_shape, np.float64, backend="hip:mi300", aligned_index=dec.origin, memory_class=cls)
         f.tensor.copy_(torch.rand(dec.local_shape, dtype=torch.float64, device="cuda", generator=gen) * (hi - lo) + lo)
         return f
 
-    fields = {"in_field": hdiff_input(dec.local_shape, np.float64, gen, dec.origin), "coeff": field(0.025, 0.025),
-              "out_field": field(-1.0, 1.0)}
+    fields = {"in_field": hdiff_input(dec.local_shape, np.float64, gen, dec.origin, cls=hint["in_field"]),
+              "coeff": field(0.025, 0.025, hint["coeff"]), "out_field": field(-1.0, 1.0, hint["out_field"])}
     origin = {k: dec.origin for k in fields}
     frozen = hd.freeze(origin=origin, domain=dec.local_domain)
     decomposed = distributed or selfloop

@@ -236,6 +236,10 @@ def test_the_line_names_every_measured_process_grid_with_its_face_sizes():
     assert grids["4x2"]["best_ms_per_apply"] == {"rccl": 0.102, "direct": 0.066} and grids["4x2"]["best_form"]["rccl"] == "4x2_twophase_swap_wg0_rccl"
     hd = per_process_grid_keys({"overlapped": 0.2, "inline_direct": 0.19}, (2048, 2048, 80), 2, 8, (4, 2))
     assert hd["4x2"]["face_bytes_per_neighbour"] == {"west_east": 1310720, "north_south": 660480} and hd["4x2"]["best_ms_per_apply"] == {"rccl": 0.2, "direct": 0.19}
+    # the one-rank self-loop rehearsal of one share of 4 x 2: its "1x1" forms are reported under the grid they rehearse
+    loop = per_process_grid_keys({"1x1_twophase_swap_wg4_rccl": 0.0977, "1x1_singlephase_inline_wg0_direct": 0.0718}, (128, 256, 512), 1, 8, (1, 1), (4, 2))
+    assert set(loop) == {"4x2"} and loop["4x2"]["selfloop"] is True and loop["4x2"]["local_domain"] == [128, 256, 512]
+    assert loop["4x2"]["face_bytes_per_neighbour"] == grids["4x2"]["face_bytes_per_neighbour"]
     stats = {"run": 5, "skipped_for_time": 0, "failed": []}
     keys = calibration_line_keys(table, stats, None, {"total": (512, 512, 512), "halo": 1, "itemsize": 8, "grid": (4, 2)})
     assert keys["per_process_grid"] == grids and "per_process_grid" not in calibration_line_keys(table, stats)

@@ -250,9 +250,12 @@ inline int hdiff_launch_share_shape(const View<const T>& in, const View<T>& out,
     const unsigned groups_j = (unsigned)cdiv(d[1], (int64_t)LJ * NW);
     const int64_t nblocks = (int64_t)waves_i * groups_j * d[2];
     if (nblocks > INT32_MAX) return fail(GT4MI_ERR_UNSUPPORTED, "hdiff: domain too large for one launch");
+    // launch_dynamic_lds(): the throttle of the overlapped distributed apply -- bytes per workgroup such that at most N workgroups
+    // share a CU (common.hip.h lds_for_workgroups_per_cu).  This kernel has static LDS of its own: only the rest is requested.
+    constexpr unsigned own_lds = NW * 4 * 1024;
+    const unsigned throttle = launch_dynamic_lds() > own_lds ? launch_dynamic_lds() - own_lds : 0u;
     hipLaunchKernelGGL((hdiff_share_kernel<T, W, PW, LIMITER, COEFF_FIELD, VEC, LJ, NW, XCDG, MINW>), dim3((unsigned)nblocks),
-                       dim3(NW * 64), launch_dynamic_lds(), stream, in, out, cf, coeff_scalar, (int)d[0], (int)d[1], waves_i, groups_j,
-                       lead);
+                       dim3(NW * 64), throttle, stream, in, out, cf, coeff_scalar, (int)d[0], (int)d[1], waves_i, groups_j, lead);
     return GT4MI_OK;
 }
 

@@ -1,4 +1,7 @@
-// Horizontal diffusion, wave-autonomous "J-march" kernel for I-contiguous fields (the fast path).
+// Horizontal diffusion, wave-autonomous "J-march" kernel for I-contiguous fields: the fast path of rounds 1-5.  Since round 6
+// whole domains on 16-byte lanes run hdiff_share.hip.h (the same lane map; the waves of a workgroup exchange their halo rows
+// through LDS instead of each loading them); this kernel remains the path for 8- / 4-byte lanes, the strips of the boundary
+// ring (hdiff_ring.hip.h) and GT4MI_HDIFF_SHARE=0.
 //
 // One wave owns a strip of 64*VEC columns (VEC contiguous elements per lane = one 8/16-byte vector)
 // and walks down LJ rows of J at one K level.  Per step it loads ONE new row of `in` (row j+2),

@@ -100,4 +100,18 @@ inline void lap5_share_launch(const View<const T>& in, const View<T>& out, int d
                        in, out, dI, dJ, tx, ty);
 }
 
+// (round 6 experiment, microbench section `lappersist`) the library's strip tiles, but a PERSISTENT grid: `grid` workgroups loop over the
+// tiles (tile = blockIdx.x, += gridDim.x) instead of one workgroup per tile -- does the dispatch of 8 192 (512 x 512 x 128) or 32 768 (512^3)
+// short-lived workgroups cost anything?  gridDim.x is a multiple of 8, so a workgroup's tiles stay on its XCD under the grouped remap.
+template <typename T, typename W, int VARIANT, int VEC, int LJ, int BLOCK, int XCDG>
+__global__ void __launch_bounds__(BLOCK)
+lap5_persistent_kernel(View<const T> in, View<T> out, int dI, int dJ, unsigned tiles_x, unsigned tiles_y, unsigned n_tiles) {
+    for (unsigned t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        unsigned b = t;
+        if constexpr (XCDG > 0) b = xcd_remap_grouped<(unsigned)XCDG>(b, n_tiles);
+        const unsigned bx = b % tiles_x, by = (b / tiles_x) % tiles_y, k = b / (tiles_x * tiles_y);
+        lap5_strip_tile<T, W, VARIANT, VEC, LJ, BLOCK>(in, out, dI, dJ, bx, (int)by * LJ, k);
+    }
+}
+
 }  // namespace gt4mi

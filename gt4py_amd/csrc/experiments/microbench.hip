@@ -580,6 +580,55 @@ static void section_lapshare() {
     lapshare_suite(334, 131, 7, "334x131x7");
 }
 
+// lappersist (round 6): one workgroup per tile (the library) against a persistent grid looping over the tiles; N rotating (in, out) pairs
+static void lappersist_suite(int dI, int dJ, int dK, int npairs, const char* tag) {
+    std::vector<DevField<double>*> in, out;
+    for (int p = 0; p < npairs; ++p) {
+        in.push_back(new DevField<double>(dI, dJ, dK, 1, 1, 16, 0));
+        out.push_back(new DevField<double>(dI, dJ, dK, 1, 1, 16, 0));
+        fill(*in.back(), 1337 + p, -1.0, 1.0);
+        CK(hipMemset(out.back()->raw, 0, out.back()->bytes));
+    }
+    DevField<double> ref(dI, dJ, dK, 1, 1, 16, 0);
+    CK(hipMemset(ref.raw, 0, ref.bytes));
+    {
+        dim3 grid((unsigned)cdiv(dI, 64), (unsigned)cdiv(dJ, 4), (unsigned)dK);
+        hipLaunchKernelGGL((lap5_generic_kernel<double, double, 0>), grid, dim3(256), 0, 0, in[0]->cview(), ref.view(), dI, dJ, dK);
+        CK(hipDeviceSynchronize());
+    }
+    const int64_t d[3] = {dI, dJ, dK};
+    const unsigned tx = (unsigned)cdiv(dI, 512), ty = (unsigned)cdiv(dJ, 8), n = tx * ty * (unsigned)dK;
+    const int iters = 40 * npairs;
+    for (int rep = 0; rep < 3; ++rep) {
+        char cfg[128];
+        {
+            const double ms = time_ms([&](int i) { lap5_launch_variant<double, double, 0>(in[i % npairs]->cview(), out[i % npairs]->view(), d, 0); }, iters, npairs);
+            snprintf(cfg, sizeof cfg, "%s library: %u workgroups, %d rotating pairs", tag, n, npairs);
+            report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+        }
+        for (unsigned per_cu : {2u, 4u, 6u, 8u, 12u, 16u}) {
+            const unsigned grid = 256u * per_cu < n ? 256u * per_cu : n;
+            const double ms = time_ms([&](int i) {
+                hipLaunchKernelGGL((lap5_persistent_kernel<double, double, 0, 2, 8, 256, 4>), dim3(grid), dim3(256), 0, 0, in[i % npairs]->cview(),
+                                   out[i % npairs]->view(), dI, dJ, tx, ty, n);
+            }, iters, npairs);
+            snprintf(cfg, sizeof cfg, "%s persistent grid of %u workgroups (%u per CU)", tag, grid, per_cu);
+            report("lap5_f64", cfg, ms, (double)dI * dJ * dK, 16.0);
+            if (rep == 0) {
+                const unsigned long long bad = count_diff(*out[0], ref, dI, dJ, dK);
+                if (bad) printf("           MISMATCHES vs the one-thread-per-point kernel: %llu\n", bad);
+            }
+        }
+    }
+    for (auto* f : in) delete f;
+    for (auto* f : out) delete f;
+}
+
+static void section_lappersist() {
+    lappersist_suite(512, 512, 128, 4, "512x512x128");
+    lappersist_suite(512, 512, 512, 2, "512^3");
+}
+
 static void section_lap() {
     lap_suite(512, 512, 512, 0, "512^3");
     lap_suite(512, 512, 128, 0, "512x512x128");
@@ -1925,6 +1974,7 @@ int main(int argc, char** argv) {
         }
     }
     if (!want.empty() && on("lapshare")) section_lapshare();
+    if (!want.empty() && on("lappersist")) section_lappersist();
     if (on("hdiff")) section_hdiff();
     if (!want.empty() && on("hdiff2")) section_hdiff2();
     if (!want.empty() && on("hdiff3")) section_hdiff3();

@@ -92,6 +92,7 @@ class MemoryGroupPlacer:
         self.live = [0, 0]                  # bytes of live classified fields per class
         self.stats = {"placed": [0, 0], "searches": 0, "candidates": 0, "probes": 0, "wanted_class_not_found": 0, "unclassified": 0}
         self.log: List[Dict[str, Any]] = []  # one record per placed field (bench.py prints it)
+        self.rates: List[float] = []  # the pair rate of every candidate probed (report(): a histogram -- is this box bimodal, where is the gap?)
 
     # ---- classification -----------------------------------------------------------------------------------------------------
     def _classify(self, block, nbytes: int) -> int:
@@ -108,6 +109,7 @@ class MemoryGroupPlacer:
             self.max_candidates = 0
             return 0
         self.stats["probes"] += 1
+        self.rates.append(float(gbs))
         return 1 if gbs >= self.threshold else 0
 
     def _ensure_reference(self, nbytes: int) -> None:
@@ -380,7 +382,12 @@ def report() -> Optional[Dict[str, Any]]:
     p = _PLACERS.get(_current_device()) if _PLACERS else None
     if p is None:
         return {"enabled": False, "why": _DISABLED_REASON} if _DISABLED_REASON else None
+    histogram: Dict[str, int] = {}
+    for r in p.rates:
+        key = str(int(r // 100) * 100)
+        histogram[key] = histogram.get(key, 0) + 1
     return {"enabled": True, "device": getattr(p, "device", None), "dormant": p.dormant, "pair_threshold_mode": p.threshold_mode,
+            "pair_rate_histogram_100gbs": dict(sorted(histogram.items(), key=lambda kv: int(kv[0]))),
             "reference_self_pair_gbs": p.self_pair_gbs, "reference_bytes": p.reference_bytes, "fields_placed_per_class": list(p.stats["placed"]), "live_bytes_per_class": list(p.live), "searches": p.stats["searches"],
             "candidates": p.stats["candidates"], "probes": p.stats["probes"], "wanted_class_not_found": p.stats["wanted_class_not_found"],
             "spacers": p.stats.get("spacers", 0), "spacer_bytes": p.spacer_bytes, "parked_blocks": sum(len(v) for v in p.parked.values()),

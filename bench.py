@@ -703,6 +703,9 @@ def main() -> None:
     ap.add_argument("--workload", choices=("lap512", "hdiff2048"), default="lap512",
                     help="lap512 (default, the headline metric) or hdiff2048 = BASELINE.json configs[4] (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allocator-variants", action="store_true",
+                    help="skip value_default_allocator / value_allocator_off (profiling runs: every launch of the headline kernel in the "
+                         "trace is then one of the timed workload's)")
     ap.add_argument("--no-other-kernels", action="store_true",
                     help="skip the informational hdiff / tridiagonal lines (N=1 only)")
     ap.add_argument("--dist-selfloop", action="store_true",
@@ -966,7 +969,7 @@ def main() -> None:
                 line["host_cost_per_call"] = host_cost_per_call(lap)
             except Exception as ex:
                 print(f"host_cost_per_call failed: {ex!r}", file=sys.stderr)
-        if headline:
+        if headline and not args.no_allocator_variants:
             # What a drop-in user gets: the headline kernel on fields from the storage allocator AT ITS
             # DEFAULTS (6 plain candidates per search, no spacers, no parked neighbours, no role hints: plain gt_storage.empty) and
             # with the memory-group placer OFF -- 5 + 20 launches each, outside the contract's timed steps.

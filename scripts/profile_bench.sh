@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o lap -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-other-kernels > "$OUT/stats_stdout.log" 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o lap -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-other-kernels > "$OUT/fetch_stdout.log" 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o lap -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-other-kernels > "$OUT/write_stdout.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o lap -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-other-kernels --no-allocator-variants > "$OUT/stats_stdout.log" 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o lap -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-other-kernels --no-allocator-variants > "$OUT/fetch_stdout.log" 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o lap -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-other-kernels --no-allocator-variants > "$OUT/write_stdout.log" 2>&1
 python3 "$R/scripts/summarize_profile.py" "$OUT" "$TAG" "$SHA"

@@ -70,7 +70,8 @@ def test_big_fields_are_dealt_over_the_two_classes():
     # rejected candidates were HELD during the search (the cache would have handed the same block out again) and released after it;
     # every candidate is probed, also one that comes back from the cache (the same address may be other memory by then)
     assert placer.stats["wanted_class_not_found"] == 0 and placer.stats["searches"] == 4
-    assert placer.stats["probes"] == placer.stats["candidates"] + 1  # (+ the calibration probe of the reference's two halves)
+    # (+ the calibration probe of the reference's two halves and the three samples that tell whether the reference sits in the common group)
+    assert placer.stats["probes"] == placer.stats["candidates"] + 1 + 3
     assert placer.live == [2 * (GB + (4 << 20)), 2 * (GB + (4 << 20))]
     # a field that dies gives its bytes back: the next one goes where the room is
     del blocks[1]
@@ -134,6 +135,22 @@ def test_the_threshold_is_calibrated_on_the_reference_itself():
     p3 = MemoryGroupPlacer(slow.allocate, slow.probe, threshold_gbs=4000.0)
     p3.place(GB)
     assert p3.threshold_mode == "fixed" and p3.threshold == 4000.0
+
+
+def test_class_0_is_the_group_the_driver_hands_out_most():
+    """A reference that lands in the RARER group would make class 0 the scarce one (every search for it walks the whole budget);
+    three plain samples after the calibration notice it and the reference moves to the common group."""
+    dev = _Device([1] + [0, 0, 0] + [0, 0, 1, 0, 0, 0, 0])  # the first block -- the reference -- in group 1, nearly everything else in 0
+    placer = MemoryGroupPlacer(dev.allocate, dev.probe, max_candidates=6)
+    kept = [placer.place(GB) for _ in range(3)]
+    assert placer.stats.get("reference_moved_to_the_common_group") == 1 and dev.group_of(placer.reference.data_ptr()) == 0
+    assert [c for _, c in kept] == [0, 1, 0] and [dev.group_of(b.data_ptr()) for b, _ in kept] == [0, 1, 0]
+    assert placer.stats["wanted_class_not_found"] == 0
+    # a reference in the common group stays
+    dev2 = _Device([0] + [0, 1, 0] + [0, 1])
+    p2 = MemoryGroupPlacer(dev2.allocate, dev2.probe, max_candidates=6)
+    p2.place(GB)
+    assert "reference_moved_to_the_common_group" not in p2.stats and dev2.group_of(p2.reference.data_ptr()) == 0
 
 
 def test_a_placer_whose_searches_keep_failing_goes_dormant():
@@ -302,7 +319,7 @@ def test_the_wide_search_reaches_a_group_that_is_far_away_and_parks_its_neighbou
 
 def test_running_out_of_memory_in_the_middle_of_a_search_ends_the_search_not_the_program():
     dev = _Device([0] * 40)
-    budget = {"left": 4}
+    budget = {"left": 4 + 3}  # (+ the three samples taken once, right after the reference; they are released again)
 
     def allocate(nbytes):
         if budget["left"] <= 0:
@@ -311,7 +328,7 @@ def test_running_out_of_memory_in_the_middle_of_a_search_ends_the_search_not_the
         return dev.allocate(nbytes)
 
     placer = MemoryGroupPlacer(allocate, dev.probe, max_candidates=8)
-    first = placer.place(GB)   # reference + one candidate
+    first = placer.place(GB)   # reference (+ its three samples) + one candidate
     second = placer.place(GB)  # wants class 1: two more candidates fit, then the device is full -> takes the first candidate
     assert first[1] == 0 and second[1] == 0 and placer.stats["search_ended_by_allocation_failure"] == 1
     budget["left"] = 0

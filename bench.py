@@ -904,7 +904,7 @@ def main() -> None:
         from gt4py_amd.storage import placement
 
         placement.configure(max_candidates=int(os.environ.get("GT4MI_BENCH_GROUP_SEARCH", "24")),
-                            spacer_bytes=int(os.environ.get("GT4MI_BENCH_GROUP_SPACER_GB", "8")) << 30, park_extra=5)
+                            spacer_bytes=int(os.environ.get("GT4MI_BENCH_GROUP_SPACER_GB", "8")) << 30, park_extra=8)
         lap = gtscript.stencil(backend="hip:mi300", definition=_lap_definition(), dtypes={"T": np.float64},
                                device_sync=False)
         origin = {"inp": (1, 1, 0), "out": (1, 1, 0)}

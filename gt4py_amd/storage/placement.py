@@ -180,9 +180,19 @@ class MemoryGroupPlacer:
         if wanted is None:
             wanted = self.forced if self.forced is not None else (0 if self.live[0] <= self.live[1] else 1)
         held, spacers, chosen, chosen_cls = [], [], None, None
+        block_bytes = nbytes  # (what the chosen raw block really holds: more than asked for when it comes from a bigger parked block)
         parked = self.parked.get((wanted, nbytes))
+        if not parked:
+            # a BIGGER parked block of the wanted class (the smallest that fits, at most 8 x the request): where the other group is
+            # far away every find is precious -- a field of 350 MB may live in a parked block of 1.1 GB rather than start a search
+            # of its own that may fail (round 6: 5 of 26 searches failed on a box whose second group was rare within reach)
+            fits = sorted(size for (cls, size), blocks in self.parked.items() if cls == wanted and blocks and nbytes < size <= 8 * nbytes)
+            if fits:
+                parked, block_bytes = self.parked[(wanted, fits[0])], fits[0]
+                self.stats["served_from_a_bigger_parked_block"] = self.stats.get("served_from_a_bigger_parked_block", 0) + 1
         if parked:
             chosen, chosen_cls = parked.pop(), wanted
+            self.known.pop((int(chosen.data_ptr()), block_bytes), None)
         else:
             self.stats["searches"] += 1
             held_bytes = 0
@@ -242,7 +252,7 @@ class MemoryGroupPlacer:
         self.live[chosen_cls] += nbytes
         self.stats["placed"][chosen_cls] += 1
         self.log.append({"label": label, "bytes": nbytes, "class": chosen_cls, "wanted": wanted, "candidates_rejected": n_rejected})
-        key = (int(chosen.data_ptr()), nbytes)
+        key = (int(chosen.data_ptr()), block_bytes)
         self.known[key] = chosen_cls
         weakref.finalize(chosen, self._gone, chosen_cls, nbytes, key)
         return chosen, chosen_cls

@@ -308,6 +308,11 @@ def test_the_wide_search_reaches_a_group_that_is_far_away_and_parks_its_neighbou
     c, cc = placer.place(GB)           # class 0 again (the frontier is back at the start: the spacers were released)
     d, cd = placer.place(GB)           # class 1 from the parked blocks: no search
     assert (cc, cd) == (0, 1) and placer.stats["searches"] == searches + 1 and sum(len(v) for v in placer.parked.values()) == 2
+    # a smaller field that wants the far class lives in one of the parked (bigger) blocks instead of starting a search that may fail
+    searches = placer.stats["searches"]
+    e, ce = placer.place(GB // 4, wanted=1)
+    assert ce == 1 and placer.stats["searches"] == searches and placer.stats["served_from_a_bigger_parked_block"] == 1
+    assert dev.live[e.data_ptr()] == 1 and sum(len(v) for v in placer.parked.values()) == 1
     # a device that is nearly full is not filled up with spacers
     FarDevice.sizes = {}
     dev2, free2 = FarDevice([]), [20 * GB]

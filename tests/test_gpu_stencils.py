@@ -453,3 +453,32 @@ def test_an_empty_axis_is_a_call_that_writes_nothing():
             assert (b.get() == 7.0).all() and (a.get() == 1.0).all(), (stencil.options["name"], domain)
         with pytest.raises(ValueError, match="Compute domain contains zero sizes"):
             stencil(mk(1.0), mk(7.0), origin=(1, 1, 0), domain=(0, 0, 0))
+
+
+@pytest.mark.multiprocess
+def test_the_headline_line_of_bench_py_carries_what_the_contract_and_the_verdicts_ask_for():
+    """`python bench.py` at N = 1 (short: 3 steps, no CPU baseline, no other kernels): ONE JSON line on stdout with the contract's keys,
+    the `roofline` object, the figures a drop-in user gets (`value_default_allocator`, `value_allocator_off`), and -- as the LAST key, so
+    that a record which keeps only the tail of a long line keeps it -- the `summary` of every config's figure."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    proc = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-other-kernels"],
+                          capture_output=True, text=True, timeout=600, cwd=str(root), env=dict(os.environ))
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1  # the contract: one line
+    line = json.loads(lines[0])
+    for key, want in (("n_gpus", 1), ("steps", 3), ("warmup", 1), ("higher_is_better", True), ("scaling", "weak"), ("dtype", "f64"), ("unit", "GLUPS")):
+        assert line[key] == want, key
+    assert "512" in line["metric"] and "workload" in line["config"] and line["vs_baseline"] is None
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert 0.5 < roof["frac"] < 1.0 and abs(line["value"] * 16.0 - roof["achieved"]) / roof["achieved"] < 0.1  # GLUPS x 16 B ~ GB/s
+    assert line["value_default_allocator"] > 0 and line["value_allocator_off"] > 0 and "allocator_note" in line
+    assert list(line)[-1] == "summary" and line["summary"]["lap5_f64_512"]["glups"] == line["value"]
+    assert line["memory_groups"]["enabled"] in (True, False) and "fields" not in line["memory_groups"]

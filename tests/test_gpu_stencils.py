@@ -473,8 +473,9 @@ def test_the_headline_line_of_bench_py_carries_what_the_contract_and_the_verdict
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1  # the contract: one line
     line = json.loads(lines[0])
-    for key, want in (("n_gpus", 1), ("steps", 3), ("warmup", 1), ("higher_is_better", True), ("scaling", "weak"), ("dtype", "f64"), ("unit", "GLUPS")):
+    for key, want in (("n_gpus", 1), ("steps", 3), ("warmup", 1), ("higher_is_better", True), ("dtype", "f64"), ("unit", "GLUPS")):
         assert line[key] == want, key
+    assert line["scaling"] == "strong"  # the 512^3 grid is FIXED and split over the ranks (hdiff2048 is the weak-scaling workload)
     assert "512" in line["metric"] and "workload" in line["config"] and line["vs_baseline"] is None
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3

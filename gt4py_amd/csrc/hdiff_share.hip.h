@@ -243,6 +243,7 @@ struct HdiffShareTuning {
     static constexpr int NW = 4;
     // workgroups per XCD run: 2 (1, 2 and no remap are within 0.3 %; 4 -- the J-march's value -- is 0.5-2 % behind, 8 and 16 2-4 %)
     static constexpr int XCDG = 2;
+    static constexpr int XCDG_ALT = 4;
     static constexpr int MINW = 4;
 };
 
@@ -266,6 +267,11 @@ template <typename T, typename W, typename PW, bool LIMITER, bool COEFF_FIELD, i
 inline int hdiff_launch_share(const View<const T>& in, const View<T>& out, const View<const T>& cf, PW coeff_scalar,
                               const int64_t d[3], hipStream_t stream, int lead) {
     using Tu = HdiffShareTuning<T>;
+    // GT4MI_HDIFF_SHARE_XCD=<runs>: the other measured XCD run length, for A/B runs on ONE box in the product's call path
+    static const int runs = env_int("GT4MI_HDIFF_SHARE_XCD", Tu::XCDG);
+    if (runs != Tu::XCDG)
+        return hdiff_launch_share_shape<T, W, PW, LIMITER, COEFF_FIELD, VEC, Tu::LJ, Tu::NW, Tu::XCDG_ALT, Tu::MINW>(in, out, cf, coeff_scalar, d,
+                                                                                                                 stream, lead);
     return hdiff_launch_share_shape<T, W, PW, LIMITER, COEFF_FIELD, VEC, Tu::LJ, Tu::NW, Tu::XCDG, Tu::MINW>(in, out, cf, coeff_scalar, d,
                                                                                                          stream, lead);
 }

@@ -23,7 +23,10 @@ CHILD = ("import sys, json; sys.path.insert(0, %r); import torch; torch.cuda.set
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--xcd", action="store_true", help="A/B the share kernel's XCD run length instead: 2 (library) against 4")
     args = ap.parse_args()
+    if args.xcd:
+        return xcd_ab(args.rounds)
     seen = {(n, s): [] for n in NAMES for s in (0, 1)}
     for r in range(args.rounds):
         for share in (1, 0) if r % 2 == 0 else (0, 1):
@@ -42,6 +45,26 @@ def main() -> int:
             ma, mb = statistics.median(a), statistics.median(b)
             print(f"median {name}: share {ma:.4f} ms ({NAMES[name] / (ma * 1e-3) / 8e12:.4f})   J-march {mb:.4f} ms ({NAMES[name] / (mb * 1e-3) / 8e12:.4f})   "
                   f"({(ma / mb - 1) * 100:+.2f} % time for the share kernel)")
+    return 0
+
+
+def xcd_ab(rounds: int) -> int:
+    seen = {(n, x): [] for n in NAMES for x in (2, 4)}
+    for r in range(rounds):
+        for runs in (2, 4) if r % 2 == 0 else (4, 2):
+            proc = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, GT4MI_HDIFF_SHARE_XCD=str(runs)), capture_output=True, text=True, timeout=600)
+            line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+            if not line:
+                print(f"round {r} xcd runs {runs}: FAILED\n{proc.stderr[-2000:]}")
+                continue
+            for name, (ms, classes) in json.loads(line[-1]).items():
+                seen[(name, runs)].append(ms)
+                print(f"round {r}  XCD runs of {runs}  {name}: {ms:.4f} ms  {NAMES[name] / (ms * 1e-3) / 8e12:.4f} of 8 TB/s  classes {classes}", flush=True)
+    for name in NAMES:
+        a, b = seen[(name, 2)], seen[(name, 4)]
+        if a and b:
+            ma, mb = statistics.median(a), statistics.median(b)
+            print(f"median {name}: runs of 2 {ma:.4f} ms   runs of 4 {mb:.4f} ms   ({(mb / ma - 1) * 100:+.2f} % time for runs of 4)")
     return 0
 
 

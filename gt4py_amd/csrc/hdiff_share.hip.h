@@ -13,8 +13,9 @@
 // Measured against the J-march on MI355X (profiles/r6_hdiff_lds_tile.txt, every variant bit-identical to the one-thread-per-
 // point kernel): float32 1024 x 1024 x 80  0.1774 -> 0.1690 ms, float64 512 x 1024 x 80  0.1759 -> 0.1690 ms; memory-side traffic
 // 1.125-1.133 x -> 1.05-1.06 x of the algorithmic bytes with XCD runs of 4, 1.08-1.095 x with the runs of 2 the library uses (same
-// speed or 0.5-2 % faster on every box; the difference is halo rows served by the Infinity Cache).  Through the call path with the
-// fields placed by role (profiles/r6_all_kernels_summary.json): float32 0.750, float64 0.776 of the HBM peak (round 5: 0.72 / 0.745).
+// speed or 0.5-2 % faster on every box; the difference is halo rows served by the Infinity Cache).  In the product's call path with
+// the fields placed by role, alternating processes on one box (profiles/r6_hdiff_share_ab_product_path.log): float32 0.1699 -> 0.1664 ms
+// (0.740 -> 0.756 of the HBM peak), float64 0.1648 -> 0.1628 (0.764 -> 0.773); XCD runs of 4 there: +0.7 % / +2.1 % time.
 // The full LDS ring (every row of `in` staged through LDS, double-buffered along J, `global_load_lds_dwordx4` or register-staged)
 // moves 1.10-1.12 x and is 8 % (float64) to 30 % (float32) SLOWER: one barrier per chunk that also drains the chunk's stores, and
 // 2-3 waves per SIMD under 36-68 KiB of LDS.

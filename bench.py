@@ -224,9 +224,10 @@ def allocator_variants(lap, frozen, shape, steps: int):
         if placer is not None:
             placement.configure(**saved)
             placer.parked = parked
-    out["allocator_note"] = ("value = fields from the wide search (placement.configure: 24 candidates, 8 GB spacers) + the stencil's "
-                             "placement_hint(); value_default_allocator = plain gt_storage.empty at the allocator's defaults; "
-                             "value_allocator_off = GT4PY_AMD_ALLOC_GROUPS=0")
+    out["allocator_note"] = ("value / value_by_events = fields from the wide search (placement.configure: 24 candidates, 8 GB spacers) + the "
+                             "stencil's placement_hint(); value_default_allocator = plain gt_storage.empty at the allocator's defaults; "
+                             "value_allocator_off = GT4PY_AMD_ALLOC_GROUPS=0; the last two are timed with HIP events around the launches: "
+                             "compare them with value_by_events")
     return out
 
 
@@ -974,6 +975,9 @@ def main() -> None:
             # DEFAULTS (6 plain candidates per search, no spacers, no parked neighbours, no role hints: plain gt_storage.empty) and
             # with the memory-group placer OFF -- 5 + 20 launches each, outside the contract's timed steps.
             try:
+                # (event-timed like the two figures below -- `value` itself is wall-clock over the K contract steps, barriers and
+                # launch gaps included, and runs 1 % under it)
+                line["value_by_events"] = round(float(np.prod(GRID)) / line["roofline"]["kernel_ms"] / 1e6, 2)
                 line.update(allocator_variants(lap, frozen, shape, args.steps))
             except Exception as ex:
                 print(f"allocator_variants failed: {ex!r}", file=sys.stderr)
@@ -1001,6 +1005,7 @@ def main() -> None:
             line["summary"] = {"lap5_f64_512": {"glups": line["value"], "frac": line["roofline"]["frac"],
                                                 "traffic_over_algorithmic": round(line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"], 4)
                                                 if line["roofline"].get("traffic") else None,
+                                                "glups_by_events": line.get("value_by_events"),
                                                 "glups_default_allocator": line.get("value_default_allocator"),
                                                 "glups_allocator_off": line.get("value_allocator_off")},
                                **{name: {"glups": e.get("glups"), "frac": e.get("frac_of_hbm_peak"),

@@ -143,6 +143,31 @@ def test_hdiff_parity_field_coeff(domain, dtype, limiter, layout):
     _eq(d_out.get(), want, f"hdiff {np.dtype(dtype).name} {domain} {layout} limiter={limiter}")
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dJ", [1, 3, 4, 5, 15, 16, 17, 33])
+@pytest.mark.parametrize("dI", [32, 33, 123, 124, 125, 126, 247, 248, 249, 250, 497])
+def test_hdiff_at_the_partition_points_of_the_shared_rows_kernel(dI, dJ, dtype):
+    """hdiff_share.hip.h (round 6) cuts a domain into strips of 62 lanes x 16 bytes (124 float64 / 248 float32 columns) and workgroups
+    of 4 waves x 4 rows: every width around a strip boundary, every height around a wave / workgroup boundary -- the last strip
+    with one column, lanes that straddle the readable columns, waves with 1-3 rows, idle waves behind the barrier -- against the
+    oracle, with the halo and everything outside the domain untouched; scalar and field coefficient, limiter on."""
+    import gpu_util as G
+    from gt4py_amd import _lib
+
+    domain = (dI, dJ, 2)
+    inp, coeff = _hdiff_inputs(domain, dtype, seed=dI * 100 + dJ)
+    for cf_field in (True, False):
+        out0 = np.full(inp.shape, -7.0, dtype)
+        want = out0.copy()
+        weight = coeff if cf_field else np.float64(0.03)
+        R.hdiff(inp, want, weight, origin_in=(2, 2, 0), origin_out=(2, 2, 0), origin_coeff=(2, 2, 0), domain=domain, limiter=True)
+        d_in = G.DevArray(inp, "ifirst", align_index=(2, 2, 0))
+        d_cf = G.DevArray(coeff, "ifirst", align_index=(2, 2, 0)) if cf_field else float(weight)
+        d_out = G.DevArray(out0, "ifirst", align_index=(2, 2, 0))
+        G.hdiff(d_in, d_out, d_cf, (2, 2, 0), (2, 2, 0), (2, 2, 0) if cf_field else None, domain, _lib.HDIFF_LIMITER)
+        _eq(d_out.get(), want, f"hdiff {np.dtype(dtype).name} {domain} coeff {'field' if cf_field else 'scalar'}")
+
+
 @pytest.mark.parametrize("dtype,lit32,c32", [(np.float64, False, False), (np.float32, False, False),
                                              (np.float32, True, True), (np.float32, True, False),
                                              (np.float32, False, True)])
@@ -439,7 +464,7 @@ def test_lap5_origin_off_the_aligned_column_and_odd_widths(domain, variant, alig
 
 @pytest.mark.parametrize("align", [(0, 0, 0), (1, 1, 0), (3, 0, 0), (2, 2, 0)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("domain", [(130, 20, 3), (257, 9, 2), (61, 33, 2), (4, 4, 1)])
+@pytest.mark.parametrize("domain", [(130, 20, 3), (257, 9, 2), (61, 33, 2), (4, 4, 1), (124, 5, 2), (125, 16, 1), (248, 17, 2), (249, 4, 1)])
 def test_hdiff_origin_off_the_aligned_column(domain, dtype, align):
     """Horizontal diffusion from an origin that lies 1 - 3 items past a 16-byte boundary (default aligned_index with origin
     (2, 2, 0) puts float32 fields 8 bytes off): the J-march strips keep their 16-byte lanes, started `lead` columns further

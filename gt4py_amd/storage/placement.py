@@ -33,6 +33,13 @@ device, a power cap, a profiler, a neighbour on the device -- the threshold beco
 whose searches fail ``dormant_after`` times in a row goes DORMANT: big fields land where the driver puts them, no more candidates, no more
 probes.  Nothing is placed while the current stream is being captured into a graph (the probe synchronises).
 
+What it costs a process that allocates big fields (all of it only from the first field of >= 192 MiB on): one reference buffer of
+512 MiB .. 1 GiB per device for the life of the process; once, three sample blocks of the reference's size (released at once) that tell
+whether the reference sits in the group the driver hands out most -- if not, one of them becomes the reference, so that class 0 is the
+COMMON group and only class 1 needs the far search; per big allocation at most ``max_candidates`` (6) candidates of the field's size held
+until the search ends (<= ``max_held_bytes``, 16 GiB) and ~5 ms of probe per candidate (the probe synchronises the stream); a smaller field
+of the far class may be served from a bigger parked block.  ``report()`` says what happened, including a histogram of the probed rates.
+
 One placer PER DEVICE (``device_placer()`` follows ``torch.cuda.current_device()``); the reference buffer is capped at 1 GiB;
 ``torch.cuda.empty_cache()`` after a search only when the search used spacers (the wide search) or ``release_cache=True`` was configured.
 

@@ -4,7 +4,9 @@ partition points of hdiff_share_kernel (strips of 62 lanes x 16 bytes, workgroup
 boundary, both dtypes and internal precisions, limiter on / off, field / scalar coefficient; the halo and everything outside the domain
 must stay untouched (NaN canaries in the padding, -7 in the halo).
 
-    python3 scripts/hdiff_share_campaign.py [--cases 600] [--seed 6] > profiles/r6_hdiff_share_campaign.log"""
+(Lives under tests/ because it calls the oracle: only tests, smoke() and bench.py's cpu_baseline leg may.)
+
+    python3 tests/hdiff_campaign.py [--cases 600] [--seed 6] > profiles/r6_hdiff_share_campaign.log"""
 import argparse
 import pathlib
 import sys
@@ -13,7 +15,7 @@ import numpy as np
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "tests"))  # gpu_util
 import gpu_util as G  # noqa: E402
 from gt4py_amd import _lib  # noqa: E402
 from oracle import ref_numpy as R  # noqa: E402
